@@ -1,0 +1,105 @@
+"""ctypes loader for libfsf_hip.so — the only way the package reaches the GPU kernels.
+
+There is deliberately NO CPU fallback: if the library is missing or a call is made without a HIP device the
+product path raises.  (The CPU oracle under `oracle/` is test infrastructure and is never imported here.)
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfsf_hip.so")
+
+_lib = None
+_lock = threading.Lock()
+
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_p = ctypes.c_void_p
+
+
+class FsfHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Fails loudly when the extension has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise FsfHipError(
+                        f"{LIB_PATH} is missing: the HIP extension was not built. "
+                        "Run `python -m fullysparsefusion_amd.build` (needs hipcc); there is no CPU fallback."
+                    )
+                h = ctypes.CDLL(LIB_PATH)
+                h.fsf_status_string.restype = ctypes.c_char_p
+                h.fsf_status_string.argtypes = [ctypes.c_int]
+                for name in (
+                    "fsf_unique_rows_workspace_bytes",
+                    "fsf_segment_plan_workspace_bytes",
+                    "fsf_segment_reduce_workspace_bytes",
+                    "fsf_rulebook_workspace_bytes",
+                    "fsf_ingroup_rank_workspace_bytes",
+                ):
+                    getattr(h, name).restype = c_i64
+                _lib = h
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().fsf_status_string(int(status)).decode()
+        raise FsfHipError(f"{what} failed: {msg} (status {status})")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise FsfHipError(
+                "fullysparsefusion_amd ops run on the HIP device only (got a CPU tensor); there is no CPU fallback"
+            )
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return c_p(None)
+    if not t.is_contiguous():
+        raise FsfHipError("non-contiguous tensor passed to the C ABI")
+    return c_p(t.data_ptr())
+
+
+def stream_ptr():
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream).  Stream-ordered reuse is safe because every C-ABI
+    call enqueues all of its work on the current stream before returning."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def f32_array(vals):
+    return (c_f32 * len(vals))(*[float(v) for v in vals])
+
+
+def i32_array(vals):
+    return (c_i32 * len(vals))(*[int(v) for v in vals])
+
+
+def i64_array(vals):
+    return (c_i64 * len(vals))(*[int(v) for v in vals])

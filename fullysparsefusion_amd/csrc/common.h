@@ -1,0 +1,77 @@
+// Shared device/host helpers for libfsf_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fsf_hip.h"
+
+#define FSF_WAVE 64
+
+#define FSF_HIP_TRY(expr)                      \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) return FSF_ERR_HIP;  \
+  } while (0)
+
+#define FSF_LAUNCH_CHECK()                               \
+  do {                                                   \
+    if (hipPeekAtLastError() != hipSuccess) return FSF_ERR_HIP; \
+  } while (0)
+
+static inline int64_t fsf_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline int fsf_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Memory-bound grids: cap at 256 CUs x 8 blocks and grid-stride the rest.
+static inline int fsf_stream_grid(int64_t work_items, int block) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+// Bump allocator over the caller's workspace (256-byte aligned slices).
+struct FsfArena {
+  char* base;
+  int64_t size;
+  int64_t used;
+  __host__ FsfArena(void* p, int64_t n) : base((char*)p), size(n), used(0) {}
+  template <typename T>
+  __host__ T* take(int64_t count) {
+    int64_t bytes = fsf_align_up((int64_t)sizeof(T) * (count > 0 ? count : 1), 256);
+    if (base == nullptr || used + bytes > size) {
+      used = size + 1;  // poison
+      return nullptr;
+    }
+    T* r = (T*)(base + used);
+    used += bytes;
+    return r;
+  }
+  __host__ bool ok() const { return used <= size; }
+};
+
+__device__ __forceinline__ int fsf_lane() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float fsf_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T fsf_wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Inclusive scan across the 64 lanes of a wave.
+template <typename T>
+__device__ __forceinline__ T fsf_wave_inclusive_scan(T v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}

@@ -1,0 +1,141 @@
+// Stable LSD radix sort for wave64 (see radix_sort.h).  HBM traffic per pass: 12 B read (histogram: 8 B)
+// + 12 B written per pair; with <= 32 significant key bits that is <= 4 passes.
+#include "radix_sort.h"
+
+namespace fsf {
+
+__global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                            uint32_t* __restrict__ hist, int tiles) {
+  __shared__ uint32_t lh[RS_BINS];
+  lh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int64_t e = base + it * RS_THREADS + threadIdx.x;
+    if (e < n) atomicAdd(&lh[(uint32_t)(keys[e] >> shift) & 0xffu], 1u);
+  }
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * tiles + blockIdx.x] = lh[threadIdx.x];
+}
+
+// Exclusive scan, in place, of `total` u32 counters by ONE workgroup of 1024 threads.
+__global__ void __launch_bounds__(1024) rs_scan_kernel(uint32_t* __restrict__ data, int64_t total) {
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x;
+  const int64_t per = (total + 1023) / 1024;
+  const int64_t lo = tid * per;
+  const int64_t hi = (lo + per < total) ? lo + per : total;
+  uint32_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += data[i];
+  uint32_t incl = fsf_wave_inclusive_scan(sum);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+  uint32_t run = wbase + incl - sum;
+  for (int64_t i = lo; i < hi; ++i) {
+    uint32_t v = data[i];
+    data[i] = run;
+    run += v;
+  }
+}
+
+__global__ void __launch_bounds__(RS_THREADS)
+    rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift,
+                      const uint32_t* __restrict__ hist, int tiles) {
+  // slot = it*4 + wave enumerates the tile's 64-key groups in key order
+  __shared__ uint32_t cnt[RS_ITEMS * 4][RS_BINS];
+  __shared__ uint32_t gbase[RS_BINS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+
+  uint64_t key[RS_ITEMS];
+  uint32_t val[RS_ITEMS];
+  uint32_t rank[RS_ITEMS];
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int64_t e = base + it * RS_THREADS + tid;
+    bool valid = e < n;
+    key[it] = valid ? keys_in[e] : 0ull;
+    val[it] = valid ? vals_in[e] : 0u;
+  }
+#pragma unroll
+  for (int s = 0; s < RS_ITEMS * 4; ++s) cnt[s][tid] = 0;
+  __syncthreads();
+
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int64_t e = base + it * RS_THREADS + tid;
+    bool valid = e < n;
+    uint32_t d = (uint32_t)(key[it] >> shift) & 0xffu;
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      bool bit = (d >> b) & 1u;
+      uint64_t bm = __ballot(valid && bit);
+      peers &= bit ? bm : ~bm;
+    }
+    uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+    rank[it] = r;
+    if (valid && r == 0) cnt[it * 4 + wave][d] = (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  {
+    uint32_t run = 0;
+#pragma unroll
+    for (int s = 0; s < RS_ITEMS * 4; ++s) {
+      uint32_t c = cnt[s][tid];
+      cnt[s][tid] = run;
+      run += c;
+    }
+    gbase[tid] = hist[(int64_t)tid * tiles + blockIdx.x];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < RS_ITEMS; ++it) {
+    int64_t e = base + it * RS_THREADS + tid;
+    if (e < n) {
+      uint32_t d = (uint32_t)(key[it] >> shift) & 0xffu;
+      uint32_t pos = gbase[d] + cnt[it * 4 + wave][d] + rank[it];
+      keys_out[pos] = key[it];
+      vals_out[pos] = val[it];
+    }
+  }
+}
+
+int64_t radix_sort_scratch_bytes(int64_t n) {
+  int64_t nn = n > 0 ? n : 1;
+  return fsf_align_up(nn * 8, 256) * 2 + fsf_align_up(nn * 4, 256) * 2 +
+         fsf_align_up(radix_num_tiles(n) * RS_BINS * 4, 256);
+}
+
+int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t* hist,
+                     int64_t n, int key_bits, uint64_t** keys_out, uint32_t** vals_out, hipStream_t stream) {
+  uint64_t* kin = keys_a;
+  uint32_t* vin = vals_a;
+  uint64_t* kout = keys_b;
+  uint32_t* vout = vals_b;
+  if (n > 0) {
+    const int tiles = (int)radix_num_tiles(n);
+    const int passes = (key_bits + 7) / 8;
+    for (int p = 0; p < passes; ++p) {
+      const int shift = p * 8;
+      hipLaunchKernelGGL(rs_hist_kernel, dim3(tiles), dim3(RS_THREADS), 0, stream, kin, n, shift, hist, tiles);
+      hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, (int64_t)tiles * RS_BINS);
+      hipLaunchKernelGGL(rs_scatter_kernel, dim3(tiles), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift,
+                         hist, tiles);
+      uint64_t* tk = kin; kin = kout; kout = tk;
+      uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    FSF_LAUNCH_CHECK();
+  }
+  *keys_out = kin;
+  *vals_out = vin;
+  return FSF_OK;
+}
+
+}  // namespace fsf

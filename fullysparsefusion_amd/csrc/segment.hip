@@ -1,0 +1,451 @@
+// K4/K5/K6: segmented sum/mean/max over sort-once segment plans, row gather, the voxel->point neck.
+// See include/fsf_hip.h.  No atomics: the sorted row list is cut into fixed 32-row chunks; a lane team
+// (channels across lanes, float4 where the row width allows) walks one chunk, writes every segment that
+// lies wholly inside it straight to `out`, and parks the (at most two) pieces that straddle a chunk
+// boundary in a partial buffer which a second pass folds in chunk order.  The summation order is a pure
+// function of the plan, so results are run-to-run deterministic.
+// Algorithmic HBM bytes: 4C B/row + 12 B/row of indices read, 4C B/segment written
+// (+8C B/segment when argmax is kept).
+#include "common.h"
+
+namespace fsf {
+
+constexpr int SEG_CHUNK = 32;
+constexpr int SEG_BLOCK = 256;
+constexpr int SEG_MIN_TEAM = 4;
+
+enum { MODE_SUM = 0, MODE_MEAN = 1, MODE_MAX = 2 };
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+  float v[1];
+};
+template <>
+struct Vec<4> {
+  float v[4];
+};
+
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> load_vec(const float* p) {
+  Vec<VEC> r;
+  if constexpr (VEC == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const Vec<VEC>& r) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  } else {
+    *p = r.v[0];
+  }
+}
+
+struct SegArgs {
+  const float* feat;
+  const int32_t* order;
+  const int64_t* inv;
+  const int32_t* seg_offsets;
+  float* out;
+  int64_t* argmax;
+  float* part_val;    // [nchunks, 2, c]
+  int32_t* part_arg;  // [nchunks, 2, c] (max + argmax only)
+  int64_t n;
+  int64_t m;
+  int c;
+  int team;  // lanes per team (power of two, 4..64)
+};
+
+template <int VEC, int MODE>
+__device__ __forceinline__ void seg_flush(const SegArgs& a, int64_t chunk, int seg, int piece_lo, int piece_hi, int ch,
+                                          const Vec<VEC>& acc, const int32_t* arg) {
+  const int S = a.seg_offsets[seg];
+  const int E = a.seg_offsets[seg + 1];
+  if (piece_lo == S && piece_hi == E) {
+    Vec<VEC> r = acc;
+    if constexpr (MODE == MODE_MEAN) {
+      const float cntf = (float)(E - S);
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) r.v[q] = __fdiv_rn(r.v[q], cntf);
+    }
+    store_vec<VEC>(a.out + (int64_t)seg * a.c + ch, r);
+    if constexpr (MODE == MODE_MAX) {
+      if (a.argmax) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) a.argmax[(int64_t)seg * a.c + ch + q] = (int64_t)arg[q];
+      }
+    }
+  } else {
+    const int which = (S < piece_lo) ? 0 : 1;  // 0: continues an earlier chunk, 1: continues into the next
+    const int64_t slot = (chunk * 2 + which) * a.c + ch;
+    store_vec<VEC>(a.part_val + slot, acc);
+    if constexpr (MODE == MODE_MAX) {
+      if (a.argmax) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) a.part_arg[slot + q] = arg[q];
+      }
+    }
+  }
+}
+
+template <int VEC, int MODE>
+__global__ void __launch_bounds__(SEG_BLOCK) seg_reduce_kernel(SegArgs a) {
+  // per wave: (64/team) teams x 32 rows of (point, segment) pairs staged once through LDS
+  __shared__ int2 rows[SEG_BLOCK / 64][(64 / SEG_MIN_TEAM) * SEG_CHUNK];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int teams_per_wave = 64 / a.team;
+  const int team_in_wave = lane / a.team;
+  const int tl = lane % a.team;
+  const int64_t nchunks = (a.n + SEG_CHUNK - 1) / SEG_CHUNK;
+  const int64_t waves_total = (int64_t)gridDim.x * (SEG_BLOCK / 64);
+  const int64_t wave_id = (int64_t)blockIdx.x * (SEG_BLOCK / 64) + wave;
+  const int rows_per_wave = teams_per_wave * SEG_CHUNK;
+  const float ident = (MODE == MODE_MAX) ? -INFINITY : 0.0f;
+
+  for (int64_t wchunk0 = wave_id * teams_per_wave; wchunk0 < nchunks; wchunk0 += waves_total * teams_per_wave) {
+    const int64_t row0 = wchunk0 * SEG_CHUNK;
+    for (int r = lane; r < rows_per_wave; r += 64) {
+      const int64_t j = row0 + r;
+      int2 e = make_int2(-1, -1);
+      if (j < a.n) {
+        e.x = a.order[j];
+        e.y = (int)a.inv[e.x];
+      }
+      rows[wave][r] = e;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const int64_t chunk = wchunk0 + team_in_wave;
+    if (chunk < nchunks) {
+      const int lo = (int)(chunk * SEG_CHUNK);
+      const int hi = (int)((lo + SEG_CHUNK < a.n) ? lo + SEG_CHUNK : a.n);
+      const int2* my_rows = &rows[wave][team_in_wave * SEG_CHUNK];
+      for (int ch = tl * VEC; ch < a.c; ch += a.team * VEC) {
+        Vec<VEC> acc;
+        int32_t arg[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          acc.v[q] = ident;
+          arg[q] = -1;
+        }
+        int cur = -1, piece_lo = lo;
+        for (int j0 = lo; j0 < hi; j0 += 4) {
+          int2 e[4];
+          Vec<VEC> v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            e[u] = (j0 + u < hi) ? my_rows[j0 + u - lo] : make_int2(-1, -1);
+            if (e[u].x >= 0) v[u] = load_vec<VEC>(a.feat + (int64_t)e[u].x * a.c + ch);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (e[u].x < 0) continue;
+            if (e[u].y != cur) {
+              if (cur >= 0) seg_flush<VEC, MODE>(a, chunk, cur, piece_lo, j0 + u, ch, acc, arg);
+              cur = e[u].y;
+              piece_lo = j0 + u;
+#pragma unroll
+              for (int q = 0; q < VEC; ++q) {
+                acc.v[q] = ident;
+                arg[q] = -1;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+              if constexpr (MODE == MODE_MAX) {
+                if (v[u].v[q] > acc.v[q] || arg[q] < 0) {
+                  acc.v[q] = v[u].v[q];
+                  arg[q] = e[u].x;
+                }
+              } else {
+                acc.v[q] = __fadd_rn(acc.v[q], v[u].v[q]);
+              }
+            }
+          }
+        }
+        if (cur >= 0) seg_flush<VEC, MODE>(a, chunk, cur, piece_lo, hi, ch, acc, arg);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// second pass: segments that straddle a chunk boundary (fold the partials in chunk order) and empty
+// segments (torch_scatter: out = 0, arg = n).
+template <int VEC, int MODE>
+__global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_kernel(SegArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int teams_per_wave = 64 / a.team;
+  const int tl = lane % a.team;
+  const int64_t team_id = ((int64_t)blockIdx.x * (SEG_BLOCK / 64) + (threadIdx.x >> 6)) * teams_per_wave + lane / a.team;
+  const int64_t teams_total = (int64_t)gridDim.x * (SEG_BLOCK / 64) * teams_per_wave;
+  for (int64_t s = team_id; s < a.m; s += teams_total) {
+    const int S = a.seg_offsets[s];
+    const int E = a.seg_offsets[s + 1];
+    if (E == S) {
+      for (int ch = tl * VEC; ch < a.c; ch += a.team * VEC) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          a.out[s * a.c + ch + q] = 0.0f;
+          if (MODE == MODE_MAX && a.argmax) a.argmax[s * a.c + ch + q] = a.n;
+        }
+      }
+      continue;
+    }
+    const int cs = S / SEG_CHUNK, ce = (E - 1) / SEG_CHUNK;
+    if (cs == ce) continue;
+    for (int ch = tl * VEC; ch < a.c; ch += a.team * VEC) {
+      Vec<VEC> acc = load_vec<VEC>(a.part_val + ((int64_t)cs * 2 + 1) * a.c + ch);
+      int32_t arg[VEC];
+      if (MODE == MODE_MAX && a.argmax) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) arg[q] = a.part_arg[((int64_t)cs * 2 + 1) * a.c + ch + q];
+      }
+      for (int cc = cs + 1; cc <= ce; ++cc) {
+        const int64_t slot = ((int64_t)cc * 2 + 0) * a.c + ch;
+        Vec<VEC> v = load_vec<VEC>(a.part_val + slot);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          if constexpr (MODE == MODE_MAX) {
+            if (v.v[q] > acc.v[q]) {
+              acc.v[q] = v.v[q];
+              if (a.argmax) arg[q] = a.part_arg[slot + q];
+            }
+          } else {
+            acc.v[q] = __fadd_rn(acc.v[q], v.v[q]);
+          }
+        }
+      }
+      if constexpr (MODE == MODE_MEAN) {
+        const float cntf = (float)(E - S);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc.v[q] = __fdiv_rn(acc.v[q], cntf);
+      }
+      store_vec<VEC>(a.out + s * a.c + ch, acc);
+      if (MODE == MODE_MAX && a.argmax) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) a.argmax[s * a.c + ch + q] = (int64_t)arg[q];
+      }
+    }
+  }
+}
+
+static int pick_team(int c, int vec) {
+  int groups = (c + vec - 1) / vec;
+  int t = SEG_MIN_TEAM;
+  while (t < groups && t < 64) t <<= 1;
+  return t;
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+    gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, int c,
+                       float* __restrict__ out) {
+  const int cv = c / VEC;
+  const int64_t total = n * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / cv;
+    const int col = (int)(t - i * cv) * VEC;
+    store_vec<VEC>(out + i * c + col, load_vec<VEC>(src + idx[i] * c + col));
+  }
+}
+
+struct V2PParams {
+  float vx, vy, vz, xmin, ymin, zmin, padding;
+};
+
+// one wave-row team per point: lanes stride the c voxel channels; lane 0..2 of the team add local xyz
+__global__ void __launch_bounds__(256)
+    voxel2point_kernel(const float* __restrict__ points, int stride, const int64_t* __restrict__ coors,
+                       const float* __restrict__ vf, int c, const int64_t* __restrict__ inv, int64_t n, V2PParams p,
+                       float* __restrict__ out, uint8_t* __restrict__ valid, int team) {
+  const int lane = threadIdx.x & 63;
+  const int tl = lane % team;
+  const int teams_per_block = 256 / team;
+  const int oc = c + 3;
+  for (int64_t i = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / team; i < n;
+       i += (int64_t)gridDim.x * teams_per_block) {
+    const int64_t row = inv[i];
+    bool all_pad = true;
+    for (int ch = tl; ch < c; ch += team) {
+      const float v = vf[row * c + ch];
+      all_pad &= (v == p.padding);
+      out[i * oc + ch] = v;
+    }
+    // team-wide AND of all_pad
+    for (int o = team >> 1; o > 0; o >>= 1) all_pad &= (bool)__shfl_xor((int)all_pad, o);
+    if (tl < 3) {
+      // (coor + 0.5) * voxel + range_min, column order x<-3, y<-2, z<-1 (voxel2point_neck.py:51)
+      const float cf = (float)coors[i * 4 + (3 - tl)];
+      const float vs = tl == 0 ? p.vx : (tl == 1 ? p.vy : p.vz);
+      const float mn = tl == 0 ? p.xmin : (tl == 1 ? p.ymin : p.zmin);
+      const float center = __fadd_rn(__fmul_rn(__fadd_rn(cf, 0.5f), vs), mn);
+      out[i * oc + c + tl] = __fsub_rn(points[i * stride + tl], center);
+    }
+    if (tl == 0 && valid) valid[i] = all_pad ? 0 : 1;
+  }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    seg_backward_dense_kernel(const float* __restrict__ grad_out, int64_t n, int c, const int64_t* __restrict__ inv,
+                              const int32_t* __restrict__ seg_offsets, float* __restrict__ grad_feat) {
+  const int64_t total = n * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / c;
+    const int ch = (int)(t - i * c);
+    const int64_t s = inv[i];
+    float g = grad_out[s * c + ch];
+    if (MODE == MODE_MEAN) {
+      const int cnt = seg_offsets[s + 1] - seg_offsets[s];
+      g = __fdiv_rn(g, (float)(cnt > 1 ? cnt : 1));
+    }
+    grad_feat[t] = g;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    seg_backward_max_kernel(const float* __restrict__ grad_out, int64_t m, int64_t n, int c,
+                            const int64_t* __restrict__ argmax, float* __restrict__ grad_feat) {
+  const int64_t total = m * c;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(t % c);
+    const int64_t p = argmax[t];
+    if (p >= 0 && p < n) grad_feat[p * c + ch] = grad_out[t];
+  }
+}
+
+}  // namespace fsf
+
+using namespace fsf;
+
+extern "C" int64_t fsf_segment_reduce_workspace_bytes(int64_t n, int64_t m, int32_t c) {
+  (void)m;
+  const int64_t nchunks = (n + SEG_CHUNK - 1) / SEG_CHUNK + 1;
+  return fsf_align_up(nchunks * 2 * c * 4, 256) * 2 + 256;
+}
+
+template <int VEC>
+static int seg_launch(const SegArgs& a, int mode, hipStream_t stream) {
+  const int64_t nchunks = (a.n + SEG_CHUNK - 1) / SEG_CHUNK;
+  const int teams_per_block = (SEG_BLOCK / 64) * (64 / a.team);
+  int64_t g1 = (nchunks + teams_per_block - 1) / teams_per_block;
+  if (g1 < 1) g1 = 1;
+  if (g1 > 8192) g1 = 8192;
+  int64_t g2 = (a.m + teams_per_block - 1) / teams_per_block;
+  if (g2 < 1) g2 = 1;
+  if (g2 > 4096) g2 = 4096;
+  switch (mode) {
+    case MODE_SUM:
+      if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_SUM>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
+      hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_SUM>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
+      break;
+    case MODE_MEAN:
+      if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_MEAN>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
+      hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MEAN>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
+      break;
+    default:
+      if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_MAX>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
+      hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MAX>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
+      break;
+  }
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_segment_reduce(const float* feat, int64_t n, int32_t c, const int32_t* order, const int64_t* inv,
+                                  const int32_t* seg_offsets, int64_t m, int32_t mode, float* out, int64_t* argmax,
+                                  void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2 || !seg_offsets || (m > 0 && !out) ||
+      (n > 0 && (!feat || !order || !inv)))
+    return FSF_ERR_INVALID_ARG;
+  if (m == 0) return FSF_OK;
+  if (workspace_bytes < fsf_segment_reduce_workspace_bytes(n, m, c)) return FSF_ERR_WORKSPACE;
+  FsfArena ar(workspace, workspace_bytes);
+  const int64_t nchunks = (n + SEG_CHUNK - 1) / SEG_CHUNK + 1;
+  SegArgs a;
+  a.feat = feat; a.order = order; a.inv = inv; a.seg_offsets = seg_offsets; a.out = out;
+  a.argmax = (mode == MODE_MAX) ? argmax : nullptr;
+  a.part_val = ar.take<float>(nchunks * 2 * c);
+  a.part_arg = ar.take<int32_t>(nchunks * 2 * c);
+  a.n = n; a.m = m; a.c = c;
+  if (!ar.ok()) return FSF_ERR_WORKSPACE;
+  const bool vec4 = (c % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
+  if (vec4) {
+    a.team = pick_team(c, 4);
+    return seg_launch<4>(a, mode, stream);
+  }
+  a.team = pick_team(c, 1);
+  return seg_launch<1>(a, mode, stream);
+}
+
+extern "C" int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int32_t c, const int64_t* inv,
+                                           const int32_t* seg_offsets, int64_t m, int32_t mode, const int64_t* argmax,
+                                           float* grad_feat, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || m < 0 || c < 1 || mode < 0 || mode > 2 || (n > 0 && (!grad_out || !grad_feat))) return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  if (mode == MODE_MAX) {
+    if (!argmax) return FSF_ERR_INVALID_ARG;
+    FSF_HIP_TRY(hipMemsetAsync(grad_feat, 0, (size_t)n * c * sizeof(float), stream));
+    if (m > 0)
+      hipLaunchKernelGGL(seg_backward_max_kernel, dim3(fsf_stream_grid(m * c, 256)), dim3(256), 0, stream, grad_out, m,
+                         n, (int)c, argmax, grad_feat);
+  } else {
+    if (!inv || !seg_offsets) return FSF_ERR_INVALID_ARG;
+    if (mode == MODE_MEAN)
+      hipLaunchKernelGGL((seg_backward_dense_kernel<MODE_MEAN>), dim3(fsf_stream_grid(n * c, 256)), dim3(256), 0, stream,
+                         grad_out, n, (int)c, inv, seg_offsets, grad_feat);
+    else
+      hipLaunchKernelGGL((seg_backward_dense_kernel<MODE_SUM>), dim3(fsf_stream_grid(n * c, 256)), dim3(256), 0, stream,
+                         grad_out, n, (int)c, inv, seg_offsets, grad_feat);
+  }
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
+                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)m;
+  if (n < 0 || c < 1 || (n > 0 && (!src || !idx || !out))) return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  const bool vec4 = (c % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
+  if (vec4)
+    hipLaunchKernelGGL((gather_rows_kernel<4>), dim3(fsf_stream_grid(n * (c / 4), 256)), dim3(256), 0, stream, src, idx,
+                       n, (int)c, out);
+  else
+    hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(fsf_stream_grid(n * c, 256)), dim3(256), 0, stream, src, idx, n,
+                       (int)c, out);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* coors_bzyx,
+                               const float* voxel_feats, int64_t m, int32_t c, const int64_t* inv, int64_t n,
+                               const float voxel_size[3], const float range_min[3], float padding, float* out,
+                               uint8_t* valid, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)m;
+  if (n < 0 || c < 1 || point_stride < 3 || !voxel_size || !range_min ||
+      (n > 0 && (!points || !coors_bzyx || !voxel_feats || !inv || !out)))
+    return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  V2PParams p{voxel_size[0], voxel_size[1], voxel_size[2], range_min[0], range_min[1], range_min[2], padding};
+  int team = 4;
+  while (team < c && team < 64) team <<= 1;
+  const int teams_per_block = 256 / team;
+  int64_t g = (n + teams_per_block - 1) / teams_per_block;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(voxel2point_kernel, dim3((unsigned)g), dim3(256), 0, stream, points, (int)point_stride, coors_bzyx,
+                     voxel_feats, (int)c, inv, n, p, out, valid, team);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}

@@ -1,0 +1,410 @@
+// K3: unique rows (+inverse, counts, CSR segment plan) by packed-key radix sort.  See include/fsf_hip.h.
+//
+// Pipeline: column min/max (device) -> pack each row into one u64 key that preserves lexicographic row
+// order -> stable LSD radix sort over the significant bits only -> head flags + exclusive scan ->
+// inverse / order / CSR offsets / decoded unique rows in one apply pass.
+// Algorithmic HBM bytes: 8k B/row read + 8 B/row inverse + 8k B/unique row.
+#include "common.h"
+#include "radix_sort.h"
+#include "scan.h"
+
+namespace fsf {
+
+struct ColRange {
+  int64_t mn[4];
+  int64_t mx[4];
+};
+
+struct PackSpec {
+  int64_t mn[4];
+  int64_t mx[4];
+  int shift[4];
+  uint64_t mask[4];
+  int k;
+};
+
+__global__ void uq_range_init_kernel(ColRange* r) {
+  int j = threadIdx.x;
+  if (j < 4) {
+    r->mn[j] = INT64_MAX;
+    r->mx[j] = INT64_MIN;
+  }
+}
+
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int64_t t = __shfl_xor(v, o);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int64_t wave_max_i64(int64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int64_t t = __shfl_xor(v, o);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) uq_range_kernel(const int64_t* __restrict__ coors, int64_t n, ColRange* r) {
+  int64_t mn[K], mx[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    mn[j] = INT64_MAX;
+    mx[j] = INT64_MIN;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      int64_t v = coors[i * K + j];
+      mn[j] = v < mn[j] ? v : mn[j];
+      mx[j] = v > mx[j] ? v : mx[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    int64_t a = wave_min_i64(mn[j]);
+    int64_t b = wave_max_i64(mx[j]);
+    if ((threadIdx.x & 63) == 0) {
+      __hip_atomic_fetch_min(&r->mn[j], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_max(&r->mx[j], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+    uq_pack_kernel(const int64_t* __restrict__ coors, int64_t n, PackSpec spec, uint64_t* __restrict__ keys,
+                   uint32_t* __restrict__ vals, int32_t* __restrict__ err_flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    uint64_t key = 0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      int64_t v = coors[i * K + j];
+      bad |= (v < spec.mn[j]) | (v > spec.mx[j]);
+      key |= ((uint64_t)(v - spec.mn[j]) & spec.mask[j]) << spec.shift[j];
+    }
+    if (bad) *err_flag = 1;
+    keys[i] = key;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+struct HeadIn {
+  const uint64_t* keys;
+  __device__ uint32_t operator()(int64_t i) const { return (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u; }
+};
+
+struct HeadOut {
+  const uint64_t* keys;
+  const uint32_t* vals;
+  PackSpec spec;
+  int64_t* new_coors;
+  int64_t* inv;
+  int32_t* order;
+  int32_t* seg_offsets;
+  __device__ void operator()(int64_t i, uint32_t excl, uint32_t head) const {
+    const uint32_t seg = excl + head - 1u;
+    const uint32_t p = vals[i];
+    inv[p] = (int64_t)seg;
+    order[i] = (int32_t)p;
+    if (head) {
+      seg_offsets[seg] = (int32_t)i;
+      const uint64_t key = keys[i];
+      for (int j = 0; j < spec.k; ++j)
+        new_coors[(int64_t)seg * spec.k + j] = (int64_t)((key >> spec.shift[j]) & spec.mask[j]) + spec.mn[j];
+    }
+  }
+};
+
+__global__ void uq_finish_kernel(const int64_t* __restrict__ m_dev, int64_t n, int32_t* __restrict__ seg_offsets,
+                                 int64_t* __restrict__ cnt) {
+  const int64_t m = *m_dev;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < m; s += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t lo = seg_offsets[s];
+    const int32_t hi = (s + 1 < m) ? seg_offsets[s + 1] : (int32_t)n;
+    if (cnt) cnt[s] = (int64_t)(hi - lo);
+    if (s + 1 == m) seg_offsets[m] = (int32_t)n;
+  }
+  if (m == 0 && blockIdx.x == 0 && threadIdx.x == 0) seg_offsets[0] = 0;
+}
+
+static int bit_width_u64(uint64_t v) {
+  int b = 0;
+  while (v) {
+    ++b;
+    v >>= 1;
+  }
+  return b;
+}
+
+// ---- segment plan from a caller-supplied inverse -------------------------------------------------
+__global__ void __launch_bounds__(256)
+    sp_pack_kernel(const int64_t* __restrict__ inv, int64_t n, int64_t m, uint64_t* __restrict__ keys,
+                   uint32_t* __restrict__ vals, int32_t* __restrict__ err_flag) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = inv[i];
+    if (v < 0 || v >= m) {
+      *err_flag = 1;
+      v = 0;
+    }
+    keys[i] = (uint64_t)v;
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// one thread per sorted position (plus one past the end): fills seg_offsets for every segment id in
+// (key[i-1], key[i]], which also covers empty segments.
+__global__ void __launch_bounds__(256)
+    sp_offsets_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n, int64_t m,
+                      int32_t* __restrict__ order, int32_t* __restrict__ seg_offsets) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t prev = (i == 0) ? -1 : (int64_t)keys[i - 1];
+    const int64_t cur = (i == n) ? m : (int64_t)keys[i];
+    for (int64_t s = prev + 1; s <= cur; ++s) seg_offsets[s] = (int32_t)i;
+    if (i < n) order[i] = (int32_t)vals[i];
+  }
+}
+
+__global__ void sp_counts_kernel(const int32_t* __restrict__ seg_offsets, int64_t m, int64_t* __restrict__ cnt) {
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < m; s += (int64_t)gridDim.x * blockDim.x)
+    cnt[s] = (int64_t)(seg_offsets[s + 1] - seg_offsets[s]);
+}
+
+// ---- in-group rank (K18) --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    ig_rank_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, int64_t n,
+                   const int32_t* __restrict__ head_pos, int64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[vals[i]] = (int64_t)(i - head_pos[i]);
+}
+
+struct IgIn {
+  const uint64_t* keys;
+  __device__ uint32_t operator()(int64_t i) const { return (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u; }
+};
+
+}  // namespace fsf
+
+using namespace fsf;
+
+extern "C" int64_t fsf_unique_rows_workspace_bytes(int64_t n, int32_t k) {
+  (void)k;
+  return radix_sort_scratch_bytes(n) + fsf_align_up(scan_num_tiles(n) * 4, 256) + 4 * 256;
+}
+
+extern "C" int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const int64_t* col_min,
+                               const int64_t* col_max, int64_t* new_coors, int64_t* inv, int64_t* cnt,
+                               int32_t* order, int32_t* seg_offsets, int64_t* m_dev, int64_t* m_host, void* workspace,
+                               int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || k < 1 || k > 4 || !m_dev || (n > 0 && (!coors || !new_coors || !inv || !order)) || !seg_offsets)
+    return FSF_ERR_INVALID_ARG;
+  if (n >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsf_unique_rows_workspace_bytes(n, k)) return FSF_ERR_WORKSPACE;
+  if (n == 0) {
+    FSF_HIP_TRY(hipMemsetAsync(m_dev, 0, sizeof(int64_t), stream));
+    FSF_HIP_TRY(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), stream));
+    if (m_host) {
+      FSF_HIP_TRY(hipStreamSynchronize(stream));
+      *m_host = 0;
+    }
+    return FSF_OK;
+  }
+  FsfArena ar(workspace, workspace_bytes);
+  uint64_t* keys_a = ar.take<uint64_t>(n);
+  uint64_t* keys_b = ar.take<uint64_t>(n);
+  uint32_t* vals_a = ar.take<uint32_t>(n);
+  uint32_t* vals_b = ar.take<uint32_t>(n);
+  uint32_t* hist = ar.take<uint32_t>(radix_num_tiles(n) * RS_BINS);
+  uint32_t* tile_sums = ar.take<uint32_t>(scan_num_tiles(n));
+  ColRange* range_dev = ar.take<ColRange>(1);
+  int32_t* err_flag = ar.take<int32_t>(1);
+  if (!ar.ok()) return FSF_ERR_WORKSPACE;
+
+  const int grid = fsf_stream_grid(n, 256);
+  ColRange range;
+  if (col_min && col_max) {
+    for (int j = 0; j < k; ++j) {
+      range.mn[j] = col_min[j];
+      range.mx[j] = col_max[j];
+      if (range.mx[j] < range.mn[j]) return FSF_ERR_INVALID_ARG;
+    }
+  } else {
+    // data-dependent bounds: one small D2H copy + sync (torch.unique in the reference syncs as well)
+    hipLaunchKernelGGL(uq_range_init_kernel, dim3(1), dim3(64), 0, stream, range_dev);
+    switch (k) {
+      case 1: hipLaunchKernelGGL((uq_range_kernel<1>), dim3(grid), dim3(256), 0, stream, coors, n, range_dev); break;
+      case 2: hipLaunchKernelGGL((uq_range_kernel<2>), dim3(grid), dim3(256), 0, stream, coors, n, range_dev); break;
+      case 3: hipLaunchKernelGGL((uq_range_kernel<3>), dim3(grid), dim3(256), 0, stream, coors, n, range_dev); break;
+      default: hipLaunchKernelGGL((uq_range_kernel<4>), dim3(grid), dim3(256), 0, stream, coors, n, range_dev); break;
+    }
+    FSF_HIP_TRY(hipMemcpyAsync(&range, range_dev, sizeof(ColRange), hipMemcpyDeviceToHost, stream));
+    FSF_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  PackSpec spec;
+  spec.k = k;
+  int total_bits = 0;
+  int bits[4] = {0, 0, 0, 0};
+  for (int j = 0; j < 4; ++j) {
+    spec.mn[j] = 0;
+    spec.mx[j] = 0;
+    spec.shift[j] = 0;
+    spec.mask[j] = 0;
+  }
+  for (int j = 0; j < k; ++j) {
+    spec.mn[j] = range.mn[j];
+    spec.mx[j] = range.mx[j];
+    const uint64_t span = (uint64_t)range.mx[j] - (uint64_t)range.mn[j];
+    bits[j] = bit_width_u64(span);
+    total_bits += bits[j];
+  }
+  if (total_bits > 64) return FSF_ERR_KEY_RANGE;
+  int sh = 0;
+  for (int j = k - 1; j >= 0; --j) {
+    spec.shift[j] = sh;
+    spec.mask[j] = bits[j] >= 64 ? ~0ull : ((1ull << bits[j]) - 1ull);
+    sh += bits[j];
+  }
+  FSF_HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int32_t), stream));
+  switch (k) {
+    case 1: hipLaunchKernelGGL((uq_pack_kernel<1>), dim3(grid), dim3(256), 0, stream, coors, n, spec, keys_a, vals_a, err_flag); break;
+    case 2: hipLaunchKernelGGL((uq_pack_kernel<2>), dim3(grid), dim3(256), 0, stream, coors, n, spec, keys_a, vals_a, err_flag); break;
+    case 3: hipLaunchKernelGGL((uq_pack_kernel<3>), dim3(grid), dim3(256), 0, stream, coors, n, spec, keys_a, vals_a, err_flag); break;
+    default: hipLaunchKernelGGL((uq_pack_kernel<4>), dim3(grid), dim3(256), 0, stream, coors, n, spec, keys_a, vals_a, err_flag); break;
+  }
+  uint64_t* keys_s;
+  uint32_t* vals_s;
+  int rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, n, total_bits, &keys_s, &vals_s, stream);
+  if (rc != FSF_OK) return rc;
+  HeadIn hin{keys_s};
+  HeadOut hout{keys_s, vals_s, spec, new_coors, inv, order, seg_offsets};
+  rc = exclusive_scan_u32(hin, hout, n, tile_sums, nullptr, m_dev, stream);
+  if (rc != FSF_OK) return rc;
+  hipLaunchKernelGGL(uq_finish_kernel, dim3(grid), dim3(256), 0, stream, m_dev, n, seg_offsets, cnt);
+  FSF_LAUNCH_CHECK();
+  if (m_host) {
+    int32_t err_h = 0;
+    FSF_HIP_TRY(hipMemcpyAsync(m_host, m_dev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    FSF_HIP_TRY(hipMemcpyAsync(&err_h, err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    FSF_HIP_TRY(hipStreamSynchronize(stream));
+    if (err_h) return FSF_ERR_KEY_RANGE;
+  }
+  return FSF_OK;
+}
+
+extern "C" int64_t fsf_segment_plan_workspace_bytes(int64_t n, int64_t m) {
+  (void)m;
+  return radix_sort_scratch_bytes(n) + 2 * 256;
+}
+
+extern "C" int fsf_segment_plan_from_inverse(const int64_t* inv, int64_t n, int64_t m, int32_t* order,
+                                             int32_t* seg_offsets, int64_t* cnt, void* workspace,
+                                             int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || m < 0 || !seg_offsets || (n > 0 && (!inv || !order))) return FSF_ERR_INVALID_ARG;
+  if (n >= (int64_t)1 << 31 || m >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsf_segment_plan_workspace_bytes(n, m)) return FSF_ERR_WORKSPACE;
+  FsfArena ar(workspace, workspace_bytes);
+  uint64_t* keys_a = ar.take<uint64_t>(n);
+  uint64_t* keys_b = ar.take<uint64_t>(n);
+  uint32_t* vals_a = ar.take<uint32_t>(n);
+  uint32_t* vals_b = ar.take<uint32_t>(n);
+  uint32_t* hist = ar.take<uint32_t>(radix_num_tiles(n) * RS_BINS);
+  int32_t* err_flag = ar.take<int32_t>(1);
+  if (!ar.ok()) return FSF_ERR_WORKSPACE;
+  const int grid = fsf_stream_grid(n + 1, 256);
+  FSF_HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int32_t), stream));
+  uint64_t* keys_s = keys_a;
+  uint32_t* vals_s = vals_a;
+  if (n > 0) {
+    hipLaunchKernelGGL(sp_pack_kernel, dim3(grid), dim3(256), 0, stream, inv, n, m, keys_a, vals_a, err_flag);
+    int rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, n, bit_width_u64(m > 0 ? (uint64_t)(m - 1) : 0),
+                              &keys_s, &vals_s, stream);
+    if (rc != FSF_OK) return rc;
+  }
+  hipLaunchKernelGGL(sp_offsets_kernel, dim3(grid), dim3(256), 0, stream, keys_s, vals_s, n, m, order, seg_offsets);
+  if (cnt && m > 0)
+    hipLaunchKernelGGL(sp_counts_kernel, dim3(fsf_stream_grid(m, 256)), dim3(256), 0, stream, seg_offsets, m, cnt);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int64_t fsf_ingroup_rank_workspace_bytes(int64_t n) {
+  return radix_sort_scratch_bytes(n) + fsf_align_up(scan_num_tiles(n) * 4, 256) + fsf_align_up((n > 0 ? n : 1) * 4, 256) +
+         4 * 256;
+}
+
+namespace fsf {
+// head position of each sorted element = running max of (head ? i : 0): computed by a scan of head flags
+// (segment id) followed by a lookup of the segment's start written at the heads.
+struct IgOut {
+  int32_t* seg_start;  // [n] scratch: start position per segment id
+  int32_t* seg_of;     // [n] scratch reused as head_pos afterwards
+  __device__ void operator()(int64_t i, uint32_t excl, uint32_t head) const {
+    const uint32_t seg = excl + head - 1u;
+    if (head) seg_start[seg] = (int32_t)i;
+    seg_of[i] = (int32_t)seg;
+  }
+};
+__global__ void __launch_bounds__(256)
+    ig_final_kernel(const uint32_t* __restrict__ vals, const int32_t* __restrict__ seg_of,
+                    const int32_t* __restrict__ seg_start, int64_t n, int64_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[vals[i]] = (int64_t)i - (int64_t)seg_start[seg_of[i]];
+}
+}  // namespace fsf
+
+extern "C" int fsf_ingroup_rank(const int64_t* group_inds, int64_t n, int64_t* out_inds, void* workspace,
+                                int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || (n > 0 && (!group_inds || !out_inds))) return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  if (n >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsf_ingroup_rank_workspace_bytes(n)) return FSF_ERR_WORKSPACE;
+  FsfArena ar(workspace, workspace_bytes);
+  uint64_t* keys_a = ar.take<uint64_t>(n);
+  uint64_t* keys_b = ar.take<uint64_t>(n);
+  uint32_t* vals_a = ar.take<uint32_t>(n);
+  uint32_t* vals_b = ar.take<uint32_t>(n);
+  uint32_t* hist = ar.take<uint32_t>(radix_num_tiles(n) * RS_BINS);
+  uint32_t* tile_sums = ar.take<uint32_t>(scan_num_tiles(n));
+  int32_t* seg_start = ar.take<int32_t>(n);
+  ColRange* range_dev = ar.take<ColRange>(1);
+  int32_t* err_flag = ar.take<int32_t>(1);
+  if (!ar.ok()) return FSF_ERR_WORKSPACE;
+  const int grid = fsf_stream_grid(n, 256);
+  ColRange range;
+  hipLaunchKernelGGL(uq_range_init_kernel, dim3(1), dim3(64), 0, stream, range_dev);
+  hipLaunchKernelGGL((uq_range_kernel<1>), dim3(grid), dim3(256), 0, stream, group_inds, n, range_dev);
+  FSF_HIP_TRY(hipMemcpyAsync(&range, range_dev, sizeof(ColRange), hipMemcpyDeviceToHost, stream));
+  FSF_HIP_TRY(hipStreamSynchronize(stream));
+  PackSpec spec;
+  for (int j = 0; j < 4; ++j) {
+    spec.mn[j] = 0; spec.mx[j] = 0; spec.shift[j] = 0; spec.mask[j] = 0;
+  }
+  spec.k = 1;
+  spec.mn[0] = range.mn[0];
+  spec.mx[0] = range.mx[0];
+  const int bits = bit_width_u64((uint64_t)range.mx[0] - (uint64_t)range.mn[0]);
+  spec.mask[0] = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+  FSF_HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int32_t), stream));
+  hipLaunchKernelGGL((uq_pack_kernel<1>), dim3(grid), dim3(256), 0, stream, group_inds, n, spec, keys_a, vals_a, err_flag);
+  uint64_t* keys_s;
+  uint32_t* vals_s;
+  int rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, n, bits, &keys_s, &vals_s, stream);
+  if (rc != FSF_OK) return rc;
+  // seg_of aliases the no-longer-needed alternate value buffer
+  int32_t* seg_of = (int32_t*)(vals_s == vals_a ? vals_b : vals_a);
+  IgIn iin{keys_s};
+  IgOut iout{seg_start, seg_of};
+  rc = exclusive_scan_u32(iin, iout, n, tile_sums, nullptr, nullptr, stream);
+  if (rc != FSF_OK) return rc;
+  hipLaunchKernelGGL(ig_final_kernel, dim3(grid), dim3(256), 0, stream, vals_s, seg_of, seg_start, n, out_inds);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}

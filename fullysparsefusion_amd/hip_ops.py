@@ -1,0 +1,352 @@
+"""Thin torch-tensor wrappers, one per C-ABI entry point of libfsf_hip.so (include/fsf_hip.h).
+
+These functions only marshal pointers/sizes and allocate caller-owned outputs with torch; all arithmetic
+happens in the HIP kernels.  The reference-shaped Python API (scatter_v2, Voxelization, SparseConvTensor,
+...) is built on top of these in `fullysparsefusion_amd.mmdet3d_plugin`.
+"""
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import c_f32, c_i32, c_i64, c_p, check, f32_array, i32_array, i64_array, ptr, require_cuda, stream_ptr
+
+_P = c_p
+_ARGTYPES = {
+    "fsf_voxelize_dynamic": [_P, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P],
+    "fsf_voxelize_divfloor": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P],
+    "fsf_unique_rows_workspace_bytes": [c_i64, c_i32],
+    "fsf_unique_rows": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_i64, _P],
+    "fsf_segment_plan_workspace_bytes": [c_i64, c_i64],
+    "fsf_segment_plan_from_inverse": [_P, c_i64, c_i64, _P, _P, _P, _P, c_i64, _P],
+    "fsf_segment_reduce_workspace_bytes": [c_i64, c_i64, c_i32],
+    "fsf_segment_reduce": [_P, c_i64, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_segment_reduce_backward": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, _P],
+    "fsf_gather_rows": [_P, c_i64, c_i32, _P, c_i64, _P, _P],
+    "fsf_voxel2point": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, _P, _P],
+    "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
+    "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
+    "fsf_rulebook_workspace_bytes": [c_i64, c_i32],
+    "fsf_rulebook_subm": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, c_i64, _P],
+    "fsf_rulebook_strided": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P],
+    "fsf_rulebook_to_pairs": [_P, c_i64, c_i32, _P, c_i64, _P, _P],
+    "fsf_spconv_transpose_weight": [_P, c_i32, c_i32, c_i32, _P, _P],
+    "fsf_spconv_forward": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P],
+    "fsf_ingroup_rank_workspace_bytes": [c_i64],
+    "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
+}
+_configured = False
+
+
+def _L():
+    global _configured
+    h = _lib.lib()
+    if not _configured:
+        for name, argtypes in _ARGTYPES.items():
+            getattr(h, name).argtypes = argtypes
+        _configured = True
+    return h
+
+
+MODE_SUM, MODE_MEAN, MODE_MAX = 0, 1, 2
+_MODES = {"sum": MODE_SUM, "mean": MODE_MEAN, "avg": MODE_MEAN, "max": MODE_MAX}
+
+
+# ------------------------------------------------------------------------------------------- voxelize
+def voxelize_dynamic(points: torch.Tensor, voxel_size, pc_range, grid, batch_idx: int = 0, want_zyx=True,
+                     want_bzyx=False):
+    """fsf_voxelize_dynamic.  points f32 [n, C>=3] -> (coors_zyx i32 [n,3] | None, coors_bzyx i64 [n,4] | None)."""
+    require_cuda(points)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.size(1) >= 3
+    points = points.contiguous()
+    n = points.size(0)
+    zyx = torch.empty((n, 3), dtype=torch.int32, device=points.device) if want_zyx else None
+    bzyx = torch.empty((n, 4), dtype=torch.int64, device=points.device) if want_bzyx else None
+    check(_L().fsf_voxelize_dynamic(ptr(points), n, points.size(1), int(batch_idx), f32_array(voxel_size),
+                                    f32_array(pc_range), i32_array(grid), ptr(zyx), ptr(bzyx), stream_ptr()),
+          "fsf_voxelize_dynamic")
+    return zyx, bzyx
+
+
+def voxelize_divfloor(points: torch.Tensor, voxel_size, range_min, order="zyx", batch_idx: Optional[torch.Tensor] = None):
+    """fsf_voxelize_divfloor: torch.div(p - min, v, rounding_mode='floor').long() keys, i64 [n, 3|4]."""
+    require_cuda(points, batch_idx)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.size(1) >= 3
+    points = points.contiguous()
+    n = points.size(0)
+    k = 4 if batch_idx is not None else 3
+    if batch_idx is not None:
+        batch_idx = batch_idx.to(torch.int64).contiguous()
+    coors = torch.empty((n, k), dtype=torch.int64, device=points.device)
+    check(_L().fsf_voxelize_divfloor(ptr(points), n, points.size(1), f32_array(voxel_size), f32_array(range_min),
+                                     {"xyz": 0, "zyx": 1}[order], ptr(batch_idx), ptr(coors), stream_ptr()),
+          "fsf_voxelize_divfloor")
+    return coors
+
+
+# --------------------------------------------------------------------------------------------- unique
+@dataclass
+class SegmentPlan:
+    """Sort-once segment plan shared by every segmented reduction over the same key."""
+    inv: torch.Tensor          # i64 [n]   point -> segment
+    order: torch.Tensor        # i32 [n]   point indices stably sorted by segment
+    seg_offsets: torch.Tensor  # i32 [m+1] CSR offsets into `order`
+    m: int
+    cnt: Optional[torch.Tensor] = None  # i64 [m]
+
+    @property
+    def n(self):
+        return self.inv.numel()
+
+
+def unique_rows(coors: torch.Tensor, col_min: Optional[Sequence[int]] = None, col_max: Optional[Sequence[int]] = None,
+                return_counts=True):
+    """fsf_unique_rows: (new_coors i64 [m,k] ascending lexicographic, SegmentPlan)."""
+    require_cuda(coors)
+    squeeze = coors.dim() == 1
+    if squeeze:
+        coors = coors[:, None]
+    assert coors.dim() == 2 and 1 <= coors.size(1) <= 4
+    coors = coors.to(torch.int64).contiguous()
+    n, k = coors.shape
+    dev = coors.device
+    new_coors = torch.empty((max(n, 1), k), dtype=torch.int64, device=dev)
+    inv = torch.empty((n,), dtype=torch.int64, device=dev)
+    cnt = torch.empty((max(n, 1),), dtype=torch.int64, device=dev) if return_counts else None
+    order = torch.empty((n,), dtype=torch.int32, device=dev)
+    seg_offsets = torch.empty((n + 1,), dtype=torch.int32, device=dev)
+    m_dev = torch.empty((1,), dtype=torch.int64, device=dev)
+    m_host = c_i64(0)
+    h = _L()
+    ws_bytes = h.fsf_unique_rows_workspace_bytes(n, k)
+    ws = _lib.workspace(ws_bytes, dev)
+    cmin = i64_array(col_min) if col_min is not None else None
+    cmax = i64_array(col_max) if col_max is not None else None
+    import ctypes
+    check(h.fsf_unique_rows(ptr(coors), n, k, cmin, cmax, ptr(new_coors), ptr(inv), ptr(cnt), ptr(order),
+                            ptr(seg_offsets), ptr(m_dev), ctypes.cast(ctypes.pointer(m_host), c_p), ptr(ws),
+                            ws.numel(), stream_ptr()), "fsf_unique_rows")
+    m = int(m_host.value)
+    new_coors = new_coors[:m]
+    if squeeze:
+        new_coors = new_coors[:, 0]
+    plan = SegmentPlan(inv=inv, order=order, seg_offsets=seg_offsets[: m + 1], m=m,
+                       cnt=cnt[:m] if cnt is not None else None)
+    return new_coors, plan
+
+
+def segment_plan_from_inverse(inv: torch.Tensor, m: int, return_counts=False) -> SegmentPlan:
+    require_cuda(inv)
+    inv = inv.to(torch.int64).contiguous()
+    n = inv.numel()
+    dev = inv.device
+    order = torch.empty((n,), dtype=torch.int32, device=dev)
+    seg_offsets = torch.empty((m + 1,), dtype=torch.int32, device=dev)
+    cnt = torch.empty((m,), dtype=torch.int64, device=dev) if return_counts else None
+    h = _L()
+    ws = _lib.workspace(h.fsf_segment_plan_workspace_bytes(n, m), dev)
+    check(h.fsf_segment_plan_from_inverse(ptr(inv), n, m, ptr(order), ptr(seg_offsets), ptr(cnt), ptr(ws), ws.numel(),
+                                          stream_ptr()), "fsf_segment_plan_from_inverse")
+    return SegmentPlan(inv=inv, order=order, seg_offsets=seg_offsets, m=m, cnt=cnt)
+
+
+# ------------------------------------------------------------------------------------- segment reduce
+def segment_reduce(feat: torch.Tensor, plan: SegmentPlan, mode: str, return_argmax=False):
+    """fsf_segment_reduce: feat f32 [n,c] -> out f32 [m,c] (+ argmax i64 [m,c] for mode='max')."""
+    require_cuda(feat)
+    assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.size(0) == plan.n
+    feat = feat.contiguous()
+    n, c = feat.shape
+    dev = feat.device
+    out = torch.empty((plan.m, c), dtype=torch.float32, device=dev)
+    md = _MODES[mode]
+    argmax = torch.empty((plan.m, c), dtype=torch.int64, device=dev) if (return_argmax and md == MODE_MAX) else None
+    h = _L()
+    ws = _lib.workspace(h.fsf_segment_reduce_workspace_bytes(n, plan.m, c), dev)
+    check(h.fsf_segment_reduce(ptr(feat), n, c, ptr(plan.order), ptr(plan.inv), ptr(plan.seg_offsets), plan.m, md,
+                               ptr(out), ptr(argmax), ptr(ws), ws.numel(), stream_ptr()), "fsf_segment_reduce")
+    return (out, argmax) if return_argmax else out
+
+
+def segment_reduce_backward(grad_out: torch.Tensor, plan: SegmentPlan, mode: str, argmax: Optional[torch.Tensor] = None):
+    require_cuda(grad_out)
+    grad_out = grad_out.contiguous()
+    m, c = grad_out.shape
+    n = plan.n
+    grad_feat = torch.empty((n, c), dtype=torch.float32, device=grad_out.device)
+    check(_L().fsf_segment_reduce_backward(ptr(grad_out), n, c, ptr(plan.inv), ptr(plan.seg_offsets), m, _MODES[mode],
+                                           ptr(argmax), ptr(grad_feat), stream_ptr()), "fsf_segment_reduce_backward")
+    return grad_feat
+
+
+def gather_rows(src: torch.Tensor, idx: torch.Tensor):
+    """fsf_gather_rows: out[i,:] = src[idx[i],:]."""
+    require_cuda(src, idx)
+    assert src.dtype == torch.float32 and src.dim() == 2
+    src = src.contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    n, (m, c) = idx.numel(), src.shape
+    out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    check(_L().fsf_gather_rows(ptr(src), m, c, ptr(idx), n, ptr(out), stream_ptr()), "fsf_gather_rows")
+    return out
+
+
+def voxel2point(points, coors_bzyx, voxel_feats, inv, voxel_size, range_min, padding=-1.0):
+    """fsf_voxel2point: fused gather + local-xyz decoration + padding mask (Voxel2PointScatterNeck)."""
+    require_cuda(points, coors_bzyx, voxel_feats, inv)
+    points = points.contiguous()
+    coors_bzyx = coors_bzyx.to(torch.int64).contiguous()
+    voxel_feats = voxel_feats.contiguous()
+    inv = inv.to(torch.int64).contiguous()
+    n = points.size(0)
+    m, c = voxel_feats.shape
+    out = torch.empty((n, c + 3), dtype=torch.float32, device=points.device)
+    valid = torch.empty((n,), dtype=torch.uint8, device=points.device)
+    check(_L().fsf_voxel2point(ptr(points), points.size(1), ptr(coors_bzyx), ptr(voxel_feats), m, c, ptr(inv), n,
+                               f32_array(voxel_size), f32_array(range_min), float(padding), ptr(out), ptr(valid),
+                               stream_ptr()), "fsf_voxel2point")
+    return out, valid.bool()
+
+
+# ---------------------------------------------------------------------------------------- projection
+def project_gather_mask(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.Tensor, return_pts_2d=False):
+    """fsf_project_gather_mask for ONE sample: xyz f32 [n,>=3], lidar2img f32 [ncam,4,4],
+    mask u8|i32 [ncam,ncls,H,W] -> obj_id i64 [n,ncam,ncls] (+ pts_2d f32 [ncam,n,2])."""
+    require_cuda(xyz, lidar2img, mask)
+    assert xyz.dtype == torch.float32 and lidar2img.dtype == torch.float32
+    assert mask.dtype in (torch.uint8, torch.int32) and mask.dim() == 4
+    xyz = xyz.contiguous()
+    lidar2img = lidar2img.contiguous()
+    mask = mask.contiguous()
+    n = xyz.size(0)
+    ncam, ncls, H, W = mask.shape
+    assert lidar2img.shape == (ncam, 4, 4)
+    obj_id = torch.empty((n, ncam, ncls), dtype=torch.int64, device=xyz.device)
+    pts_2d = torch.empty((ncam, n, 2), dtype=torch.float32, device=xyz.device) if return_pts_2d else None
+    check(_L().fsf_project_gather_mask(ptr(xyz), n, xyz.size(1), ptr(lidar2img), ncam, ptr(mask), mask.element_size(),
+                                       ncls, H, W, ptr(obj_id), ptr(pts_2d), stream_ptr()), "fsf_project_gather_mask")
+    return (obj_id, pts_2d) if return_pts_2d else obj_id
+
+
+def cam_select_score(obj_id: torch.Tensor, mask_anno: torch.Tensor, score_col=4, return_ids=False):
+    """fsf_cam_select_score for ONE sample: obj_id i64 [n,ncam,ncls], mask_anno f32 [A,D] -> score f32 [n,ncls]."""
+    require_cuda(obj_id, mask_anno)
+    obj_id = obj_id.contiguous()
+    mask_anno = mask_anno.to(torch.float32).contiguous()
+    n, ncam, ncls = obj_id.shape
+    score = torch.empty((n, ncls), dtype=torch.float32, device=obj_id.device)
+    ids = torch.empty((n, ncls), dtype=torch.int64, device=obj_id.device) if return_ids else None
+    check(_L().fsf_cam_select_score(ptr(obj_id), n, ncam, ncls, ptr(mask_anno), mask_anno.size(0), mask_anno.size(1),
+                                    int(score_col), ptr(ids), ptr(score), stream_ptr()), "fsf_cam_select_score")
+    return (score, ids) if return_ids else score
+
+
+# ------------------------------------------------------------------------------------------ rulebooks
+def rulebook_subm(indices: torch.Tensor, batch_size: int, spatial_shape, ksize=(3, 3, 3), dilation=(1, 1, 1)):
+    """fsf_rulebook_subm: indices i32 [m,4] (b,z,y,x) -> nbr i32 [m, kvol]."""
+    require_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.size(1) == 4
+    indices = indices.contiguous()
+    m = indices.size(0)
+    kvol = int(ksize[0] * ksize[1] * ksize[2])
+    nbr = torch.empty((m, kvol), dtype=torch.int32, device=indices.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_rulebook_workspace_bytes(m, kvol), indices.device)
+    check(h.fsf_rulebook_subm(ptr(indices), m, int(batch_size), i32_array(spatial_shape), i32_array(ksize),
+                              i32_array(dilation), ptr(nbr), ptr(ws), ws.numel(), stream_ptr()), "fsf_rulebook_subm")
+    return nbr
+
+
+def conv_out_shape(spatial_shape, ksize, stride, padding, dilation):
+    return [(spatial_shape[j] + 2 * padding[j] - dilation[j] * (ksize[j] - 1) - 1) // stride[j] + 1 for j in range(3)]
+
+
+def rulebook_strided(indices: torch.Tensor, batch_size: int, spatial_shape, ksize, stride, padding, dilation=(1, 1, 1),
+                     want_inverse=True):
+    """fsf_rulebook_strided -> (out_indices i32 [m_out,4], nbr i32 [m_out,kvol], nbr_inv i32 [m,kvol] | None, out_shape)."""
+    import ctypes
+    require_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.size(1) == 4
+    indices = indices.contiguous()
+    m = indices.size(0)
+    dev = indices.device
+    kvol = int(ksize[0] * ksize[1] * ksize[2])
+    out_shape = conv_out_shape(spatial_shape, ksize, stride, padding, dilation)
+    cells = int(batch_size) * out_shape[0] * out_shape[1] * out_shape[2]
+    cap = max(1, min(m * kvol, cells))
+    out_indices = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    nbr = torch.empty((cap, kvol), dtype=torch.int32, device=dev)
+    nbr_inv = torch.empty((m, kvol), dtype=torch.int32, device=dev) if want_inverse else None
+    m_out_host = c_i64(0)
+    h = _L()
+    ws = _lib.workspace(h.fsf_rulebook_workspace_bytes(m, kvol), dev)
+    check(h.fsf_rulebook_strided(ptr(indices), m, int(batch_size), i32_array(spatial_shape), i32_array(ksize),
+                                 i32_array(stride), i32_array(padding), i32_array(dilation), ptr(out_indices), cap,
+                                 ptr(nbr), ptr(nbr_inv), None, ctypes.cast(ctypes.pointer(m_out_host), c_p), ptr(ws),
+                                 ws.numel(), stream_ptr()), "fsf_rulebook_strided")
+    m_out = int(m_out_host.value)
+    return out_indices[:m_out], nbr[:m_out], nbr_inv, out_shape
+
+
+def rulebook_to_pairs(nbr: torch.Tensor):
+    """fsf_rulebook_to_pairs: nbr i32 [m_out,kvol] -> (indice_pairs i32 [kvol,2,m_out], indice_num i32 [kvol])."""
+    require_cuda(nbr)
+    nbr = nbr.contiguous()
+    m_out, kvol = nbr.shape
+    cap = max(m_out, 1)
+    pairs = torch.full((kvol, 2, cap), -1, dtype=torch.int32, device=nbr.device)
+    num = torch.empty((kvol,), dtype=torch.int32, device=nbr.device)
+    check(_L().fsf_rulebook_to_pairs(ptr(nbr), m_out, kvol, ptr(pairs), cap, ptr(num), stream_ptr()),
+          "fsf_rulebook_to_pairs")
+    return pairs, num
+
+
+# --------------------------------------------------------------------------------------- sparse conv
+def spconv_transpose_weight(weight: torch.Tensor):
+    """weight f32 [kvol, cin, cout] (spconv v1 layout flattened) -> [kvol, cout, cin]."""
+    require_cuda(weight)
+    weight = weight.contiguous()
+    kvol, cin, cout = weight.shape
+    wt = torch.empty((kvol, cout, cin), dtype=torch.float32, device=weight.device)
+    check(_L().fsf_spconv_transpose_weight(ptr(weight), kvol, cin, cout, ptr(wt), stream_ptr()),
+          "fsf_spconv_transpose_weight")
+    return wt
+
+
+def spconv_forward(feat: torch.Tensor, weight_t: torch.Tensor, nbr: torch.Tensor, scale=None, shift=None, residual=None,
+                   relu=False):
+    """fsf_spconv_forward: feat f32 [m_in,cin], weight_t f32 [kvol,cout,cin], nbr i32 [m_out,kvol] -> f32 [m_out,cout]."""
+    require_cuda(feat, weight_t, nbr)
+    feat = feat.contiguous()
+    weight_t = weight_t.contiguous()
+    nbr = nbr.contiguous()
+    m_in, cin = feat.shape
+    kvol, cout, cin_w = weight_t.shape
+    assert cin_w == cin and nbr.size(1) == kvol and nbr.dtype == torch.int32
+    m_out = nbr.size(0)
+    out = torch.empty((m_out, cout), dtype=torch.float32, device=feat.device)
+    if scale is not None:
+        scale = scale.contiguous()
+    if shift is not None:
+        shift = shift.contiguous()
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == out.shape
+    check(_L().fsf_spconv_forward(ptr(feat), m_in, cin, ptr(weight_t), kvol, cout, ptr(nbr), m_out, ptr(scale),
+                                  ptr(shift), ptr(residual), int(bool(relu)), ptr(out), stream_ptr()),
+          "fsf_spconv_forward")
+    return out
+
+
+# ------------------------------------------------------------------------------------- in-group rank
+def ingroup_rank(group_inds: torch.Tensor):
+    """fsf_ingroup_rank: stable rank of each element inside its group (TorchEx ingroup_indices contract)."""
+    require_cuda(group_inds)
+    g = group_inds.to(torch.int64).contiguous()
+    n = g.numel()
+    out = torch.empty((n,), dtype=torch.int64, device=g.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_ingroup_rank_workspace_bytes(n), g.device)
+    check(h.fsf_ingroup_rank(ptr(g), n, ptr(out), ptr(ws), ws.numel(), stream_ptr()), "fsf_ingroup_rank")
+    return out

@@ -1,0 +1,221 @@
+/*
+ * fsf_hip.h — C ABI of libfsf_hip.so, the MI355X (gfx950) hot path of FullySparseFusion.
+ *
+ * Every entry point takes raw DEVICE pointers + sizes + a hipStream_t (passed as void*), writes into
+ * caller-owned buffers and returns an int status (0 = FSF_OK, negative = error, see fsf_status_string).
+ * No torch types cross this boundary.  Data-dependent output sizes use "capacity in, count out":
+ * the caller allocates worst-case capacity, the callee writes the count to a device scalar and, when the
+ * `*_host` out-pointer is non-NULL, also synchronises the stream and stores it on the host.
+ *
+ * Each declaration cites the reference interface it replaces.  Paths are relative to the reference repo
+ * (BraveGroup/FullySparseFusion); "[UNVENDORED]" marks a symbol whose native source lives in a dependency
+ * that is not in the reference tree (mmdet3d fork / spconv v1 / torch_scatter 2.0.2 / TorchEx), see SURVEY.md §2.2.
+ */
+#ifndef FSF_HIP_H_
+#define FSF_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSF_OK 0
+#define FSF_ERR_INVALID_ARG (-1)   /* bad pointer / size / mode */
+#define FSF_ERR_WORKSPACE (-2)     /* workspace too small */
+#define FSF_ERR_KEY_RANGE (-3)     /* unique: packed row key does not fit in 64 bits */
+#define FSF_ERR_HIP (-4)           /* a HIP runtime call failed (hipGetLastError has the detail) */
+#define FSF_ERR_CAPACITY (-5)      /* data-dependent output exceeded the caller's capacity */
+#define FSF_ERR_UNSUPPORTED (-6)   /* shape outside what the kernels are built for */
+
+const char* fsf_status_string(int status);
+/* ABI version, bumped whenever a signature changes. */
+int fsf_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1+K2  dynamic voxelization
+ * Replaces: mmdet3d.ops.Voxelization(max_num_points=-1) [UNVENDORED dynamic_voxelize_kernel], constructed at
+ *   projects/mmdet3d_plugin/models/detectors/single_stage_fsd.py:176, called :218, plus the batch-index pad,
+ *   concat and .long() glue of VoteSegmentor.voxelize/extract_feat (:206-226, :231).
+ * c = floor((p - range_min) / voxel) evaluated in fp32, subtract-then-divide; x, then y, then z early-out;
+ * out-of-range: x OOB writes -1 to slot 0 only, y OOB slots 0,1, z OOB slots 0,1,2 (upstream semantics;
+ * the untouched slots are written as 0, which is what the reference's zero-initialised output holds).
+ *   points      f32 [n, point_stride] row-major, columns 0..2 = x,y,z
+ *   grid        {gx, gy, gz} voxel counts
+ *   coors_zyx   i32 [n,3] (z,y,x) or NULL         — what Voxelization returns
+ *   coors_bzyx  i64 [n,4] (batch,z,y,x) or NULL   — what extract_feat consumes after pad+long
+ */
+int fsf_voxelize_dynamic(const float* points, int64_t n, int32_t point_stride, int32_t batch_idx,
+                         const float voxel_size[3], const float pc_range[6], const int32_t grid[3],
+                         int32_t* coors_zyx, int64_t* coors_bzyx, void* stream);
+
+/* torch.div(p - min, v, rounding_mode='floor') voxel keys (c10::div_floor_floating semantics).
+ * Replaces the pure-PyTorch sites single_stage_fsd.py:270 (voxel_downsample), :591-592 (pre_voxelize, zyx)
+ * and :948-950 (ClusterAssigner.forward_single_class, xyz).  These sites DISAGREE with fsf_voxelize_dynamic
+ * on some boundary values; each keeps its own formula.
+ *   order: 0 = (x,y,z) columns, 1 = (z,y,x) columns
+ *   batch_idx_in: i64 [n] per-point batch index to prepend, or NULL (then coors has 3 columns)
+ *   coors: i64 [n, 3 or 4]
+ */
+int fsf_voxelize_divfloor(const float* points, int64_t n, int32_t point_stride, const float voxel_size[3],
+                          const float range_min[3], int32_t order, const int64_t* batch_idx_in,
+                          int64_t* coors, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  unique rows (+ inverse, counts, CSR segment plan)
+ * Replaces: torch.unique(coors, return_inverse=True, return_counts=True, dim=0) at
+ *   projects/mmdet3d_plugin/ops/sst_ops.py:156,165; models/backbones/sir.py:68; single_stage_fsd.py:32,595;
+ *   roi_heads/bbox_heads/fsd_bbox_head.py:115.
+ * new_coors are in ascending lexicographic row order (load-bearing).
+ * Beyond what torch.unique returns, the call emits the sort-once segment plan reused by every segmented
+ * reduction on the same key (`order` = point indices stably sorted by segment, `seg_offsets` = CSR).
+ *   coors        i64 [n,k], k in 1..4
+ *   new_coors    i64 [cap>=n rows, k]   (first m rows valid)
+ *   inv          i64 [n]
+ *   cnt          i64 [cap] or NULL
+ *   order        i32 [n]
+ *   seg_offsets  i32 [cap+1]            (first m+1 valid)
+ *   m_dev        i64 device scalar  (count of unique rows)
+ *   m_host       host pointer or NULL; when non-NULL the stream is synchronised
+ *   col_min/max  HOST arrays [k] bounding every column (e.g. the voxel grid), or NULL: then the bounds are
+ *                reduced on the device and read back (one extra sync).  Rows are packed into one u64 key
+ *                (sum of per-column bit widths must be <= 64, else FSF_ERR_KEY_RANGE); a value outside the
+ *                given bounds is reported as FSF_ERR_KEY_RANGE at the m_host sync.
+ */
+int64_t fsf_unique_rows_workspace_bytes(int64_t n, int32_t k);
+int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const int64_t* col_min, const int64_t* col_max,
+                    int64_t* new_coors, int64_t* inv, int64_t* cnt, int32_t* order, int32_t* seg_offsets,
+                    int64_t* m_dev, int64_t* m_host, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Segment plan from a caller-supplied inverse (values in [0,m)): the `unq_inv=`/`new_coors=` path of
+ * scatter_v2 (sst_ops.py:157-158).  Writes order/seg_offsets (and cnt if non-NULL). */
+int64_t fsf_segment_plan_workspace_bytes(int64_t n, int64_t m);
+int fsf_segment_plan_from_inverse(const int64_t* inv, int64_t n, int64_t m, int32_t* order, int32_t* seg_offsets,
+                                  int64_t* cnt, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4/K5  segmented reduce  (mode: 0 = sum, 1 = mean, 2 = max)
+ * Replaces: torch_scatter.scatter(feat, inv, dim=0, reduce='sum'|'mean') and torch_scatter.scatter_max
+ *   [UNVENDORED torch_scatter 2.0.2] at projects/mmdet3d_plugin/ops/sst_ops.py:168,170.
+ * mean = sum / max(count,1) in fp32; max also returns the arg row (first row attaining the max in
+ * ascending point index; torch_scatter's choice among ties is atomics-order dependent upstream).
+ * Deterministic: no atomics, fixed summation order (ascending point index inside fixed 64-row chunks,
+ * then chunks in order).
+ *   feat f32 [n,c]; order/inv/seg_offsets: the plan from fsf_unique_rows or fsf_segment_plan_from_inverse;
+ *   out f32 [m,c]; argmax i64 [m,c] or NULL (mode 2 only)
+ */
+int64_t fsf_segment_reduce_workspace_bytes(int64_t n, int64_t m, int32_t c);
+int fsf_segment_reduce(const float* feat, int64_t n, int32_t c, const int32_t* order, const int64_t* inv,
+                       const int32_t* seg_offsets, int64_t m, int32_t mode, float* out, int64_t* argmax,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Backward of the above w.r.t. feat (scatter_v2 is differentiable w.r.t. feat):
+ *   sum : grad_feat[i,:] = grad_out[inv[i],:]
+ *   mean: grad_feat[i,:] = grad_out[inv[i],:] / max(cnt[inv[i]],1)
+ *   max : grad_feat[argmax[s,ch], ch] = grad_out[s,ch], zero elsewhere (torch_scatter scatter_max backward)
+ */
+int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int32_t c, const int64_t* inv,
+                                const int32_t* seg_offsets, int64_t m, int32_t mode, const int64_t* argmax,
+                                float* grad_feat, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K6  row gather  out[i,:] = src[idx[i],:]   (and its adjoint, a deterministic segmented sum)
+ * Replaces: ATen advanced-index `voxel_feats[voxel2point_inds]` at
+ *   projects/mmdet3d_plugin/models/necks/voxel2point_neck.py:42 and the "map back" gathers inside
+ *   DynamicScatterVFE / SIRLayer [UNVENDORED], FSF.py:311.
+ */
+int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
+                    void* stream);
+
+/* Fused a7: Voxel2PointScatterNeck.forward (voxel2point_neck.py:27-70) without the boolean compaction:
+ *   out[i, 0:c]   = voxel_feats[inv[i], :]
+ *   out[i, c:c+3] = xyz[i] - ((coors[i,[3,2,1]] + 0.5) * voxel + range_min)
+ *   valid[i]      = !(all(out[i,0:c] == padding))
+ */
+int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* coors_bzyx, const float* voxel_feats,
+                    int64_t m, int32_t c, const int64_t* inv, int64_t n, const float voxel_size[3],
+                    const float range_min[3], float padding, float* out, uint8_t* valid, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K13-K15  LiDAR -> camera projection + per-point instance-mask gather
+ * Replaces: FSF.prj_points_2d (projects/mmdet3d_plugin/models/detectors/FSF.py:169-200) and
+ *   FSF.points_in_mask (:202-226) for one batch sample; the caller loops samples like frustum_gather (:228-258).
+ * Gathers straight from the integer mask (no .float() copy, FSF.py:209); pixel =
+ * nearbyint(((g+1)*S-1)/2) (round-half-even, grid_sample nearest, align_corners=False, zero padding).
+ *   xyz        f32 [n, xyz_stride] (cols 0..2)
+ *   lidar2img  f32 [ncam,4,4] row-major
+ *   mask       u8 (elem_bytes=1, nuScenes) or i32 (elem_bytes=4, AV2) [ncam,ncls,H,W]
+ *   obj_id     i64 [n,ncam,ncls]
+ *   pts_2d     f32 [ncam,n,2] or NULL (the normalised grid coords, -2 for invalid)
+ */
+int fsf_project_gather_mask(const float* xyz, int64_t n, int32_t xyz_stride, const float* lidar2img, int32_t ncam,
+                            const void* mask, int32_t elem_bytes, int32_t ncls, int32_t img_h, int32_t img_w,
+                            int64_t* obj_id, float* pts_2d, void* stream);
+
+/* K16  camera select + 2-D prediction lookup for the per-point branch (nuScenes: score column only).
+ * Replaces: FSF.img_cross_attn cam-select (FSF.py:716-718) + get_all_cls_preds_2d (:506-535) +
+ *   encode_preds_2d(encode_single_cls=False) (:449-474) for one batch sample:
+ *   cam* = argmax_c sum_k id[i,c,k] (first max); ids = id[i,cam*,:]; score[i,k] = ids>0 ? anno[ids-1, col] : 0
+ *   obj_id i64 [n,ncam,ncls]; mask_anno f32 [num_anno, anno_dim]; out_ids i64 [n,ncls] or NULL;
+ *   out_score f32 [n,ncls]
+ */
+int fsf_cam_select_score(const int64_t* obj_id, int64_t n, int32_t ncam, int32_t ncls, const float* mask_anno,
+                         int32_t num_anno, int32_t anno_dim, int32_t score_col, int64_t* out_ids, float* out_score,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K7/K8  sparse-conv rulebooks (hash table instead of spconv v1's dense grid)
+ * Replaces: mmdet3d.ops.spconv get_indice_pairs [UNVENDORED spconv v1 indice_cuda.cu] used inside
+ *   SimpleSparseUNet [UNVENDORED], configured at projects/configs/nuScenes/FSF_nuScenes_config.py:58-70.
+ * Rulebook layout is OUTPUT-MAJOR: nbr[o*kvol + k] = input row feeding output row o through kernel offset
+ * k = (kz*KY + ky)*KX + kx, or -1.  fsf_rulebook_to_pairs converts to spconv v1's indicePairs[kvol,2,cap] /
+ * indiceNum[kvol] (pairs in ascending output row — a canonical order; upstream order is atomics-dependent).
+ *   indices i32 [m,4] (b,z,y,x), spatial_shape {Z,Y,X}
+ */
+int64_t fsf_rulebook_workspace_bytes(int64_t m_in, int32_t kvol);
+int fsf_rulebook_subm(const int32_t* indices, int64_t m, int32_t batch_size, const int32_t spatial_shape[3],
+                      const int32_t ksize[3], const int32_t dilation[3], int32_t* nbr, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+/* Strided SparseConv3d: out coords are the ascending-linear-index unique set of
+ * (in + pad - k*dil)/stride (divisible, in-range); out_shape = (in + 2p - d(k-1) - 1)/s + 1.
+ *   out_indices i32 [cap,4]; nbr i32 [cap,kvol]; m_out_dev/m_out_host as in fsf_unique_rows.
+ * Also emits the transposed table for SparseInverseConv3d on the same indice_key:
+ *   nbr_inv i32 [m, kvol] (fine row -> coarse row per offset) or NULL.
+ */
+int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t batch_size, const int32_t spatial_shape[3],
+                         const int32_t ksize[3], const int32_t stride[3], const int32_t padding[3],
+                         const int32_t dilation[3], int32_t* out_indices, int64_t cap, int32_t* nbr,
+                         int32_t* nbr_inv, int64_t* m_out_dev, int64_t* m_out_host, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+int fsf_rulebook_to_pairs(const int32_t* nbr, int64_t m_out, int32_t kvol, int32_t* indice_pairs, int64_t cap,
+                          int32_t* indice_num, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K9/K11  sparse convolution forward: out[o,:] = act(scale * (sum_k feat[nbr[o,k],:] @ W[k]) + shift + residual)
+ * Replaces: spconv v1 indice_conv (per-offset gather -> cuBLAS mm -> scatter-add, 27x3 launches per layer)
+ *   [UNVENDORED] for SubMConv3d / SparseConv3d / SparseInverseConv3d inside SimpleSparseUNet; the eval-mode
+ *   naiveSyncBN1d affine and ReLU that follow every conv (cfg :63 order conv-norm-act) are the fused epilogue.
+ *   feat f32 [m_in,cin] (cin % 16 == 0); weight_t f32 [kvol,cout,cin] = the spconv v1 weight
+ *   [kz,ky,kx,Cin,Cout] transposed once per layer by fsf_spconv_transpose_weight; scale/shift f32 [cout] or
+ *   NULL (shift alone = bias); residual f32 [m_out,cout] or NULL (added before the ReLU); relu 0/1.
+ * One launch per layer; fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32 fma accumulation, deterministic.
+ */
+int fsf_spconv_transpose_weight(const float* weight, int32_t kvol, int32_t cin, int32_t cout, float* weight_t,
+                                void* stream);
+int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float* weight_t, int32_t kvol,
+                       int32_t cout, const int32_t* nbr, int64_t m_out, const float* scale, const float* shift,
+                       const float* residual, int32_t relu, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K18  in-group rank (TorchEx ingroup_indices [UNVENDORED]); sst_ops.py:239-259.
+ * Upstream is an atomicAdd counter (a nondeterministic permutation of 0..n_g-1 per group); this returns the
+ * stable rank (ascending original index), which satisfies the same contract (sst_ops.py:225-235).
+ */
+int64_t fsf_ingroup_rank_workspace_bytes(int64_t n);
+int fsf_ingroup_rank(const int64_t* group_inds, int64_t n, int64_t* out_inds, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FSF_HIP_H_ */

@@ -1,0 +1,398 @@
+"""GPU parity tests: every C-ABI entry point of libfsf_hip.so against the CPU oracle and the committed golden
+vectors.  Integer / index outputs are compared bit-exact; fp32 reductions within 1e-5 (sum order differs),
+max bit-exact; sparse-conv features within 1e-4 (BASELINE.json north_star tolerance)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+from oracle import project as oproj
+from oracle import scatter as oscatter
+from oracle import spconv as osp
+from oracle import voxelize as ovox
+
+pytestmark = pytest.mark.gpu
+
+PC_RANGE = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+VOXEL = (0.2, 0.2, 0.2)
+
+
+@pytest.fixture(scope="module")
+def ops(device):
+    from fullysparsefusion_amd import hip_ops
+
+    return hip_ops
+
+
+def cloud(n, seed=0, oob_frac=0.0):
+    rng = np.random.default_rng(seed)
+    p = np.empty((n, 5), dtype=np.float32)
+    lo, hi = (-50, 50) if oob_frac == 0 else (-53, 53)
+    p[:, 0] = rng.uniform(lo, hi, n)
+    p[:, 1] = rng.uniform(lo, hi, n)
+    p[:, 2] = rng.uniform(-4.99, 2.99, n) if oob_frac == 0 else rng.uniform(-5.5, 3.5, n)
+    p[:, 3] = rng.random(n)
+    p[:, 4] = rng.integers(0, 10, n) * 0.05
+    return p
+
+
+# ------------------------------------------------------------------------------------------ voxelize
+@pytest.mark.parametrize("n,oob", [(10000, 0.0), (307200, 0.0), (5000, 0.3), (1, 0.0)])
+def test_voxelize_dynamic_bit_exact(ops, device, n, oob):
+    pts = cloud(n, seed=n, oob_frac=oob)
+    k = np.arange(513, dtype=np.float32)
+    b = (k * np.float32(0.2) + np.float32(-51.2)).astype(np.float32)
+    edge = np.zeros((3 * b.size, 5), dtype=np.float32)
+    edge[:, 0] = np.concatenate([b, np.nextafter(b, np.float32(100)), np.nextafter(b, np.float32(-100))])
+    edge[:, 1] = edge[::-1, 0]
+    edge[:, 2] = np.clip(edge[:, 0] / 12.8, -5.0, 3.0)
+    pts = np.concatenate([pts, edge], 0)
+    grid = ovox.grid_size(VOXEL, PC_RANGE)
+    want = ovox.dynamic_voxelize(pts, VOXEL, PC_RANGE)
+    zyx, bzyx = ops.voxelize_dynamic(torch.from_numpy(pts).to(device), VOXEL, PC_RANGE, grid, batch_idx=3,
+                                     want_zyx=True, want_bzyx=True)
+    np.testing.assert_array_equal(zyx.cpu().numpy(), want)
+    np.testing.assert_array_equal(bzyx.cpu().numpy()[:, 1:], want.astype(np.int64))
+    assert (bzyx[:, 0] == 3).all()
+
+
+@pytest.mark.parametrize("tag", ["v01", "v03", "v005", "v02"])
+def test_voxelize_divfloor_golden(ops, device, tag):
+    g = golden_cases(load_golden("divfloor.npz"))[tag]
+    pts = torch.from_numpy(g["points"]).to(device)
+    c = ops.voxelize_divfloor(pts, g["voxel"].tolist(), g["min"].tolist(), order="xyz")
+    np.testing.assert_array_equal(c.cpu().numpy(), g["coors_xyz"])
+    bidx = torch.arange(pts.size(0), device=device) % 2
+    c4 = ops.voxelize_divfloor(pts, g["voxel"].tolist(), g["min"].tolist(), order="zyx", batch_idx=bidx)
+    np.testing.assert_array_equal(c4.cpu().numpy()[:, 1:], g["coors_xyz"][:, ::-1])
+    np.testing.assert_array_equal(c4.cpu().numpy()[:, 0], bidx.cpu().numpy())
+
+
+# -------------------------------------------------------------------------------------------- unique
+def check_unique(ops, device, coors_np, bounds=None):
+    coors = torch.from_numpy(coors_np)
+    want_c, want_inv, want_cnt = torch.unique(coors, return_inverse=True, return_counts=True, dim=0)
+    kw = {}
+    if bounds is not None:
+        kw = dict(col_min=bounds[0], col_max=bounds[1])
+    new_coors, plan = ops.unique_rows(coors.to(device), **kw)
+    assert plan.m == want_c.size(0)
+    np.testing.assert_array_equal(new_coors.cpu().numpy(), want_c.numpy())
+    np.testing.assert_array_equal(plan.inv.cpu().numpy(), want_inv.numpy())
+    np.testing.assert_array_equal(plan.cnt.cpu().numpy(), want_cnt.numpy())
+    order = plan.order.cpu().numpy().astype(np.int64)
+    offs = plan.seg_offsets.cpu().numpy()
+    n = coors.size(0)
+    assert sorted(order.tolist()) == list(range(n))
+    np.testing.assert_array_equal(np.diff(offs), want_cnt.numpy())
+    assert offs[0] == 0 and offs[-1] == n
+    seg_of_sorted = want_inv.numpy()[order]
+    assert (np.diff(seg_of_sorted) >= 0).all()
+    # stable: ascending point index inside each segment
+    same = np.diff(seg_of_sorted) == 0
+    assert (np.diff(order)[same] > 0).all()
+    return plan
+
+
+@pytest.mark.parametrize("case", ["k4_avg", "k3_avg", "k1_avg", "single_row", "all_same"])
+def test_unique_rows_golden_keys(ops, device, case):
+    g = golden_cases(load_golden("scatter_v2.npz"))[case]
+    check_unique(ops, device, g["coors"])
+
+
+def test_unique_rows_voxel_grid_full_size(ops, device):
+    pts = cloud(307200, seed=7)
+    _, coors = ovox.voxelize_batch([pts[:150000], pts[150000:]], VOXEL, PC_RANGE)
+    check_unique(ops, device, coors, bounds=([0, 0, 0, 0], [1, 39, 511, 511]))
+    check_unique(ops, device, coors)  # data-dependent bounds path
+
+
+def test_unique_rows_wide_and_negative_keys(ops, device):
+    rng = np.random.default_rng(5)
+    c = np.stack([rng.integers(-5, 5, 50000), rng.integers(-100000, 100000, 50000), rng.integers(0, 3, 50000)], 1)
+    check_unique(ops, device, c.astype(np.int64))
+    c1 = rng.integers(-(2 ** 40), 2 ** 40, (20000, 1)).astype(np.int64)
+    check_unique(ops, device, c1)
+
+
+def test_unique_rows_empty(ops, device):
+    new_coors, plan = ops.unique_rows(torch.zeros((0, 4), dtype=torch.int64, device=device))
+    assert plan.m == 0 and new_coors.shape == (0, 4)
+
+
+def test_unique_rows_out_of_bounds_is_reported(ops, device):
+    from fullysparsefusion_amd._lib import FsfHipError
+
+    c = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 600]], dtype=torch.int64, device=device)
+    with pytest.raises(FsfHipError):
+        ops.unique_rows(c, col_min=[0, 0, 0, 0], col_max=[1, 39, 511, 511])
+
+
+# ------------------------------------------------------------------------------------ segment reduce
+@pytest.mark.parametrize("c", [3, 4, 5, 11, 64, 128, 131, 260])
+@pytest.mark.parametrize("mode", ["sum", "mean", "max"])
+def test_segment_reduce_vs_oracle(ops, device, c, mode):
+    rng = np.random.default_rng(c)
+    n = 20000
+    # skewed segments: singletons, ~3-point voxels and one 6000-row group
+    keys = rng.integers(0, 5000, n)
+    keys[:6000] = 17
+    keys = keys[rng.permutation(n)]
+    feat = rng.standard_normal((n, c)).astype(np.float32)
+    coors = torch.from_numpy(keys.astype(np.int64))[:, None]
+    _, plan = ops.unique_rows(coors.to(device))
+    want_c, want_inv = torch.unique(coors, return_inverse=True, dim=0)
+    m = want_c.size(0)
+    f = torch.from_numpy(feat)
+    if mode == "max":
+        out, arg = ops.segment_reduce(f.to(device), plan, "max", return_argmax=True)
+        want, want_arg = oscatter.segment_max(f, want_inv, m)
+        np.testing.assert_array_equal(out.cpu().numpy(), want.numpy())
+        np.testing.assert_array_equal(arg.cpu().numpy(), want_arg.numpy())
+    else:
+        out = ops.segment_reduce(f.to(device), plan, mode)
+        want = oscatter.segment_sum(f.double(), want_inv, m)
+        if mode == "mean":
+            want = want / torch.bincount(want_inv, minlength=m).clamp(min=1)[:, None]
+        np.testing.assert_allclose(out.cpu().numpy(), want.float().numpy(), rtol=1e-5, atol=2e-5)
+    # run-to-run determinism (no atomics)
+    out2 = ops.segment_reduce(f.to(device), plan, mode)
+    first = out if mode != "max" else out
+    assert torch.equal(first, out2)
+
+
+@pytest.mark.parametrize("case", sorted(golden_cases(load_golden("scatter_v2.npz"))))
+def test_segment_reduce_reference_golden(ops, device, case):
+    g = golden_cases(load_golden("scatter_v2.npz"))[case]
+    if int(g["min_points"]) > 0:
+        pytest.skip("min_points path is exercised through scatter_v2 (test_plugin_ops)")
+    new_coors, plan = ops.unique_rows(torch.from_numpy(g["coors"]).to(device))
+    out = ops.segment_reduce(torch.from_numpy(g["feat"]).to(device), plan, str(g["mode"]))
+    np.testing.assert_array_equal(new_coors.cpu().numpy(), g["new_coors"])
+    np.testing.assert_array_equal(plan.inv.cpu().numpy(), g["inv"])
+    if str(g["mode"]) == "max":
+        np.testing.assert_array_equal(out.cpu().numpy(), g["new_feat"])
+    else:
+        np.testing.assert_allclose(out.cpu().numpy(), g["new_feat"], rtol=1e-5, atol=1e-5)
+
+
+def test_segment_plan_from_inverse_with_empty_segments(ops, device):
+    rng = np.random.default_rng(0)
+    m, n = 300, 5000
+    inv = rng.integers(0, m, n)
+    inv[inv % 7 == 3] = 0  # leave some segment ids unused
+    plan = ops.segment_plan_from_inverse(torch.from_numpy(inv).to(device), m, return_counts=True)
+    cnt = np.bincount(inv, minlength=m)
+    np.testing.assert_array_equal(plan.cnt.cpu().numpy(), cnt)
+    np.testing.assert_array_equal(np.diff(plan.seg_offsets.cpu().numpy()), cnt)
+    f = torch.from_numpy(rng.standard_normal((n, 16)).astype(np.float32))
+    out, arg = ops.segment_reduce(f.to(device), plan, "max", return_argmax=True)
+    want, want_arg = oscatter.segment_max(f, torch.from_numpy(inv), m)
+    np.testing.assert_array_equal(out.cpu().numpy(), want.numpy())
+    np.testing.assert_array_equal(arg.cpu().numpy(), want_arg.numpy())
+    s = ops.segment_reduce(f.to(device), plan, "mean")
+    np.testing.assert_allclose(s.cpu().numpy(), oscatter.segment_mean(f, torch.from_numpy(inv), m).numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["sum", "mean", "max"])
+def test_segment_reduce_backward(ops, device, mode):
+    rng = np.random.default_rng(11)
+    n, c = 4000, 24
+    keys = torch.from_numpy(rng.integers(0, 700, (n, 1)))
+    f = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).requires_grad_(True)
+    _, inv = torch.unique(keys, return_inverse=True, dim=0)
+    m = int(inv.max()) + 1
+    go = torch.from_numpy(rng.standard_normal((m, c)).astype(np.float32))
+    if mode == "max":
+        want_out, _ = oscatter.segment_max(f, inv, m)
+        ref = f.new_zeros((m, c)).scatter_reduce(0, inv[:, None].expand(n, c), f, reduce="amax", include_self=False)
+    elif mode == "mean":
+        ref = f.new_zeros((m, c)).scatter_reduce(0, inv[:, None].expand(n, c), f, reduce="mean", include_self=False)
+    else:
+        ref = f.new_zeros((m, c)).index_add(0, inv, f)
+    ref.backward(go)
+    _, plan = ops.unique_rows(keys.to(device))
+    arg = None
+    if mode == "max":
+        _, arg = ops.segment_reduce(f.detach().to(device), plan, "max", return_argmax=True)
+    g = ops.segment_reduce_backward(go.to(device), plan, mode, argmax=arg)
+    np.testing.assert_allclose(g.cpu().numpy(), f.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_gather_rows(ops, device):
+    rng = np.random.default_rng(2)
+    for c in (3, 64, 128, 131):
+        src = torch.from_numpy(rng.standard_normal((999, c)).astype(np.float32))
+        idx = torch.from_numpy(rng.integers(0, 999, 12345))
+        out = ops.gather_rows(src.to(device), idx.to(device))
+        assert torch.equal(out.cpu(), src[idx])
+
+
+def test_voxel2point_golden(ops, device):
+    g = load_golden("neck.npz")
+    out, valid = ops.voxel2point(torch.from_numpy(g["points"]).to(device), torch.from_numpy(g["coors"]).to(device),
+                                 torch.from_numpy(g["voxel_feats"]).to(device), torch.from_numpy(g["inv"]).to(device),
+                                 g["voxel_size"].tolist(), g["pc_range"][:3].tolist(), padding=-1.0)
+    np.testing.assert_array_equal(valid.cpu().numpy(), g["mask"])
+    np.testing.assert_array_equal(out.cpu().numpy()[g["mask"]], g["out"])  # fp32 bit-exact (same op order)
+    assert (~g["mask"]).sum() > 0
+
+
+# ---------------------------------------------------------------------------------------- projection
+@pytest.mark.parametrize("tag", ["nusc_small", "nusc_mid", "av2_small"])
+def test_project_gather_golden(ops, device, tag):
+    g = golden_cases(load_golden("project.npz"))[tag]
+    ids, p2d = ops.project_gather_mask(torch.from_numpy(g["points"]).to(device), torch.from_numpy(g["lidar2img"]).to(device),
+                                       torch.from_numpy(g["mask"]).to(device), return_pts_2d=True)
+    np.testing.assert_array_equal(p2d.cpu().numpy(), g["pts_2d"])
+    np.testing.assert_array_equal(ids.cpu().numpy(), g["obj_id"])
+    if "score" in g:
+        score, cam_ids = ops.cam_select_score(ids, torch.from_numpy(g["mask_anno"]).to(device), return_ids=True)
+        np.testing.assert_array_equal(cam_ids.cpu().numpy(), g["cam_ids"])
+        np.testing.assert_array_equal(score.cpu().numpy(), g["score"])
+
+
+def test_project_gather_full_size_vs_oracle(ops, device):
+    """BASELINE config-3 shape: 3e5 points x 6 cams x 10 classes on a 900x1600 u8 mask."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from fullysparsefusion_amd.synthetic import make_lidar2img, make_mask_data
+
+    rng = np.random.default_rng(0)
+    n = 300000
+    pts = cloud(n, seed=3)[:, :3].copy()
+    L = make_lidar2img(6)
+    mask, anno = make_mask_data(rng, 6, 10, 900, 1600, 250)
+    want, want_p2d = oproj.points_in_mask(pts, mask, L)
+    ids, p2d = ops.project_gather_mask(torch.from_numpy(pts).to(device), torch.from_numpy(L).to(device),
+                                       torch.from_numpy(mask).to(device), return_pts_2d=True)
+    np.testing.assert_array_equal(p2d.cpu().numpy(), want_p2d)
+    np.testing.assert_array_equal(ids.cpu().numpy(), want)
+    assert (want > 0).any(-1).any(-1).mean() > 0.05
+    wi, ws = oproj.cam_select_score(want, anno)
+    score, cam_ids = ops.cam_select_score(ids, torch.from_numpy(anno).to(device), return_ids=True)
+    np.testing.assert_array_equal(cam_ids.cpu().numpy(), wi)
+    np.testing.assert_array_equal(score.cpu().numpy(), ws)
+
+
+# ----------------------------------------------------------------------------------------- rulebooks
+def sparse_sites(rng, batch, shape, m):
+    cells = batch * shape[0] * shape[1] * shape[2]
+    lin = np.sort(rng.choice(cells, size=m, replace=False))
+    x = lin % shape[2]
+    y = (lin // shape[2]) % shape[1]
+    z = (lin // (shape[2] * shape[1])) % shape[0]
+    b = lin // (shape[2] * shape[1] * shape[0])
+    return np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+def surface_sites(rng, batch, shape, m):
+    """LiDAR-like occupancy: a thin, x-y dense sheet (ground) plus scattered columns."""
+    z0 = shape[0] // 3
+    sites = set()
+    while len(sites) < m:
+        b = int(rng.integers(batch))
+        y = int(rng.integers(shape[1]))
+        x = int(rng.integers(shape[2]))
+        z = z0 + int(rng.integers(0, 2)) if rng.random() < 0.8 else int(rng.integers(shape[0]))
+        sites.add((b, z, y, x))
+    arr = np.array(sorted(sites), dtype=np.int32)
+    return arr
+
+
+@pytest.mark.parametrize("shape,m", [((8, 12, 10), 400), ((40, 128, 128), 20000), ((3, 3, 3), 2)])
+def test_rulebook_subm_bit_exact(ops, device, shape, m):
+    rng = np.random.default_rng(m)
+    idx = sparse_sites(rng, 2, shape, m) if m != 20000 else surface_sites(rng, 2, shape, m)
+    _, pairs, _ = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True)
+    want = osp.pairs_to_nbr(pairs, idx.shape[0])
+    nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), 2, shape)
+    np.testing.assert_array_equal(nbr.cpu().numpy(), want)
+    # spconv v1 pair-list form (canonical: ascending output row per offset)
+    ip, num = ops.rulebook_to_pairs(nbr)
+    ip, num = ip.cpu().numpy(), num.cpu().numpy()
+    for k, (i_r, o_r) in enumerate(pairs):
+        assert num[k] == len(i_r)
+        np.testing.assert_array_equal(ip[k, 0, : num[k]], i_r)
+        np.testing.assert_array_equal(ip[k, 1, : num[k]], o_r)
+
+
+@pytest.mark.parametrize("shape,padding,m", [((8, 12, 10), (1, 1, 1), 400), ((5, 12, 10), (0, 1, 1), 300),
+                                             ((40, 128, 128), (1, 1, 1), 20000), ((4, 4, 4), (1, 1, 1), 9)])
+def test_rulebook_strided_bit_exact(ops, device, shape, padding, m):
+    rng = np.random.default_rng(m + 1)
+    idx = sparse_sites(rng, 2, shape, m) if m != 20000 else surface_sites(rng, 2, shape, m)
+    out_idx, pairs, oshape = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (2, 2, 2), padding, (1, 1, 1), False)
+    o, nbr, nbr_inv, got_shape = ops.rulebook_strided(torch.from_numpy(idx).to(device), 2, shape, (3, 3, 3), (2, 2, 2), padding)
+    assert list(got_shape) == list(oshape)
+    np.testing.assert_array_equal(o.cpu().numpy(), out_idx)  # ascending linear (b,z,y,x), bit-exact
+    np.testing.assert_array_equal(nbr.cpu().numpy(), osp.pairs_to_nbr(pairs, out_idx.shape[0]))
+    np.testing.assert_array_equal(nbr_inv.cpu().numpy(), osp.pairs_inverse_nbr(pairs, idx.shape[0]))
+
+
+# --------------------------------------------------------------------------------------- sparse conv
+@pytest.mark.parametrize("cin,cout", [(16, 16), (64, 64), (64, 128), (128, 128), (256, 128), (128, 256), (32, 20)])
+def test_spconv_forward_subm_vs_oracle(ops, device, cin, cout):
+    rng = np.random.default_rng(cin * 1000 + cout)
+    shape = (16, 48, 48)
+    idx = surface_sites(rng, 2, shape, 3000)
+    feat = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 6)).astype(np.float32)
+    _, pairs, _ = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True)
+    want = osp.indice_conv(feat, w, pairs, idx.shape[0])
+    nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), 2, shape)
+    wt = ops.spconv_transpose_weight(torch.from_numpy(w).to(device))
+    assert torch.equal(wt.cpu(), torch.from_numpy(w).permute(0, 2, 1).contiguous())
+    out = ops.spconv_forward(torch.from_numpy(feat).to(device), wt, nbr)
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    # fused epilogue: BN affine + residual + ReLU
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32))
+    shift = torch.from_numpy(rng.standard_normal(cout).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((idx.shape[0], cout)).astype(np.float32))
+    out2 = ops.spconv_forward(torch.from_numpy(feat).to(device), wt, nbr, scale=scale.to(device), shift=shift.to(device),
+                              residual=res.to(device), relu=True)
+    want2 = torch.relu(want * scale + shift + res)
+    np.testing.assert_allclose(out2.cpu().numpy(), want2.numpy(), rtol=1e-4, atol=1e-4)
+    assert torch.equal(out2, ops.spconv_forward(torch.from_numpy(feat).to(device), wt, nbr, scale=scale.to(device),
+                                                shift=shift.to(device), residual=res.to(device), relu=True))
+
+
+def test_spconv_forward_strided_and_inverse_vs_dense(ops, device):
+    rng = np.random.default_rng(9)
+    shape = (9, 24, 24)
+    idx = surface_sites(rng, 1, shape, 900)
+    cin, cout = 32, 48
+    feat = rng.standard_normal((idx.shape[0], cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / 10).astype(np.float32)
+    for padding in [(1, 1, 1), (0, 1, 1)]:
+        o, nbr, nbr_inv, oshape = ops.rulebook_strided(torch.from_numpy(idx).to(device), 1, shape, (3, 3, 3), (2, 2, 2), padding)
+        wt = ops.spconv_transpose_weight(torch.from_numpy(w.reshape(27, cin, cout)).to(device))
+        out = ops.spconv_forward(torch.from_numpy(feat).to(device), wt, nbr)
+        dense = osp.dense_conv3d_reference(feat, idx, 1, shape, w, (2, 2, 2), padding, (1, 1, 1), o.cpu().numpy())
+        np.testing.assert_allclose(out.cpu().numpy(), dense.numpy(), rtol=1e-4, atol=1e-4)
+        # inverse conv back to the fine sites with the swapped pairs
+        w2 = (rng.standard_normal((27, cout, 16)) / 10).astype(np.float32)
+        out_idx, pairs, _ = osp.build_rulebook(idx, 1, shape, (3, 3, 3), (2, 2, 2), padding, (1, 1, 1), False)
+        want_up = osp.indice_conv(out.cpu().numpy(), w2, pairs, idx.shape[0], inverse=True)
+        up = ops.spconv_forward(out, ops.spconv_transpose_weight(torch.from_numpy(w2).to(device)), nbr_inv)
+        np.testing.assert_allclose(up.cpu().numpy(), want_up.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_spconv_asymmetric_weight_detects_transposes(ops, device):
+    """A = I-like check with an asymmetric B (guide §3): one active site, identity features."""
+    idx = np.array([[0, 1, 1, 1]], dtype=np.int32)
+    cin = cout = 16
+    feat = np.eye(1, cin, 3, dtype=np.float32)  # e_3
+    w = np.zeros((27, cin, cout), dtype=np.float32)
+    w[13] = np.arange(cin * cout, dtype=np.float32).reshape(cin, cout)
+    nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), 1, (3, 3, 3))
+    out = ops.spconv_forward(torch.from_numpy(feat).to(device), ops.spconv_transpose_weight(torch.from_numpy(w).to(device)), nbr)
+    np.testing.assert_array_equal(out.cpu().numpy()[0], w[13][3])
+
+
+# ------------------------------------------------------------------------------------- in-group rank
+def test_ingroup_rank(ops, device):
+    rng = np.random.default_rng(4)
+    g = torch.from_numpy(rng.integers(0, 300, 50000))
+    r = ops.ingroup_rank(g.to(device)).cpu()
+    assert torch.equal(r, oscatter.ingroup_rank(g))
