@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(SC_THREADS) scan_reduce_kernel(In in, int64_t 
 }
 
 // One workgroup: exclusive scan of tile sums in place; total -> *total_u32 and (optionally) *total_i64.
+template <int UNUSED>
 __global__ void __launch_bounds__(1024)
     scan_tilesums_kernel(uint32_t* __restrict__ tile_sums, int64_t tiles, uint32_t* total_u32, int64_t* total_i64) {
   __shared__ uint32_t wave_tot[16];
@@ -96,7 +97,7 @@ static inline int exclusive_scan_u32(In in, Out out, int64_t n, uint32_t* tile_s
                                      int64_t* total_i64, hipStream_t stream) {
   const int64_t tiles = scan_num_tiles(n);
   hipLaunchKernelGGL((scan_reduce_kernel<In>), dim3((unsigned)tiles), dim3(SC_THREADS), 0, stream, in, n, tile_sums);
-  hipLaunchKernelGGL(scan_tilesums_kernel, dim3(1), dim3(1024), 0, stream, tile_sums, tiles, total_u32, total_i64);
+  hipLaunchKernelGGL((scan_tilesums_kernel<0>), dim3(1), dim3(1024), 0, stream, tile_sums, tiles, total_u32, total_i64);
   hipLaunchKernelGGL((scan_apply_kernel<In, Out>), dim3((unsigned)tiles), dim3(SC_THREADS), 0, stream, in, out, n,
                      tile_sums);
   FSF_LAUNCH_CHECK();

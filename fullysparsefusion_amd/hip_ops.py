@@ -33,6 +33,8 @@ _ARGTYPES = {
     "fsf_rulebook_to_pairs": [_P, c_i64, c_i32, _P, c_i64, _P, _P],
     "fsf_spconv_transpose_weight": [_P, c_i32, c_i32, c_i32, _P, _P],
     "fsf_spconv_forward": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P],
+    "fsf_connected_components_workspace_bytes": [c_i64],
+    "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
 }
@@ -350,3 +352,20 @@ def ingroup_rank(group_inds: torch.Tensor):
     ws = _lib.workspace(h.fsf_ingroup_rank_workspace_bytes(n), g.device)
     check(h.fsf_ingroup_rank(ptr(g), n, ptr(out), ptr(ws), ws.numel(), stream_ptr()), "fsf_ingroup_rank")
     return out
+
+
+# ------------------------------------------------------------------------------ connected components
+def connected_components(points: torch.Tensor, dist: float, batch_idx: Optional[torch.Tensor] = None):
+    """fsf_connected_components: labels i32 [n] (0..K-1 in order of each component's first member)."""
+    require_cuda(points, batch_idx)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.size(1) >= 2
+    points = points.contiguous()
+    n = points.size(0)
+    if batch_idx is not None:
+        batch_idx = batch_idx.to(torch.int32).contiguous()
+    labels = torch.empty((n,), dtype=torch.int32, device=points.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_connected_components_workspace_bytes(n), points.device)
+    check(h.fsf_connected_components(ptr(points), n, points.size(1), ptr(batch_idx), float(dist), ptr(labels), None,
+                                     ptr(ws), ws.numel(), stream_ptr()), "fsf_connected_components")
+    return labels

@@ -1,0 +1,123 @@
+"""`SimpleSparseUNet` (BACKBONES) — defined in the authors' mmdet3d fork [UNVENDORED]; configured at
+projects/configs/nuScenes/FSF_nuScenes_config.py:58-70 and called at
+projects/mmdet3d_plugin/models/detectors/single_stage_fsd.py:234.  Restated from the published SST module
+(SURVEY.md App. C): SubM input conv, encoder stages (stride-2 SparseConv3d + SubMConv3d), decoder levels
+(lateral SparseBasicBlock, concat, merge SubM, channel-reduce-add, SparseInverseConv3d / final SubM upsample),
+output rows in the input voxel order.  Submodule names follow upstream (`conv_input`,
+`encoder_layers.encoder_layerN`, `lateral_layerN`, `merge_layerN`, `upsample_layerN`)."""
+import torch
+import torch.nn as nn
+
+from ...ops.spconv import SparseBasicBlock, SparseConvTensor, SparseSequential, make_sparse_convmodule
+from ...registry import BACKBONES
+
+
+@BACKBONES.register_module()
+class SimpleSparseUNet(nn.Module):
+    def __init__(self, in_channels, sparse_shape, order=("conv", "norm", "act"),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), base_channels=16, output_channels=128, ndim=3,
+                 encoder_channels=((16,), (32, 32, 32), (64, 64, 64), (64, 64, 64)),
+                 encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
+                 decoder_channels=((64, 64, 64), (64, 64, 32), (32, 32, 16), (16, 16, 16)),
+                 decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1)), keep_coors_dims=None, act_type="relu",
+                 init_cfg=None):
+        super().__init__()
+        assert ndim == 3 and act_type == "relu"
+        self.sparse_shape = list(sparse_shape)
+        self.in_channels = in_channels
+        self.order = tuple(order)
+        self.base_channels = base_channels
+        self.output_channels = output_channels
+        self.encoder_channels = encoder_channels
+        self.encoder_paddings = encoder_paddings
+        self.decoder_channels = decoder_channels
+        self.decoder_paddings = decoder_paddings
+        self.stage_num = len(self.encoder_channels)
+        self.keep_coors_dims = keep_coors_dims
+        self.fp16_enabled = False
+        assert isinstance(order, (list, tuple)) and len(order) == 3 and set(order) == {"conv", "norm", "act"}
+        if self.order[0] != "conv":
+            self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                     indice_key="subm1", conv_type="SubMConv3d", order=("conv",))
+        else:
+            self.conv_input = make_sparse_convmodule(in_channels, base_channels, 3, norm_cfg=norm_cfg, padding=1,
+                                                     indice_key="subm1", conv_type="SubMConv3d", order=self.order)
+        enc_out = self.make_encoder_layers(norm_cfg, base_channels)
+        self.make_decoder_layers(norm_cfg, enc_out)
+
+    def make_encoder_layers(self, norm_cfg, in_channels):
+        self.encoder_layers = SparseSequential()
+        for i, blocks in enumerate(self.encoder_channels):
+            blocks_list = []
+            for j, out_channels in enumerate(tuple(blocks)):
+                padding = tuple(self.encoder_paddings[i])[j]
+                if i != 0 and j == 0:  # every stage but the first opens with a stride-2 sparse conv
+                    blocks_list.append(make_sparse_convmodule(in_channels, out_channels, 3, norm_cfg=norm_cfg, stride=2,
+                                                              padding=padding, indice_key=f"spconv{i + 1}",
+                                                              conv_type="SparseConv3d", order=self.order))
+                else:
+                    blocks_list.append(make_sparse_convmodule(in_channels, out_channels, 3, norm_cfg=norm_cfg,
+                                                              padding=padding, indice_key=f"subm{i + 1}",
+                                                              conv_type="SubMConv3d", order=self.order))
+                in_channels = out_channels
+            self.encoder_layers.add_module(f"encoder_layer{i + 1}", SparseSequential(*blocks_list))
+        return out_channels
+
+    def make_decoder_layers(self, norm_cfg, in_channels):
+        block_num = len(self.decoder_channels)
+        for i, block_channels in enumerate(self.decoder_channels):
+            paddings = self.decoder_paddings[i]
+            lvl = block_num - i
+            setattr(self, f"lateral_layer{lvl}",
+                    SparseBasicBlock(in_channels, block_channels[0],
+                                     conv_cfg=dict(type="SubMConv3d", indice_key=f"subm{lvl}"), norm_cfg=norm_cfg))
+            setattr(self, f"merge_layer{lvl}",
+                    make_sparse_convmodule(in_channels * 2, block_channels[1], 3, norm_cfg=norm_cfg, padding=paddings[0],
+                                           indice_key=f"subm{lvl}", conv_type="SubMConv3d", order=self.order))
+            if lvl != 1:
+                setattr(self, f"upsample_layer{lvl}",
+                        make_sparse_convmodule(in_channels, block_channels[2], 3, norm_cfg=norm_cfg,
+                                               indice_key=f"spconv{lvl}", conv_type="SparseInverseConv3d",
+                                               order=self.order))
+            else:  # the last level upsamples with a submanifold conv on the input sites
+                setattr(self, f"upsample_layer{lvl}",
+                        make_sparse_convmodule(in_channels, block_channels[2], 3, norm_cfg=norm_cfg, padding=paddings[1],
+                                               indice_key="subm1", conv_type="SubMConv3d", order=self.order))
+            in_channels = block_channels[2]
+
+    @staticmethod
+    def reduce_channel(x, out_channels):
+        features = x.features
+        n, in_channels = features.shape
+        assert in_channels % out_channels == 0 and in_channels >= out_channels
+        return x._like(features.view(n, out_channels, -1).sum(dim=2))
+
+    def decoder_layer_forward(self, x_lateral, x_bottom, lateral_layer, merge_layer, upsample_layer):
+        x = lateral_layer(x_lateral)
+        x = x._like(torch.cat((x_bottom.features, x.features), dim=1))
+        x_merge = merge_layer(x)
+        x = self.reduce_channel(x, x_merge.features.shape[1])
+        x = x._like(x_merge.features + x.features)
+        return upsample_layer(x)
+
+    def forward(self, voxel_info, batch_size=None):
+        coors = voxel_info["voxel_coors"]
+        if self.keep_coors_dims is not None:
+            coors = coors[:, self.keep_coors_dims]
+        voxel_features = voxel_info["voxel_feats"]
+        coors = coors.int()
+        if batch_size is None:
+            batch_size = voxel_info.get("batch_size")
+        if batch_size is None:
+            batch_size = int(coors[:, 0].max().item()) + 1  # upstream's host sync; callers that know B pass it
+        x = SparseConvTensor(voxel_features, coors.contiguous(), self.sparse_shape, batch_size)
+        x = self.conv_input(x)
+        encode_features = []
+        for encoder_layer in self.encoder_layers._modules.values():
+            x = encoder_layer(x)
+            encode_features.append(x)
+        x = encode_features[-1]
+        for i in range(self.stage_num, 0, -1):
+            x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f"lateral_layer{i}"),
+                                           getattr(self, f"merge_layer{i}"), getattr(self, f"upsample_layer{i}"))
+        return [{"voxel_feats": x.features}]

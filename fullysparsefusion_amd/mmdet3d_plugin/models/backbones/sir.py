@@ -1,0 +1,63 @@
+"""`SIR` (BACKBONES): a stack of SIRLayer blocks over (points, feats, group ids).
+Mirror of projects/mmdet3d_plugin/models/backbones/sir.py:13-85 — same constructor, same block wiring, same
+return triple; the single `torch.unique` of the stack (:68) is the HIP packed-key sort whose segment plan all
+2 x num_blocks segmented max reductions and gathers of the stack reuse."""
+import torch
+import torch.nn as nn
+
+from ...ops.sst_ops import unique_with_plan
+from ...registry import BACKBONES, build_voxel_encoder
+
+
+@BACKBONES.register_module()
+class SIR(nn.Module):
+    def __init__(self, num_blocks=5, in_channels=[], feat_channels=[], rel_mlp_hidden_dims=[], with_rel_mlp=True,
+                 with_distance=False, with_cluster_center=False, norm_cfg=dict(type="LN", eps=1e-3), mode="max",
+                 xyz_normalizer=[1.0, 1.0, 1.0], act="relu", dropout=0, unique_once=False):
+        super().__init__()
+        self.num_blocks = num_blocks
+        self.unique_once = unique_once
+        blocks = []
+        for i in range(num_blocks):
+            blocks.append(build_voxel_encoder(dict(
+                type="SIRLayer",
+                in_channels=in_channels[i],
+                feat_channels=feat_channels[i],
+                with_distance=with_distance,
+                with_cluster_center=with_cluster_center,
+                with_rel_mlp=with_rel_mlp,
+                rel_mlp_hidden_dims=rel_mlp_hidden_dims[i],
+                with_voxel_center=False,
+                voxel_size=[0.1, 0.1, 0.1],  # unused by SIRLayer, kept for interface parity (sir.py:48-49)
+                point_cloud_range=[-74.88, -74.88, -2, 74.88, 74.88, 4],
+                norm_cfg=norm_cfg,
+                mode=mode,
+                fusion_layer=None,
+                return_point_feats=i != num_blocks - 1,
+                return_inv=False,
+                rel_dist_scaler=10.0,
+                xyz_normalizer=xyz_normalizer,
+                act=act,
+                dropout=dropout,
+            )))
+        self.block_list = nn.ModuleList(blocks)
+
+    def forward(self, points, features, coors, f_cluster=None):
+        if self.unique_once:
+            new_coors, unq_inv, _ = unique_with_plan(coors)
+        else:
+            new_coors = unq_inv = None
+        out_feats = features
+        cluster_feat_list = []
+        out_coors = None
+        for i, block in enumerate(self.block_list):
+            in_feats = torch.cat([points, out_feats], 1)
+            if i < self.num_blocks - 1:
+                out_feats, out_cluster_feats = block(in_feats, coors, f_cluster, unq_inv_once=unq_inv,
+                                                     new_coors_once=new_coors)
+            else:
+                out_feats, out_cluster_feats, out_coors = block(in_feats, coors, f_cluster, return_both=True,
+                                                                unq_inv_once=unq_inv, new_coors_once=new_coors)
+            cluster_feat_list.append(out_cluster_feats)
+        final_cluster_feats = torch.cat(cluster_feat_list, dim=1)
+        return out_feats, final_cluster_feats, out_coors

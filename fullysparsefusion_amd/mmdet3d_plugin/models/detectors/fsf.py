@@ -1,0 +1,348 @@
+"""`FSF` (DETECTORS): inference hot path of projects/mmdet3d_plugin/models/detectors/FSF.py —
+prj_points_2d :169-200, points_in_mask :202-226, frustum_gather :228-258, double_overlap_pts :260-297,
+extract_fg_pts :299-308, get_cluster_delta_weighted :313-329, get_point_fg_weights :346-355,
+get_sir_coors :357-365, frustum_pooling :384-447, encode_preds_2d :449-474, get_single_cls_preds_2d :476-504,
+get_all_cls_preds_2d :506-535, encode_2d_feats :537-552, split_points_last_3dim :554-560,
+combine_by_batch :562-567, fsd_forward :569-605, frustum_forward :607-655, img_cross_attn :694-728,
+segmentor_feat_inhance_test :772-804, simple_test :1114-1178.
+
+Same method names and return conventions.  What changes underneath:
+  * projection + `mask_data.float()` + 6 x grid_sample + cat/permute is ONE kernel reading the u8/i32 mask directly
+    (the reference converts the 86 MB mask to 346 MB of fp32 three times per forward);
+  * the per-point image branch never materialises `[n, 10, 9]` predictions: camera select + id -> score lookup is
+    one kernel (nuScenes branch; the Argoverse branch keeps the generic torch path);
+  * the same frustum gather requested twice for the same points inside one forward (:626 after :709) is computed once;
+  * every torch.unique / torch_scatter call goes through the sort-once segment plans of the HIP library;
+  * clustering runs on the device (no scipy round trip).
+Heads, box decoding, NMS and the refine stage are outside this round: `simple_test` runs the
+three query-generation stages and returns their features via `forward_hot_path`.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import hip_ops
+from ...ops.sst_ops import build_mlp, gather_by_inverse, scatter_v2
+from ...registry import DETECTORS, build_head
+from .single_stage_fsd import SingleStageFSD
+
+
+@DETECTORS.register_module()
+class FSF(SingleStageFSD):
+    def __init__(self, backbone, segmentor, voxel_layer=None, voxel_encoder=None, middle_encoder=None, neck=None,
+                 frustum_obj_head=None, frustum_sir=None, bbox_head=None, roi_head=None, train_cfg=None, test_cfg=None,
+                 cluster_assigner=None, pretrained=None, tanh_dims=3, init_cfg=None,
+                 encode_2d_mlp_cfg=dict(in_channel=16, mlp_channel=[128, 128], norm_cfg=dict(type="LN", eps=1e-3), act="gelu"),
+                 refine_encode_2d_mlp_cfg=None, num_classes=10, num_cams=6, vis_dir=None, encode_label_only=False,
+                 class_names=None, min_pts=5, bbox_coder=None, roi_extractor=None, single_refine_sir_layer=None,
+                 mlp_cfg=dict(embed_dims=256, norm_cfg=dict(type="LN", eps=1e-3), act="gelu",
+                              lidar_img_input_dim=128 * 3 * 2 + 128),
+                 fsd_begin_idx=1000, refined_obj_head=None,
+                 segmentor_updated_mlp=dict(in_channel=10, mlp_channel=[128, 67 + 64], norm_cfg=dict(type="LN", eps=1e-3),
+                                            act="gelu"),
+                 tta_test_cfg={}, use_frustum=True, use_fsd=True, voxel_downsampling_size=None, is_argo=False):
+        super().__init__(backbone=backbone, segmentor=segmentor, voxel_layer=voxel_layer, voxel_encoder=voxel_encoder,
+                         middle_encoder=middle_encoder, neck=neck, bbox_head=bbox_head, train_cfg=train_cfg,
+                         test_cfg=test_cfg, cluster_assigner=cluster_assigner, pretrained=pretrained, init_cfg=init_cfg)
+        self.runtime_info = dict()
+        self.tanh_dims = tanh_dims
+        self.num_classes = num_classes
+        self.num_cams = num_cams
+        self.vis_dir = vis_dir
+        self.encode_label_only = encode_label_only
+        self.class_names = class_names
+        self.min_pts = min_pts
+        self.mlp_cfg = mlp_cfg
+        self.embed_dims = mlp_cfg.get("embed_dims", 256)
+        self.norm_cfg = mlp_cfg.get("norm_cfg", dict(type="LN", eps=1e-3))
+        self.act = mlp_cfg.get("act", "gelu")
+        self.lidar_img_input_dim = mlp_cfg.get("lidar_img_input_dim", 128 * 3 * 2 + 128)
+        self.lidar_input_dim = mlp_cfg.get("lidar_input_dim", 128 * 3 * 2)
+        self.use_fsd, self.use_frustum = use_fsd, use_frustum
+        self.frustum_obj_head = build_head(frustum_obj_head)
+        self.frustum_sir = build_head(frustum_sir)
+        self.combine_frustum_feat_mlp = build_mlp(self.lidar_img_input_dim, [self.embed_dims], self.norm_cfg, act=self.act)
+        self.encode_2d_mlp_cfg = encode_2d_mlp_cfg
+        self.encode_2d_mlp = build_mlp(encode_2d_mlp_cfg["in_channel"], encode_2d_mlp_cfg["mlp_channel"],
+                                       encode_2d_mlp_cfg["norm_cfg"], is_head=False, act=encode_2d_mlp_cfg["act"])
+        self.combine_fsd_feat_mlp = build_mlp(self.lidar_input_dim, [self.embed_dims], self.norm_cfg, act=self.act)
+        self.segmentor_updated_mlp = build_mlp(segmentor_updated_mlp["in_channel"], segmentor_updated_mlp["mlp_channel"],
+                                               segmentor_updated_mlp["norm_cfg"], is_head=True,
+                                               act=segmentor_updated_mlp["act"])
+        nn.init.constant_(self.segmentor_updated_mlp[-1].weight, 0.0)  # FSF.py:142-143
+        nn.init.constant_(self.segmentor_updated_mlp[-1].bias, 0.0)
+        self.fsd_begin_idx = fsd_begin_idx
+        self.refined_obj_head_cfg = refined_obj_head
+        self.num_extra_stages = len(refined_obj_head) if refined_obj_head is not None else 0
+        self.refine_cfgs = dict(bbox_coder=bbox_coder, roi_extractor=roi_extractor,
+                                single_refine_sir_layer=single_refine_sir_layer,
+                                refine_encode_2d_mlp_cfg=refine_encode_2d_mlp_cfg)
+        self.tta_test_cfg = tta_test_cfg
+        self.voxel_downsampling_size = voxel_downsampling_size
+        self.is_argo = is_argo
+        self._gather_cache = None
+
+    # ----------------------------------------------------------------------------------- projection
+    def prj_points_2d(self, points, lidar2img, img_h, img_w):
+        """points [N,3], lidar2img [ncam,4,4] -> pts_2d [ncam,N,2] (normalised, -2 = invalid)."""
+        dummy = torch.zeros((lidar2img.size(0), 1, img_h, img_w), dtype=torch.uint8, device=points.device)
+        _, pts_2d = hip_ops.project_gather_mask(points, lidar2img, dummy, return_pts_2d=True)
+        return pts_2d
+
+    def points_in_mask(self, points, mask_data, lidar2img):
+        """One sample: mask_data [ncam,ncls,H,W] (u8 / i32) -> obj id of every point [N,ncam,ncls]."""
+        if mask_data.dtype not in (torch.uint8, torch.int32):
+            mask_data = mask_data.to(torch.int32)
+        return hip_ops.project_gather_mask(points, lidar2img, mask_data)
+
+    def frustum_gather(self, batch_idx, points, mask_data, mask_anno, img_metas):
+        key = (batch_idx.data_ptr(), points.data_ptr(), mask_data.data_ptr(), points.size(0), points._version)
+        if self._gather_cache is not None and self._gather_cache[0] == key:
+            return self._gather_cache[1]
+        device = batch_idx.device
+        bz, num_cams, num_classes = mask_data.shape[0:3]
+        if bz == 1:
+            lidar2img = torch.as_tensor(img_metas[0]["lidar2img"], dtype=torch.float32, device=device)
+            obj_id_tensor = self.points_in_mask(points[:, :3], mask_data[0], lidar2img)
+        else:
+            obj_id_tensor = batch_idx.new_zeros((batch_idx.shape[0], num_cams, num_classes))
+            for bidx in range(bz):
+                bz_mask = batch_idx == bidx
+                lidar2img = torch.as_tensor(img_metas[bidx]["lidar2img"], dtype=torch.float32, device=device)
+                obj_id_tensor[bz_mask] = self.points_in_mask(points[bz_mask][:, :3].contiguous(), mask_data[bidx], lidar2img)
+        self._gather_cache = (key, obj_id_tensor)
+        return obj_id_tensor
+
+    # ----------------------------------------------------------------------------- frustum grouping
+    def double_overlap_pts(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights):
+        """A point inside k > 1 masks is duplicated k - 1 times (appended), ids taken in topk order (:260-297)."""
+        obj_id_tensor = obj_id_tensor.reshape(obj_id_tensor.shape[0], -1)
+        overlaps_tensor = (obj_id_tensor > 0).sum(-1)
+        max_overlap_num = int(overlaps_tensor.max()) + 1
+        src_feat, src_bz, src_pts, src_w = pts_feat, bz_coor, points, point_fg_weights
+        raw_obj_id_tensor = obj_id_tensor.max(-1)[0]
+        feats, bzs, pts, ws, ids = [pts_feat], [bz_coor], [points], [point_fg_weights], [raw_obj_id_tensor]
+        for overlap_num in range(2, max_overlap_num):
+            overlaps_mask = overlaps_tensor == overlap_num
+            if not overlaps_mask.any():
+                continue
+            feats.append(src_feat[overlaps_mask].repeat(overlap_num - 1, 1))
+            bzs.append(src_bz[overlaps_mask].repeat(overlap_num - 1, 1))
+            pts.append(src_pts[overlaps_mask].repeat(overlap_num - 1, 1))
+            ws.append(src_w[overlaps_mask].repeat(overlap_num - 1))
+            sort_value = obj_id_tensor[overlaps_mask].topk(overlap_num, dim=-1)[0]
+            for pad_idx in range(1, overlap_num):
+                ids.append(sort_value[:, pad_idx])
+        return torch.cat(feats, 0), torch.cat(bzs, 0), torch.cat(pts, 0), torch.cat(ids, 0), torch.cat(ws, 0)
+
+    def extract_fg_pts(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights):
+        fg_mask = obj_id_tensor.sum((-2, -1)) > 0
+        return pts_feat[fg_mask], bz_coor[fg_mask], points[fg_mask], obj_id_tensor[fg_mask], point_fg_weights[fg_mask]
+
+    def map_voxel_center_to_point(self, voxel_mean, voxel2point_inds):
+        return gather_by_inverse(voxel_mean, voxel2point_inds)
+
+    def get_cluster_delta_weighted(self, points, sir_coors, point_weights):
+        point_weights = point_weights.clamp(min=1e-5).detach()
+        input_feat = torch.cat([points[:, :3] * point_weights, point_weights], dim=-1)
+        voxel_mean_feat, voxel_mean_coors, unq_inv = scatter_v2(input_feat, sir_coors, mode="avg")
+        voxel_center = voxel_mean_feat[:, :3] / voxel_mean_feat[:, 3:4]
+        points_center = self.map_voxel_center_to_point(voxel_center, unq_inv)
+        f_cluster = points[:, :3] - points_center[:, :3]
+        return f_cluster, voxel_center, voxel_mean_coors
+
+    def get_cluster_delta_from_center(self, points, sir_coors, cluster_center):
+        _, _, unq_inv = scatter_v2(points, sir_coors, mode="avg")
+        points_center = self.map_voxel_center_to_point(cluster_center, unq_inv)
+        return points[:, :3] - points_center[:, :3]
+
+    def get_point_fg_weights(self, seg_logits):
+        return 1 - seg_logits.softmax(1)[:, -1]
+
+    def get_sir_coors(self, bz_coor, obj_id_tensor, point_fg_weights):
+        sir_coors = torch.cat([bz_coor, torch.zeros_like(bz_coor), obj_id_tensor.unsqueeze(-1)], dim=-1)
+        return sir_coors, obj_id_tensor
+
+    def frustum_pooling(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights, img_metas=None,
+                        cluster_center=None):
+        pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights = self.extract_fg_pts(
+            pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights)
+        if obj_id_tensor.numel() == 0 or obj_id_tensor.sum() == 0:
+            fake_num = 1  # fake an object when the frustum branch has no output (:407-414)
+            points = points.new_zeros(fake_num, points.shape[-1])
+            pts_feat = pts_feat.new_zeros(fake_num, pts_feat.shape[-1])
+            sir_coors = bz_coor.new_zeros(fake_num, 3)
+            points_delta = points.new_zeros(fake_num, 3)
+            cluster_center = points.new_zeros(fake_num, 3)
+        else:
+            pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights = self.double_overlap_pts(
+                pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights)
+            sir_coors, obj_id_tensor = self.get_sir_coors(bz_coor, obj_id_tensor, point_fg_weights)
+            if cluster_center is None:
+                points_delta, cluster_center, _ = self.get_cluster_delta_weighted(points, sir_coors,
+                                                                                  point_fg_weights.unsqueeze(-1))
+            else:
+                points_delta = self.get_cluster_delta_from_center(points, sir_coors, cluster_center)
+        out_feats, final_cluster_feats, out_coors = self.frustum_sir(points, pts_feat, sir_coors, f_cluster=points_delta)
+        if out_coors.shape[0] == 0:
+            out_coors = out_coors.new_zeros((0, 3))
+        return final_cluster_feats, out_coors, cluster_center
+
+    # ---------------------------------------------------------------------------- 2-D prediction encoding
+    def encode_preds_2d(self, preds_2d, img_w, img_h, encode_single_cls=True):
+        bbox_2d, score, category, cam_id = preds_2d[:, :4], preds_2d[:, 4:5], preds_2d[:, 5], preds_2d[:, 6]
+        en_bbox_2d = bbox_2d.clone()
+        en_bbox_2d[:, 0::2] /= img_w
+        en_bbox_2d[:, 1::2] /= img_h
+        en_category = F.one_hot(category.long(), num_classes=self.num_classes + 1)
+        if self.encode_label_only:
+            return en_category.float()
+        if encode_single_cls:
+            return torch.cat([en_bbox_2d, score, en_category.float()], dim=-1)
+        return score  # per-point branch on nuScenes: the ten class scores only
+
+    def _anno_lookup(self, mask_anno, batch_tensor, obj_id_tensor, fill_category):
+        """Rows of mask_anno[b][id - 1]; id <= 0 -> zeros with category = fill_category."""
+        valid = obj_id_tensor > 0
+        safe = (obj_id_tensor - 1).clamp(min=0)
+        b = batch_tensor.view(-1, *([1] * (obj_id_tensor.dim() - 1))).expand_as(obj_id_tensor)
+        out = mask_anno[b, safe] * valid.unsqueeze(-1)
+        out[..., 5] = torch.where(valid, out[..., 5], out.new_full((), float(fill_category)))
+        return out
+
+    def get_single_cls_preds_2d(self, mask_anno, obj_coors):
+        return self._anno_lookup(mask_anno.float(), obj_coors[:, 0], obj_coors[:, 2], self.num_classes)
+
+    def get_all_cls_preds_2d(self, mask_anno, batch_tensor, obj_id_tensor):
+        return self._anno_lookup(mask_anno.float(), batch_tensor, obj_id_tensor, obj_id_tensor.shape[-1])
+
+    def encode_2d_feats(self, preds_2d, img_w, img_h, encode_mlp):
+        if preds_2d.dim() == 3:
+            num_objs, num_classes, num_mask_annos = preds_2d.shape
+            encoded_2d = self.encode_preds_2d(preds_2d.reshape(-1, num_mask_annos), img_w, img_h,
+                                              encode_single_cls=self.is_argo)
+            if not self.is_argo:
+                encoded_2d = encoded_2d.reshape(num_objs, num_classes)
+        else:
+            encoded_2d = self.encode_preds_2d(preds_2d, img_w, img_h)
+        return encode_mlp(encoded_2d)
+
+    def split_points_last_3dim(self, points):
+        return [p[:, :-3] for p in points], [p[:, -3:] for p in points]
+
+    def combine_by_batch(self, data_list, batch_idx, batch_size):
+        if batch_size == 1 and data_list[0].shape[0] == batch_idx.shape[0]:
+            return data_list[0]  # one sample: rows already in order (the bench / inference case)
+        flat = data_list[0].new_zeros((batch_idx.shape[0], data_list[0].shape[-1]))
+        for bidx in range(batch_size):
+            flat[batch_idx == bidx] = data_list[bidx]
+        return flat
+
+    # ----------------------------------------------------------------------------------- stages
+    def img_cross_attn(self, point_infos, batch_idx, mask_anno, mask_data, img_metas, encode_mlp, ext_pts_inds=None):
+        batch_size = mask_anno.shape[0]
+        points_info_flat = self.combine_by_batch(point_infos, batch_idx, batch_size)
+        if ext_pts_inds is not None:
+            points_info_flat = points_info_flat[ext_pts_inds]
+            batch_idx = batch_idx[ext_pts_inds]
+        obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
+        _, num_cams, num_classes = obj_id_tensor.shape
+        if not self.is_argo and not self.encode_label_only and batch_size == 1:
+            # fused: argmax-camera select + id -> score lookup (FSF.py:716-719, :506-535, :472-473)
+            score = hip_ops.cam_select_score(obj_id_tensor, mask_anno[0], score_col=4)
+            return encode_mlp(score)
+        cam_select_value = obj_id_tensor.sum(-1).max(-1)[1]
+        cam_select_mask = F.one_hot(cam_select_value, num_cams).bool().unsqueeze(-1)
+        points_obj_id_multi_cls = obj_id_tensor.masked_select(cam_select_mask).reshape(-1, num_classes)
+        preds_2d = self.get_all_cls_preds_2d(mask_anno, batch_idx, points_obj_id_multi_cls)
+        return self.encode_2d_feats(preds_2d, img_w=mask_data.shape[-1], img_h=mask_data.shape[-2], encode_mlp=encode_mlp)
+
+    def segmentor_feat_inhance_test(self, seg_out_tuple, point_infos, mask_anno, mask_data, img_metas):
+        (neck_out, pts_coors, points) = seg_out_tuple
+        pts_lidar_feats, valid_pts_mask = neck_out[0], neck_out[1]
+        if not bool(valid_pts_mask.all()):
+            # padded (dropped) voxels only exist on the SST path; keep the reference's compaction when they do
+            points, pts_coors = points[valid_pts_mask], pts_coors[valid_pts_mask]
+            point_infos_valid = None
+        batch_idx = pts_coors[:, 0]
+        pts_updated_feats = self.img_cross_attn(point_infos, batch_idx, mask_anno, mask_data, img_metas,
+                                                encode_mlp=self.segmentor_updated_mlp)
+        pts_feats = pts_lidar_feats + pts_updated_feats
+        seg_logits, vote_preds = self.segmentor.segmentation_head.forward_test(pts_feats, img_metas, self.segmentor.test_cfg)
+        offsets = self.segmentor.segmentation_head.decode_vote_targets(vote_preds)
+        return dict(seg_points=points, seg_logits=seg_logits, seg_vote_preds=vote_preds, offsets=offsets,
+                    seg_feats=pts_feats, batch_idx=pts_coors[:, 0])
+
+    def frustum_forward(self, seg_out_dict, mask_anno, mask_data, point_infos, img_metas, cluster_center=None,
+                        run_head=True):
+        pts_feat, batch_idx = seg_out_dict["seg_feats"], seg_out_dict["batch_idx"]
+        points, seg_logits = seg_out_dict["seg_points"], seg_out_dict["seg_logits"]
+        point_fg_weights = self.get_point_fg_weights(seg_logits)
+        batch_size = mask_anno.shape[0]
+        points_info_flat = self.combine_by_batch(point_infos, batch_idx, batch_size)
+        obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
+        lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, obj_id_tensor,
+                                                                  point_fg_weights, img_metas, cluster_center)
+        preds_2d = self.get_single_cls_preds_2d(mask_anno, obj_coors)
+        img_feat = self.encode_2d_feats(preds_2d, img_w=mask_data.shape[-1], img_h=mask_data.shape[-2],
+                                        encode_mlp=self.encode_2d_mlp)
+        obj_feat = torch.cat([lidar_feat, img_feat], dim=-1)
+        frustum_obj_result = self.frustum_obj_head(obj_feat) if run_head else None
+        return obj_feat, obj_centers, obj_coors, frustum_obj_result, preds_2d
+
+    def fsd_forward(self, seg_out_dict, img_metas, run_head=True):
+        dict_to_sample = dict(
+            seg_points=seg_out_dict["seg_points"],
+            seg_logits=seg_out_dict["seg_logits"].detach(),
+            seg_vote_preds=seg_out_dict["seg_vote_preds"].detach(),
+            seg_feats=seg_out_dict["seg_feats"],
+            batch_idx=seg_out_dict["batch_idx"],
+            vote_offsets=seg_out_dict["offsets"].detach(),
+        )
+        if self.cfg.get("pre_voxelization_size", None) is not None:
+            dict_to_sample = self.pre_voxelize(dict_to_sample)
+        sampled_out = self.sample(dict_to_sample, dict_to_sample["vote_offsets"])
+        cluster_inds_list, valid_mask_list = self.cluster_assigner(sampled_out["center_preds"], sampled_out["batch_idx"],
+                                                                   origin_points=sampled_out["seg_points"])
+        pts_cluster_inds = torch.cat(cluster_inds_list, dim=0)  # [N, 3] (cls_id, batch_idx, cluster_id)
+        sampled_out = self.update_sample_results_by_mask(sampled_out, valid_mask_list)
+        combined_out = self.combine_classes(sampled_out, ["seg_points", "seg_logits", "seg_vote_preds", "seg_feats",
+                                                          "center_preds"])
+        points = combined_out["seg_points"]
+        pts_feats = torch.cat([combined_out["seg_logits"], combined_out["seg_vote_preds"], combined_out["seg_feats"]], dim=1)
+        assert len(pts_cluster_inds) == len(points) == len(pts_feats)
+        extracted_outs = self.extract_feat(points, pts_feats, pts_cluster_inds, img_metas, combined_out["center_preds"])
+        cluster_feats, cluster_xyz = extracted_outs["cluster_feats"], extracted_outs["cluster_xyz"]
+        cluster_inds = extracted_outs["cluster_inds"]  # [class, batch, groups]
+        outs = self.bbox_head(cluster_feats) if run_head else None
+        return cluster_feats, cluster_xyz, cluster_inds, outs
+
+    def forward_hot_path(self, points, img_metas, mask_data, mask_anno):
+        """Stages 1-3 of simple_test (:1114-1144): segmentation + image fusion, camera queries, LiDAR queries —
+        everything on the north-star hot path; returns the query features the heads consume."""
+        self._gather_cache = None
+        if self.voxel_downsampling_size is not None:
+            points = self.segmentor.voxel_downsample(points)
+        points, point_infos = self.split_points_last_3dim(points)
+        seg_out_tuple = self.segmentor.simple_test(points, img_metas, extract_feat_only=True, rescale=False)
+        seg_out_dict = self.segmentor_feat_inhance_test(seg_out_tuple, point_infos, mask_anno, mask_data, img_metas)
+        f_feats, f_centers, f_coors, _, f_preds_2d = self.frustum_forward(seg_out_dict, mask_anno, mask_data, point_infos,
+                                                                           img_metas, cluster_center=None, run_head=False)
+        l_feats, l_centers, l_coors, _ = self.fsd_forward(seg_out_dict, img_metas, run_head=False)
+        self._gather_cache = None
+        return dict(seg=seg_out_dict, frustum_obj_feats=f_feats, frustum_obj_centers=f_centers, frustum_obj_coors=f_coors,
+                    frustum_preds_2d=f_preds_2d, fsd_obj_feats=l_feats, fsd_obj_centers=l_centers, fsd_obj_coors=l_coors)
+
+    def simple_test(self, points, img_metas, mask_data, mask_anno, **kwargs):
+        out = self.forward_hot_path(points, img_metas, mask_data, mask_anno)
+        if kwargs.get("hot_path_only", True):
+            return out
+        raise NotImplementedError("query refinement, box decoding and NMS (FSF.py:1146-1178) are outside this round")
+
+    def forward_test(self, points, img_metas, mask_data, mask_anno, **kwargs):
+        if len(points) != 1:
+            raise NotImplementedError("test-time augmentation is outside the hot path")
+        return self.simple_test(points[0], img_metas[0], mask_data[0], mask_anno[0], **kwargs)
+
+    def forward_train(self, *args, **kwargs):
+        raise NotImplementedError("training path (targets, assigners, losses) is outside this round's hot path")

@@ -1,0 +1,314 @@
+"""`VoteSegmentor`, `SingleStageFSD`, `ClusterAssigner`: inference path of
+projects/mmdet3d_plugin/models/detectors/single_stage_fsd.py (voxelize :206-226, extract_feat :228-245,
+voxel_downsample :263-273, simple_test :342-378; SingleStageFSD.extract_feat :458-474, pre_voxelize :585-605,
+group_sample :802-865, get_fg_mask :742-784, ClusterAssigner :903-982).
+
+Same class / method names and argument meaning; torch.unique / torch_scatter / Voxelization / scipy CCL calls go
+to the HIP library.  Training-only branches (targets, losses, SSG/Hybrid assigners) are outside this round.
+"""
+import torch
+from torch import nn
+
+from .... import hip_ops
+from ...ops.sst_ops import gather_by_inverse, get_inner_win_inds, scatter_v2, unique_with_plan
+from ...ops.voxel import Voxelization
+from ...registry import (DETECTORS, SEGMENTORS, build_backbone, build_detector, build_head, build_middle_encoder,
+                         build_neck, build_voxel_encoder)
+
+
+def filter_almost_empty(coors, min_points):
+    """single_stage_fsd.py:31-35."""
+    new_coors, unq_inv, unq_cnt = unique_with_plan(coors)
+    return unq_cnt[unq_inv] >= min_points
+
+
+def find_connected_componets(points, batch_idx, dist):
+    """single_stage_fsd.py:45-67 (per-sample components, ids offset sample by sample) without the host
+    round trip: one device union-find over all samples with the batch index as an extra adjacency condition,
+    then relabel in (sample, first-member) order."""
+    assert len(points) > 0
+    labels = hip_ops.connected_components(points, dist, batch_idx=batch_idx)
+    # device labels are numbered by first member overall; the reference numbers sample 0's components first
+    key = torch.stack([batch_idx.long(), labels.long()], 1)
+    _, inv, _ = unique_with_plan(key)
+    return inv.int()
+
+
+def find_connected_componets_single_batch(points, batch_idx, dist):
+    """single_stage_fsd.py:69-82: the batch index is ignored (test-time, one sample)."""
+    return hip_ops.connected_components(points, dist)
+
+
+def modify_cluster_by_class(cluster_inds_list):
+    """single_stage_fsd.py:139-152: prepend the class id to every (batch, cluster) pair."""
+    new_list = []
+    for i, inds in enumerate(cluster_inds_list):
+        cls_pad = inds.new_ones((len(inds),)) * i
+        new_list.append(torch.cat([cls_pad[:, None], inds], 1))
+    return new_list
+
+
+@SEGMENTORS.register_module()
+@DETECTORS.register_module()
+class VoteSegmentor(nn.Module):
+    def __init__(self, voxel_layer, voxel_encoder, middle_encoder, backbone, segmentation_head, decode_neck=None,
+                 auxiliary_head=None, voxel_downsampling_size=None, train_cfg=None, test_cfg=None, init_cfg=None,
+                 pretrained=None, tanh_dims=[], **extra_kwargs):
+        super().__init__()
+        self.voxel_layer = Voxelization(**voxel_layer)
+        self.voxel_encoder = build_voxel_encoder(voxel_encoder)
+        self.middle_encoder = build_middle_encoder(middle_encoder)
+        self.backbone = build_backbone(backbone)
+        self.segmentation_head = build_head(segmentation_head)
+        self.segmentation_head.train_cfg = train_cfg
+        self.segmentation_head.test_cfg = test_cfg
+        self.decode_neck = build_neck(decode_neck)
+        assert voxel_encoder["type"] == "DynamicScatterVFE"
+        self.print_info = {}
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.cfg = train_cfg if train_cfg is not None else test_cfg
+        self.num_classes = segmentation_head["num_classes"]
+        self.save_list = []
+        self.point_cloud_range = voxel_layer["point_cloud_range"]
+        self.voxel_size = voxel_layer["voxel_size"]
+        self.voxel_downsampling_size = voxel_downsampling_size
+        self.tanh_dims = tanh_dims
+
+    @torch.no_grad()
+    def voxelize(self, points):
+        """list of [N_b, C] -> (points [N, C], coors i64 [N, 4] (b,z,y,x)); one fused kernel per sample."""
+        return self.voxel_layer.forward_batch(points)
+
+    def extract_feat(self, points, img_metas):
+        batch_points, coors = self.voxelize(points)
+        self.voxel_encoder.max_batch = len(points)
+        voxel_features, voxel_coors, voxel2point_inds = self.voxel_encoder(batch_points, coors, return_inv=True)
+        voxel_info = self.middle_encoder(voxel_features, voxel_coors, batch_size=len(points))
+        x = self.backbone(voxel_info)[0]
+        padding = -1
+        assert "shuffle_inds" not in voxel_info  # SST-only branch (:238-241)
+        voxel_feats_reorder = x["voxel_feats"]
+        out = self.decode_neck(batch_points, coors, voxel_feats_reorder, voxel2point_inds, padding)
+        return out, coors, batch_points
+
+    def voxel_downsample(self, points_list):
+        out_points_list = []
+        for points in points_list:
+            coors = hip_ops.voxelize_divfloor(points, self.voxel_downsampling_size, self.point_cloud_range[:3], order="xyz")
+            out_points, _ = scatter_v2(points, coors, mode="avg", return_inv=False)
+            out_points_list.append(out_points)
+        return out_points_list
+
+    def _prep(self, points):
+        if self.tanh_dims == []:
+            return [p.contiguous() for p in points]
+        if self.tanh_dims is not None:
+            for p in points:
+                p[:, self.tanh_dims] = torch.tanh(p[:, self.tanh_dims])
+            return [p.contiguous() for p in points]
+        if points[0].size(1) in (4, 5):
+            return [torch.cat([p[:, :3], torch.tanh(p[:, 3:])], dim=1) for p in points]
+        return points
+
+    def simple_test(self, points, img_metas, gt_bboxes_3d=None, gt_labels_3d=None, extract_feat_only=False,
+                    rescale=False):
+        points = self._prep(points)
+        x, pts_coors, points = self.extract_feat(points, img_metas)
+        if extract_feat_only:
+            return x, pts_coors, points
+        feats, valid_pts_mask = x[0], x[1]
+        points = points[valid_pts_mask]
+        pts_coors = pts_coors[valid_pts_mask]
+        seg_logits, vote_preds = self.segmentation_head.forward_test(feats, img_metas, self.test_cfg)
+        offsets = self.segmentation_head.decode_vote_targets(vote_preds)
+        return dict(seg_points=points, seg_logits=seg_logits, seg_vote_preds=vote_preds, offsets=offsets,
+                    seg_feats=feats, batch_idx=pts_coors[:, 0])
+
+    def forward_train(self, *args, **kwargs):
+        raise NotImplementedError("training path (targets + losses) is outside this round's hot path")
+
+
+@DETECTORS.register_module()
+class SingleStageFSD(nn.Module):
+    def __init__(self, backbone, segmentor, voxel_layer=None, voxel_encoder=None, middle_encoder=None, neck=None,
+                 bbox_head=None, train_cfg=None, test_cfg=None, cluster_assigner=None, pretrained=None, init_cfg=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck) if neck is not None else None
+        if bbox_head is not None:
+            bbox_head = dict(bbox_head)
+            # mmdet3d SingleStage3DDetector injects the model-level cfgs into the head
+            bbox_head.update(train_cfg=train_cfg)
+            bbox_head.update(test_cfg=test_cfg)
+            self.bbox_head = build_head(bbox_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        if voxel_layer is not None:
+            self.voxel_layer = Voxelization(**voxel_layer)
+        if voxel_encoder is not None:
+            self.voxel_encoder = build_voxel_encoder(voxel_encoder)
+        if middle_encoder is not None:
+            self.middle_encoder = build_middle_encoder(middle_encoder)
+        self.segmentor = build_detector(segmentor)
+        self.head_type = bbox_head["type"]
+        self.num_classes = bbox_head["num_classes"]
+        self.cfg = self.train_cfg if self.train_cfg else self.test_cfg
+        cluster_assigner = dict(cluster_assigner)
+        if "radius" in cluster_assigner or "hybrid" in cluster_assigner:
+            raise NotImplementedError("SSGAssigner / HybridAssigner are not configured by the FSF configs")
+        self.cluster_assigner = ClusterAssigner(**cluster_assigner)
+        self.cluster_assigner.num_classes = self.num_classes
+        self.print_info = {}
+        self.as_rpn = bbox_head.get("as_rpn", False)
+        self.runtime_info = dict() if self.cfg.get("disable_pretrain", False) else None
+
+    def extract_feat(self, points, pts_feats, pts_cluster_inds, img_metas, center_preds):
+        """:458-474 — cluster centroid of the vote centres, per-point offset to it, then the SIR backbone."""
+        cluster_xyz, _, inv_inds = scatter_v2(center_preds, pts_cluster_inds, mode="avg", return_inv=True)
+        f_cluster = points[:, :3] - gather_by_inverse(cluster_xyz, inv_inds)
+        out_pts_feats, cluster_feats, out_coors = self.backbone(points, pts_feats, pts_cluster_inds, f_cluster)
+        out_dict = dict(cluster_feats=cluster_feats, cluster_xyz=cluster_xyz, cluster_inds=out_coors)
+        if self.as_rpn:
+            out_dict["cluster_pts_feats"] = out_pts_feats
+            out_dict["cluster_pts_xyz"] = points
+        return out_dict
+
+    def update_sample_results_by_mask(self, sampled_out, valid_mask_list):
+        for k in sampled_out:
+            old_data = sampled_out[k]
+            if len(old_data[0]) == len(valid_mask_list[0]) or "fg_mask" in k:
+                if "fg_mask" in k:
+                    new_data_list = []
+                    for data, mask in zip(old_data, valid_mask_list):
+                        new_data = data.clone()
+                        new_data[data] = mask
+                        assert new_data.sum() == mask.sum()
+                        new_data_list.append(new_data)
+                    sampled_out[k] = new_data_list
+                else:
+                    sampled_out[k] = [data[mask] for data, mask in zip(old_data, valid_mask_list)]
+        return sampled_out
+
+    def combine_classes(self, data_dict, name_list):
+        return {name: torch.cat(data_dict[name], 0) for name in data_dict if name in name_list}
+
+    def pre_voxelize(self, data_dict):
+        """:585-605 — torch.div-floor 0.1 m keys (zyx + batch), ONE unique, mean of every float field."""
+        batch_idx = data_dict["batch_idx"]
+        points = data_dict["seg_points"]
+        coors = hip_ops.voxelize_divfloor(points, self.cfg["pre_voxelization_size"],
+                                          self.cluster_assigner.point_cloud_range[:3], order="zyx", batch_idx=batch_idx)
+        new_coors, unq_inv, _ = unique_with_plan(coors)
+        voxelized = {}
+        voxel_coors = new_coors
+        for name, data in data_dict.items():
+            if data.dtype in (torch.float, torch.float16):
+                voxelized[name], voxel_coors = scatter_v2(data, coors, mode="avg", return_inv=False, new_coors=new_coors,
+                                                          unq_inv=unq_inv)
+        voxelized["batch_idx"] = voxel_coors[:, 0]
+        return voxelized
+
+    def get_sample_beg_position(self, batch_idx, fg_mask):
+        assert batch_idx.shape == fg_mask.shape
+        inner_inds = get_inner_win_inds(batch_idx.contiguous())
+        return torch.where(inner_inds == 0)[0]
+
+    def get_fg_mask(self, seg_scores, seg_points, cls_id, batch_inds, gt_bboxes_3d, gt_labels_3d):
+        assert not self.training, "training-time sampling is outside this round's hot path"
+        return seg_scores[:, cls_id] > self.cfg["score_thresh"][cls_id]
+
+    def gather_group_by_names(self, scores):
+        groups, class_names = self.cfg["group_names"], self.cfg["class_names"]
+        assert (scores >= 0).all()
+        return torch.stack([scores[:, [class_names.index(n) for n in g]].sum(1) for g in groups], dim=1)
+
+    def get_offset_weight(self, seg_logit):
+        if self.cfg["offset_weight"] != "max":
+            raise NotImplementedError
+        weight = ((seg_logit - seg_logit.max(1)[0][:, None]).abs() < 1e-6).float()
+        assert ((weight == 1).any(1)).all()
+        return weight / weight.sum(1)[:, None]  # ties split evenly
+
+    def sample(self, dict_to_sample, offset, gt_bboxes_3d=None, gt_labels_3d=None):
+        if self.cfg.get("group_sample", False):
+            return self.group_sample(dict_to_sample, offset)
+        raise NotImplementedError("per-class sampling (:682-730) is not used by the FSF configs")
+
+    def group_sample(self, dict_to_sample, offset):
+        """:802-865."""
+        batch_idx = dict_to_sample["batch_idx"]
+        bsz = int(batch_idx.max().item()) + 1
+        cfg = self.train_cfg if self.training else self.test_cfg
+        seg_logits = dict_to_sample["seg_logits"]
+        assert (seg_logits < 0).any()  # make sure no sigmoid applied
+        assert seg_logits.size(1) == self.num_classes + 1
+        seg_scores = seg_logits.softmax(1)
+        offset = offset.reshape(-1, self.num_classes + 1, 3)
+        seg_points = dict_to_sample["seg_points"][:, :3]
+        fg_mask_list, center_preds_list = [], []
+        cls_score_thrs, group_names, class_names = cfg["score_thresh"], cfg["group_names"], cfg["class_names"]
+        assert len(group_names) == len(cls_score_thrs)
+        grouped_score = self.gather_group_by_names(seg_scores[:, :-1])
+        for i in range(len(group_names)):
+            fg_mask = self.get_fg_mask(grouped_score, None, i, None, None, None)
+            if len(torch.unique(batch_idx[fg_mask])) < bsz:
+                fg_mask[self.get_sample_beg_position(batch_idx, fg_mask)] = True  # at least one point per sample
+            fg_mask_list.append(fg_mask)
+            tmp_idx = [class_names.index(name) for name in group_names[i]]
+            this_offset = offset[:, tmp_idx, :][fg_mask, ...]
+            this_logits = seg_logits[:, tmp_idx][fg_mask, :]
+            offset_weight = self.get_offset_weight(this_logits)
+            this_offset = (this_offset * offset_weight[:, :, None]).sum(dim=1)
+            center_preds_list.append(seg_points[fg_mask, :] + this_offset)
+        output_dict = {name: [data[m] for m in fg_mask_list] for name, data in dict_to_sample.items()}
+        output_dict["fg_mask_list"] = fg_mask_list
+        output_dict["center_preds"] = center_preds_list
+        return output_dict
+
+
+class ClusterAssigner(nn.Module):
+    """:903-982 — per class group: divfloor voxel keys, drop almost-empty voxels, voxel centroids, connected
+    components of the centroids, map component ids back to the points."""
+
+    def __init__(self, cluster_voxel_size, min_points, point_cloud_range, connected_dist,
+                 class_names=["Car", "Cyclist", "Pedestrian"], gpu_clustering=(False, False)):
+        super().__init__()
+        self.cluster_voxel_size = cluster_voxel_size
+        self.min_points = min_points
+        self.connected_dist = connected_dist
+        self.point_cloud_range = point_cloud_range
+        self.class_names = class_names
+        self.gpu_clustering = gpu_clustering  # kept for config parity; clustering always runs on the device here
+
+    def _per_class(self, table, class_name):
+        if isinstance(table, dict):
+            return table[class_name]
+        if isinstance(table, list):
+            return table[self.class_names.index(class_name)]
+        return table
+
+    @torch.no_grad()
+    def forward(self, points_list, batch_idx_list, gt_bboxes_3d=None, gt_labels_3d=None, origin_points=None):
+        assert self.num_classes == len(self.class_names)
+        outs = [self.forward_single_class(p, b, n, o)
+                for p, b, n, o in zip(points_list, batch_idx_list, self.class_names, origin_points)]
+        cluster_inds_list = modify_cluster_by_class([o[0] for o in outs])
+        return cluster_inds_list, [o[1] for o in outs]
+
+    def forward_single_class(self, points, batch_idx, class_name, origin_points):
+        batch_idx = batch_idx.int()
+        cluster_vsize = self._per_class(self.cluster_voxel_size, class_name)
+        coors = hip_ops.voxelize_divfloor(points, cluster_vsize, self.point_cloud_range[:3], order="xyz",
+                                          batch_idx=batch_idx.long())
+        valid_mask = filter_almost_empty(coors, min_points=self.min_points)
+        if not valid_mask.any():
+            valid_mask = ~valid_mask
+        points, batch_idx, coors = points[valid_mask], batch_idx[valid_mask], coors[valid_mask]
+        sampled_centers, voxel_coors, inv_inds = scatter_v2(points, coors, mode="avg", return_inv=True)
+        dist = self._per_class(self.connected_dist, class_name)
+        if self.training:
+            cluster_inds = find_connected_componets(sampled_centers, voxel_coors[:, 0].int(), dist)
+        else:
+            cluster_inds = find_connected_componets_single_batch(sampled_centers, voxel_coors[:, 0], dist)
+        assert len(cluster_inds) == len(sampled_centers)
+        cluster_inds_per_point = cluster_inds[inv_inds]
+        return torch.stack([batch_idx, cluster_inds_per_point], 1), valid_mask

@@ -1,0 +1,173 @@
+"""`DynamicScatterVFE` and `SIRLayer` (VOXEL_ENCODERS) — defined in the authors' mmdet3d fork [UNVENDORED];
+selected at projects/configs/nuScenes/FSF_nuScenes_config.py:42-52 and built by
+projects/mmdet3d_plugin/models/backbones/sir.py:41-61.  Restated from the published SST/FSD modules
+(SURVEY.md App. C); module / parameter names follow upstream so state dicts keep their keys
+(`vfe_layers.N.linear.weight`, `vfe_layers.N.norm.*`, `rel_mlp.*`).
+
+Per call: ONE packed-key radix sort (unique_once), then every segmented mean/max and every "map back to the
+points" gather reuses that sort-once segment plan through the HIP library.
+"""
+import torch
+import torch.nn as nn
+
+from ...ops.sst_ops import build_mlp, gather_by_inverse, get_activation_layer, scatter_v2, unique_with_plan
+from ...registry import VOXEL_ENCODERS, build_norm_layer
+
+
+class DynamicVFELayer(nn.Module):
+    """Linear(bias=False) -> norm -> act (-> dropout); upstream `DynamicVFELayer`."""
+
+    def __init__(self, in_channels, out_channels, norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), act="relu",
+                 dropout=0.0):
+        super().__init__()
+        self.fp16_enabled = False
+        self.norm = build_norm_layer(norm_cfg, out_channels)[1]
+        self.linear = nn.Linear(in_channels, out_channels, bias=False)
+        self.act = get_activation_layer(act, out_channels)
+        self.dropout = nn.Dropout(dropout) if dropout > 0 else None
+
+    def forward(self, inputs):
+        x = self.act(self.norm(self.linear(inputs)))
+        if self.dropout is not None:
+            x = self.dropout(x)
+        return x
+
+
+@VOXEL_ENCODERS.register_module()
+class DynamicScatterVFE(nn.Module):
+    def __init__(self, in_channels=4, feat_channels=[], with_distance=False, with_cluster_center=False,
+                 with_voxel_center=False, voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), mode="max", fusion_layer=None,
+                 return_point_feats=False, unique_once=False):
+        super().__init__()
+        assert mode in ("avg", "max") and len(feat_channels) > 0 and fusion_layer is None
+        if with_cluster_center:
+            in_channels += 3
+        if with_voxel_center:
+            in_channels += 3
+        if with_distance:
+            in_channels += 1
+        self.in_channels = in_channels
+        self._with_distance = with_distance
+        self._with_cluster_center = with_cluster_center
+        self._with_voxel_center = with_voxel_center
+        self.return_point_feats = return_point_feats
+        self.unique_once = unique_once
+        self.fp16_enabled = False
+        self.vx, self.vy, self.vz = voxel_size
+        self.x_offset = self.vx / 2 + point_cloud_range[0]
+        self.y_offset = self.vy / 2 + point_cloud_range[1]
+        self.z_offset = self.vz / 2 + point_cloud_range[2]
+        self.point_cloud_range = list(point_cloud_range)
+        self.voxel_size = list(voxel_size)
+        self.mode = mode
+        chans = [self.in_channels] + list(feat_channels)
+        layers = []
+        for i in range(len(chans) - 1):
+            in_filters = chans[i] * 2 if i > 0 else chans[i]
+            layers.append(DynamicVFELayer(in_filters, chans[i + 1], norm_cfg))
+        self.vfe_layers = nn.ModuleList(layers)
+        self.num_vfe = len(layers)
+        gx = round((point_cloud_range[3] - point_cloud_range[0]) / voxel_size[0])
+        gy = round((point_cloud_range[4] - point_cloud_range[1]) / voxel_size[1])
+        gz = round((point_cloud_range[5] - point_cloud_range[2]) / voxel_size[2])
+        self._grid_zyx = (gz, gy, gx)
+
+    def _key_bounds(self, coors):
+        """Known voxel-grid bounds let the unique kernel skip the device min/max pass + host sync."""
+        if coors.size(1) != 4:
+            return None, None
+        gz, gy, gx = self._grid_zyx
+        return [0, -1, -1, -1], [max(int(getattr(self, "max_batch", 64)) - 1, 0), gz - 1, gy - 1, gx - 1]
+
+    def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False):
+        if self.unique_once:
+            cmin, cmax = self._key_bounds(coors)
+            new_coors, unq_inv, _ = unique_with_plan(coors, cmin, cmax)
+        else:
+            new_coors = unq_inv = None
+        features_ls = [features]
+        if self._with_cluster_center:
+            voxel_mean, mean_coors, unq_inv_c = scatter_v2(features, coors, mode="avg", unq_inv=unq_inv, new_coors=new_coors)
+            points_mean = gather_by_inverse(voxel_mean, unq_inv_c)
+            features_ls.append(features[:, :3] - points_mean[:, :3])
+        if self._with_voxel_center:
+            f_center = features.new_zeros(size=(features.size(0), 3))
+            f_center[:, 0] = features[:, 0] - (coors[:, 3].type_as(features) * self.vx + self.x_offset)
+            f_center[:, 1] = features[:, 1] - (coors[:, 2].type_as(features) * self.vy + self.y_offset)
+            f_center[:, 2] = features[:, 2] - (coors[:, 1].type_as(features) * self.vz + self.z_offset)
+            features_ls.append(f_center)
+        if self._with_distance:
+            features_ls.append(torch.norm(features[:, :3], 2, 1, keepdim=True))
+        features = torch.cat(features_ls, dim=-1)
+        for i, vfe in enumerate(self.vfe_layers):
+            point_feats = vfe(features)
+            voxel_feats, voxel_coors, unq_inv_l = scatter_v2(point_feats, coors, mode=self.mode, unq_inv=unq_inv,
+                                                             new_coors=new_coors)
+            if i != len(self.vfe_layers) - 1:
+                feat_per_point = gather_by_inverse(voxel_feats, unq_inv_l)
+                features = torch.cat([point_feats, feat_per_point], dim=1)
+        if self.return_point_feats:
+            return point_feats
+        if return_inv:
+            return voxel_feats, voxel_coors, unq_inv_l
+        return voxel_feats, voxel_coors
+
+
+@VOXEL_ENCODERS.register_module()
+class SIRLayer(nn.Module):
+    def __init__(self, in_channels=4, feat_channels=[], with_distance=False, with_cluster_center=False,
+                 with_rel_mlp=True, rel_mlp_hidden_dims=[16, ], rel_mlp_in_channel=3, with_voxel_center=False,
+                 voxel_size=(0.2, 0.2, 4), point_cloud_range=(0, -40, -3, 70.4, 40, 1),
+                 norm_cfg=dict(type="BN1d", eps=1e-3, momentum=0.01), mode="max", fusion_layer=None,
+                 return_point_feats=False, return_inv=True, rel_dist_scaler=10.0, with_shortcut=True,
+                 xyz_normalizer=[1.0, 1.0, 1.0], act="relu", dropout=0.0):
+        super().__init__()
+        assert mode in ("avg", "max") and len(feat_channels) > 0 and fusion_layer is None
+        assert not with_cluster_center and not with_voxel_center and not with_distance, \
+            "the FSF configs build SIRLayer without these decorations (sir.py:44-48)"
+        self.in_channels = in_channels
+        self.return_point_feats = return_point_feats
+        self.return_inv = return_inv
+        self.rel_dist_scaler = rel_dist_scaler
+        self.mode = mode
+        self.with_shortcut = with_shortcut
+        self._with_rel_mlp = with_rel_mlp
+        self.xyz_normalizer = list(xyz_normalizer)
+        self.fp16_enabled = False
+        chans = [self.in_channels] + list(feat_channels)
+        layers = []
+        for i in range(len(chans) - 1):
+            in_filters = chans[i] * 2 if i > 0 else chans[i]
+            layers.append(DynamicVFELayer(in_filters, chans[i + 1], norm_cfg, act=act, dropout=dropout))
+        self.vfe_layers = nn.ModuleList(layers)
+        self.num_vfe = len(layers)
+        if with_rel_mlp:
+            self.rel_mlp = build_mlp(rel_mlp_in_channel, list(rel_mlp_hidden_dims) + [in_channels], norm_cfg, act=act)
+
+    def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None, return_both=False,
+                unq_inv_once=None, new_coors_once=None):
+        xyz_normalizer = torch.tensor(self.xyz_normalizer, device=features.device, dtype=features.dtype)
+        features = torch.cat([features[:, :3] / xyz_normalizer[None, :], features[:, 3:]], dim=1)
+        if self._with_rel_mlp:
+            features = features * self.rel_mlp(f_cluster / self.rel_dist_scaler)
+        voxel_feats_list = []
+        for i, vfe in enumerate(self.vfe_layers):
+            point_feats = vfe(features)
+            if i == len(self.vfe_layers) - 1 and self.with_shortcut and point_feats.shape == features.shape:
+                point_feats = point_feats + features  # never shape-compatible in the FSF configs
+            voxel_feats, voxel_coors, unq_inv = scatter_v2(point_feats, coors, mode=self.mode, unq_inv=unq_inv_once,
+                                                           new_coors=new_coors_once)
+            voxel_feats_list.append(voxel_feats)
+            if i != len(self.vfe_layers) - 1:
+                features = torch.cat([point_feats, gather_by_inverse(voxel_feats, unq_inv)], dim=1)
+        voxel_feats = torch.cat(voxel_feats_list, dim=1)
+        if return_both:
+            if self.return_inv:
+                return point_feats, voxel_feats, voxel_coors, unq_inv
+            return point_feats, voxel_feats, voxel_coors
+        if self.return_point_feats:
+            return point_feats, voxel_feats
+        if self.return_inv:
+            return voxel_feats, voxel_coors, unq_inv
+        return voxel_feats, voxel_coors

@@ -1,0 +1,286 @@
+"""Module-level mirror of `mmdet3d.ops.spconv` (vendored spconv v1.x, [UNVENDORED] in the reference tree; imported
+at projects/mmdet3d_plugin/ops/sst_ops.py:5 and used by SimpleSparseUNet): `SparseConvTensor`, `SubMConv3d`,
+`SparseConv3d`, `SparseInverseConv3d`, `SparseSequential`, `SparseBasicBlock`, `make_sparse_convmodule`.
+
+Same constructor arguments, parameter names/shapes (weight [kz,ky,kx,Cin,Cout], no bias when a norm follows) and
+`indice_key` caching semantics; the rulebook is an output-major neighbour table built through a hash (no dense
+grid) and each conv layer is ONE fused gather -> fp32 MFMA -> epilogue launch instead of 27 x (gather, mm,
+scatter-add).  In eval mode the BatchNorm affine, the residual add and the ReLU that follow a conv are folded
+into that launch.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import hip_ops
+
+
+class SparseConvTensor:
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices  # i32 [m,4] (b,z,y,x)
+        self.spatial_shape = list(spatial_shape)
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}
+        self.grid = grid
+
+    @property
+    def spatial_size(self):
+        return math.prod(self.spatial_shape)
+
+    def find_indice_pair(self, key):
+        if key is None:
+            return None
+        return self.indice_dict.get(key)
+
+    def dense(self, channels_first=True):
+        b, c = self.batch_size, self.features.size(1)
+        out = self.features.new_zeros((b, *self.spatial_shape, c))
+        idx = self.indices.long()
+        out[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]] = self.features
+        return out.permute(0, 4, 1, 2, 3).contiguous() if channels_first else out
+
+    def _like(self, features, indices=None, spatial_shape=None):
+        t = SparseConvTensor(features, self.indices if indices is None else indices,
+                             self.spatial_shape if spatial_shape is None else spatial_shape, self.batch_size, self.grid)
+        t.indice_dict = self.indice_dict
+        return t
+
+
+class Rulebook:
+    """What spconv v1 keeps per indice_key (outids, indices, indice_pairs, indice_pair_num, out_spatial_shape),
+    in output-major form."""
+
+    def __init__(self, kind, nbr, in_indices, in_shape, out_indices, out_shape, nbr_inv=None):
+        self.kind = kind
+        self.nbr = nbr                  # i32 [m_out, kvol]
+        self.nbr_inv = nbr_inv          # i32 [m_in, kvol] (strided only)
+        self.in_indices, self.in_shape = in_indices, in_shape
+        self.out_indices, self.out_shape = out_indices, out_shape
+
+
+class _SparseConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, weight, nbr, scale, shift, residual, relu):
+        kvol = nbr.size(1)
+        w = weight.reshape(kvol, weight.shape[-2], weight.shape[-1])
+        wt = hip_ops.spconv_transpose_weight(w)
+        return hip_ops.spconv_forward(feat, wt, nbr, scale=scale, shift=shift, residual=residual, relu=relu)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError("sparse-conv backward (K10) is not built yet: forward/inference only")
+
+
+def _to3(v):
+    return [int(v)] * 3 if not isinstance(v, (list, tuple)) else [int(x) for x in v]
+
+
+class SparseModule(nn.Module):
+    pass
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None,
+                 fused_bn=False):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed
+        self.ndim = ndim
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _to3(kernel_size)
+        self.stride, self.padding, self.dilation = _to3(stride), _to3(padding), _to3(dilation)
+        self.conv1x1 = math.prod(self.kernel_size) == 1
+        self.subm, self.inverse, self.indice_key = subm, inverse, indice_key
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self._wt_cache = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # spconv v1: kaiming_uniform(a=sqrt(5)) with fan_in = kvol * Cin
+        fan_in = math.prod(self.kernel_size) * self.in_channels
+        bound = 1.0 / math.sqrt(fan_in) * math.sqrt(3.0) * math.sqrt(2.0 / (1 + 5.0))
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                b = 1.0 / math.sqrt(fan_in)
+                self.bias.uniform_(-b, b)
+
+    # -- rulebook ------------------------------------------------------------------------------------
+    def _rulebook(self, x):
+        rb = x.find_indice_pair(self.indice_key)
+        if self.inverse:
+            assert rb is not None and rb.kind == "strided", "SparseInverseConv3d needs the forward conv's indice_key"
+            return rb
+        if rb is not None:
+            return rb
+        if self.subm:
+            nbr = hip_ops.rulebook_subm(x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+            rb = Rulebook("subm", nbr, x.indices, x.spatial_shape, x.indices, x.spatial_shape)
+        else:
+            out_idx, nbr, nbr_inv, out_shape = hip_ops.rulebook_strided(
+                x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation)
+            rb = Rulebook("strided", nbr, x.indices, x.spatial_shape, out_idx, out_shape, nbr_inv)
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = rb
+        return rb
+
+    def _weight_t(self):
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        if self._wt_cache is None or self._wt_cache[0] != key:
+            kvol = math.prod(self.kernel_size)
+            wt = hip_ops.spconv_transpose_weight(w.detach().reshape(kvol, self.in_channels, self.out_channels))
+            self._wt_cache = (key, wt)
+        return self._wt_cache[1]
+
+    def forward(self, x, scale=None, shift=None, residual=None, relu=False):
+        """x: SparseConvTensor.  The optional epilogue arguments are the eval-mode BN affine / residual / ReLU
+        that SparseSequential and SparseBasicBlock fold into the conv launch."""
+        rb = self._rulebook(x)
+        if self.inverse:
+            nbr, out_indices, out_shape = rb.nbr_inv, rb.in_indices, rb.in_shape
+        else:
+            nbr, out_indices, out_shape = rb.nbr, rb.out_indices, rb.out_shape
+        if shift is None and self.bias is not None:
+            shift = self.bias
+        elif shift is not None and self.bias is not None:
+            shift = shift + (self.bias * scale if scale is not None else self.bias)
+        feat = x.features
+        needs_grad = torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad)
+        if needs_grad:
+            out = _SparseConvFn.apply(feat, self.weight, nbr, scale, shift, residual, relu)
+        else:
+            out = hip_ops.spconv_forward(feat, self._weight_t(), nbr, scale=scale, shift=shift, residual=residual,
+                                         relu=relu)
+        return x._like(out, out_indices, out_shape)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)
+
+
+class SparseInverseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, indice_key, bias=True):
+        super().__init__(3, in_channels, out_channels, kernel_size, bias=bias, inverse=True, indice_key=indice_key)
+
+
+CONV_TYPES = {"SparseConv3d": SparseConv3d, "SubMConv3d": SubMConv3d, "SparseInverseConv3d": SparseInverseConv3d}
+
+
+def _bn_affine(bn):
+    """eval-mode BatchNorm1d as y = x * scale + shift."""
+    invstd = torch.rsqrt(bn.running_var + bn.eps)
+    scale = bn.weight * invstd if bn.affine else invstd
+    shift = (bn.bias if bn.affine else 0) - bn.running_mean * scale
+    return scale, shift
+
+
+def _is_eval_bn(m):
+    return isinstance(m, nn.BatchNorm1d) and not m.training and m.track_running_stats
+
+
+class SparseSequential(SparseModule):
+    """spconv.SparseSequential: dense modules act on `.features`.  Peephole: conv -> eval BN (-> ReLU) becomes one
+    fused launch."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for i, m in enumerate(args):
+            self.add_module(str(i), m)
+        for name, m in kwargs.items():
+            self.add_module(name, m)
+
+    def __getitem__(self, idx):
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, SparseConvolution) and i + 1 < len(mods) and _is_eval_bn(mods[i + 1]) and not torch.is_grad_enabled():
+                scale, shift = _bn_affine(mods[i + 1])
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                x = m(x, scale=scale, shift=shift, relu=relu)
+                i += 3 if relu else 2
+                continue
+            if isinstance(m, SparseModule):
+                x = m(x)
+            elif isinstance(x, SparseConvTensor):
+                if x.indices.size(0) != 0:
+                    x = x._like(m(x.features))
+            else:
+                x = m(x)
+            i += 1
+        return x
+
+
+def make_sparse_convmodule(in_channels, out_channels, kernel_size, indice_key, stride=1, padding=0,
+                           conv_type="SubMConv3d", norm_cfg=None, order=("conv", "norm", "act")):
+    """mmdet3d.ops.make_sparse_convmodule: SparseSequential(conv, norm, ReLU) in the given order."""
+    from ..registry import build_norm_layer
+
+    assert isinstance(order, tuple) and len(order) <= 3 and set(order) | {"conv", "norm", "act"} == {"conv", "norm", "act"}
+    layers = []
+    for layer in order:
+        if layer == "conv":
+            if conv_type == "SparseInverseConv3d":
+                layers.append(SparseInverseConv3d(in_channels, out_channels, kernel_size, indice_key=indice_key, bias=False))
+            else:
+                layers.append(CONV_TYPES[conv_type](in_channels, out_channels, kernel_size, stride=stride,
+                                                    padding=padding, bias=False, indice_key=indice_key))
+        elif layer == "norm":
+            layers.append(build_norm_layer(norm_cfg, out_channels)[1])
+        elif layer == "act":
+            layers.append(nn.ReLU(inplace=True))
+    return SparseSequential(*layers)
+
+
+class SparseBasicBlock(SparseModule):
+    """mmdet3d.ops.SparseBasicBlock: conv-bn-relu-conv-bn + identity, relu (both convs SubM on one indice_key)."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, conv_cfg=None, norm_cfg=None):
+        super().__init__()
+        from ..registry import build_norm_layer
+
+        conv_cfg = dict(conv_cfg or dict(type="SubMConv3d"))
+        ctype = CONV_TYPES[conv_cfg.pop("type")]
+        self.conv1 = ctype(inplanes, planes, 3, stride=stride, padding=1, bias=False, **conv_cfg)
+        self.norm1 = build_norm_layer(norm_cfg, planes)[1]
+        self.conv2 = ctype(planes, planes, 3, padding=1, bias=False, **conv_cfg)
+        self.norm2 = build_norm_layer(norm_cfg, planes)[1]
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        assert downsample is None
+
+    def forward(self, x):
+        identity = x.features
+        if _is_eval_bn(self.norm1) and _is_eval_bn(self.norm2) and not torch.is_grad_enabled():
+            s1, b1 = _bn_affine(self.norm1)
+            out = self.conv1(x, scale=s1, shift=b1, relu=True)
+            s2, b2 = _bn_affine(self.norm2)
+            return self.conv2(out, scale=s2, shift=b2, residual=identity, relu=True)
+        out = self.conv1(x)
+        out = out._like(self.relu(self.norm1(out.features)))
+        out = self.conv2(out)
+        return out._like(self.relu(self.norm2(out.features) + identity))

@@ -1,0 +1,144 @@
+"""Host-side mirror of projects/mmdet3d_plugin/ops/sst_ops.py for the functions the FSF configs use:
+`scatter_v2` (:150-177), `get_inner_win_inds` (:239-259), `build_mlp` (:808-833),
+`get_activation` / `get_activation_layer` (:835-864).  Same names, arguments and error behaviour; the work is
+done by the HIP library (no torch_scatter, no TorchEx)."""
+import traceback
+
+import torch
+import torch.nn as nn
+
+from ... import hip_ops
+from ..registry import build_norm_layer
+
+_PLAN_ATTR = "_fsf_segment_plan"
+
+
+class _SegmentReduce(torch.autograd.Function):
+    """Differentiable w.r.t. `feat` only, like torch_scatter's scatter / scatter_max (sst_ops.py:168-170)."""
+
+    @staticmethod
+    def forward(ctx, feat, plan, mode):
+        ctx.plan, ctx.mode = plan, mode
+        if mode == "max" and feat.requires_grad:
+            out, arg = hip_ops.segment_reduce(feat, plan, "max", return_argmax=True)
+            ctx.save_for_backward(arg)
+            return out
+        ctx.save_for_backward()
+        return hip_ops.segment_reduce(feat, plan, mode)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        arg = ctx.saved_tensors[0] if ctx.mode == "max" else None
+        return hip_ops.segment_reduce_backward(grad_out.contiguous(), ctx.plan, ctx.mode, argmax=arg), None, None
+
+
+class _GatherRows(torch.autograd.Function):
+    """rows[inv] with a deterministic segmented-sum adjoint (replaces ATen index + index_put atomics)."""
+
+    @staticmethod
+    def forward(ctx, src, plan):
+        ctx.plan = plan
+        return hip_ops.gather_rows(src, plan.inv)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return hip_ops.segment_reduce(grad_out.contiguous(), ctx.plan, "sum"), None
+
+
+def unique_with_plan(coors, col_min=None, col_max=None):
+    """torch.unique(coors, return_inverse=True, return_counts=True, dim=0) + the sort-once segment plan.
+    The plan rides on the returned inverse tensor so that the `unq_inv=`/`new_coors=` path of scatter_v2
+    (used by unique_once VFE / SIR blocks) reuses it instead of sorting again."""
+    new_coors, plan = hip_ops.unique_rows(coors, col_min=col_min, col_max=col_max)
+    inv = plan.inv.detach()  # a second tensor object on the same storage: tensor -> plan -> tensor would be a cycle
+    setattr(inv, _PLAN_ATTR, plan)
+    return new_coors, inv, plan.cnt
+
+
+def plan_of(unq_inv, num_segments):
+    plan = getattr(unq_inv, _PLAN_ATTR, None)
+    if plan is None or plan.m != num_segments:
+        plan = hip_ops.segment_plan_from_inverse(unq_inv, int(num_segments))
+        setattr(unq_inv, _PLAN_ATTR, plan)
+    return plan
+
+
+def gather_by_inverse(rows, unq_inv):
+    """`rows[unq_inv]` (the "map back to points" gather of DynamicScatterVFE / SIRLayer / the neck)."""
+    return _GatherRows.apply(rows, plan_of(unq_inv, rows.size(0)))
+
+
+def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, new_coors=None):
+    assert feat.size(0) == coors.size(0)
+    if mode == "avg":
+        mode = "mean"
+    if mode not in ("max", "mean", "sum"):
+        raise NotImplementedError
+    unq_cnt = None
+    if unq_inv is None:
+        new_coors, unq_inv, unq_cnt = unique_with_plan(coors)
+    else:
+        assert new_coors is not None, "please pass new_coors for interface consistency, caller: {}".format(
+            traceback.extract_stack()[-2][2])
+    if min_points > 0:
+        cnt_per_point = unq_cnt[unq_inv]  # NameError-equivalent upstream when unq_inv was supplied (:161)
+        valid_mask = cnt_per_point >= min_points
+        feat = feat[valid_mask]
+        coors = coors[valid_mask]
+        new_coors, unq_inv, unq_cnt = unique_with_plan(coors)
+    plan = plan_of(unq_inv, new_coors.size(0))
+    new_feat = _SegmentReduce.apply(feat.float().contiguous(), plan, mode)
+    if not return_inv:
+        return new_feat, new_coors
+    return new_feat, new_coors, unq_inv
+
+
+@torch.no_grad()
+def get_inner_win_inds(group_inds):
+    """IngroupIndicesFunction.apply (sst_ops.py:239-259): per element its rank inside its group
+    (non-differentiable).  TorchEx hands out ranks in atomicAdd order; this is the stable rank."""
+    return hip_ops.ingroup_rank(group_inds)
+
+
+def get_activation(activation):
+    if activation == "relu":
+        return torch.nn.functional.relu
+    if activation == "gelu":
+        return torch.nn.functional.gelu
+    if activation == "glu":
+        return torch.nn.functional.glu
+    raise RuntimeError(f"activation should be relu/gelu, not {activation}.")
+
+
+def get_activation_layer(act, dim=None):
+    act = act.lower()
+    table = {
+        "relu": lambda: nn.ReLU(inplace=True),
+        "gelu": lambda: nn.GELU(),
+        "leakyrelu": lambda: nn.LeakyReLU(inplace=True),
+        "prelu": lambda: nn.PReLU(num_parameters=dim),
+        "swish": lambda: nn.SiLU(inplace=True),
+        "silu": lambda: nn.SiLU(inplace=True),
+        "glu": lambda: nn.GLU(),
+        "elu": lambda: nn.ELU(inplace=True),
+    }
+    if act not in table:
+        raise NotImplementedError
+    return table[act]()
+
+
+def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act="relu", bias=False, dropout=0):
+    """Sequential of [Linear(bias) -> norm -> act (-> Dropout)] blocks; with `is_head` the last entry is a
+    plain Linear(bias=True).  Dense GEMMs stay on rocBLAS through torch."""
+    layers = []
+    last = in_channel
+    for i, c in enumerate(hidden_dims):
+        if is_head and i == len(hidden_dims) - 1:
+            layers.append(nn.Linear(last, c, bias=True))
+        else:
+            block = [nn.Linear(last, c, bias=bias), build_norm_layer(norm_cfg, c)[1], get_activation_layer(act, c)]
+            if dropout > 0:
+                block.append(nn.Dropout(dropout))
+            layers.append(nn.Sequential(*block))
+        last = c
+    return nn.Sequential(*layers)

@@ -207,6 +207,22 @@ int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float
                        const float* residual, int32_t relu, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K19  connected components of the graph "xy-distance < dist" (same batch index), labels contiguous 0..K-1
+ * numbered in order of each component's smallest member index — the labelling
+ * scipy.sparse.csgraph.connected_components(adj, directed=False)[1] produces.
+ * Replaces: find_connected_componets_single_batch / find_connected_componets
+ *   (projects/mmdet3d_plugin/models/detectors/single_stage_fsd.py:45-82): dense n x n distance matrix on the
+ *   GPU, .cpu().numpy(), scipy, back to the device — six times per frame — and the optional
+ *   torchex.connected_components path (:37-43).
+ *   points f32 [n, point_stride] (cols 0,1 = x,y); batch_idx i32 [n] or NULL (single batch);
+ *   labels i32 [n]; num_components_dev i64 device scalar or NULL.
+ */
+int64_t fsf_connected_components_workspace_bytes(int64_t n);
+int fsf_connected_components(const float* points, int64_t n, int32_t point_stride, const int32_t* batch_idx,
+                             float dist, int32_t* labels, int64_t* num_components_dev, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K18  in-group rank (TorchEx ingroup_indices [UNVENDORED]); sst_ops.py:239-259.
  * Upstream is an atomicAdd counter (a nondeterministic permutation of 0..n_g-1 per group); this returns the
  * stable rank (ascending original index), which satisfies the same contract (sst_ops.py:225-235).

@@ -1,0 +1,294 @@
+"""Oracle: module-level CPU restatement of the hot path.  TEST INFRASTRUCTURE ONLY.
+
+Every function takes a CPU copy of the product's nn.Module ONLY as a parameter container (Linear / norm weights
+are data) and restates the forward wiring with the oracle primitives: torch.unique + scatter_reduce
+(oracle.scatter), the spconv-v1 restatement (oracle.spconv), the numpy projection (oracle.project).
+
+PARITY UNPINNED for DynamicScatterVFE / SIRLayer / SimpleSparseUNet: their sources are in the authors' mmdet3d fork,
+not in the reference tree; restated from the published SST/FSD modules.  SIR's block wiring and the
+neck are pinned by tests/golden/{sir_flow,neck}.npz; the FSF glue by tests/golden/{project,frustum_glue}.npz.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import project as oproj
+from . import scatter as oscatter
+from . import spconv as osp
+
+
+# ------------------------------------------------------------------------------------- DynamicScatterVFE
+def vfe_forward(vfe, features, coors):
+    """Published SST `DynamicScatterVFE.forward(features, coors, return_inv=True)`; called at
+    projects/mmdet3d_plugin/models/detectors/single_stage_fsd.py:232."""
+    new_coors, unq_inv = torch.unique(coors, return_inverse=True, return_counts=False, dim=0)
+    m = new_coors.size(0)
+    ls = [features]
+    if vfe._with_cluster_center:
+        voxel_mean = oscatter.segment_mean(features, unq_inv, m)
+        ls.append(features[:, :3] - voxel_mean[unq_inv][:, :3])
+    if vfe._with_voxel_center:
+        f_center = features.new_zeros((features.size(0), 3))
+        f_center[:, 0] = features[:, 0] - (coors[:, 3].type_as(features) * vfe.vx + vfe.x_offset)
+        f_center[:, 1] = features[:, 1] - (coors[:, 2].type_as(features) * vfe.vy + vfe.y_offset)
+        f_center[:, 2] = features[:, 2] - (coors[:, 1].type_as(features) * vfe.vz + vfe.z_offset)
+        ls.append(f_center)
+    x = torch.cat(ls, dim=-1)
+    for i, layer in enumerate(vfe.vfe_layers):
+        point_feats = layer.act(layer.norm(layer.linear(x)))
+        voxel_feats, _ = oscatter.segment_max(point_feats, unq_inv, m)
+        if i != len(vfe.vfe_layers) - 1:
+            x = torch.cat([point_feats, voxel_feats[unq_inv]], dim=1)
+    return voxel_feats, new_coors, unq_inv
+
+
+# ---------------------------------------------------------------------------------------------- SIRLayer
+def sir_layer_forward(layer, features, coors, f_cluster, unq_inv, new_coors):
+    """Published FSD `SIRLayer.forward` (built by projects/mmdet3d_plugin/models/backbones/sir.py:41-61)."""
+    xyz_norm = torch.tensor(layer.xyz_normalizer, dtype=features.dtype)
+    x = torch.cat([features[:, :3] / xyz_norm[None, :], features[:, 3:]], dim=1)
+    x = x * layer.rel_mlp(f_cluster / layer.rel_dist_scaler)
+    m = new_coors.size(0)
+    outs = []
+    for i, vfe in enumerate(layer.vfe_layers):
+        point_feats = vfe.act(vfe.norm(vfe.linear(x)))
+        grp, _ = oscatter.segment_max(point_feats, unq_inv, m)
+        outs.append(grp)
+        if i != len(layer.vfe_layers) - 1:
+            x = torch.cat([point_feats, grp[unq_inv]], dim=1)
+    return point_feats, torch.cat(outs, dim=1)
+
+
+def sir_forward(sir, points, features, coors, f_cluster):
+    """projects/mmdet3d_plugin/models/backbones/sir.py:65-85."""
+    new_coors, unq_inv = torch.unique(coors, return_inverse=True, return_counts=False, dim=0)
+    out_feats = features
+    cluster_feats = []
+    for block in sir.block_list:
+        in_feats = torch.cat([points, out_feats], 1)
+        out_feats, grp = sir_layer_forward(block, in_feats, coors, f_cluster, unq_inv, new_coors)
+        cluster_feats.append(grp)
+    return out_feats, torch.cat(cluster_feats, dim=1), new_coors
+
+
+# --------------------------------------------------------------------------------------- SimpleSparseUNet
+class _SpT:
+    def __init__(self, features, indices, shape, batch_size, rulebooks):
+        self.features, self.indices, self.shape, self.batch_size, self.rb = features, indices, list(shape), batch_size, rulebooks
+
+
+def _bn_eval(bn, x):
+    return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+
+
+def _conv(conv, x):
+    """spconv v1 SubMConv3d / SparseConv3d / SparseInverseConv3d with indice_key caching."""
+    key = conv.indice_key
+    w = conv.weight.detach()
+    if conv.inverse:
+        out_idx, pairs, in_idx, in_shape = x.rb[key]
+        feat = osp.indice_conv(x.features, w, pairs, in_idx.shape[0], inverse=True)
+        return _SpT(feat, in_idx, in_shape, x.batch_size, x.rb)
+    if key not in x.rb:
+        if conv.subm:
+            pad = [(k - 1) // 2 * d for k, d in zip(conv.kernel_size, conv.dilation)]
+            out_idx, pairs, oshape = osp.build_rulebook(x.indices, x.batch_size, x.shape, conv.kernel_size, (1, 1, 1), pad,
+                                                        conv.dilation, True)
+        else:
+            out_idx, pairs, oshape = osp.build_rulebook(x.indices, x.batch_size, x.shape, conv.kernel_size, conv.stride,
+                                                        conv.padding, conv.dilation, False)
+        x.rb[key] = (out_idx, pairs, x.indices, x.shape)
+        x.rb[key + "/oshape"] = oshape
+    out_idx, pairs, _, _ = x.rb[key]
+    feat = osp.indice_conv(x.features, w, pairs, out_idx.shape[0])
+    return _SpT(feat, out_idx, x.rb[key + "/oshape"], x.batch_size, x.rb)
+
+
+def _convmodule(seq, x):
+    mods = list(seq._modules.values())
+    x = _conv(mods[0], x)
+    x.features = torch.relu(_bn_eval(mods[1], x.features))
+    return x
+
+
+def _basic_block(blk, x):
+    identity = x.features
+    out = _conv(blk.conv1, x)
+    out.features = torch.relu(_bn_eval(blk.norm1, out.features))
+    out = _conv(blk.conv2, out)
+    out.features = torch.relu(_bn_eval(blk.norm2, out.features) + identity)
+    return out
+
+
+def unet_forward(unet, voxel_feats, voxel_coors, batch_size):
+    """Published SST `SimpleSparseUNet.forward` in eval mode (called at single_stage_fsd.py:234)."""
+    x = _SpT(voxel_feats, voxel_coors.int().numpy(), unet.sparse_shape, batch_size, {})
+    x = _convmodule(unet.conv_input, x)
+    enc = []
+    for stage in unet.encoder_layers._modules.values():
+        for block in stage._modules.values():
+            x = _convmodule(block, x)
+        enc.append(x)
+    x = enc[-1]
+    for i in range(unet.stage_num, 0, -1):
+        lat = _basic_block(getattr(unet, f"lateral_layer{i}"), enc[i - 1])
+        cat = _SpT(torch.cat((x.features, lat.features), dim=1), lat.indices, lat.shape, lat.batch_size, lat.rb)
+        merged = _convmodule(getattr(unet, f"merge_layer{i}"), cat)
+        n, c_out = merged.features.shape
+        reduced = cat.features.view(n, c_out, -1).sum(dim=2)
+        cat.features = merged.features + reduced
+        x = _convmodule(getattr(unet, f"upsample_layer{i}"), cat)
+    return x.features
+
+
+# --------------------------------------------------------------------------------------------------- neck
+def neck_forward(neck, points, pts_coors, voxel_feats, inv, padding=-1):
+    """projects/mmdet3d_plugin/models/necks/voxel2point_neck.py:27-70 (with_xyz, not normalised)."""
+    pts_feats = voxel_feats[inv]
+    mask = ~((pts_feats == padding).all(1))
+    pts_feats, pts_coors, points = pts_feats[mask], pts_coors[mask], points[mask]
+    vs = torch.tensor(neck.voxel_size, dtype=torch.float32).reshape(1, 3)
+    mn = torch.tensor(neck.point_cloud_range[:3], dtype=torch.float32).reshape(1, 3)
+    centers = (pts_coors[:, [3, 2, 1]].float() + 0.5) * vs + mn
+    return torch.cat([pts_feats, points[:, :3] - centers], 1), mask
+
+
+# ----------------------------------------------------------------------------------------- VoteSegmentor
+def segmentor_extract_feat(seg, points_list):
+    """VoteSegmentor.extract_feat (single_stage_fsd.py:228-245)."""
+    from . import voxelize as ovox
+
+    pts, coors = ovox.voxelize_batch([p.numpy() for p in points_list], seg.voxel_size, seg.point_cloud_range)
+    pts, coors = torch.from_numpy(pts), torch.from_numpy(coors)
+    voxel_feats, voxel_coors, inv = vfe_forward(seg.voxel_encoder, pts, coors)
+    unet_out = unet_forward(seg.backbone, voxel_feats, voxel_coors, len(points_list))
+    out, mask = neck_forward(seg.decode_neck, pts, coors, unet_out, inv)
+    return dict(neck=out, mask=mask, coors=coors, points=pts, voxel_feats=voxel_feats, voxel_coors=voxel_coors, inv=inv,
+                unet=unet_out)
+
+
+# --------------------------------------------------------------------------------------------------- FSF
+def fsf_stage1(fsf, points8, mask_data, mask_anno, lidar2img):
+    """FSF.simple_test step 1 (FSF.py:1123-1130): segmentor features + image branch + seg head, one sample."""
+    points = [points8[:, :-3]]
+    infos = points8[:, -3:]
+    ex = segmentor_extract_feat(fsf.segmentor, points)
+    assert bool(ex["mask"].all())
+    obj_id, _ = oproj.points_in_mask(infos.numpy(), mask_data.numpy(), lidar2img.numpy())
+    ids, score = oproj.cam_select_score(obj_id, mask_anno.numpy())
+    img_feat = fsf.segmentor_updated_mlp(torch.from_numpy(score))
+    pts_feats = ex["neck"] + img_feat
+    head = fsf.segmentor.segmentation_head
+    h = head.pre_seg_conv(pts_feats)
+    seg_logits, vote_preds = head.conv_seg(h), head.voting(h)
+    return dict(ex=ex, obj_id=torch.from_numpy(obj_id), seg_points=ex["points"], seg_logits=seg_logits,
+                seg_vote_preds=vote_preds, offsets=vote_preds * vote_preds.abs(), seg_feats=pts_feats,
+                batch_idx=ex["coors"][:, 0])
+
+
+def double_overlap_pts(pts_feat, bz_coor, points, obj_id_tensor, w):
+    """FSF.double_overlap_pts (FSF.py:260-297); pinned by tests/golden/frustum_glue.npz."""
+    obj = obj_id_tensor.reshape(obj_id_tensor.shape[0], -1)
+    overlaps = (obj > 0).sum(-1)
+    raw = obj.max(-1)[0]
+    feats, bzs, pts, ws, ids = [pts_feat], [bz_coor], [points], [w], [raw]
+    for k in range(2, int(overlaps.max()) + 1):
+        msk = overlaps == k
+        if msk.sum() == 0:
+            continue
+        feats.append(pts_feat[msk].repeat(k - 1, 1))
+        bzs.append(bz_coor[msk].repeat(k - 1, 1))
+        pts.append(points[msk].repeat(k - 1, 1))
+        ws.append(w[msk].repeat(k - 1))
+        sv = obj[msk].topk(k, dim=-1)[0]
+        for j in range(1, k):
+            ids.append(sv[:, j])
+    return torch.cat(feats), torch.cat(bzs), torch.cat(pts), torch.cat(ids), torch.cat(ws)
+
+
+def fsf_stage2(fsf, s1, mask_anno, img_hw):
+    """FSF.frustum_forward without the head (FSF.py:607-650)."""
+    w = 1 - s1["seg_logits"].softmax(1)[:, -1]
+    obj = s1["obj_id"]
+    fg = obj.sum((-2, -1)) > 0
+    a = (s1["seg_feats"][fg], s1["batch_idx"][fg].unsqueeze(-1), s1["seg_points"][fg], obj[fg], w[fg])
+    feat, bz, pts, ids, ww = double_overlap_pts(*a)
+    sir_coors = torch.cat([bz, torch.zeros_like(bz), ids.unsqueeze(-1)], dim=-1)
+    pw = ww.unsqueeze(-1).clamp(min=1e-5)
+    mean, mcoors, inv = oscatter.scatter_v2(torch.cat([pts[:, :3] * pw, pw], -1), sir_coors, "avg")
+    center = mean[:, :3] / mean[:, 3:4]
+    f_cluster = pts[:, :3] - center[inv]
+    _, cluster_feats, out_coors = sir_forward(fsf.frustum_sir, pts, feat, sir_coors, f_cluster)
+    ids_k = out_coors[:, 2]
+    preds = torch.zeros((out_coors.size(0), 9))
+    valid = ids_k > 0
+    preds[valid] = mask_anno[ids_k[valid] - 1]
+    preds[~valid, 5] = fsf.num_classes
+    bbox = preds[:, :4].clone()
+    bbox[:, 0::2] /= img_hw[1]
+    bbox[:, 1::2] /= img_hw[0]
+    enc = torch.cat([bbox, preds[:, 4:5], F.one_hot(preds[:, 5].long(), fsf.num_classes + 1).float()], -1)
+    img_feat = fsf.encode_2d_mlp(enc)
+    return dict(obj_feat=torch.cat([cluster_feats, img_feat], -1), obj_coors=out_coors, obj_centers=center,
+                sir_coors=sir_coors, f_cluster=f_cluster, preds_2d=preds)
+
+
+def connected_components_xy(points, dist):
+    """find_connected_componets_single_batch (single_stage_fsd.py:69-82)."""
+    from scipy.sparse.csgraph import connected_components
+
+    p = points[:, :2]
+    d = p[:, None, :] - p[None, :, :]
+    d = (d ** 2).sum(2) ** 0.5
+    return torch.from_numpy(connected_components((d < dist).numpy(), directed=False)[1]).int()
+
+
+def fsf_stage3(fsf, s1):
+    """FSF.fsd_forward without the head (FSF.py:569-600): pre_voxelize, group_sample, ClusterAssigner, SIR."""
+    from . import voxelize as ovox
+
+    cfg = fsf.cfg
+    d = dict(seg_points=s1["seg_points"], seg_logits=s1["seg_logits"], seg_vote_preds=s1["seg_vote_preds"],
+             seg_feats=s1["seg_feats"], batch_idx=s1["batch_idx"], vote_offsets=s1["offsets"])
+    rng = fsf.cluster_assigner.point_cloud_range
+    coors = torch.from_numpy(ovox.divfloor_coors(d["seg_points"][:, :3].numpy(), cfg["pre_voxelization_size"], rng[:3],
+                                                 "zyx", d["batch_idx"].numpy()))
+    new_coors, inv = torch.unique(coors, return_inverse=True, dim=0)
+    vox = {k: oscatter.segment_mean(v, inv, new_coors.size(0)) for k, v in d.items() if v.dtype == torch.float32}
+    vox["batch_idx"] = new_coors[:, 0]
+    seg_logits = vox["seg_logits"]
+    scores = seg_logits.softmax(1)
+    offset = vox["vote_offsets"].reshape(-1, fsf.num_classes + 1, 3)
+    names = cfg["class_names"]
+    pts_all, feats_all, inds_all, centers_all = [], [], [], []
+    for gi, group in enumerate(cfg["group_names"]):
+        idx = [names.index(n) for n in group]
+        fg = scores[:, idx].sum(1) > cfg["score_thresh"][gi]
+        if fg.sum() == 0:
+            fg[0] = True
+        lg = seg_logits[:, idx][fg]
+        wgt = ((lg - lg.max(1)[0][:, None]).abs() < 1e-6).float()
+        wgt = wgt / wgt.sum(1)[:, None]
+        centers = vox["seg_points"][fg, :3] + (offset[:, idx, :][fg] * wgt[:, :, None]).sum(1)
+        vs = fsf.cluster_assigner.cluster_voxel_size[gi]
+        bidx = vox["batch_idx"][fg].int()
+        cc = torch.from_numpy(ovox.divfloor_coors(centers.numpy(), vs, rng[:3], "xyz", bidx.numpy())).int()
+        _, cinv, ccnt = torch.unique(cc, return_inverse=True, return_counts=True, dim=0)
+        valid = ccnt[cinv] >= fsf.cluster_assigner.min_points
+        if not valid.any():
+            valid = ~valid
+        cpts, cco = centers[valid], cc[valid]
+        vc, vcoors, vinv = oscatter.scatter_v2(cpts, cco, "avg")
+        comp = connected_components_xy(vc, fsf.cluster_assigner.connected_dist[gi])
+        per_pt = comp[vinv]
+        inds_all.append(torch.stack([torch.full_like(per_pt, gi), bidx[valid], per_pt], 1))
+        pts_all.append(vox["seg_points"][fg][valid])
+        feats_all.append(torch.cat([vox["seg_logits"][fg][valid], vox["seg_vote_preds"][fg][valid], vox["seg_feats"][fg][valid]], 1))
+        centers_all.append(cpts)
+    points, feats = torch.cat(pts_all), torch.cat(feats_all)
+    cluster_inds, center_preds = torch.cat(inds_all), torch.cat(centers_all)
+    cxyz, _, cinv2 = oscatter.scatter_v2(center_preds, cluster_inds, "avg")
+    f_cluster = points[:, :3] - cxyz[cinv2]
+    _, cluster_feats, out_coors = sir_forward(fsf.backbone, points, feats, cluster_inds, f_cluster)
+    return dict(cluster_feats=cluster_feats, cluster_xyz=cxyz, cluster_inds=out_coors, pts_cluster_inds=cluster_inds,
+                points=points, pre_voxel_coors=new_coors)

@@ -1,0 +1,84 @@
+"""CPU: the drop-in boundary b1: mmcv-style configs load through compat.Config, every `type=`
+resolves against the plugin registries, and the model builds with the reference's own kwargs."""
+import os
+
+import pytest
+
+from fullysparsefusion_amd import mmdet3d_plugin as plugin
+from fullysparsefusion_amd.compat import Config
+from fullysparsefusion_amd.mmdet3d_plugin import registry as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_CFG = "/root/reference/projects/configs/nuScenes/FSF_nuScenes_config.py"
+# types owned by mmcv's runner / torch.optim / the conv_cfg-act_cfg mini-dialect, not by plugin registries
+EXTERNAL = {"AdamW", "Conv1d", "ReLU", "EpochBasedRunner", "TensorboardLoggerHook", "TextLoggerHook", "cyclic", "CosineAnnealing"}
+REGS = [R.MODELS, R.SEGMENTORS, R.VOXEL_ENCODERS, R.MIDDLE_ENCODERS, R.BBOX_CODERS, R.BBOX_ASSIGNERS, R.PIPELINES, R.DATASETS,
+        R.HOOKS, R.NORM_LAYERS]
+
+
+def unresolved(cfg_dict):
+    missing = set()
+
+    def walk(o):
+        if isinstance(o, dict):
+            t = o.get("type")
+            if isinstance(t, str) and t not in EXTERNAL and not any(t in r for r in REGS):
+                missing.add(t)
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                walk(v)
+
+    walk(cfg_dict)
+    return missing
+
+
+def test_own_config_builds():
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "fsf_nuscenes.py"))
+    assert not unresolved(cfg.to_dict())
+    model = plugin.build_model(cfg.model)
+    assert type(model).__name__ == "FSF"
+    # channel arithmetic that must close
+    assert model.segmentor.voxel_encoder.vfe_layers[0].linear.in_features == 11
+    assert model.segmentor.voxel_encoder.vfe_layers[1].linear.in_features == 128
+    assert model.backbone.block_list[0].vfe_layers[0].linear.in_features == 5 + 11 + 33 + 131
+    assert model.frustum_sir.block_list[0].vfe_layers[0].linear.in_features == 5 + 131
+    assert model.segmentor.segmentation_head.conv_seg.out_features == 11
+    assert model.segmentor.segmentation_head.voting.out_features == 33
+    unet = model.segmentor.backbone
+    n_conv = sum(1 for m in unet.modules() if type(m).__name__ in ("SubMConv3d", "SparseConv3d", "SparseInverseConv3d"))
+    assert n_conv == 34
+    assert float(model.segmentor_updated_mlp[-1].weight.detach().abs().sum()) == 0.0  # zero-init (FSF.py:142-143)
+    keys = model.state_dict().keys()
+    for k in ["segmentor.voxel_encoder.vfe_layers.0.linear.weight", "segmentor.backbone.conv_input.0.weight",
+              "segmentor.backbone.encoder_layers.encoder_layer2.0.0.weight", "segmentor.backbone.lateral_layer5.conv1.weight",
+              "segmentor.backbone.upsample_layer1.0.weight", "backbone.block_list.0.rel_mlp.0.0.weight",
+              "frustum_sir.block_list.2.vfe_layers.1.norm.weight"]:
+        assert k in keys, k
+    assert tuple(model.state_dict()["segmentor.backbone.conv_input.0.weight"].shape) == (3, 3, 3, 64, 64)
+
+
+def test_config_merge_semantics(tmp_path):
+    base = tmp_path / "base.py"
+    base.write_text("a = dict(x=1, y=dict(z=2, w=3))\nb = [1, 2]\n")
+    child = tmp_path / "child.py"
+    child.write_text("_base_ = ['base.py']\na = dict(y=dict(z=5))\nc = dict(_delete_=True, q=1)\n")
+    cfg = Config.fromfile(str(child))
+    assert cfg.a.x == 1 and cfg.a.y.z == 5 and cfg.a.y.w == 3 and cfg.b == [1, 2] and cfg.c == dict(q=1)
+    cfg.merge_from_dict({"a.y.w": 9, "d": 4})
+    assert cfg.a.y.w == 9 and cfg.d == 4
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason="reference tree only exists in the build container")
+def test_reference_config_loads_and_builds_unchanged():
+    cfg = Config.fromfile(REF_CFG)
+    assert cfg.plugin is True and cfg.plugin_dir == "projects/mmdet3d_plugin/"
+    assert not unresolved(cfg.to_dict()), unresolved(cfg.to_dict())
+    model = plugin.build_model(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
+    own = Config.fromfile(os.path.join(ROOT, "configs", "fsf_nuscenes.py"))
+    for key in ["segmentor", "backbone", "frustum_sir", "cluster_assigner", "test_cfg", "mlp_cfg"]:
+        assert cfg.model[key] == own.model[key], key
+    own_model = plugin.build_model(own.model)
+    ref_keys = {k for k in model.state_dict() if not k.startswith(("refine", "lidar_img_mlp", "position_encoder", "out_proj"))}
+    assert ref_keys == set(own_model.state_dict().keys())
