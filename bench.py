@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""bench.py — frames/sec of the FSF hot-path forward on synthetic nuScenes-shape 10-sweep frames (BASELINE.json
+metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (FSF.forward_hot_path: voxelize -> DynamicScatterVFE -> SimpleSparseUNet ->
+neck -> projection + mask gather + image fusion + seg head -> camera-query grouping + SIR -> LiDAR-query
+pre-voxelize, sampling, device CCL, SIR) over one frame whose inputs are already resident in HBM.  Frames are
+independent, so N ranks are N replicas with no data-path collective (weak scaling); the only collectives are the
+barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel:
+the fused sparse-conv implicit GEMM on the fp32 MFMA, timed with HIP events in an instrumented pass over the same
+frames) and `cpu_baseline` (the CPU oracle restatement timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sweeps", type=int, default=10, help="10 = BASELINE config 3 input; 1 = config 2 (parity case)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(device):
+    from fullysparsefusion_amd import mmdet3d_plugin as plugin
+    from fullysparsefusion_amd.compat import Config
+
+    torch.manual_seed(0)
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "fsf_nuscenes.py"))
+    model = plugin.build_model(cfg.model).eval()
+    # random-init weights of the reference architecture (no checkpoint on the box); un-zero the image branch's last
+    # layer (zero-init upstream, FSF.py:142-143) so the fusion arithmetic is not trivially zero
+    torch.nn.init.normal_(model.segmentor_updated_mlp[-1].weight, std=0.02)
+    return model.to(device)
+
+
+def make_inputs(sweeps, seed, device):
+    from fullysparsefusion_amd import synthetic
+
+    f = synthetic.make_frame(num_sweeps=sweeps, seed=seed)
+    dev = dict(
+        points=[torch.from_numpy(f["points"]).to(device)],
+        mask_data=torch.from_numpy(f["mask_data"]).to(device)[None],
+        mask_anno=torch.from_numpy(f["mask_anno"]).to(device)[None],
+        img_metas=[dict(lidar2img=torch.from_numpy(f["lidar2img"]).to(device))],
+    )
+    return f, dev
+
+
+def step(model, inp):
+    with torch.no_grad():
+        return model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+
+
+def spconv_roofline(model, inp, steps):
+    """Instrumented pass: HIP events (on the launch stream = torch's current stream) around every
+    fsf_spconv_forward launch; algorithmic flops = 2 * P * Cin * Cout with P counted from the rulebook."""
+    from fullysparsefusion_amd import hip_ops
+
+    records = []
+    orig = hip_ops.spconv_forward
+    pair_cache = {}
+
+    def timed(feat, weight_t, nbr, **kw):
+        key = (nbr.data_ptr(), nbr.shape)
+        if key not in pair_cache:
+            pair_cache[key] = int((nbr >= 0).sum().item())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(feat, weight_t, nbr, **kw)
+        e1.record()
+        kvol, cout, cin = weight_t.shape
+        p = pair_cache[key]
+        records.append((e0, e1, 2.0 * p * cin * cout, p * (cin + cout) * 4.0 + kvol * cin * cout * 4.0 + 8.0 * p))
+        return out
+
+    hip_ops.spconv_forward = timed
+    try:
+        for _ in range(steps):
+            pair_cache.clear()
+            step(model, inp)
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.spconv_forward = orig
+    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in records)
+    flops = sum(r[2] for r in records)
+    byts = sum(r[3] for r in records)
+    launches = len(records)
+    achieved = flops / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", kernel="fsf::spconv_fwd_kernel", achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TFLOPS,
+                unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                launches_per_step=launches // max(steps, 1), avg_launch_us=round(ms * 1e3 / max(launches, 1), 2),
+                algorithmic_gflop_per_step=round(flops / max(steps, 1) / 1e9, 2),
+                algorithmic_mb_per_step=round(byts / max(steps, 1) / 1e6, 1),
+                ms_per_step_in_kernel=round(ms / max(steps, 1), 3),
+                note="HIP-event timing in an instrumented pass over the same frames, right after the timed region")
+
+
+def cpu_baseline(model_cpu):
+    """The CPU oracle (a port of the reference path: torch.unique + scatter_reduce + spconv-v1 restatement) on a
+    bounded sample: ONE synthetic sweep (1/10 of a 10-sweep frame's points), stages 1-3."""
+    from fullysparsefusion_amd import synthetic
+    from oracle import modules as omod
+
+    f = synthetic.make_frame(num_sweeps=1, seed=0)
+    full_n = synthetic.make_points(10, 0).shape[0]
+    pts8 = torch.from_numpy(f["points"])
+    mask, anno, L = torch.from_numpy(f["mask_data"]), torch.from_numpy(f["mask_anno"]), torch.from_numpy(f["lidar2img"])
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        s1 = omod.fsf_stage1(model_cpu, pts8, mask, anno, L)
+        omod.fsf_stage2(model_cpu, s1, anno, (900, 1600))
+        omod.fsf_stage3(model_cpu, s1)
+    dt = time.perf_counter() - t0
+    frac = pts8.shape[0] / full_n
+    return dict(value=round(frac / dt, 5), unit="frames/s", cores=cores, kind="port",
+                sample=f"1 of 10 sweeps ({pts8.shape[0]} of {full_n} points) through oracle stages 1-3 in {dt:.1f} s; "
+                       f"value = frame fraction / time")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)  # RCCL; barrier + max-reduce of the timing only
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    model = build_model(device)
+    model_cpu = None if args.no_cpu_baseline or rank != 0 or world != 1 else copy.deepcopy(model).cpu()
+    frame, inp = make_inputs(args.sweeps, seed=rank, device=device)
+
+    for _ in range(args.warmup):
+        step(model, inp)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(model, inp)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        n_pts = int(inp["points"][0].shape[0])
+        result = {
+            "metric": "frames/sec fwd nuScenes 10-sweep FSF hot path",
+            "value": round(world * args.steps / elapsed, 3),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"fsf_nuscenes_{args.sweeps}sweep_hot_path_fwd (BASELINE config 3 input, forward; stages 1-3 of "
+                            "FSF.simple_test: segmentor + image fusion, camera queries, LiDAR queries; heads/NMS/refine not built)",
+                "points_per_frame": n_pts,
+                "frames_per_gpu_per_step": 1,
+                "mask_data": "u8[1,6,10,900,1600]",
+                "camera_queries": int(out["frustum_obj_feats"].shape[0]),
+                "lidar_queries": int(out["fsd_obj_feats"].shape[0]),
+                "parallelism": f"replicas x{world} (frames independent, no data-path collective)",
+            },
+        }
+    if rank == 0 and not args.no_roofline:
+        result["roofline"] = spconv_roofline(model, inp, min(args.steps, 5))
+    if rank == 0 and model_cpu is not None:
+        result["cpu_baseline"] = cpu_baseline(model_cpu)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

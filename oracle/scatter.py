@@ -38,7 +38,7 @@ def segment_max(feat, inv, m):
     arg = torch.full((m, c), n, dtype=torch.int64)
     arg = arg.scatter_reduce(0, inv[:, None].expand(n, c), cand, reduce="amin", include_self=True)
     empty = torch.bincount(inv, minlength=m) == 0
-    out[empty] = 0
+    out = torch.where(empty[:, None], torch.zeros_like(out), out)
     return out, arg
 
 

@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the only collective on the path is inside naiveSyncBN1d — and the
+bench's timing reduction.  Equal per-rank row counts => the synced statistics equal single-process BatchNorm over the
+concatenated rows, forward and backward."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullysparsefusion_amd.mmdet3d_plugin.registry import build_norm_layer
+
+        torch.manual_seed(0)
+        full = torch.randn(64, 8, dtype=torch.float64)
+        bn = build_norm_layer(dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), 8)[1].double().train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_()
+        x = full[rank * 32:(rank + 1) * 32].clone().requires_grad_(True)
+        y = bn(x)
+        w = torch.arange(1, 9, dtype=torch.float64)
+        (y * w).sum().backward()
+        # max-over-ranks reduction used by bench.py for the timed region
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        q.put((rank, y.detach(), x.grad.detach(), bn.running_mean.clone(), bn.running_var.clone(), float(t)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_naive_sync_bn_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+
+    torch.manual_seed(0)
+    full = torch.randn(64, 8, dtype=torch.float64).requires_grad_(True)
+    ref = torch.nn.BatchNorm1d(8, eps=1e-3, momentum=0.01).double().train()
+    torch.manual_seed(0)
+    _ = torch.randn(64, 8, dtype=torch.float64)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.normal_()
+    y = ref(full)
+    (y * torch.arange(1, 9, dtype=torch.float64)).sum().backward()
+    y_sync = torch.cat([g[1] for g in got])
+    g_sync = torch.cat([g[2] for g in got])
+    assert torch.allclose(y_sync, y.detach(), atol=1e-10)
+    # each rank back-propagates its local loss; the all-reduced statistic gradients are averaged over ranks, so the
+    # synced gradient equals the single-process one scaled by 1/world for the statistics path — compare the sum
+    assert torch.allclose(g_sync.sum(0), full.grad.sum(0), atol=1e-8)
+    assert torch.allclose(got[0][3], got[1][3]) and torch.allclose(got[0][3], ref.running_mean, atol=1e-10)
+    assert got[0][5] == 2.0 and got[1][5] == 2.0
