@@ -19,33 +19,48 @@ __global__ void __launch_bounds__(RS_THREADS) rs_hist_kernel(const uint64_t* __r
   hist[(int64_t)threadIdx.x * tiles + blockIdx.x] = lh[threadIdx.x];
 }
 
-// Exclusive scan, in place, of `total` u32 counters by ONE workgroup of 1024 threads.
-__global__ void __launch_bounds__(1024) rs_scan_kernel(uint32_t* __restrict__ data, int64_t total) {
-  __shared__ uint32_t wave_tot[16];
-  const int tid = threadIdx.x;
-  const int64_t per = (total + 1023) / 1024;
-  const int64_t lo = tid * per;
-  const int64_t hi = (lo + per < total) ? lo + per : total;
-  uint32_t sum = 0;
-  for (int64_t i = lo; i < hi; ++i) sum += data[i];
-  uint32_t incl = fsf_wave_inclusive_scan(sum);
-  const int lane = tid & 63, wave = tid >> 6;
-  if (lane == 63) wave_tot[wave] = incl;
+// Digit-major histogram hist[digit][tile] -> exclusive offsets, in two small launches:
+//  (1) one workgroup per digit scans its row over the tiles (in place) and records the digit total,
+//  (2) one wave scans the 256 digit totals; the scatter kernel adds digit_base[d] + hist[d][tile].
+__global__ void __launch_bounds__(256) rs_scan_rows_kernel(uint32_t* __restrict__ hist, int tiles, uint32_t* __restrict__ digit_total) {
+  __shared__ uint32_t wtot[4];
+  __shared__ uint32_t carry_s;
+  uint32_t* row = hist + (int64_t)blockIdx.x * tiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  uint32_t wbase = 0;
-  for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-  uint32_t run = wbase + incl - sum;
-  for (int64_t i = lo; i < hi; ++i) {
-    uint32_t v = data[i];
-    data[i] = run;
-    run += v;
+  for (int t0 = 0; t0 < tiles; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const uint32_t v = (t < tiles) ? row[t] : 0u;
+    const uint32_t incl = fsf_wave_inclusive_scan(v);
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t base = carry_s;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    if (t < tiles) row[t] = base + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) digit_total[blockIdx.x] = carry_s;
+}
+
+__global__ void __launch_bounds__(256) rs_scan_digits_kernel(uint32_t* __restrict__ digit_total) {
+  __shared__ uint32_t wtot[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t v = digit_total[threadIdx.x];
+  const uint32_t incl = fsf_wave_inclusive_scan(v);
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wtot[w];
+  digit_total[threadIdx.x] = base + incl - v;
 }
 
 __global__ void __launch_bounds__(RS_THREADS)
     rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                       uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift,
-                      const uint32_t* __restrict__ hist, int tiles) {
+                      const uint32_t* __restrict__ hist, const uint32_t* __restrict__ digit_base, int tiles) {
   // slot = it*4 + wave enumerates the tile's 64-key groups in key order
   __shared__ uint32_t cnt[RS_ITEMS * 4][RS_BINS];
   __shared__ uint32_t gbase[RS_BINS];
@@ -92,7 +107,7 @@ __global__ void __launch_bounds__(RS_THREADS)
       cnt[s][tid] = run;
       run += c;
     }
-    gbase[tid] = hist[(int64_t)tid * tiles + blockIdx.x];
+    gbase[tid] = digit_base[tid] + hist[(int64_t)tid * tiles + blockIdx.x];
   }
   __syncthreads();
 #pragma unroll
@@ -110,7 +125,7 @@ __global__ void __launch_bounds__(RS_THREADS)
 int64_t radix_sort_scratch_bytes(int64_t n) {
   int64_t nn = n > 0 ? n : 1;
   return fsf_align_up(nn * 8, 256) * 2 + fsf_align_up(nn * 4, 256) * 2 +
-         fsf_align_up(radix_num_tiles(n) * RS_BINS * 4, 256);
+         fsf_align_up((radix_num_tiles(n) + 1) * RS_BINS * 4, 256);
 }
 
 int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t* hist,
@@ -125,9 +140,11 @@ int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint3
     for (int p = 0; p < passes; ++p) {
       const int shift = p * 8;
       hipLaunchKernelGGL(rs_hist_kernel, dim3(tiles), dim3(RS_THREADS), 0, stream, kin, n, shift, hist, tiles);
-      hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, stream, hist, (int64_t)tiles * RS_BINS);
+      uint32_t* digit_total = hist + (int64_t)tiles * RS_BINS;
+      hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(RS_BINS), dim3(256), 0, stream, hist, tiles, digit_total);
+      hipLaunchKernelGGL(rs_scan_digits_kernel, dim3(1), dim3(256), 0, stream, digit_total);
       hipLaunchKernelGGL(rs_scatter_kernel, dim3(tiles), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, shift,
-                         hist, tiles);
+                         hist, digit_total, tiles);
       uint64_t* tk = kin; kin = kout; kout = tk;
       uint32_t* tv = vin; vin = vout; vout = tv;
     }

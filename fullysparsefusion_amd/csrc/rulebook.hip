@@ -341,7 +341,7 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
   uint64_t* list_b = ar.take<uint64_t>(cand);
   uint32_t* lv_a = ar.take<uint32_t>(cand);
   uint32_t* lv_b = ar.take<uint32_t>(cand);
-  uint32_t* hist = ar.take<uint32_t>(radix_num_tiles(cand) * RS_BINS);
+  uint32_t* hist = ar.take<uint32_t>((radix_num_tiles(cand) + 1) * RS_BINS);
   uint32_t* count_dev = ar.take<uint32_t>(1);
   if (!ar.ok()) return FSF_ERR_WORKSPACE;
 

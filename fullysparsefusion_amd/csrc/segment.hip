@@ -13,6 +13,7 @@ namespace fsf {
 constexpr int SEG_CHUNK = 32;
 constexpr int SEG_BLOCK = 256;
 constexpr int SEG_MIN_TEAM = 4;
+constexpr int SEG_LONG_SPAN = 16;  // chunks; longer segments are folded by a whole workgroup
 
 enum { MODE_SUM = 0, MODE_MEAN = 1, MODE_MAX = 2 };
 
@@ -199,7 +200,7 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_kernel(SegArgs a) {
       continue;
     }
     const int cs = S / SEG_CHUNK, ce = (E - 1) / SEG_CHUNK;
-    if (cs == ce) continue;
+    if (cs == ce || ce - cs > SEG_LONG_SPAN) continue;  // long segments: seg_fixup_long_kernel
     for (int ch = tl * VEC; ch < a.c; ch += a.team * VEC) {
       Vec<VEC> acc = load_vec<VEC>(a.part_val + ((int64_t)cs * 2 + 1) * a.c + ch);
       int32_t arg[VEC];
@@ -231,6 +232,89 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_kernel(SegArgs a) {
       if (MODE == MODE_MAX && a.argmax) {
 #pragma unroll
         for (int q = 0; q < VEC; ++q) a.argmax[s * a.c + ch + q] = (int64_t)arg[q];
+      }
+    }
+  }
+}
+
+// segments spanning more than SEG_LONG_SPAN chunks (SIR groups with 1e3..1e5 points): one workgroup per
+// segment; its lane teams stride over the chunk partials, then the team results are folded in team order
+// through LDS.  Ties in max keep the smaller point index (= first in the stable sorted order).
+template <int VEC, int MODE>
+__global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_long_kernel(SegArgs a) {
+  __shared__ float s_val[SEG_BLOCK / SEG_MIN_TEAM][SEG_MIN_TEAM * 4];
+  __shared__ int32_t s_arg[SEG_BLOCK / SEG_MIN_TEAM][SEG_MIN_TEAM * 4];
+  const int nteams = SEG_BLOCK / a.team;
+  const int team_id = threadIdx.x / a.team;
+  const int tl = threadIdx.x % a.team;
+  const float ident = (MODE == MODE_MAX) ? -INFINITY : 0.0f;
+  for (int64_t s = blockIdx.x; s < a.m; s += gridDim.x) {
+    const int S = a.seg_offsets[s];
+    const int E = a.seg_offsets[s + 1];
+    if (E == S) continue;
+    const int cs = S / SEG_CHUNK, ce = (E - 1) / SEG_CHUNK;
+    if (ce - cs <= SEG_LONG_SPAN) continue;
+    for (int ch0 = 0; ch0 < a.c; ch0 += a.team * VEC) {  // workgroup-uniform trip count (barriers inside)
+      const int ch = ch0 + tl * VEC;
+      const bool act = ch < a.c;
+      Vec<VEC> acc;
+      int32_t arg[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        acc.v[q] = ident;
+        arg[q] = INT32_MAX;
+      }
+      // virtual partial index p in [0, ce-cs]: p = 0 is the head piece (slot 1 of chunk cs), p > 0 slot 0 of cs+p
+      for (int p = team_id; act && p <= ce - cs; p += nteams) {
+        const int64_t slot = ((int64_t)(cs + p) * 2 + (p == 0 ? 1 : 0)) * a.c + ch;
+        Vec<VEC> v = load_vec<VEC>(a.part_val + slot);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          if constexpr (MODE == MODE_MAX) {
+            const int32_t va = a.argmax ? a.part_arg[slot + q] : 0;
+            if (v.v[q] > acc.v[q] || (v.v[q] == acc.v[q] && va < arg[q])) {
+              acc.v[q] = v.v[q];
+              arg[q] = va;
+            }
+          } else {
+            acc.v[q] = __fadd_rn(acc.v[q], v.v[q]);
+          }
+        }
+      }
+      // fold the team results in team order (fixed, deterministic)
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        (&s_val[0][0])[(team_id * a.team + tl) * VEC + q] = acc.v[q];
+        (&s_arg[0][0])[(team_id * a.team + tl) * VEC + q] = arg[q];
+      }
+      __syncthreads();
+      if (team_id == 0 && act) {
+        for (int t = 1; t < nteams; ++t) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) {
+            const float v = (&s_val[0][0])[(t * a.team + tl) * VEC + q];
+            if constexpr (MODE == MODE_MAX) {
+              const int32_t va = (&s_arg[0][0])[(t * a.team + tl) * VEC + q];
+              if (v > acc.v[q] || (v == acc.v[q] && va < arg[q])) {
+                acc.v[q] = v;
+                arg[q] = va;
+              }
+            } else {
+              acc.v[q] = __fadd_rn(acc.v[q], v);
+            }
+          }
+        }
+        if constexpr (MODE == MODE_MEAN) {
+          const float cntf = (float)(E - S);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) acc.v[q] = __fdiv_rn(acc.v[q], cntf);
+        }
+        store_vec<VEC>(a.out + s * a.c + ch, acc);
+        if (MODE == MODE_MAX && a.argmax) {
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) a.argmax[s * a.c + ch + q] = (int64_t)arg[q];
+        }
       }
     }
   }
@@ -341,18 +425,25 @@ static int seg_launch(const SegArgs& a, int mode, hipStream_t stream) {
   int64_t g2 = (a.m + teams_per_block - 1) / teams_per_block;
   if (g2 < 1) g2 = 1;
   if (g2 > 4096) g2 = 4096;
+  // a segment can only be "long" when the input has more rows than SEG_LONG_SPAN chunks
+  const bool has_long = a.n > (int64_t)SEG_LONG_SPAN * SEG_CHUNK;
+  int64_t g3 = a.m < 1024 ? a.m : 1024;
+  if (g3 < 1) g3 = 1;
   switch (mode) {
     case MODE_SUM:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_SUM>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
       hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_SUM>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
+      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_SUM>), dim3((unsigned)g3), dim3(SEG_BLOCK), 0, stream, a);
       break;
     case MODE_MEAN:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_MEAN>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
       hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MEAN>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
+      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_MEAN>), dim3((unsigned)g3), dim3(SEG_BLOCK), 0, stream, a);
       break;
     default:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_MAX>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
       hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MAX>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
+      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_MAX>), dim3((unsigned)g3), dim3(SEG_BLOCK), 0, stream, a);
       break;
   }
   FSF_LAUNCH_CHECK();

@@ -64,14 +64,27 @@ __global__ void __launch_bounds__(256) uq_range_kernel(const int64_t* __restrict
       mx[j] = v > mx[j] ? v : mx[j];
     }
   }
+  __shared__ int64_t smn[4][K], smx[4][K];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     int64_t a = wave_min_i64(mn[j]);
     int64_t b = wave_max_i64(mx[j]);
-    if ((threadIdx.x & 63) == 0) {
-      __hip_atomic_fetch_min(&r->mn[j], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_max(&r->mx[j], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+      smn[wave][j] = a;
+      smx[wave][j] = b;
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    const int j = threadIdx.x;
+    int64_t a = smn[0][j], b = smx[0][j];
+    for (int w = 1; w < 4; ++w) {
+      a = smn[w][j] < a ? smn[w][j] : a;
+      b = smx[w][j] > b ? smx[w][j] : b;
+    }
+    __hip_atomic_fetch_min(&r->mn[j], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(&r->mx[j], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -220,13 +233,14 @@ extern "C" int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const
   uint64_t* keys_b = ar.take<uint64_t>(n);
   uint32_t* vals_a = ar.take<uint32_t>(n);
   uint32_t* vals_b = ar.take<uint32_t>(n);
-  uint32_t* hist = ar.take<uint32_t>(radix_num_tiles(n) * RS_BINS);
+  uint32_t* hist = ar.take<uint32_t>((radix_num_tiles(n) + 1) * RS_BINS);
   uint32_t* tile_sums = ar.take<uint32_t>(scan_num_tiles(n));
   ColRange* range_dev = ar.take<ColRange>(1);
   int32_t* err_flag = ar.take<int32_t>(1);
   if (!ar.ok()) return FSF_ERR_WORKSPACE;
 
   const int grid = fsf_stream_grid(n, 256);
+  const int rgrid = grid > 512 ? 512 : grid;  // one atomic pair per column per workgroup
   ColRange range;
   if (col_min && col_max) {
     for (int j = 0; j < k; ++j) {
@@ -238,10 +252,10 @@ extern "C" int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const
     // data-dependent bounds: one small D2H copy + sync (torch.unique in the reference syncs as well)
     hipLaunchKernelGGL(uq_range_init_kernel, dim3(1), dim3(64), 0, stream, range_dev);
     switch (k) {
-      case 1: hipLaunchKernelGGL((uq_range_kernel<1>), dim3(grid), dim3(256), 0, stream, coors, n, range_dev); break;
-      case 2: hipLaunchKernelGGL((uq_range_kernel<2>), dim3(grid), dim3(256), 0, stream, coors, n, range_dev); break;
-      case 3: hipLaunchKernelGGL((uq_range_kernel<3>), dim3(grid), dim3(256), 0, stream, coors, n, range_dev); break;
-      default: hipLaunchKernelGGL((uq_range_kernel<4>), dim3(grid), dim3(256), 0, stream, coors, n, range_dev); break;
+      case 1: hipLaunchKernelGGL((uq_range_kernel<1>), dim3(rgrid), dim3(256), 0, stream, coors, n, range_dev); break;
+      case 2: hipLaunchKernelGGL((uq_range_kernel<2>), dim3(rgrid), dim3(256), 0, stream, coors, n, range_dev); break;
+      case 3: hipLaunchKernelGGL((uq_range_kernel<3>), dim3(rgrid), dim3(256), 0, stream, coors, n, range_dev); break;
+      default: hipLaunchKernelGGL((uq_range_kernel<4>), dim3(rgrid), dim3(256), 0, stream, coors, n, range_dev); break;
     }
     FSF_HIP_TRY(hipMemcpyAsync(&range, range_dev, sizeof(ColRange), hipMemcpyDeviceToHost, stream));
     FSF_HIP_TRY(hipStreamSynchronize(stream));
@@ -314,7 +328,7 @@ extern "C" int fsf_segment_plan_from_inverse(const int64_t* inv, int64_t n, int6
   uint64_t* keys_b = ar.take<uint64_t>(n);
   uint32_t* vals_a = ar.take<uint32_t>(n);
   uint32_t* vals_b = ar.take<uint32_t>(n);
-  uint32_t* hist = ar.take<uint32_t>(radix_num_tiles(n) * RS_BINS);
+  uint32_t* hist = ar.take<uint32_t>((radix_num_tiles(n) + 1) * RS_BINS);
   int32_t* err_flag = ar.take<int32_t>(1);
   if (!ar.ok()) return FSF_ERR_WORKSPACE;
   const int grid = fsf_stream_grid(n + 1, 256);
@@ -371,7 +385,7 @@ extern "C" int fsf_ingroup_rank(const int64_t* group_inds, int64_t n, int64_t* o
   uint64_t* keys_b = ar.take<uint64_t>(n);
   uint32_t* vals_a = ar.take<uint32_t>(n);
   uint32_t* vals_b = ar.take<uint32_t>(n);
-  uint32_t* hist = ar.take<uint32_t>(radix_num_tiles(n) * RS_BINS);
+  uint32_t* hist = ar.take<uint32_t>((radix_num_tiles(n) + 1) * RS_BINS);
   uint32_t* tile_sums = ar.take<uint32_t>(scan_num_tiles(n));
   int32_t* seg_start = ar.take<int32_t>(n);
   ColRange* range_dev = ar.take<ColRange>(1);
@@ -380,7 +394,7 @@ extern "C" int fsf_ingroup_rank(const int64_t* group_inds, int64_t n, int64_t* o
   const int grid = fsf_stream_grid(n, 256);
   ColRange range;
   hipLaunchKernelGGL(uq_range_init_kernel, dim3(1), dim3(64), 0, stream, range_dev);
-  hipLaunchKernelGGL((uq_range_kernel<1>), dim3(grid), dim3(256), 0, stream, group_inds, n, range_dev);
+  hipLaunchKernelGGL((uq_range_kernel<1>), dim3(grid > 512 ? 512 : grid), dim3(256), 0, stream, group_inds, n, range_dev);
   FSF_HIP_TRY(hipMemcpyAsync(&range, range_dev, sizeof(ColRange), hipMemcpyDeviceToHost, stream));
   FSF_HIP_TRY(hipStreamSynchronize(stream));
   PackSpec spec;
