@@ -24,6 +24,7 @@ _ARGTYPES = {
     "fsf_segment_reduce": [_P, c_i64, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_segment_reduce_backward": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, _P],
     "fsf_gather_rows": [_P, c_i64, c_i32, _P, c_i64, _P, _P],
+    "fsf_norm_act": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i32, _P, _P],
     "fsf_voxel2point": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, _P, _P],
     "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
@@ -369,3 +370,18 @@ def connected_components(points: torch.Tensor, dist: float, batch_idx: Optional[
     check(h.fsf_connected_components(ptr(points), n, points.size(1), ptr(batch_idx), float(dist), ptr(labels), None,
                                      ptr(ws), ws.numel(), stream_ptr()), "fsf_connected_components")
     return labels
+
+
+# ------------------------------------------------------------------------------------ norm + activation
+_ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
+
+
+def norm_act(x: torch.Tensor, gamma, beta, eps: float, norm: str, act, inplace=True):
+    """fsf_norm_act: LayerNorm ('ln') or per-channel affine ('affine') fused with ReLU/GELU; x f32 [n,c]."""
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
+    n, c = x.shape
+    out = x if inplace else torch.empty_like(x)
+    check(_L().fsf_norm_act(ptr(x), n, c, ptr(gamma), ptr(beta), float(eps), {"ln": 0, "affine": 1}[norm], _ACTS[act],
+                            ptr(out), stream_ptr()), "fsf_norm_act")
+    return out

@@ -127,6 +127,40 @@ def get_activation_layer(act, dim=None):
     return table[act]()
 
 
+def fused_norm_act(x, norm, act):
+    """`act(norm(x))` for x [n, C].  When no gradient is needed and the pair is LayerNorm / eval BatchNorm1d followed by
+    ReLU / GELU, this is ONE fused HIP pass over the activations (fsf_norm_act) instead of two or three ATen kernels;
+    otherwise the torch modules run (training, exotic activations)."""
+    act_code = None
+    if isinstance(act, nn.ReLU):
+        act_code = "relu"
+    elif isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none":
+        act_code = "gelu"
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in norm.parameters()))
+    if act_code is not None and not needs_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(1) <= 512:
+        x = x.contiguous()
+        if isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1:
+            return hip_ops.norm_act(x, norm.weight, norm.bias, norm.eps, "ln", act_code)
+        if isinstance(norm, nn.BatchNorm1d) and not norm.training and norm.track_running_stats:
+            invstd = torch.rsqrt(norm.running_var + norm.eps)
+            scale = norm.weight * invstd if norm.affine else invstd
+            shift = (norm.bias if norm.affine else 0) - norm.running_mean * scale
+            return hip_ops.norm_act(x, scale.contiguous(), shift.contiguous(), 0.0, "affine", act_code)
+    return act(norm(x))
+
+
+class MLPBlock(nn.Sequential):
+    """[Linear, norm, act(, Dropout)] with the same child names ('0', '1', '2'[, '3']) as the reference's
+    nn.Sequential, so state-dict keys are unchanged; forward fuses norm + act."""
+
+    def forward(self, x):
+        mods = list(self._modules.values())
+        x = fused_norm_act(mods[0](x), mods[1], mods[2])
+        for m in mods[3:]:
+            x = m(x)
+        return x
+
+
 def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act="relu", bias=False, dropout=0):
     """Sequential of [Linear(bias) -> norm -> act (-> Dropout)] blocks; with `is_head` the last entry is a
     plain Linear(bias=True).  Dense GEMMs stay on rocBLAS through torch."""
@@ -139,6 +173,6 @@ def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act="relu", bias
             block = [nn.Linear(last, c, bias=bias), build_norm_layer(norm_cfg, c)[1], get_activation_layer(act, c)]
             if dropout > 0:
                 block.append(nn.Dropout(dropout))
-            layers.append(nn.Sequential(*block))
+            layers.append(MLPBlock(*block))
         last = c
     return nn.Sequential(*layers)

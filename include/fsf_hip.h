@@ -137,6 +137,18 @@ int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* co
                     const float range_min[3], float padding, float* out, uint8_t* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K12  fused row normalisation + activation (the tail of every `Linear -> norm -> act` MLP block)
+ * Replaces: LayerNorm (or eval-mode BatchNorm1d) followed by GELU / ReLU as separate ATen kernels in the MLPs built
+ *   by build_mlp (projects/mmdet3d_plugin/ops/sst_ops.py:808-833) and in DynamicVFELayer [UNVENDORED].
+ *   norm: 0 = LayerNorm over the c channels of each row (biased variance, eps inside the sqrt; gamma/beta [c] or
+ *             both NULL), 1 = per-channel affine y = x * gamma + beta (eval BatchNorm folded by the caller)
+ *   act:  0 = none, 1 = ReLU, 2 = GELU (erf form)
+ *   x f32 [n,c] -> out f32 [n,c] (out may alias x); c <= 512.
+ */
+int fsf_norm_act(const float* x, int64_t n, int32_t c, const float* gamma, const float* beta, float eps, int32_t norm,
+                 int32_t act, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K13-K15  LiDAR -> camera projection + per-point instance-mask gather
  * Replaces: FSF.prj_points_2d (projects/mmdet3d_plugin/models/detectors/FSF.py:169-200) and
  *   FSF.points_in_mask (:202-226) for one batch sample; the caller loops samples like frustum_gather (:228-258).

@@ -396,3 +396,26 @@ def test_ingroup_rank(ops, device):
     g = torch.from_numpy(rng.integers(0, 300, 50000))
     r = ops.ingroup_rank(g.to(device)).cpu()
     assert torch.equal(r, oscatter.ingroup_rank(g))
+
+
+# ------------------------------------------------------------------------------------ norm + activation
+@pytest.mark.parametrize("c", [3, 16, 32, 64, 128, 133, 180, 256, 512])
+@pytest.mark.parametrize("act", ["gelu", "relu", None])
+def test_norm_act_vs_torch(ops, device, c, act):
+    torch.manual_seed(c)
+    n = 5000
+    x = torch.randn(n, c) * 3 + 0.5
+    ln = torch.nn.LayerNorm(c, eps=1e-3)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5)
+        ln.bias.normal_()
+    f = {"gelu": torch.nn.functional.gelu, "relu": torch.relu, None: lambda t: t}[act]
+    w64, b64 = ln.weight.detach().double(), ln.bias.detach().double()
+    want = f(torch.nn.functional.layer_norm(x.double(), (c,), w64, b64, 1e-3)).float()
+    got = ops.norm_act(x.to(device), ln.weight.detach().to(device), ln.bias.detach().to(device), 1e-3, "ln", act, inplace=False)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+    scale, shift = torch.rand(c) + 0.5, torch.randn(c)
+    want2 = f(x * scale + shift)
+    got2 = ops.norm_act(x.to(device), scale.to(device), shift.to(device), 0.0, "affine", act, inplace=False)
+    # GELU's 1 + erf(x/sqrt2) cancels for x << 0: absolute error of a few 1e-6 on tiny outputs, both sides in fp32
+    np.testing.assert_allclose(got2.cpu().numpy(), want2.numpy(), rtol=1e-6, atol=5e-6)
