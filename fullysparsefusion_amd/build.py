@@ -46,7 +46,8 @@ def _deps_mtime():
 
 
 def _compile_one(src, obj, verbose):
-    cmd = [_hipcc(), *HIPCC_FLAGS, "-c", src, "-o", obj]
+    extra = os.environ.get("FSF_EXTRA_HIPCC_FLAGS", "").split()  # ablation builds (scratch/ablate.sh), never set in product runs
+    cmd = [_hipcc(), *HIPCC_FLAGS, *extra, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

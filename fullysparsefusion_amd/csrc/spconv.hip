@@ -4,12 +4,21 @@
 // One workgroup (4 waves) owns a tile of TM=64 output rows x TN<=128 output channels whose accumulator
 // lives in LDS for the whole kernel-offset loop, so every output row is written exactly once (no
 // scatter-add atomics, deterministic).  For each kernel offset k the rows of the tile that actually have
-// a neighbour are COMPACTED (ballot prefix, precomputed per tile), their input rows are gathered with
-// coalesced 16-byte loads into an LDS A tile, and v_mfma_f32_16x16x4_f32 runs over ceil(cnt/16) row blocks
-// only — on LiDAR data ~22 % of (row, offset) pairs exist, so the dense 27-offset product would waste 4/5
-// of the matrix-core time.  Each wave owns a 32-column slice and keeps its B (weight) fragments for the
-// current offset in registers (weights pre-transposed to [k][cout][cin] so a lane's four consecutive
-// K values arrive as one 16-byte load).  Eval-mode BN affine + residual + ReLU are the fused epilogue.
+// a neighbour are COMPACTED (ballot prefix, precomputed per tile) and v_mfma_f32_16x16x4_f32 runs over
+// ceil(cnt/16) row blocks only — on LiDAR data 20-55 % of (row, offset) pairs exist, so the dense 27-offset
+// product would waste most of the matrix-core time.  Each wave owns a TN/4-column slice and keeps its B
+// (weight) fragments for the current stage in registers (weights pre-transposed to [k][cout][cin] so a lane's
+// four consecutive K values arrive as one 16-byte load).
+//
+// Stages = (offset k, 64-wide cin chunk).  The compacted input rows of stage s+1 are gathered by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging) into the second half of a double-buffered A tile while the
+// matrix cores work on stage s, and the B fragments of s+1 stream into a second register set; ONE barrier per
+// stage.  The DMA writes LDS linearly (wave base + lane*16), so the bank-conflict swizzle is applied to the
+// per-lane SOURCE address and undone on the ds_read_b128 side (16-byte chunk c of row j lives at c ^ (j & 15)).
+// Tiles are mapped to workgroups so that each XCD walks a contiguous range of output rows (neighbouring tiles
+// re-gather the same input rows -> L2 hits).  Layers with too few tiles to fill 256 CUs split the offset loop
+// over gridDim.z and a second kernel folds the partial tiles in fixed order.  Eval-mode BN affine + residual +
+// ReLU are the fused epilogue.
 //
 // Roofline: flops = 2*P*Cin*Cout on the fp32 MFMA (157.3 TF/s peak),
 // bytes = P*(Cin+Cout)*4 + kvol*Cin*Cout*4 + 8P.
@@ -20,9 +29,12 @@ namespace fsf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SC_TM = 64;
-constexpr int SC_KC = 128;
-constexpr int SC_ASTRIDE = SC_KC + 4;
+constexpr int SC_KC = 64;                 // cin chunk per stage (floats)
+constexpr int SC_NSTEPS = SC_KC / 16;     // 16-wide K steps per stage
+constexpr int SC_AROW = SC_KC;            // A tile row stride in floats (linear: the DMA cannot pad)
+constexpr int SC_ABUF = SC_TM * SC_AROW;  // floats per A buffer
 constexpr int SC_MAXK = 27;
+constexpr int SC_NXCD = 8;
 
 struct SpconvArgs {
   const float* feat;
@@ -32,137 +44,444 @@ struct SpconvArgs {
   const float* shift;
   const float* residual;
   float* out;
+  float* partial;  // [ksplit][m_out][cout] when ksplit > 1
   int64_t m_in, m_out;
-  int cin, cout, kvol, relu;
+  int cin, cout, kvol, relu, ksplit;
 };
 
+__device__ __forceinline__ float epilogue_one(const SpconvArgs& a, float x, int64_t o, int col) {
+  if (a.scale) x = __fmaf_rn(x, a.scale[col], a.shift[col]);
+  else if (a.shift) x = __fadd_rn(x, a.shift[col]);
+  if (a.residual) x = __fadd_rn(x, a.residual[o * a.cout + col]);
+  if (a.relu) x = fmaxf(x, 0.0f);
+  return x;
+}
+
+// LDS carve shared by both kernels
 template <int TN>
-__global__ void __launch_bounds__(256, 2) spconv_fwd_kernel(SpconvArgs a) {
-  constexpr int CS_STRIDE = TN + 4;
-  constexpr int WCOLS = TN / 4;    // columns per wave
-  constexpr int NCT = WCOLS / 16;  // 16-column MFMA tiles per wave
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Cs = reinterpret_cast<float*>(smem);                          // [SC_TM][CS_STRIDE]
-  float* As = Cs + SC_TM * CS_STRIDE;                                  // [SC_TM][SC_ASTRIDE]
-  int32_t* rl_in = reinterpret_cast<int32_t*>(As + SC_TM * SC_ASTRIDE);  // [SC_MAXK][SC_TM]
-  uint8_t* rl_loc = reinterpret_cast<uint8_t*>(rl_in + SC_MAXK * SC_TM);  // [SC_MAXK][SC_TM]
-  int32_t* rl_cnt = reinterpret_cast<int32_t*>(rl_loc + SC_MAXK * SC_TM);  // [SC_MAXK]
+struct SpconvSmem {
+  static constexpr int CS_STRIDE = TN + 4;
+  static constexpr int CS_FLOATS = (SC_TM + 1) * CS_STRIDE;  // + dump row
+  static constexpr int A_FLOATS = 2 * SC_ABUF > SC_TM * (SC_KC + 4) ? 2 * SC_ABUF : SC_TM * (SC_KC + 4);
+  static constexpr size_t bytes() {
+    return (size_t)(CS_FLOATS + A_FLOATS) * 4 + (size_t)SC_MAXK * SC_TM * 4 + (size_t)SC_MAXK * SC_TM + (size_t)SC_MAXK * 8 + 64;
+  }
+};
 
+// XCD-aware tile mapping (bijective): workgroup b runs on XCD b % 8; give each XCD a contiguous tile range
+__device__ __forceinline__ int xcd_tile(int b, int ntiles) {
+  const int q = ntiles / SC_NXCD, r = ntiles % SC_NXCD, xcd = b % SC_NXCD;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / SC_NXCD;
+}
+
+// per-tile compaction lists for every offset + the active-offset list of this z-split.
+// The tile's [64][kvol] block of the neighbour table is contiguous in HBM: it is staged through LDS with
+// coalesced loads (`stage`, >= 64*kvol ints), then each wave compacts offsets k = wave, wave+4, ...
+// rl_in holds ELEMENT offsets (input row * cin) so the gather needs no 64-bit multiply per row.
+__device__ __forceinline__ void build_row_lists(const SpconvArgs& a, int64_t o0, int zsplit, int32_t* stage, int32_t* rl_in,
+                                                uint8_t* rl_loc, int32_t* rl_cnt, int32_t* act_k, int32_t* act_n) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t o0 = (int64_t)blockIdx.x * SC_TM;
-  const int n0 = blockIdx.y * TN;
-
-  // ---- per-tile compaction lists for every offset (wave w handles k = w, w+4, ...) ----
+  const int64_t rows_left = a.m_out - o0;
+  const int nvalid = (int)((rows_left < SC_TM ? rows_left : SC_TM) * a.kvol);
+  const int32_t* src = a.nbr + o0 * a.kvol;
+  for (int t = tid; t < SC_TM * a.kvol; t += 256) stage[t] = (t < nvalid) ? src[t] : -1;
+  __syncthreads();
   for (int k = wave; k < a.kvol; k += 4) {
-    const int64_t o = o0 + lane;
-    const int32_t in = (o < a.m_out) ? a.nbr[o * a.kvol + k] : -1;
+    const int32_t in = stage[lane * a.kvol + k];
     const bool has = in >= 0;
     const uint64_t bal = __ballot(has);
     if (has) {
       const int pos = (int)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-      rl_in[k * SC_TM + pos] = in;
+      rl_in[k * SC_TM + pos] = in * a.cin;
       rl_loc[k * SC_TM + pos] = (uint8_t)lane;
     }
     if (lane == 0) rl_cnt[k] = (int)__popcll(bal);
   }
-  for (int t = tid; t < SC_TM * CS_STRIDE; t += 256) Cs[t] = 0.0f;
+  __syncthreads();
+  if (wave == 0) {  // active offsets of this z-split, in ascending k (ballot prefix instead of a serial loop)
+    const bool on = lane < a.kvol && rl_cnt[lane < a.kvol ? lane : 0] > 0;
+    const uint64_t bal = __ballot(on);
+    const int rank = (int)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    const bool mine = on && (rank % a.ksplit == zsplit);
+    const uint64_t bal2 = __ballot(mine);
+    if (mine) act_k[(int)__popcll(bal2 & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = lane;
+    if (lane == 0) act_n[0] = (int)__popcll(bal2);
+  }
+  __syncthreads();
+}
+
+template <int TN>
+__device__ __forceinline__ void write_tile(const SpconvArgs& a, const float* Cs, int64_t o0, int n0, int zsplit) {
+  constexpr int CS_STRIDE = TN + 4;
+  constexpr int F4_PER_ROW = TN / 4;
+  constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+  // a thread keeps the same 4 columns for all of its rows: the BN affine is loaded once
+  const int c4 = (threadIdx.x % F4_PER_ROW) * 4;
+  const int r0 = threadIdx.x / F4_PER_ROW;
+  const int col = n0 + c4;
+  if (col >= a.cout) return;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool fin = a.ksplit == 1;
+  if (fin && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + col);
+  if (fin && a.shift) sh = *reinterpret_cast<const float4*>(a.shift + col);
+#pragma unroll 4
+  for (int r = r0; r < SC_TM; r += ROWS_PER_PASS) {
+    const int64_t o = o0 + r;
+    if (o >= a.m_out) break;
+    float4 v = *reinterpret_cast<const float4*>(Cs + r * CS_STRIDE + c4);
+    if (!fin) {
+      *reinterpret_cast<float4*>(a.partial + ((int64_t)zsplit * a.m_out + o) * a.cout + col) = v;
+      continue;
+    }
+    if (a.scale) {
+      v.x = __fmaf_rn(v.x, sc.x, sh.x); v.y = __fmaf_rn(v.y, sc.y, sh.y);
+      v.z = __fmaf_rn(v.z, sc.z, sh.z); v.w = __fmaf_rn(v.w, sc.w, sh.w);
+    } else if (a.shift) {
+      v.x = __fadd_rn(v.x, sh.x); v.y = __fadd_rn(v.y, sh.y); v.z = __fadd_rn(v.z, sh.z); v.w = __fadd_rn(v.w, sh.w);
+    }
+    if (a.residual) {
+      const float4 rs = *reinterpret_cast<const float4*>(a.residual + o * a.cout + col);
+      v.x = __fadd_rn(v.x, rs.x); v.y = __fadd_rn(v.y, rs.y); v.z = __fadd_rn(v.z, rs.z); v.w = __fadd_rn(v.w, rs.w);
+    }
+    if (a.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(a.out + o * a.cout + col) = v;
+  }
+}
+
+#ifdef FSF_ABL_TIMING
+__device__ long long fsf_dbg[4096 * 8];
+#define FSF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) fsf_dbg[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#else
+#define FSF_STAMP(i) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------------------
+// Fast path: cin % 64 == 0.  LDS-DMA double-buffered A tile, register double-buffered B, one barrier per stage.
+template <int TN>
+__global__ void __launch_bounds__(256, 2) spconv_fwd_dma_kernel(SpconvArgs a) {
+  using SM = SpconvSmem<TN>;
+  constexpr int CS_STRIDE = SM::CS_STRIDE;
+  constexpr int WCOLS = TN / 4;    // columns per wave
+  constexpr int NCT = WCOLS / 16;  // 16-column MFMA tiles per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Cs = reinterpret_cast<float*>(smem);                         // [SC_TM + 1][CS_STRIDE], row SC_TM = dump row
+  float* As = Cs + SM::CS_FLOATS;                                     // [2][SC_TM][SC_AROW], swizzled 16-B chunks
+  int32_t* rl_in = reinterpret_cast<int32_t*>(As + SM::A_FLOATS);     // [SC_MAXK][SC_TM]
+  uint8_t* rl_loc = reinterpret_cast<uint8_t*>(rl_in + SC_MAXK * SC_TM);
+  int32_t* rl_cnt = reinterpret_cast<int32_t*>(rl_loc + SC_MAXK * SC_TM);
+  int32_t* act_k = rl_cnt + SC_MAXK;
+  int32_t* act_n = act_k + SC_MAXK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int64_t o0 = (int64_t)tile * SC_TM;
+  const int n0 = blockIdx.y * TN;
+  const int zsplit = blockIdx.z;
+
+  FSF_STAMP(0);
+  // the A buffers double as the staging area of the neighbour-table block; afterwards C (incl. the dump row) and
+  // both A buffers are zeroed: rows past the live data must hold finite values
+  build_row_lists(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
+  FSF_STAMP(1);
+  for (int t = tid; t < (SM::CS_FLOATS + SM::A_FLOATS) / 4; t += 256)
+    reinterpret_cast<float4*>(Cs)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  FSF_STAMP(2);
+
+  const int lrow = lane & 15;  // A row / B column inside a 16x16 tile
+  const int kgrp = lane >> 4;  // which 4-float K group this lane feeds
+  const int wcol0 = wave * WCOLS;
+  const int nchunks = a.cin / SC_KC;
+  const int nstages = act_n[0] * nchunks;
+
+  f32x4 bcur[NCT][SC_NSTEPS], bnext[NCT][SC_NSTEPS];
+
+  // LDS-DMA gather of stage s into A buffer `buf`: one wave instruction moves 4 rows (64 lanes x 16 B); wave w
+  // takes row groups w, w+4, ...; a group is issued iff its first row is live (wave-uniform branch)
+  auto issue_gather = [&](int k, int cin0, int buf) {
+    const int cnt = rl_cnt[k];
+    float* abuf = As + buf * SC_ABUF;
+#pragma unroll
+    for (int it = 0; it < SC_TM / 16; ++it) {
+      const int g = wave + 4 * it;  // row group: rows 4g .. 4g+3
+      if (4 * g < cnt) {
+        int j = 4 * g + (lane >> 4);
+        const int phys = lane & 15;
+        const int chunk = phys ^ (j & 15);  // logical 16-B chunk that must land at physical slot `phys` of row j
+        j = j < cnt ? j : cnt - 1;          // rows past cnt re-read the last live row (finite filler)
+        const float* src = a.feat + rl_in[k * SC_TM + j] + cin0 + 4 * chunk;
+#ifndef FSF_ABL_NO_GATHER
+        __builtin_amdgcn_global_load_lds(src, abuf + 4 * g * SC_AROW, 16, 0, 0);
+#else
+        asm volatile("" ::"v"(src));
+#endif
+      }
+    }
+  };
+  // lane owns an adjacent column pair (see the C accesses); columns >= cout read column 0 and are never written out
+  const float* wlane[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int col = n0 + wcol0 + NCT * lrow + ct;
+    wlane[ct] = a.wt + (int64_t)(col < a.cout ? col : 0) * a.cin + 4 * kgrp;
+  }
+  const int64_t wk_stride = (int64_t)a.cout * a.cin;
+  auto load_b = [&](int k, int cin0, f32x4 (&bf)[NCT][SC_NSTEPS]) {
+    const int64_t koff = k * wk_stride + cin0;  // wave-uniform
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const float* wp = wlane[ct] + koff;
+#pragma unroll
+      for (int st = 0; st < SC_NSTEPS; ++st)  // columns >= cout read column 0 (finite) and are never written out;
+        bf[ct][st] = *reinterpret_cast<const f32x4*>(wp + 16 * st);  // a select here would wait for the load at once
+    }
+  };
+
+  if (nstages > 0) {
+    issue_gather(act_k[0], 0, 0);
+    load_b(act_k[0], 0, bcur);
+  }
+  __syncthreads();  // (the compiler drains the DMA before the barrier) A[0] complete and visible
+  FSF_STAMP(3);
+
+  // Accumulators of ALL row blocks of the current offset stay in registers across its cin chunks: the LDS C tile is
+  // read once and written once per (offset, row block) instead of once per 64-wide chunk (the C read-modify-write
+  // through LDS is what competes with the MFMA issue otherwise).  Lane (lrow, kgrp) owns columns wcol0 + 2*lrow + ct
+  // (adjacent pair -> one 8-byte LDS access) of compact rows rb*16 + kgrp*4 + r.
+  constexpr int MAXRB = SC_TM / 16;
+  f32x4 acc[MAXRB][NCT];
+  int loc[MAXRB][4];
+  int chunk_c = 0, ki = 0;
+  for (int s = 0; s < nstages; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nstages) {
+      const bool same_k = chunk_c + 1 < nchunks;
+      const int nk = act_k[same_k ? ki : ki + 1], ncin0 = same_k ? (chunk_c + 1) * SC_KC : 0;
+      issue_gather(nk, ncin0, cur ^ 1);  // lands in the other A buffer while the matrix cores work on stage s
+#ifndef FSF_ABL_NO_BLOAD
+      load_b(nk, ncin0, bnext);
+#else
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int st = 0; st < SC_NSTEPS; ++st) bnext[ct][st] = bcur[ct][st];
+#endif
+    }
+    {
+      const int k = act_k[ki];
+      const int cnt = rl_cnt[k];
+      const int nrb = (cnt + 15) >> 4;
+      const float* abuf = As + cur * SC_ABUF;
+#ifdef FSF_ABL_NO_CRMW
+      if (s == 0) {
+#else
+      if (chunk_c == 0) {
+#endif
+#pragma unroll
+        for (int rb = 0; rb < MAXRB; ++rb) {
+          if (rb < nrb) {
+            // compacted row -> local output row (4 consecutive bytes); rows past cnt go to the dump row
+            const uint32_t packed = *reinterpret_cast<const uint32_t*>(rl_loc + k * SC_TM + rb * 16 + kgrp * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int j = rb * 16 + kgrp * 4 + r;
+              loc[rb][r] = (j < cnt) ? (int)((packed >> (8 * r)) & 0xffu) : SC_TM;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float* cp = Cs + loc[rb][r] * CS_STRIDE + wcol0 + NCT * lrow;
+              if constexpr (NCT == 2) {
+                const float2 c2 = *reinterpret_cast<const float2*>(cp);
+                acc[rb][0][r] = (loc[rb][r] < SC_TM) ? c2.x : 0.0f;
+                acc[rb][1][r] = (loc[rb][r] < SC_TM) ? c2.y : 0.0f;
+              } else {
+                acc[rb][0][r] = (loc[rb][r] < SC_TM) ? cp[0] : 0.0f;
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < MAXRB; ++rb) {
+        if (rb < nrb) {
+          f32x4 af[SC_NSTEPS];
+          const int arow_idx = rb * 16 + lrow;
+          const float* arow = abuf + arow_idx * SC_AROW;
+#pragma unroll
+          for (int st = 0; st < SC_NSTEPS; ++st)  // logical chunk 4*st + kgrp lives at physical (chunk ^ (row & 15))
+#ifndef FSF_ABL_NO_AREAD
+            af[st] = *reinterpret_cast<const f32x4*>(arow + 4 * ((4 * st + kgrp) ^ (arow_idx & 15)));
+#else
+            af[st] = f32x4{(float)arow_idx, 1.f, 2.f, (float)st};
+#endif
+#pragma unroll
+          for (int st = 0; st < SC_NSTEPS; ++st) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+              for (int ct = 0; ct < NCT; ++ct)
+#ifndef FSF_ABL_NO_MFMA
+                acc[rb][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[st][t], bcur[ct][st][t], acc[rb][ct], 0, 0, 0);
+#else
+                acc[rb][ct][t] += af[st][t] * bcur[ct][st][t];
+#endif
+            }
+          }
+        }
+      }
+#ifdef FSF_ABL_NO_CRMW
+      if (s == nstages - 1) {
+#else
+      if (chunk_c == nchunks - 1) {
+#endif
+#pragma unroll
+        for (int rb = 0; rb < MAXRB; ++rb) {
+          if (rb < nrb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* cp = Cs + loc[rb][r] * CS_STRIDE + wcol0 + NCT * lrow;
+              if constexpr (NCT == 2) *reinterpret_cast<float2*>(cp) = make_float2(acc[rb][0][r], acc[rb][1][r]);
+              else cp[0] = acc[rb][0][r];
+            }
+          }
+        }
+      }
+    }
+    if (++chunk_c == nchunks) {
+      chunk_c = 0;
+      ++ki;
+    }
+    if (s + 1 < nstages) {
+      // Pin the first use of the prefetched B fragments HERE (after the MFMA loop): without this hipcc hoists the
+      // bcur <- bnext copies above the loop and with them the vmcnt(0) wait, which serialises the prefetch.
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int st = 0; st < SC_NSTEPS; ++st) asm volatile("" : "+v"(bnext[ct][st]) : : "memory");
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int st = 0; st < SC_NSTEPS; ++st) bcur[ct][st] = bnext[ct][st];
+    }
+#ifndef FSF_ABL_NO_BARRIER
+    __syncthreads();  // A[cur^1] landed + visible, everyone is done reading A[cur]
+#endif
+  }
+  FSF_STAMP(4);
+  write_tile<TN>(a, Cs, o0, n0, zsplit);
+  FSF_STAMP(5);
+#ifdef FSF_ABL_TIMING
+  if (threadIdx.x == 0 && blockIdx.x < 4096) { fsf_dbg[blockIdx.x * 8 + 6] = nstages; fsf_dbg[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(0); }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Generic path (cin % 16 == 0, any cin): synchronous register-staged gather, used for the odd channel counts
+// only the unit tests exercise.
+template <int TN>
+__global__ void __launch_bounds__(256, 2) spconv_fwd_generic_kernel(SpconvArgs a) {
+  using SM = SpconvSmem<TN>;
+  constexpr int CS_STRIDE = SM::CS_STRIDE;
+  constexpr int WCOLS = TN / 4;
+  constexpr int NCT = WCOLS / 16;
+  constexpr int ASTRIDE = SC_KC + 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Cs = reinterpret_cast<float*>(smem);
+  float* As = Cs + SM::CS_FLOATS;  // [SC_TM][ASTRIDE]
+  int32_t* rl_in = reinterpret_cast<int32_t*>(As + SM::A_FLOATS);
+  uint8_t* rl_loc = reinterpret_cast<uint8_t*>(rl_in + SC_MAXK * SC_TM);
+  int32_t* rl_cnt = reinterpret_cast<int32_t*>(rl_loc + SC_MAXK * SC_TM);
+  int32_t* act_k = rl_cnt + SC_MAXK;
+  int32_t* act_n = act_k + SC_MAXK;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = xcd_tile(blockIdx.x, gridDim.x);
+  const int64_t o0 = (int64_t)tile * SC_TM;
+  const int n0 = blockIdx.y * TN;
+  const int zsplit = blockIdx.z;
+  build_row_lists(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
+  for (int t = tid; t < SM::CS_FLOATS + SM::A_FLOATS; t += 256) Cs[t] = 0.0f;
   __syncthreads();
 
-  const int lrow = lane & 15;   // A row / B column inside a 16x16 tile
-  const int kgrp = lane >> 4;   // which 4-float K group this lane feeds
+  const int lrow = lane & 15, kgrp = lane >> 4;
   const int wcol0 = wave * WCOLS;
-
-  for (int k = 0; k < a.kvol; ++k) {
+  const int nact = act_n[0];
+  for (int ai = 0; ai < nact; ++ai) {
+    const int k = act_k[ai];
     const int cnt = rl_cnt[k];
-    if (cnt == 0) continue;
     const int nrb = (cnt + 15) >> 4;
     for (int cin0 = 0; cin0 < a.cin; cin0 += SC_KC) {
       const int kc = (a.cin - cin0 < SC_KC) ? (a.cin - cin0) : SC_KC;  // multiple of 16
-      // ---- gather the compacted input rows into As ----
-      {
-        const int f4_per_row = kc >> 2;
-        const int rows_per_pass = 256 / f4_per_row;
-        const int v = tid % f4_per_row;
-        const int r0 = tid / f4_per_row;
-        for (int j = r0; j < cnt; j += rows_per_pass) {
-          const int64_t in = rl_in[k * SC_TM + j];
-          const float4 val = *reinterpret_cast<const float4*>(a.feat + in * a.cin + cin0 + 4 * v);
-          *reinterpret_cast<float4*>(As + j * SC_ASTRIDE + 4 * v) = val;
-        }
+      const int f4_per_row = kc >> 2;
+      for (int t = tid; t < cnt * f4_per_row; t += 256) {
+        const int j = t / f4_per_row, v = t % f4_per_row;
+        const int64_t in_off = rl_in[k * SC_TM + j];
+        *reinterpret_cast<float4*>(As + j * ASTRIDE + 4 * v) =
+            *reinterpret_cast<const float4*>(a.feat + in_off + cin0 + 4 * v);
       }
       __syncthreads();
-      // ---- B fragments of this offset / cin chunk, kept in registers across row blocks ----
-      f32x4 bfrag[NCT][SC_KC / 16];
       const int nsteps = kc >> 4;
-#pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        const int col = n0 + wcol0 + ct * 16 + lrow;
-        const float* wp = a.wt + ((int64_t)k * a.cout + (col < a.cout ? col : 0)) * a.cin + cin0 + 4 * kgrp;
-#pragma unroll
-        for (int s = 0; s < SC_KC / 16; ++s) {
-          f32x4 w = {0.f, 0.f, 0.f, 0.f};
-          if (s < nsteps && col < a.cout) w = *reinterpret_cast<const f32x4*>(wp + 16 * s);
-          bfrag[ct][s] = w;
-        }
-      }
       for (int rb = 0; rb < nrb; ++rb) {
         f32x4 acc[NCT];
         int loc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = rb * 16 + kgrp * 4 + r;
-          loc[r] = (j < cnt) ? (int)rl_loc[k * SC_TM + j] : -1;
+          const int l = (int)rl_loc[k * SC_TM + (j < SC_TM ? j : SC_TM - 1)];
+          loc[r] = (j < cnt) ? l : SC_TM;
         }
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[ct][r] = (loc[r] >= 0) ? Cs[loc[r] * CS_STRIDE + wcol0 + ct * 16 + lrow] : 0.0f;
-        }
-        const float* arow = As + (rb * 16 + lrow) * SC_ASTRIDE + 4 * kgrp;
+          for (int r = 0; r < 4; ++r) {
+            const float c = Cs[loc[r] * CS_STRIDE + wcol0 + ct * 16 + lrow];
+            acc[ct][r] = (loc[r] < SC_TM) ? c : 0.0f;
+          }
+        const float* arow = As + (rb * 16 + lrow) * ASTRIDE + 4 * kgrp;
+        for (int st = 0; st < nsteps; ++st) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * st);
 #pragma unroll
-        for (int s = 0; s < SC_KC / 16; ++s) {
-          if (s < nsteps) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 16 * s);
+          for (int ct = 0; ct < NCT; ++ct) {
+            const int col = n0 + wcol0 + ct * 16 + lrow;
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            if (col < a.cout)
+              w = *reinterpret_cast<const f32x4*>(a.wt + ((int64_t)k * a.cout + col) * a.cin + cin0 + 4 * kgrp + 16 * st);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-#pragma unroll
-              for (int ct = 0; ct < NCT; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bfrag[ct][s][t], acc[ct], 0, 0, 0);
-            }
+            for (int t = 0; t < 4; ++t) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], w[t], acc[ct], 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
+        for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (loc[r] >= 0) Cs[loc[r] * CS_STRIDE + wcol0 + ct * 16 + lrow] = acc[ct][r];
-        }
+          for (int r = 0; r < 4; ++r) Cs[loc[r] * CS_STRIDE + wcol0 + ct * 16 + lrow] = acc[ct][r];
       }
       __syncthreads();
     }
   }
+  write_tile<TN>(a, Cs, o0, n0, zsplit);
+}
 
-  // ---- epilogue: BN affine (+ residual) (+ ReLU), coalesced float4 stores ----
-  constexpr int F4_PER_ROW = TN / 4;
-  for (int t = tid; t < SC_TM * F4_PER_ROW; t += 256) {
-    const int r = t / F4_PER_ROW;
-    const int c4 = (t % F4_PER_ROW) * 4;
-    const int64_t o = o0 + r;
-    const int col = n0 + c4;
-    if (o >= a.m_out || col >= a.cout) continue;
-    float4 v = *reinterpret_cast<const float4*>(Cs + r * CS_STRIDE + c4);
-    float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float x = vv[q];
-      if (a.scale) x = __fmaf_rn(x, a.scale[col + q], a.shift[col + q]);
-      else if (a.shift) x = __fadd_rn(x, a.shift[col + q]);
-      if (a.residual) x = __fadd_rn(x, a.residual[o * a.cout + col + q]);
-      if (a.relu) x = fmaxf(x, 0.0f);
-      vv[q] = x;
+// folds the ksplit partial tiles in fixed order and applies the epilogue
+__global__ void __launch_bounds__(256) spconv_reduce_kernel(SpconvArgs a) {
+  const int64_t total4 = a.m_out * (a.cout / 4);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = t / (a.cout / 4);
+    const int col = (int)(t - o * (a.cout / 4)) * 4;
+    float4 acc = *reinterpret_cast<const float4*>(a.partial + o * a.cout + col);
+    for (int z = 1; z < a.ksplit; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(a.partial + ((int64_t)z * a.m_out + o) * a.cout + col);
+      acc.x = __fadd_rn(acc.x, v.x);
+      acc.y = __fadd_rn(acc.y, v.y);
+      acc.z = __fadd_rn(acc.z, v.z);
+      acc.w = __fadd_rn(acc.w, v.w);
     }
-    *reinterpret_cast<float4*>(a.out + o * a.cout + col) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    acc.x = epilogue_one(a, acc.x, o, col);
+    acc.y = epilogue_one(a, acc.y, o, col + 1);
+    acc.z = epilogue_one(a, acc.z, o, col + 2);
+    acc.w = epilogue_one(a, acc.w, o, col + 3);
+    *reinterpret_cast<float4*>(a.out + o * a.cout + col) = acc;
   }
 }
 
@@ -179,15 +498,30 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <int TN>
-static size_t spconv_smem_bytes() {
-  return (size_t)SC_TM * (TN + 4) * 4 + (size_t)SC_TM * SC_ASTRIDE * 4 + (size_t)SC_MAXK * SC_TM * 4 +
-         (size_t)SC_MAXK * SC_TM + (size_t)SC_MAXK * 4 + 64;
+static int pick_ksplit(int64_t tiles, int cout_blocks, int kvol) {
+  // 256 CUs x 2 resident workgroups = 512 slots.  A launch of B workgroups runs in ceil(B / 512) rounds and the last,
+  // partly filled round costs a full tile duration (571 tiles = 2 rounds for 1.1 rounds of work).  Splitting the
+  // offset loop z ways makes B large and each workgroup short, so the tail shrinks; the price is the partial-tile
+  // round trip (2 * z * m_out * cout * 4 B) folded by spconv_reduce_kernel.
+  const int64_t blocks = tiles * cout_blocks;
+  if (kvol < 3) return 1;
+  constexpr int64_t kTarget = 2048;  // >= 4 rounds
+  if (blocks >= kTarget) return 1;
+  int64_t g = (kTarget + blocks - 1) / blocks;
+  if (g > 9) g = 9;
+  if (g > kvol / 3) g = kvol / 3;
+  return (int)(g < 1 ? 1 : g);
 }
 
 }  // namespace fsf
 
 using namespace fsf;
+
+#ifdef FSF_ABL_TIMING
+extern "C" int fsf_debug_read(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fsf::fsf_dbg), sizeof(long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int fsf_spconv_transpose_weight(const float* weight, int32_t kvol, int32_t cin, int32_t cout, float* weight_t,
                                            void* stream_) {
@@ -199,34 +533,52 @@ extern "C" int fsf_spconv_transpose_weight(const float* weight, int32_t kvol, in
   return FSF_OK;
 }
 
+extern "C" int64_t fsf_spconv_workspace_bytes(int64_t m_out, int32_t cout, int32_t kvol) {
+  const int64_t tiles = (m_out + SC_TM - 1) / SC_TM;
+  const int g = pick_ksplit(tiles, cout <= 64 ? 1 : (cout + 127) / 128, kvol);
+  return g > 1 ? fsf_align_up((int64_t)g * m_out * cout * 4, 256) + 256 : 256;
+}
+
 extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float* weight_t, int32_t kvol,
                                   int32_t cout, const int32_t* nbr, int64_t m_out, const float* scale, const float* shift,
-                                  const float* residual, int32_t relu, float* out, void* stream_) {
+                                  const float* residual, int32_t relu, float* out, void* workspace, int64_t workspace_bytes,
+                                  void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (m_in < 0 || m_out < 0 || cin < 1 || cout < 1 || kvol < 1 || !weight_t || (scale && !shift) ||
       (m_out > 0 && (!nbr || !out)) || (m_in > 0 && !feat))
     return FSF_ERR_INVALID_ARG;
   if (kvol > SC_MAXK || (cin % 16) != 0 || (cout % 4) != 0) return FSF_ERR_UNSUPPORTED;
+  if (m_in * cin >= ((int64_t)1 << 31)) return FSF_ERR_UNSUPPORTED;  // row lists hold 32-bit element offsets
   if (m_out == 0) return FSF_OK;
-  SpconvArgs a{feat, weight_t, nbr, scale, shift, residual, out, m_in, m_out, (int)cin, (int)cout, (int)kvol, (int)relu};
-  const unsigned tiles = (unsigned)((m_out + SC_TM - 1) / SC_TM);
+  const int64_t tiles = (m_out + SC_TM - 1) / SC_TM;
+  if (tiles >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
+  const int cout_blocks = cout <= 64 ? 1 : (cout + 127) / 128;
+  const int ksplit = pick_ksplit(tiles, cout_blocks, kvol);
+  if (workspace_bytes < fsf_spconv_workspace_bytes(m_out, cout, kvol) || (ksplit > 1 && !workspace)) return FSF_ERR_WORKSPACE;
+  SpconvArgs a{feat, weight_t, nbr, scale, shift, residual, out, (float*)workspace, m_in, m_out,
+               (int)cin, (int)cout, (int)kvol, (int)relu, ksplit};
+  const dim3 grid((unsigned)tiles, cout_blocks, ksplit);
+  const bool fast = (cin % SC_KC) == 0;
+#define FSF_SPCONV_LAUNCH(KERNEL, TN_)                                                                                \
+  do {                                                                                                                \
+    static bool attr_set = false;                                                                                     \
+    const size_t smem_bytes = SpconvSmem<TN_>::bytes();                                                               \
+    if (!attr_set) {                                                                                                  \
+      FSF_HIP_TRY(hipFuncSetAttribute((const void*)KERNEL<TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes)); \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((KERNEL<TN_>), grid, dim3(256), smem_bytes, stream, a);                                        \
+  } while (0)
   if (cout <= 64) {
-    static bool attr_set64 = false;
-    if (!attr_set64) {
-      FSF_HIP_TRY(hipFuncSetAttribute((const void*)spconv_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)spconv_smem_bytes<64>()));
-      attr_set64 = true;
-    }
-    hipLaunchKernelGGL((spconv_fwd_kernel<64>), dim3(tiles, (cout + 63) / 64), dim3(256), spconv_smem_bytes<64>(), stream, a);
+    if (fast) FSF_SPCONV_LAUNCH(spconv_fwd_dma_kernel, 64);
+    else FSF_SPCONV_LAUNCH(spconv_fwd_generic_kernel, 64);
   } else {
-    static bool attr_set128 = false;
-    if (!attr_set128) {
-      FSF_HIP_TRY(hipFuncSetAttribute((const void*)spconv_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)spconv_smem_bytes<128>()));
-      attr_set128 = true;
-    }
-    hipLaunchKernelGGL((spconv_fwd_kernel<128>), dim3(tiles, (cout + 127) / 128), dim3(256), spconv_smem_bytes<128>(), stream, a);
+    if (fast) FSF_SPCONV_LAUNCH(spconv_fwd_dma_kernel, 128);
+    else FSF_SPCONV_LAUNCH(spconv_fwd_generic_kernel, 128);
   }
+#undef FSF_SPCONV_LAUNCH
+  if (ksplit > 1)
+    hipLaunchKernelGGL(spconv_reduce_kernel, dim3(fsf_stream_grid(m_out * (cout / 4), 256)), dim3(256), 0, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -33,7 +33,8 @@ _ARGTYPES = {
     "fsf_rulebook_strided": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P],
     "fsf_rulebook_to_pairs": [_P, c_i64, c_i32, _P, c_i64, _P, _P],
     "fsf_spconv_transpose_weight": [_P, c_i32, c_i32, c_i32, _P, _P],
-    "fsf_spconv_forward": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P],
+    "fsf_spconv_workspace_bytes": [c_i64, c_i32, c_i32],
+    "fsf_spconv_forward": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
     "fsf_connected_components_workspace_bytes": [c_i64],
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
@@ -336,8 +337,10 @@ def spconv_forward(feat: torch.Tensor, weight_t: torch.Tensor, nbr: torch.Tensor
     if residual is not None:
         residual = residual.contiguous()
         assert residual.shape == out.shape
-    check(_L().fsf_spconv_forward(ptr(feat), m_in, cin, ptr(weight_t), kvol, cout, ptr(nbr), m_out, ptr(scale),
-                                  ptr(shift), ptr(residual), int(bool(relu)), ptr(out), stream_ptr()),
+    h = _L()
+    ws = _lib.workspace(h.fsf_spconv_workspace_bytes(m_out, cout, kvol), feat.device)
+    check(h.fsf_spconv_forward(ptr(feat), m_in, cin, ptr(weight_t), kvol, cout, ptr(nbr), m_out, ptr(scale), ptr(shift),
+                               ptr(residual), int(bool(relu)), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_spconv_forward")
     return out
 
