@@ -18,8 +18,8 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 template <int TEAM, int ACT, int NORM>
 __global__ void __launch_bounds__(256)
-    norm_act_kernel(const float* __restrict__ x, int64_t n, int c, const float* __restrict__ gamma,
-                    const float* __restrict__ beta, float eps, float* __restrict__ out) {
+    norm_act_kernel(const float* x, int64_t n, int c, const float* __restrict__ gamma,
+                    const float* __restrict__ beta, float eps, float* out, int64_t out_stride) {
   const int tl = threadIdx.x % TEAM;
   const int teams_per_block = 256 / TEAM;
   const float inv_c = 1.0f / (float)c;
@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256)
       for (int o = TEAM >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
       rstd = rsqrtf(q * inv_c + eps);
     }
-    float* orow = out + row * c;
+    float* orow = out + row * out_stride;
 #pragma unroll
     for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
       const int ch = tl + k * TEAM;
@@ -73,13 +73,13 @@ __global__ void __launch_bounds__(256)
 
 template <int TEAM>
 static int launch_norm_act(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps, int norm,
-                           int act, float* out, hipStream_t stream) {
+                           int act, float* out, int64_t out_stride, hipStream_t stream) {
   const int teams_per_block = 256 / TEAM;
   int64_t g = (n + teams_per_block - 1) / teams_per_block;
   if (g > 16384) g = 16384;
   if (g < 1) g = 1;
 #define FSF_NA(N_, A_) \
-  hipLaunchKernelGGL((norm_act_kernel<TEAM, A_, N_>), dim3((unsigned)g), dim3(256), 0, stream, x, n, c, gamma, beta, eps, out)
+  hipLaunchKernelGGL((norm_act_kernel<TEAM, A_, N_>), dim3((unsigned)g), dim3(256), 0, stream, x, n, c, gamma, beta, eps, out, out_stride)
   if (norm == NORM_LN) {
     if (act == ACT_GELU) FSF_NA(NORM_LN, ACT_GELU);
     else if (act == ACT_RELU) FSF_NA(NORM_LN, ACT_RELU);
@@ -99,14 +99,16 @@ static int launch_norm_act(const float* x, int64_t n, int c, const float* gamma,
 using namespace fsf;
 
 extern "C" int fsf_norm_act(const float* x, int64_t n, int32_t c, const float* gamma, const float* beta, float eps,
-                            int32_t norm, int32_t act, float* out, void* stream_) {
+                            int32_t norm, int32_t act, float* out, int64_t out_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || c < 1 || norm < 0 || norm > 1 || act < 0 || act > 2 || (n > 0 && (!x || !out)) || ((gamma == nullptr) != (beta == nullptr)) ||
       (norm == NORM_AFFINE && !gamma))
     return FSF_ERR_INVALID_ARG;
   if (c > 64 * NA_MAX_PER_LANE) return FSF_ERR_UNSUPPORTED;
+  if (out_stride == 0) out_stride = c;
+  if (out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
-  if (c <= 16 * NA_MAX_PER_LANE / 2) return launch_norm_act<16>(x, n, c, gamma, beta, eps, norm, act, out, stream);
-  if (c <= 32 * NA_MAX_PER_LANE / 2) return launch_norm_act<32>(x, n, c, gamma, beta, eps, norm, act, out, stream);
-  return launch_norm_act<64>(x, n, c, gamma, beta, eps, norm, act, out, stream);
+  if (c <= 16 * NA_MAX_PER_LANE / 2) return launch_norm_act<16>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
+  if (c <= 32 * NA_MAX_PER_LANE / 2) return launch_norm_act<32>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
+  return launch_norm_act<64>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
 }

@@ -61,6 +61,7 @@ struct SegArgs {
   int64_t m;
   int c;
   int team;  // lanes per team (power of two, 4..64)
+  int64_t feat_stride;  // row stride of feat in floats (>= c)
 };
 
 template <int VEC, int MODE>
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_reduce_kernel(SegArgs a) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             e[u] = (j0 + u < hi) ? my_rows[j0 + u - lo] : make_int2(-1, -1);
-            if (e[u].x >= 0) v[u] = load_vec<VEC>(a.feat + (int64_t)e[u].x * a.c + ch);
+            if (e[u].x >= 0) v[u] = load_vec<VEC>(a.feat + (int64_t)e[u].x * a.feat_stride + ch);
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
@@ -330,13 +331,13 @@ static int pick_team(int c, int vec) {
 template <int VEC>
 __global__ void __launch_bounds__(256)
     gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, int c,
-                       float* __restrict__ out) {
+                       float* __restrict__ out, int64_t out_stride) {
   const int cv = c / VEC;
   const int64_t total = n * cv;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / cv;
     const int col = (int)(t - i * cv) * VEC;
-    store_vec<VEC>(out + i * c + col, load_vec<VEC>(src + idx[i] * c + col));
+    store_vec<VEC>(out + i * out_stride + col, load_vec<VEC>(src + idx[i] * c + col));
   }
 }
 
@@ -450,7 +451,7 @@ static int seg_launch(const SegArgs& a, int mode, hipStream_t stream) {
   return FSF_OK;
 }
 
-extern "C" int fsf_segment_reduce(const float* feat, int64_t n, int32_t c, const int32_t* order, const int64_t* inv,
+extern "C" int fsf_segment_reduce(const float* feat, int64_t feat_stride, int64_t n, int32_t c, const int32_t* order, const int64_t* inv,
                                   const int32_t* seg_offsets, int64_t m, int32_t mode, float* out, int64_t* argmax,
                                   void* workspace, int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -467,8 +468,10 @@ extern "C" int fsf_segment_reduce(const float* feat, int64_t n, int32_t c, const
   a.part_val = ar.take<float>(nchunks * 2 * c);
   a.part_arg = ar.take<int32_t>(nchunks * 2 * c);
   a.n = n; a.m = m; a.c = c;
+  a.feat_stride = feat_stride > 0 ? feat_stride : c;
+  if (a.feat_stride < c) return FSF_ERR_INVALID_ARG;
   if (!ar.ok()) return FSF_ERR_WORKSPACE;
-  const bool vec4 = (c % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
+  const bool vec4 = (c % 4 == 0) && (a.feat_stride % 4 == 0) && (((uintptr_t)feat | (uintptr_t)out) % 16 == 0);
   if (vec4) {
     a.team = pick_team(c, 4);
     return seg_launch<4>(a, mode, stream);
@@ -503,18 +506,20 @@ extern "C" int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int
 }
 
 extern "C" int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
-                               void* stream_) {
+                               int64_t out_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)m;
   if (n < 0 || c < 1 || (n > 0 && (!src || !idx || !out))) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
-  const bool vec4 = (c % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
+  if (out_stride == 0) out_stride = c;
+  if (out_stride < c) return FSF_ERR_INVALID_ARG;
+  const bool vec4 = (c % 4 == 0) && (out_stride % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
   if (vec4)
     hipLaunchKernelGGL((gather_rows_kernel<4>), dim3(fsf_stream_grid(n * (c / 4), 256)), dim3(256), 0, stream, src, idx,
-                       n, (int)c, out);
+                       n, (int)c, out, out_stride);
   else
     hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(fsf_stream_grid(n * c, 256)), dim3(256), 0, stream, src, idx, n,
-                       (int)c, out);
+                       (int)c, out, out_stride);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

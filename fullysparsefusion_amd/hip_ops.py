@@ -21,10 +21,10 @@ _ARGTYPES = {
     "fsf_segment_plan_workspace_bytes": [c_i64, c_i64],
     "fsf_segment_plan_from_inverse": [_P, c_i64, c_i64, _P, _P, _P, _P, c_i64, _P],
     "fsf_segment_reduce_workspace_bytes": [c_i64, c_i64, c_i32],
-    "fsf_segment_reduce": [_P, c_i64, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_segment_reduce": [_P, c_i64, c_i64, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_segment_reduce_backward": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, _P],
-    "fsf_gather_rows": [_P, c_i64, c_i32, _P, c_i64, _P, _P],
-    "fsf_norm_act": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i32, _P, _P],
+    "fsf_gather_rows": [_P, c_i64, c_i32, _P, c_i64, _P, c_i64, _P],
+    "fsf_norm_act": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i32, _P, c_i64, _P],
     "fsf_voxel2point": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, _P, _P],
     "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
@@ -51,6 +51,15 @@ def _L():
             getattr(h, name).argtypes = argtypes
         _configured = True
     return h
+
+
+def _rows_view(t):
+    """(tensor, row stride in elements) for a 2-D tensor whose rows are contiguous (a column slice of a wider
+    row-major buffer qualifies); anything else is made contiguous."""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.size(1):
+        return t, t.stride(0)
+    t = t.contiguous()
+    return t, t.size(1)
 
 
 MODE_SUM, MODE_MEAN, MODE_MAX = 0, 1, 2
@@ -160,7 +169,7 @@ def segment_reduce(feat: torch.Tensor, plan: SegmentPlan, mode: str, return_argm
     """fsf_segment_reduce: feat f32 [n,c] -> out f32 [m,c] (+ argmax i64 [m,c] for mode='max')."""
     require_cuda(feat)
     assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.size(0) == plan.n
-    feat = feat.contiguous()
+    feat, feat_stride = _rows_view(feat)
     n, c = feat.shape
     dev = feat.device
     out = torch.empty((plan.m, c), dtype=torch.float32, device=dev)
@@ -168,7 +177,7 @@ def segment_reduce(feat: torch.Tensor, plan: SegmentPlan, mode: str, return_argm
     argmax = torch.empty((plan.m, c), dtype=torch.int64, device=dev) if (return_argmax and md == MODE_MAX) else None
     h = _L()
     ws = _lib.workspace(h.fsf_segment_reduce_workspace_bytes(n, plan.m, c), dev)
-    check(h.fsf_segment_reduce(ptr(feat), n, c, ptr(plan.order), ptr(plan.inv), ptr(plan.seg_offsets), plan.m, md,
+    check(h.fsf_segment_reduce(c_p(feat.data_ptr()), feat_stride, n, c, ptr(plan.order), ptr(plan.inv), ptr(plan.seg_offsets), plan.m, md,
                                ptr(out), ptr(argmax), ptr(ws), ws.numel(), stream_ptr()), "fsf_segment_reduce")
     return (out, argmax) if return_argmax else out
 
@@ -184,15 +193,18 @@ def segment_reduce_backward(grad_out: torch.Tensor, plan: SegmentPlan, mode: str
     return grad_feat
 
 
-def gather_rows(src: torch.Tensor, idx: torch.Tensor):
-    """fsf_gather_rows: out[i,:] = src[idx[i],:]."""
-    require_cuda(src, idx)
+def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """fsf_gather_rows: out[i,:] = src[idx[i],:].  `out` may be a column slice of a wider row-major buffer."""
+    require_cuda(src, idx, out)
     assert src.dtype == torch.float32 and src.dim() == 2
     src = src.contiguous()
     idx = idx.to(torch.int64).contiguous()
     n, (m, c) = idx.numel(), src.shape
-    out = torch.empty((n, c), dtype=torch.float32, device=src.device)
-    check(_L().fsf_gather_rows(ptr(src), m, c, ptr(idx), n, ptr(out), stream_ptr()), "fsf_gather_rows")
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) >= c
+    check(_L().fsf_gather_rows(ptr(src), m, c, ptr(idx), n, c_p(out.data_ptr()), out.stride(0), stream_ptr()),
+          "fsf_gather_rows")
     return out
 
 
@@ -379,12 +391,15 @@ def connected_components(points: torch.Tensor, dist: float, batch_idx: Optional[
 _ACTS = {None: 0, "none": 0, "relu": 1, "gelu": 2}
 
 
-def norm_act(x: torch.Tensor, gamma, beta, eps: float, norm: str, act, inplace=True):
-    """fsf_norm_act: LayerNorm ('ln') or per-channel affine ('affine') fused with ReLU/GELU; x f32 [n,c]."""
-    require_cuda(x)
+def norm_act(x: torch.Tensor, gamma, beta, eps: float, norm: str, act, inplace=True, out: Optional[torch.Tensor] = None):
+    """fsf_norm_act: LayerNorm ('ln') or per-channel affine ('affine') fused with ReLU/GELU; x f32 [n,c].
+    `out` may be a column slice of a wider row-major buffer."""
+    require_cuda(x, out)
     assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()
     n, c = x.shape
-    out = x if inplace else torch.empty_like(x)
+    if out is None:
+        out = x if inplace else torch.empty_like(x)
+    assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) >= c
     check(_L().fsf_norm_act(ptr(x), n, c, ptr(gamma), ptr(beta), float(eps), {"ln": 0, "affine": 1}[norm], _ACTS[act],
-                            ptr(out), stream_ptr()), "fsf_norm_act")
+                            c_p(out.data_ptr()), out.stride(0), stream_ptr()), "fsf_norm_act")
     return out

@@ -136,8 +136,9 @@ class FSF(SingleStageFSD):
         return torch.cat(feats, 0), torch.cat(bzs, 0), torch.cat(pts, 0), torch.cat(ids, 0), torch.cat(ws, 0)
 
     def extract_fg_pts(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights):
-        fg_mask = obj_id_tensor.sum((-2, -1)) > 0
-        return pts_feat[fg_mask], bz_coor[fg_mask], points[fg_mask], obj_id_tensor[fg_mask], point_fg_weights[fg_mask]
+        fg_idx = (obj_id_tensor.sum((-2, -1)) > 0).nonzero(as_tuple=False).squeeze(1)  # one compaction for all five
+        return (pts_feat.index_select(0, fg_idx), bz_coor.index_select(0, fg_idx), points.index_select(0, fg_idx),
+                obj_id_tensor.index_select(0, fg_idx), point_fg_weights.index_select(0, fg_idx))
 
     def map_voxel_center_to_point(self, voxel_mean, voxel2point_inds):
         return gather_by_inverse(voxel_mean, voxel2point_inds)

@@ -173,6 +173,8 @@ class SingleStageFSD(nn.Module):
         return out_dict
 
     def update_sample_results_by_mask(self, sampled_out, valid_mask_list):
+        # one nonzero() per mask, reused by every field (the reference re-derives it per field via data[mask])
+        valid_idx = [m.nonzero(as_tuple=False).squeeze(1) for m in valid_mask_list]
         for k in sampled_out:
             old_data = sampled_out[k]
             if len(old_data[0]) == len(valid_mask_list[0]) or "fg_mask" in k:
@@ -181,11 +183,10 @@ class SingleStageFSD(nn.Module):
                     for data, mask in zip(old_data, valid_mask_list):
                         new_data = data.clone()
                         new_data[data] = mask
-                        assert new_data.sum() == mask.sum()
                         new_data_list.append(new_data)
                     sampled_out[k] = new_data_list
                 else:
-                    sampled_out[k] = [data[mask] for data, mask in zip(old_data, valid_mask_list)]
+                    sampled_out[k] = [data.index_select(0, idx) for data, idx in zip(old_data, valid_idx)]
         return sampled_out
 
     def combine_classes(self, data_dict, name_list):
@@ -225,8 +226,7 @@ class SingleStageFSD(nn.Module):
         if self.cfg["offset_weight"] != "max":
             raise NotImplementedError
         weight = ((seg_logit - seg_logit.max(1)[0][:, None]).abs() < 1e-6).float()
-        assert ((weight == 1).any(1)).all()
-        return weight / weight.sum(1)[:, None]  # ties split evenly
+        return weight / weight.sum(1)[:, None]  # ties split evenly (the row maximum always has weight 1)
 
     def sample(self, dict_to_sample, offset, gt_bboxes_3d=None, gt_labels_3d=None):
         if self.cfg.get("group_sample", False):
@@ -239,27 +239,30 @@ class SingleStageFSD(nn.Module):
         bsz = int(batch_idx.max().item()) + 1
         cfg = self.train_cfg if self.training else self.test_cfg
         seg_logits = dict_to_sample["seg_logits"]
-        assert (seg_logits < 0).any()  # make sure no sigmoid applied
-        assert seg_logits.size(1) == self.num_classes + 1
+        assert seg_logits.size(1) == self.num_classes + 1  # (the reference also host-syncs on `(seg_logits < 0).any()`)
         seg_scores = seg_logits.softmax(1)
         offset = offset.reshape(-1, self.num_classes + 1, 3)
         seg_points = dict_to_sample["seg_points"][:, :3]
-        fg_mask_list, center_preds_list = [], []
+        fg_mask_list, fg_idx_list, center_preds_list = [], [], []
         cls_score_thrs, group_names, class_names = cfg["score_thresh"], cfg["group_names"], cfg["class_names"]
         assert len(group_names) == len(cls_score_thrs)
         grouped_score = self.gather_group_by_names(seg_scores[:, :-1])
         for i in range(len(group_names)):
             fg_mask = self.get_fg_mask(grouped_score, None, i, None, None, None)
-            if len(torch.unique(batch_idx[fg_mask])) < bsz:
-                fg_mask[self.get_sample_beg_position(batch_idx, fg_mask)] = True  # at least one point per sample
+            if bsz == 1:
+                fg_mask[0] |= ~fg_mask.any()  # "at least one point per sample" (:832-834) without the unique() sync
+            elif len(torch.unique(batch_idx[fg_mask])) < bsz:
+                fg_mask[self.get_sample_beg_position(batch_idx, fg_mask)] = True
             fg_mask_list.append(fg_mask)
+            fg_idx = fg_mask.nonzero(as_tuple=False).squeeze(1)  # one compaction per group, reused for every field
+            fg_idx_list.append(fg_idx)
             tmp_idx = [class_names.index(name) for name in group_names[i]]
-            this_offset = offset[:, tmp_idx, :][fg_mask, ...]
-            this_logits = seg_logits[:, tmp_idx][fg_mask, :]
+            this_offset = offset.index_select(0, fg_idx)[:, tmp_idx, :]
+            this_logits = seg_logits.index_select(0, fg_idx)[:, tmp_idx]
             offset_weight = self.get_offset_weight(this_logits)
             this_offset = (this_offset * offset_weight[:, :, None]).sum(dim=1)
-            center_preds_list.append(seg_points[fg_mask, :] + this_offset)
-        output_dict = {name: [data[m] for m in fg_mask_list] for name, data in dict_to_sample.items()}
+            center_preds_list.append(seg_points.index_select(0, fg_idx) + this_offset)
+        output_dict = {name: [data.index_select(0, idx) for idx in fg_idx_list] for name, data in dict_to_sample.items()}
         output_dict["fg_mask_list"] = fg_mask_list
         output_dict["center_preds"] = center_preds_list
         return output_dict
@@ -300,9 +303,12 @@ class ClusterAssigner(nn.Module):
         coors = hip_ops.voxelize_divfloor(points, cluster_vsize, self.point_cloud_range[:3], order="xyz",
                                           batch_idx=batch_idx.long())
         valid_mask = filter_almost_empty(coors, min_points=self.min_points)
-        if not valid_mask.any():
+        valid_idx = valid_mask.nonzero(as_tuple=False).squeeze(1)
+        if valid_idx.numel() == 0:
             valid_mask = ~valid_mask
-        points, batch_idx, coors = points[valid_mask], batch_idx[valid_mask], coors[valid_mask]
+            valid_idx = valid_mask.nonzero(as_tuple=False).squeeze(1)
+        points, batch_idx, coors = points.index_select(0, valid_idx), batch_idx.index_select(0, valid_idx), \
+            coors.index_select(0, valid_idx)
         sampled_centers, voxel_coors, inv_inds = scatter_v2(points, coors, mode="avg", return_inv=True)
         dist = self._per_class(self.connected_dist, class_name)
         if self.training:

@@ -10,8 +10,8 @@ points" gather reuses that sort-once segment plan through the HIP library.
 import torch
 import torch.nn as nn
 
-from ...ops.sst_ops import (build_mlp, fused_norm_act, gather_by_inverse, get_activation_layer, scatter_v2,
-                            unique_with_plan)
+from ...ops.sst_ops import (build_mlp, fused_norm_act, gather_by_inverse, get_activation_layer, point_group_concat,
+                            scatter_v2, unique_with_plan)
 from ...registry import VOXEL_ENCODERS, build_norm_layer
 
 
@@ -102,12 +102,11 @@ class DynamicScatterVFE(nn.Module):
             features_ls.append(torch.norm(features[:, :3], 2, 1, keepdim=True))
         features = torch.cat(features_ls, dim=-1)
         for i, vfe in enumerate(self.vfe_layers):
-            point_feats = vfe(features)
-            voxel_feats, voxel_coors, unq_inv_l = scatter_v2(point_feats, coors, mode=self.mode, unq_inv=unq_inv,
-                                                             new_coors=new_coors)
-            if i != len(self.vfe_layers) - 1:
-                feat_per_point = gather_by_inverse(voxel_feats, unq_inv_l)
-                features = torch.cat([point_feats, feat_per_point], dim=1)
+            last = i == len(self.vfe_layers) - 1
+            point_feats, voxel_feats, voxel_coors, unq_inv_l, cat = point_group_concat(
+                vfe, features, coors, self.mode, unq_inv, new_coors, want_concat=not last)
+            if not last:
+                features = cat
         if self.return_point_feats:
             return point_feats
         if return_inv:
@@ -154,14 +153,18 @@ class SIRLayer(nn.Module):
             features = features * self.rel_mlp(f_cluster / self.rel_dist_scaler)
         voxel_feats_list = []
         for i, vfe in enumerate(self.vfe_layers):
-            point_feats = vfe(features)
-            if i == len(self.vfe_layers) - 1 and self.with_shortcut and point_feats.shape == features.shape:
-                point_feats = point_feats + features  # never shape-compatible in the FSF configs
-            voxel_feats, voxel_coors, unq_inv = scatter_v2(point_feats, coors, mode=self.mode, unq_inv=unq_inv_once,
-                                                           new_coors=new_coors_once)
+            last = i == len(self.vfe_layers) - 1
+            if last and self.with_shortcut and vfe.linear.out_features == features.shape[1]:
+                # shortcut (never shape-compatible in the FSF configs): plain path
+                point_feats = vfe(features) + features
+                voxel_feats, voxel_coors, unq_inv = scatter_v2(point_feats, coors, mode=self.mode, unq_inv=unq_inv_once,
+                                                               new_coors=new_coors_once)
+            else:
+                point_feats, voxel_feats, voxel_coors, unq_inv, cat = point_group_concat(
+                    vfe, features, coors, self.mode, unq_inv_once, new_coors_once, want_concat=not last)
+                if not last:
+                    features = cat
             voxel_feats_list.append(voxel_feats)
-            if i != len(self.vfe_layers) - 1:
-                features = torch.cat([point_feats, gather_by_inverse(voxel_feats, unq_inv)], dim=1)
         voxel_feats = torch.cat(voxel_feats_list, dim=1)
         if return_both:
             if self.return_inv:

@@ -184,10 +184,17 @@ CONV_TYPES = {"SparseConv3d": SparseConv3d, "SubMConv3d": SubMConv3d, "SparseInv
 
 
 def _bn_affine(bn):
-    """eval-mode BatchNorm1d as y = x * scale + shift."""
-    invstd = torch.rsqrt(bn.running_var + bn.eps)
-    scale = bn.weight * invstd if bn.affine else invstd
-    shift = (bn.bias if bn.affine else 0) - bn.running_mean * scale
+    """eval-mode BatchNorm1d as y = x * scale + shift, cached per module until a parameter / buffer changes."""
+    tensors = [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
+    key = tuple((t.data_ptr(), t._version) for t in tensors)
+    cached = getattr(bn, "_fsf_affine", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], cached[2]
+    with torch.no_grad():
+        invstd = torch.rsqrt(bn.running_var + bn.eps)
+        scale = (bn.weight * invstd if bn.affine else invstd).contiguous()
+        shift = ((bn.bias if bn.affine else 0) - bn.running_mean * scale).contiguous()
+    bn._fsf_affine = (key, scale, shift)
     return scale, shift
 
 

@@ -38,7 +38,7 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, src, plan):
         ctx.plan = plan
-        return hip_ops.gather_rows(src, plan.inv)
+        return hip_ops.gather_rows(src.float(), plan.inv)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -63,9 +63,33 @@ def plan_of(unq_inv, num_segments):
     return plan
 
 
-def gather_by_inverse(rows, unq_inv):
-    """`rows[unq_inv]` (the "map back to points" gather of DynamicScatterVFE / SIRLayer / the neck)."""
-    return _GatherRows.apply(rows, plan_of(unq_inv, rows.size(0)))
+def gather_by_inverse(rows, unq_inv, out=None):
+    """`rows[unq_inv]` (the "map back to points" gather of DynamicScatterVFE / SIRLayer / the neck).  With `out` (a
+    column slice of a wider buffer; inference only) the rows land in place and no concat copy is needed."""
+    plan = plan_of(unq_inv, rows.size(0))
+    if out is not None:
+        return hip_ops.gather_rows(rows, plan.inv, out=out)
+    return _GatherRows.apply(rows, plan)
+
+
+def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, want_concat):
+    """One `DynamicVFELayer` step of DynamicScatterVFE / SIRLayer: point_feats = act(norm(linear(x))), group feats =
+    segmented reduce, and (unless it is the last layer) `cat([point_feats, group_feats[inv]], 1)`.
+    Inference: the fused norm+act writes the left half of the concat buffer and the row gather the right half — the
+    [n, 2C] tensor is written exactly once; the segmented reduce reads the left half through its row stride."""
+    no_grad = not (torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in vfe_layer.parameters())))
+    if no_grad and want_concat and vfe_layer.dropout is None:
+        lin = vfe_layer.linear(features)
+        n, c = lin.shape
+        buf = torch.empty((n, 2 * c), dtype=lin.dtype, device=lin.device)
+        point_feats = fused_norm_act(lin, vfe_layer.norm, vfe_layer.act, out=buf[:, :c])
+        group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors)
+        gather_by_inverse(group_feats, inv, out=buf[:, c:])
+        return point_feats, group_feats, group_coors, inv, buf
+    point_feats = vfe_layer(features)
+    group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors)
+    cat = torch.cat([point_feats, gather_by_inverse(group_feats, inv)], dim=1) if want_concat else None
+    return point_feats, group_feats, group_coors, inv, cat
 
 
 def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, new_coors=None):
@@ -87,7 +111,7 @@ def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, n
         coors = coors[valid_mask]
         new_coors, unq_inv, unq_cnt = unique_with_plan(coors)
     plan = plan_of(unq_inv, new_coors.size(0))
-    new_feat = _SegmentReduce.apply(feat.float().contiguous(), plan, mode)
+    new_feat = _SegmentReduce.apply(feat.float(), plan, mode)
     if not return_inv:
         return new_feat, new_coors
     return new_feat, new_coors, unq_inv
@@ -127,7 +151,7 @@ def get_activation_layer(act, dim=None):
     return table[act]()
 
 
-def fused_norm_act(x, norm, act):
+def fused_norm_act(x, norm, act, out=None):
     """`act(norm(x))` for x [n, C].  When no gradient is needed and the pair is LayerNorm / eval BatchNorm1d followed by
     ReLU / GELU, this is ONE fused HIP pass over the activations (fsf_norm_act) instead of two or three ATen kernels;
     otherwise the torch modules run (training, exotic activations)."""
@@ -140,13 +164,17 @@ def fused_norm_act(x, norm, act):
     if act_code is not None and not needs_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(1) <= 512:
         x = x.contiguous()
         if isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1:
-            return hip_ops.norm_act(x, norm.weight, norm.bias, norm.eps, "ln", act_code)
+            return hip_ops.norm_act(x, norm.weight, norm.bias, norm.eps, "ln", act_code, out=out)
         if isinstance(norm, nn.BatchNorm1d) and not norm.training and norm.track_running_stats:
-            invstd = torch.rsqrt(norm.running_var + norm.eps)
-            scale = norm.weight * invstd if norm.affine else invstd
-            shift = (norm.bias if norm.affine else 0) - norm.running_mean * scale
-            return hip_ops.norm_act(x, scale.contiguous(), shift.contiguous(), 0.0, "affine", act_code)
-    return act(norm(x))
+            from .spconv import _bn_affine
+
+            scale, shift = _bn_affine(norm)
+            return hip_ops.norm_act(x, scale, shift, 0.0, "affine", act_code, out=out)
+    y = act(norm(x))
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 class MLPBlock(nn.Sequential):

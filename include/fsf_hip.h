@@ -101,11 +101,12 @@ int fsf_segment_plan_from_inverse(const int64_t* inv, int64_t n, int64_t m, int3
  * ascending point index; torch_scatter's choice among ties is atomics-order dependent upstream).
  * Deterministic: no atomics, fixed summation order (ascending point index inside fixed 64-row chunks,
  * then chunks in order).
- *   feat f32 [n,c]; order/inv/seg_offsets: the plan from fsf_unique_rows or fsf_segment_plan_from_inverse;
+ *   feat f32 [n,c] with row stride feat_stride floats (0 = c: dense; > c: a column slice of a wider buffer);
+ *   order/inv/seg_offsets: the plan from fsf_unique_rows or fsf_segment_plan_from_inverse;
  *   out f32 [m,c]; argmax i64 [m,c] or NULL (mode 2 only)
  */
 int64_t fsf_segment_reduce_workspace_bytes(int64_t n, int64_t m, int32_t c);
-int fsf_segment_reduce(const float* feat, int64_t n, int32_t c, const int32_t* order, const int64_t* inv,
+int fsf_segment_reduce(const float* feat, int64_t feat_stride, int64_t n, int32_t c, const int32_t* order, const int64_t* inv,
                        const int32_t* seg_offsets, int64_t m, int32_t mode, float* out, int64_t* argmax,
                        void* workspace, int64_t workspace_bytes, void* stream);
 
@@ -119,13 +120,15 @@ int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int32_t c, con
                                 float* grad_feat, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * K6  row gather  out[i,:] = src[idx[i],:]   (and its adjoint, a deterministic segmented sum)
+ * K6  row gather  out[i,:] = src[idx[i],:]   (and its adjoint, a deterministic segmented sum).
+ * out_stride (floats, 0 = c) lets the rows land in a column slice of a wider buffer — the
+ * `cat([point_feats, voxel_feats[inv]], 1)` of the VFE / SIR layers then needs no concat copy.
  * Replaces: ATen advanced-index `voxel_feats[voxel2point_inds]` at
  *   projects/mmdet3d_plugin/models/necks/voxel2point_neck.py:42 and the "map back" gathers inside
  *   DynamicScatterVFE / SIRLayer [UNVENDORED], FSF.py:311.
  */
 int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
-                    void* stream);
+                    int64_t out_stride, void* stream);
 
 /* Fused a7: Voxel2PointScatterNeck.forward (voxel2point_neck.py:27-70) without the boolean compaction:
  *   out[i, 0:c]   = voxel_feats[inv[i], :]
@@ -143,10 +146,10 @@ int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* co
  *   norm: 0 = LayerNorm over the c channels of each row (biased variance, eps inside the sqrt; gamma/beta [c] or
  *             both NULL), 1 = per-channel affine y = x * gamma + beta (eval BatchNorm folded by the caller)
  *   act:  0 = none, 1 = ReLU, 2 = GELU (erf form)
- *   x f32 [n,c] -> out f32 [n,c] (out may alias x); c <= 512.
+ *   x f32 [n,c] -> out f32 [n,c] with row stride out_stride floats (0 = c; out may alias x when dense); c <= 512.
  */
 int fsf_norm_act(const float* x, int64_t n, int32_t c, const float* gamma, const float* beta, float eps, int32_t norm,
-                 int32_t act, float* out, void* stream);
+                 int32_t act, float* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K13-K15  LiDAR -> camera projection + per-point instance-mask gather
