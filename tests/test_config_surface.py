@@ -82,3 +82,16 @@ def test_reference_config_loads_and_builds_unchanged():
     own_model = plugin.build_model(own.model)
     ref_keys = {k for k in model.state_dict() if not k.startswith(("refine", "lidar_img_mlp", "position_encoder", "out_proj"))}
     assert ref_keys == set(own_model.state_dict().keys())
+
+
+REF_AV2 = "/root/reference/projects/configs/Argoverse2/FSF_AV2_config.py"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_AV2), reason="reference tree only exists in the build container")
+def test_reference_av2_config_resolves():
+    cfg = Config.fromfile(REF_AV2)
+    assert cfg.model.is_argo is True and cfg.model.num_cams == 7
+    assert not unresolved(cfg.to_dict()), unresolved(cfg.to_dict())
+    seg = plugin.registry.build_detector(cfg.model.segmentor)
+    assert seg.backbone.sparse_shape == [32, 2048, 2048]
+    assert seg.voxel_layer.grid_size.tolist() == [2048, 2048, 32]

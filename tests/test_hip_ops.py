@@ -275,6 +275,28 @@ def test_project_gather_full_size_vs_oracle(ops, device):
     np.testing.assert_array_equal(score.cpu().numpy(), ws)
 
 
+def test_project_gather_av2_shape_vs_oracle(ops, device):
+    """BASELINE config-5 shape: 7 ring cameras, one int32 instance-id plane per camera (ids exceed 255), 1550x2048."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from fullysparsefusion_amd.synthetic import make_lidar2img, make_mask_data
+
+    rng = np.random.default_rng(5)
+    n = 150000
+    r = rng.uniform(1.0, 200.0, n)
+    a = rng.uniform(-np.pi, np.pi, n)
+    pts = np.stack([r * np.cos(a), r * np.sin(a), rng.normal(-1.0, 1.0, n)], 1).astype(np.float32)
+    L = make_lidar2img(7, fx=1780.0, cx=1024.0, cy=775.0)
+    mask, anno = make_mask_data(rng, 7, 1, 1550, 2048, 600, dtype=np.int32)
+    assert mask.max() > 255
+    want, want_p2d = oproj.points_in_mask(pts, mask, L)
+    ids, p2d = ops.project_gather_mask(torch.from_numpy(pts).to(device), torch.from_numpy(L).to(device),
+                                       torch.from_numpy(mask).to(device), return_pts_2d=True)
+    np.testing.assert_array_equal(p2d.cpu().numpy(), want_p2d)
+    np.testing.assert_array_equal(ids.cpu().numpy(), want)
+    assert want.max() > 255 and (want > 0).any(-1).any(-1).mean() > 0.05
+
+
 # ----------------------------------------------------------------------------------------- rulebooks
 def sparse_sites(rng, batch, shape, m):
     cells = batch * shape[0] * shape[1] * shape[2]
@@ -290,20 +312,22 @@ def surface_sites(rng, batch, shape, m):
     """LiDAR-like occupancy: a thin, x-y dense sheet (ground) plus scattered columns."""
     z0 = shape[0] // 3
     sites = set()
+    y0 = max(0, shape[1] - 300)  # long-range grids: keep the sheet dense and put it at the far corner (large coordinates)
+    x0 = max(0, shape[2] - 300)
     while len(sites) < m:
         b = int(rng.integers(batch))
-        y = int(rng.integers(shape[1]))
-        x = int(rng.integers(shape[2]))
+        y = int(rng.integers(y0, shape[1]))
+        x = int(rng.integers(x0, shape[2]))
         z = z0 + int(rng.integers(0, 2)) if rng.random() < 0.8 else int(rng.integers(shape[0]))
         sites.add((b, z, y, x))
     arr = np.array(sorted(sites), dtype=np.int32)
     return arr
 
 
-@pytest.mark.parametrize("shape,m", [((8, 12, 10), 400), ((40, 128, 128), 20000), ((3, 3, 3), 2)])
+@pytest.mark.parametrize("shape,m", [((8, 12, 10), 400), ((40, 128, 128), 20000), ((3, 3, 3), 2), ((32, 2048, 2048), 60000)])
 def test_rulebook_subm_bit_exact(ops, device, shape, m):
     rng = np.random.default_rng(m)
-    idx = sparse_sites(rng, 2, shape, m) if m != 20000 else surface_sites(rng, 2, shape, m)
+    idx = sparse_sites(rng, 2, shape, m) if m < 20000 else surface_sites(rng, 2, shape, m)
     _, pairs, _ = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True)
     want = osp.pairs_to_nbr(pairs, idx.shape[0])
     nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), 2, shape)
@@ -318,10 +342,11 @@ def test_rulebook_subm_bit_exact(ops, device, shape, m):
 
 
 @pytest.mark.parametrize("shape,padding,m", [((8, 12, 10), (1, 1, 1), 400), ((5, 12, 10), (0, 1, 1), 300),
-                                             ((40, 128, 128), (1, 1, 1), 20000), ((4, 4, 4), (1, 1, 1), 9)])
+                                             ((40, 128, 128), (1, 1, 1), 20000), ((4, 4, 4), (1, 1, 1), 9),
+                                             ((32, 2048, 2048), (1, 1, 1), 60000), ((4, 256, 256), (0, 1, 1), 30000)])
 def test_rulebook_strided_bit_exact(ops, device, shape, padding, m):
     rng = np.random.default_rng(m + 1)
-    idx = sparse_sites(rng, 2, shape, m) if m != 20000 else surface_sites(rng, 2, shape, m)
+    idx = sparse_sites(rng, 2, shape, m) if m < 20000 else surface_sites(rng, 2, shape, m)
     out_idx, pairs, oshape = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (2, 2, 2), padding, (1, 1, 1), False)
     o, nbr, nbr_inv, got_shape = ops.rulebook_strided(torch.from_numpy(idx).to(device), 2, shape, (3, 3, 3), (2, 2, 2), padding)
     assert list(got_shape) == list(oshape)

@@ -341,3 +341,53 @@ def test_fsf_hot_path_vs_oracle(fsf_pair, frame1, device):
     np.testing.assert_array_equal(l_inds.cpu().numpy(), want_coors.numpy())
     close(l_feats, want_feats)
     assert s3["cluster_inds"].shape[0] > 10 and s2["obj_coors"].shape[0] > 10
+
+
+# ------------------------------------------------------------------------ Argoverse-2 shape (BASELINE config 5)
+AV2_RANGE = [-204.8, -204.8, -3.2, 204.8, 204.8, 3.2]
+AV2_SEGMENTOR = dict(
+    type="VoteSegmentor", tanh_dims=[],
+    voxel_layer=dict(voxel_size=(0.2, 0.2, 0.2), max_num_points=-1, point_cloud_range=AV2_RANGE, max_voxels=(-1, -1)),
+    voxel_encoder=dict(type="DynamicScatterVFE", in_channels=4, feat_channels=[64, 64], voxel_size=(0.2, 0.2, 0.2),
+                       with_cluster_center=True, with_voxel_center=True, point_cloud_range=AV2_RANGE,
+                       norm_cfg=dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01)),
+    middle_encoder=dict(type="PseudoMiddleEncoderForSpconvFSD"),
+    backbone=dict(type="SimpleSparseUNet", in_channels=64, sparse_shape=[32, 2048, 2048], order=("conv", "norm", "act"),
+                  norm_cfg=dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), base_channels=64, output_channels=128,
+                  encoder_channels=((64,), (64, 64, 64), (64, 64, 64), (128, 128, 128)),
+                  encoder_paddings=((1,), (1, 1, 1), (1, 1, 1), ((0, 1, 1), 1, 1)),
+                  decoder_channels=((128, 128, 64), (64, 64, 64), (64, 64, 64), (64, 64, 64)),
+                  decoder_paddings=((1, 0), (1, 0), (0, 0), (0, 1))),
+    decode_neck=dict(type="Voxel2PointScatterNeck", voxel_size=(0.2, 0.2, 0.2), point_cloud_range=AV2_RANGE),
+    segmentation_head=dict(type="VoteSegHead", in_channel=67, hidden_dims=[128, 128], num_classes=26, dropout_ratio=0.0,
+                           norm_cfg=dict(type="naiveSyncBN1d"), act_cfg=dict(type="ReLU"),
+                           loss_decode=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=3.0),
+                           loss_vote=dict(type="L1Loss", loss_weight=1.0)),
+)
+
+
+def test_av2_long_range_segmentor_vs_oracle(plugin, device):
+    """±204.8 m range, 2048 x 2048 x 32 grid (spconv v1 would allocate a 537 MB dense grid per sample; the hash
+    rulebook does not care), 4-d points, VFE without unique_once, 4-stage U-Net with 64-wide layers."""
+    torch.manual_seed(1)
+    seg = plugin.registry.build_detector(AV2_SEGMENTOR).eval()
+    for m in seg.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    cpu = copy.deepcopy(seg)
+    seg.to(device)
+    rng = np.random.default_rng(2)
+    n = 40000
+    r = rng.uniform(2.0, 200.0, n) ** 1.0
+    a = rng.uniform(-np.pi, np.pi, n)
+    pts = np.stack([r * np.cos(a), r * np.sin(a), rng.normal(-1.5, 0.4, n).clip(-3.1, 3.1), rng.random(n)], 1).astype(np.float32)
+    pts = pts[(np.abs(pts[:, 0]) < 204.7) & (np.abs(pts[:, 1]) < 204.7)]
+    t = torch.from_numpy(pts)
+    ex = omod.segmentor_extract_feat(cpu, [t])
+    with torch.no_grad():
+        (neck_out, mask), coors, _ = seg.extract_feat([t.to(device)], None)
+    np.testing.assert_array_equal(coors.cpu().numpy(), ex["coors"].numpy())
+    assert int(ex["coors"][:, 3].max()) > 1500 and int(ex["coors"][:, 2].max()) > 1500  # really uses the 2048^2 grid
+    assert neck_out.shape == (pts.shape[0], 67)
+    close(neck_out, ex["neck"])
