@@ -46,7 +46,7 @@ def lib():
                     "fsf_rulebook_workspace_bytes",
                     "fsf_ingroup_rank_workspace_bytes",
                     "fsf_connected_components_workspace_bytes",
-                    "fsf_spconv_workspace_bytes",
+                    "fsf_spconv_workspace_bytes", "fsf_spconv_backward_weight_workspace_bytes",
                 ):
                     getattr(h, name).restype = c_i64
                 _lib = h

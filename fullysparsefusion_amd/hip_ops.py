@@ -35,6 +35,8 @@ _ARGTYPES = {
     "fsf_spconv_transpose_weight": [_P, c_i32, c_i32, c_i32, _P, _P],
     "fsf_spconv_workspace_bytes": [c_i64, c_i32, c_i32],
     "fsf_spconv_forward": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
+    "fsf_spconv_backward_weight_workspace_bytes": [c_i64, c_i32, c_i32, c_i32],
+    "fsf_spconv_backward_weight": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_connected_components_workspace_bytes": [c_i64],
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
@@ -355,6 +357,26 @@ def spconv_forward(feat: torch.Tensor, weight_t: torch.Tensor, nbr: torch.Tensor
                                ptr(residual), int(bool(relu)), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_spconv_forward")
     return out
+
+
+def spconv_backward_weight(feat: torch.Tensor, grad_out: torch.Tensor, pairs: torch.Tensor, num: torch.Tensor):
+    """fsf_spconv_backward_weight: feat f32 [m_in,cin], grad_out f32 [m_out,cout], (pairs, num) from
+    rulebook_to_pairs -> grad_weight f32 [kvol,cin,cout]."""
+    require_cuda(feat, grad_out, pairs, num)
+    feat = feat.contiguous()
+    grad_out = grad_out.contiguous()
+    assert pairs.is_contiguous() and pairs.dtype == torch.int32 and num.dtype == torch.int32
+    kvol, _, cap = pairs.shape
+    m_in, cin = feat.shape
+    m_out, cout = grad_out.shape
+    if m_in == 0 or m_out == 0:
+        return torch.zeros((kvol, cin, cout), dtype=torch.float32, device=feat.device)
+    gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_spconv_backward_weight_workspace_bytes(cap, cin, cout, kvol), feat.device)
+    check(h.fsf_spconv_backward_weight(ptr(feat), m_in, cin, ptr(grad_out), m_out, cout, ptr(pairs), ptr(num), cap, kvol,
+                                       ptr(gw), ptr(ws), ws.numel(), stream_ptr()), "fsf_spconv_backward_weight")
+    return gw
 
 
 # ------------------------------------------------------------------------------------- in-group rank

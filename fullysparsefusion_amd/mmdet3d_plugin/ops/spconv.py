@@ -58,19 +58,52 @@ class Rulebook:
         self.nbr_inv = nbr_inv          # i32 [m_in, kvol] (strided only)
         self.in_indices, self.in_shape = in_indices, in_shape
         self.out_indices, self.out_shape = out_indices, out_shape
+        self._pairs = {}
+
+    def table(self, inverse):
+        return self.nbr_inv if inverse else self.nbr
+
+    def table_transposed(self, inverse):
+        """(table, flip_k) for the data gradient: the conv over the transposed rulebook.  A SubM rulebook is its
+        own transpose up to reversing the kernel offsets."""
+        if self.kind == "subm":
+            return self.nbr, True
+        return (self.nbr if inverse else self.nbr_inv), False
+
+    def pairs(self, inverse):
+        """spconv-v1 pair lists of the table (built once per rulebook, only when a weight gradient is needed)."""
+        if inverse not in self._pairs:
+            self._pairs[inverse] = hip_ops.rulebook_to_pairs(self.table(inverse))
+        return self._pairs[inverse]
 
 
 class _SparseConvFn(torch.autograd.Function):
+    """out = sum_k feat[table[:, k]] @ W[k] with the K10 backward: data gradient = the same fused kernel over the
+    transposed table, weight gradient = fsf_spconv_backward_weight over the pair lists."""
+
     @staticmethod
-    def forward(ctx, feat, weight, nbr, scale, shift, residual, relu):
-        kvol = nbr.size(1)
-        w = weight.reshape(kvol, weight.shape[-2], weight.shape[-1])
-        wt = hip_ops.spconv_transpose_weight(w)
-        return hip_ops.spconv_forward(feat, wt, nbr, scale=scale, shift=shift, residual=residual, relu=relu)
+    def forward(ctx, feat, weight, rb, inverse):
+        kvol = rb.nbr.size(1)
+        w = weight.detach().reshape(kvol, weight.shape[-2], weight.shape[-1])
+        ctx.rb, ctx.inverse = rb, inverse
+        ctx.save_for_backward(feat, weight)
+        return hip_ops.spconv_forward(feat, hip_ops.spconv_transpose_weight(w), rb.table(inverse))
 
     @staticmethod
     def backward(ctx, grad):
-        raise NotImplementedError("sparse-conv backward (K10) is not built yet: forward/inference only")
+        feat, weight = ctx.saved_tensors
+        rb, inverse = ctx.rb, ctx.inverse
+        grad = grad.contiguous()
+        kvol = rb.nbr.size(1)
+        g_feat = g_w = None
+        if ctx.needs_input_grad[0]:
+            table_t, flip = rb.table_transposed(inverse)
+            w = weight.detach().reshape(kvol, weight.shape[-2], weight.shape[-1])
+            g_feat = hip_ops.spconv_forward(grad, w.flip(0) if flip else w, table_t)
+        if ctx.needs_input_grad[1]:
+            pairs, num = rb.pairs(inverse)
+            g_w = hip_ops.spconv_backward_weight(feat, grad, pairs, num).reshape(weight.shape)
+        return g_feat, g_w, None, None
 
 
 def _to3(v):
@@ -153,8 +186,16 @@ class SparseConvolution(SparseModule):
             shift = shift + (self.bias * scale if scale is not None else self.bias)
         feat = x.features
         needs_grad = torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad)
-        if needs_grad:
-            out = _SparseConvFn.apply(feat, self.weight, nbr, scale, shift, residual, relu)
+        if needs_grad:  # training: the epilogue stays in autograd-visible torch ops
+            out = _SparseConvFn.apply(feat, self.weight, rb, self.inverse)
+            if scale is not None:
+                out = out * scale
+            if shift is not None:
+                out = out + shift
+            if residual is not None:
+                out = out + residual
+            if relu:
+                out = torch.relu(out)
         else:
             out = hip_ops.spconv_forward(feat, self._weight_t(), nbr, scale=scale, shift=shift, residual=residual,
                                          relu=relu)

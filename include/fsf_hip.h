@@ -226,6 +226,24 @@ int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float
                        void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K10  sparse convolution backward (training)
+ * Replaces: spconv v1 indice_conv_backward [UNVENDORED mmdet3d.ops.spconv] = per offset
+ *   (gather in, gather grad, mm^T for dW, mm for dX, scatter-add), 27 x 5 launches per layer.
+ * Data gradient: no entry point of its own — it IS a forward conv over the transposed table with the
+ *   un-transposed weight:  fsf_spconv_forward(grad_out, m_out, cout, weight /[kvol,cin,cout]/, kvol, cin,
+ *   nbr_inv /[m_in,kvol]/, m_in, NULL, NULL, NULL, 0, grad_feat, ...).  SubM layers have
+ *   nbr_inv[i,k] = nbr[i,kvol-1-k], i.e. pass nbr and the weight flipped along k.
+ * Weight gradient: grad_weight[k,ci,co] = sum_p feat[in_k[p],ci] * grad_out[out_k[p],co] over the pair lists
+ *   of fsf_rulebook_to_pairs (indice_pairs i32 [kvol,2,cap], indice_num i32 [kvol], both on the device).
+ *   cin % 4 == 0, cout % 4 == 0.  fp32 MFMA, partial sums folded in a fixed order (deterministic).
+ */
+int64_t fsf_spconv_backward_weight_workspace_bytes(int64_t cap, int32_t cin, int32_t cout, int32_t kvol);
+int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32_t cin, const float* grad_out, int64_t m_out,
+                               int32_t cout, const int32_t* indice_pairs, const int32_t* indice_num, int64_t cap,
+                               int32_t kvol, float* grad_weight, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K19  connected components of the graph "xy-distance < dist" (same batch index), labels contiguous 0..K-1
  * numbered in order of each component's smallest member index — the labelling
  * scipy.sparse.csgraph.connected_components(adj, directed=False)[1] produces.

@@ -77,14 +77,19 @@ class _SpT:
         self.features, self.indices, self.shape, self.batch_size, self.rb = features, indices, list(shape), batch_size, rulebooks
 
 
+_TRAIN = [False]  # unet_forward(train=True): batch statistics in the norms, autograd through the conv weights
+
+
 def _bn_eval(bn, x):
+    if _TRAIN[0]:
+        return F.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.0, bn.eps)
     return F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
 
 
 def _conv(conv, x):
     """spconv v1 SubMConv3d / SparseConv3d / SparseInverseConv3d with indice_key caching."""
     key = conv.indice_key
-    w = conv.weight.detach()
+    w = conv.weight if _TRAIN[0] else conv.weight.detach()
     if conv.inverse:
         out_idx, pairs, in_idx, in_shape = x.rb[key]
         feat = osp.indice_conv(x.features, w, pairs, in_idx.shape[0], inverse=True)
@@ -120,8 +125,16 @@ def _basic_block(blk, x):
     return out
 
 
-def unet_forward(unet, voxel_feats, voxel_coors, batch_size):
-    """Published SST `SimpleSparseUNet.forward` in eval mode (called at single_stage_fsd.py:234)."""
+def unet_forward(unet, voxel_feats, voxel_coors, batch_size, train=False):
+    """Published SST `SimpleSparseUNet.forward` (called at single_stage_fsd.py:234); eval mode unless `train`."""
+    _TRAIN[0] = bool(train)
+    try:
+        return _unet_forward(unet, voxel_feats, voxel_coors, batch_size)
+    finally:
+        _TRAIN[0] = False
+
+
+def _unet_forward(unet, voxel_feats, voxel_coors, batch_size):
     x = _SpT(voxel_feats, voxel_coors.int().numpy(), unet.sparse_shape, batch_size, {})
     x = _convmodule(unet.conv_input, x)
     enc = []

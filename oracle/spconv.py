@@ -101,10 +101,12 @@ def pairs_inverse_nbr(pairs, m_in):
 
 def indice_conv(feat, weight, pairs, m_out, inverse=False):
     """spconv v1 indice_conv: per-offset gather -> mm -> scatter-add.  weight [KZ,KY,KX,Cin,Cout] or [kvol,Cin,Cout]."""
-    feat = torch.as_tensor(feat, dtype=torch.float32)
-    w = torch.as_tensor(weight, dtype=torch.float32)
+    feat = torch.as_tensor(feat)
+    if feat.dtype != torch.float64:  # float64 only when the caller asks for a higher-precision yardstick
+        feat = feat.to(torch.float32)
+    w = torch.as_tensor(weight).to(feat.dtype)
     w = w.reshape(-1, w.shape[-2], w.shape[-1])
-    out = torch.zeros((m_out, w.shape[-1]), dtype=torch.float32)
+    out = torch.zeros((m_out, w.shape[-1]), dtype=feat.dtype)
     for k, (i_r, o_r) in enumerate(pairs):
         if len(i_r) == 0:
             continue

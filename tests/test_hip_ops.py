@@ -403,6 +403,75 @@ def test_spconv_forward_strided_and_inverse_vs_dense(ops, device):
         np.testing.assert_allclose(up.cpu().numpy(), want_up.numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (64, 128), (128, 64), (256, 128), (128, 320), (48, 32), (16, 16)])
+@pytest.mark.parametrize("kind", ["subm", "strided", "inverse"])
+def test_spconv_backward_vs_oracle_autograd(ops, device, kind, cin, cout):
+    """K10: d/d feat = conv over the transposed rulebook, d/d W = pair-list outer products; oracle = autograd through
+    the per-offset gather / mm / index_add restatement.  fp32, rtol 1e-4 of the gradient scale."""
+    rng = np.random.default_rng(cin * 7 + cout + len(kind))
+    shape = (12, 40, 40)
+    idx = surface_sites(rng, 2, shape, 2500 if kind == "subm" else 1800)
+    subm = kind == "subm"
+    stride = (1, 1, 1) if subm else (2, 2, 2)
+    out_idx, pairs, _ = osp.build_rulebook(idx, 2, shape, (3, 3, 3), stride, (1, 1, 1), (1, 1, 1), subm)
+    dev_idx = torch.from_numpy(idx).to(device)
+    if subm:
+        nbr = ops.rulebook_subm(dev_idx, 2, shape)
+        table, table_t, flip = nbr, nbr, True
+        m_in, m_out = idx.shape[0], idx.shape[0]
+    else:
+        _, nbr, nbr_inv, _ = ops.rulebook_strided(dev_idx, 2, shape, (3, 3, 3), stride, (1, 1, 1))
+        if kind == "strided":
+            table, table_t, flip = nbr, nbr_inv, False
+            m_in, m_out = idx.shape[0], out_idx.shape[0]
+        else:
+            table, table_t, flip = nbr_inv, nbr, False
+            m_in, m_out = out_idx.shape[0], idx.shape[0]
+    feat = torch.from_numpy(rng.standard_normal((m_in, cin)).astype(np.float32)).requires_grad_()
+    w = torch.from_numpy((rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 6)).astype(np.float32)).requires_grad_()
+    gout = torch.from_numpy(rng.standard_normal((m_out, cout)).astype(np.float32))
+    want = osp.indice_conv(feat, w, pairs, m_out, inverse=kind == "inverse")
+    want.backward(gout)
+    # data gradient: the forward kernel over the transposed table with the un-transposed (k-flipped for SubM) weight
+    wd = w.detach().to(device)
+    g_feat = ops.spconv_forward(gout.to(device), wd.flip(0).contiguous() if flip else wd, table_t)
+    np.testing.assert_allclose(g_feat.cpu().numpy(), feat.grad.numpy(), rtol=1e-4, atol=1e-4)
+    # weight gradient
+    ip, num = ops.rulebook_to_pairs(table)
+    g_w = ops.spconv_backward_weight(feat.detach().to(device), gout.to(device), ip, num)
+    tol = 1e-4 * float(w.grad.abs().max())
+    np.testing.assert_allclose(g_w.cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=tol)
+    assert torch.equal(g_w, ops.spconv_backward_weight(feat.detach().to(device), gout.to(device), ip, num))  # deterministic
+
+
+def test_spconv_backward_weight_large_and_empty_offsets(ops, device):
+    """Many pair-range splits (partials folded in split order), offsets with zero pairs (isolated sites) and a pair
+    count that is not a multiple of the 32-pair stage."""
+    rng = np.random.default_rng(77)
+    shape = (24, 300, 300)
+    idx = surface_sites(rng, 1, shape, 70001)
+    cin = cout = 64
+    nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), 1, shape)
+    ip, num = ops.rulebook_to_pairs(nbr)
+    feat = torch.from_numpy(rng.standard_normal((idx.shape[0], cin)).astype(np.float32)).to(device)
+    gout = torch.from_numpy(rng.standard_normal((idx.shape[0], cout)).astype(np.float32)).to(device)
+    g_w = ops.spconv_backward_weight(feat, gout, ip, num)
+    nb = nbr.long()
+    for k in [0, 4, 13, 22, 26]:
+        sel = (nb[:, k] >= 0).nonzero().squeeze(1)
+        want = feat[nb[sel, k]].double().t() @ gout[sel].double()
+        err = (g_w[k].double() - want).abs().max().item()
+        assert err <= 1e-4 * max(1.0, want.abs().max().item()), (k, err)
+    # isolated sites: only the centre offset has pairs, every other slice must come back exactly zero
+    lone = np.stack([np.zeros(50), np.full(50, 3), np.arange(50) * 5, np.arange(50) * 5], 1).astype(np.int32)
+    nbr1 = ops.rulebook_subm(torch.from_numpy(lone).to(device), 1, shape)
+    ip1, num1 = ops.rulebook_to_pairs(nbr1)
+    assert num1.cpu().tolist() == [0] * 13 + [50] + [0] * 13
+    g1 = ops.spconv_backward_weight(feat[:50], gout[:50], ip1, num1)
+    assert torch.count_nonzero(g1[:13]) == 0 and torch.count_nonzero(g1[14:]) == 0
+    np.testing.assert_allclose(g1[13].cpu().numpy(), (feat[:50].t() @ gout[:50]).cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
 def test_spconv_asymmetric_weight_detects_transposes(ops, device):
     """A = I-like check with an asymmetric B (guide §3): one active site, identity features."""
     idx = np.array([[0, 1, 1, 1]], dtype=np.int32)
