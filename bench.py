@@ -108,8 +108,19 @@ def spconv_roofline(model, inp, steps):
     byts = sum(r[3] for r in records)
     launches = len(records)
     achieved = flops / (ms * 1e-3) / 1e12
-    return dict(bound="mfma", kernel="fsf::spconv_fwd_kernel", achieved=round(achieved, 3), peak=MFMA_F32_PEAK_TFLOPS,
-                unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+    # HBM bytes per fsf_spconv_forward call from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
+    # inside the process; scratch/pmc_traffic.sh collects them under rocprofv3 with this same command line)
+    traffic, traffic_src = None, None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith("_pmc_traffic.json"):
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)["spconv_forward"]["hbm_bytes_per_api_launch"]
+            traffic_src = "profiles/" + name
+            break
+    return dict(bound="mfma", kernel="fsf::spconv_fwd_dma_kernel (+ spconv_reduce_kernel)", achieved=round(achieved, 3),
+                peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                traffic=traffic, traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
+                traffic_source=traffic_src,
                 launches_per_step=launches // max(steps, 1), avg_launch_us=round(ms * 1e3 / max(launches, 1), 2),
                 algorithmic_gflop_per_step=round(flops / max(steps, 1) / 1e9, 2),
                 algorithmic_mb_per_step=round(byts / max(steps, 1) / 1e6, 1),
