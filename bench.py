@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--sweeps", type=int, default=10, help="10 = BASELINE config 3 input; 1 = config 2 (parity case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="time the training step instead (BASELINE configs 3/4): fwd + bwd of a dummy scalar loss over the "
+                         "hot-path outputs + bucketed gradient all-reduce over RCCL + AdamW")
+    ap.add_argument("--frames-per-gpu", type=int, default=1, help="batch size per rank (config 4 uses 2)")
     return ap.parse_args()
 
 
@@ -55,22 +59,49 @@ def build_model(device):
     return model.to(device)
 
 
-def make_inputs(sweeps, seed, device):
+def make_inputs(sweeps, seed, device, frames=1):
     from fullysparsefusion_amd import synthetic
 
-    f = synthetic.make_frame(num_sweeps=sweeps, seed=seed)
+    fs = [synthetic.make_frame(num_sweeps=sweeps, seed=seed * 97 + i) for i in range(frames)]
     dev = dict(
-        points=[torch.from_numpy(f["points"]).to(device)],
-        mask_data=torch.from_numpy(f["mask_data"]).to(device)[None],
-        mask_anno=torch.from_numpy(f["mask_anno"]).to(device)[None],
-        img_metas=[dict(lidar2img=torch.from_numpy(f["lidar2img"]).to(device))],
+        points=[torch.from_numpy(f["points"]).to(device) for f in fs],
+        mask_data=torch.stack([torch.from_numpy(f["mask_data"]) for f in fs]).to(device),
+        mask_anno=torch.stack([torch.from_numpy(f["mask_anno"]) for f in fs]).to(device),
+        img_metas=[dict(lidar2img=torch.from_numpy(f["lidar2img"]).to(device)) for f in fs],
     )
-    return f, dev
+    return fs[0], dev
 
 
 def step(model, inp):
     with torch.no_grad():
         return model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+
+
+def dummy_loss(out):
+    """'fwd+bwd with a dummy scalar loss (sum of head outputs)' — the loss/target path is not
+    built, so every tensor the heads would consume contributes."""
+    seg = out["seg"]
+    return (seg["seg_logits"].sum() + seg["seg_vote_preds"].sum() + out["frustum_obj_feats"].sum()
+            + out["fsd_obj_feats"].sum()) * 1e-6
+
+
+class TrainStep:
+    """fwd (training-mode norms) + bwd + gradient all-reduce (FrameDataParallel buckets, overlapped with the backward
+    pass) + AdamW."""
+
+    def __init__(self, model):
+        from fullysparsefusion_amd.data_parallel import FrameDataParallel
+
+        self.model = model.train()
+        self.dp = FrameDataParallel(model)
+        self.opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-6, weight_decay=0.01)
+
+    def __call__(self, inp):
+        self.dp.zero_grad()
+        out = self.model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+        self.dp.backward(dummy_loss(out))
+        self.opt.step()
+        return out
 
 
 def spconv_roofline(model, inp, steps):
@@ -168,18 +199,23 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     model = build_model(device)
-    model_cpu = None if args.no_cpu_baseline or rank != 0 or world != 1 else copy.deepcopy(model).cpu()
-    frame, inp = make_inputs(args.sweeps, seed=rank, device=device)
+    model_cpu = None if args.no_cpu_baseline or rank != 0 or world != 1 or args.train else copy.deepcopy(model).cpu()
+    frame, inp = make_inputs(args.sweeps, seed=rank, device=device, frames=args.frames_per_gpu)
+    if args.train:
+        train_step = TrainStep(model)
+        run = lambda: train_step(inp)
+    else:
+        run = lambda: step(model, inp)
 
     for _ in range(args.warmup):
-        step(model, inp)
+        run()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step(model, inp)
+        out = run()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -194,8 +230,9 @@ def main():
     if rank == 0:
         n_pts = int(inp["points"][0].shape[0])
         result = {
-            "metric": "frames/sec fwd nuScenes 10-sweep FSF hot path",
-            "value": round(world * args.steps / elapsed, 3),
+            "metric": ("frames/sec fwd+bwd+allreduce+AdamW nuScenes 10-sweep FSF hot path (dummy loss)" if args.train
+                       else "frames/sec fwd nuScenes 10-sweep FSF hot path"),
+            "value": round(world * args.frames_per_gpu * args.steps / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -207,17 +244,19 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"fsf_nuscenes_{args.sweeps}sweep_hot_path_fwd (BASELINE config 3 input, forward; stages 1-3 of "
-                            "FSF.simple_test: segmentor + image fusion, camera queries, LiDAR queries; heads/NMS/refine not built)",
+                "workload": (f"fsf_nuscenes_{args.sweeps}sweep_hot_path_{'train_step' if args.train else 'fwd'} (BASELINE config 3 "
+                             "input; stages 1-3 of FSF.simple_test: segmentor + image fusion, camera queries, LiDAR queries; "
+                             "heads/NMS/refine not built)"),
                 "points_per_frame": n_pts,
-                "frames_per_gpu_per_step": 1,
+                "frames_per_gpu_per_step": args.frames_per_gpu,
                 "mask_data": "u8[1,6,10,900,1600]",
                 "camera_queries": int(out["frustum_obj_feats"].shape[0]),
                 "lidar_queries": int(out["fsd_obj_feats"].shape[0]),
-                "parallelism": f"replicas x{world} (frames independent, no data-path collective)",
+                "parallelism": (f"dp{world}: frame-level data parallel, bucketed gradient all-reduce over RCCL" if args.train
+                                else f"replicas x{world} (frames independent, no data-path collective)"),
             },
         }
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and not args.train:
         result["roofline"] = spconv_roofline(model, inp, min(args.steps, 5))
     if rank == 0 and model_cpu is not None:
         result["cpu_baseline"] = cpu_baseline(model_cpu)

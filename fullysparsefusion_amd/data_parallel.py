@@ -1,0 +1,133 @@
+"""Frame-level data parallelism for training (collective C1): one process per GPU, every rank owns
+whole frames, the only exchange per iteration is the gradient all-reduce.
+
+Stands in for what the reference gets from `MMDistributedDataParallel` (tools/train.py -> mmdet3d.apis.train_model,
+launched by tools/dist_train.sh:8-9 with one process per GPU).  Differences that matter on MI355X:
+
+  * gradients live in a few large flat fp32 buckets (default 96 MB: xGMI is point-to-point, 7 links x ~153 GB/s, so
+    ring steps are per-link bound and small buckets pay the ring latency many times over; ~340 MB of FSF gradients
+    become 4 collectives), and `param.grad` are VIEWS into the bucket — no flatten / unflatten copies;
+  * a bucket's all-reduce is launched (async, RCCL's own stream) from the autograd hook of its last-arriving
+    parameter, so it overlaps the rest of the backward pass; buckets are filled in reverse registration order, which
+    is the order gradients become ready;
+  * the FSF graph is data dependent (a class group without points skips its layers on one rank only), so parameters
+    that received no gradient are treated as zeros and their buckets are reduced in `finish()` — every rank always
+    issues the same collectives in the same order.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    def __init__(self, params, device):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.views = []
+        off = 0
+        for p in params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self.pending = 0
+        self.work = None
+        self.launched = False
+
+
+class FrameDataParallel(torch.nn.Module):
+    """model wrapper: `forward` delegates; after `loss.backward()` call `finish()` (or use `backward(loss)`) and every
+    `param.grad` holds the mean over ranks."""
+
+    def __init__(self, module, bucket_mb=96, process_group=None):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        params = [p for p in module.parameters() if p.requires_grad]
+        assert all(p.dtype == torch.float32 for p in params), "gradient buckets are fp32"
+        cap = int(bucket_mb * (1 << 20)) // 4
+        self.buckets, cur, cur_n = [], [], 0
+        for p in reversed(params):  # reverse registration order ~ gradient-ready order
+            if cur and cur_n + p.numel() > cap:
+                self.buckets.append(_Bucket(cur, p.device))
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self.buckets.append(_Bucket(cur, cur[0].device))
+        self._where, self._view = {}, {}
+        for b in self.buckets:
+            for p, v in zip(b.params, b.views):
+                p.grad = v  # gradients accumulate straight into the bucket
+                self._where[p], self._view[p] = b, v
+                p.register_post_accumulate_grad_hook(self._on_grad)
+        if self.world > 1:  # same starting point on every rank (what DDP's constructor broadcast does)
+            for t in list(module.parameters()) + list(module.buffers()):
+                dist.broadcast(t.data, src=0, group=self.group)
+        self._armed = False
+
+    def forward(self, *args, **kwargs):
+        self._arm()
+        return self.module(*args, **kwargs)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.module, name)
+
+    # ------------------------------------------------------------------------------------------------
+    def _arm(self):
+        """Start of an iteration: zero the buckets, re-point grads at them, reset the ready counters."""
+        for b in self.buckets:
+            b.flat.zero_()
+            b.pending = len(b.params)
+            b.work, b.launched = None, False
+            for p, v in zip(b.params, b.views):
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
+        self._armed = True
+
+    def zero_grad(self, set_to_none=False):
+        self._arm()
+
+    def _launch(self, b):
+        b.launched = True
+        if self.world > 1:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        b, view = self._where[p], self._view[p]
+        if p.grad.data_ptr() != view.data_ptr():  # autograd replaced the view (first accumulation into None)
+            view.copy_(p.grad)
+            p.grad = view
+        b.pending -= 1
+        # launch in bucket order only: every rank must issue the same sequence of collectives
+        if b.pending == 0:
+            for nb in self.buckets:
+                if nb.launched:
+                    continue
+                if nb.pending == 0:
+                    self._launch(nb)
+                else:
+                    break
+
+    def finish(self):
+        """After backward: reduce the buckets whose parameters did not all receive gradients (zeros stand in), wait for
+        every collective and turn sums into means."""
+        for b in self.buckets:
+            if not b.launched:
+                self._launch(b)
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+            if self.world > 1:
+                b.flat.div_(self.world)
+        self._armed = False
+
+    def backward(self, loss):
+        if not self._armed:
+            self._arm()
+        loss.backward()
+        self.finish()

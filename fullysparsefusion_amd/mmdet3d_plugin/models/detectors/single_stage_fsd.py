@@ -214,8 +214,23 @@ class SingleStageFSD(nn.Module):
         return torch.where(inner_inds == 0)[0]
 
     def get_fg_mask(self, seg_scores, seg_points, cls_id, batch_inds, gt_bboxes_3d, gt_labels_3d):
-        assert not self.training, "training-time sampling is outside this round's hot path"
-        return seg_scores[:, cls_id] > self.cfg["score_thresh"][cls_id]
+        """(:740-782) score threshold (+ the train-time `threshold_buffer`) or, while detection is still disabled in
+        pre-training, the top-k points; the ground-truth-box augmentation (`add_gt_fg_points`) needs box geometry ops
+        that are outside the hot path."""
+        train_cfg = getattr(self, "train_cfg", None) or {}
+        runtime_info = getattr(self, "runtime_info", None) or {}
+        seg_scores = seg_scores[:, cls_id]
+        if self.training and train_cfg.get("disable_pretrain", False) and not runtime_info.get("enable_detection", False):
+            k = min(train_cfg.get("disable_pretrain_topks", [100, 100, 100])[cls_id], len(seg_scores))
+            fg_mask = torch.zeros_like(seg_scores, dtype=torch.bool)
+            fg_mask[torch.topk(seg_scores, k)[1]] = True
+        else:
+            buffer_thr = runtime_info.get("threshold_buffer", 0) if self.training else 0
+            fg_mask = seg_scores > self.cfg["score_thresh"][cls_id] + buffer_thr
+        cfg = train_cfg if self.training else (getattr(self, "test_cfg", None) or {})
+        if cfg.get("add_gt_fg_points", False):
+            raise NotImplementedError("add_gt_fg_points (points_in_boxes on the GT boxes) is outside the hot path")
+        return fg_mask
 
     def gather_group_by_names(self, scores):
         groups, class_names = self.cfg["group_names"], self.cfg["class_names"]
