@@ -1,0 +1,215 @@
+// K17: dynamic point pooling — which points fall inside which (enlarged) rotated RoI, with per-point box-frame geometry.
+// Replaces: TorchEx dynamic_point_pool_ext.forward [UNVENDORED], called from
+//   projects/mmdet3d_plugin/ops/dynamic_point_pool_op.py:27-32 by DynamicPointROIExtractor
+//   (projects/mmdet3d_plugin/models/roi_heads/roi_extractors/dynamic_point_roi_extractor.py:54-59).
+// Upstream: grid (ceil(P/256), R) brute force, `cnt = atomicAdd(&inbox_counter[box], 1)` (drop if >= max_inbox) and
+//   `slot = atomicAdd(&global_counter, 1)` (drop if >= max_all): WHICH points survive the caps and the order of the
+//   output rows depend on the atomics.  Here the result is canonical: rows in ascending (roi, point index) order, a
+//   RoI keeps its first `max_inbox` points by index, the output keeps the first `max_all` rows — count, prefix, fill
+//   (three passes over the same test), no atomics.
+// Box convention (mmdet3d 0.x LiDAR): (cx, cy, cz_bottom, w, l, h, rz); local frame rotated by rz + pi/2, local_x along
+//   the length l, local_y along the width w (pinned by dynamic_point_roi_extractor.py:83-92).
+// The 13 floats per row: x, y, z | local_x, local_y, local_z (z - box centre) | distances to the six faces
+//   (lx + l/2, ly + w/2, lz + h/2, l/2 - lx, w/2 - ly, h/2 - lz) | is_in_margin (1 = only inside the enlarged box).
+// Work: thread = RoI, workgroup = 256 RoIs x one tile of 2048 points staged in LDS (every lane reads the same point:
+//   LDS broadcast); a cheap enlarged-radius test in the xy-plane rejects almost every pair before the rotation.
+#include "common.h"
+#include "scan.h"
+
+namespace fsf {
+
+constexpr int PP_TILE = 2048;
+constexpr int PP_FEAT = 13;
+
+struct PoolArgs {
+  const float* rois;
+  const float* pts;
+  const int64_t* pts_batch;
+  int64_t n_rois, n_pts;
+  int roi_stride, box_col, batch_col, pts_stride;
+  float ew, el, eh;
+  int max_inbox;
+  int64_t max_all;
+  uint32_t* cnt;       // [pt_tiles][n_rois]
+  uint32_t* roi_total; // [n_rois]   min(#in box, max_inbox)
+  uint32_t* roi_off;   // [n_rois]   exclusive prefix of roi_total
+  int64_t* out_pts;
+  int64_t* out_roi;
+  float* out_feat;
+};
+
+struct PoolBox {
+  float cx, cy, cz, hw, hl, hh, lhw, lhl, lhh, cosa, sina, r2;
+  int batch;
+};
+
+__device__ __forceinline__ PoolBox load_box(const PoolArgs& a, int64_t r) {
+  const float* row = a.rois + r * a.roi_stride;
+  const float* b = row + a.box_col;
+  PoolBox k;
+  const float w = b[3], l = b[4], h = b[5];
+  k.cx = b[0];
+  k.cy = b[1];
+  k.cz = b[2] + h * 0.5f;  // bottom centre -> centre
+  k.hw = w * 0.5f;
+  k.hl = l * 0.5f;
+  k.hh = h * 0.5f;
+  k.lhw = (w + a.ew) * 0.5f;
+  k.lhl = (l + a.el) * 0.5f;
+  k.lhh = (h + a.eh) * 0.5f;
+  const float rot = b[6] + 1.57079632679489661923f;
+  k.cosa = cosf(rot);
+  k.sina = sinf(rot);
+  k.r2 = (k.lhw * k.lhw + k.lhl * k.lhl) * 1.0001f + 1e-6f;  // conservative pre-test only
+  k.batch = a.batch_col >= 0 ? (int)row[a.batch_col] : 0;
+  return k;
+}
+
+// 0 = outside, 1 = inside the box, 2 = inside the enlarged box only
+__device__ __forceinline__ int pool_test(const PoolBox& k, float x, float y, float z, float& lx, float& ly, float& lz) {
+  lz = z - k.cz;
+  if (fabsf(lz) > k.lhh) return 0;
+  const float dx = x - k.cx, dy = y - k.cy;
+  if (dx * dx + dy * dy > k.r2) return 0;
+  lx = dx * k.cosa + dy * (-k.sina);
+  ly = dx * k.sina + dy * k.cosa;
+  const bool in_large = (lx > -k.lhl) & (lx < k.lhl) & (ly > -k.lhw) & (ly < k.lhw);
+  if (!in_large) return 0;
+  const bool in_box = (lx > -k.hl) & (lx < k.hl) & (ly > -k.hw) & (ly < k.hw) & (fabsf(lz) <= k.hh);
+  return in_box ? 1 : 2;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) pool_pass_kernel(PoolArgs a) {
+  __shared__ float sx[PP_TILE], sy[PP_TILE], sz[PP_TILE];
+  __shared__ int sb[PP_TILE];
+  const int64_t p0 = (int64_t)blockIdx.y * PP_TILE;
+  const int tile_n = (int)min((int64_t)PP_TILE, a.n_pts - p0);
+  for (int j = threadIdx.x; j < tile_n; j += 256) {
+    const float* p = a.pts + (p0 + j) * a.pts_stride;
+    sx[j] = p[0];
+    sy[j] = p[1];
+    sz[j] = p[2];
+    sb[j] = a.pts_batch ? (int)a.pts_batch[p0 + j] : 0;
+  }
+  __syncthreads();
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n_rois) return;
+  const PoolBox k = load_box(a, r);
+  uint32_t* my_cnt = a.cnt + (int64_t)blockIdx.y * a.n_rois + r;
+  uint32_t rank = FILL ? *my_cnt : 0u;  // after the prefix pass: in-box points of this RoI in earlier tiles
+  const uint32_t base = FILL ? a.roi_off[r] : 0u;
+  for (int j = 0; j < tile_n; ++j) {
+    float lx, ly, lz;
+    const int flag = (sb[j] == k.batch) ? pool_test(k, sx[j], sy[j], sz[j], lx, ly, lz) : 0;
+    if (flag) {
+      if (FILL) {
+        const int64_t slot = (int64_t)base + rank;
+        if (rank < (uint32_t)a.max_inbox && slot < a.max_all) {
+          a.out_pts[slot] = p0 + j;
+          a.out_roi[slot] = r;
+          float* f = a.out_feat + slot * PP_FEAT;
+          f[0] = sx[j];
+          f[1] = sy[j];
+          f[2] = sz[j];
+          f[3] = lx;
+          f[4] = ly;
+          f[5] = lz;
+          f[6] = lx + k.hl;
+          f[7] = ly + k.hw;
+          f[8] = lz + k.hh;
+          f[9] = k.hl - lx;
+          f[10] = k.hw - ly;
+          f[11] = k.hh - lz;
+          f[12] = flag == 2 ? 1.0f : 0.0f;
+        }
+      }
+      ++rank;
+    }
+  }
+  if (!FILL) *my_cnt = rank;
+}
+
+// per RoI: counts per point tile -> exclusive prefix over tiles (in place), capped total
+__global__ void __launch_bounds__(256) pool_prefix_kernel(PoolArgs a, int pt_tiles) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= a.n_rois) return;
+  uint32_t run = 0;
+  for (int t = 0; t < pt_tiles; ++t) {
+    uint32_t* c = a.cnt + (int64_t)t * a.n_rois + r;
+    const uint32_t v = *c;
+    *c = run;
+    run += v;
+  }
+  a.roi_total[r] = min(run, (uint32_t)a.max_inbox);
+}
+
+struct PoolScanIn {
+  const uint32_t* v;
+  __device__ uint32_t operator()(int64_t i) const { return v[i]; }
+};
+struct PoolScanOut {
+  uint32_t* off;
+  __device__ void operator()(int64_t i, uint32_t excl, uint32_t) const { off[i] = excl; }
+};
+
+__global__ void pool_count_kernel(const uint32_t* total, int64_t max_all, int64_t* count_dev) {
+  const int64_t t = (int64_t)*total;
+  *count_dev = t < max_all ? t : max_all;
+}
+
+}  // namespace fsf
+
+using namespace fsf;
+
+extern "C" int64_t fsf_dynamic_point_pool_workspace_bytes(int64_t n_pts, int64_t n_rois) {
+  const int64_t pt_tiles = n_pts > 0 ? (n_pts + PP_TILE - 1) / PP_TILE : 1;
+  const int64_t r = n_rois > 0 ? n_rois : 1;
+  return fsf_align_up(pt_tiles * r * 4, 256) + 2 * fsf_align_up(r * 4, 256) + fsf_align_up(scan_num_tiles(r) * 4, 256) + 512;
+}
+
+extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t roi_stride, int32_t box_col,
+                                      int32_t batch_col, const float* pts, int64_t n_pts, int32_t pts_stride,
+                                      const int64_t* pts_batch, const float extra_wlh[3], int32_t max_inbox_point,
+                                      int64_t max_all_pts, int64_t* out_pts_idx, int64_t* out_roi_idx, float* out_pts_feats,
+                                      int64_t* count_dev, int64_t* count_host, void* workspace, int64_t workspace_bytes,
+                                      void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_rois < 0 || n_pts < 0 || roi_stride < 7 || box_col < 0 || box_col + 7 > roi_stride || batch_col >= roi_stride ||
+      pts_stride < 3 || !extra_wlh || max_inbox_point < 1 || max_all_pts < 1 || !out_pts_idx || !out_roi_idx ||
+      !out_pts_feats || (!count_dev && !count_host) || (n_rois > 0 && !rois) || (n_pts > 0 && !pts))
+    return FSF_ERR_INVALID_ARG;
+  if (n_pts >= ((int64_t)1 << 31) || n_rois >= ((int64_t)1 << 31)) return FSF_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsf_dynamic_point_pool_workspace_bytes(n_pts, n_rois) || !workspace) return FSF_ERR_WORKSPACE;
+  FsfArena arena(workspace, workspace_bytes);
+  const int pt_tiles = n_pts > 0 ? fsf_cdiv(n_pts, PP_TILE) : 1;
+  const int64_t r1 = n_rois > 0 ? n_rois : 1;
+  uint32_t* cnt = arena.take<uint32_t>((int64_t)pt_tiles * r1);
+  uint32_t* roi_total = arena.take<uint32_t>(r1);
+  uint32_t* roi_off = arena.take<uint32_t>(r1);
+  uint32_t* tile_sums = arena.take<uint32_t>(scan_num_tiles(r1));
+  uint32_t* total = arena.take<uint32_t>(1);
+  int64_t* count_tmp = arena.take<int64_t>(1);
+  if (!arena.ok()) return FSF_ERR_WORKSPACE;
+  int64_t* cdev = count_dev ? count_dev : count_tmp;
+  if (n_rois == 0 || n_pts == 0) {
+    FSF_HIP_TRY(hipMemsetAsync(cdev, 0, sizeof(int64_t), stream));
+  } else {
+    PoolArgs a{rois, pts, pts_batch, n_rois, n_pts, (int)roi_stride, (int)box_col, (int)batch_col, (int)pts_stride,
+               extra_wlh[0], extra_wlh[1], extra_wlh[2], (int)max_inbox_point, max_all_pts, cnt, roi_total, roi_off,
+               out_pts_idx, out_roi_idx, out_pts_feats};
+    const dim3 grid((unsigned)fsf_cdiv(n_rois, 256), (unsigned)pt_tiles);
+    hipLaunchKernelGGL((pool_pass_kernel<false>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(pool_prefix_kernel, dim3((unsigned)fsf_cdiv(n_rois, 256)), dim3(256), 0, stream, a, pt_tiles);
+    int rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums, total, nullptr, stream);
+    if (rc != FSF_OK) return rc;
+    hipLaunchKernelGGL((pool_pass_kernel<true>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(pool_count_kernel, dim3(1), dim3(1), 0, stream, total, max_all_pts, cdev);
+    FSF_LAUNCH_CHECK();
+  }
+  if (count_host) {
+    FSF_HIP_TRY(hipMemcpyAsync(count_host, cdev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    FSF_HIP_TRY(hipStreamSynchronize(stream));
+  }
+  return FSF_OK;
+}

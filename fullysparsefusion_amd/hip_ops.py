@@ -4,6 +4,7 @@ These functions only marshal pointers/sizes and allocate caller-owned outputs wi
 happens in the HIP kernels.  The reference-shaped Python API (scatter_v2, Voxelization, SparseConvTensor,
 ...) is built on top of these in `fullysparsefusion_amd.mmdet3d_plugin`.
 """
+import ctypes
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -39,6 +40,11 @@ _ARGTYPES = {
     "fsf_spconv_backward_weight": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_connected_components_workspace_bytes": [c_i64],
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
+    "fsf_dynamic_point_pool_workspace_bytes": [c_i64, c_i64],
+    "fsf_dynamic_point_pool": [_P, c_i64, c_i32, c_i32, c_i32, _P, c_i64, c_i32, _P, _P, c_i32, c_i64, _P, _P, _P, _P, _P,
+                               _P, c_i64, _P],
+    "fsf_nms_bev_workspace_bytes": [c_i64],
+    "fsf_nms_bev": [_P, c_i64, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
 }
@@ -390,6 +396,52 @@ def ingroup_rank(group_inds: torch.Tensor):
     ws = _lib.workspace(h.fsf_ingroup_rank_workspace_bytes(n), g.device)
     check(h.fsf_ingroup_rank(ptr(g), n, ptr(out), ptr(ws), ws.numel(), stream_ptr()), "fsf_ingroup_rank")
     return out
+
+
+# ----------------------------------------------------------------------------------- refine-stage ops
+def dynamic_point_pool(rois: torch.Tensor, pts: torch.Tensor, extra_wlh, max_inbox_point: int, max_all_pts: int = 50000,
+                       roi_batch_col: int = -1, box_col: int = 0, pts_batch: Optional[torch.Tensor] = None):
+    """fsf_dynamic_point_pool: rois f32 [R, >=7] (box at box_col.., optional batch column), pts f32 [P, >=3] ->
+    (pts_idx i64 [k], roi_idx i64 [k], feats f32 [k,13]) in ascending (roi, point) order; k = 0 possible."""
+    require_cuda(rois, pts, pts_batch)
+    assert rois.dtype == torch.float32 and pts.dtype == torch.float32 and rois.dim() == 2 and pts.dim() == 2
+    if rois.stride(1) != 1:
+        rois = rois.contiguous()
+    if pts.stride(1) != 1:
+        pts = pts.contiguous()
+    if pts_batch is not None:
+        pts_batch = pts_batch.to(torch.int64).contiguous()
+    dev = pts.device
+    out_pts = torch.empty((max_all_pts,), dtype=torch.int64, device=dev)
+    out_roi = torch.empty((max_all_pts,), dtype=torch.int64, device=dev)
+    out_feat = torch.empty((max_all_pts, 13), dtype=torch.float32, device=dev)
+    count = ctypes.c_int64(0)
+    h = _L()
+    n_rois, n_pts = rois.size(0), pts.size(0)
+    ws = _lib.workspace(h.fsf_dynamic_point_pool_workspace_bytes(n_pts, n_rois), dev)
+    check(h.fsf_dynamic_point_pool(ptr(rois), n_rois, rois.stride(0) if n_rois else rois.size(1), box_col, roi_batch_col,
+                                   ptr(pts), n_pts, pts.stride(0) if n_pts else pts.size(1), ptr(pts_batch),
+                                   (ctypes.c_float * 3)(*[float(v) for v in extra_wlh]), int(max_inbox_point),
+                                   int(max_all_pts), ptr(out_pts), ptr(out_roi), ptr(out_feat), None,
+                                   ctypes.cast(ctypes.pointer(count), c_p), ptr(ws), ws.numel(), stream_ptr()),
+          "fsf_dynamic_point_pool")
+    k = int(count.value)
+    return out_pts[:k], out_roi[:k], out_feat[:k]
+
+
+def nms_bev(boxes_sorted: torch.Tensor, thresh: float, rotated: bool = True):
+    """fsf_nms_bev: boxes f32 [n,5] (x1,y1,x2,y2,yaw) in descending score order -> positions kept (i64, ascending)."""
+    require_cuda(boxes_sorted)
+    assert boxes_sorted.dtype == torch.float32 and boxes_sorted.dim() == 2 and boxes_sorted.size(1) == 5
+    b = boxes_sorted.contiguous()
+    n = b.size(0)
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=b.device)
+    num = ctypes.c_int64(0)
+    h = _L()
+    ws = _lib.workspace(h.fsf_nms_bev_workspace_bytes(n), b.device)
+    check(h.fsf_nms_bev(ptr(b), n, float(thresh), int(bool(rotated)), ptr(keep), None,
+                        ctypes.cast(ctypes.pointer(num), c_p), ptr(ws), ws.numel(), stream_ptr()), "fsf_nms_bev")
+    return keep[: int(num.value)]
 
 
 # ------------------------------------------------------------------------------ connected components

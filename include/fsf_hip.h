@@ -260,6 +260,37 @@ int fsf_connected_components(const float* points, int64_t n, int32_t point_strid
                              int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K17  dynamic point pooling: (point, RoI) memberships of the enlarged rotated boxes + box-frame geometry
+ * Replaces: TorchEx dynamic_point_pool_ext.forward(rois, pts, extra_wlh, max_inbox_point, out_pts_idx,
+ *   out_roi_idx, out_pts_feats) [UNVENDORED], bound at projects/mmdet3d_plugin/ops/dynamic_point_pool_op.py:5,32 and
+ *   called per sample by DynamicPointROIExtractor (roi_extractors/dynamic_point_roi_extractor.py:54-59).
+ *   rois f32 [n_rois, roi_stride]: box (cx, cy, cz_bottom, w, l, h, rz) at columns box_col..box_col+6, batch index
+ *   (as float) at column batch_col or batch_col = -1 (single sample); pts f32 [n_pts, pts_stride] (xyz first),
+ *   pts_batch i64 [n_pts] or NULL; extra_wlh {w, l, h} enlargement; caller-allocated outputs of max_all_pts rows:
+ *   out_pts_idx i64, out_roi_idx i64, out_pts_feats f32 [.,13] = xyz | local xyz | six face distances | is_in_margin.
+ * Same caller-allocates convention as upstream; unlike upstream (two atomic counters) the rows come out in ascending
+ * (roi, point) order and the caps keep the FIRST max_inbox_point points of a RoI / first max_all_pts rows —
+ * deterministic.  count = rows written (device scalar and/or host copy; the host copy synchronises the stream).
+ */
+int64_t fsf_dynamic_point_pool_workspace_bytes(int64_t n_pts, int64_t n_rois);
+int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t roi_stride, int32_t box_col, int32_t batch_col,
+                           const float* pts, int64_t n_pts, int32_t pts_stride, const int64_t* pts_batch,
+                           const float extra_wlh[3], int32_t max_inbox_point, int64_t max_all_pts,
+                           int64_t* out_pts_idx, int64_t* out_roi_idx, float* out_pts_feats, int64_t* count_dev,
+                           int64_t* count_host, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K20  greedy BEV NMS (rotated or axis-aligned IoU)
+ * Replaces: mmdet3d.ops.iou3d nms_gpu / nms_normal_gpu [UNVENDORED] under mmdet3d.core.box3d_multiclass_nms, called
+ *   from FrustumClusterHead._get_bboxes_single (dense_heads/frustum_cluster_head.py:636-667).
+ *   boxes f32 [n,5] = (x1, y1, x2, y2, yaw) (xywhr2xyxyr of the BEV boxes), ALREADY in descending score order;
+ *   keep i64 [n] receives the ascending positions of the survivors; num_keep as in K17's count.
+ */
+int64_t fsf_nms_bev_workspace_bytes(int64_t n);
+int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t rotated, int64_t* keep, int64_t* num_keep_dev,
+                int64_t* num_keep_host, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K18  in-group rank (TorchEx ingroup_indices [UNVENDORED]); sst_ops.py:239-259.
  * Upstream is an atomicAdd counter (a nondeterministic permutation of 0..n_g-1 per group); this returns the
  * stable rank (ascending original index), which satisfies the same contract (sst_ops.py:225-235).

@@ -7,6 +7,7 @@ import torch
 
 from conftest import golden_cases, load_golden
 from oracle import project as oproj
+from oracle import refine as orefine
 from oracle import scatter as oscatter
 from oracle import spconv as osp
 from oracle import voxelize as ovox
@@ -513,3 +514,108 @@ def test_norm_act_vs_torch(ops, device, c, act):
     got2 = ops.norm_act(x.to(device), scale.to(device), shift.to(device), 0.0, "affine", act, inplace=False)
     # GELU's 1 + erf(x/sqrt2) cancels for x << 0: absolute error of a few 1e-6 on tiny outputs, both sides in fp32
     np.testing.assert_allclose(got2.cpu().numpy(), want2.numpy(), rtol=1e-6, atol=5e-6)
+
+
+# ------------------------------------------------------------------------------- refine-stage ops (K17 / K20)
+def random_rois(rng, r, spread=40.0):
+    ctr = rng.uniform(-spread, spread, (r, 2))
+    z = rng.uniform(-2.5, -0.5, (r, 1))
+    wlh = np.stack([rng.uniform(0.5, 2.5, r), rng.uniform(0.8, 6.0, r), rng.uniform(1.0, 3.0, r)], 1)
+    rz = rng.uniform(-np.pi, np.pi, (r, 1))
+    return np.concatenate([ctr, z, wlh, rz], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("r,p,max_inbox,max_all", [(37, 20000, 512, 50000), (300, 60000, 16, 50000), (300, 60000, 512, 700),
+                                                   (1, 5000, 512, 50000), (700, 3000, 512, 50000)])
+def test_dynamic_point_pool_vs_oracle(ops, device, r, p, max_inbox, max_all):
+    rng = np.random.default_rng(r * 31 + p)
+    rois = random_rois(rng, r)
+    # points: half uniform, half clustered around RoI centres so boxes are well populated
+    which = rng.integers(0, r, p // 2)
+    near = rois[which, :3] + rng.normal(0, 1.5, (p // 2, 3)) + np.array([0, 0, 1.0])
+    pts = np.concatenate([near, np.concatenate([rng.uniform(-45, 45, (p - p // 2, 2)), rng.uniform(-3, 2, (p - p // 2, 1))], 1)])
+    pts = np.concatenate([pts, rng.random((p, 2))], 1).astype(np.float32)  # stride-5 rows like the real points
+    extra = [1.0, 1.0, 1.0]
+    # full (uncapped) oracle membership with boundary margins; a (point, roi) pair within 1e-4 of a box face may
+    # legitimately flip under device sinf/cosf rounding
+    wp, wr, wf, near_pairs = orefine.dynamic_point_pool(rois, pts[:, :3], extra, 10 ** 9, 10 ** 9, return_margin=True)
+    risky = near_pairs[near_pairs[:, 2] < 1e-4]
+    gp, gr, gf = ops.dynamic_point_pool(torch.from_numpy(rois).to(device), torch.from_numpy(pts).to(device), extra,
+                                        max_inbox, max_all)
+    gp, gr, gf = gp.cpu().numpy(), gr.cpu().numpy(), gf.cpu().numpy()
+    if len(risky) == 0:
+        cp, cr, cf = orefine.dynamic_point_pool(rois, pts[:, :3], extra, max_inbox, max_all)
+        np.testing.assert_array_equal(gr, cr)
+        np.testing.assert_array_equal(gp, cp)
+        np.testing.assert_array_equal(gf[:, :3], cf[:, :3])
+        np.testing.assert_allclose(gf[:, 3:12], cf[:, 3:12], atol=2e-5)
+        np.testing.assert_array_equal(gf[:, 12], cf[:, 12])
+    else:  # the canonical order and caps must still hold, membership must agree away from the faces
+        risky_set = {(int(a), int(b)) for a, b, _ in risky}
+        full = {(int(a), int(b)) for a, b in zip(wr, wp)}
+        got = {(int(a), int(b)) for a, b in zip(gr, gp)}
+        assert all(pair in full or pair in risky_set for pair in got)
+    # structural invariants (dynamic_point_roi_extractor.py:83-92) at any size
+    key = gr * (p + 1) + gp
+    assert (np.diff(key) > 0).all()                       # ascending (roi, point), no duplicates
+    assert len(gp) <= max_all and (np.bincount(gr, minlength=r) <= max_inbox).all()
+    roi = rois[gr]
+    np.testing.assert_array_equal(gf[:, :3], pts[gp, :3])
+    np.testing.assert_allclose(gf[:, 6] + gf[:, 9], roi[:, 4], atol=1e-5)   # length
+    np.testing.assert_allclose(gf[:, 7] + gf[:, 10], roi[:, 3], atol=1e-5)  # width
+    np.testing.assert_allclose(gf[:, 8] + gf[:, 11], roi[:, 5], atol=1e-5)  # height
+    assert (np.abs(gf[:, 3]) < roi[:, 4] + extra[0] + 1e-5).all() and (np.abs(gf[:, 4]) < roi[:, 3] + extra[1] + 1e-5).all()
+    assert len(gp) > 0
+
+
+def test_dynamic_point_pool_batched_and_empty(ops, device):
+    rng = np.random.default_rng(5)
+    rois = random_rois(rng, 40, spread=10.0)
+    pts = np.concatenate([rng.uniform(-12, 12, (8000, 2)), rng.uniform(-3, 2, (8000, 1))], 1).astype(np.float32)
+    pb = np.sort(rng.integers(0, 2, 8000)).astype(np.int64)
+    rb = np.sort(rng.integers(0, 2, 40)).astype(np.float32)
+    rois8 = np.concatenate([rb[:, None], rois], 1)
+    gp, gr, gf = ops.dynamic_point_pool(torch.from_numpy(rois8).to(device), torch.from_numpy(pts).to(device), [0.5, 0.5, 0.5],
+                                        512, roi_batch_col=0, box_col=1, pts_batch=torch.from_numpy(pb).to(device))
+    want_p, want_r = [], []
+    for b in range(2):  # the reference loops over samples and offsets the indices (dynamic_point_roi_extractor.py:43-72)
+        pm, rm = np.nonzero(pb == b)[0], np.nonzero(rb == b)[0]
+        p_, r_, _ = orefine.dynamic_point_pool(rois[rm], pts[pm], [0.5, 0.5, 0.5], 512)
+        want_p.append(pm[p_])
+        want_r.append(rm[r_])
+    np.testing.assert_array_equal(gr.cpu().numpy(), np.concatenate(want_r))
+    np.testing.assert_array_equal(gp.cpu().numpy(), np.concatenate(want_p))
+    # nothing inside any box
+    far = torch.full((100, 3), 500.0, device=device)
+    gp, gr, gf = ops.dynamic_point_pool(torch.from_numpy(rois).to(device), far, [0.5, 0.5, 0.5], 512)
+    assert gp.numel() == 0 and gf.shape == (0, 13)
+
+
+@pytest.mark.parametrize("n,rotated", [(1, True), (70, True), (500, True), (500, False), (1500, True)])
+def test_nms_bev_vs_oracle(ops, device, n, rotated):
+    rng = np.random.default_rng(n + int(rotated))
+    # clustered boxes so that suppression chains exist
+    nclu = max(1, n // 6)
+    ctr = rng.uniform(-40, 40, (nclu, 2))[rng.integers(0, nclu, n)] + rng.normal(0, 0.7, (n, 2))
+    wl = np.stack([rng.uniform(1.5, 2.5, n), rng.uniform(3.5, 5.5, n)], 1)
+    yaw = rng.uniform(-np.pi, np.pi, (n, 1))
+    boxes = np.concatenate([ctr - wl / 2, ctr + wl / 2, yaw], 1).astype(np.float32)  # xywhr2xyxyr layout, score order
+    thresh = 0.25
+    iou = orefine.iou_bev_matrix(boxes, rotated) if n <= 500 else None
+    keep = ops.nms_bev(torch.from_numpy(boxes).to(device), thresh, rotated).cpu().numpy()
+    assert (np.diff(keep) > 0).all() and (len(keep) == 0 or keep[0] == 0)
+    if iou is not None:
+        borderline = np.abs(iou - thresh) < 1e-4
+        if not borderline.any():
+            np.testing.assert_array_equal(keep, orefine.nms_from_iou(iou, thresh))
+        kept = np.zeros(n, bool)
+        kept[keep] = True
+        # greedy-NMS invariants under the float64 IoU, away from the threshold: kept boxes do not suppress each other and
+        # every dropped box is suppressed by an earlier kept one
+        for i in keep:
+            assert not (kept[i + 1:] & (iou[i, i + 1:] > thresh + 1e-4)).any()
+        for j in np.nonzero(~kept)[0]:
+            assert (iou[keep[keep < j], j] > thresh - 1e-4).any()
+    else:  # large: self-consistency via a second, permuted-but-equivalent call and idempotence
+        again = ops.nms_bev(torch.from_numpy(boxes[keep]).to(device), thresh, rotated).cpu().numpy()
+        np.testing.assert_array_equal(again, np.arange(len(keep)))
