@@ -43,6 +43,7 @@ def _cluster_head(head_type, in_channel, train_cfg=None, **extra):
     return cfg
 
 
+_HEAD_TEST_CFG = dict(use_rotate_nms=True, nms_pre=-1, nms_thr=0.35, score_thr=0.01, min_bbox_size=0, max_num=500)
 _sample_cfg = dict(score_thresh=SCORE_THRESH, pre_voxelization_size=(0.1, 0.1, 0.1), group_sample=True, offset_weight="max",
                    group_lens=GROUP_LENS, class_names=CLASSES, group_names=GROUPS)
 
@@ -86,9 +87,23 @@ model = dict(
         min_points=2, point_cloud_range=PC_RANGE, connected_dist=[0.6, 0.6, 0.6, 0.2, 0.4, 0.1], class_names=CLASSES),
     # camera query generation
     frustum_sir=_sir(67 + 64 + 5),
-    frustum_obj_head=_cluster_head("FrustumClusterHead", 128 * 3 * 2 + 128, train_cfg=dict()),
+    frustum_obj_head=_cluster_head("FrustumClusterHead", 128 * 3 * 2 + 128, train_cfg=dict(), test_cfg=_HEAD_TEST_CFG,
+                                   as_rpn=False),
     encode_2d_mlp_cfg=dict(in_channel=16, mlp_channel=[128, 128], norm_cfg=LN3, act="gelu"),
     segmentor_updated_mlp=dict(in_channel=10, mlp_channel=[128, 67 + 64], norm_cfg=LN3, act="gelu"),
     mlp_cfg=dict(embed_dims=1024, norm_cfg=LN3, act="gelu", lidar_img_input_dim=128 * 3 * 2 + 128, lidar_input_dim=128 * 3 * 2),
-    refined_obj_head=[],  # the refine stage is not built in this round
+    # query refinement: RoI point pooling (K17) -> 3 SIR layers per RoI -> fused query -> head -> BEV NMS (K20)
+    bbox_coder=dict(type="BasePointBBoxCoder", code_size=10),
+    roi_extractor=dict(type="DynamicPointROIExtractor", extra_wlh=[1.0, 1.0, 1.0], max_inbox_point=512, debug=False),
+    single_refine_sir_layer=dict(
+        type="FullySparseBboxHead", num_classes=NUM_CLASSES, num_blocks=3,
+        in_channels=[67 + 5 + 13 + 32 + 64, 131 + 13 + 2, 131 + 13 + 2], feat_channels=[[128, 128]] * 3, with_distance=False,
+        with_cluster_center=False, with_rel_mlp=True, rel_mlp_hidden_dims=[[16, 32]] * 3, rel_mlp_in_channels=[13] * 3,
+        reg_mlp=[512, 512], cls_mlp=[512, 512], mode="max", xyz_normalizer=[20, 20, 4], cat_voxel_feats=True, pos_fusion="mul",
+        fusion="cat", act="gelu", geo_input=True, use_middle_cluster_feature=True, norm_cfg=LN3, unique_once=True),
+    refined_obj_head=[
+        _cluster_head("FrustumClusterHead", 1024, test_cfg=_HEAD_TEST_CFG, as_rpn=False,
+                      loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=4.0, alpha=0.25, loss_weight=2.0)),
+    ],
+    refine_encode_2d_mlp_cfg=dict(in_channel=10, mlp_channel=[32, 32], norm_cfg=LN3, act="gelu"),
 )

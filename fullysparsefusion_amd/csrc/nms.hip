@@ -20,8 +20,9 @@ struct NmsArgs {
   int64_t n;
   float thresh;
   int rotated;
-  uint64_t* mask;  // [n][words]
-  int words;
+  uint64_t* mask;    // [n][words]   bit j of word w of row i: box 64 w + j (> i) overlaps box i beyond the threshold
+  uint64_t* rowsum;  // [n][sum_words]   bit w set iff mask[i][w] != 0 (lets the scan skip the zero words)
+  int words, sum_words;
   int64_t* keep;
   int64_t* num_keep;
 };
@@ -96,41 +97,119 @@ __device__ __forceinline__ float iou_bev(const float* a, const float* b, int rot
   return ov / fmaxf(sa + sb - ov, 1e-8f);
 }
 
-// block (col word, row block): thread = row box, tests it against the 64 boxes of the column word
+// block (col word, row block): thread = row box, tests it against the 64 boxes of the column word.  A pair whose
+// circumscribed circles do not touch cannot overlap: that test (5 flops) removes nearly every pair of a real scene
+// before the polygon clipping.
 __global__ void __launch_bounds__(64) nms_mask_kernel(NmsArgs a) {
   const int col_blk = blockIdx.x, row_blk = blockIdx.y;
   if (col_blk < row_blk) return;  // a box is only suppressed by an earlier (higher-score) one
   __shared__ float cb[64 * 5];
+  __shared__ float ccx[64], ccy[64], crad[64];
   const int64_t c0 = (int64_t)col_blk * 64;
   const int ncol = (int)min((int64_t)64, a.n - c0);
   for (int t = threadIdx.x; t < ncol * 5; t += 64) cb[t] = a.boxes[c0 * 5 + t];
+  __syncthreads();
+  if ((int)threadIdx.x < ncol) {
+    const float* b = cb + threadIdx.x * 5;
+    const float hx = 0.5f * (b[2] - b[0]), hy = 0.5f * (b[3] - b[1]);
+    ccx[threadIdx.x] = 0.5f * (b[0] + b[2]);
+    ccy[threadIdx.x] = 0.5f * (b[1] + b[3]);
+    crad[threadIdx.x] = sqrtf(hx * hx + hy * hy);
+  }
   __syncthreads();
   const int64_t i = (int64_t)row_blk * 64 + threadIdx.x;
   if (i >= a.n) return;
   float mine[5];
 #pragma unroll
   for (int t = 0; t < 5; ++t) mine[t] = a.boxes[i * 5 + t];
+  const float mhx = 0.5f * (mine[2] - mine[0]), mhy = 0.5f * (mine[3] - mine[1]);
+  const float mcx = 0.5f * (mine[0] + mine[2]), mcy = 0.5f * (mine[1] + mine[3]);
+  const float mrad = sqrtf(mhx * mhx + mhy * mhy);
   uint64_t bits = 0;
   const int start = (row_blk == col_blk) ? threadIdx.x + 1 : 0;
-  for (int j = start; j < ncol; ++j)
+  for (int j = start; j < ncol; ++j) {
+    if (a.rotated) {
+      const float dx = ccx[j] - mcx, dy = ccy[j] - mcy, rr = (crad[j] + mrad) * 1.0001f;
+      if (dx * dx + dy * dy > rr * rr) continue;
+    }
     if (iou_bev(mine, cb + j * 5, a.rotated) > a.thresh) bits |= 1ull << j;
+  }
   a.mask[i * a.words + col_blk] = bits;
+  if (bits) atomicOr((unsigned long long*)&a.rowsum[i * a.sum_words + (col_blk >> 6)], 1ull << (col_blk & 63));
 }
 
-// one workgroup: greedy scan in score order
+// One workgroup: greedy scan in score order, one 64-box word at a time.  Inside a word the dependency chain (a kept box
+// removes later boxes of the same word) is resolved by wave 0 on the diagonal mask words held one per lane; the rows
+// of the kept boxes are then OR-ed into the `removed` bits of the later words — only the non-zero words, found through
+// the per-row summary bits (a real scene has a handful of overlaps per box, so the dense row is never walked).
 __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
   extern __shared__ uint64_t removed[];
+  __shared__ uint64_t kept_word;
   __shared__ int64_t nkeep;
   for (int w = threadIdx.x; w < a.words; w += 256) removed[w] = 0;
   if (threadIdx.x == 0) nkeep = 0;
   __syncthreads();
-  for (int64_t i = 0; i < a.n; ++i) {
-    const bool dead = (removed[i >> 6] >> (i & 63)) & 1ull;  // same value in every thread (read after a barrier)
-    if (dead) continue;
-    __syncthreads();  // everyone has read bit i before anyone updates the words
-    if (threadIdx.x == 0) a.keep[nkeep++] = i;
-    const uint64_t* row = a.mask + i * a.words;
-    for (int w = (int)(i >> 6) + threadIdx.x; w < a.words; w += 256) removed[w] |= row[w];
+  const int lane = threadIdx.x & 63;
+  // up to 16384 boxes the summary words of a 64-row block are one load per thread and are prefetched a step ahead
+  // together with the diagonal words; beyond that they are loaded on demand
+  const bool pre = 64 * a.sum_words <= 256;
+  const int ub = threadIdx.x & 63, uq = threadIdx.x >> 6;
+  uint64_t diag_next = (threadIdx.x < 64 && lane < a.n) ? a.mask[(int64_t)lane * a.words] : 0ull;
+  uint64_t sum_next = (pre && uq < a.sum_words && ub < a.n) ? a.rowsum[(int64_t)ub * a.sum_words + uq] : 0ull;
+  for (int w = 0; w < a.words; ++w) {
+    const int64_t i0 = (int64_t)w * 64;
+    const int nb = (int)min((int64_t)64, a.n - i0);
+    const uint64_t sum_cur = sum_next;
+    if (pre && w + 1 < a.words && uq < a.sum_words && i0 + 64 + ub < a.n) sum_next = a.rowsum[(i0 + 64 + ub) * a.sum_words + uq];
+    else sum_next = 0ull;
+    if (threadIdx.x < 64) {
+      const uint64_t diag = diag_next;
+      if (w + 1 < a.words && i0 + 64 + lane < a.n) diag_next = a.mask[(i0 + 64 + lane) * a.words + w + 1];  // prefetch
+      else diag_next = 0ull;
+      const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+      uint64_t alive = ~removed[w];
+      if (nb < 64) alive &= (1ull << nb) - 1ull;
+      uint64_t kept = 0;
+      while (alive) {  // `alive` is the same in every lane; each pass settles its lowest box
+        const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+        const uint64_t row = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dlo, b) |
+                             ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dhi, b) << 32);
+        kept |= 1ull << b;
+        alive &= ~row;
+        alive &= ~(1ull << b);
+      }
+      if (lane == 0) {
+        kept_word = kept;
+        int64_t k = nkeep;
+        for (uint64_t m = kept; m; m &= m - 1) a.keep[k++] = i0 + __builtin_ctzll(m);
+        nkeep = k;
+      }
+    }
+    __syncthreads();
+    const uint64_t kept = kept_word;
+    const int q0 = w >> 6;
+    if (pre) {
+      if (uq >= q0 && uq < a.sum_words && ((kept >> ub) & 1ull)) {
+        uint64_t sbits = sum_cur;
+        if (uq == q0) sbits &= ~((2ull << (w & 63)) - 1ull);  // words <= w are already settled
+        for (; sbits; sbits &= sbits - 1) {
+          const int w2 = uq * 64 + __builtin_ctzll(sbits);
+          atomicOr((unsigned long long*)&removed[w2], (unsigned long long)a.mask[(i0 + ub) * a.words + w2]);
+        }
+      }
+    } else {
+      for (int u = threadIdx.x; u < 64 * (a.sum_words - q0); u += 256) {
+        const int b = u & 63, q = q0 + (u >> 6);
+        if (!((kept >> b) & 1ull)) continue;
+        const int64_t i = i0 + b;
+        uint64_t sbits = a.rowsum[i * a.sum_words + q];
+        if (q == q0) sbits &= ~((2ull << (w & 63)) - 1ull);
+        for (; sbits; sbits &= sbits - 1) {
+          const int w2 = q * 64 + __builtin_ctzll(sbits);
+          atomicOr((unsigned long long*)&removed[w2], (unsigned long long)a.mask[i * a.words + w2]);
+        }
+      }
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) *a.num_keep = nkeep;
@@ -141,8 +220,9 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
 using namespace fsf;
 
 extern "C" int64_t fsf_nms_bev_workspace_bytes(int64_t n) {
-  const int64_t words = (n + 63) / 64;
-  return fsf_align_up((n > 0 ? n : 1) * (words > 0 ? words : 1) * 8, 256) + 512;
+  const int64_t words = (n + 63) / 64, sum_words = (words + 63) / 64;
+  const int64_t n1 = n > 0 ? n : 1;
+  return fsf_align_up(n1 * (words > 0 ? words : 1) * 8, 256) + fsf_align_up(n1 * (sum_words > 0 ? sum_words : 1) * 8, 256) + 512;
 }
 
 extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t rotated, int64_t* keep,
@@ -154,14 +234,17 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
   if (words * 8 > 60 * 1024) return FSF_ERR_UNSUPPORTED;  // `removed` bitset lives in LDS (n <= 491520)
   if (workspace_bytes < fsf_nms_bev_workspace_bytes(n) || !workspace) return FSF_ERR_WORKSPACE;
   FsfArena arena(workspace, workspace_bytes);
+  const int64_t sum_words = (words + 63) / 64;
   uint64_t* mask = arena.take<uint64_t>((n > 0 ? n : 1) * (words > 0 ? words : 1));
+  uint64_t* rowsum = arena.take<uint64_t>((n > 0 ? n : 1) * (sum_words > 0 ? sum_words : 1));
   int64_t* tmp = arena.take<int64_t>(1);
   if (!arena.ok()) return FSF_ERR_WORKSPACE;
   int64_t* ndev = num_keep_dev ? num_keep_dev : tmp;
   if (n == 0) {
     FSF_HIP_TRY(hipMemsetAsync(ndev, 0, sizeof(int64_t), stream));
   } else {
-    NmsArgs a{boxes, n, thresh, (int)rotated, mask, (int)words, keep, ndev};
+    NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, ndev};
+    FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)n * sum_words * 8, stream));
     // words below the diagonal are never written by the mask kernel and never read by the scan (w starts at i / 64)
     hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, stream, a);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), (size_t)words * 8, stream, a);

@@ -419,8 +419,10 @@ def dynamic_point_pool(rois: torch.Tensor, pts: torch.Tensor, extra_wlh, max_inb
     h = _L()
     n_rois, n_pts = rois.size(0), pts.size(0)
     ws = _lib.workspace(h.fsf_dynamic_point_pool_workspace_bytes(n_pts, n_rois), dev)
-    check(h.fsf_dynamic_point_pool(ptr(rois), n_rois, rois.stride(0) if n_rois else rois.size(1), box_col, roi_batch_col,
-                                   ptr(pts), n_pts, pts.stride(0) if n_pts else pts.size(1), ptr(pts_batch),
+    # row-strided views (e.g. the xyz columns of [P,5] points) go through as they are: base pointer + row stride
+    check(h.fsf_dynamic_point_pool(c_p(rois.data_ptr()), n_rois, rois.stride(0) if n_rois else rois.size(1), box_col,
+                                   roi_batch_col, c_p(pts.data_ptr()), n_pts, pts.stride(0) if n_pts else pts.size(1),
+                                   ptr(pts_batch),
                                    (ctypes.c_float * 3)(*[float(v) for v in extra_wlh]), int(max_inbox_point),
                                    int(max_all_pts), ptr(out_pts), ptr(out_roi), ptr(out_feat), None,
                                    ctypes.cast(ctypes.pointer(count), c_p), ptr(ws), ws.numel(), stream_ptr()),

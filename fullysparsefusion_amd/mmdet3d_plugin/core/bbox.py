@@ -1,0 +1,183 @@
+"""Box-side pieces the heads need at inference:
+
+* `BasePointBBoxCoder` — projects/mmdet3d_plugin/core/bbox/coders/base_point_bbox_coder.py:8-82.
+* `LiDARInstance3DBoxes`, `xywhr2xyxyr`, `box3d_multiclass_nms`, `nms_gpu`, `nms_normal_gpu`, `bbox3d2result` — the
+  handful of mmdet3d 0.x [UNVENDORED] symbols imported at
+  projects/mmdet3d_plugin/models/dense_heads/frustum_cluster_head.py:9 and detectors/FSF.py (bbox3d2result), restated
+  from their published behaviour.  The NMS itself is the HIP kernel pair behind `fsf_nms_bev` (K20): the greedy scan
+  stays on the device instead of mmdet3d's bitmask-to-host round trip.
+"""
+import torch
+
+from ... import hip_ops
+from ..registry import BBOX_CODERS
+
+
+@BBOX_CODERS.register_module(force=True)
+class BasePointBBoxCoder:
+    """reg = (center - base_point, log(dims), sin(yaw), cos(yaw)[, vx, vy])."""
+
+    def __init__(self, post_center_range=None, score_thresh=0.1, num_classes=10, max_num=500, code_size=10):
+        self.post_center_range = post_center_range
+        self.code_size = code_size
+        self.EPS = 1e-6
+        self.score_thresh = score_thresh
+        self.num_classes = num_classes
+        self.max_num = max_num
+
+    def encode(self, bboxes, base_points):
+        assert bboxes.size(1) in (7, 9, 10), f"bboxes shape: {bboxes.shape}"
+        assert bboxes.size(0) == base_points.size(0)
+        yaw = bboxes[:, 6:7]
+        target = torch.cat([bboxes[:, :3] - base_points, (bboxes[:, 3:6] + self.EPS).log(), yaw.sin(), yaw.cos()], dim=1)
+        if bboxes.size(1) in (9, 10):  # velocity (or copy-paste flag) rides along
+            assert self.code_size == 10
+            target = torch.cat([target, bboxes[:, [7, 8]]], dim=1)
+        return target
+
+    def decode(self, reg_preds, base_points, detach_yaw=False):
+        assert reg_preds.size(1) in (8, 10) and reg_preds.size(1) == self.code_size
+        velo = reg_preds[:, -2:] if self.code_size == 10 else None
+        reg = reg_preds[:, :8]
+        dims = reg[:, 3:6].exp() - self.EPS
+        xyz = reg[:, :3] + base_points
+        yaw = torch.atan2(reg[:, 6:7], reg[:, 7:8])
+        if detach_yaw:
+            yaw = yaw.clone().detach()
+        parts = [xyz, dims, yaw] + ([velo] if velo is not None else [])
+        return torch.cat(parts, dim=1)
+
+
+class LiDARInstance3DBoxes:
+    """mmdet3d 0.x LiDAR boxes, as far as the FSF heads touch them: rows (x, y, z_bottom, w, l, h, yaw[, extras])."""
+
+    def __init__(self, tensor, box_dim=7, with_yaw=True, origin=(0.5, 0.5, 0)):
+        if not isinstance(tensor, torch.Tensor):
+            tensor = torch.as_tensor(tensor, dtype=torch.float32)
+        if tensor.numel() == 0:
+            tensor = tensor.reshape((0, box_dim)).to(dtype=torch.float32)
+        assert tensor.dim() == 2 and tensor.size(-1) == box_dim, tensor.size()
+        if tensor.shape[-1] == 6:
+            assert box_dim == 6
+            tensor = torch.cat((tensor, tensor.new_zeros(tensor.shape[0], 1)), dim=-1)
+            box_dim, with_yaw = 7, False
+        self.box_dim, self.with_yaw = box_dim, with_yaw
+        self.tensor = tensor.clone()
+        if tuple(origin) != (0.5, 0.5, 0):
+            self.tensor[:, :3] += self.tensor[:, 3:6] * (self.tensor.new_tensor((0.5, 0.5, 0)) - self.tensor.new_tensor(origin))
+
+    @property
+    def bev(self):
+        return self.tensor[:, [0, 1, 3, 4, 6]]
+
+    @property
+    def gravity_center(self):
+        c = self.tensor[:, :3].clone()
+        c[:, 2] = c[:, 2] + self.tensor[:, 5] * 0.5
+        return c
+
+    @property
+    def dims(self):
+        return self.tensor[:, 3:6]
+
+    @property
+    def yaw(self):
+        return self.tensor[:, 6]
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __getitem__(self, item):
+        if isinstance(item, int):
+            return type(self)(self.tensor[item].view(1, -1), box_dim=self.box_dim, with_yaw=self.with_yaw)
+        return type(self)(self.tensor[item], box_dim=self.box_dim, with_yaw=self.with_yaw)
+
+    def to(self, device):
+        return type(self)(self.tensor.to(device), box_dim=self.box_dim, with_yaw=self.with_yaw)
+
+    def clone(self):
+        return type(self)(self.tensor.clone(), box_dim=self.box_dim, with_yaw=self.with_yaw)
+
+    @classmethod
+    def cat(cls, boxes_list):
+        assert isinstance(boxes_list, (list, tuple))
+        if len(boxes_list) == 0:
+            return cls(torch.empty(0))
+        assert all(isinstance(b, cls) for b in boxes_list)
+        return cls(torch.cat([b.tensor for b in boxes_list], dim=0), box_dim=boxes_list[0].tensor.shape[1],
+                   with_yaw=boxes_list[0].with_yaw)
+
+    def __repr__(self):
+        return self.__class__.__name__ + "(\n    " + str(self.tensor) + ")"
+
+
+def xywhr2xyxyr(boxes_xywhr):
+    """(x, y, w, h, r) -> (x - w/2, y - h/2, x + w/2, y + h/2, r)."""
+    boxes = torch.zeros_like(boxes_xywhr)
+    half_w, half_h = boxes_xywhr[:, 2] / 2, boxes_xywhr[:, 3] / 2
+    boxes[:, 0] = boxes_xywhr[:, 0] - half_w
+    boxes[:, 1] = boxes_xywhr[:, 1] - half_h
+    boxes[:, 2] = boxes_xywhr[:, 0] + half_w
+    boxes[:, 3] = boxes_xywhr[:, 1] + half_h
+    boxes[:, 4] = boxes_xywhr[:, 4]
+    return boxes
+
+
+def _nms(boxes, scores, thresh, rotated, pre_maxsize=None, post_max_size=None):
+    order = scores.sort(0, descending=True)[1]
+    if pre_maxsize is not None:
+        order = order[:pre_maxsize]
+    keep = hip_ops.nms_bev(boxes[order].float().contiguous(), thresh, rotated=rotated)
+    keep = order[keep].contiguous()
+    if post_max_size is not None:
+        keep = keep[:post_max_size]
+    return keep
+
+
+def nms_gpu(boxes, scores, thresh, pre_maxsize=None, post_max_size=None):
+    """mmdet3d.ops.iou3d.nms_gpu: rotated BEV NMS; boxes (x1, y1, x2, y2, ry); returns kept indices into `boxes`."""
+    return _nms(boxes, scores, thresh, True, pre_maxsize, post_max_size)
+
+
+def nms_normal_gpu(boxes, scores, thresh):
+    """mmdet3d.ops.iou3d.nms_normal_gpu: the same with the yaw ignored."""
+    return _nms(boxes, scores, thresh, False)
+
+
+def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg):
+    """mmdet3d.core.post_processing.box3d_multiclass_nms (the arguments the FSF heads pass): per class, threshold ->
+    BEV NMS -> concatenate; over max_num keep the best scores.  The last score column is the padded background."""
+    num_classes = mlvl_scores.shape[1] - 1
+    bboxes, scores, labels = [], [], []
+    nms_func = nms_gpu if cfg.get("use_rotate_nms", False) else nms_normal_gpu
+    for i in range(num_classes):
+        cls_inds = (mlvl_scores[:, i] > score_thr).nonzero(as_tuple=False).squeeze(1)
+        if cls_inds.numel() == 0:
+            continue
+        _scores = mlvl_scores[cls_inds, i]
+        selected = nms_func(mlvl_bboxes_for_nms[cls_inds, :], _scores, cfg["nms_thr"])
+        bboxes.append(mlvl_bboxes[cls_inds, :][selected])
+        scores.append(_scores[selected])
+        labels.append(mlvl_bboxes.new_full((len(selected),), i, dtype=torch.long))
+    if bboxes:
+        bboxes, scores, labels = torch.cat(bboxes, dim=0), torch.cat(scores, dim=0), torch.cat(labels, dim=0)
+        if bboxes.shape[0] > max_num:
+            inds = scores.sort(descending=True)[1][:max_num]
+            bboxes, labels, scores = bboxes[inds, :], labels[inds], scores[inds]
+    else:
+        bboxes = mlvl_scores.new_zeros((0, mlvl_bboxes.size(-1)))
+        scores = mlvl_scores.new_zeros((0,))
+        labels = mlvl_scores.new_zeros((0,), dtype=torch.long)
+    return bboxes, scores, labels
+
+
+def bbox3d2result(bboxes, scores, labels, attrs=None):
+    """mmdet3d.core.bbox3d2result: results on the host, the form the dataset evaluators take."""
+    result = dict(boxes_3d=bboxes.to("cpu"), scores_3d=scores.cpu(), labels_3d=labels.cpu())
+    if attrs is not None:
+        result["attrs_3d"] = attrs.cpu()
+    return result

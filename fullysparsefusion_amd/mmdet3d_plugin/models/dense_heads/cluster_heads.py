@@ -1,0 +1,257 @@
+"""Query heads, inference side: `SparseClusterHead` (projects/mmdet3d_plugin/models/dense_heads/sparse_cluster_head.py
+:18-115, split_by_batch :269-278), `FSDSeparateHead` / `SparseClusterHeadV2` (sparse_cluster_head_v2.py:18-167,
+get_bboxes :447-608) and `FrustumClusterHead` (frustum_cluster_head.py:19-95, get_bboxes :500-697).
+
+Same constructor arguments, sub-module names (state-dict keys `shared_mlp.*`, `task_heads.N.<attr>.*`) and return
+conventions.  The MLPs are the fused Linear -> LayerNorm+GELU blocks of ops/sst_ops.py; box decoding is the coder of
+core/bbox.py; NMS is the HIP kernel pair K20.  Losses / target assignment (train time) are not built: `loss` raises.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from ...core.bbox import LiDARInstance3DBoxes, box3d_multiclass_nms, xywhr2xyxyr
+from ...ops.sst_ops import build_mlp
+from ...registry import BBOX_ASSIGNERS, BBOX_CODERS, HEADS, build_head, build_loss
+
+
+def _cfg_get(cfg, key, default=None):
+    if cfg is None:
+        return default
+    return cfg.get(key, default)
+
+
+@HEADS.register_module()
+class FSDSeparateHead(nn.Module):
+    def __init__(self, in_channels, attrs, norm_cfg=dict(type="LN"), act="relu", init_cfg=None):
+        super().__init__()
+        self.attrs = attrs
+        for attr_name in self.attrs:
+            out_dim, num_layer, hidden_dim = self.attrs[attr_name]
+            self.add_module(attr_name, build_mlp(in_channels, [hidden_dim] * num_layer + [out_dim], norm_cfg, is_head=True, act=act))
+
+    def forward(self, x):
+        return {attr_name: getattr(self, attr_name)(x) for attr_name in self.attrs}
+
+
+@HEADS.register_module()
+class SparseClusterHead(nn.Module):
+    def __init__(self, num_classes, bbox_coder, loss_cls, loss_center, loss_size, loss_rot, in_channel, shared_mlp_dims,
+                 shared_dropout=0, cls_mlp=None, reg_mlp=None, iou_mlp=None, train_cfg=None, test_cfg=None,
+                 norm_cfg=dict(type="LN"), loss_iou=None, act="relu", corner_loss_cfg=None, enlarge_width=None,
+                 as_rpn=False, init_cfg=None):
+        super().__init__()
+        self.print_info = {}
+        self.loss_center, self.loss_size = build_loss(loss_center), build_loss(loss_size)
+        self.loss_rot, self.loss_cls = build_loss(loss_rot), build_loss(loss_cls)
+        self.bbox_coder = BBOX_CODERS.build(bbox_coder)
+        self.box_code_size = self.bbox_coder.code_size
+        self.corner_loss_cfg = corner_loss_cfg
+        self.num_classes = num_classes
+        self.enlarge_width = enlarge_width
+        self.sync_reg_avg_factor = False if train_cfg is None else train_cfg.get("sync_reg_avg_factor", True)
+        self.sync_cls_avg_factor = False if train_cfg is None else train_cfg.get("sync_cls_avg_factor", True)
+        self.as_rpn = as_rpn
+        self.train_cfg = self.test_cfg = None
+        if train_cfg is not None:
+            self.cfg = self.train_cfg = train_cfg
+        if test_cfg is not None:
+            self.cfg = self.test_cfg = test_cfg
+        self.num_anchors = num_anchors = 1
+        self.loss_iou = build_loss(loss_iou) if loss_iou is not None else None
+        self.fp16_enabled = False
+        self.shared_mlp = None
+        if len(shared_mlp_dims) > 0:
+            self.shared_mlp = build_mlp(in_channel, shared_mlp_dims, norm_cfg, act=act, dropout=shared_dropout)
+        end_channel = shared_mlp_dims[-1] if len(shared_mlp_dims) > 0 else in_channel
+        if cls_mlp is not None:
+            self.conv_cls = build_mlp(end_channel, cls_mlp + [num_classes * num_anchors], norm_cfg, True, act=act)
+        else:
+            self.conv_cls = nn.Linear(end_channel, num_classes * num_anchors)
+        if reg_mlp is not None:
+            self.conv_reg = build_mlp(end_channel, reg_mlp + [self.box_code_size * num_anchors], norm_cfg, True, act=act)
+        else:
+            self.conv_reg = nn.Linear(end_channel, self.box_code_size * num_anchors)
+        self.save_list = []
+
+    def forward(self, feats, pts_xyz=None, pts_inds=None):
+        if self.shared_mlp is not None:
+            feats = self.shared_mlp(feats)
+        return dict(cls_logits=self.conv_cls(feats), reg_preds=self.conv_reg(feats))
+
+    def split_by_batch(self, data, batch_idx, batch_size):
+        if batch_size == 1:
+            return [data]
+        return [data[batch_idx == i] for i in range(batch_size)]
+
+    def combine_by_batch(self, data_list, batch_idx, batch_size):
+        assert len(data_list) == batch_size
+        if data_list[0] is None:
+            return None
+        full = data_list[0].new_zeros((len(batch_idx),) + data_list[0].shape[1:])
+        for i, data in enumerate(data_list):
+            full[batch_idx == i] = data
+        return full
+
+    def loss(self, *args, **kwargs):
+        raise NotImplementedError("head losses / target assignment are train-time code outside the built path")
+
+
+@HEADS.register_module()
+class SparseClusterHeadV2(SparseClusterHead):
+    BATCH_COL = 1  # cluster_inds rows are (class, batch, cluster id)  (sparse_cluster_head_v2.py:509-512)
+    EMPTY_BOX_DIM = 7
+
+    def __init__(self, num_classes, bbox_coder, loss_cls, loss_center, loss_size, loss_rot, in_channel, shared_mlp_dims,
+                 tasks, class_names, common_attrs, num_cls_layer, cls_hidden_dim, separate_head, cls_mlp=None,
+                 reg_mlp=None, iou_mlp=None, train_cfg=None, test_cfg=None, norm_cfg=dict(type="LN"), loss_iou=None,
+                 act="relu", corner_loss_cfg=None, enlarge_width=None, as_rpn=False, init_cfg=None, shared_dropout=0,
+                 loss_vel=None):
+        super().__init__(num_classes, bbox_coder, loss_cls, loss_center, loss_size, loss_rot, in_channel, shared_mlp_dims,
+                         shared_dropout, cls_mlp, reg_mlp, iou_mlp, train_cfg, test_cfg, norm_cfg, loss_iou, act,
+                         corner_loss_cfg, enlarge_width, as_rpn, init_cfg)
+        self.conv_cls = None  # overridden by the per-task separate heads
+        self.conv_reg = None
+        sep_head_in_channels = shared_mlp_dims[-1] if self.shared_mlp is not None else in_channel
+        self.tasks = tasks
+        self.task_heads = nn.ModuleList()
+        for t in tasks:
+            attrs = copy.deepcopy(dict(common_attrs))
+            attrs.update(dict(score=(len(t["class_names"]), num_cls_layer, cls_hidden_dim)))
+            head_cfg = dict(separate_head)
+            head_cfg.update(in_channels=sep_head_in_channels, attrs=attrs)
+            self.task_heads.append(build_head(head_cfg))
+        self.class_names = class_names
+        self.loss_vel = build_loss(loss_vel) if loss_vel is not None else None
+
+    def forward(self, feats, pts_xyz=None, pts_inds=None):
+        if self.shared_mlp is not None:
+            feats = self.shared_mlp(feats)
+        cls_logit_list, reg_pred_list, iou_logits_list = [], [], []
+        for h in self.task_heads:
+            ret = h(feats)
+            parts = [ret["center"], ret["dim"], ret["rot"]] + ([ret["vel"]] if "vel" in ret else [])
+            reg_pred_list.append(torch.cat(parts, dim=-1))  # same column order as v1's single regression branch
+            cls_logit_list.append(ret["score"])
+            if "iou" in ret:
+                iou_logits_list.append(ret["iou"])
+        outs = dict(cls_logits=cls_logit_list, reg_preds=reg_pred_list)
+        if len(iou_logits_list) > 0:
+            outs.update(iou_logits=iou_logits_list)
+        return outs
+
+    # ------------------------------------------------------------------------------------------- boxes
+    @torch.no_grad()
+    def get_bboxes(self, cls_logits, reg_preds, cluster_xyz, cluster_inds, input_metas, iou_logits=None, rescale=False):
+        return self._get_bboxes_all_tasks(cls_logits, reg_preds, None, cluster_xyz, cluster_inds, input_metas, iou_logits)
+
+    def _get_bboxes_all_tasks(self, cls_logits, reg_preds, preds_2d, cluster_xyz, cluster_inds, input_metas, iou_logits):
+        assert isinstance(cls_logits, list) and isinstance(reg_preds, list)
+        assert len(cls_logits) == len(reg_preds) == len(self.tasks)
+        per_task = [self.get_bboxes_single_task(i, cls_logits[i], reg_preds[i], preds_2d, cluster_xyz, cluster_inds,
+                                                input_metas, iou_logits[i] if iou_logits is not None else None)
+                    for i in range(len(self.tasks))]
+        batch_size = len(input_metas)
+        assert len(per_task[0]) <= batch_size
+        out = []
+        for b_idx in range(batch_size):
+            out.append((LiDARInstance3DBoxes.cat([t[b_idx][0] for t in per_task]),
+                        torch.cat([t[b_idx][1] for t in per_task], dim=0),
+                        torch.cat([t[b_idx][2] for t in per_task], dim=0)))
+        return out
+
+    @torch.no_grad()
+    def get_bboxes_single_task(self, task_id, cls_logits, reg_preds, preds_2d, cluster_xyz, cluster_inds, input_metas,
+                               iou_logits=None, rescale=False):
+        batch_inds = cluster_inds if cluster_inds.ndim == 1 else cluster_inds[:, self.BATCH_COL]
+        batch_size = len(input_metas)
+        split = lambda t: self.split_by_batch(t, batch_inds, batch_size)  # noqa: E731
+        cls_l, reg_l, xyz_l = split(cls_logits), split(reg_preds), split(cluster_xyz)
+        p2d_l = split(preds_2d) if preds_2d is not None else [None] * len(cls_l)
+        iou_l = split(iou_logits) if iou_logits is not None else [None] * len(cls_l)
+        return [self._get_bboxes_single(task_id, cls_l[b], iou_l[b], reg_l[b], p2d_l[b], xyz_l[b], input_metas[b])
+                for b in range(len(cls_l))]
+
+    def _box_type(self, input_meta):
+        return input_meta.get("box_type_3d", LiDARInstance3DBoxes) if isinstance(input_meta, dict) else LiDARInstance3DBoxes
+
+    def _get_bboxes_single(self, task_id, cls_logits, iou_logits, reg_preds, preds_2d, cluster_xyz, input_meta):
+        """One sample, one task: sigmoid scores -> (optional top-k) -> decode -> per-class rotated BEV NMS."""
+        if self.as_rpn:
+            cfg = self.train_cfg["rpn"] if self.training else self.test_cfg["rpn"]
+        else:
+            cfg = self.test_cfg
+        box_type = self._box_type(input_meta)
+        assert cls_logits.size(0) == reg_preds.size(0) == cluster_xyz.size(0)
+        assert cls_logits.size(1) == len(self.tasks[task_id]["class_names"])
+        assert reg_preds.size(1) == self.box_code_size
+        if len(cls_logits) == 0:
+            empty = reg_preds.new_zeros((0, self.EMPTY_BOX_DIM))
+            return box_type(empty, box_dim=self.EMPTY_BOX_DIM), reg_preds.new_zeros(0), reg_preds.new_zeros(0)
+        scores = cls_logits.sigmoid()
+        if iou_logits is not None:
+            a = cfg.get("iou_score_weight", 0.5)
+            scores = (scores ** (1 - a)) * (iou_logits.sigmoid() ** a)
+        nms_pre = cfg.get("nms_pre", -1)
+        if nms_pre > 0 and scores.shape[0] > nms_pre:
+            topk_inds = scores.max(dim=1)[0].topk(nms_pre)[1]
+            reg_preds, scores, cluster_xyz = reg_preds[topk_inds, :], scores[topk_inds, :], cluster_xyz[topk_inds, :]
+        bboxes = self.bbox_coder.decode(reg_preds, cluster_xyz)
+        bboxes = self._append_debug_columns(bboxes, preds_2d)
+        bboxes_for_nms = xywhr2xyxyr(box_type(bboxes, box_dim=bboxes.size(1)).bev)
+        scores = torch.cat([scores, scores.new_zeros(scores.shape[0], 1)], dim=1)  # dummy background column
+        out_bboxes, out_scores, out_labels = box3d_multiclass_nms(bboxes, bboxes_for_nms, scores, cfg.get("score_thr", 0),
+                                                                  cfg["max_num"], cfg)
+        out_bboxes, out_scores = self._strip_debug_columns(out_bboxes, out_scores)
+        out_bboxes = box_type(out_bboxes, out_bboxes.size(1))
+        new_labels = torch.zeros_like(out_labels) - 1  # task-local label -> global class index
+        if len(out_labels) > 0:
+            for i, name in enumerate(self.tasks[task_id]["class_names"]):
+                new_labels[out_labels == i] = self.class_names.index(name)
+            assert (new_labels >= 0).all()
+        return out_bboxes, out_scores, new_labels
+
+    def _append_debug_columns(self, bboxes, preds_2d):
+        return bboxes
+
+    def _strip_debug_columns(self, out_bboxes, out_scores):
+        return out_bboxes, out_scores
+
+
+@HEADS.register_module()
+class FrustumClusterHead(SparseClusterHeadV2):
+    BATCH_COL = 0  # frustum query coors are (batch, 0, obj id)  (frustum_cluster_head.py:562-565)
+    EMPTY_BOX_DIM = 9
+
+    def __init__(self, num_classes, bbox_coder, loss_cls, loss_center, loss_size, loss_rot, in_channel, shared_mlp_dims,
+                 tasks, class_names, common_attrs, num_cls_layer, cls_hidden_dim, separate_head, cls_mlp=None,
+                 reg_mlp=None, iou_mlp=None, train_cfg=dict(), test_cfg=dict(), norm_cfg=dict(type="LN"), loss_iou=None,
+                 act="relu", corner_loss_cfg=None, enlarge_width=None, as_rpn=False, init_cfg=None, shared_dropout=0,
+                 loss_vel=None, assigner=None, num_objs=250, vis_dir=None, use_one_to_one=False):
+        super().__init__(num_classes, bbox_coder, loss_cls, loss_center, loss_size, loss_rot, in_channel, shared_mlp_dims,
+                         tasks, class_names, common_attrs, num_cls_layer, cls_hidden_dim, separate_head, cls_mlp, reg_mlp,
+                         iou_mlp, train_cfg, test_cfg, norm_cfg, loss_iou, act, corner_loss_cfg, enlarge_width, as_rpn,
+                         init_cfg, shared_dropout, loss_vel)
+        self.assigner = BBOX_ASSIGNERS.build(assigner) if assigner is not None else None
+        self.num_objs = num_objs
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.task_info = {}
+        self.vis_dir = vis_dir
+        self.use_one_to_one = use_one_to_one
+
+    @torch.no_grad()
+    def get_bboxes(self, cls_logits, reg_preds, preds_2d, cluster_xyz, cluster_inds, input_metas, iou_logits=None,
+                   rescale=False):
+        return self._get_bboxes_all_tasks(cls_logits, reg_preds, preds_2d, cluster_xyz, cluster_inds, input_metas, iou_logits)
+
+    def _append_debug_columns(self, bboxes, preds_2d):
+        if self.vis_dir is not None:  # visualisation runs carry the 2-D object id through NMS (:629-631)
+            bboxes = torch.cat([bboxes, preds_2d[:, 7:8]], dim=-1)
+        return bboxes
+
+    def _strip_debug_columns(self, out_bboxes, out_scores):
+        if self.vis_dir is not None:
+            out_bboxes, out_obj_id = out_bboxes[:, :-1], out_bboxes[:, -1]
+            out_scores = out_scores + out_obj_id
+        return out_bboxes, out_scores

@@ -1,5 +1,5 @@
 """Registered-by-name stand-ins for the config types that are OUT OF SCOPE of the hot path (SURVEY.md §2.1 rows
-6-12, §8 f2/f3): detection heads, box coders, label assigners, losses, dataset pipelines and hooks.  They exist so
+6-12): unused head variants, label assigners, losses, dataset pipelines and hooks.  They exist so
 that `projects/configs/nuScenes/FSF_nuScenes_config.py` resolves every `type=` and the model builds; calling one
 raises, naming what is missing — they never compute anything (no silent fallbacks)."""
 import torch.nn as nn
@@ -37,20 +37,13 @@ def _plain_placeholder(name, where):
 
 
 _HEADS = {
-    "SparseClusterHeadV2": "models/dense_heads/sparse_cluster_head_v2.py",
-    "SparseClusterHead": "models/dense_heads/sparse_cluster_head.py",
-    "FSDSeparateHead": "models/dense_heads/sparse_cluster_head_v2.py",
-    "FrustumClusterHead": "models/dense_heads/frustum_cluster_head.py",
     "MultiStageRefineHead": "models/dense_heads/multi_stage_refine_head.py",
-    "FullySparseBboxHead": "models/roi_heads/bbox_heads/fsd_bbox_head.py",
     "GroupCorrectionHead": "models/roi_heads/fsd_roi_head.py",
-    "DynamicPointROIExtractor": "models/roi_heads/roi_extractors/dynamic_point_roi_extractor.py",
     "FocalLoss": "mmdet loss", "L1Loss": "mmdet loss", "SmoothL1Loss": "mmdet loss", "CrossEntropyLoss": "mmdet loss",
 }
 for _n, _w in _HEADS.items():
     MODELS.register_module(_n, module=_module_placeholder(_n, _w))
-VOXEL_ENCODERS.register_module("DynamicClusterVFE", module=_module_placeholder("DynamicClusterVFE", "mmdet3d fork voxel encoder (refine stage)"))
-for _n in ("BasePointBBoxCoder", "ABSPointBBoxCoder"):
+for _n in ("ABSPointBBoxCoder",):
     BBOX_CODERS.register_module(_n, module=_plain_placeholder(_n, "core/bbox/coders"))
 for _n in ("HybridAssigner", "FrustumAssigner", "PointInBoxAssigner", "DistAssigner", "MaxIoUAssigner"):
     BBOX_ASSIGNERS.register_module(_n, module=_plain_placeholder(_n, "core/bbox/assigners"))

@@ -1,0 +1,122 @@
+"""Refine stage: `DynamicPointROIExtractor`
+(projects/mmdet3d_plugin/models/roi_heads/roi_extractors/dynamic_point_roi_extractor.py:9-100) and
+`FullySparseBboxHead` (models/roi_heads/bbox_heads/fsd_bbox_head.py:22-197), inference path.
+
+The extractor upstream loops over the samples of the batch, calls the TorchEx kernel per sample and offsets the
+indices; here the batch index travels into ONE launch of K17 (`fsf_dynamic_point_pool`), whose rows come back already
+in ascending (roi, point) order — i.e. sorted by the RoI index the SIR layers group on.
+"""
+import torch
+import torch.nn as nn
+
+from .... import hip_ops
+from ...ops.sst_ops import unique_with_plan
+from ...registry import HEADS, ROI_EXTRACTORS, build_voxel_encoder
+
+
+@ROI_EXTRACTORS.register_module()
+class DynamicPointROIExtractor(nn.Module):
+    def __init__(self, init_cfg=None, debug=True, extra_wlh=[0, 0, 0], max_inbox_point=512, max_all_pts=50000):
+        super().__init__()
+        self.debug = debug
+        self.extra_wlh = extra_wlh
+        self.max_inbox_point = max_inbox_point
+        self.max_all_pts = max_all_pts  # upstream: the default of DynamicPointPoolFunction.forward, PER SAMPLE
+
+    def forward(self, pts_xyz, batch_inds, rois):
+        """pts_xyz [P,3], batch_inds [P] (sorted), rois [R,8] (batch, x, y, z_bottom, w, l, h, rz) ->
+        (point indices [k], roi indices [k], dict(local_xyz [k,3], boundary_offset [k,6], is_in_margin [k]))."""
+        assert len(pts_xyz) > 0 and len(batch_inds) > 0 and len(rois) > 0
+        rois = rois.float()
+        single = rois.size(1) == 7
+        inds, roi_inds, info = hip_ops.dynamic_point_pool(
+            rois, pts_xyz.float(), self.extra_wlh, self.max_inbox_point, self.max_all_pts,
+            roi_batch_col=-1 if single else 0, box_col=0 if single else 1, pts_batch=None if single else batch_inds)
+        if inds.numel() == 0:  # upstream fakes one (-1, -1, zeros) row so that downstream shapes stay non-empty
+            inds = inds.new_full((1,), -1)
+            roi_inds = roi_inds.new_full((1,), -1)
+            info = info.new_zeros((1, 13))
+        if self.debug and inds[0] >= 0:
+            roi_per_pts = rois[:, -7:][roi_inds]
+            assert torch.isclose(pts_xyz[inds], info[:, :3]).all()
+            assert torch.isclose(info[:, 6] + info[:, 9], roi_per_pts[:, 4], atol=1e-4).all()
+            assert torch.isclose(info[:, 7] + info[:, 10], roi_per_pts[:, 3], atol=1e-4).all()
+            assert torch.isclose(info[:, 8] + info[:, 11], roi_per_pts[:, 5], atol=1e-4).all()
+        ext_pts_info = dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1], is_in_margin=info[:, -1])
+        return inds, roi_inds, ext_pts_info
+
+
+@HEADS.register_module()
+class FullySparseBboxHead(nn.Module):
+    """Three `DynamicClusterVFE` (SIR-layer) blocks over the points pooled into each RoI; returns one feature row per
+    RoI (zeros for RoIs without points) and the non-empty mask."""
+
+    def __init__(self, num_classes, num_blocks, in_channels, feat_channels, with_distance, with_cluster_center,
+                 with_rel_mlp, rel_mlp_hidden_dims, rel_mlp_in_channels, reg_mlp, cls_mlp, mode="max",
+                 xyz_normalizer=[20, 20, 4], cat_voxel_feats=True, pos_fusion="mul", fusion="cat", act="gelu",
+                 geo_input=True, use_middle_cluster_feature=True, norm_cfg=dict(type="LN", eps=1e-3, momentum=0.01),
+                 dropout=0, unique_once=False, init_cfg=None, no_head=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.geo_input = geo_input
+        self.num_blocks = num_blocks
+        self.use_middle_cluster_feature = use_middle_cluster_feature
+        self.print_info = {}
+        self.unique_once = unique_once
+        blocks = []
+        for i in range(num_blocks):
+            blocks.append(build_voxel_encoder(dict(
+                type="DynamicClusterVFE", in_channels=in_channels[i], feat_channels=feat_channels[i],
+                with_distance=with_distance, with_cluster_center=with_cluster_center, with_rel_mlp=with_rel_mlp,
+                rel_mlp_hidden_dims=rel_mlp_hidden_dims[i], rel_mlp_in_channel=rel_mlp_in_channels[i],
+                with_voxel_center=False, voxel_size=[0.1, 0.1, 0.1], point_cloud_range=[-74.88, -74.88, -2, 74.88, 74.88, 4],
+                norm_cfg=norm_cfg, mode=mode, fusion_layer=None, return_point_feats=i != num_blocks - 1, return_inv=False,
+                rel_dist_scaler=10.0, fusion=fusion, pos_fusion=pos_fusion, xyz_normalizer=xyz_normalizer,
+                cat_voxel_feats=cat_voxel_feats, act=act, dropout=dropout)))
+        self.block_list = nn.ModuleList(blocks)
+
+    def forward(self, pts_xyz, pts_features, pts_info, roi_inds, rois):
+        assert pts_features.size(0) > 0
+        rois = rois[:, 1:]
+        rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds]
+        coors = roi_inds.unsqueeze(1)  # the segment machinery takes key ROWS; upstream groups on the 1-D index
+        if self.unique_once:  # torch.unique(roi_inds, return_inverse=True) upstream (:114-115), with the segment plan
+            new_coors, unq_inv, _ = unique_with_plan(coors)
+        else:
+            new_coors = unq_inv = None
+        out_feats = pts_features
+        f_cluster = torch.cat([pts_info["local_xyz"], pts_info["boundary_offset"], pts_info["is_in_margin"][:, None], rel_xyz],
+                              dim=-1)
+        cluster_feat_list = []
+        for i, block in enumerate(self.block_list):
+            in_feats = torch.cat([pts_xyz, out_feats], 1)
+            if self.geo_input:
+                in_feats = torch.cat([in_feats, f_cluster / 10], 1)
+            if i < self.num_blocks - 1:
+                out_feats, out_cluster_feats = block(in_feats, coors, f_cluster, unq_inv_once=unq_inv, new_coors_once=new_coors)
+                if self.use_middle_cluster_feature:
+                    cluster_feat_list.append(out_cluster_feats)
+            else:
+                out_cluster_feats, out_coors = block(in_feats, coors, f_cluster, unq_inv_once=unq_inv, new_coors_once=new_coors)
+                cluster_feat_list.append(out_cluster_feats)
+        final_cluster_feats = torch.cat(cluster_feat_list, dim=1)
+        out_coors = out_coors.squeeze(1)
+        nonempty_roi_mask = self.get_nonempty_roi_mask(out_coors, len(rois))
+        return self.align_roi_feature_and_rois(final_cluster_feats, out_coors, len(rois)), nonempty_roi_mask
+
+    def get_nonempty_roi_mask(self, out_coors, num_rois):
+        out_coors = out_coors[out_coors >= 0]
+        mask = torch.zeros(num_rois, dtype=torch.bool, device=out_coors.device)
+        mask[out_coors] = True
+        return mask
+
+    def align_roi_feature_and_rois(self, features, out_coors, num_rois):
+        """Group features come out in ascending RoI index with a possible leading -1 group (the fake row of an empty
+        pooling result); scatter them to one row per RoI."""
+        new_feature = features.new_zeros((num_rois, features.size(1)))
+        coors_mask = out_coors >= 0
+        if not coors_mask.any():
+            new_feature[:len(features), :] = features * 0  # pseudo gradient, as upstream
+            return new_feature
+        new_feature[out_coors[coors_mask]] = features[coors_mask]
+        return new_feature

@@ -1,3 +1,3 @@
-from .voxel_encoder import DynamicScatterVFE, DynamicVFELayer, SIRLayer
+from .voxel_encoder import DynamicClusterVFE, DynamicScatterVFE, DynamicVFELayer, SIRLayer
 
-__all__ = ["DynamicScatterVFE", "DynamicVFELayer", "SIRLayer"]
+__all__ = ["DynamicClusterVFE", "DynamicScatterVFE", "DynamicVFELayer", "SIRLayer"]

@@ -175,3 +175,18 @@ class SIRLayer(nn.Module):
         if self.return_inv:
             return voxel_feats, voxel_coors, unq_inv
         return voxel_feats, voxel_coors
+
+
+@VOXEL_ENCODERS.register_module()
+class DynamicClusterVFE(SIRLayer):
+    """The refine stage's SIR-layer variant [UNVENDORED in the reference; built by FullySparseBboxHead,
+    projects/mmdet3d_plugin/models/roi_heads/bbox_heads/fsd_bbox_head.py:60-88].  With the only argument values that
+    call site passes (`fusion='cat'`, `pos_fusion='mul'`, `cat_voxel_feats=True`, no cluster/voxel-centre/distance
+    decorations, gelu => in-filters not doubled for block 0) the published module computes exactly what SIRLayer does;
+    other values are refused instead of guessed."""
+
+    def __init__(self, *args, fusion="cat", pos_fusion="mul", cat_voxel_feats=True, **kwargs):
+        assert fusion == "cat" and pos_fusion == "mul" and cat_voxel_feats, \
+            "DynamicClusterVFE: only the fusion='cat' / pos_fusion='mul' / cat_voxel_feats=True variant is built"
+        kwargs.setdefault("with_shortcut", False)
+        super().__init__(*args, **kwargs)

@@ -305,3 +305,56 @@ def fsf_stage3(fsf, s1):
     _, cluster_feats, out_coors = sir_forward(fsf.backbone, points, feats, cluster_inds, f_cluster)
     return dict(cluster_feats=cluster_feats, cluster_xyz=cxyz, cluster_inds=out_coors, pts_cluster_inds=cluster_inds,
                 points=points, pre_voxel_coors=new_coors)
+
+
+# --------------------------------------------------------------------------------------- query refinement
+def refine_head_forward(head, pts_xyz, pts_features, pts_info, roi_inds, rois):
+    """FullySparseBboxHead.forward (projects/mmdet3d_plugin/models/roi_heads/bbox_heads/fsd_bbox_head.py:96-151) with its
+    DynamicClusterVFE blocks restated as SIR layers (PARITY UNPINNED: un-vendored, see module docstring)."""
+    rois = rois[:, 1:]
+    rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds]
+    new_coors, unq_inv = torch.unique(roi_inds, return_inverse=True)
+    f_cluster = torch.cat([pts_info["local_xyz"], pts_info["boundary_offset"], pts_info["is_in_margin"][:, None], rel_xyz], -1)
+    out_feats, cluster = pts_features, []
+    for i, block in enumerate(head.block_list):
+        in_feats = torch.cat([pts_xyz, out_feats], 1)
+        if head.geo_input:
+            in_feats = torch.cat([in_feats, f_cluster / 10], 1)
+        out_feats, grp = sir_layer_forward(block, in_feats, roi_inds, f_cluster, unq_inv, new_coors)
+        if i == head.num_blocks - 1 or head.use_middle_cluster_feature:
+            cluster.append(grp)
+    feats = torch.cat(cluster, 1)
+    out = feats.new_zeros((rois.size(0), feats.size(1)))
+    ok = new_coors >= 0
+    out[new_coors[ok]] = feats[ok]
+    mask = torch.zeros(rois.size(0), dtype=torch.bool)
+    mask[new_coors[ok]] = True
+    return out, mask
+
+
+def multiclass_nms(boxes, scores, score_thr, nms_thr, max_num, rotated=True):
+    """mmdet3d box3d_multiclass_nms over (x, y, z, w, l, h, yaw, ...) boxes and [n, C] scores (no background column),
+    with the float64 IoU oracle; returns (row index into boxes, score, class) in the published output order."""
+    from . import refine as orefine
+
+    bev = boxes[:, [0, 1, 3, 4, 6]].double().numpy()
+    xyxyr = np.stack([bev[:, 0] - bev[:, 2] / 2, bev[:, 1] - bev[:, 3] / 2, bev[:, 0] + bev[:, 2] / 2,
+                      bev[:, 1] + bev[:, 3] / 2, bev[:, 4]], 1)
+    rows, scs, labs = [], [], []
+    for c in range(scores.shape[1]):
+        sel = torch.nonzero(scores[:, c] > score_thr).squeeze(1)
+        if sel.numel() == 0:
+            continue
+        order = torch.argsort(scores[sel, c], descending=True, stable=True)
+        cand = sel[order]
+        keep = orefine.nms_from_iou(orefine.iou_bev_matrix(xyxyr[cand.numpy()], rotated), nms_thr)
+        rows.append(cand[keep])
+        scs.append(scores[cand[keep], c])
+        labs.append(torch.full((len(keep),), c, dtype=torch.long))
+    if not rows:
+        return torch.zeros(0, dtype=torch.long), torch.zeros(0), torch.zeros(0, dtype=torch.long)
+    rows, scs, labs = torch.cat(rows), torch.cat(scs), torch.cat(labs)
+    if rows.numel() > max_num:
+        top = torch.argsort(scs, descending=True, stable=True)[:max_num]
+        rows, scs, labs = rows[top], scs[top], labs[top]
+    return rows, scs, labs

@@ -353,6 +353,104 @@ def gen_sir_flow(sst, rng):
                         unq_inv=layers[0].seen[1].numpy(), new_coors=layers[0].seen[2].numpy())
 
 
+def gen_refine_glue(rng):
+    """Query-refinement glue that IS vendored python in the reference: BasePointBBoxCoder.encode/decode
+    (core/bbox/coders/base_point_bbox_coder.py:36-82), FSF.combine_frustum_and_fsd / decode_stage_bboxes
+    (FSF.py:657-692, 1085-1094), FullySparseBboxHead.get_nonempty_roi_mask / align_roi_feature_and_rois
+    (fsd_bbox_head.py:153-197) and FrustumClusterHead._get_bboxes_single (frustum_cluster_head.py:593-697) with
+    the un-vendored mmdet3d symbols it calls replaced by recording stand-ins (no suppression: every box above the
+    score threshold is kept, class by class), which pins everything around the NMS call."""
+    coder_fns = lift_methods(os.path.join(PLUGIN, "core/bbox/coders/base_point_bbox_coder.py"), "BasePointBBoxCoder",
+                             ["encode", "decode"], {"torch": torch})
+    coder = types.SimpleNamespace(code_size=10, EPS=1e-6)
+    coder.decode = types.MethodType(coder_fns["decode"], coder)
+    n = 300
+    base = torch.from_numpy(rng.uniform(-40, 40, (n, 3)).astype(np.float32))
+    reg = torch.from_numpy(rng.normal(0, 0.6, (n, 10)).astype(np.float32))
+    boxes = coder_fns["decode"](coder, reg, base)
+    enc = coder_fns["encode"](coder, boxes, base)
+
+    fsf = lift_methods(os.path.join(PLUGIN, "models/detectors/FSF.py"), "FSF", ["combine_frustum_and_fsd", "decode_stage_bboxes"],
+                       {"torch": torch})
+    ns = types.SimpleNamespace(fsd_begin_idx=1000, bbox_coder=coder, combine_frustum_feat_mlp=lambda x: x[:, :6] * 2.0,
+                               combine_fsd_feat_mlp=lambda x: x[:, :6] - 1.0)
+    nf, nl = 40, 110
+    f_centers = torch.from_numpy(rng.uniform(-30, 30, (nf, 3)).astype(np.float32))
+    l_centers = torch.from_numpy(rng.uniform(-30, 30, (nl, 3)).astype(np.float32))
+    f_coors = torch.stack([torch.zeros(nf), torch.zeros(nf), torch.arange(1, nf + 1).float()], 1).long()
+    l_coors = torch.stack([torch.from_numpy(rng.integers(0, 6, nl)), torch.zeros(nl).long(), torch.arange(nl)], 1).long()
+    f_res = dict(cls_logits=[torch.from_numpy(rng.normal(0, 1, (nf, 10)).astype(np.float32))],
+                 reg_preds=[torch.from_numpy(rng.normal(0, 0.5, (nf, 10)).astype(np.float32))])
+    l_res = dict(cls_logits=[torch.from_numpy(rng.normal(0, 1, (nl, 10)).astype(np.float32))],
+                 reg_preds=[torch.from_numpy(rng.normal(0, 0.5, (nl, 10)).astype(np.float32))])
+    f_feats = torch.from_numpy(rng.normal(0, 1, (nf, 9)).astype(np.float32))
+    l_feats = torch.from_numpy(rng.normal(0, 1, (nl, 8)).astype(np.float32))
+    f_p2d = torch.from_numpy(rng.uniform(0, 1, (nf, 9)).astype(np.float32))
+    c_centers, c_coors, c_res, c_feats, c_p2d = fsf["combine_frustum_and_fsd"](ns, f_centers, f_coors, f_res, f_feats, f_p2d,
+                                                                              l_centers, l_coors, l_res, l_feats)
+    rois = fsf["decode_stage_bboxes"](ns, c_centers, c_coors[:, 0], c_res["reg_preds"])
+
+    head = lift_methods(os.path.join(PLUGIN, "models/roi_heads/bbox_heads/fsd_bbox_head.py"), "FullySparseBboxHead",
+                        ["get_nonempty_roi_mask", "align_roi_feature_and_rois"], {"torch": torch})
+    hns = types.SimpleNamespace(training=False)
+    out_coors = torch.tensor([-1, 0, 3, 4, 9])
+    feats = torch.from_numpy(rng.normal(0, 1, (5, 7)).astype(np.float32))
+    mask = head["get_nonempty_roi_mask"](hns, out_coors, 12)
+    aligned = head["align_roi_feature_and_rois"](hns, feats, out_coors, 12)
+
+    class Boxes:  # what `input_meta['box_type_3d']` has to offer to _get_bboxes_single
+        def __init__(self, tensor, box_dim=7):
+            self.tensor = tensor
+
+        @property
+        def bev(self):
+            return self.tensor[:, [0, 1, 3, 4, 6]]
+
+    def xywhr2xyxyr(b):
+        out = torch.zeros_like(b)
+        out[:, 0], out[:, 1] = b[:, 0] - b[:, 2] / 2, b[:, 1] - b[:, 3] / 2
+        out[:, 2], out[:, 3], out[:, 4] = b[:, 0] + b[:, 2] / 2, b[:, 1] + b[:, 3] / 2, b[:, 4]
+        return out
+
+    seen = {}
+
+    def keep_all_nms(bboxes, bboxes_for_nms, scores, score_thr, max_num, cfg):
+        seen["for_nms"] = bboxes_for_nms.clone()
+        bb, ss, ll = [], [], []
+        for i in range(scores.shape[1] - 1):
+            sel = scores[:, i] > score_thr
+            bb.append(bboxes[sel]); ss.append(scores[sel, i]); ll.append(torch.full((int(sel.sum()),), i, dtype=torch.long))
+        return torch.cat(bb), torch.cat(ss), torch.cat(ll)
+
+    gb = lift_methods(os.path.join(PLUGIN, "models/dense_heads/frustum_cluster_head.py"), "FrustumClusterHead",
+                      ["_get_bboxes_single"], {"torch": torch, "xywhr2xyxyr": xywhr2xyxyr, "box3d_multiclass_nms": keep_all_nms})
+    classes = ["car", "truck", "trailer", "bus", "construction_vehicle", "bicycle", "motorcycle", "pedestrian", "traffic_cone",
+               "barrier"]
+    task_names = ["bus", "car", "pedestrian"]  # task-local label order differs from the global one on purpose
+    cfg = dict(use_rotate_nms=True, nms_pre=150, nms_thr=0.35, score_thr=0.3, min_bbox_size=0, max_num=500)
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    hd = types.SimpleNamespace(as_rpn=False, training=False, test_cfg=Cfg(cfg), tasks=[dict(class_names=task_names)],
+                               box_code_size=10, bbox_coder=coder, vis_dir=None, class_names=classes)
+    cls_logits = torch.from_numpy(rng.normal(0, 1.5, (200, 3)).astype(np.float32))
+    reg2 = torch.from_numpy(rng.normal(0, 0.5, (200, 10)).astype(np.float32))
+    xyz2 = torch.from_numpy(rng.uniform(-30, 30, (200, 3)).astype(np.float32))
+    ob, os_, ol = gb["_get_bboxes_single"](hd, 0, cls_logits, None, reg2, torch.zeros(200, 9), xyz2, dict(box_type_3d=Boxes))
+    np.savez_compressed(
+        os.path.join(OUT, "refine_glue.npz"),
+        base=base.numpy(), reg=reg.numpy(), boxes=boxes.numpy(), enc=enc.numpy(),
+        f_centers=f_centers.numpy(), l_centers=l_centers.numpy(), f_coors=f_coors.numpy(), l_coors=l_coors.numpy(),
+        f_cls=f_res["cls_logits"][0].numpy(), f_reg=f_res["reg_preds"][0].numpy(), l_cls=l_res["cls_logits"][0].numpy(),
+        l_reg=l_res["reg_preds"][0].numpy(), f_feats=f_feats.numpy(), l_feats=l_feats.numpy(), f_p2d=f_p2d.numpy(),
+        c_centers=c_centers.numpy(), c_coors=c_coors.numpy(), c_cls=c_res["cls_logits"][0].numpy(),
+        c_reg=c_res["reg_preds"][0].numpy(), c_feats=c_feats.numpy(), c_p2d=c_p2d.numpy(), rois=rois.numpy(),
+        out_coors=out_coors.numpy(), roi_feats=feats.numpy(), roi_mask=mask.numpy(), roi_aligned=aligned.numpy(),
+        gb_cls=cls_logits.numpy(), gb_reg=reg2.numpy(), gb_xyz=xyz2.numpy(), gb_for_nms=seen["for_nms"].numpy(),
+        gb_boxes=ob.tensor.numpy(), gb_scores=os_.numpy(), gb_labels=ol.numpy())
+
+
 def main():
     assert os.path.isdir(REF), "the reference tree is only available in the build container"
     install_stubs()
@@ -370,6 +468,7 @@ def main():
     gen_neck(rng)
     gen_divfloor(rng)
     gen_sir_flow(sst, rng)
+    gen_refine_glue(np.random.default_rng(777))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

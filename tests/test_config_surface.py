@@ -77,11 +77,20 @@ def test_reference_config_loads_and_builds_unchanged():
     assert not unresolved(cfg.to_dict()), unresolved(cfg.to_dict())
     model = plugin.build_model(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
     own = Config.fromfile(os.path.join(ROOT, "configs", "fsf_nuscenes.py"))
-    for key in ["segmentor", "backbone", "frustum_sir", "cluster_assigner", "test_cfg", "mlp_cfg"]:
+    for key in ["segmentor", "backbone", "frustum_sir", "cluster_assigner", "test_cfg", "mlp_cfg", "bbox_coder", "roi_extractor",
+                "single_refine_sir_layer", "refine_encode_2d_mlp_cfg"]:
         assert cfg.model[key] == own.model[key], key
+    for head in ["bbox_head", "frustum_obj_head"]:  # inference-relevant head arguments (assigners / losses are train-time)
+        for key in ["type", "num_classes", "bbox_coder", "in_channel", "shared_mlp_dims", "tasks", "class_names", "common_attrs",
+                    "num_cls_layer", "cls_hidden_dim", "separate_head", "norm_cfg"]:
+            assert cfg.model[head][key] == own.model[head][key], (head, key)
+    assert cfg.model.refined_obj_head[0].test_cfg == own.model.refined_obj_head[0].test_cfg
+    assert cfg.model.frustum_obj_head.test_cfg == own.model.frustum_obj_head.test_cfg
     own_model = plugin.build_model(own.model)
-    ref_keys = {k for k in model.state_dict() if not k.startswith(("refine", "lidar_img_mlp", "position_encoder", "out_proj"))}
-    assert ref_keys == set(own_model.state_dict().keys())
+    ref_sd, own_sd = model.state_dict(), own_model.state_dict()
+    assert {k: tuple(v.shape) for k, v in ref_sd.items()} == {k: tuple(v.shape) for k, v in own_sd.items()}
+    assert model.num_extra_stages == own_model.num_extra_stages == 1
+    assert sum(p.numel() for p in model.parameters()) > 80e6  # the full detector, refine stage and heads included
 
 
 REF_AV2 = "/root/reference/projects/configs/Argoverse2/FSF_AV2_config.py"

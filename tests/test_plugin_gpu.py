@@ -441,3 +441,102 @@ def test_av2_long_range_segmentor_vs_oracle(plugin, device):
     assert int(ex["coors"][:, 3].max()) > 1500 and int(ex["coors"][:, 2].max()) > 1500  # really uses the 2048^2 grid
     assert neck_out.shape == (pts.shape[0], 67)
     close(neck_out, ex["neck"])
+
+
+# ----------------------------------------------------------------------------------- query refinement (f2 / f3)
+def test_refine_head_vs_oracle(plugin, device):
+    """DynamicPointROIExtractor (K17) + FullySparseBboxHead on the same pooled points as the oracle."""
+    from oracle import refine as orefine
+
+    torch.manual_seed(5)
+    rng = np.random.default_rng(6)
+    head = plugin.registry.build_head(dict(
+        type="FullySparseBboxHead", num_classes=10, num_blocks=3, in_channels=[5 + 40 + 13, 5 + 128 + 13, 5 + 128 + 13],
+        feat_channels=[[128, 128]] * 3, with_distance=False, with_cluster_center=False, with_rel_mlp=True,
+        rel_mlp_hidden_dims=[[16, 32]] * 3, rel_mlp_in_channels=[13] * 3, reg_mlp=[512, 512], cls_mlp=[512, 512], mode="max",
+        xyz_normalizer=[20, 20, 4], cat_voxel_feats=True, pos_fusion="mul", fusion="cat", act="gelu", geo_input=True,
+        use_middle_cluster_feature=True, norm_cfg=dict(type="LN", eps=1e-3), unique_once=True)).eval()
+    cpu = copy.deepcopy(head)
+    head.to(device)
+    r, p = 60, 20000
+    rois = np.concatenate([np.zeros((r, 1)), rng.uniform(-30, 30, (r, 2)), rng.uniform(-2.5, -1.0, (r, 1)),
+                           rng.uniform(1.5, 2.5, (r, 1)), rng.uniform(3.0, 6.0, (r, 1)), rng.uniform(1.2, 2.5, (r, 1)),
+                           rng.uniform(-3.1, 3.1, (r, 1))], 1).astype(np.float32)
+    rois[7, 1:3] = 400.0  # an RoI with no points: its feature row must stay zero
+    which = rng.integers(0, r, p // 2)
+    which[which == 7] = 0
+    near = rois[which, 1:4] + rng.normal(0, 1.2, (p // 2, 3)) + np.array([0, 0, 1.0])
+    pts = np.concatenate([near, np.concatenate([rng.uniform(-35, 35, (p - p // 2, 2)), rng.uniform(-3, 1, (p - p // 2, 1))], 1)])
+    pts = np.concatenate([pts, rng.random((p, 2))], 1).astype(np.float32)
+    feats = rng.standard_normal((p, 40)).astype(np.float32)
+
+    ext = plugin.registry.build_roi_extractor(dict(type="DynamicPointROIExtractor", extra_wlh=[1.0, 1.0, 1.0], max_inbox_point=512,
+                                                   debug=True))
+    d_pts, d_rois = torch.from_numpy(pts).to(device), torch.from_numpy(rois).to(device)
+    inds, roi_inds, info = ext(d_pts[:, :3], torch.zeros(p, dtype=torch.long, device=device), d_rois)
+    wp, wr, wf, margins = orefine.dynamic_point_pool(rois[:, 1:], pts[:, :3], [1.0, 1.0, 1.0], 512, return_margin=True)
+    if (margins[:, 2] < 1e-4).sum() == 0:
+        np.testing.assert_array_equal(inds.cpu().numpy(), wp)
+        np.testing.assert_array_equal(roi_inds.cpu().numpy(), wr)
+    with torch.no_grad():
+        out, mask = head(d_pts[inds], torch.from_numpy(feats).to(device)[inds], info, roi_inds, d_rois)
+    c = lambda x: x.cpu()  # noqa: E731
+    want, wmask = omod.refine_head_forward(cpu, c(d_pts[inds]), torch.from_numpy(feats)[c(inds)],
+                                           {k: c(v) for k, v in info.items()}, c(roi_inds), torch.from_numpy(rois))
+    assert out.shape == (r, 128 * 2 * 3)
+    np.testing.assert_array_equal(mask.cpu().numpy(), wmask.numpy())
+    assert not bool(mask[7]) and not out[7].any()
+    close(out, want)
+
+
+def test_multiclass_nms_path_vs_oracle(plugin, device):
+    """box3d_multiclass_nms (per class: threshold, score sort, K20 rotated NMS, concat, top max_num) against the float64
+    oracle on clustered boxes."""
+    from fullysparsefusion_amd.mmdet3d_plugin.core.bbox import LiDARInstance3DBoxes, box3d_multiclass_nms, xywhr2xyxyr
+    from oracle import refine as orefine
+
+    rng = np.random.default_rng(12)
+    n, ncls = 260, 3
+    ctr = rng.uniform(-30, 30, (40, 2))[rng.integers(0, 40, n)] + rng.normal(0, 0.6, (n, 2))
+    boxes = np.concatenate([ctr, rng.uniform(-2, 0, (n, 1)), rng.uniform(1.6, 2.2, (n, 1)), rng.uniform(3.8, 5.0, (n, 1)),
+                            rng.uniform(1.4, 2.0, (n, 1)), rng.uniform(-3.1, 3.1, (n, 1)), rng.normal(0, 1, (n, 2))], 1).astype(np.float32)
+    scores = rng.random((n, ncls)).astype(np.float32)
+    cfg = dict(use_rotate_nms=True, nms_thr=0.3, score_thr=0.2, max_num=120)
+    tb, ts = torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device)
+    for_nms = xywhr2xyxyr(LiDARInstance3DBoxes(tb, box_dim=9).bev)
+    ob, osc, ol = box3d_multiclass_nms(tb, for_nms, torch.cat([ts, ts.new_zeros(n, 1)], 1), cfg["score_thr"], cfg["max_num"], cfg)
+    rows, wsc, wl = omod.multiclass_nms(torch.from_numpy(boxes), torch.from_numpy(scores), cfg["score_thr"], cfg["nms_thr"],
+                                        cfg["max_num"])
+    # the comparison is only meaningful if no pair sits within rounding of the IoU threshold
+    bev = boxes[:, [0, 1, 3, 4, 6]].astype(np.float64)
+    xyxyr = np.stack([bev[:, 0] - bev[:, 2] / 2, bev[:, 1] - bev[:, 3] / 2, bev[:, 0] + bev[:, 2] / 2, bev[:, 1] + bev[:, 3] / 2,
+                      bev[:, 4]], 1)
+    iou = orefine.iou_bev_matrix(xyxyr)
+    assert not (np.abs(iou - cfg["nms_thr"]) < 1e-5).any()
+    assert ob.shape[0] == cfg["max_num"] == rows.numel()
+    np.testing.assert_array_equal(ob.cpu().numpy(), boxes[rows.numpy()])
+    np.testing.assert_array_equal(osc.cpu().numpy(), wsc.numpy())
+    np.testing.assert_array_equal(ol.cpu().numpy(), wl.numpy())
+
+
+def test_simple_test_end_to_end_boxes(fsf_pair, frame1, device):
+    """FSF.simple_test = stages 1-3 + heads + query combination + refine stage + decode + NMS: shape / range / determinism
+    contract of the result (values are checked module by module above)."""
+    model, _ = fsf_pair
+    pts = [torch.from_numpy(frame1["points"]).to(device)]
+    metas = [dict(lidar2img=torch.from_numpy(frame1["lidar2img"]).to(device))]
+    mask = torch.from_numpy(frame1["mask_data"]).to(device)[None]
+    anno = torch.from_numpy(frame1["mask_anno"]).to(device)[None]
+    with torch.no_grad():
+        res = model.simple_test(pts, metas, mask, anno)
+        again = model.simple_test(pts, metas, mask, anno)
+    assert isinstance(res, list) and len(res) == 1
+    r = res[0]
+    boxes, scores, labels = r["boxes_3d"].tensor, r["scores_3d"], r["labels_3d"]
+    assert boxes.device.type == "cpu" and boxes.shape[1] == 9 and 0 < boxes.shape[0] <= 500
+    assert scores.shape == (boxes.shape[0],) and labels.shape == (boxes.shape[0],)
+    assert torch.isfinite(boxes).all() and (scores > 0.01).all() and (scores <= 1).all()
+    assert (labels >= 0).all() and (labels < 10).all() and (boxes[:, 3:6] > 0).all()
+    assert torch.equal(again[0]["boxes_3d"].tensor, boxes) and torch.equal(again[0]["scores_3d"], scores)
+    hot = model.simple_test(pts, metas, mask, anno, hot_path_only=True)
+    assert "frustum_obj_feats" in hot and "fsd_obj_feats" in hot

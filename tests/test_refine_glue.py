@@ -1,0 +1,103 @@
+"""CPU: the query-refinement glue of the plugin against vectors produced by the reference's own python
+(tests/golden/make_golden.py::gen_refine_glue) — box coder, query combination, stage box decoding, RoI feature
+alignment and everything FrustumClusterHead._get_bboxes_single does around its NMS call."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from fullysparsefusion_amd.mmdet3d_plugin.core.bbox import BasePointBBoxCoder, LiDARInstance3DBoxes, xywhr2xyxyr
+from fullysparsefusion_amd.mmdet3d_plugin.models.dense_heads import cluster_heads
+from fullysparsefusion_amd.mmdet3d_plugin.models.detectors.fsf import FSF
+from fullysparsefusion_amd.mmdet3d_plugin.models.roi_heads.refine import FullySparseBboxHead
+
+
+@pytest.fixture(scope="module")
+def g():
+    return load_golden("refine_glue.npz")
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_box_coder_decode_encode(g):
+    coder = BasePointBBoxCoder(code_size=10)
+    boxes = coder.decode(t(g["reg"]), t(g["base"]))
+    np.testing.assert_array_equal(boxes.numpy(), g["boxes"])
+    np.testing.assert_array_equal(coder.encode(boxes, t(g["base"])).numpy(), g["enc"])
+    with pytest.raises(AssertionError):
+        BasePointBBoxCoder(code_size=8).decode(t(g["reg"]), t(g["base"]))
+
+
+def test_combine_frustum_and_fsd_and_stage_decode(g):
+    ns = types.SimpleNamespace(fsd_begin_idx=1000, bbox_coder=BasePointBBoxCoder(code_size=10),
+                               combine_frustum_feat_mlp=lambda x: x[:, :6] * 2.0, combine_fsd_feat_mlp=lambda x: x[:, :6] - 1.0)
+    f_res = dict(cls_logits=[t(g["f_cls"])], reg_preds=[t(g["f_reg"])])
+    l_res = dict(cls_logits=[t(g["l_cls"])], reg_preds=[t(g["l_reg"])])
+    centers, coors, res, feats, p2d = FSF.combine_frustum_and_fsd(ns, t(g["f_centers"]), t(g["f_coors"]), f_res, t(g["f_feats"]),
+                                                                 t(g["f_p2d"]), t(g["l_centers"]), t(g["l_coors"]), l_res,
+                                                                 t(g["l_feats"]))
+    np.testing.assert_array_equal(centers.numpy(), g["c_centers"])
+    np.testing.assert_array_equal(coors.numpy(), g["c_coors"])
+    np.testing.assert_array_equal(res["cls_logits"][0].numpy(), g["c_cls"])
+    np.testing.assert_array_equal(res["reg_preds"][0].numpy(), g["c_reg"])
+    np.testing.assert_array_equal(feats.numpy(), g["c_feats"])
+    np.testing.assert_array_equal(p2d.numpy(), g["c_p2d"])
+    assert (coors[40:, 2] >= 1000).all() and (coors[:40, 2] < 1000).all()
+    rois = FSF.decode_stage_bboxes(ns, centers, coors[:, 0], res["reg_preds"])
+    np.testing.assert_array_equal(rois.numpy(), g["rois"])
+
+
+def test_roi_feature_alignment(g):
+    ns = types.SimpleNamespace(training=False)
+    mask = FullySparseBboxHead.get_nonempty_roi_mask(ns, t(g["out_coors"]), 12)
+    aligned = FullySparseBboxHead.align_roi_feature_and_rois(ns, t(g["roi_feats"]), t(g["out_coors"]), 12)
+    np.testing.assert_array_equal(mask.numpy(), g["roi_mask"])
+    np.testing.assert_array_equal(aligned.numpy(), g["roi_aligned"])
+    empty = FullySparseBboxHead.align_roi_feature_and_rois(ns, t(g["roi_feats"][:1]), torch.tensor([-1]), 12)
+    assert empty.shape == (12, 7) and not empty.any()
+
+
+def test_get_bboxes_single_around_the_nms_call(g, monkeypatch):
+    seen = {}
+
+    def keep_all_nms(bboxes, bboxes_for_nms, scores, score_thr, max_num, cfg):
+        seen["for_nms"] = bboxes_for_nms.clone()
+        bb, ss, ll = [], [], []
+        for i in range(scores.shape[1] - 1):
+            sel = scores[:, i] > score_thr
+            bb.append(bboxes[sel]); ss.append(scores[sel, i]); ll.append(torch.full((int(sel.sum()),), i, dtype=torch.long))
+        return torch.cat(bb), torch.cat(ss), torch.cat(ll)
+
+    monkeypatch.setattr(cluster_heads, "box3d_multiclass_nms", keep_all_nms)
+    classes = ["car", "truck", "trailer", "bus", "construction_vehicle", "bicycle", "motorcycle", "pedestrian", "traffic_cone",
+               "barrier"]
+    cfg = dict(use_rotate_nms=True, nms_pre=150, nms_thr=0.35, score_thr=0.3, min_bbox_size=0, max_num=500)
+    head = types.SimpleNamespace(as_rpn=False, training=False, test_cfg=cfg, tasks=[dict(class_names=["bus", "car", "pedestrian"])],
+                                 box_code_size=10, bbox_coder=BasePointBBoxCoder(code_size=10), vis_dir=None, class_names=classes,
+                                 EMPTY_BOX_DIM=9)
+    for name in ("_box_type", "_append_debug_columns", "_strip_debug_columns"):
+        setattr(head, name, types.MethodType(getattr(cluster_heads.FrustumClusterHead, name), head))
+    boxes, scores, labels = cluster_heads.FrustumClusterHead._get_bboxes_single(
+        head, 0, t(g["gb_cls"]), None, t(g["gb_reg"]), torch.zeros(200, 9), t(g["gb_xyz"]), dict(box_type_3d=LiDARInstance3DBoxes))
+    np.testing.assert_array_equal(seen["for_nms"].numpy(), g["gb_for_nms"])  # top-k pre-selection, decode, bev, xywhr2xyxyr
+    np.testing.assert_array_equal(boxes.tensor.numpy(), g["gb_boxes"])
+    np.testing.assert_array_equal(scores.numpy(), g["gb_scores"])
+    np.testing.assert_array_equal(labels.numpy(), g["gb_labels"])
+    assert set(labels.tolist()) <= {3, 0, 7}
+    # empty input keeps the reference's shapes
+    b0, s0, l0 = cluster_heads.FrustumClusterHead._get_bboxes_single(
+        head, 0, torch.zeros(0, 3), None, torch.zeros(0, 10), torch.zeros(0, 9), torch.zeros(0, 3), dict(box_type_3d=LiDARInstance3DBoxes))
+    assert b0.tensor.shape == (0, 9) and s0.numel() == 0 and l0.numel() == 0
+
+
+def test_xywhr2xyxyr_and_box_container():
+    b = LiDARInstance3DBoxes(torch.tensor([[1.0, 2.0, 0.0, 2.0, 4.0, 1.5, 0.3, 0.1, 0.2]]), box_dim=9)
+    assert b.bev.tolist() == [[1.0, 2.0, 2.0, 4.0, pytest.approx(0.3)]]
+    assert xywhr2xyxyr(b.bev).tolist() == [[0.0, 0.0, 2.0, 4.0, pytest.approx(0.3)]]
+    cat = LiDARInstance3DBoxes.cat([b, b])
+    assert len(cat) == 2 and cat.box_dim == 9
+    assert b.gravity_center.tolist() == [[1.0, 2.0, 0.75]]
