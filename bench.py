@@ -1,18 +1,21 @@
 #!/usr/bin/env python
-"""bench.py — frames/sec of the FSF hot-path forward on synthetic nuScenes-shape 10-sweep frames (BASELINE.json
-metric), one process per GPU.
+"""bench.py — frames/sec of the FSF forward on synthetic nuScenes-shape 10-sweep frames (BASELINE.json metric), one
+process per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (FSF.forward_hot_path: voxelize -> DynamicScatterVFE -> SimpleSparseUNet ->
-neck -> projection + mask gather + image fusion + seg head -> camera-query grouping + SIR -> LiDAR-query
-pre-voxelize, sampling, device CCL, SIR) over one frame whose inputs are already resident in HBM.  Frames are
-independent, so N ranks are N replicas with no data-path collective (weak scaling); the only collectives are the
-barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line with `roofline` (dominant kernel:
-the fused sparse-conv implicit GEMM on the fp32 MFMA, timed with HIP events in an instrumented pass over the same
-frames) and `cpu_baseline` (the CPU oracle restatement timed on this box's host cores on a bounded sample).
+A "step" is one full forward of the detector (FSF.simple_test: voxelize -> DynamicScatterVFE -> SimpleSparseUNet ->
+neck -> projection + mask gather + image fusion + seg head -> camera-query grouping + SIR -> LiDAR-query pre-voxelize,
+sampling, device CCL, SIR -> heads -> query combination -> RoI point pooling + refine SIR -> box decode + rotated BEV
+NMS -> results on the host) over one frame whose inputs are already resident in HBM.  `--hot-path-only` stops after the
+three query-generation stages; `--train` times fwd + bwd of a dummy loss + gradient all-reduce + AdamW instead.
+Frames are independent, so for inference N ranks are N replicas with no data-path collective (weak scaling); the only
+collectives are the barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line with `roofline`
+(dominant kernel: the fused sparse-conv implicit GEMM on the fp32 MFMA, timed with HIP events in an instrumented pass
+over the same frames) and `cpu_baseline` (the CPU oracle restatement timed on this box's host cores on a bounded
+sample).
 """
 import argparse
 import copy
@@ -43,6 +46,8 @@ def parse():
                     help="time the training step instead (BASELINE configs 3/4): fwd + bwd of a dummy scalar loss over the "
                          "hot-path outputs + bucketed gradient all-reduce over RCCL + AdamW")
     ap.add_argument("--frames-per-gpu", type=int, default=1, help="batch size per rank (config 4 uses 2)")
+    ap.add_argument("--hot-path-only", action="store_true",
+                    help="time stages 1-3 only (segmentor + fusion, camera queries, LiDAR queries), no heads / refine / NMS")
     return ap.parse_args()
 
 
@@ -72,9 +77,23 @@ def make_inputs(sweeps, seed, device, frames=1):
     return fs[0], dev
 
 
-def step(model, inp):
+def step(model, inp, hot_path_only=False):
+    """One forward of the detector over one batch: FSF.simple_test (segmentation + image fusion, camera queries, LiDAR
+    queries, query refinement, box decoding + NMS, results to the host) — or only its three query-generation stages."""
     with torch.no_grad():
-        return model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+        if hot_path_only:
+            return model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+        return model.simple_test(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+
+
+def describe_output(model, inp, out, args):
+    """Query / box counts of the timed workload (one extra untimed pass when the timed output does not carry them)."""
+    if not (args.train or args.hot_path_only):
+        hot = step(model, inp, hot_path_only=True)
+        extra = {"boxes_out": int(sum(len(r["boxes_3d"]) for r in out))}
+    else:
+        hot, extra = out, {}
+    return dict(camera_queries=int(hot["frustum_obj_feats"].shape[0]), lidar_queries=int(hot["fsd_obj_feats"].shape[0]), **extra)
 
 
 def dummy_loss(out):
@@ -104,7 +123,7 @@ class TrainStep:
         return out
 
 
-def spconv_roofline(model, inp, steps):
+def spconv_roofline(model, inp, steps, hot_path_only=False):
     """Instrumented pass: HIP events (on the launch stream = torch's current stream) around every
     fsf_spconv_forward launch; algorithmic flops = 2 * P * Cin * Cout with P counted from the rulebook."""
     from fullysparsefusion_amd import hip_ops
@@ -130,7 +149,7 @@ def spconv_roofline(model, inp, steps):
     try:
         for _ in range(steps):
             pair_cache.clear()
-            step(model, inp)
+            step(model, inp, hot_path_only)
         torch.cuda.synchronize()
     finally:
         hip_ops.spconv_forward = orig
@@ -178,8 +197,9 @@ def cpu_baseline(model_cpu):
     dt = time.perf_counter() - t0
     frac = pts8.shape[0] / full_n
     return dict(value=round(frac / dt, 5), unit="frames/s", cores=cores, kind="port",
-                sample=f"1 of 10 sweeps ({pts8.shape[0]} of {full_n} points) through oracle stages 1-3 in {dt:.1f} s; "
-                       f"value = frame fraction / time")
+                sample=f"1 of 10 sweeps ({pts8.shape[0]} of {full_n} points) through oracle stages 1-3 (segmentor + fusion, camera "
+                       f"queries, LiDAR queries; the refine stage and NMS are not in the CPU sample, so this over-states the "
+                       f"CPU rate of the full forward) in {dt:.1f} s; value = frame fraction / time")
 
 
 def main():
@@ -205,7 +225,7 @@ def main():
         train_step = TrainStep(model)
         run = lambda: train_step(inp)
     else:
-        run = lambda: step(model, inp)
+        run = lambda: step(model, inp, args.hot_path_only)
 
     for _ in range(args.warmup):
         run()
@@ -230,8 +250,8 @@ def main():
     if rank == 0:
         n_pts = int(inp["points"][0].shape[0])
         result = {
-            "metric": ("frames/sec fwd+bwd+allreduce+AdamW nuScenes 10-sweep FSF hot path (dummy loss)" if args.train
-                       else "frames/sec fwd nuScenes 10-sweep FSF hot path"),
+            "metric": ("frames/sec fwd+bwd+allreduce+AdamW nuScenes 10-sweep FSF (dummy loss)" if args.train
+                       else "frames/sec fwd nuScenes 10-sweep FSF" + (" (query-generation stages only)" if args.hot_path_only else "")),
             "value": round(world * args.frames_per_gpu * args.steps / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,
@@ -244,20 +264,31 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"fsf_nuscenes_{args.sweeps}sweep_hot_path_{'train_step' if args.train else 'fwd'} (BASELINE config 3 "
-                             "input; stages 1-3 of FSF.simple_test: segmentor + image fusion, camera queries, LiDAR queries; "
-                             "heads/NMS/refine not built)"),
+                "workload": (f"fsf_nuscenes_{args.sweeps}sweep_" + (
+                    "train_step: fwd of the query-generation stages + bwd of a dummy scalar loss + gradient all-reduce + AdamW"
+                    if args.train else "hot_path_fwd: stages 1-3 of FSF.simple_test only" if args.hot_path_only else
+                    "simple_test: full forward = segmentor + image fusion, camera queries, LiDAR queries, heads, query "
+                    "refinement (RoI point pooling + SIR), box decode + rotated BEV NMS, results to host") +
+                    " (BASELINE config 3 input, random-init weights of the reference architecture)"),
                 "points_per_frame": n_pts,
                 "frames_per_gpu_per_step": args.frames_per_gpu,
                 "mask_data": "u8[1,6,10,900,1600]",
-                "camera_queries": int(out["frustum_obj_feats"].shape[0]),
-                "lidar_queries": int(out["fsd_obj_feats"].shape[0]),
+                **describe_output(model, inp, out, args),
                 "parallelism": (f"dp{world}: frame-level data parallel, bucketed gradient all-reduce over RCCL" if args.train
                                 else f"replicas x{world} (frames independent, no data-path collective)"),
             },
         }
     if rank == 0 and not args.no_roofline and not args.train:
-        result["roofline"] = spconv_roofline(model, inp, min(args.steps, 5))
+        result["roofline"] = spconv_roofline(model, inp, min(args.steps, 5), args.hot_path_only)
+        if not args.hot_path_only:  # where the frame time goes: the three query-generation stages vs the rest
+            n = min(args.steps, 5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                step(model, inp, hot_path_only=True)
+            torch.cuda.synchronize()
+            result["stages"] = {"query_generation_ms": round((time.perf_counter() - t0) / n * 1e3, 3),
+                                "full_forward_ms": result["ms_per_step"]}
     if rank == 0 and model_cpu is not None:
         result["cpu_baseline"] = cpu_baseline(model_cpu)
     if dist is not None:
