@@ -25,6 +25,19 @@ struct NmsArgs {
   int words, sum_words;
   int64_t* keep;
   int64_t* num_keep;
+  // multi-class form: one scan workgroup per class over its own (mask, rowsum, keep) slice; boxes per class on the device
+  const int32_t* count;
+  int64_t mask_stride, sum_stride, keep_stride;
+};
+
+struct NmsBuildArgs {
+  const uint64_t* mask0;    // pair bits in the original box order (upper triangle)
+  const uint64_t* rowsum0;
+  const int32_t* rank;      // [C][n] position of box i in class c's descending-score order, -1 = below the threshold
+  uint64_t* mask;           // [C][n][words]
+  uint64_t* rowsum;         // [C][n][sum_words]
+  int64_t n;
+  int words, sum_words;
 };
 
 __device__ __forceinline__ float rect_overlap_rotated(const float* a, const float* b) {
@@ -146,6 +159,17 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
   extern __shared__ uint64_t removed[];
   __shared__ uint64_t kept_word;
   __shared__ int64_t nkeep;
+  if (a.count) {  // class slice; the row strides (a.words, a.sum_words) are those of the full box count
+    const int c = blockIdx.x;
+    a.n = a.count[c];
+    a.mask += c * a.mask_stride;
+    a.rowsum += c * a.sum_stride;
+    a.keep += c * a.keep_stride;
+    a.num_keep += c;
+  }
+  const int row_words = a.words, row_sum = a.sum_words;
+  a.words = (int)((a.n + 63) / 64);
+  a.sum_words = (a.words + 63) / 64;
   for (int w = threadIdx.x; w < a.words; w += 256) removed[w] = 0;
   if (threadIdx.x == 0) nkeep = 0;
   __syncthreads();
@@ -154,17 +178,17 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
   // together with the diagonal words; beyond that they are loaded on demand
   const bool pre = 64 * a.sum_words <= 256;
   const int ub = threadIdx.x & 63, uq = threadIdx.x >> 6;
-  uint64_t diag_next = (threadIdx.x < 64 && lane < a.n) ? a.mask[(int64_t)lane * a.words] : 0ull;
-  uint64_t sum_next = (pre && uq < a.sum_words && ub < a.n) ? a.rowsum[(int64_t)ub * a.sum_words + uq] : 0ull;
+  uint64_t diag_next = (threadIdx.x < 64 && lane < a.n) ? a.mask[(int64_t)lane * row_words] : 0ull;
+  uint64_t sum_next = (pre && uq < a.sum_words && ub < a.n) ? a.rowsum[(int64_t)ub * row_sum + uq] : 0ull;
   for (int w = 0; w < a.words; ++w) {
     const int64_t i0 = (int64_t)w * 64;
     const int nb = (int)min((int64_t)64, a.n - i0);
     const uint64_t sum_cur = sum_next;
-    if (pre && w + 1 < a.words && uq < a.sum_words && i0 + 64 + ub < a.n) sum_next = a.rowsum[(i0 + 64 + ub) * a.sum_words + uq];
+    if (pre && w + 1 < a.words && uq < a.sum_words && i0 + 64 + ub < a.n) sum_next = a.rowsum[(i0 + 64 + ub) * row_sum + uq];
     else sum_next = 0ull;
     if (threadIdx.x < 64) {
       const uint64_t diag = diag_next;
-      if (w + 1 < a.words && i0 + 64 + lane < a.n) diag_next = a.mask[(i0 + 64 + lane) * a.words + w + 1];  // prefetch
+      if (w + 1 < a.words && i0 + 64 + lane < a.n) diag_next = a.mask[(i0 + 64 + lane) * row_words + w + 1];  // prefetch
       else diag_next = 0ull;
       const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
       uint64_t alive = ~removed[w];
@@ -194,7 +218,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
         if (uq == q0) sbits &= ~((2ull << (w & 63)) - 1ull);  // words <= w are already settled
         for (; sbits; sbits &= sbits - 1) {
           const int w2 = uq * 64 + __builtin_ctzll(sbits);
-          atomicOr((unsigned long long*)&removed[w2], (unsigned long long)a.mask[(i0 + ub) * a.words + w2]);
+          atomicOr((unsigned long long*)&removed[w2], (unsigned long long)a.mask[(i0 + ub) * row_words + w2]);
         }
       }
     } else {
@@ -202,17 +226,45 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
         const int b = u & 63, q = q0 + (u >> 6);
         if (!((kept >> b) & 1ull)) continue;
         const int64_t i = i0 + b;
-        uint64_t sbits = a.rowsum[i * a.sum_words + q];
+        uint64_t sbits = a.rowsum[i * row_sum + q];
         if (q == q0) sbits &= ~((2ull << (w & 63)) - 1ull);
         for (; sbits; sbits &= sbits - 1) {
           const int w2 = q * 64 + __builtin_ctzll(sbits);
-          atomicOr((unsigned long long*)&removed[w2], (unsigned long long)a.mask[i * a.words + w2]);
+          atomicOr((unsigned long long*)&removed[w2], (unsigned long long)a.mask[i * row_words + w2]);
         }
       }
     }
     __syncthreads();
   }
   if (threadIdx.x == 0) *a.num_keep = nkeep;
+}
+
+// Multi-class: the pair bits were computed once in the original box order; class c's scan needs them in ITS score order.
+// thread = (box i, summary word q): walk the few set bits, translate both ends through rank[c], set the bit (lower rank
+// = row) in the class's mask and summary.
+__global__ void __launch_bounds__(256) nms_build_kernel(NmsBuildArgs a) {
+  const int c = blockIdx.y;
+  const int32_t* rank = a.rank + (int64_t)c * a.n;
+  uint64_t* mask = a.mask + (int64_t)c * a.n * a.words;
+  uint64_t* rowsum = a.rowsum + (int64_t)c * a.n * a.sum_words;
+  const int64_t total = a.n * a.sum_words;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t i = t / a.sum_words;
+    const int q = (int)(t - i * a.sum_words);
+    const int ri = rank[i];
+    if (ri < 0) continue;
+    for (uint64_t sb = a.rowsum0[t]; sb; sb &= sb - 1) {
+      const int w = q * 64 + __builtin_ctzll(sb);
+      for (uint64_t bits = a.mask0[i * a.words + w]; bits; bits &= bits - 1) {
+        const int64_t j = (int64_t)w * 64 + __builtin_ctzll(bits);
+        const int rj = rank[j];
+        if (rj < 0) continue;
+        const int lo = min(ri, rj), hi = max(ri, rj);
+        atomicOr((unsigned long long*)&mask[(int64_t)lo * a.words + (hi >> 6)], 1ull << (hi & 63));
+        atomicOr((unsigned long long*)&rowsum[(int64_t)lo * a.sum_words + (hi >> 12)], 1ull << ((hi >> 6) & 63));
+      }
+    }
+  }
 }
 
 }  // namespace fsf
@@ -243,7 +295,7 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
   if (n == 0) {
     FSF_HIP_TRY(hipMemsetAsync(ndev, 0, sizeof(int64_t), stream));
   } else {
-    NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, ndev};
+    NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, ndev, nullptr, 0, 0, 0};
     FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)n * sum_words * 8, stream));
     // words below the diagonal are never written by the mask kernel and never read by the scan (w starts at i / 64)
     hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, stream, a);
@@ -254,5 +306,46 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
     FSF_HIP_TRY(hipMemcpyAsync(num_keep_host, ndev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
     FSF_HIP_TRY(hipStreamSynchronize(stream));
   }
+  return FSF_OK;
+}
+
+extern "C" int64_t fsf_nms_bev_multiclass_workspace_bytes(int64_t n, int32_t num_classes) {
+  const int64_t words = (n + 63) / 64, sum_words = (words + 63) / 64;
+  const int64_t n1 = n > 0 ? n : 1, w1 = words > 0 ? words : 1, s1 = sum_words > 0 ? sum_words : 1;
+  const int64_t c1 = num_classes > 0 ? num_classes : 1;
+  return (1 + c1) * (fsf_align_up(n1 * w1 * 8, 256) + fsf_align_up(n1 * s1 * 8, 256)) + 512;
+}
+
+extern "C" int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank,
+                                      const int32_t* count, float thresh, int32_t rotated, int64_t* keep, int64_t* num_keep,
+                                      void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || num_classes < 1 || !count || !num_keep || (n > 0 && (!boxes || !rank || !keep))) return FSF_ERR_INVALID_ARG;
+  const int64_t words = (n + 63) / 64, sum_words = (words + 63) / 64;
+  if (words * 8 > 60 * 1024) return FSF_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsf_nms_bev_multiclass_workspace_bytes(n, num_classes) || !workspace) return FSF_ERR_WORKSPACE;
+  if (n == 0) {
+    FSF_HIP_TRY(hipMemsetAsync(num_keep, 0, sizeof(int64_t) * num_classes, stream));
+    return FSF_OK;
+  }
+  FsfArena arena(workspace, workspace_bytes);
+  uint64_t* mask0 = arena.take<uint64_t>(n * words);
+  uint64_t* rowsum0 = arena.take<uint64_t>(n * sum_words);
+  uint64_t* mask = arena.take<uint64_t>((int64_t)num_classes * n * words);
+  uint64_t* rowsum = arena.take<uint64_t>((int64_t)num_classes * n * sum_words);
+  if (!arena.ok()) return FSF_ERR_WORKSPACE;
+  // the build kernel walks mask0 through rowsum0, so the lower-triangle words the mask kernel skips are never read
+  FSF_HIP_TRY(hipMemsetAsync(rowsum0, 0, (size_t)n * sum_words * 8, stream));
+  FSF_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)num_classes * n * words * 8, stream));
+  FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)num_classes * n * sum_words * 8, stream));
+  NmsArgs a0{boxes, n, thresh, (int)rotated, mask0, rowsum0, (int)words, (int)sum_words, nullptr, nullptr, nullptr, 0, 0, 0};
+  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, stream, a0);
+  NmsBuildArgs b{mask0, rowsum0, rank, mask, rowsum, n, (int)words, (int)sum_words};
+  hipLaunchKernelGGL(nms_build_kernel, dim3((unsigned)fsf_stream_grid(n * sum_words, 256), (unsigned)num_classes), dim3(256), 0,
+                     stream, b);
+  NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, num_keep, count,
+            n * words, n * sum_words, n};
+  hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)num_classes), dim3(256), (size_t)words * 8, stream, a);
+  FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -45,6 +45,8 @@ _ARGTYPES = {
                                _P, c_i64, _P],
     "fsf_nms_bev_workspace_bytes": [c_i64],
     "fsf_nms_bev": [_P, c_i64, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
+    "fsf_nms_bev_multiclass_workspace_bytes": [c_i64, c_i32],
+    "fsf_nms_bev_multiclass": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
 }
@@ -444,6 +446,23 @@ def nms_bev(boxes_sorted: torch.Tensor, thresh: float, rotated: bool = True):
     check(h.fsf_nms_bev(ptr(b), n, float(thresh), int(bool(rotated)), ptr(keep), None,
                         ctypes.cast(ctypes.pointer(num), c_p), ptr(ws), ws.numel(), stream_ptr()), "fsf_nms_bev")
     return keep[: int(num.value)]
+
+
+def nms_bev_multiclass(boxes: torch.Tensor, rank: torch.Tensor, count: torch.Tensor, thresh: float, rotated: bool = True):
+    """fsf_nms_bev_multiclass: boxes f32 [n,5] (caller's order), rank i32 [C,n], count i32 [C] ->
+    (keep i64 [C,n] kept ranks per class, num_keep i64 [C]), all on the device (no sync)."""
+    require_cuda(boxes, rank, count)
+    assert boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.size(1) == 5
+    assert rank.dtype == torch.int32 and count.dtype == torch.int32 and rank.dim() == 2 and rank.size(1) == boxes.size(0)
+    b, rank, count = boxes.contiguous(), rank.contiguous(), count.contiguous()
+    n, c = b.size(0), rank.size(0)
+    keep = torch.empty((c, max(n, 1)), dtype=torch.int64, device=b.device)
+    num = torch.empty((c,), dtype=torch.int64, device=b.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_nms_bev_multiclass_workspace_bytes(n, c), b.device)
+    check(h.fsf_nms_bev_multiclass(ptr(b), n, c, ptr(rank), ptr(count), float(thresh), int(bool(rotated)), ptr(keep), ptr(num),
+                                   ptr(ws), ws.numel(), stream_ptr()), "fsf_nms_bev_multiclass")
+    return keep, num
 
 
 # ------------------------------------------------------------------------------ connected components

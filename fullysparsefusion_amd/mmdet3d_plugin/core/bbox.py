@@ -150,28 +150,30 @@ def nms_normal_gpu(boxes, scores, thresh):
 
 def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_thr, max_num, cfg):
     """mmdet3d.core.post_processing.box3d_multiclass_nms (the arguments the FSF heads pass): per class, threshold ->
-    BEV NMS -> concatenate; over max_num keep the best scores.  The last score column is the padded background."""
+    BEV NMS -> concatenate class by class; over max_num keep the best scores.  The last score column is the padded
+    background.  Upstream runs one nms_gpu per class (each with its own host round trip); here every class goes through
+    ONE `fsf_nms_bev_multiclass` call and there is a single device->host read (how many boxes survived)."""
     num_classes = mlvl_scores.shape[1] - 1
-    bboxes, scores, labels = [], [], []
-    nms_func = nms_gpu if cfg.get("use_rotate_nms", False) else nms_normal_gpu
-    for i in range(num_classes):
-        cls_inds = (mlvl_scores[:, i] > score_thr).nonzero(as_tuple=False).squeeze(1)
-        if cls_inds.numel() == 0:
-            continue
-        _scores = mlvl_scores[cls_inds, i]
-        selected = nms_func(mlvl_bboxes_for_nms[cls_inds, :], _scores, cfg["nms_thr"])
-        bboxes.append(mlvl_bboxes[cls_inds, :][selected])
-        scores.append(_scores[selected])
-        labels.append(mlvl_bboxes.new_full((len(selected),), i, dtype=torch.long))
-    if bboxes:
-        bboxes, scores, labels = torch.cat(bboxes, dim=0), torch.cat(scores, dim=0), torch.cat(labels, dim=0)
-        if bboxes.shape[0] > max_num:
-            inds = scores.sort(descending=True)[1][:max_num]
-            bboxes, labels, scores = bboxes[inds, :], labels[inds], scores[inds]
-    else:
-        bboxes = mlvl_scores.new_zeros((0, mlvl_bboxes.size(-1)))
-        scores = mlvl_scores.new_zeros((0,))
-        labels = mlvl_scores.new_zeros((0,), dtype=torch.long)
+    n = mlvl_scores.shape[0]
+    if n == 0 or num_classes == 0:
+        return (mlvl_scores.new_zeros((0, mlvl_bboxes.size(-1))), mlvl_scores.new_zeros((0,)),
+                mlvl_scores.new_zeros((0,), dtype=torch.long))
+    st = mlvl_scores[:, :num_classes].t().contiguous()                      # [C, n]
+    valid = st > score_thr
+    order = torch.where(valid, st, st.new_full((), float("-inf"))).sort(dim=1, descending=True, stable=True)[1]
+    count = valid.sum(1, dtype=torch.int32)
+    pos = torch.arange(n, device=st.device, dtype=torch.int32).expand(num_classes, n)
+    rank = torch.empty_like(pos).scatter_(1, order, pos)
+    rank = torch.where(valid, rank, rank.new_full((), -1))
+    keep, num = hip_ops.nms_bev_multiclass(mlvl_bboxes_for_nms.float(), rank, count, cfg["nms_thr"],
+                                           rotated=bool(cfg.get("use_rotate_nms", False)))
+    kept = (torch.arange(n, device=st.device)[None, :] < num[:, None]).nonzero(as_tuple=False)  # class-major, score order
+    labels = kept[:, 0]
+    box_idx = order[labels, keep[labels, kept[:, 1]]]
+    bboxes, scores = mlvl_bboxes[box_idx], st[labels, box_idx]
+    if bboxes.shape[0] > max_num:
+        inds = scores.sort(descending=True)[1][:max_num]
+        bboxes, labels, scores = bboxes[inds, :], labels[inds], scores[inds]
     return bboxes, scores, labels
 
 

@@ -289,6 +289,18 @@ int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t roi_stride
 int64_t fsf_nms_bev_workspace_bytes(int64_t n);
 int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t rotated, int64_t* keep, int64_t* num_keep_dev,
                 int64_t* num_keep_host, void* workspace, int64_t workspace_bytes, void* stream);
+/* All classes of one head in three launches (box3d_multiclass_nms runs nms_gpu once per class on the SAME boxes with
+ * different score orders): the overlap test runs once in the original box order, each class gets its bits permuted into
+ * its own score order, and the greedy scans of all classes run side by side (one workgroup each).
+ *   boxes f32 [n,5] in the caller's order; rank i32 [num_classes,n] = position of box i in class c's descending-score
+ *   order among the boxes above the score threshold, -1 otherwise; count i32 [num_classes] (device) = boxes per class;
+ *   keep i64 [num_classes,n]: kept RANKS of class c, ascending, in keep[c, 0 .. num_keep[c]); num_keep i64
+ *   [num_classes] (device).
+ */
+int64_t fsf_nms_bev_multiclass_workspace_bytes(int64_t n, int32_t num_classes);
+int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank, const int32_t* count,
+                           float thresh, int32_t rotated, int64_t* keep, int64_t* num_keep, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K18  in-group rank (TorchEx ingroup_indices [UNVENDORED]); sst_ops.py:239-259.

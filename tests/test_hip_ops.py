@@ -619,3 +619,26 @@ def test_nms_bev_vs_oracle(ops, device, n, rotated):
     else:  # large: self-consistency via a second, permuted-but-equivalent call and idempotence
         again = ops.nms_bev(torch.from_numpy(boxes[keep]).to(device), thresh, rotated).cpu().numpy()
         np.testing.assert_array_equal(again, np.arange(len(keep)))
+
+
+def test_nms_bev_multiclass_equals_per_class_calls(ops, device):
+    """One batched call == one fsf_nms_bev call per class on the class's own score order (incl. an empty class)."""
+    rng = np.random.default_rng(21)
+    n, c = 900, 5
+    ctr = rng.uniform(-40, 40, (150, 2))[rng.integers(0, 150, n)] + rng.normal(0, 0.7, (n, 2))
+    wl = np.stack([rng.uniform(1.5, 2.5, n), rng.uniform(3.5, 5.5, n)], 1)
+    boxes = torch.from_numpy(np.concatenate([ctr - wl / 2, ctr + wl / 2, rng.uniform(-np.pi, np.pi, (n, 1))], 1).astype(np.float32)).to(device)
+    scores = torch.from_numpy(rng.random((c, n)).astype(np.float32)).to(device)
+    scores[3] = 0.0  # nothing above the threshold
+    valid = scores > 0.3
+    order = torch.where(valid, scores, scores.new_full((), float("-inf"))).sort(dim=1, descending=True, stable=True)[1]
+    count = valid.sum(1, dtype=torch.int32)
+    pos = torch.arange(n, device=device, dtype=torch.int32).expand(c, n)
+    rank = torch.where(valid, torch.empty_like(pos).scatter_(1, order, pos), pos.new_full((), -1))
+    keep, num = ops.nms_bev_multiclass(boxes, rank, count, 0.25, True)
+    for k in range(c):
+        nk = int(count[k])
+        want = ops.nms_bev(boxes[order[k, :nk]], 0.25, True)
+        assert int(num[k]) == want.numel()
+        assert torch.equal(keep[k, : int(num[k])], want)
+    assert int(num[3]) == 0
