@@ -67,10 +67,10 @@ __device__ __forceinline__ PoolBox load_box(const PoolArgs& a, int64_t r) {
 
 // 0 = outside, 1 = inside the box, 2 = inside the enlarged box only
 __device__ __forceinline__ int pool_test(const PoolBox& k, float x, float y, float z, float& lx, float& ly, float& lz) {
+  const float dx = x - k.cx, dy = y - k.cy;
+  if (dx * dx + dy * dy > k.r2) return 0;  // rejects almost every pair: keep it first
   lz = z - k.cz;
   if (fabsf(lz) > k.lhh) return 0;
-  const float dx = x - k.cx, dy = y - k.cy;
-  if (dx * dx + dy * dy > k.r2) return 0;
   lx = dx * k.cosa + dy * (-k.sina);
   ly = dx * k.sina + dy * k.cosa;
   const bool in_large = (lx > -k.lhl) & (lx < k.lhl) & (ly > -k.lhw) & (ly < k.lhw);
@@ -81,27 +81,33 @@ __device__ __forceinline__ int pool_test(const PoolBox& k, float x, float y, flo
 
 template <bool FILL>
 __global__ void __launch_bounds__(256) pool_pass_kernel(PoolArgs a) {
-  __shared__ float sx[PP_TILE], sy[PP_TILE], sz[PP_TILE];
-  __shared__ int sb[PP_TILE];
+  __shared__ float4 sp[PP_TILE];  // x, y, z, batch index (exact in fp32)
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (FILL) {
+    // rows past the global cap are never written: when the whole RoI tile starts beyond it there is nothing to do
+    // (with max_all_pts = 50000 and thousands of queries that is nearly every tile)
+    const int64_t r_first = (int64_t)blockIdx.x * 256;
+    if ((int64_t)a.roi_off[r_first] >= a.max_all) return;
+  }
   const int64_t p0 = (int64_t)blockIdx.y * PP_TILE;
   const int tile_n = (int)min((int64_t)PP_TILE, a.n_pts - p0);
   for (int j = threadIdx.x; j < tile_n; j += 256) {
     const float* p = a.pts + (p0 + j) * a.pts_stride;
-    sx[j] = p[0];
-    sy[j] = p[1];
-    sz[j] = p[2];
-    sb[j] = a.pts_batch ? (int)a.pts_batch[p0 + j] : 0;
+    sp[j] = make_float4(p[0], p[1], p[2], a.pts_batch ? (float)a.pts_batch[p0 + j] : 0.0f);
   }
   __syncthreads();
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= a.n_rois) return;
   const PoolBox k = load_box(a, r);
+  const float kbatch = (float)k.batch;
   uint32_t* my_cnt = a.cnt + (int64_t)blockIdx.y * a.n_rois + r;
   uint32_t rank = FILL ? *my_cnt : 0u;  // after the prefix pass: in-box points of this RoI in earlier tiles
   const uint32_t base = FILL ? a.roi_off[r] : 0u;
+  if (FILL && (rank >= (uint32_t)a.max_inbox || (int64_t)base + rank >= a.max_all)) return;  // caps already reached
+#pragma unroll 4
   for (int j = 0; j < tile_n; ++j) {
+    const float4 q = sp[j];
     float lx, ly, lz;
-    const int flag = (sb[j] == k.batch) ? pool_test(k, sx[j], sy[j], sz[j], lx, ly, lz) : 0;
+    const int flag = (q.w == kbatch) ? pool_test(k, q.x, q.y, q.z, lx, ly, lz) : 0;
     if (flag) {
       if (FILL) {
         const int64_t slot = (int64_t)base + rank;
@@ -109,9 +115,9 @@ __global__ void __launch_bounds__(256) pool_pass_kernel(PoolArgs a) {
           a.out_pts[slot] = p0 + j;
           a.out_roi[slot] = r;
           float* f = a.out_feat + slot * PP_FEAT;
-          f[0] = sx[j];
-          f[1] = sy[j];
-          f[2] = sz[j];
+          f[0] = q.x;
+          f[1] = q.y;
+          f[2] = q.z;
           f[3] = lx;
           f[4] = ly;
           f[5] = lz;
