@@ -104,3 +104,14 @@ def test_reference_av2_config_resolves():
     seg = plugin.registry.build_detector(cfg.model.segmentor)
     assert seg.backbone.sparse_shape == [32, 2048, 2048]
     assert seg.voxel_layer.grid_size.tolist() == [2048, 2048, 32]
+    # the repository's own AV2 model file describes the same model (parameters and inference-relevant arguments)
+    own = Config.fromfile(os.path.join(ROOT, "configs", "fsf_av2.py"))
+    for key in ["segmentor", "backbone", "frustum_sir", "cluster_assigner", "test_cfg", "mlp_cfg", "bbox_coder", "roi_extractor",
+                "single_refine_sir_layer", "refine_encode_2d_mlp_cfg", "encode_2d_mlp_cfg", "segmentor_updated_mlp", "is_argo",
+                "num_cams", "num_classes"]:
+        assert cfg.model[key] == own.model[key], key
+    ref_model = plugin.build_model(cfg.model, train_cfg=cfg.get("train_cfg"), test_cfg=cfg.get("test_cfg"))
+    own_model = plugin.build_model(own.model)
+    assert {k: tuple(v.shape) for k, v in ref_model.state_dict().items()} == \
+           {k: tuple(v.shape) for k, v in own_model.state_dict().items()}
+    assert own_model.bbox_coder.code_size == 8 and own_model.is_argo

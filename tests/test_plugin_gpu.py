@@ -540,3 +540,38 @@ def test_simple_test_end_to_end_boxes(fsf_pair, frame1, device):
     assert torch.equal(again[0]["boxes_3d"].tensor, boxes) and torch.equal(again[0]["scores_3d"], scores)
     hot = model.simple_test(pts, metas, mask, anno, hot_path_only=True)
     assert "frustum_obj_feats" in hot and "fsd_obj_feats" in hot
+
+
+def test_av2_full_detector_end_to_end(plugin, device):
+    """BASELINE config 5 through the whole detector: +-200 m cloud of 4-d points, 7 cameras, ONE int32 id plane per camera
+    (ids > 255), 26 classes, the `is_argo` image branch (box + score + one-hot, FSF.py:540-548), 8-d box code."""
+    from fullysparsefusion_amd import synthetic
+    from fullysparsefusion_amd.compat import Config
+
+    torch.manual_seed(11)
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "fsf_av2.py"))
+    model = plugin.build_model(cfg.model).eval()
+    torch.nn.init.normal_(model.segmentor_updated_mlp[-1].weight, std=0.05)
+    model.to(device)
+    rng = np.random.default_rng(13)
+    n = 60000
+    r = rng.uniform(2.0, 200.0, n)
+    a = rng.uniform(-np.pi, np.pi, n)
+    xyz = np.stack([r * np.cos(a), r * np.sin(a), rng.normal(-1.5, 0.5, n).clip(-3.1, 3.1)], 1)
+    xyz = xyz[(np.abs(xyz[:, 0]) < 204.7) & (np.abs(xyz[:, 1]) < 204.7)]
+    pts = np.concatenate([xyz, rng.random((xyz.shape[0], 1)), xyz], 1).astype(np.float32)  # x y z i | no-aug xyz
+    L = synthetic.make_lidar2img(7, fx=1780.0, cx=1024.0, cy=775.0)
+    mask, anno = synthetic.make_mask_data(rng, 7, 1, 1550, 2048, 400, dtype=np.int32)
+    anno[:, 5] = rng.integers(0, 26, anno.shape[0])  # category: one of the 26 classes
+    pts_t = [torch.from_numpy(pts).to(device)]
+    metas = [dict(lidar2img=torch.from_numpy(L).to(device))]
+    with torch.no_grad():
+        hot = model.forward_hot_path(pts_t, metas, torch.from_numpy(mask).to(device)[None], torch.from_numpy(anno).to(device)[None])
+        res = model.simple_test(pts_t, metas, torch.from_numpy(mask).to(device)[None], torch.from_numpy(anno).to(device)[None])
+    seg = hot["seg"]
+    assert seg["seg_logits"].shape == (pts.shape[0], 27) and seg["seg_vote_preds"].shape == (pts.shape[0], 27 * 3)
+    assert hot["frustum_obj_feats"].shape[1] == 128 * 3 * 2 + 128 and hot["fsd_obj_feats"].shape[1] == 128 * 3 * 2
+    assert hot["frustum_obj_feats"].shape[0] > 0 and int(hot["frustum_obj_coors"][:, 2].max()) > 255  # ids beyond u8 survive
+    boxes, scores, labels = res[0]["boxes_3d"].tensor, res[0]["scores_3d"], res[0]["labels_3d"]
+    assert boxes.shape[1] == 7 and 0 < boxes.shape[0] <= 500 and torch.isfinite(boxes).all()
+    assert (labels >= 0).all() and (labels < 26).all() and float(boxes[:, :2].abs().max()) > 60.0  # long-range boxes exist
