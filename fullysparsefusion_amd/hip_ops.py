@@ -40,6 +40,8 @@ _ARGTYPES = {
     "fsf_spconv_backward_weight": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_connected_components_workspace_bytes": [c_i64],
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
+    "fsf_sir_input": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
+                      _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
     "fsf_dynamic_point_pool_workspace_bytes": [c_i64, c_i64],
     "fsf_dynamic_point_pool": [_P, c_i64, c_i32, c_i32, c_i32, _P, c_i64, c_i32, _P, _P, c_i32, c_i64, _P, _P, _P, _P, _P,
                                _P, c_i64, _P],
@@ -397,6 +399,29 @@ def ingroup_rank(group_inds: torch.Tensor):
     h = _L()
     ws = _lib.workspace(h.fsf_ingroup_rank_workspace_bytes(n), g.device)
     check(h.fsf_ingroup_rank(ptr(g), n, ptr(out), ptr(ws), ws.numel(), stream_ptr()), "fsf_ingroup_rank")
+    return out
+
+
+# ------------------------------------------------------------------------------------- SIR-layer input
+def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_div: float, extra=None, extra_div: float = 1.0):
+    """fsf_sir_input: cat(points / normalizer, feats[, extra / extra_div]) * rel_mlp(f_cluster / rel_div) -> f32 [n, C].
+    `layers` = three (linear_weight, ln_weight, ln_bias) triples of the position MLP; one eps (taken by the caller)."""
+    require_cuda(points, feats, f_cluster, extra)
+    n = points.size(0)
+    (w1, g1, b1), (w2, g2, b2), (w3, g3, b3), eps = layers
+    c = points.size(1) + feats.size(1) + (extra.size(1) if extra is not None else 0)
+    assert w3.size(0) == c and w1.size(1) == f_cluster.size(1) and w2.size(1) == w1.size(0) and w3.size(1) == w2.size(0)
+    for t in (points, feats, f_cluster, extra):
+        assert t is None or (t.dtype == torch.float32 and t.dim() == 2 and (t.size(0) == 0 or t.stride(1) == 1))
+    out = torch.empty((n, c), dtype=torch.float32, device=points.device)
+    rp = lambda t: c_p(t.data_ptr()) if t is not None and t.numel() else c_p(None)  # noqa: E731  row-strided views pass as is
+    st = lambda t: t.stride(0) if t is not None and t.size(0) > 1 else (t.size(1) if t is not None else 0)  # noqa: E731
+    check(_L().fsf_sir_input(rp(points), st(points), points.size(1), f32_array(xyz_normalizer), rp(feats), st(feats),
+                             feats.size(1), rp(extra), st(extra), extra.size(1) if extra is not None else 0, float(extra_div),
+                             rp(f_cluster), st(f_cluster), f_cluster.size(1), float(rel_div),
+                             ptr(w1.contiguous()), ptr(g1), ptr(b1), w1.size(0), ptr(w2.contiguous()), ptr(g2), ptr(b2), w2.size(0),
+                             ptr(w3.contiguous()), ptr(g3), ptr(b3), float(eps), {"none": 0, "relu": 1, "gelu": 2}[act], n,
+                             ptr(out), c, stream_ptr()), "fsf_sir_input")
     return out
 
 

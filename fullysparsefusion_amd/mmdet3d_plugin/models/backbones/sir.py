@@ -51,13 +51,16 @@ class SIR(nn.Module):
         cluster_feat_list = []
         out_coors = None
         for i, block in enumerate(self.block_list):
-            in_feats = torch.cat([points, out_feats], 1)
+            # block(torch.cat([points, out_feats], 1), coors, f_cluster, ...); SIRLayer folds the concat into its input kernel
+            run = getattr(block, "forward_parts", None)
+            if run is None:
+                run = lambda p, f, *a, _b=block, **k: _b(torch.cat([p, f], 1), *a, **k)  # noqa: E731
             if i < self.num_blocks - 1:
-                out_feats, out_cluster_feats = block(in_feats, coors, f_cluster, unq_inv_once=unq_inv,
-                                                     new_coors_once=new_coors)
+                out_feats, out_cluster_feats = run(points, out_feats, coors, f_cluster, unq_inv_once=unq_inv,
+                                                   new_coors_once=new_coors)
             else:
-                out_feats, out_cluster_feats, out_coors = block(in_feats, coors, f_cluster, return_both=True,
-                                                                unq_inv_once=unq_inv, new_coors_once=new_coors)
+                out_feats, out_cluster_feats, out_coors = run(points, out_feats, coors, f_cluster, return_both=True,
+                                                              unq_inv_once=unq_inv, new_coors_once=new_coors)
             cluster_feat_list.append(out_cluster_feats)
         final_cluster_feats = torch.cat(cluster_feat_list, dim=1)
         return out_feats, final_cluster_feats, out_coors

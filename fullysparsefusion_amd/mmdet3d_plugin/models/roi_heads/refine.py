@@ -89,15 +89,16 @@ class FullySparseBboxHead(nn.Module):
                               dim=-1)
         cluster_feat_list = []
         for i, block in enumerate(self.block_list):
-            in_feats = torch.cat([pts_xyz, out_feats], 1)
-            if self.geo_input:
-                in_feats = torch.cat([in_feats, f_cluster / 10], 1)
+            # in_feats = cat([pts_xyz, out_feats(, f_cluster / 10)], 1) (:127-132), folded into the block's input kernel
+            geo = dict(extra=f_cluster, extra_div=10.0) if self.geo_input else {}
             if i < self.num_blocks - 1:
-                out_feats, out_cluster_feats = block(in_feats, coors, f_cluster, unq_inv_once=unq_inv, new_coors_once=new_coors)
+                out_feats, out_cluster_feats = block.forward_parts(pts_xyz, out_feats, coors, f_cluster, unq_inv_once=unq_inv,
+                                                                   new_coors_once=new_coors, **geo)
                 if self.use_middle_cluster_feature:
                     cluster_feat_list.append(out_cluster_feats)
             else:
-                out_cluster_feats, out_coors = block(in_feats, coors, f_cluster, unq_inv_once=unq_inv, new_coors_once=new_coors)
+                out_cluster_feats, out_coors = block.forward_parts(pts_xyz, out_feats, coors, f_cluster, unq_inv_once=unq_inv,
+                                                                   new_coors_once=new_coors, **geo)
                 cluster_feat_list.append(out_cluster_feats)
         final_cluster_feats = torch.cat(cluster_feat_list, dim=1)
         out_coors = out_coors.squeeze(1)

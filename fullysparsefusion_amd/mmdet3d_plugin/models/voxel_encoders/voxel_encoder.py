@@ -145,12 +145,54 @@ class SIRLayer(nn.Module):
         if with_rel_mlp:
             self.rel_mlp = build_mlp(rel_mlp_in_channel, list(rel_mlp_hidden_dims) + [in_channels], norm_cfg, act=act)
 
+    def _fused_input_layers(self):
+        """The position MLP as three (Linear weight, LN weight, LN bias) triples if it has the shape K21 fuses."""
+        from ...ops.sst_ops import MLPBlock
+
+        if not self._with_rel_mlp or len(self.rel_mlp) != 3:
+            return None
+        layers, eps, act = [], None, None
+        for blk in self.rel_mlp:
+            if not isinstance(blk, MLPBlock) or len(blk) != 3:
+                return None
+            lin, norm, a = blk[0], blk[1], blk[2]
+            code = "relu" if isinstance(a, nn.ReLU) else "gelu" if isinstance(a, nn.GELU) and getattr(a, "approximate", "none") == "none" else None
+            if lin.bias is not None or not isinstance(norm, nn.LayerNorm) or code is None or (act or code) != code or \
+                    (eps or norm.eps) != norm.eps:
+                return None
+            eps, act = norm.eps, code
+            layers.append((lin.weight, norm.weight, norm.bias))
+        if layers[0][0].size(1) > 16 or layers[0][0].size(0) > 16 or layers[1][0].size(0) > 32 or layers[2][0].size(0) > 256:
+            return None
+        return layers, eps, act
+
+    def forward_parts(self, points, feats, coors, f_cluster, extra=None, extra_div=1.0, **kwargs):
+        """`forward(cat([points, feats(, extra / extra_div)], 1), coors, f_cluster, ...)` — what SIR.forward and the refine
+        head feed a block.  Inference: concat, xyz normalisation, position MLP and the product are ONE kernel (K21)."""
+        fused = None
+        needs_grad = torch.is_grad_enabled() and (feats.requires_grad or points.requires_grad or
+                                                  any(p.requires_grad for p in self.parameters()))
+        if not needs_grad and feats.is_cuda and feats.dtype == torch.float32 and feats.size(0) > 0:
+            fused = self._fused_input_layers()
+        if fused is None:
+            parts = [points, feats] + ([extra / extra_div] if extra is not None else [])
+            return self.forward(torch.cat(parts, 1), coors, f_cluster, **kwargs)
+        from .... import hip_ops
+
+        layers, eps, act = fused
+        features = hip_ops.sir_input(points, feats, f_cluster, self.xyz_normalizer, (*layers, eps), act, self.rel_dist_scaler,
+                                     extra=extra, extra_div=extra_div)
+        return self._run_vfe(features, coors, **kwargs)
+
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None, return_both=False,
                 unq_inv_once=None, new_coors_once=None):
         xyz_normalizer = torch.tensor(self.xyz_normalizer, device=features.device, dtype=features.dtype)
         features = torch.cat([features[:, :3] / xyz_normalizer[None, :], features[:, 3:]], dim=1)
         if self._with_rel_mlp:
             features = features * self.rel_mlp(f_cluster / self.rel_dist_scaler)
+        return self._run_vfe(features, coors, return_both=return_both, unq_inv_once=unq_inv_once, new_coors_once=new_coors_once)
+
+    def _run_vfe(self, features, coors, return_both=False, unq_inv_once=None, new_coors_once=None):
         voxel_feats_list = []
         for i, vfe in enumerate(self.vfe_layers):
             last = i == len(self.vfe_layers) - 1

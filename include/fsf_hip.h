@@ -260,6 +260,26 @@ int fsf_connected_components(const float* points, int64_t n, int32_t point_strid
                              int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K21  SIR-layer input: out = cat(points / xyz_normalizer (first 3 cols), feats, extra / extra_div) * rel_mlp(f_cluster / rel_div)
+ *   (true fp32 divisions, as the reference's `/`)
+ * Replaces (inference): `in_feats = torch.cat([points, out_feats], 1)` of SIR.forward
+ *   (projects/mmdet3d_plugin/models/backbones/sir.py:72-74) / FullySparseBboxHead.forward
+ *   (models/roi_heads/bbox_heads/fsd_bbox_head.py:127-132), and inside SIRLayer / DynamicClusterVFE [UNVENDORED] the
+ *   xyz normalisation, the three Linear(no bias)->LayerNorm->act blocks of `rel_mlp` (build_mlp, ops/sst_ops.py:808-833)
+ *   and the `features * rel` product.
+ *   points f32 [n, >=p_cols] (row stride in floats), feats f32 [n, f_cols], extra f32 [n, e_cols] or NULL,
+ *   f_cluster f32 [n, r_cols]; w1 [h1, r_cols], w2 [h2, h1], w3 [c, h2] in torch Linear layout, g/b = LayerNorm weight /
+ *   bias of each block, one eps; act 0 none / 1 ReLU / 2 GELU(erf); out f32 [n, c], c = p_cols + f_cols + e_cols <= 256;
+ *   r_cols <= 16, h1 <= 16, h2 <= 32 (the FSF configs: 3|13 -> 16 -> 32 -> C).
+ */
+int fsf_sir_input(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3],
+                  const float* feats, int64_t feats_stride, int32_t f_cols, const float* extra, int64_t extra_stride,
+                  int32_t e_cols, float extra_div, const float* f_cluster, int64_t f_cluster_stride, int32_t r_cols,
+                  float rel_div, const float* w1, const float* g1, const float* b1, int32_t h1, const float* w2,
+                  const float* g2, const float* b2, int32_t h2, const float* w3, const float* g3, const float* b3, float eps,
+                  int32_t act, int64_t n, float* out, int64_t out_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K17  dynamic point pooling: (point, RoI) memberships of the enlarged rotated boxes + box-frame geometry
  * Replaces: TorchEx dynamic_point_pool_ext.forward(rois, pts, extra_wlh, max_inbox_point, out_pts_idx,
  *   out_roi_idx, out_pts_feats) [UNVENDORED], bound at projects/mmdet3d_plugin/ops/dynamic_point_pool_op.py:5,32 and

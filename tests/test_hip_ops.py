@@ -642,3 +642,39 @@ def test_nms_bev_multiclass_equals_per_class_calls(ops, device):
         assert int(num[k]) == want.numel()
         assert torch.equal(keep[k, : int(num[k])], want)
     assert int(num[3]) == 0
+
+
+# ------------------------------------------------------------------------------------------ K21 SIR-layer input
+@pytest.mark.parametrize("p,cf,ce,r,act", [(5, 175, 0, 3, "gelu"), (5, 128, 0, 3, "gelu"), (5, 163, 13, 13, "gelu"),
+                                           (4, 128, 0, 3, "gelu"), (5, 40, 0, 3, "relu"), (5, 251, 0, 3, "gelu")])
+def test_sir_input_vs_torch_composition(ops, device, p, cf, ce, r, act):
+    """cat -> xyz normalisation -> rel_mlp (3 x Linear/LayerNorm/act) -> product, against the same steps in torch fp64."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(p * 100 + cf)
+    n, c = 5003, p + cf + ce
+    big = torch.randn(n, p + 3, device=device)
+    points = big[:, :p]                      # a row-strided view, like points[:, :5] of the [N, 8] input
+    feats = torch.randn(n, cf, device=device)
+    fcl = torch.randn(n, r, device=device) * torch.tensor([3.0] + [0.5] * (r - 1), device=device)
+    fcl[:7] = 0.0                            # singleton clusters: f_cluster exactly zero
+    extra = fcl if ce else None
+    dims = [r, 16, 32, c]
+    layers = []
+    for i in range(3):
+        layers.append((torch.randn(dims[i + 1], dims[i], device=device) / dims[i] ** 0.5,
+                       torch.rand(dims[i + 1], device=device) + 0.5, torch.randn(dims[i + 1], device=device) * 0.1))
+    norm = [20.0, 20.0, 4.0]
+    out = ops.sir_input(points, feats, fcl, norm, (*layers, 1e-3), act, 10.0, extra=extra, extra_div=10.0)
+    d = lambda t: t.double()  # noqa: E731
+    x = torch.cat([d(points[:, :3]) / torch.tensor(norm, device=device, dtype=torch.float64), d(points[:, 3:]), d(feats)] +
+                  ([d(extra) / 10.0] if ce else []), 1)
+    h = d(fcl) / 10.0
+    for w, g, b in layers:
+        h = F.layer_norm(F.linear(h, d(w)), (w.size(0),), d(g), d(b), 1e-3)
+        h = F.gelu(h) if act == "gelu" else F.relu(h)
+    want = x * h
+    assert out.shape == (n, c)
+    err = (out.double() - want).abs().max().item()
+    assert err <= 2e-5 * max(1.0, want.abs().max().item()), err
+    assert torch.equal(out, ops.sir_input(points, feats, fcl, norm, (*layers, 1e-3), act, 10.0, extra=extra, extra_div=10.0))
