@@ -163,7 +163,9 @@ __global__ void __launch_bounds__(256) sir_input_kernel(SirInputArgs a) {
           x[rr][t] = v;
         }
       }
-      // last layer for the eight rows at once: one read of the weight column block feeds all of them
+      // last layer for the eight rows at once: one read of the weight column block feeds all of them.  (The kernel is
+      // VALU-bound — a wave64 VALU op occupies its SIMD for 4 cycles, ~300 of them per row — and pairing rows into
+      // v_pk_fma_f32 was measured 2x SLOWER on gfx950, so these stay scalar FMAs.)
       float y[RB][T];
 #pragma unroll
       for (int rr = 0; rr < RB; ++rr)
@@ -202,8 +204,8 @@ __global__ void __launch_bounds__(256) sir_input_kernel(SirInputArgs a) {
           for (int t = 0; t < T; ++t) {
             const int c = lane + 64 * t;
             float xv = x[rr][t];
-            if (c < 3) xv = __fdiv_rn(xv, a.norm[c]);  // true divisions, as the reference's `/`
-            else if (c >= a.p_cols + a.f_cols) xv = __fdiv_rn(xv, a.extra_div);
+            if (t == 0 && c < 3) xv = __fdiv_rn(xv, a.norm[c]);  // true divisions, as the reference's `/`
+            if (a.e_cols > 0 && c >= a.p_cols + a.f_cols) xv = __fdiv_rn(xv, a.extra_div);  // (wave-uniform guard first)
             if (c < a.c) orow[c] = xv * si_act((y[rr][t] - mean) * rstd * g3[t] + b3[t], a.act);
           }
         }

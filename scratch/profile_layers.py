@@ -17,7 +17,7 @@ def timed(feat, wt, nbr, **kw):
     rec.append((e0, e1, feat.shape[0], nbr.shape[0], wt.shape[2], wt.shape[1], int((nbr >= 0).sum()), (nbr >= 0).sum(0).tolist()))
     return out
 hip_ops.spconv_forward = timed
-out = bench.step(model, inp)
+out = bench.step(model, inp, hot_path_only=True)
 torch.cuda.synchronize()
 hip_ops.spconv_forward = orig
 print(f"{'i':>3} {'m_in':>7} {'m_out':>7} {'cin':>5} {'cout':>5} {'pairs':>9} {'p/out':>6} {'us':>8} {'TF/s':>7} {'tile_eff':>8}")
@@ -40,7 +40,7 @@ f1 = model.frustum_sir.forward
 def capg(points, features, coors, f_cluster=None):
     cap['nf'] = points.shape[0]; return f1(points, features, coors, f_cluster)
 model.frustum_sir.forward = capg
-bench.step(model, inp)
+bench.step(model, inp, hot_path_only=True)
 print('LiDAR SIR points', cap.get('n'), 'frustum SIR points', cap.get('nf'))
 import torch.nn.functional as F
 sc = seg['seg_logits'].softmax(1)
