@@ -366,13 +366,18 @@ class FSF(SingleStageFSD):
         return obj_centers, obj_coors, obj_result, obj_feats, preds_2d
 
     def decode_stage_bboxes(self, obj_centers, bz_coors, reg_preds):
-        """(:1085-1094) `reg_preds` is the per-TASK list of the head; upstream walks it with the sample index, which is
-        the same thing for the single-task heads and batch size 1 the test configs use — kept as is."""
+        """(:1085-1094) `reg_preds` is the per-TASK list of the head; upstream walks it with the SAMPLE index, which is the
+        same thing for the single-task heads at batch size 1 the test configs use (and raises for any larger batch).
+        Single-task heads decode every query in one go here — identical at batch size 1, and correct beyond it; a
+        multi-task list keeps upstream's walk."""
         decode_size = reg_preds[0].shape[-1] - 1
-        bboxes_tensor = reg_preds[0].new_zeros((bz_coors.shape[0], decode_size))
-        for bidx in range(len(reg_preds)):
-            bz_mask = bz_coors == bidx
-            bboxes_tensor[bz_mask] = self.bbox_coder.decode(reg_preds[bidx], obj_centers[bz_mask])
+        if len(reg_preds) == 1:
+            bboxes_tensor = self.bbox_coder.decode(reg_preds[0], obj_centers)
+        else:
+            bboxes_tensor = reg_preds[0].new_zeros((bz_coors.shape[0], decode_size))
+            for bidx in range(len(reg_preds)):
+                bz_mask = bz_coors == bidx
+                bboxes_tensor[bz_mask] = self.bbox_coder.decode(reg_preds[bidx], obj_centers[bz_mask])
         return torch.cat([bz_coors.unsqueeze(-1), bboxes_tensor], dim=-1)
 
     def query_feat_refine(self, points, pts_feat, batch_idx, input_bbox_rois, i_stage, point_infos, mask_anno, mask_data,

@@ -575,3 +575,22 @@ def test_av2_full_detector_end_to_end(plugin, device):
     boxes, scores, labels = res[0]["boxes_3d"].tensor, res[0]["scores_3d"], res[0]["labels_3d"]
     assert boxes.shape[1] == 7 and 0 < boxes.shape[0] <= 500 and torch.isfinite(boxes).all()
     assert (labels >= 0).all() and (labels < 26).all() and float(boxes[:, :2].abs().max()) > 60.0  # long-range boxes exist
+
+
+def test_simple_test_edge_cases(fsf_pair, frame1, device):
+    """Batch of two frames, a frame without any mask (no camera queries -> the fake frustum object of FSF.py:407-414) and a
+    tiny cloud all go through the complete simple_test."""
+    model, _ = fsf_pair
+    L = torch.from_numpy(frame1["lidar2img"]).to(device)
+    mask = torch.from_numpy(frame1["mask_data"]).to(device)
+    anno = torch.from_numpy(frame1["mask_anno"]).to(device)
+    pts = torch.from_numpy(frame1["points"]).to(device)
+    with torch.no_grad():
+        two = model.simple_test([pts, pts[:20000].contiguous()], [dict(lidar2img=L), dict(lidar2img=L)],
+                                torch.stack([mask, mask]), torch.stack([anno, anno]))
+        assert len(two) == 2 and all(r["boxes_3d"].tensor.shape[1] == 9 for r in two)
+        assert len(two[0]["boxes_3d"]) > 0
+        none = model.simple_test([pts], [dict(lidar2img=L)], torch.zeros_like(mask)[None], anno[None])
+        assert len(none) == 1 and torch.isfinite(none[0]["boxes_3d"].tensor).all()
+        tiny = model.simple_test([pts[:300].contiguous()], [dict(lidar2img=L)], mask[None], anno[None])
+        assert len(tiny) == 1 and torch.isfinite(tiny[0]["boxes_3d"].tensor).all()
