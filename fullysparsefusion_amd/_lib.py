@@ -77,8 +77,16 @@ def ptr(t):
     return c_p(t.data_ptr())
 
 
+def _raw_stream(device_index=None):
+    """hipStream_t of torch's current stream as an int.  `torch.cuda.current_stream()` builds a Stream object (~8 us, and
+    the wrappers need it ~300 times per frame); the raw getter is the same value without the object."""
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(device_index)
+
+
 def stream_ptr():
-    return c_p(torch.cuda.current_stream().cuda_stream)
+    return c_p(_raw_stream())
 
 
 _ws_cache = {}
@@ -87,8 +95,8 @@ _ws_cache = {}
 def workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream).  Stream-ordered reuse is safe because every C-ABI
     call enqueues all of its work on the current stream before returning."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream().cuda_stream)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, _raw_stream(index))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
