@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(256) ccl_init_kernel(int* parent, int64_t n) {
 // upper-triangular 256 x 256 tiles of the pair matrix
 __global__ void __launch_bounds__(256)
     ccl_pairs_kernel(const float* __restrict__ pts, int stride, const int32_t* __restrict__ batch, int64_t n, float dist,
-                     int* __restrict__ parent, int tiles) {
+                     int* __restrict__ parent, int tiles, const float* __restrict__ dist_table,
+                     const int2* __restrict__ tile_range) {
   __shared__ float sx[256], sy[256];
   __shared__ int sb[256];
   // linear block id -> (ti, tj) with tj >= ti
@@ -54,6 +55,10 @@ __global__ void __launch_bounds__(256)
     ++ti;
   }
   const int tj = ti + rem;
+  if (tile_range) {  // grouped form: two tiles whose group ranges do not meet have no pair to test
+    const int2 ri = tile_range[ti], rj = tile_range[tj];
+    if (ri.y < rj.x || rj.y < ri.x) return;
+  }
   const int64_t j0 = (int64_t)tj * 256;
   {
     const int64_t j = j0 + threadIdx.x;
@@ -66,6 +71,7 @@ __global__ void __launch_bounds__(256)
   if (i >= n) return;
   const float x = pts[i * stride + 0], y = pts[i * stride + 1];
   const int b = batch ? batch[i] : 0;
+  if (dist_table) dist = dist_table[b];
   const int jn = (int)((n - j0 < 256) ? (n - j0) : 256);
   for (int jj = 0; jj < jn; ++jj) {
     const int64_t j = j0 + jj;
@@ -75,6 +81,25 @@ __global__ void __launch_bounds__(256)
     const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
     if (d < dist) uf_union(parent, (int)i, (int)j);
   }
+}
+
+// (min, max) group id of every 256-point tile
+__global__ void __launch_bounds__(256) ccl_tile_range_kernel(const int32_t* __restrict__ group, int64_t n, int2* __restrict__ range) {
+  __shared__ int smin[4], smax[4];
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int lo = i < n ? group[i] : 0x7fffffff, hi = i < n ? group[i] : (int)0x80000000;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    smin[threadIdx.x >> 6] = lo;
+    smax[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    range[blockIdx.x] = make_int2(min(min(smin[0], smin[1]), min(smin[2], smin[3])), max(max(smax[0], smax[1]), max(smax[2], smax[3])));
 }
 
 __global__ void __launch_bounds__(256) ccl_flatten_kernel(int* parent, int64_t n) {
@@ -105,13 +130,12 @@ using namespace fsf;
 
 extern "C" int64_t fsf_connected_components_workspace_bytes(int64_t n) {
   const int64_t nn = n > 0 ? n : 1;
-  return fsf_align_up(nn * 4, 256) * 2 + fsf_align_up(scan_num_tiles(n) * 4, 256) + 256;
+  return fsf_align_up(nn * 4, 256) * 2 + fsf_align_up(scan_num_tiles(n) * 4, 256) + fsf_align_up((nn + 255) / 256 * 8, 256) + 256;
 }
 
-extern "C" int fsf_connected_components(const float* points, int64_t n, int32_t point_stride, const int32_t* batch_idx,
-                                        float dist, int32_t* labels, int64_t* num_components_dev, void* workspace,
-                                        int64_t workspace_bytes, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int ccl_run(const float* points, int64_t n, int32_t point_stride, const int32_t* batch_idx, float dist,
+                   const float* dist_table, int32_t* labels, int64_t* num_components_dev, void* workspace,
+                   int64_t workspace_bytes, hipStream_t stream) {
   if (n < 0 || point_stride < 2 || (n > 0 && (!points || !labels))) return FSF_ERR_INVALID_ARG;
   if (n >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
   if (n == 0) {
@@ -123,14 +147,16 @@ extern "C" int fsf_connected_components(const float* points, int64_t n, int32_t 
   int* parent = ar.take<int>(n);
   int* rank = ar.take<int>(n);
   uint32_t* tile_sums = ar.take<uint32_t>(scan_num_tiles(n));
+  const int64_t tiles = (n + 255) / 256;
+  int2* tile_range = dist_table ? ar.take<int2>(tiles) : nullptr;
   if (!ar.ok()) return FSF_ERR_WORKSPACE;
   const int grid = fsf_stream_grid(n, 256);
   hipLaunchKernelGGL(ccl_init_kernel, dim3(grid), dim3(256), 0, stream, parent, n);
-  const int64_t tiles = (n + 255) / 256;
   const int64_t blocks = tiles * (tiles + 1) / 2;
   if (blocks >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
+  if (tile_range) hipLaunchKernelGGL(ccl_tile_range_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, batch_idx, n, tile_range);
   hipLaunchKernelGGL(ccl_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, points, (int)point_stride, batch_idx,
-                     n, dist, parent, (int)tiles);
+                     n, dist, parent, (int)tiles, dist_table, (const int2*)tile_range);
   hipLaunchKernelGGL(ccl_flatten_kernel, dim3(grid), dim3(256), 0, stream, parent, n);
   RootIn rin{parent};
   RootOut rout{rank};
@@ -139,4 +165,20 @@ extern "C" int fsf_connected_components(const float* points, int64_t n, int32_t 
   hipLaunchKernelGGL(ccl_label_kernel, dim3(grid), dim3(256), 0, stream, parent, rank, n, labels);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
+}
+
+extern "C" int fsf_connected_components(const float* points, int64_t n, int32_t point_stride, const int32_t* batch_idx,
+                                        float dist, int32_t* labels, int64_t* num_components_dev, void* workspace,
+                                        int64_t workspace_bytes, void* stream_) {
+  return ccl_run(points, n, point_stride, batch_idx, dist, nullptr, labels, num_components_dev, workspace, workspace_bytes,
+                 (hipStream_t)stream_);
+}
+
+extern "C" int fsf_connected_components_grouped(const float* points, int64_t n, int32_t point_stride, const int32_t* group_idx,
+                                                const float* dist_table, int32_t num_groups, int32_t* labels,
+                                                int64_t* num_components_dev, void* workspace, int64_t workspace_bytes,
+                                                void* stream_) {
+  if (!group_idx || !dist_table || num_groups < 1) return FSF_ERR_INVALID_ARG;
+  return ccl_run(points, n, point_stride, group_idx, 0.0f, dist_table, labels, num_components_dev, workspace, workspace_bytes,
+                 (hipStream_t)stream_);
 }

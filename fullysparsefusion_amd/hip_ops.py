@@ -49,6 +49,7 @@ _ARGTYPES = {
     "fsf_nms_bev": [_P, c_i64, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_nms_bev_multiclass_workspace_bytes": [c_i64, c_i32],
     "fsf_nms_bev_multiclass": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_connected_components_grouped": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
 }
@@ -504,6 +505,24 @@ def connected_components(points: torch.Tensor, dist: float, batch_idx: Optional[
     ws = _lib.workspace(h.fsf_connected_components_workspace_bytes(n), points.device)
     check(h.fsf_connected_components(ptr(points), n, points.size(1), ptr(batch_idx), float(dist), ptr(labels), None,
                                      ptr(ws), ws.numel(), stream_ptr()), "fsf_connected_components")
+    return labels
+
+
+def connected_components_grouped(points: torch.Tensor, group_idx: torch.Tensor, dist_table: torch.Tensor):
+    """fsf_connected_components_grouped: per-group distance thresholds, no adjacency across groups; labels i32 [n]
+    numbered by first member over all points."""
+    require_cuda(points, group_idx, dist_table)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.size(1) >= 2
+    points = points.contiguous()
+    group_idx = group_idx.to(torch.int32).contiguous()
+    dist_table = dist_table.to(torch.float32).contiguous()
+    n = points.size(0)
+    labels = torch.empty((n,), dtype=torch.int32, device=points.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_connected_components_workspace_bytes(n), points.device)
+    check(h.fsf_connected_components_grouped(ptr(points), n, points.size(1), ptr(group_idx), ptr(dist_table), dist_table.numel(),
+                                             ptr(labels), None, ptr(ws), ws.numel(), stream_ptr()),
+          "fsf_connected_components_grouped")
     return labels
 
 

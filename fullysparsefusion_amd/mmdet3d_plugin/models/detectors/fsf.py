@@ -314,17 +314,22 @@ class FSF(SingleStageFSD):
         )
         if self.cfg.get("pre_voxelization_size", None) is not None:
             dict_to_sample = self.pre_voxelize(dict_to_sample)
-        sampled_out = self.sample(dict_to_sample, dict_to_sample["vote_offsets"])
-        cluster_inds_list, valid_mask_list = self.cluster_assigner(sampled_out["center_preds"], sampled_out["batch_idx"],
-                                                                   origin_points=sampled_out["seg_points"])
-        pts_cluster_inds = torch.cat(cluster_inds_list, dim=0)  # [N, 3] (cls_id, batch_idx, cluster_id)
-        sampled_out = self.update_sample_results_by_mask(sampled_out, valid_mask_list)
-        combined_out = self.combine_classes(sampled_out, ["seg_points", "seg_logits", "seg_vote_preds", "seg_feats",
-                                                          "center_preds"])
-        points = combined_out["seg_points"]
-        pts_feats = torch.cat([combined_out["seg_logits"], combined_out["seg_vote_preds"], combined_out["seg_feats"]], dim=1)
+        if not self.training and self.cfg.get("group_sample", False) and not self.test_cfg.get("add_gt_fg_points", False):
+            points, seg_logits, seg_vote_preds, seg_feats, center_preds, pts_cluster_inds = \
+                self.grouped_sample_and_cluster(dict_to_sample)
+            pts_feats = torch.cat([seg_logits, seg_vote_preds, seg_feats], dim=1)
+        else:
+            sampled_out = self.sample(dict_to_sample, dict_to_sample["vote_offsets"])
+            cluster_inds_list, valid_mask_list = self.cluster_assigner(sampled_out["center_preds"], sampled_out["batch_idx"],
+                                                                       origin_points=sampled_out["seg_points"])
+            pts_cluster_inds = torch.cat(cluster_inds_list, dim=0)  # [N, 3] (cls_id, batch_idx, cluster_id)
+            sampled_out = self.update_sample_results_by_mask(sampled_out, valid_mask_list)
+            combined_out = self.combine_classes(sampled_out, ["seg_points", "seg_logits", "seg_vote_preds", "seg_feats",
+                                                              "center_preds"])
+            points, center_preds = combined_out["seg_points"], combined_out["center_preds"]
+            pts_feats = torch.cat([combined_out["seg_logits"], combined_out["seg_vote_preds"], combined_out["seg_feats"]], dim=1)
         assert len(pts_cluster_inds) == len(points) == len(pts_feats)
-        extracted_outs = self.extract_feat(points, pts_feats, pts_cluster_inds, img_metas, combined_out["center_preds"])
+        extracted_outs = self.extract_feat(points, pts_feats, pts_cluster_inds, img_metas, center_preds)
         cluster_feats, cluster_xyz = extracted_outs["cluster_feats"], extracted_outs["cluster_xyz"]
         cluster_inds = extracted_outs["cluster_inds"]  # [class, batch, groups]
         outs = self.bbox_head(cluster_feats) if run_head else None

@@ -189,6 +189,75 @@ class SingleStageFSD(nn.Module):
                     sampled_out[k] = [data.index_select(0, idx) for data, idx in zip(old_data, valid_idx)]
         return sampled_out
 
+    @torch.no_grad()
+    def grouped_sample_and_cluster(self, d):
+        """Inference: `group_sample` (:802-865) + `ClusterAssigner.forward` (:903-982) + `update_sample_results_by_mask`
+        (:867-890) + `combine_classes` (:892-901) for ALL class groups at once.  Upstream (and `sample()` / the assigner
+        above, kept for training) walks the six groups one by one — per group a threshold mask, a compaction, a unique, a
+        second compaction, a scatter-mean and a connected-components call, each with its own host round trip; here the
+        group id rides along as the leading key column, so the whole stage is one compaction, two uniques, one
+        connected-components launch and one gather per field.  Rows come out group-major in ascending point order, i.e. in
+        the order `combine_classes` concatenates them.
+        Returns (points, seg_logits, seg_vote_preds, seg_feats, center_preds, pts_cluster_inds [N,3] = (group, batch, id))."""
+        cfg = self.test_cfg
+        ca = self.cluster_assigner  # (upstream pairs group i with class_names[i] to index its per-group tables, :912-916)
+        batch_idx = d["batch_idx"]
+        bsz = int(batch_idx.max().item()) + 1
+        seg_logits = d["seg_logits"]
+        nc = self.num_classes
+        dev = seg_logits.device
+        groups, class_names = cfg["group_names"], cfg["class_names"]
+        ng = len(groups)
+        member = torch.zeros((ng, nc), dtype=torch.bool)
+        for gi, g in enumerate(groups):
+            member[gi, [class_names.index(n) for n in g]] = True
+        member = member.to(dev)
+        scores = seg_logits.softmax(1)[:, :-1]
+        grouped_score = torch.stack([scores[:, member[gi]].sum(1) for gi in range(ng)], dim=1)  # the reference's sums
+        fg = grouped_score > torch.tensor(cfg["score_thresh"], device=dev, dtype=grouped_score.dtype)[None, :]
+        if bsz == 1:
+            fg[0] |= ~fg.any(0)  # "at least one point per sample" (:832-834)
+        else:
+            for gi in range(ng):
+                if len(torch.unique(batch_idx[fg[:, gi]])) < bsz:
+                    fg[self.get_sample_beg_position(batch_idx, fg[:, gi]), gi] = True
+        gp = fg.t().nonzero(as_tuple=False)                      # (group, point), group-major
+        g_ids, p_ids = gp[:, 0], gp[:, 1]
+        # vote centre: the offsets of the group's classes weighted by "is the group's arg-max class" (ties split evenly)
+        logit = seg_logits.index_select(0, p_ids)[:, :nc]
+        mem = member.index_select(0, g_ids)
+        masked = torch.where(mem, logit, logit.new_full((), float("-inf")))
+        w = ((masked - masked.max(1)[0][:, None]).abs() < 1e-6) & mem
+        w = w.float()
+        w = w / w.sum(1)[:, None]
+        offset = d["vote_offsets"].reshape(-1, nc + 1, 3).index_select(0, p_ids)[:, :nc, :]
+        centers = d["seg_points"][:, :3].index_select(0, p_ids) + (offset * w[:, :, None]).sum(dim=1)
+        # cluster voxels: torch.div(.., 'floor') keys (:948-950) with the group's voxel size; group folded into the batch column
+        vsize = torch.tensor([ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]], device=dev, dtype=centers.dtype)
+        rmin = torch.tensor(ca.point_cloud_range[:3], device=dev, dtype=centers.dtype)
+        vox = torch.div(centers - rmin[None, :], vsize.index_select(0, g_ids), rounding_mode="floor").long()
+        b_pts = batch_idx.index_select(0, p_ids).long()
+        keys = torch.cat([(g_ids * bsz + b_pts)[:, None], vox], dim=1)
+        _, inv, cnt = unique_with_plan(keys)
+        valid = cnt[inv] >= ca.min_points
+        has_valid = torch.zeros(ng, dtype=torch.int32, device=dev).index_add_(0, g_ids, valid.int()) > 0
+        valid |= ~has_valid.index_select(0, g_ids)             # a group without any dense voxel keeps all its points (:953-954)
+        v_idx = valid.nonzero(as_tuple=False).squeeze(1)
+        g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
+        centers = centers.index_select(0, v_idx)
+        vox_centers, vox_keys, vox_inv = scatter_v2(centers, keys.index_select(0, v_idx), mode="avg", return_inv=True)
+        vox_group = torch.div(vox_keys[:, 0], bsz, rounding_mode="floor")
+        dist = torch.tensor([ca._per_class(ca.connected_dist, n) for n in ca.class_names[:ng]], device=dev, dtype=torch.float32)
+        # test-time clustering ignores the sample index inside a group (:69-82); components never span groups
+        labels = hip_ops.connected_components_grouped(vox_centers, vox_group, dist).long()
+        first = torch.searchsorted(vox_group, torch.arange(ng, device=dev))            # voxels are group-sorted
+        base = labels[first.clamp(max=labels.numel() - 1)]                              # a group's labels start at its first voxel's
+        cluster = (labels - base.index_select(0, vox_group)).index_select(0, vox_inv)
+        pts_cluster_inds = torch.stack([g_ids, b_pts, cluster], 1)
+        take = lambda t: t.index_select(0, p_ids)  # noqa: E731
+        return (take(d["seg_points"]), take(seg_logits), take(d["seg_vote_preds"]), take(d["seg_feats"]), centers,
+                pts_cluster_inds)
+
     def combine_classes(self, data_dict, name_list):
         return {name: torch.cat(data_dict[name], 0) for name in data_dict if name in name_list}
 

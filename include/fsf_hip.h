@@ -258,6 +258,13 @@ int64_t fsf_connected_components_workspace_bytes(int64_t n);
 int fsf_connected_components(const float* points, int64_t n, int32_t point_stride, const int32_t* batch_idx,
                              float dist, int32_t* labels, int64_t* num_components_dev, void* workspace,
                              int64_t workspace_bytes, void* stream);
+/* All class groups of ClusterAssigner.forward (single_stage_fsd.py:912-934 loops over the classes, each with its own
+ * `connected_dist`) in one call: group_idx i32 [n] (points of different groups are never adjacent), dist_table f32
+ * [num_groups] (device).  Labels are numbered by first member over ALL points; with group-sorted input the labels of
+ * a group form a contiguous range starting at the label of its first point. */
+int fsf_connected_components_grouped(const float* points, int64_t n, int32_t point_stride, const int32_t* group_idx,
+                                     const float* dist_table, int32_t num_groups, int32_t* labels,
+                                     int64_t* num_components_dev, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K21  SIR-layer input: out = cat(points / xyz_normalizer (first 3 cols), feats, extra / extra_div) * rel_mlp(f_cluster / rel_div)
