@@ -47,11 +47,10 @@ for _n in ("ABSPointBBoxCoder",):
     BBOX_CODERS.register_module(_n, module=_plain_placeholder(_n, "core/bbox/coders"))
 for _n in ("HybridAssigner", "FrustumAssigner", "PointInBoxAssigner", "DistAssigner", "MaxIoUAssigner"):
     BBOX_ASSIGNERS.register_module(_n, module=_plain_placeholder(_n, "core/bbox/assigners"))
-for _n in ("LoadMaskFromFiles", "SaveNoAugPoints", "NormalizePoints", "MyLoadPointsFromFile", "MyLoadPointsFromMultiSweeps",
-           "LoadAnnotations3D", "ObjectSample", "GlobalRotScaleTrans", "RandomFlip3D", "PointsRangeFilter",
-           "ObjectRangeFilter", "ObjectNameFilter", "PointShuffle", "DefaultFormatBundle3D", "Collect3D",
-           "MultiScaleFlipAug3D", "MyMultiScaleFlipAug3D", "LoadPointsFromFile", "LoadPointsFromMultiSweeps",
-           "MyObjectSample", "MyObjectRangeFilter", "MyGlobalRotScaleTrans", "MyRandomFlip3D", "MyPointsRangeFilter", "MyPointShuffle"):
+for _n in ("MyLoadPointsFromMultiSweeps",
+           "LoadAnnotations3D", "ObjectSample",
+           "ObjectRangeFilter", "ObjectNameFilter", "PointShuffle",
+           "MyObjectSample", "MyObjectRangeFilter", "MyGlobalRotScaleTrans", "MyRandomFlip3D", "MyPointShuffle"):
     PIPELINES.register_module(_n, module=_plain_placeholder(_n, "datasets/pipelines"))
 for _n in ("NuScenesDataset", "CBGSDataset", "Argo2Dataset", "My_Resample_Dataset", "RepeatDataset"):
     DATASETS.register_module(_n, module=_plain_placeholder(_n, "datasets"))

@@ -451,6 +451,124 @@ def gen_refine_glue(rng):
         gb_boxes=ob.tensor.numpy(), gb_scores=os_.numpy(), gb_labels=ol.numpy())
 
 
+def gen_input_pipeline(rng):
+    """Input side by the reference's own pipeline classes, lifted from
+    projects/mmdet3d_plugin/datasets/pipelines/loading.py: LoadMaskFromFiles.load_nusc / reorg_anno_multi_cls /
+    reorg_anno_single_cls / pad_tensor (:213-339), MyLoadPointsFromFile.__call__ (:660-700),
+    MyLoadPointsFromMultiSweeps.__call__ / _remove_close (:781-877), SaveNoAugPoints (:341-354), NormalizePoints
+    (:537-563).  cv2.imread(path, -1) is served by PIL; mmcv.FileClient raises ConnectionError so the np.fromfile branch
+    runs.  Stores the synthetic files' CONTENTS and the classes' outputs."""
+    import json
+    import tempfile
+    from PIL import Image
+
+    path = os.path.join(PLUGIN, "datasets/pipelines/loading.py")
+
+    class Pts:  # stand-in for mmdet3d BasePoints / LiDARPoints as far as these methods use it
+        def __init__(self, tensor, points_dim=None, attribute_dims=None):
+            self.tensor = torch.as_tensor(np.ascontiguousarray(tensor), dtype=torch.float32).reshape(-1, points_dim or np.shape(tensor)[-1]).clone()
+
+        def new_point(self, data):
+            return Pts(data, self.tensor.shape[1])
+
+        @classmethod
+        def cat(cls, lst):
+            return cls(torch.cat([p.tensor for p in lst], 0))
+
+        def __getitem__(self, item):
+            return Pts(self.tensor[item])
+
+    class FileClient:
+        def __init__(self, **kw):
+            pass
+
+        def get(self, name):
+            raise ConnectionError
+
+    cv2 = types.SimpleNamespace(imread=lambda p, flag: np.array(Image.open(p)))
+    mmcv = types.SimpleNamespace(FileClient=FileClient, check_file_exist=lambda p: None)
+    g = {"torch": torch, "np": np, "os": os, "json": json, "cv2": cv2, "mmcv": mmcv, "BasePoints": Pts,
+         "get_points_type": lambda coord: Pts}
+    mask_fns = lift_methods(path, "LoadMaskFromFiles", ["load_nusc", "reorg_anno_multi_cls", "reorg_anno_single_cls", "pad_tensor"], g)
+    file_fns = lift_methods(path, "MyLoadPointsFromFile", ["__call__", "_load_points"], g)
+    sweep_fns = lift_methods(path, "MyLoadPointsFromMultiSweeps", ["__call__", "_load_points", "_remove_close"], g)
+    save_fns = lift_methods(path, "SaveNoAugPoints", ["__call__"], g)
+    norm_fns = lift_methods(path, "NormalizePoints", ["__call__"], g)
+
+    classes = ["car", "truck", "trailer", "bus", "construction_vehicle", "bicycle", "motorcycle", "pedestrian", "traffic_cone",
+               "barrier"]
+    H, W = 45, 80
+    planes = np.zeros((6, 10, H, W), dtype=np.uint8)
+    anno = [dict() for _ in range(6)]
+    ids = rng.permutation(np.arange(1, 41))  # obj ids NOT in camera order: reorg sorts by id
+    for n, oid in enumerate(ids):
+        cam, cls = int(rng.integers(6)), int(rng.integers(10))
+        x1, y1 = int(rng.integers(0, W - 12)), int(rng.integers(0, H - 8))
+        w, h = int(rng.integers(3, 12)), int(rng.integers(3, 8))
+        planes[cam, cls, y1:y1 + h, x1:x1 + w] = oid
+        anno[cam].setdefault(classes[cls], []).append(dict(bbox=[float(x1), float(y1), float(x1 + w), float(y1 + h)],
+                                                           score=float(rng.uniform(0.1, 1)), category=cls, cam_id=cam,
+                                                           obj_id=int(oid)))
+    key = np.stack([rng.uniform(-60, 60, 3000), rng.uniform(-60, 60, 3000), rng.uniform(-6, 4, 3000), rng.uniform(0, 255, 3000),
+                    rng.integers(0, 32, 3000)], 1).astype(np.float32)
+    key[:50, :2] = rng.uniform(-0.9, 0.9, (50, 2))  # points the close filter has to drop
+    sweeps, sweep_meta = [], []
+    for k in range(3):
+        sw = key + rng.normal(0, 0.3, key.shape).astype(np.float32)
+        ang = 0.02 * (k + 1)
+        rot = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]])
+        sweeps.append(sw.astype(np.float32))
+        sweep_meta.append(dict(timestamp=1.5e15 - 5e4 * (k + 1), sensor2lidar_rotation=rot.tolist(),
+                               sensor2lidar_translation=[0.4 * (k + 1), -0.1 * k, 0.02]))
+    with tempfile.TemporaryDirectory() as tmp:
+        sdir = os.path.join(tmp, "masks", "sample0")
+        os.makedirs(sdir)
+        for cam in range(6):
+            for ci, name in enumerate(classes):
+                Image.fromarray(planes[cam, ci]).save(os.path.join(sdir, f"{cam}_{name}.png"))
+        json.dump(anno, open(os.path.join(sdir, "anno.json"), "w"))
+        key.tofile(os.path.join(tmp, "key.bin"))
+        for k, sw in enumerate(sweeps):
+            sw.tofile(os.path.join(tmp, f"sweep{k}.bin"))
+            sweep_meta[k]["data_path"] = os.path.join(tmp, f"sweep{k}.bin")
+        m_ns = types.SimpleNamespace(data_path=os.path.join(tmp, "masks"), obj_max_num=250, class_names=classes)
+        for n in ("reorg_anno_multi_cls", "reorg_anno_single_cls", "pad_tensor"):
+            setattr(m_ns, n, types.MethodType(mask_fns[n], m_ns))
+        res = mask_fns["load_nusc"](m_ns, dict(sample_idx="sample0"))
+        f_ns = types.SimpleNamespace(load_dim=5, use_dim=[0, 1, 2, 3, 4], coord_type="LIDAR", shift_height=False, use_color=False,
+                                     virtual_path=None, file_client=None, file_client_args={})
+        f_ns._load_points = types.MethodType(file_fns["_load_points"], f_ns)
+        r = file_fns["__call__"](f_ns, dict(pts_filename=os.path.join(tmp, "key.bin")))
+        loaded = r["points"].tensor.clone()
+        s_ns = types.SimpleNamespace(load_dim=5, sweeps_num=9, use_dim=[0, 1, 2, 3, 4], pad_empty_sweeps=True, remove_close=True,
+                                     test_mode=True, virtual_path=None, file_client=None, file_client_args={})
+        s_ns._load_points = types.MethodType(sweep_fns["_load_points"], s_ns)
+        s_ns._remove_close = types.MethodType(sweep_fns["_remove_close"], s_ns)
+        as_np = [dict(m, sensor2lidar_rotation=np.array(m["sensor2lidar_rotation"]),
+                      sensor2lidar_translation=np.array(m["sensor2lidar_translation"])) for m in sweep_meta]
+        r.update(timestamp=1.5e9, sweeps=as_np)
+        r = sweep_fns["__call__"](s_ns, r)
+        multi = r["points"].tensor.clone()
+        r_pad = file_fns["__call__"](f_ns, dict(pts_filename=os.path.join(tmp, "key.bin")))
+        r_pad.update(timestamp=1.5e9, sweeps=[])
+        s_ns.sweeps_num = 2
+        padded = sweep_fns["__call__"](s_ns, r_pad)["points"].tensor.clone()
+        r = save_fns["__call__"](types.SimpleNamespace(), r)
+        saved = r["points"].tensor.clone()
+        r = norm_fns["__call__"](types.SimpleNamespace(dims=[3], std=[255], mean=[0]), r)
+        normed = r["points"].tensor.clone()
+    single = mask_fns["reorg_anno_single_cls"](m_ns, [[dict(bbox=[1.0, 2.0, 3.0, 4.0], score=0.5, category=3, cam_id=0, obj_id=7)], [],
+                                                      [dict(bbox=[5.0, 6.0, 7.0, 8.0], score=0.25, category=1, cam_id=2, obj_id=2)]])
+    for m in sweep_meta:
+        m.pop("data_path")
+    np.savez_compressed(
+        os.path.join(OUT, "input_pipeline.npz"),
+        planes=planes, anno_json=np.frombuffer(json.dumps(anno).encode(), dtype=np.uint8), key=key, sweeps=np.stack(sweeps),
+        sweep_meta_json=np.frombuffer(json.dumps(sweep_meta).encode(), dtype=np.uint8),
+        mask_data=res["mask_data"].numpy(), mask_anno=res["mask_anno"].numpy(), loaded=loaded.numpy(), multi=multi.numpy(),
+        padded=padded.numpy(), saved=saved.numpy(), normed=normed.numpy(), single_anno=single.numpy())
+
+
 def main():
     assert os.path.isdir(REF), "the reference tree is only available in the build container"
     install_stubs()
@@ -469,6 +587,7 @@ def main():
     gen_divfloor(rng)
     gen_sir_flow(sst, rng)
     gen_refine_glue(np.random.default_rng(777))
+    gen_input_pipeline(np.random.default_rng(4242))
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

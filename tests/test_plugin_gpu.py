@@ -594,3 +594,51 @@ def test_simple_test_edge_cases(fsf_pair, frame1, device):
         assert len(none) == 1 and torch.isfinite(none[0]["boxes_3d"].tensor).all()
         tiny = model.simple_test([pts[:300].contiguous()], [dict(lidar2img=L)], mask[None], anno[None])
         assert len(tiny) == 1 and torch.isfinite(tiny[0]["boxes_3d"].tensor).all()
+
+
+def test_files_to_boxes_through_the_input_pipeline(fsf_pair, frame1, device, tmp_path):
+    """On-disk formats -> test pipeline -> one host->device copy -> FSF.simple_test: the same boxes as feeding the
+    tensors directly (the pipeline's range filter / intensity scaling applied to both)."""
+    import json
+
+    from PIL import Image
+
+    from fullysparsefusion_amd.mmdet3d_plugin import datasets as D
+
+    model, _ = fsf_pair
+    classes = model.class_names
+    pts5 = frame1["points"][:, :5].copy()
+    pts5[:, 3] *= 255.0                       # stored intensity is 0..255; NormalizePoints divides it back
+    pts5.tofile(tmp_path / "key.bin")
+    sdir = tmp_path / "masks" / "s0"
+    sdir.mkdir(parents=True)
+    for cam in range(6):
+        for ci, name in enumerate(classes):
+            Image.fromarray(frame1["mask_data"][cam, ci]).save(sdir / f"{cam}_{name}.png")
+    anno = [dict() for _ in range(6)]
+    for row in frame1["mask_anno"]:
+        cam, cls = int(row[6]), int(row[5])
+        anno[cam].setdefault(classes[cls], []).append(dict(bbox=[float(v) for v in row[:4]], score=float(row[4]), category=cls,
+                                                           cam_id=cam, obj_id=int(row[7])))
+    (sdir / "anno.json").write_text(json.dumps(anno))
+    pipeline = D.Compose([
+        dict(type="LoadPointsFromFile", coord_type="LIDAR", load_dim=5, use_dim=[0, 1, 2, 3, 4]),
+        dict(type="LoadPointsFromMultiSweeps", sweeps_num=9, use_dim=[0, 1, 2, 3, 4], pad_empty_sweeps=False, remove_close=True),
+        dict(type="SaveNoAugPoints"),
+        dict(type="LoadMaskFromFiles", data_path=str(tmp_path / "masks"), class_names=classes),
+        dict(type="MultiScaleFlipAug3D", img_scale=(1333, 800), pts_scale_ratio=1, flip=False, transforms=[
+            dict(type="PointsRangeFilter", point_cloud_range=[-51.2, -51.2, -5, 51.2, 51.2, 3]),
+            dict(type="NormalizePoints"),
+            dict(type="DefaultFormatBundle3D", class_names=classes, with_label=False),
+            dict(type="Collect3D", keys=["points", "mask_data", "mask_anno"])])])
+    data = pipeline(dict(pts_filename=str(tmp_path / "key.bin"), timestamp=0.0, sweeps=[], sample_idx="s0",
+                         lidar2img=list(frame1["lidar2img"])))
+    points, metas, mask, anno_t = D.frame_to_device(data, device)
+    assert mask.dtype == torch.uint8 and mask.is_cuda and points[0].shape[1] == 8
+    np.testing.assert_array_equal(mask[0].cpu().numpy(), frame1["mask_data"])
+    np.testing.assert_allclose(anno_t[0].cpu().numpy(), frame1["mask_anno"], rtol=1e-6)
+    with torch.no_grad():
+        res = model.simple_test(points, metas, mask, anno_t)
+        direct_pts = points[0].clone()
+        ref = model.simple_test([direct_pts], [dict(lidar2img=torch.from_numpy(frame1["lidar2img"]).to(device))], mask, anno_t)
+    assert torch.equal(res[0]["boxes_3d"].tensor, ref[0]["boxes_3d"].tensor) and len(res[0]["boxes_3d"]) > 0
