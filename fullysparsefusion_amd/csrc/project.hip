@@ -144,3 +144,59 @@ extern "C" int fsf_cam_select_score(const int64_t* obj_id, int64_t n, int32_t nc
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// The k largest ids of every row, descending — `obj_id_tensor[mask].topk(k, dim=-1)[0]` of FSF.double_overlap_pts
+// (projects/mmdet3d_plugin/models/detectors/FSF.py:284-286): rows are the 60 (camera, class) slots of a point, at most
+// a handful non-zero.  ATen's generic radix top-k spends ~0.2 ms per call on this shape; a team of 16 lanes per row with
+// a k-step "take the max, knock it out" loop is one coalesced read of the row.
+namespace fsf {
+__global__ void __launch_bounds__(256) row_topk_kernel(const int64_t* __restrict__ x, int64_t n, int w, int k,
+                                                       int64_t* __restrict__ out) {
+  const int tl = threadIdx.x & 15;
+  for (int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); row < n; row += (int64_t)gridDim.x * 16) {
+    constexpr int PER = 8;  // w <= 128
+    int64_t v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int c = tl + 16 * j;
+      v[j] = c < w ? x[row * w + c] : INT64_MIN;
+    }
+    for (int t = 0; t < k; ++t) {
+      int64_t best = INT64_MIN;
+      int where = 0;
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        if (v[j] > best) {
+          best = v[j];
+          where = tl + 16 * j;  // column of this lane's candidate
+        }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {  // team arg-max; ties -> the lower column (torch.topk's value order is unaffected)
+        const int64_t ob = __shfl_xor(best, o, 16);
+        const int ow = __shfl_xor(where, o, 16);
+        if (ob > best || (ob == best && ow < where)) {
+          best = ob;
+          where = ow;
+        }
+      }
+      if (tl == 0) out[row * k + t] = best;
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        if (tl + 16 * j == where) v[j] = INT64_MIN;
+    }
+  }
+}
+}  // namespace fsf
+
+extern "C" int fsf_row_topk_desc(const int64_t* x, int64_t n, int32_t w, int32_t k, int64_t* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || w < 1 || k < 1 || k > w || (n > 0 && (!x || !out))) return FSF_ERR_INVALID_ARG;
+  if (w > 128) return FSF_ERR_UNSUPPORTED;
+  if (n == 0) return FSF_OK;
+  int64_t g = (n + 15) / 16;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(fsf::row_topk_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, n, (int)w, (int)k, out);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}

@@ -22,6 +22,8 @@
 //
 // Roofline: flops = 2*P*Cin*Cout on the fp32 MFMA (157.3 TF/s peak),
 // bytes = P*(Cin+Cout)*4 + kvol*Cin*Cout*4 + 8P.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace fsf {
@@ -505,7 +507,11 @@ static int pick_ksplit(int64_t tiles, int cout_blocks, int kvol) {
   // round trip (2 * z * m_out * cout * 4 B) folded by spconv_reduce_kernel.
   const int64_t blocks = tiles * cout_blocks;
   if (kvol < 3) return 1;
-  constexpr int64_t kTarget = 2048;  // >= 4 rounds
+  static const int64_t kTarget = [] {  // >= 4 rounds by default; FSF_KSPLIT_TARGET overrides it for tuning runs
+    const char* e = getenv("FSF_KSPLIT_TARGET");
+    const int64_t v = e ? atoll(e) : 0;
+    return v > 0 ? v : (int64_t)2048;
+  }();
   if (blocks >= kTarget) return 1;
   int64_t g = (kTarget + blocks - 1) / blocks;
   if (g > 9) g = 9;

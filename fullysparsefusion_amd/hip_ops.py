@@ -40,6 +40,7 @@ _ARGTYPES = {
     "fsf_spconv_backward_weight": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_connected_components_workspace_bytes": [c_i64],
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
+    "fsf_row_topk_desc": [_P, c_i64, c_i32, c_i32, _P, _P],
     "fsf_sir_input": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
                       _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
     "fsf_dynamic_point_pool_workspace_bytes": [c_i64, c_i64],
@@ -400,6 +401,17 @@ def ingroup_rank(group_inds: torch.Tensor):
     h = _L()
     ws = _lib.workspace(h.fsf_ingroup_rank_workspace_bytes(n), g.device)
     check(h.fsf_ingroup_rank(ptr(g), n, ptr(out), ptr(ws), ws.numel(), stream_ptr()), "fsf_ingroup_rank")
+    return out
+
+
+def row_topk_desc(x: torch.Tensor, k: int):
+    """fsf_row_topk_desc: x i64 [n, w<=128] -> the k largest values of each row, descending, i64 [n, k]."""
+    require_cuda(x)
+    assert x.dtype == torch.int64 and x.dim() == 2
+    x = x.contiguous()
+    n, w = x.shape
+    out = torch.empty((n, k), dtype=torch.int64, device=x.device)
+    check(_L().fsf_row_topk_desc(ptr(x), n, w, int(k), ptr(out), stream_ptr()), "fsf_row_topk_desc")
     return out
 
 

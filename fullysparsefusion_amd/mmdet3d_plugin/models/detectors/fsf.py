@@ -142,7 +142,11 @@ class FSF(SingleStageFSD):
             bzs.append(src_bz[overlaps_mask].repeat(overlap_num - 1, 1))
             pts.append(src_pts[overlaps_mask].repeat(overlap_num - 1, 1))
             ws.append(src_w[overlaps_mask].repeat(overlap_num - 1))
-            sort_value = obj_id_tensor[overlaps_mask].topk(overlap_num, dim=-1)[0]
+            rows = obj_id_tensor[overlaps_mask]
+            if rows.is_cuda and rows.dtype == torch.int64 and rows.size(1) <= 128:
+                sort_value = hip_ops.row_topk_desc(rows, overlap_num)
+            else:
+                sort_value = rows.topk(overlap_num, dim=-1)[0]
             for pad_idx in range(1, overlap_num):
                 ids.append(sort_value[:, pad_idx])
         return torch.cat(feats, 0), torch.cat(bzs, 0), torch.cat(pts, 0), torch.cat(ids, 0), torch.cat(ws, 0)

@@ -178,6 +178,10 @@ int fsf_cam_select_score(const int64_t* obj_id, int64_t n, int32_t ncam, int32_t
                          int32_t num_anno, int32_t anno_dim, int32_t score_col, int64_t* out_ids, float* out_score,
                          void* stream);
 
+/* The k largest values of every row, descending: `obj_id_tensor[overlaps_mask].topk(overlap_num, dim=-1)[0]` of
+ * FSF.double_overlap_pts (models/detectors/FSF.py:284-286).  x i64 [n, w] (w <= 128), out i64 [n, k]. */
+int fsf_row_topk_desc(const int64_t* x, int64_t n, int32_t w, int32_t k, int64_t* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K7/K8  sparse-conv rulebooks (hash table instead of spconv v1's dense grid)
  * Replaces: mmdet3d.ops.spconv get_indice_pairs [UNVENDORED spconv v1 indice_cuda.cu] used inside

@@ -678,3 +678,14 @@ def test_sir_input_vs_torch_composition(ops, device, p, cf, ce, r, act):
     err = (out.double() - want).abs().max().item()
     assert err <= 2e-5 * max(1.0, want.abs().max().item()), err
     assert torch.equal(out, ops.sir_input(points, feats, fcl, norm, (*layers, 1e-3), act, 10.0, extra=extra, extra_div=10.0))
+
+
+@pytest.mark.parametrize("n,w,k", [(20000, 60, 2), (3000, 60, 4), (17, 7, 7), (1, 128, 5)])
+def test_row_topk_desc_equals_torch_topk(ops, device, n, w, k):
+    torch.manual_seed(n + w)
+    x = torch.zeros((n, w), dtype=torch.int64, device=device)
+    sel = torch.rand(n, w, device=device) < 0.08
+    x[sel] = torch.randint(1, 251, (int(sel.sum()),), device=device)
+    x[0, :] = 5  # ties
+    got = ops.row_topk_desc(x, k)
+    assert torch.equal(got, x.topk(k, dim=-1)[0])
