@@ -266,19 +266,36 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_long_kernel(SegArgs a) {
         arg[q] = INT32_MAX;
       }
       // virtual partial index p in [0, ce-cs]: p = 0 is the head piece (slot 1 of chunk cs), p > 0 slot 0 of cs+p
-      for (int p = team_id; act && p <= ce - cs; p += nteams) {
-        const int64_t slot = ((int64_t)(cs + p) * 2 + (p == 0 ? 1 : 0)) * a.c + ch;
-        Vec<VEC> v = load_vec<VEC>(a.part_val + slot);
+      // four partials are requested before the first is folded (same fold order as one by one, 4x the loads in
+      // flight: a 30 k-point camera frustum is ~940 partials for its one workgroup)
+      constexpr int UNR = 4;
+      for (int p0 = team_id; act && p0 <= ce - cs; p0 += nteams * UNR) {
+        Vec<VEC> v[UNR];
+        int32_t va[UNR][VEC];
+        bool live[UNR];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-          if constexpr (MODE == MODE_MAX) {
-            const int32_t va = a.argmax ? a.part_arg[slot + q] : 0;
-            if (v.v[q] > acc.v[q] || (v.v[q] == acc.v[q] && va < arg[q])) {
-              acc.v[q] = v.v[q];
-              arg[q] = va;
+        for (int u = 0; u < UNR; ++u) {
+          const int p = p0 + u * nteams;
+          live[u] = p <= ce - cs;
+          const int pc = live[u] ? p : p0;
+          const int64_t slot = ((int64_t)(cs + pc) * 2 + (pc == 0 ? 1 : 0)) * a.c + ch;
+          v[u] = load_vec<VEC>(a.part_val + slot);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) va[u][q] = (MODE == MODE_MAX && a.argmax) ? a.part_arg[slot + q] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (!live[u]) continue;
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) {
+            if constexpr (MODE == MODE_MAX) {
+              if (v[u].v[q] > acc.v[q] || (v[u].v[q] == acc.v[q] && va[u][q] < arg[q])) {
+                acc.v[q] = v[u].v[q];
+                arg[q] = va[u][q];
+              }
+            } else {
+              acc.v[q] = __fadd_rn(acc.v[q], v[u].v[q]);
             }
-          } else {
-            acc.v[q] = __fadd_rn(acc.v[q], v.v[q]);
           }
         }
       }
