@@ -81,38 +81,87 @@ __device__ __forceinline__ int pool_test(const PoolBox& k, float x, float y, flo
 
 template <bool FILL>
 __global__ void __launch_bounds__(256) pool_pass_kernel(PoolArgs a) {
-  __shared__ float4 sp[PP_TILE];  // x, y, z, batch index (exact in fp32)
+  __shared__ float4 sp[PP_TILE];       // x, y, z, batch index (exact in fp32) of the tile's points that can matter
+  __shared__ uint16_t sj[PP_TILE];     // their position in the tile
+  __shared__ float sred[4][4];
+  __shared__ int swave[4];
+  __shared__ int s_ns;
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (FILL) {
     // rows past the global cap are never written: when the whole RoI tile starts beyond it there is nothing to do
     // (with max_all_pts = 50000 and thousands of queries that is nearly every tile)
     const int64_t r_first = (int64_t)blockIdx.x * 256;
     if ((int64_t)a.roi_off[r_first] >= a.max_all) return;
   }
+  // This workgroup's 256 RoIs.  Queries arrive cluster by cluster in voxel order, so consecutive RoIs are close in
+  // space: the bounding box of their (enlarged) circles is small, and only the tile's points inside it are kept —
+  // an order-preserving compaction, so ranks and output order are unchanged.  Unsorted RoIs just keep every point.
+  const bool has_roi = r < a.n_rois;
+  PoolBox k = load_box(a, has_roi ? r : a.n_rois - 1);
+  const float rad = sqrtf(k.r2);
+  float bx0 = k.cx - rad, bx1 = k.cx + rad, by0 = k.cy - rad, by1 = k.cy + rad;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    bx0 = fminf(bx0, __shfl_xor(bx0, o));
+    bx1 = fmaxf(bx1, __shfl_xor(bx1, o));
+    by0 = fminf(by0, __shfl_xor(by0, o));
+    by1 = fmaxf(by1, __shfl_xor(by1, o));
+  }
+  if (lane == 0) {
+    sred[wave][0] = bx0;
+    sred[wave][1] = bx1;
+    sred[wave][2] = by0;
+    sred[wave][3] = by1;
+  }
+  if (threadIdx.x == 0) s_ns = 0;
+  __syncthreads();
+  bx0 = fminf(fminf(sred[0][0], sred[1][0]), fminf(sred[2][0], sred[3][0]));
+  bx1 = fmaxf(fmaxf(sred[0][1], sred[1][1]), fmaxf(sred[2][1], sred[3][1]));
+  by0 = fminf(fminf(sred[0][2], sred[1][2]), fminf(sred[2][2], sred[3][2]));
+  by1 = fmaxf(fmaxf(sred[0][3], sred[1][3]), fmaxf(sred[2][3], sred[3][3]));
   const int64_t p0 = (int64_t)blockIdx.y * PP_TILE;
   const int tile_n = (int)min((int64_t)PP_TILE, a.n_pts - p0);
-  for (int j = threadIdx.x; j < tile_n; j += 256) {
-    const float* p = a.pts + (p0 + j) * a.pts_stride;
-    sp[j] = make_float4(p[0], p[1], p[2], a.pts_batch ? (float)a.pts_batch[p0 + j] : 0.0f);
+  for (int j0 = 0; j0 < tile_n; j0 += 256) {  // 256 points per round, appended in index order
+    const int j = j0 + threadIdx.x;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool keep = false;
+    if (j < tile_n) {
+      const float* p = a.pts + (p0 + j) * a.pts_stride;
+      q = make_float4(p[0], p[1], p[2], a.pts_batch ? (float)a.pts_batch[p0 + j] : 0.0f);
+      keep = (q.x >= bx0) & (q.x <= bx1) & (q.y >= by0) & (q.y <= by1);
+    }
+    const uint64_t bal = __ballot(keep);
+    if (lane == 0) swave[wave] = __popcll(bal);
+    __syncthreads();
+    int base = s_ns;
+    for (int w = 0; w < wave; ++w) base += swave[w];
+    if (keep) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      sp[pos] = q;
+      sj[pos] = (uint16_t)j;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_ns += swave[0] + swave[1] + swave[2] + swave[3];
+    __syncthreads();
   }
-  __syncthreads();
-  if (r >= a.n_rois) return;
-  const PoolBox k = load_box(a, r);
+  const int ns = s_ns;
+  if (!has_roi) return;
   const float kbatch = (float)k.batch;
   uint32_t* my_cnt = a.cnt + (int64_t)blockIdx.y * a.n_rois + r;
   uint32_t rank = FILL ? *my_cnt : 0u;  // after the prefix pass: in-box points of this RoI in earlier tiles
   const uint32_t base = FILL ? a.roi_off[r] : 0u;
   if (FILL && (rank >= (uint32_t)a.max_inbox || (int64_t)base + rank >= a.max_all)) return;  // caps already reached
 #pragma unroll 4
-  for (int j = 0; j < tile_n; ++j) {
-    const float4 q = sp[j];
+  for (int i = 0; i < ns; ++i) {
+    const float4 q = sp[i];
     float lx, ly, lz;
     const int flag = (q.w == kbatch) ? pool_test(k, q.x, q.y, q.z, lx, ly, lz) : 0;
     if (flag) {
       if (FILL) {
         const int64_t slot = (int64_t)base + rank;
         if (rank < (uint32_t)a.max_inbox && slot < a.max_all) {
-          a.out_pts[slot] = p0 + j;
+          a.out_pts[slot] = p0 + sj[i];
           a.out_roi[slot] = r;
           float* f = a.out_feat + slot * PP_FEAT;
           f[0] = q.x;
