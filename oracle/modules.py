@@ -78,6 +78,7 @@ class _SpT:
 
 
 _TRAIN = [False]  # unet_forward(train=True): batch statistics in the norms, autograd through the conv weights
+_GRAD = [False]   # keep the conv weights attached to the autograd graph (eval-mode norms): gradient parity tests
 
 
 def _bn_eval(bn, x):
@@ -89,7 +90,7 @@ def _bn_eval(bn, x):
 def _conv(conv, x):
     """spconv v1 SubMConv3d / SparseConv3d / SparseInverseConv3d with indice_key caching."""
     key = conv.indice_key
-    w = conv.weight if _TRAIN[0] else conv.weight.detach()
+    w = conv.weight if (_TRAIN[0] or _GRAD[0]) else conv.weight.detach()
     if conv.inverse:
         out_idx, pairs, in_idx, in_shape = x.rb[key]
         feat = osp.indice_conv(x.features, w, pairs, in_idx.shape[0], inverse=True)
@@ -125,13 +126,14 @@ def _basic_block(blk, x):
     return out
 
 
-def unet_forward(unet, voxel_feats, voxel_coors, batch_size, train=False):
-    """Published SST `SimpleSparseUNet.forward` (called at single_stage_fsd.py:234); eval mode unless `train`."""
-    _TRAIN[0] = bool(train)
+def unet_forward(unet, voxel_feats, voxel_coors, batch_size, train=False, grad=False):
+    """Published SST `SimpleSparseUNet.forward` (called at single_stage_fsd.py:234); eval mode unless `train`; `grad`
+    keeps the conv weights in the autograd graph."""
+    _TRAIN[0], _GRAD[0] = bool(train), bool(grad)
     try:
         return _unet_forward(unet, voxel_feats, voxel_coors, batch_size)
     finally:
-        _TRAIN[0] = False
+        _TRAIN[0] = _GRAD[0] = False
 
 
 def _unet_forward(unet, voxel_feats, voxel_coors, batch_size):
@@ -162,34 +164,34 @@ def neck_forward(neck, points, pts_coors, voxel_feats, inv, padding=-1):
     pts_feats, pts_coors, points = pts_feats[mask], pts_coors[mask], points[mask]
     vs = torch.tensor(neck.voxel_size, dtype=torch.float32).reshape(1, 3)
     mn = torch.tensor(neck.point_cloud_range[:3], dtype=torch.float32).reshape(1, 3)
-    centers = (pts_coors[:, [3, 2, 1]].float() + 0.5) * vs + mn
+    centers = ((pts_coors[:, [3, 2, 1]].float() + 0.5) * vs + mn).to(points.dtype)
     return torch.cat([pts_feats, points[:, :3] - centers], 1), mask
 
 
 # ----------------------------------------------------------------------------------------- VoteSegmentor
-def segmentor_extract_feat(seg, points_list):
+def segmentor_extract_feat(seg, points_list, grad=False, dtype=torch.float32):
     """VoteSegmentor.extract_feat (single_stage_fsd.py:228-245)."""
     from . import voxelize as ovox
 
-    pts, coors = ovox.voxelize_batch([p.numpy() for p in points_list], seg.voxel_size, seg.point_cloud_range)
-    pts, coors = torch.from_numpy(pts), torch.from_numpy(coors)
+    pts, coors = ovox.voxelize_batch([p.float().numpy() for p in points_list], seg.voxel_size, seg.point_cloud_range)
+    pts, coors = torch.from_numpy(pts).to(dtype), torch.from_numpy(coors)
     voxel_feats, voxel_coors, inv = vfe_forward(seg.voxel_encoder, pts, coors)
-    unet_out = unet_forward(seg.backbone, voxel_feats, voxel_coors, len(points_list))
+    unet_out = unet_forward(seg.backbone, voxel_feats, voxel_coors, len(points_list), grad=grad)
     out, mask = neck_forward(seg.decode_neck, pts, coors, unet_out, inv)
     return dict(neck=out, mask=mask, coors=coors, points=pts, voxel_feats=voxel_feats, voxel_coors=voxel_coors, inv=inv,
                 unet=unet_out)
 
 
 # --------------------------------------------------------------------------------------------------- FSF
-def fsf_stage1(fsf, points8, mask_data, mask_anno, lidar2img):
+def fsf_stage1(fsf, points8, mask_data, mask_anno, lidar2img, grad=False, dtype=torch.float32):
     """FSF.simple_test step 1 (FSF.py:1123-1130): segmentor features + image branch + seg head, one sample."""
     points = [points8[:, :-3]]
     infos = points8[:, -3:]
-    ex = segmentor_extract_feat(fsf.segmentor, points)
+    ex = segmentor_extract_feat(fsf.segmentor, points, grad=grad, dtype=dtype)
     assert bool(ex["mask"].all())
     obj_id, _ = oproj.points_in_mask(infos.numpy(), mask_data.numpy(), lidar2img.numpy())
     ids, score = oproj.cam_select_score(obj_id, mask_anno.numpy())
-    img_feat = fsf.segmentor_updated_mlp(torch.from_numpy(score))
+    img_feat = fsf.segmentor_updated_mlp(torch.from_numpy(score).to(dtype))
     pts_feats = ex["neck"] + img_feat
     head = fsf.segmentor.segmentation_head
     h = head.pre_seg_conv(pts_feats)
