@@ -74,14 +74,15 @@ __global__ void __launch_bounds__(256, 2) spconv_bwd_weight_kernel(SpconvBwdArgs
   const int split = blockIdx.x;
   const int a0 = (blockIdx.z / a.tiles_b) * TA;
   const int b0 = (blockIdx.z % a.tiles_b) * TB;
-  const int n = a.num[k];
+  const int n = a.num ? a.num[k] : (int)a.cap;  // no pair lists: the identity pairing of a dense layer (kvol = 1)
   const int p_begin = split * a.range;
   if (p_begin >= n) return;  // uniform; the fold kernel only reads live splits
   const int p_end = min(n, p_begin + a.range);
   const int nstages = (p_end - p_begin + BW_RT - 1) / BW_RT;
 
-  const int32_t* pin = a.pairs + (int64_t)k * 2 * a.cap;
-  const int32_t* pout = pin + a.cap;
+  const bool ident = a.pairs == nullptr;
+  const int32_t* pin = ident ? nullptr : a.pairs + (int64_t)k * 2 * a.cap;
+  const int32_t* pout = ident ? nullptr : pin + a.cap;
 
   // wave tile: 64 x 64 channels; waves that share (wa, wb) split the k-steps of each stage
   const int wt = wave / KS, ks = wave % KS;
@@ -103,9 +104,15 @@ __global__ void __launch_bounds__(256, 2) spconv_bwd_weight_kernel(SpconvBwdArgs
   auto load_indices = [&](int stage) {
     const int p0 = p_begin + stage * BW_RT;
 #pragma unroll
-    for (int i = 0; i < LA::PER_WAVE; ++i) ia[i] = pin[min(p0 + (wave + 4 * i) * LA::RPI + ra, p_end - 1)];
+    for (int i = 0; i < LA::PER_WAVE; ++i) {
+      const int p = min(p0 + (wave + 4 * i) * LA::RPI + ra, p_end - 1);
+      ia[i] = ident ? p : pin[p];
+    }
 #pragma unroll
-    for (int i = 0; i < LB::PER_WAVE; ++i) ib[i] = pout[min(p0 + (wave + 4 * i) * LB::RPI + rb, p_end - 1)];
+    for (int i = 0; i < LB::PER_WAVE; ++i) {
+      const int p = min(p0 + (wave + 4 * i) * LB::RPI + rb, p_end - 1);
+      ib[i] = ident ? p : pout[p];
+    }
   };
   auto issue_stage = [&](int stage) {
     float* As = S + (stage & 1) * SM::STAGE_FLOATS;
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(256) spconv_bwd_fold_kernel(SpconvBwdArgs a) {
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int k = (int)(t / per_k);
     const int64_t e = t - (int64_t)k * per_k;
-    const int n = a.num[k];
+    const int n = a.num ? a.num[k] : (int)a.cap;
     const int live = (n + a.range - 1) / a.range;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.nsplit > 1) {
@@ -227,7 +234,9 @@ static void bwd_plan(int64_t cap, int cin, int cout, int kvol, int* ta, int* tb,
   const int64_t tiles = (int64_t)fsf_cdiv(cin, *ta) * fsf_cdiv(cout, *tb);
   // enough workgroups to keep 512 resident slots busy despite the uneven pair counts per offset, but at least 8 stages
   // each so the accumulator write-out stays small next to the MFMA work
-  int64_t s = fsf_cdiv(3072, kvol * tiles);
+  // (a dense layer, kvol = 1, has one evenly divisible pair list: fewer, longer ranges keep the fold pass — which reads
+  // nsplit x cin x cout floats — negligible)
+  int64_t s = fsf_cdiv(kvol >= 8 ? 3072 : 1024, kvol * tiles);
   const int64_t max_s = fsf_cdiv(cap, 8 * BW_RT);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -252,8 +261,10 @@ extern "C" int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32
                                           int32_t kvol, float* grad_weight, void* workspace, int64_t workspace_bytes,
                                           void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (m_in < 0 || m_out < 0 || cin < 1 || cout < 1 || kvol < 1 || cap < 0 || !grad_weight || !indice_num ||
-      (cap > 0 && (!indice_pairs || !feat || !grad_out)))
+  const bool identity = indice_pairs == nullptr && indice_num == nullptr;  // dense layer: pair p = (row p, row p), kvol 1
+  if (m_in < 0 || m_out < 0 || cin < 1 || cout < 1 || kvol < 1 || cap < 0 || !grad_weight ||
+      (!identity && (!indice_num || (cap > 0 && !indice_pairs))) || (identity && (kvol != 1 || cap > m_in || cap > m_out)) ||
+      (cap > 0 && (!feat || !grad_out)))
     return FSF_ERR_INVALID_ARG;
   if ((cin % 4) != 0 || (cout % 4) != 0 || cap >= ((int64_t)1 << 31)) return FSF_ERR_UNSUPPORTED;
   int ta, tb, nsplit, range;

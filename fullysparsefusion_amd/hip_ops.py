@@ -371,6 +371,20 @@ def spconv_forward(feat: torch.Tensor, weight_t: torch.Tensor, nbr: torch.Tensor
     return out
 
 
+def linear_backward_weight(x: torch.Tensor, grad_out: torch.Tensor):
+    """X^T dY through fsf_spconv_backward_weight's identity pairing: x f32 [n,cin], grad_out f32 [n,cout] -> f32 [cin,cout]."""
+    require_cuda(x, grad_out)
+    x, grad_out = x.contiguous(), grad_out.contiguous()
+    n, cin = x.shape
+    cout = grad_out.size(1)
+    gw = torch.empty((1, cin, cout), dtype=torch.float32, device=x.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_spconv_backward_weight_workspace_bytes(n, cin, cout, 1), x.device)
+    check(h.fsf_spconv_backward_weight(ptr(x), n, cin, ptr(grad_out), n, cout, None, None, n, 1, ptr(gw), ptr(ws), ws.numel(),
+                                       stream_ptr()), "fsf_spconv_backward_weight")
+    return gw[0]
+
+
 def spconv_backward_weight(feat: torch.Tensor, grad_out: torch.Tensor, pairs: torch.Tensor, num: torch.Tensor):
     """fsf_spconv_backward_weight: feat f32 [m_in,cin], grad_out f32 [m_out,cout], (pairs, num) from
     rulebook_to_pairs -> grad_weight f32 [kvol,cin,cout]."""

@@ -240,6 +240,9 @@ int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float
  * Weight gradient: grad_weight[k,ci,co] = sum_p feat[in_k[p],ci] * grad_out[out_k[p],co] over the pair lists
  *   of fsf_rulebook_to_pairs (indice_pairs i32 [kvol,2,cap], indice_num i32 [kvol], both on the device).
  *   cin % 4 == 0, cout % 4 == 0.  fp32 MFMA, partial sums folded in a fixed order (deterministic).
+ *   indice_pairs = indice_num = NULL with kvol = 1: the identity pairing of the first `cap` rows, i.e. X^T dY — the weight
+ *   gradient of a per-point Linear layer (build_mlp, ops/sst_ops.py:808-833), a [<=256 x 128] result reduced over 5e5
+ *   rows, the shape GEMM libraries serve worst.
  */
 int64_t fsf_spconv_backward_weight_workspace_bytes(int64_t cap, int32_t cin, int32_t cout, int32_t kvol);
 int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32_t cin, const float* grad_out, int64_t m_out,

@@ -689,3 +689,16 @@ def test_row_topk_desc_equals_torch_topk(ops, device, n, w, k):
     x[0, :] = 5  # ties
     got = ops.row_topk_desc(x, k)
     assert torch.equal(got, x.topk(k, dim=-1)[0])
+
+
+@pytest.mark.parametrize("n,cin,cout", [(50000, 180, 128), (20001, 136, 128), (70000, 256, 128), (33, 64, 64)])
+def test_linear_weight_gradient_through_identity_pairs(ops, device, n, cin, cout):
+    """X^T dY via K10's identity pairing == the autograd weight gradient of nn.Linear (float64 yardstick)."""
+    torch.manual_seed(n)
+    x = torch.randn(n, cin, device=device)
+    g = torch.randn(n, cout, device=device)
+    got = ops.linear_backward_weight(x, g)
+    want = x.double().t() @ g.double()
+    assert got.shape == (cin, cout)
+    assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) * max(1.0, (n / 1e4) ** 0.5)
+    assert torch.equal(got, ops.linear_backward_weight(x, g))
