@@ -5,7 +5,7 @@ generation and losses (train-time, host-side label assignment) are out of scope 
 import torch
 from torch import nn
 
-from ...ops.sst_ops import build_mlp
+from ...ops.sst_ops import PointLinear, build_mlp
 from ...registry import HEADS
 
 
@@ -32,8 +32,8 @@ class VoteSegHead(nn.Module):
         if not self.use_sigmoid:
             self.num_classes += 1
         self.logit_scale = logit_scale
-        self.conv_seg = nn.Linear(end_channel, self.num_classes)
-        self.voting = nn.Linear(end_channel, self.num_classes * 3)
+        self.conv_seg = PointLinear(end_channel, self.num_classes)
+        self.voting = PointLinear(end_channel, self.num_classes * 3)
         self.checkpointing = checkpointing
         self.init_bias = init_bias
         self.train_cfg = self.test_cfg = None

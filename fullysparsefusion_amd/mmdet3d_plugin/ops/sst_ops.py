@@ -210,7 +210,14 @@ def point_linear(linear, x):
     if (torch.is_grad_enabled() and linear.weight.requires_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
             and x.size(0) >= 16384 and linear.in_features >= 32 and linear.out_features % 4 == 0):
         return _PointLinearFn.apply(x, linear.weight, linear.bias)
-    return linear(x)
+    return F.linear(x, linear.weight, linear.bias)
+
+
+class PointLinear(nn.Linear):
+    """nn.Linear (same parameters, same state-dict keys) whose training-time weight gradient takes the K10 route."""
+
+    def forward(self, x):
+        return point_linear(self, x)
 
 
 class MLPBlock(nn.Sequential):
@@ -232,9 +239,9 @@ def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act="relu", bias
     last = in_channel
     for i, c in enumerate(hidden_dims):
         if is_head and i == len(hidden_dims) - 1:
-            layers.append(nn.Linear(last, c, bias=True))
+            layers.append(PointLinear(last, c, bias=True))
         else:
-            block = [nn.Linear(last, c, bias=bias), build_norm_layer(norm_cfg, c)[1], get_activation_layer(act, c)]
+            block = [PointLinear(last, c, bias=bias), build_norm_layer(norm_cfg, c)[1], get_activation_layer(act, c)]
             if dropout > 0:
                 block.append(nn.Dropout(dropout))
             layers.append(MLPBlock(*block))
