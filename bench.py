@@ -46,17 +46,20 @@ def parse():
                     help="time the training step instead (BASELINE configs 3/4): fwd + bwd of a dummy scalar loss over the "
                          "hot-path outputs + bucketed gradient all-reduce over RCCL + AdamW")
     ap.add_argument("--frames-per-gpu", type=int, default=1, help="batch size per rank (config 4 uses 2)")
+    ap.add_argument("--dataset", choices=["nuscenes", "av2"], default="nuscenes",
+                    help="nuscenes = BASELINE config 3 input (the headline); av2 = config 5 shape (+-204.8 m, 2048^2 x 32 grid, 7 cams, "
+                         "int32 id planes, 26 classes)")
     ap.add_argument("--hot-path-only", action="store_true",
                     help="time stages 1-3 only (segmentor + fusion, camera queries, LiDAR queries), no heads / refine / NMS")
     return ap.parse_args()
 
 
-def build_model(device):
+def build_model(device, dataset="nuscenes"):
     from fullysparsefusion_amd import mmdet3d_plugin as plugin
     from fullysparsefusion_amd.compat import Config
 
     torch.manual_seed(0)
-    cfg = Config.fromfile(os.path.join(ROOT, "configs", "fsf_nuscenes.py"))
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "fsf_nuscenes.py" if dataset == "nuscenes" else "fsf_av2.py"))
     model = plugin.build_model(cfg.model).eval()
     # random-init weights of the reference architecture (no checkpoint on the box); un-zero the image branch's last
     # layer (zero-init upstream, FSF.py:142-143) so the fusion arithmetic is not trivially zero
@@ -64,10 +67,13 @@ def build_model(device):
     return model.to(device)
 
 
-def make_inputs(sweeps, seed, device, frames=1):
+def make_inputs(sweeps, seed, device, frames=1, dataset="nuscenes"):
     from fullysparsefusion_amd import synthetic
 
-    fs = [synthetic.make_frame(num_sweeps=sweeps, seed=seed * 97 + i) for i in range(frames)]
+    if dataset == "av2":
+        fs = [synthetic.make_frame_av2(seed=seed * 97 + i) for i in range(frames)]
+    else:
+        fs = [synthetic.make_frame(num_sweeps=sweeps, seed=seed * 97 + i) for i in range(frames)]
     dev = dict(
         points=[torch.from_numpy(f["points"]).to(device) for f in fs],
         mask_data=torch.stack([torch.from_numpy(f["mask_data"]) for f in fs]).to(device),
@@ -218,9 +224,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # RCCL; barrier + max-reduce of the timing only
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    model = build_model(device)
-    model_cpu = None if args.no_cpu_baseline or rank != 0 or world != 1 or args.train else copy.deepcopy(model).cpu()
-    frame, inp = make_inputs(args.sweeps, seed=rank, device=device, frames=args.frames_per_gpu)
+    model = build_model(device, args.dataset)
+    model_cpu = (None if args.no_cpu_baseline or rank != 0 or world != 1 or args.train or args.dataset != "nuscenes"
+                 else copy.deepcopy(model).cpu())
+    frame, inp = make_inputs(args.sweeps, seed=rank, device=device, frames=args.frames_per_gpu, dataset=args.dataset)
     if args.train:
         train_step = TrainStep(model)
         run = lambda: train_step(inp)
@@ -250,8 +257,10 @@ def main():
     if rank == 0:
         n_pts = int(inp["points"][0].shape[0])
         result = {
-            "metric": ("frames/sec fwd+bwd+allreduce+AdamW nuScenes 10-sweep FSF (dummy loss)" if args.train
-                       else "frames/sec fwd nuScenes 10-sweep FSF" + (" (query-generation stages only)" if args.hot_path_only else "")),
+            "metric": (("frames/sec fwd+bwd+allreduce+AdamW nuScenes 10-sweep FSF (dummy loss)" if args.train
+                        else "frames/sec fwd nuScenes 10-sweep FSF" + (" (query-generation stages only)" if args.hot_path_only else ""))
+                       if args.dataset == "nuscenes" else
+                       "frames/sec " + ("fwd+bwd+allreduce+AdamW" if args.train else "fwd") + " Argoverse-2-shape FSF"),
             "value": round(world * args.frames_per_gpu * args.steps / elapsed, 3),
             "unit": "frames/s",
             "n_gpus": world,
@@ -264,15 +273,16 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": (f"fsf_nuscenes_{args.sweeps}sweep_" + (
+                "workload": ((f"fsf_nuscenes_{args.sweeps}sweep_" if args.dataset == "nuscenes" else "fsf_av2_long_range_") + (
                     "train_step: fwd of the query-generation stages + bwd of a dummy scalar loss + gradient all-reduce + AdamW"
                     if args.train else "hot_path_fwd: stages 1-3 of FSF.simple_test only" if args.hot_path_only else
                     "simple_test: full forward = segmentor + image fusion, camera queries, LiDAR queries, heads, query "
                     "refinement (RoI point pooling + SIR), box decode + rotated BEV NMS, results to host") +
-                    " (BASELINE config 3 input, random-init weights of the reference architecture)"),
+                    (" (BASELINE config 3 input" if args.dataset == "nuscenes" else " (BASELINE config 5 shape") +
+                    ", random-init weights of the reference architecture)"),
                 "points_per_frame": n_pts,
                 "frames_per_gpu_per_step": args.frames_per_gpu,
-                "mask_data": "u8[1,6,10,900,1600]",
+                "mask_data": "u8[1,6,10,900,1600]" if args.dataset == "nuscenes" else "i32[1,7,1,1550,2048]",
                 **describe_output(model, inp, out, args),
                 "parallelism": (f"dp{world}: frame-level data parallel, bucketed gradient all-reduce over RCCL" if args.train
                                 else f"replicas x{world} (frames independent, no data-path collective)"),
@@ -280,6 +290,8 @@ def main():
         }
     if rank == 0 and not args.no_roofline and not args.train:
         result["roofline"] = spconv_roofline(model, inp, min(args.steps, 5), args.hot_path_only)
+        if args.dataset != "nuscenes":  # the committed PMC passes were taken on the nuScenes-shape workload
+            result["roofline"].update(traffic=None, traffic_source=None)
         if not args.hot_path_only:  # where the frame time goes: the three query-generation stages vs the rest
             n = min(args.steps, 5)
             torch.cuda.synchronize()

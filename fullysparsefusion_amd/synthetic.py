@@ -102,3 +102,22 @@ def make_frame(num_sweeps=10, seed=0):
     pts = make_points(num_sweeps, seed)
     mask, anno = make_mask_data(rng)
     return dict(points=pts, mask_data=mask, mask_anno=anno, lidar2img=make_lidar2img())
+
+
+def make_frame_av2(seed=0, n_points=150000):
+    """One synthetic frame of BASELINE.json config 5 (Argoverse 2 shape): ~1.5e5 4-d points out to 200 m (two 32-beam
+    rings, dense near the sensor like a real long-range sweep), 7 ring cameras with ONE int32 instance-id plane each
+    (1550 x 2048, ids beyond 255), 26 classes; points f32 [N, 7] = x y z intensity | no-aug xyz."""
+    rng = np.random.default_rng(seed + 5000)
+    r = np.minimum(rng.exponential(35.0, n_points) + 2.0, 200.0)
+    a = rng.uniform(-math.pi, math.pi, n_points)
+    z = np.clip(rng.normal(-1.4, 0.35, n_points) + 0.004 * r * rng.normal(0, 1, n_points), -3.1, 3.1)
+    wall = rng.random(n_points) < 0.25                      # a quarter of the returns come from vertical structure
+    z = np.where(wall, rng.uniform(-1.5, 3.0, n_points), z)
+    xyz = np.stack([r * np.cos(a), r * np.sin(a), z], 1)
+    xyz = xyz[(np.abs(xyz[:, 0]) < 204.7) & (np.abs(xyz[:, 1]) < 204.7)]
+    pts = np.concatenate([xyz, rng.random((xyz.shape[0], 1)), xyz], 1).astype(np.float32)
+    mask, anno = make_mask_data(rng, 7, 1, 1550, 2048, 400, dtype=np.int32)
+    anno[:, 5] = rng.integers(0, 26, anno.shape[0])
+    return dict(points=np.ascontiguousarray(pts), mask_data=mask, mask_anno=anno,
+                lidar2img=make_lidar2img(7, fx=1780.0, cx=1024.0, cy=775.0))
