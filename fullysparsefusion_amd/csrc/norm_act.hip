@@ -94,6 +94,142 @@ static int launch_norm_act(const float* x, int64_t n, int c, const float* gamma,
   return FSF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward of y = act(LayerNorm(x)) in one pass over (x, grad_out): the row statistics and the pre-activation are
+// recomputed from x in registers (nothing but x is kept from the forward), d(act) is applied, the two row means of the
+// LayerNorm gradient are team reductions, grad_x is written once.  grad_gamma / grad_beta are column sums over all
+// rows: every lane owns fixed channels, accumulates them over the rows its team walks, teams of a workgroup are folded
+// through LDS in team order, workgroups write partials that a second kernel folds in workgroup order (deterministic).
+// Replaces, in training, ATen's layer_norm_backward (2 kernels + a column reduction) and the separate GELU backward.
+__device__ __forceinline__ float dgelu_erf(float y) {
+  const float cdf = 0.5f * (1.0f + erff(y * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * y * y);
+  return cdf + y * pdf;
+}
+
+template <int TEAM, int ACT>
+__global__ void __launch_bounds__(256)
+    norm_act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout, int64_t n, int c,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ gx,
+                        float* __restrict__ part /* [gridDim.x][2][c] */) {
+  constexpr int TEAMS = 256 / TEAM;
+  __shared__ float red[TEAMS][2][TEAM * NA_MAX_PER_LANE + 1];
+  const int tl = threadIdx.x % TEAM, team = threadIdx.x / TEAM;
+  const float inv_c = 1.0f / (float)c;
+  float g[NA_MAX_PER_LANE], b[NA_MAX_PER_LANE], dg[NA_MAX_PER_LANE], db[NA_MAX_PER_LANE];
+#pragma unroll
+  for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+    const int ch = tl + k * TEAM;
+    g[k] = (ch < c && gamma) ? gamma[ch] : 1.0f;
+    b[k] = (ch < c && beta) ? beta[ch] : 0.0f;
+    dg[k] = db[k] = 0.0f;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * TEAMS + team; row < n; row += (int64_t)gridDim.x * TEAMS) {
+    const float* xr = x + row * c;
+    const float* gr = gout + row * c;
+    float v[NA_MAX_PER_LANE], go[NA_MAX_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+      const int ch = tl + k * TEAM;
+      v[k] = ch < c ? xr[ch] : 0.0f;
+      go[k] = ch < c ? gr[ch] : 0.0f;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NA_MAX_PER_LANE; ++k) s += v[k];
+#pragma unroll
+    for (int o = TEAM >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * inv_c;
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+      const float d = (tl + k * TEAM < c) ? v[k] - mean : 0.0f;
+      q += d * d;
+    }
+#pragma unroll
+    for (int o = TEAM >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * inv_c + eps);
+    float s1 = 0.0f, s2 = 0.0f;  // sum(g_xhat), sum(g_xhat * xhat)
+    float xh[NA_MAX_PER_LANE], gh[NA_MAX_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+      const bool live = tl + k * TEAM < c;
+      xh[k] = live ? (v[k] - mean) * rstd : 0.0f;
+      const float y = xh[k] * g[k] + b[k];
+      float gy = go[k];
+      if (ACT == ACT_RELU) gy = y > 0.0f ? gy : 0.0f;
+      if (ACT == ACT_GELU) gy *= dgelu_erf(y);
+      gy = live ? gy : 0.0f;
+      db[k] += gy;
+      dg[k] += gy * xh[k];
+      gh[k] = gy * g[k];
+      s1 += gh[k];
+      s2 += gh[k] * xh[k];
+    }
+#pragma unroll
+    for (int o = TEAM >> 1; o > 0; o >>= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    const float m1 = s1 * inv_c, m2 = s2 * inv_c;
+    float* gxr = gx + row * c;
+#pragma unroll
+    for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+      const int ch = tl + k * TEAM;
+      if (ch < c) gxr[ch] = rstd * (gh[k] - m1 - xh[k] * m2);
+    }
+  }
+  // column sums: teams -> workgroup (team order), workgroup partial to memory
+#pragma unroll
+  for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+    red[team][0][tl + k * TEAM] = dg[k];
+    red[team][1][tl + k * TEAM] = db[k];
+  }
+  __syncthreads();
+  for (int ch = threadIdx.x; ch < c; ch += 256) {
+    float a0 = 0.0f, a1 = 0.0f;
+    for (int t = 0; t < TEAMS; ++t) {
+      a0 += red[t][0][ch];
+      a1 += red[t][1][ch];
+    }
+    part[((int64_t)blockIdx.x * 2 + 0) * c + ch] = a0;
+    part[((int64_t)blockIdx.x * 2 + 1) * c + ch] = a1;
+  }
+}
+
+__global__ void __launch_bounds__(256) norm_act_bwd_fold_kernel(const float* __restrict__ part, int blocks, int c,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  float a0 = 0.0f, a1 = 0.0f;
+  for (int b = 0; b < blocks; ++b) {
+    a0 += part[((int64_t)b * 2 + 0) * c + ch];
+    a1 += part[((int64_t)b * 2 + 1) * c + ch];
+  }
+  if (dgamma) dgamma[ch] = a0;
+  if (dbeta) dbeta[ch] = a1;
+}
+
+constexpr int NA_BWD_BLOCKS = 1024;
+
+template <int TEAM>
+static int launch_norm_act_bwd(const float* x, const float* gout, int64_t n, int c, const float* gamma, const float* beta,
+                               float eps, int act, float* gx, float* dgamma, float* dbeta, float* part, hipStream_t stream) {
+  const int teams_per_block = 256 / TEAM;
+  int64_t g = (n + teams_per_block - 1) / teams_per_block;
+  if (g > NA_BWD_BLOCKS) g = NA_BWD_BLOCKS;
+  if (g < 1) g = 1;
+#define FSF_NAB(A_) \
+  hipLaunchKernelGGL((norm_act_bwd_kernel<TEAM, A_>), dim3((unsigned)g), dim3(256), 0, stream, x, gout, n, c, gamma, beta, eps, gx, part)
+  if (act == ACT_GELU) FSF_NAB(ACT_GELU);
+  else if (act == ACT_RELU) FSF_NAB(ACT_RELU);
+  else FSF_NAB(ACT_NONE);
+#undef FSF_NAB
+  hipLaunchKernelGGL(norm_act_bwd_fold_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, stream, part, (int)g, c, dgamma, dbeta);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
 }  // namespace fsf
 
 using namespace fsf;
@@ -111,4 +247,29 @@ extern "C" int fsf_norm_act(const float* x, int64_t n, int32_t c, const float* g
   if (c <= 16 * NA_MAX_PER_LANE / 2) return launch_norm_act<16>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
   if (c <= 32 * NA_MAX_PER_LANE / 2) return launch_norm_act<32>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
   return launch_norm_act<64>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
+}
+
+extern "C" int64_t fsf_norm_act_backward_workspace_bytes(int32_t c) {
+  return (int64_t)NA_BWD_BLOCKS * 2 * (c > 0 ? c : 1) * 4 + 256;
+}
+
+extern "C" int fsf_norm_act_backward(const float* x, const float* grad_out, int64_t n, int32_t c, const float* gamma,
+                                     const float* beta, float eps, int32_t act, float* grad_x, float* grad_gamma,
+                                     float* grad_beta, void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || c < 1 || act < 0 || act > 2 || (n > 0 && (!x || !grad_out || !grad_x)) || ((gamma == nullptr) != (beta == nullptr)))
+    return FSF_ERR_INVALID_ARG;
+  if (c > 64 * NA_MAX_PER_LANE) return FSF_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsf_norm_act_backward_workspace_bytes(c) || !workspace) return FSF_ERR_WORKSPACE;
+  float* part = (float*)workspace;
+  if (n == 0) {
+    if (grad_gamma) FSF_HIP_TRY(hipMemsetAsync(grad_gamma, 0, sizeof(float) * c, stream));
+    if (grad_beta) FSF_HIP_TRY(hipMemsetAsync(grad_beta, 0, sizeof(float) * c, stream));
+    return FSF_OK;
+  }
+  if (c <= 16 * NA_MAX_PER_LANE / 2)
+    return launch_norm_act_bwd<16>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
+  if (c <= 32 * NA_MAX_PER_LANE / 2)
+    return launch_norm_act_bwd<32>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
+  return launch_norm_act_bwd<64>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
 }

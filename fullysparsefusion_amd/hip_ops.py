@@ -40,6 +40,8 @@ _ARGTYPES = {
     "fsf_spconv_backward_weight": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_connected_components_workspace_bytes": [c_i64],
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
+    "fsf_norm_act_backward_workspace_bytes": [c_i32],
+    "fsf_norm_act_backward": [_P, _P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_row_topk_desc": [_P, c_i64, c_i32, c_i32, _P, _P],
     "fsf_sir_input": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
                       _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
@@ -568,3 +570,18 @@ def norm_act(x: torch.Tensor, gamma, beta, eps: float, norm: str, act, inplace=T
     check(_L().fsf_norm_act(ptr(x), n, c, ptr(gamma), ptr(beta), float(eps), {"ln": 0, "affine": 1}[norm], _ACTS[act],
                             c_p(out.data_ptr()), out.stride(0), stream_ptr()), "fsf_norm_act")
     return out
+
+
+def norm_act_backward(x: torch.Tensor, grad_out: torch.Tensor, gamma, beta, eps: float, act):
+    """fsf_norm_act_backward (LayerNorm form): -> (grad_x [n,c], grad_gamma [c] | None, grad_beta [c] | None)."""
+    require_cuda(x, grad_out)
+    x, grad_out = x.contiguous(), grad_out.contiguous()
+    n, c = x.shape
+    gx = torch.empty_like(x)
+    dg = torch.empty((c,), dtype=torch.float32, device=x.device) if gamma is not None else None
+    db = torch.empty((c,), dtype=torch.float32, device=x.device) if beta is not None else None
+    h = _L()
+    ws = _lib.workspace(h.fsf_norm_act_backward_workspace_bytes(c), x.device)
+    check(h.fsf_norm_act_backward(ptr(x), ptr(grad_out), n, c, ptr(gamma), ptr(beta), float(eps), _ACTS[act], ptr(gx), ptr(dg),
+                                  ptr(db), ptr(ws), ws.numel(), stream_ptr()), "fsf_norm_act_backward")
+    return gx, dg, db

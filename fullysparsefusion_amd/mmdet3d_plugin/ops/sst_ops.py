@@ -152,6 +152,24 @@ def get_activation_layer(act, dim=None):
     return table[act]()
 
 
+class _NormActFn(torch.autograd.Function):
+    """act(LayerNorm(x)) with both directions fused: the forward keeps only x, the backward recomputes the row statistics
+    and the pre-activation in registers and emits grad_x, grad_gamma, grad_beta in one pass (fsf_norm_act_backward)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, act_code):
+        x = x.contiguous()
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.eps, ctx.act_code = eps, act_code
+        return hip_ops.norm_act(x, gamma, beta, eps, "ln", act_code, inplace=False)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, gamma, beta = ctx.saved_tensors
+        gx, dg, db = hip_ops.norm_act_backward(x, grad, gamma, beta, ctx.eps, ctx.act_code)
+        return gx, dg, db, None, None
+
+
 def fused_norm_act(x, norm, act, out=None):
     """`act(norm(x))` for x [n, C].  When no gradient is needed and the pair is LayerNorm / eval BatchNorm1d followed by
     ReLU / GELU, this is ONE fused HIP pass over the activations (fsf_norm_act) instead of two or three ATen kernels;
@@ -162,7 +180,11 @@ def fused_norm_act(x, norm, act, out=None):
     elif isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none":
         act_code = "gelu"
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in norm.parameters()))
-    if act_code is not None and not needs_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(1) <= 512:
+    fusable = act_code is not None and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(1) <= 512
+    if (fusable and needs_grad and out is None and isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1
+            and norm.elementwise_affine and x.size(0) > 0):
+        return _NormActFn.apply(x, norm.weight, norm.bias, norm.eps, act_code)  # training: fused forward AND backward (K12)
+    if fusable and not needs_grad:
         x = x.contiguous()
         if isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1:
             return hip_ops.norm_act(x, norm.weight, norm.bias, norm.eps, "ln", act_code, out=out)

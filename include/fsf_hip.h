@@ -150,6 +150,13 @@ int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* co
  */
 int fsf_norm_act(const float* x, int64_t n, int32_t c, const float* gamma, const float* beta, float eps, int32_t norm,
                  int32_t act, float* out, int64_t out_stride, void* stream);
+/* Backward of the LayerNorm form (norm = 0) for training: grad_x f32 [n,c], grad_gamma / grad_beta f32 [c] (NULL to skip);
+ * x is the forward INPUT (statistics and pre-activation are recomputed).  Replaces ATen's layer_norm_backward + the
+ * activation's own backward kernel behind the MLP blocks of build_mlp (ops/sst_ops.py:808-833). */
+int64_t fsf_norm_act_backward_workspace_bytes(int32_t c);
+int fsf_norm_act_backward(const float* x, const float* grad_out, int64_t n, int32_t c, const float* gamma, const float* beta,
+                          float eps, int32_t act, float* grad_x, float* grad_gamma, float* grad_beta, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K13-K15  LiDAR -> camera projection + per-point instance-mask gather

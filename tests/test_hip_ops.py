@@ -702,3 +702,27 @@ def test_linear_weight_gradient_through_identity_pairs(ops, device, n, cin, cout
     assert got.shape == (cin, cout)
     assert float((got.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) * max(1.0, (n / 1e4) ** 0.5)
     assert torch.equal(got, ops.linear_backward_weight(x, g))
+
+
+@pytest.mark.parametrize("c", [16, 32, 64, 128, 133, 180, 256])
+@pytest.mark.parametrize("act", ["gelu", "relu"])
+def test_norm_act_backward_vs_torch_autograd(ops, device, c, act):
+    """Fused LayerNorm + activation backward (grad_x, grad_gamma, grad_beta) against float64 autograd."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(c)
+    n = 30011
+    x = torch.randn(n, c, device=device) * 2 + 0.5
+    g = torch.rand(c, device=device) + 0.5
+    b = torch.randn(c, device=device) * 0.2
+    go = torch.randn(n, c, device=device)
+    gx, dg, db = ops.norm_act_backward(x, go, g, b, 1e-3, act)
+    xd, gd, bd = x.double().requires_grad_(), g.double().requires_grad_(), b.double().requires_grad_()
+    y = F.layer_norm(xd, (c,), gd, bd, 1e-3)
+    y = F.gelu(y) if act == "gelu" else F.relu(y)
+    y.backward(go.double())
+    assert float((gx.double() - xd.grad).abs().max()) <= 2e-5 * max(1.0, float(xd.grad.abs().max()))
+    assert float((dg.double() - gd.grad).abs().max()) <= 1e-4 * max(1.0, float(gd.grad.abs().max()))
+    assert float((db.double() - bd.grad).abs().max()) <= 1e-4 * max(1.0, float(bd.grad.abs().max()))
+    gx2, dg2, db2 = ops.norm_act_backward(x, go, g, b, 1e-3, act)
+    assert torch.equal(gx, gx2) and torch.equal(dg, dg2) and torch.equal(db, db2)  # deterministic
