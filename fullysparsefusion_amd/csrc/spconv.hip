@@ -1,7 +1,7 @@
 // K9/K11: sparse convolution forward as an output-stationary implicit GEMM on the fp32 matrix cores.
 // See include/fsf_hip.h.
 //
-// One workgroup (4 waves) owns a tile of TM=64 output rows x TN<=128 output channels whose accumulator
+// One workgroup (4 waves) owns a tile of TM=64 (or 128, big layers) output rows x TN<=128 output channels whose accumulator
 // lives in LDS for the whole kernel-offset loop, so every output row is written exactly once (no
 // scatter-add atomics, deterministic).  For each kernel offset k the rows of the tile that actually have
 // a neighbour are COMPACTED (ballot prefix, precomputed per tile) and v_mfma_f32_16x16x4_f32 runs over
@@ -59,14 +59,14 @@ __device__ __forceinline__ float epilogue_one(const SpconvArgs& a, float x, int6
   return x;
 }
 
-// LDS carve shared by both kernels
-template <int TN>
+// LDS carve shared by both kernels (TM = output rows per workgroup)
+template <int TN, int TM = SC_TM>
 struct SpconvSmem {
   static constexpr int CS_STRIDE = TN + 4;
-  static constexpr int CS_FLOATS = (SC_TM + 1) * CS_STRIDE;  // + dump row
-  static constexpr int A_FLOATS = 2 * SC_ABUF > SC_TM * (SC_KC + 4) ? 2 * SC_ABUF : SC_TM * (SC_KC + 4);
+  static constexpr int CS_FLOATS = (TM + 1) * CS_STRIDE;  // + dump row
+  static constexpr int A_FLOATS = 2 * TM * SC_AROW > TM * (SC_KC + 4) ? 2 * TM * SC_AROW : TM * (SC_KC + 4);
   static constexpr size_t bytes() {
-    return (size_t)(CS_FLOATS + A_FLOATS) * 4 + (size_t)SC_MAXK * SC_TM * 4 + (size_t)SC_MAXK * SC_TM + (size_t)SC_MAXK * 8 + 64;
+    return (size_t)(CS_FLOATS + A_FLOATS) * 4 + (size_t)SC_MAXK * TM * 4 + (size_t)SC_MAXK * TM + (size_t)SC_MAXK * 8 + 64;
   }
 };
 
@@ -80,24 +80,30 @@ __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
 // The tile's [64][kvol] block of the neighbour table is contiguous in HBM: it is staged through LDS with
 // coalesced loads (`stage`, >= 64*kvol ints), then each wave compacts offsets k = wave, wave+4, ...
 // rl_in holds ELEMENT offsets (input row * cin) so the gather needs no 64-bit multiply per row.
+template <int TM>
 __device__ __forceinline__ void build_row_lists(const SpconvArgs& a, int64_t o0, int zsplit, int32_t* stage, int32_t* rl_in,
                                                 uint8_t* rl_loc, int32_t* rl_cnt, int32_t* act_k, int32_t* act_n) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t rows_left = a.m_out - o0;
-  const int nvalid = (int)((rows_left < SC_TM ? rows_left : SC_TM) * a.kvol);
+  const int nvalid = (int)((rows_left < TM ? rows_left : TM) * a.kvol);
   const int32_t* src = a.nbr + o0 * a.kvol;
-  for (int t = tid; t < SC_TM * a.kvol; t += 256) stage[t] = (t < nvalid) ? src[t] : -1;
+  for (int t = tid; t < TM * a.kvol; t += 256) stage[t] = (t < nvalid) ? src[t] : -1;
   __syncthreads();
   for (int k = wave; k < a.kvol; k += 4) {
-    const int32_t in = stage[lane * a.kvol + k];
-    const bool has = in >= 0;
-    const uint64_t bal = __ballot(has);
-    if (has) {
-      const int pos = (int)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-      rl_in[k * SC_TM + pos] = in * a.cin;
-      rl_loc[k * SC_TM + pos] = (uint8_t)lane;
+    int base = 0;
+#pragma unroll
+    for (int h = 0; h < TM / 64; ++h) {  // 64 tile rows per ballot, appended in row order
+      const int32_t in = stage[(h * 64 + lane) * a.kvol + k];
+      const bool has = in >= 0;
+      const uint64_t bal = __ballot(has);
+      if (has) {
+        const int pos = base + (int)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+        rl_in[k * TM + pos] = in * a.cin;
+        rl_loc[k * TM + pos] = (uint8_t)(h * 64 + lane);
+      }
+      base += (int)__popcll(bal);
     }
-    if (lane == 0) rl_cnt[k] = (int)__popcll(bal);
+    if (lane == 0) rl_cnt[k] = base;
   }
   __syncthreads();
   if (wave == 0) {  // active offsets of this z-split, in ascending k (ballot prefix instead of a serial loop)
@@ -112,7 +118,7 @@ __device__ __forceinline__ void build_row_lists(const SpconvArgs& a, int64_t o0,
   __syncthreads();
 }
 
-template <int TN>
+template <int TN, int TM = SC_TM>
 __device__ __forceinline__ void write_tile(const SpconvArgs& a, const float* Cs, int64_t o0, int n0, int zsplit) {
   constexpr int CS_STRIDE = TN + 4;
   constexpr int F4_PER_ROW = TN / 4;
@@ -127,7 +133,7 @@ __device__ __forceinline__ void write_tile(const SpconvArgs& a, const float* Cs,
   if (fin && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + col);
   if (fin && a.shift) sh = *reinterpret_cast<const float4*>(a.shift + col);
 #pragma unroll 4
-  for (int r = r0; r < SC_TM; r += ROWS_PER_PASS) {
+  for (int r = r0; r < TM; r += ROWS_PER_PASS) {
     const int64_t o = o0 + r;
     if (o >= a.m_out) break;
     float4 v = *reinterpret_cast<const float4*>(Cs + r * CS_STRIDE + c4);
@@ -161,31 +167,32 @@ __device__ long long fsf_dbg[4096 * 8];
 
 // ------------------------------------------------------------------------------------------------------
 // Fast path: cin % 64 == 0.  LDS-DMA double-buffered A tile, register double-buffered B, one barrier per stage.
-template <int TN>
-__global__ void __launch_bounds__(256, 2) spconv_fwd_dma_kernel(SpconvArgs a) {
-  using SM = SpconvSmem<TN>;
+template <int TN, int TM>
+__global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel(SpconvArgs a) {
+  using SM = SpconvSmem<TN, TM>;
+  constexpr int ABUF = TM * SC_AROW;  // floats per A buffer
   constexpr int CS_STRIDE = SM::CS_STRIDE;
   constexpr int WCOLS = TN / 4;    // columns per wave
   constexpr int NCT = WCOLS / 16;  // 16-column MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Cs = reinterpret_cast<float*>(smem);                         // [SC_TM + 1][CS_STRIDE], row SC_TM = dump row
-  float* As = Cs + SM::CS_FLOATS;                                     // [2][SC_TM][SC_AROW], swizzled 16-B chunks
-  int32_t* rl_in = reinterpret_cast<int32_t*>(As + SM::A_FLOATS);     // [SC_MAXK][SC_TM]
-  uint8_t* rl_loc = reinterpret_cast<uint8_t*>(rl_in + SC_MAXK * SC_TM);
-  int32_t* rl_cnt = reinterpret_cast<int32_t*>(rl_loc + SC_MAXK * SC_TM);
+  float* Cs = reinterpret_cast<float*>(smem);                         // [TM + 1][CS_STRIDE], row TM = dump row
+  float* As = Cs + SM::CS_FLOATS;                                     // [2][TM][SC_AROW], swizzled 16-B chunks
+  int32_t* rl_in = reinterpret_cast<int32_t*>(As + SM::A_FLOATS);     // [SC_MAXK][TM]
+  uint8_t* rl_loc = reinterpret_cast<uint8_t*>(rl_in + SC_MAXK * TM);
+  int32_t* rl_cnt = reinterpret_cast<int32_t*>(rl_loc + SC_MAXK * TM);
   int32_t* act_k = rl_cnt + SC_MAXK;
   int32_t* act_n = act_k + SC_MAXK;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int64_t o0 = (int64_t)tile * SC_TM;
+  const int64_t o0 = (int64_t)tile * TM;
   const int n0 = blockIdx.y * TN;
   const int zsplit = blockIdx.z;
 
   FSF_STAMP(0);
   // the A buffers double as the staging area of the neighbour-table block; afterwards C (incl. the dump row) and
   // both A buffers are zeroed: rows past the live data must hold finite values
-  build_row_lists(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
+  build_row_lists<TM>(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
   FSF_STAMP(1);
   for (int t = tid; t < (SM::CS_FLOATS + SM::A_FLOATS) / 4; t += 256)
     reinterpret_cast<float4*>(Cs)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -204,16 +211,16 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_dma_kernel(SpconvArgs a) {
   // takes row groups w, w+4, ...; a group is issued iff its first row is live (wave-uniform branch)
   auto issue_gather = [&](int k, int cin0, int buf) {
     const int cnt = rl_cnt[k];
-    float* abuf = As + buf * SC_ABUF;
+    float* abuf = As + buf * ABUF;
 #pragma unroll
-    for (int it = 0; it < SC_TM / 16; ++it) {
+    for (int it = 0; it < TM / 16; ++it) {
       const int g = wave + 4 * it;  // row group: rows 4g .. 4g+3
       if (4 * g < cnt) {
         int j = 4 * g + (lane >> 4);
         const int phys = lane & 15;
         const int chunk = phys ^ (j & 15);  // logical 16-B chunk that must land at physical slot `phys` of row j
         j = j < cnt ? j : cnt - 1;          // rows past cnt re-read the last live row (finite filler)
-        const float* src = a.feat + rl_in[k * SC_TM + j] + cin0 + 4 * chunk;
+        const float* src = a.feat + rl_in[k * TM + j] + cin0 + 4 * chunk;
 #ifndef FSF_ABL_NO_GATHER
         __builtin_amdgcn_global_load_lds(src, abuf + 4 * g * SC_AROW, 16, 0, 0);
 #else
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_dma_kernel(SpconvArgs a) {
   // read once and written once per (offset, row block) instead of once per 64-wide chunk (the C read-modify-write
   // through LDS is what competes with the MFMA issue otherwise).  Lane (lrow, kgrp) owns columns wcol0 + 2*lrow + ct
   // (adjacent pair -> one 8-byte LDS access) of compact rows rb*16 + kgrp*4 + r.
-  constexpr int MAXRB = SC_TM / 16;
+  constexpr int MAXRB = TM / 16;
   f32x4 acc[MAXRB][NCT];
   int loc[MAXRB][4];
   int chunk_c = 0, ki = 0;
@@ -275,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_dma_kernel(SpconvArgs a) {
       const int k = act_k[ki];
       const int cnt = rl_cnt[k];
       const int nrb = (cnt + 15) >> 4;
-      const float* abuf = As + cur * SC_ABUF;
+      const float* abuf = As + cur * ABUF;
 #ifdef FSF_ABL_NO_CRMW
       if (s == 0) {
 #else
@@ -285,21 +292,21 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_dma_kernel(SpconvArgs a) {
         for (int rb = 0; rb < MAXRB; ++rb) {
           if (rb < nrb) {
             // compacted row -> local output row (4 consecutive bytes); rows past cnt go to the dump row
-            const uint32_t packed = *reinterpret_cast<const uint32_t*>(rl_loc + k * SC_TM + rb * 16 + kgrp * 4);
+            const uint32_t packed = *reinterpret_cast<const uint32_t*>(rl_loc + k * TM + rb * 16 + kgrp * 4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int j = rb * 16 + kgrp * 4 + r;
-              loc[rb][r] = (j < cnt) ? (int)((packed >> (8 * r)) & 0xffu) : SC_TM;
+              loc[rb][r] = (j < cnt) ? (int)((packed >> (8 * r)) & 0xffu) : TM;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const float* cp = Cs + loc[rb][r] * CS_STRIDE + wcol0 + NCT * lrow;
               if constexpr (NCT == 2) {
                 const float2 c2 = *reinterpret_cast<const float2*>(cp);
-                acc[rb][0][r] = (loc[rb][r] < SC_TM) ? c2.x : 0.0f;
-                acc[rb][1][r] = (loc[rb][r] < SC_TM) ? c2.y : 0.0f;
+                acc[rb][0][r] = (loc[rb][r] < TM) ? c2.x : 0.0f;
+                acc[rb][1][r] = (loc[rb][r] < TM) ? c2.y : 0.0f;
               } else {
-                acc[rb][0][r] = (loc[rb][r] < SC_TM) ? cp[0] : 0.0f;
+                acc[rb][0][r] = (loc[rb][r] < TM) ? cp[0] : 0.0f;
               }
             }
           }
@@ -372,7 +379,7 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_dma_kernel(SpconvArgs a) {
 #endif
   }
   FSF_STAMP(4);
-  write_tile<TN>(a, Cs, o0, n0, zsplit);
+  write_tile<TN, TM>(a, Cs, o0, n0, zsplit);
   FSF_STAMP(5);
 #ifdef FSF_ABL_TIMING
   if (threadIdx.x == 0 && blockIdx.x < 4096) { fsf_dbg[blockIdx.x * 8 + 6] = nstages; fsf_dbg[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(0); }
@@ -403,7 +410,7 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_generic_kernel(SpconvArgs a
   const int64_t o0 = (int64_t)tile * SC_TM;
   const int n0 = blockIdx.y * TN;
   const int zsplit = blockIdx.z;
-  build_row_lists(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
+  build_row_lists<SC_TM>(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
   for (int t = tid; t < SM::CS_FLOATS + SM::A_FLOATS; t += 256) Cs[t] = 0.0f;
   __syncthreads();
 
@@ -500,23 +507,49 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-static int pick_ksplit(int64_t tiles, int cout_blocks, int kvol) {
-  // 256 CUs x 2 resident workgroups = 512 slots.  A launch of B workgroups runs in ceil(B / 512) rounds and the last,
-  // partly filled round costs a full tile duration (571 tiles = 2 rounds for 1.1 rounds of work).  Splitting the
-  // offset loop z ways makes B large and each workgroup short, so the tail shrinks; the price is the partial-tile
-  // round trip (2 * z * m_out * cout * 4 B) folded by spconv_reduce_kernel.
+static int pick_ksplit(int64_t tiles, int cout_blocks, int kvol, int64_t slots) {
+  // `slots` resident workgroups (256 CUs x 2 for the 64-row tile, x 1 for the 128-row tile).  A launch of B workgroups
+  // runs in ceil(B / slots) rounds and the last, partly filled round costs a full tile duration (571 tiles = 2 rounds
+  // for 1.1 rounds of work).  Splitting the offset loop z ways makes B large and each workgroup short, so the tail
+  // shrinks; the price is the partial-tile round trip (2 * z * m_out * cout * 4 B) folded by spconv_reduce_kernel.
   const int64_t blocks = tiles * cout_blocks;
   if (kvol < 3) return 1;
-  static const int64_t kTarget = [] {  // >= 4 rounds by default; FSF_KSPLIT_TARGET overrides it for tuning runs
+  static const int64_t kTargetEnv = [] {  // FSF_KSPLIT_TARGET overrides the default (4 rounds) for tuning runs
     const char* e = getenv("FSF_KSPLIT_TARGET");
-    const int64_t v = e ? atoll(e) : 0;
-    return v > 0 ? v : (int64_t)2048;
+    return e ? atoll(e) : (long long)0;
   }();
+  const int64_t kTarget = kTargetEnv > 0 ? kTargetEnv : 4 * slots;
   if (blocks >= kTarget) return 1;
   int64_t g = (kTarget + blocks - 1) / blocks;
   if (g > 9) g = 9;
   if (g > kvol / 3) g = kvol / 3;
   return (int)(g < 1 ? 1 : g);
+}
+
+// Launch shape of one layer.  The 128-row tile (FSF_SPCONV_TM=128) loads each weight fragment once per 128 rows and rounds
+// the compacted row counts to 16 over twice as many rows (row-block utilisation 0.85 -> 0.91 on the level-2 layers); it
+// needs ~150 KB of LDS, i.e. one workgroup per CU.
+struct SpconvPlan {
+  int tm, ksplit, cout_blocks;
+  int64_t tiles;
+};
+
+static SpconvPlan spconv_plan(int64_t m_out, int cin, int cout, int kvol) {
+  static const int tm_env = [] {  // FSF_SPCONV_TM = 64 | 128 forces the tile height (tuning runs)
+    const char* e = getenv("FSF_SPCONV_TM");
+    return e ? atoi(e) : 0;
+  }();
+  SpconvPlan p;
+  p.cout_blocks = cout <= 64 ? 1 : (cout + 127) / 128;
+  const bool fast = (cin % SC_KC) == 0;
+  // Measured on the 10-sweep frame (34 layers): the 128-row tile is 5-30 % SLOWER on every layer (U-Net 16.1 ms vs 14.3 ms)
+  // — one workgroup per CU leaves a single wave per SIMD and nothing to hide the per-stage barrier and LDS latency
+  // behind — so it stays opt-in until it gets a second wave group.
+  const bool big = tm_env == 128 && fast;
+  p.tm = big ? 128 : SC_TM;
+  p.tiles = (m_out + p.tm - 1) / p.tm;
+  p.ksplit = pick_ksplit(p.tiles, p.cout_blocks, kvol, big ? 256 : 512);
+  return p;
 }
 
 }  // namespace fsf
@@ -540,8 +573,9 @@ extern "C" int fsf_spconv_transpose_weight(const float* weight, int32_t kvol, in
 }
 
 extern "C" int64_t fsf_spconv_workspace_bytes(int64_t m_out, int32_t cout, int32_t kvol) {
-  const int64_t tiles = (m_out + SC_TM - 1) / SC_TM;
-  const int g = pick_ksplit(tiles, cout <= 64 ? 1 : (cout + 127) / 128, kvol);
+  // (the channel count of the input is not known here: take the larger of the two possible launch shapes)
+  const SpconvPlan a = spconv_plan(m_out, SC_KC, cout, kvol), b = spconv_plan(m_out, 16, cout, kvol);
+  const int g = a.ksplit > b.ksplit ? a.ksplit : b.ksplit;
   return g > 1 ? fsf_align_up((int64_t)g * m_out * cout * 4, 256) + 256 : 256;
 }
 
@@ -556,31 +590,36 @@ extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, 
   if (kvol > SC_MAXK || (cin % 16) != 0 || (cout % 4) != 0) return FSF_ERR_UNSUPPORTED;
   if (m_in * cin >= ((int64_t)1 << 31)) return FSF_ERR_UNSUPPORTED;  // row lists hold 32-bit element offsets
   if (m_out == 0) return FSF_OK;
-  const int64_t tiles = (m_out + SC_TM - 1) / SC_TM;
-  if (tiles >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
-  const int cout_blocks = cout <= 64 ? 1 : (cout + 127) / 128;
-  const int ksplit = pick_ksplit(tiles, cout_blocks, kvol);
+  const SpconvPlan plan = spconv_plan(m_out, cin, cout, kvol);
+  if (plan.tiles >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
+  const int ksplit = plan.ksplit;
   if (workspace_bytes < fsf_spconv_workspace_bytes(m_out, cout, kvol) || (ksplit > 1 && !workspace)) return FSF_ERR_WORKSPACE;
   SpconvArgs a{feat, weight_t, nbr, scale, shift, residual, out, (float*)workspace, m_in, m_out,
                (int)cin, (int)cout, (int)kvol, (int)relu, ksplit};
-  const dim3 grid((unsigned)tiles, cout_blocks, ksplit);
+  const dim3 grid((unsigned)plan.tiles, plan.cout_blocks, ksplit);
   const bool fast = (cin % SC_KC) == 0;
-#define FSF_SPCONV_LAUNCH(KERNEL, TN_)                                                                                \
-  do {                                                                                                                \
-    static bool attr_set = false;                                                                                     \
-    const size_t smem_bytes = SpconvSmem<TN_>::bytes();                                                               \
-    if (!attr_set) {                                                                                                  \
-      FSF_HIP_TRY(hipFuncSetAttribute((const void*)KERNEL<TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes)); \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((KERNEL<TN_>), grid, dim3(256), smem_bytes, stream, a);                                        \
+#define FSF_SPCONV_LAUNCH(KERNEL, SMEM_T)                                                                            \
+  do {                                                                                                               \
+    static bool attr_set = false;                                                                                    \
+    const size_t smem_bytes = SMEM_T::bytes();                                                                       \
+    if (!attr_set) {                                                                                                 \
+      FSF_HIP_TRY(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes)); \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(256), smem_bytes, stream, a);                                              \
   } while (0)
+  using S64_64 = SpconvSmem<64, 64>;
+  using S128_64 = SpconvSmem<128, 64>;
+  using S64_128 = SpconvSmem<64, 128>;
+  using S128_128 = SpconvSmem<128, 128>;
   if (cout <= 64) {
-    if (fast) FSF_SPCONV_LAUNCH(spconv_fwd_dma_kernel, 64);
-    else FSF_SPCONV_LAUNCH(spconv_fwd_generic_kernel, 64);
+    if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 128>), S64_128);
+    else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 64>), S64_64);
+    else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<64>), S64_64);
   } else {
-    if (fast) FSF_SPCONV_LAUNCH(spconv_fwd_dma_kernel, 128);
-    else FSF_SPCONV_LAUNCH(spconv_fwd_generic_kernel, 128);
+    if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 128>), S128_128);
+    else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 64>), S128_64);
+    else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<128>), S128_64);
   }
 #undef FSF_SPCONV_LAUNCH
   if (ksplit > 1)
