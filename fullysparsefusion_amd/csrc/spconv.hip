@@ -49,6 +49,9 @@ struct SpconvArgs {
   float* partial;  // [ksplit][m_out][cout] when ksplit > 1
   int64_t m_in, m_out;
   int cin, cout, kvol, relu, ksplit;
+  int* queue;  // [SC_NXCD] work counters of the persistent fast path, then [ntiles * cout_blocks] arrival counters of
+               // the offset splits (all zeroed before the launch)
+  int ntiles, cout_blocks;
 };
 
 __device__ __forceinline__ float epilogue_one(const SpconvArgs& a, float x, int64_t o, int col) {
@@ -66,7 +69,7 @@ struct SpconvSmem {
   static constexpr int CS_FLOATS = (TM + 1) * CS_STRIDE;  // + dump row
   static constexpr int A_FLOATS = 2 * TM * SC_AROW > TM * (SC_KC + 4) ? 2 * TM * SC_AROW : TM * (SC_KC + 4);
   static constexpr size_t bytes() {
-    return (size_t)(CS_FLOATS + A_FLOATS) * 4 + (size_t)SC_MAXK * TM * 4 + (size_t)SC_MAXK * TM + (size_t)SC_MAXK * 8 + 64;
+    return (size_t)(CS_FLOATS + A_FLOATS) * 4 + (size_t)SC_MAXK * TM * 4 + (size_t)SC_MAXK * TM + (size_t)SC_MAXK * 8 + 64 + 16;
   }
 };
 
@@ -74,6 +77,38 @@ struct SpconvSmem {
 __device__ __forceinline__ int xcd_tile(int b, int ntiles) {
   const int q = ntiles / SC_NXCD, r = ntiles % SC_NXCD, xcd = b % SC_NXCD;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / SC_NXCD;
+}
+
+// Work queue of the persistent fast path.  The tiles are cut into SC_NXCD contiguous ranges, one per XCD (neighbouring
+// tiles re-gather the same input rows -> hits in that XCD's L2); inside a range the items run tile-major, i.e. the cout
+// blocks and offset splits of one tile are handed out back to back and gather the same rows at about the same time.
+// A workgroup asks its own XCD's counter first and, once that range is drained, the other ranges in ring order — the
+// ranges differ in work (ground-plane tiles have 3x the pairs of the tiles above them), a static split leaves whole
+// XCDs idle for the last ~20 % of the kernel.
+__device__ __forceinline__ void queue_range(const SpconvArgs& a, int x, int& start, int& len) {
+  const int q = a.ntiles / SC_NXCD, r = a.ntiles % SC_NXCD;
+  start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  len = x < r ? q + 1 : q;
+}
+
+__device__ __forceinline__ void fetch_item(const SpconvArgs& a, int xcd, unsigned& drained, int32_t* item) {
+  const int per_tile = a.cout_blocks * a.ksplit;
+  for (int v = 0; v < SC_NXCD; ++v) {
+    const int x = (xcd + v) & (SC_NXCD - 1);
+    if (drained & (1u << x)) continue;
+    int start, len;
+    queue_range(a, x, start, len);
+    const int i = __hip_atomic_fetch_add(a.queue + x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i < len * per_tile) {
+      const int rem = i % per_tile;
+      item[0] = start + i / per_tile;
+      item[1] = rem / a.ksplit;
+      item[2] = rem % a.ksplit;
+      return;
+    }
+    drained |= 1u << x;
+  }
+  item[0] = -1;
 }
 
 // per-tile compaction lists for every offset + the active-offset list of this z-split.
@@ -118,7 +153,16 @@ __device__ __forceinline__ void build_row_lists(const SpconvArgs& a, int64_t o0,
   __syncthreads();
 }
 
-template <int TN, int TM = SC_TM>
+// 16-byte write-through (sc1) store: the partial tiles of an offset split are read by a workgroup that may sit on
+// another XCD, whose L2 never sees this one's dirty lines.  Written through, they need no release fence (a
+// buffer_wbl2 per work item costs more than the separate fold launch it replaces).  The compiler does not count
+// this store: the publisher drains with an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void store_f4_write_through(float* p, float4 v) {
+  const f32x4 x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+}
+
+template <int TN, int TM = SC_TM, bool WT = false>
 __device__ __forceinline__ void write_tile(const SpconvArgs& a, const float* Cs, int64_t o0, int n0, int zsplit) {
   constexpr int CS_STRIDE = TN + 4;
   constexpr int F4_PER_ROW = TN / 4;
@@ -138,8 +182,54 @@ __device__ __forceinline__ void write_tile(const SpconvArgs& a, const float* Cs,
     if (o >= a.m_out) break;
     float4 v = *reinterpret_cast<const float4*>(Cs + r * CS_STRIDE + c4);
     if (!fin) {
-      *reinterpret_cast<float4*>(a.partial + ((int64_t)zsplit * a.m_out + o) * a.cout + col) = v;
+      float* pp = a.partial + ((int64_t)zsplit * a.m_out + o) * a.cout + col;
+      if constexpr (WT) store_f4_write_through(pp, v);
+      else *reinterpret_cast<float4*>(pp) = v;
       continue;
+    }
+    if (a.scale) {
+      v.x = __fmaf_rn(v.x, sc.x, sh.x); v.y = __fmaf_rn(v.y, sc.y, sh.y);
+      v.z = __fmaf_rn(v.z, sc.z, sh.z); v.w = __fmaf_rn(v.w, sc.w, sh.w);
+    } else if (a.shift) {
+      v.x = __fadd_rn(v.x, sh.x); v.y = __fadd_rn(v.y, sh.y); v.z = __fadd_rn(v.z, sh.z); v.w = __fadd_rn(v.w, sh.w);
+    }
+    if (a.residual) {
+      const float4 rs = *reinterpret_cast<const float4*>(a.residual + o * a.cout + col);
+      v.x = __fadd_rn(v.x, rs.x); v.y = __fadd_rn(v.y, rs.y); v.z = __fadd_rn(v.z, rs.z); v.w = __fadd_rn(v.w, rs.w);
+    }
+    if (a.relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *reinterpret_cast<float4*>(a.out + o * a.cout + col) = v;
+  }
+}
+
+// Offset-split layers, persistent path: the workgroup that finishes a (tile, cout block) LAST folds the partial tiles
+// of the other splits into the result — in split order, its own contribution taken from LDS, so the sum is the same
+// fixed-order sum the stand-alone fold kernel computes — and applies the epilogue.  Release/acquire at agent scope:
+// the partial tiles cross XCDs, whose L2s are not coherent with each other.
+template <int TN, int TM>
+__device__ __forceinline__ void fold_tile(const SpconvArgs& a, const float* Cs, int64_t o0, int n0, int zsplit) {
+  constexpr int CS_STRIDE = TN + 4;
+  constexpr int F4_PER_ROW = TN / 4;
+  constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+  const int c4 = (threadIdx.x % F4_PER_ROW) * 4;
+  const int r0 = threadIdx.x / F4_PER_ROW;
+  const int col = n0 + c4;
+  if (col >= a.cout) return;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a.scale) sc = *reinterpret_cast<const float4*>(a.scale + col);
+  if (a.shift) sh = *reinterpret_cast<const float4*>(a.shift + col);
+  for (int r = r0; r < TM; r += ROWS_PER_PASS) {
+    const int64_t o = o0 + r;
+    if (o >= a.m_out) break;
+    const float4 own = *reinterpret_cast<const float4*>(Cs + r * CS_STRIDE + c4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < a.ksplit; ++z) {
+      float4 p = own;
+      if (z != zsplit) p = *reinterpret_cast<const float4*>(a.partial + ((int64_t)z * a.m_out + o) * a.cout + col);
+      if (z == 0) v = p;
+      else { v.x = __fadd_rn(v.x, p.x); v.y = __fadd_rn(v.y, p.y); v.z = __fadd_rn(v.z, p.z); v.w = __fadd_rn(v.w, p.w); }
     }
     if (a.scale) {
       v.x = __fmaf_rn(v.x, sc.x, sh.x); v.y = __fmaf_rn(v.y, sc.y, sh.y);
@@ -160,7 +250,8 @@ __device__ __forceinline__ void write_tile(const SpconvArgs& a, const float* Cs,
 
 #ifdef FSF_ABL_TIMING
 __device__ long long fsf_dbg[4096 * 8];
-#define FSF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) fsf_dbg[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#define FSF_BID ((item[0] * a.cout_blocks + item[1]) * a.ksplit + item[2])
+#define FSF_STAMP(i) do { if (threadIdx.x == 0 && FSF_BID < 4096) fsf_dbg[FSF_BID * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define FSF_STAMP(i) do { } while (0)
 #endif
@@ -182,27 +273,32 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
   int32_t* rl_cnt = reinterpret_cast<int32_t*>(rl_loc + SC_MAXK * TM);
   int32_t* act_k = rl_cnt + SC_MAXK;
   int32_t* act_n = act_k + SC_MAXK;
+  int32_t* item = act_n + 4;  // [3] tile, cout block, offset split of the current work item
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = xcd_tile(blockIdx.x, gridDim.x);
-  const int64_t o0 = (int64_t)tile * TM;
-  const int n0 = blockIdx.y * TN;
-  const int zsplit = blockIdx.z;
-
-  FSF_STAMP(0);
-  // the A buffers double as the staging area of the neighbour-table block; afterwards C (incl. the dump row) and
-  // both A buffers are zeroed: rows past the live data must hold finite values
-  build_row_lists<TM>(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
-  FSF_STAMP(1);
-  for (int t = tid; t < (SM::CS_FLOATS + SM::A_FLOATS) / 4; t += 256)
-    reinterpret_cast<float4*>(Cs)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __syncthreads();
-  FSF_STAMP(2);
-
   const int lrow = lane & 15;  // A row / B column inside a 16x16 tile
   const int kgrp = lane >> 4;  // which 4-float K group this lane feeds
   const int wcol0 = wave * WCOLS;
   const int nchunks = a.cin / SC_KC;
+  const int64_t wk_stride = (int64_t)a.cout * a.cin;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int xcd = (int)(xcc & (SC_NXCD - 1));
+  unsigned drained = 0;  // (thread 0) ranges known to be empty
+
+  // Persistent workgroup: 2 per CU, each pulls (tile, cout block, offset split) items until the queues are dry.
+  for (;;) {
+  if (tid == 0) fetch_item(a, xcd, drained, item);
+  __syncthreads();
+  if (item[0] < 0) break;
+  const int64_t o0 = (int64_t)item[0] * TM;
+  const int n0 = item[1] * TN;
+  const int zsplit = item[2];
+
+  FSF_STAMP(0);
+  // the A buffers double as the staging area of the neighbour-table block
+  build_row_lists<TM>(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
+  FSF_STAMP(1);
   const int nstages = act_n[0] * nchunks;
 
   f32x4 bcur[NCT][SC_NSTEPS], bnext[NCT][SC_NSTEPS];
@@ -236,7 +332,6 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
     const int col = n0 + wcol0 + NCT * lrow + ct;
     wlane[ct] = a.wt + (int64_t)(col < a.cout ? col : 0) * a.cin + 4 * kgrp;
   }
-  const int64_t wk_stride = (int64_t)a.cout * a.cin;
   auto load_b = [&](int k, int cin0, f32x4 (&bf)[NCT][SC_NSTEPS]) {
     const int64_t koff = k * wk_stride + cin0;  // wave-uniform
 #pragma unroll
@@ -252,6 +347,11 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
     issue_gather(act_k[0], 0, 0);
     load_b(act_k[0], 0, bcur);
   }
+  FSF_STAMP(2);
+  // C (incl. the dump row) is zeroed while the first stage is in flight.  The A buffers are NOT cleared: rows past an
+  // offset's live count hold stale data, but an MFMA output row depends on its own A row only and those rows land in
+  // the dump row, which is never read back.
+  for (int t = tid; t < SM::CS_FLOATS / 4; t += 256) reinterpret_cast<float4*>(Cs)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();  // (the compiler drains the DMA before the barrier) A[0] complete and visible
   FSF_STAMP(3);
 
@@ -379,11 +479,32 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
 #endif
   }
   FSF_STAMP(4);
-  write_tile<TN, TM>(a, Cs, o0, n0, zsplit);
+  write_tile<TN, TM, true>(a, Cs, o0, n0, zsplit);
+  if (a.ksplit > 1) {
+    // publish the partial tile (write-through stores), then take an arrival ticket: every wave drains its stores,
+    // barrier, ONE lane draws the relaxed agent-scope ticket; the last arriver acquires once (drops this CU's stale L1
+    // lines) and folds.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int ticket = __hip_atomic_fetch_add(a.queue + SC_NXCD + item[0] * a.cout_blocks + item[1], 1, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+      if (ticket == a.ksplit - 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      item[3] = ticket;
+    }
+    __syncthreads();
+    if (item[3] == a.ksplit - 1) fold_tile<TN, TM>(a, Cs, o0, n0, zsplit);
+  }
   FSF_STAMP(5);
 #ifdef FSF_ABL_TIMING
-  if (threadIdx.x == 0 && blockIdx.x < 4096) { fsf_dbg[blockIdx.x * 8 + 6] = nstages; fsf_dbg[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(0); }
+  if (threadIdx.x == 0 && FSF_BID < 4096) {
+    fsf_dbg[FSF_BID * 8 + 6] = nstages;
+    unsigned hwid;  // HW_ID: cu_id [11:8], sh [12], se [15:13]; XCC_ID is a separate register
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    fsf_dbg[FSF_BID * 8 + 7] = (long long)hwid | ((long long)(xcc & 0xf) << 32);
+  }
 #endif
+  }  // work-item loop
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -507,23 +628,37 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-static int pick_ksplit(int64_t tiles, int cout_blocks, int kvol, int64_t slots) {
-  // `slots` resident workgroups (256 CUs x 2 for the 64-row tile, x 1 for the 128-row tile).  A launch of B workgroups
-  // runs in ceil(B / slots) rounds and the last, partly filled round costs a full tile duration (571 tiles = 2 rounds
-  // for 1.1 rounds of work).  Splitting the offset loop z ways makes B large and each workgroup short, so the tail
-  // shrinks; the price is the partial-tile round trip (2 * z * m_out * cout * 4 B) folded by spconv_reduce_kernel.
-  const int64_t blocks = tiles * cout_blocks;
+// How many ways to split the offset loop of a layer (work items = tiles x cout blocks x splits, handed to `slots`
+// resident workgroups).  A small layer needs the split to fill the chip at all; a mid-size one to avoid a last round
+// that is mostly empty (864 items on 512 slots run as long as 1024).  Cost model in microseconds, constants measured
+// on the 10-sweep frame: a work item costs ~8 us of fixed work (neighbour-table block, compaction, first gather, tile
+// write) + ~3.8 us per (offset, 64-channel chunk) stage when two workgroups share a CU's matrix pipe (x0.65 when one
+// has the CU to itself); every extra split adds a partial tile written and re-read by the last-arriving workgroup.
+static int pick_ksplit(int64_t tiles, int cout_blocks, int kvol, int nchunks, int64_t m_out, int cout, int64_t slots) {
   if (kvol < 3) return 1;
-  static const int64_t kTargetEnv = [] {  // FSF_KSPLIT_TARGET overrides the default (4 rounds) for tuning runs
-    const char* e = getenv("FSF_KSPLIT_TARGET");
-    return e ? atoll(e) : (long long)0;
+  static const int kForce = [] {  // FSF_KSPLIT forces the split (tuning runs)
+    const char* e = getenv("FSF_KSPLIT");
+    return e ? atoi(e) : 0;
   }();
-  const int64_t kTarget = kTargetEnv > 0 ? kTargetEnv : 4 * slots;
-  if (blocks >= kTarget) return 1;
-  int64_t g = (kTarget + blocks - 1) / blocks;
-  if (g > 9) g = 9;
-  if (g > kvol / 3) g = kvol / 3;
-  return (int)(g < 1 ? 1 : g);
+  int gmax = kvol / 3 < 9 ? kvol / 3 : 9;
+  if (kForce > 0) return kForce < gmax ? kForce : gmax;
+  const double t_stage = cout <= 64 ? 2.6 : 3.8, fixed = 8.0;
+  const double tile_mb = (double)m_out * cout * 4 * 1e-6;
+  double best = 0;
+  int best_g = 1;
+  for (int g = 1; g <= gmax; ++g) {
+    const double n = (double)tiles * cout_blocks * g;
+    // items differ in length (p90 / mean ~ 1.25): a single round ends with its slowest item; many rounds of
+    // dynamically scheduled items end about 0.8 item lengths after the mean load per slot
+    const double rounds = n <= slots ? 1.3 : n / slots + 0.8;
+    const int offsets = (kvol + g - 1) / g;
+    double item = fixed + offsets * nchunks * t_stage;
+    if (2 * n <= slots) item *= 0.65;
+    const double fold = g > 1 ? 0.5 * (2 * g - 1) * tile_mb / 3.0 : 0.0;  // MB / (3 TB/s) = us; half of it hides under other items
+    const double t = rounds * item + fold;
+    if (g == 1 || t < best) best = t, best_g = g;
+  }
+  return best_g;
 }
 
 // Launch shape of one layer.  The 128-row tile (FSF_SPCONV_TM=128) loads each weight fragment once per 128 rows and rounds
@@ -548,8 +683,12 @@ static SpconvPlan spconv_plan(int64_t m_out, int cin, int cout, int kvol) {
   const bool big = tm_env == 128 && fast;
   p.tm = big ? 128 : SC_TM;
   p.tiles = (m_out + p.tm - 1) / p.tm;
-  p.ksplit = pick_ksplit(p.tiles, p.cout_blocks, kvol, big ? 256 : 512);
+  p.ksplit = pick_ksplit(p.tiles, p.cout_blocks, kvol, (cin + SC_KC - 1) / SC_KC, m_out, cout, big ? 256 : 512);
   return p;
+}
+
+static int64_t spconv_queue_bytes(int64_t tiles, int cout_blocks, int ksplit) {
+  return fsf_align_up((SC_NXCD + (ksplit > 1 ? tiles * cout_blocks : 0)) * (int64_t)sizeof(int), 256);
 }
 
 }  // namespace fsf
@@ -572,11 +711,11 @@ extern "C" int fsf_spconv_transpose_weight(const float* weight, int32_t kvol, in
   return FSF_OK;
 }
 
-extern "C" int64_t fsf_spconv_workspace_bytes(int64_t m_out, int32_t cout, int32_t kvol) {
-  // (the channel count of the input is not known here: take the larger of the two possible launch shapes)
-  const SpconvPlan a = spconv_plan(m_out, SC_KC, cout, kvol), b = spconv_plan(m_out, 16, cout, kvol);
-  const int g = a.ksplit > b.ksplit ? a.ksplit : b.ksplit;
-  return g > 1 ? fsf_align_up((int64_t)g * m_out * cout * 4, 256) + 256 : 256;
+extern "C" int64_t fsf_spconv_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout, int32_t kvol) {
+  if (m_out <= 0 || cin < 1 || cout < 1 || kvol < 1) return 256;
+  const SpconvPlan p = spconv_plan(m_out, cin, cout, kvol);
+  return (p.ksplit > 1 ? fsf_align_up((int64_t)p.ksplit * m_out * cout * 4, 256) : 0) +
+         spconv_queue_bytes(p.tiles, p.cout_blocks, p.ksplit);
 }
 
 extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float* weight_t, int32_t kvol,
@@ -593,11 +732,20 @@ extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, 
   const SpconvPlan plan = spconv_plan(m_out, cin, cout, kvol);
   if (plan.tiles >= (int64_t)1 << 31) return FSF_ERR_UNSUPPORTED;
   const int ksplit = plan.ksplit;
-  if (workspace_bytes < fsf_spconv_workspace_bytes(m_out, cout, kvol) || (ksplit > 1 && !workspace)) return FSF_ERR_WORKSPACE;
-  SpconvArgs a{feat, weight_t, nbr, scale, shift, residual, out, (float*)workspace, m_in, m_out,
-               (int)cin, (int)cout, (int)kvol, (int)relu, ksplit};
-  const dim3 grid((unsigned)plan.tiles, plan.cout_blocks, ksplit);
+  if (workspace_bytes < fsf_spconv_workspace_bytes(m_out, cin, cout, kvol)) return FSF_ERR_WORKSPACE;
+  if (!workspace) return FSF_ERR_WORKSPACE;
   const bool fast = (cin % SC_KC) == 0;
+  // workspace = [ksplit partial tiles][work-queue counters]
+  int* queue = reinterpret_cast<int*>((char*)workspace + (ksplit > 1 ? fsf_align_up((int64_t)ksplit * m_out * cout * 4, 256) : 0));
+  SpconvArgs a{feat, weight_t, nbr, scale, shift, residual, out, (float*)workspace, m_in, m_out,
+               (int)cin, (int)cout, (int)kvol, (int)relu, ksplit, queue, (int)plan.tiles, plan.cout_blocks};
+  dim3 grid((unsigned)plan.tiles, plan.cout_blocks, ksplit);
+  if (fast) {  // persistent: one workgroup per resident slot
+    const int64_t items = plan.tiles * plan.cout_blocks * ksplit;
+    const int64_t slots = plan.tm == 128 ? 256 : 512;
+    grid = dim3((unsigned)(items < slots ? items : slots), 1, 1);
+    FSF_HIP_TRY(hipMemsetAsync(queue, 0, spconv_queue_bytes(plan.tiles, plan.cout_blocks, ksplit), stream));
+  }
 #define FSF_SPCONV_LAUNCH(KERNEL, SMEM_T)                                                                            \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
@@ -622,7 +770,7 @@ extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, 
     else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<128>), S128_64);
   }
 #undef FSF_SPCONV_LAUNCH
-  if (ksplit > 1)
+  if (ksplit > 1 && !fast)
     hipLaunchKernelGGL(spconv_reduce_kernel, dim3(fsf_stream_grid(m_out * (cout / 4), 256)), dim3(256), 0, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;

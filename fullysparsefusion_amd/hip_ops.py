@@ -34,7 +34,7 @@ _ARGTYPES = {
     "fsf_rulebook_strided": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P],
     "fsf_rulebook_to_pairs": [_P, c_i64, c_i32, _P, c_i64, _P, _P],
     "fsf_spconv_transpose_weight": [_P, c_i32, c_i32, c_i32, _P, _P],
-    "fsf_spconv_workspace_bytes": [c_i64, c_i32, c_i32],
+    "fsf_spconv_workspace_bytes": [c_i64, c_i32, c_i32, c_i32],
     "fsf_spconv_forward": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
     "fsf_spconv_backward_weight_workspace_bytes": [c_i64, c_i32, c_i32, c_i32],
     "fsf_spconv_backward_weight": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
@@ -366,7 +366,7 @@ def spconv_forward(feat: torch.Tensor, weight_t: torch.Tensor, nbr: torch.Tensor
         residual = residual.contiguous()
         assert residual.shape == out.shape
     h = _L()
-    ws = _lib.workspace(h.fsf_spconv_workspace_bytes(m_out, cout, kvol), feat.device)
+    ws = _lib.workspace(h.fsf_spconv_workspace_bytes(m_out, cin, cout, kvol), feat.device)
     check(h.fsf_spconv_forward(ptr(feat), m_in, cin, ptr(weight_t), kvol, cout, ptr(nbr), m_out, ptr(scale), ptr(shift),
                                ptr(residual), int(bool(relu)), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_spconv_forward")

@@ -224,13 +224,15 @@ int fsf_rulebook_to_pairs(const int32_t* nbr, int64_t m_out, int32_t kvol, int32
  *   feat f32 [m_in,cin] (cin % 16 == 0); weight_t f32 [kvol,cout,cin] = the spconv v1 weight
  *   [kz,ky,kx,Cin,Cout] transposed once per layer by fsf_spconv_transpose_weight; scale/shift f32 [cout] or
  *   NULL (shift alone = bias); residual f32 [m_out,cout] or NULL (added before the ReLU); relu 0/1.
- * One launch per layer (plus a fold of partial tiles when a small layer splits its offset loop over more
- * workgroups; the workspace holds those partials); fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32 fma
- * accumulation in a fixed order, deterministic.
+ * One launch per layer: persistent workgroups (2 per CU) pull (tile, cout block, offset split) work items from
+ * per-XCD queues; a layer that splits its offset loop keeps the partial tiles in the workspace and the workgroup
+ * that finishes a tile last folds them in split order (the workspace also holds the queue words and is always
+ * required: fsf_spconv_workspace_bytes).  fp32 MFMA (v_mfma_f32_16x16x4_f32), exact fp32 fma accumulation in
+ * a fixed order, deterministic.
  */
 int fsf_spconv_transpose_weight(const float* weight, int32_t kvol, int32_t cin, int32_t cout, float* weight_t,
                                 void* stream);
-int64_t fsf_spconv_workspace_bytes(int64_t m_out, int32_t cout, int32_t kvol);
+int64_t fsf_spconv_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout, int32_t kvol);
 int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float* weight_t, int32_t kvol,
                        int32_t cout, const int32_t* nbr, int64_t m_out, const float* scale, const float* shift,
                        const float* residual, int32_t relu, float* out, void* workspace, int64_t workspace_bytes,
