@@ -115,16 +115,16 @@ __device__ __forceinline__ void fetch_item(const SpconvArgs& a, int xcd, unsigne
 // The tile's [64][kvol] block of the neighbour table is contiguous in HBM: it is staged through LDS with
 // coalesced loads (`stage`, >= 64*kvol ints), then each wave compacts offsets k = wave, wave+4, ...
 // rl_in holds ELEMENT offsets (input row * cin) so the gather needs no 64-bit multiply per row.
-template <int TM>
+template <int TM, int NT = 256>
 __device__ __forceinline__ void build_row_lists(const SpconvArgs& a, int64_t o0, int zsplit, int32_t* stage, int32_t* rl_in,
                                                 uint8_t* rl_loc, int32_t* rl_cnt, int32_t* act_k, int32_t* act_n) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t rows_left = a.m_out - o0;
   const int nvalid = (int)((rows_left < TM ? rows_left : TM) * a.kvol);
   const int32_t* src = a.nbr + o0 * a.kvol;
-  for (int t = tid; t < TM * a.kvol; t += 256) stage[t] = (t < nvalid) ? src[t] : -1;
+  for (int t = tid; t < TM * a.kvol; t += NT) stage[t] = (t < nvalid) ? src[t] : -1;
   __syncthreads();
-  for (int k = wave; k < a.kvol; k += 4) {
+  for (int k = wave; k < a.kvol; k += NT / 64) {
     int base = 0;
 #pragma unroll
     for (int h = 0; h < TM / 64; ++h) {  // 64 tile rows per ballot, appended in row order
@@ -162,11 +162,11 @@ __device__ __forceinline__ void store_f4_write_through(float* p, float4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
 }
 
-template <int TN, int TM = SC_TM, bool WT = false>
+template <int TN, int TM = SC_TM, bool WT = false, int NT = 256>
 __device__ __forceinline__ void write_tile(const SpconvArgs& a, const float* Cs, int64_t o0, int n0, int zsplit) {
   constexpr int CS_STRIDE = TN + 4;
   constexpr int F4_PER_ROW = TN / 4;
-  constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+  constexpr int ROWS_PER_PASS = NT / F4_PER_ROW;
   // a thread keeps the same 4 columns for all of its rows: the BN affine is loaded once
   const int c4 = (threadIdx.x % F4_PER_ROW) * 4;
   const int r0 = threadIdx.x / F4_PER_ROW;
@@ -208,11 +208,11 @@ __device__ __forceinline__ void write_tile(const SpconvArgs& a, const float* Cs,
 // of the other splits into the result — in split order, its own contribution taken from LDS, so the sum is the same
 // fixed-order sum the stand-alone fold kernel computes — and applies the epilogue.  Release/acquire at agent scope:
 // the partial tiles cross XCDs, whose L2s are not coherent with each other.
-template <int TN, int TM>
+template <int TN, int TM, int NT>
 __device__ __forceinline__ void fold_tile(const SpconvArgs& a, const float* Cs, int64_t o0, int n0, int zsplit) {
   constexpr int CS_STRIDE = TN + 4;
   constexpr int F4_PER_ROW = TN / 4;
-  constexpr int ROWS_PER_PASS = 256 / F4_PER_ROW;
+  constexpr int ROWS_PER_PASS = NT / F4_PER_ROW;
   const int c4 = (threadIdx.x % F4_PER_ROW) * 4;
   const int r0 = threadIdx.x / F4_PER_ROW;
   const int col = n0 + c4;
@@ -258,12 +258,15 @@ __device__ long long fsf_dbg[4096 * 8];
 
 // ------------------------------------------------------------------------------------------------------
 // Fast path: cin % 64 == 0.  LDS-DMA double-buffered A tile, register double-buffered B, one barrier per stage.
-template <int TN, int TM>
-__global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel(SpconvArgs a) {
+// NW waves per workgroup: 4 (each wave owns TN/4 columns) or 8 (TN/8 columns: twice the waves per SIMD to hide the
+// per-stage barrier, LDS and load latency behind, half the B and accumulator registers per wave).
+template <int TN, int TM, int NW>
+__global__ void __launch_bounds__(NW * 64, (TM == 64 ? 2 : 1) * NW / 4) spconv_fwd_dma_kernel(SpconvArgs a) {
   using SM = SpconvSmem<TN, TM>;
+  constexpr int NT = NW * 64;
   constexpr int ABUF = TM * SC_AROW;  // floats per A buffer
   constexpr int CS_STRIDE = SM::CS_STRIDE;
-  constexpr int WCOLS = TN / 4;    // columns per wave
+  constexpr int WCOLS = TN / NW;   // columns per wave
   constexpr int NCT = WCOLS / 16;  // 16-column MFMA tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Cs = reinterpret_cast<float*>(smem);                         // [TM + 1][CS_STRIDE], row TM = dump row
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
 
   FSF_STAMP(0);
   // the A buffers double as the staging area of the neighbour-table block
-  build_row_lists<TM>(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
+  build_row_lists<TM, NT>(a, o0, zsplit, reinterpret_cast<int32_t*>(As), rl_in, rl_loc, rl_cnt, act_k, act_n);
   FSF_STAMP(1);
   const int nstages = act_n[0] * nchunks;
 
@@ -309,8 +312,8 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
     const int cnt = rl_cnt[k];
     float* abuf = As + buf * ABUF;
 #pragma unroll
-    for (int it = 0; it < TM / 16; ++it) {
-      const int g = wave + 4 * it;  // row group: rows 4g .. 4g+3
+    for (int it = 0; it < TM / (4 * NW); ++it) {
+      const int g = wave + NW * it;  // row group: rows 4g .. 4g+3
       if (4 * g < cnt) {
         int j = 4 * g + (lane >> 4);
         const int phys = lane & 15;
@@ -351,7 +354,7 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
   // C (incl. the dump row) is zeroed while the first stage is in flight.  The A buffers are NOT cleared: rows past an
   // offset's live count hold stale data, but an MFMA output row depends on its own A row only and those rows land in
   // the dump row, which is never read back.
-  for (int t = tid; t < SM::CS_FLOATS / 4; t += 256) reinterpret_cast<float4*>(Cs)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = tid; t < SM::CS_FLOATS / 4; t += NT) reinterpret_cast<float4*>(Cs)[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();  // (the compiler drains the DMA before the barrier) A[0] complete and visible
   FSF_STAMP(3);
 
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
   // (adjacent pair -> one 8-byte LDS access) of compact rows rb*16 + kgrp*4 + r.
   constexpr int MAXRB = TM / 16;
   f32x4 acc[MAXRB][NCT];
-  int loc[MAXRB][4];
+  uint32_t locp[MAXRB];  // 4 local output rows (one byte each) of this lane's compact rows; dead rows -> dump row TM
   int chunk_c = 0, ki = 0;
   for (int s = 0; s < nstages; ++s) {
     const int cur = s & 1;
@@ -393,20 +396,19 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
           if (rb < nrb) {
             // compacted row -> local output row (4 consecutive bytes); rows past cnt go to the dump row
             const uint32_t packed = *reinterpret_cast<const uint32_t*>(rl_loc + k * TM + rb * 16 + kgrp * 4);
+            const int live = cnt - (rb * 16 + kgrp * 4);  // this lane's rows r < live exist
+            const uint32_t keep = live >= 4 ? 0xffffffffu : (live <= 0 ? 0u : (1u << (8 * live)) - 1u);
+            locp[rb] = (packed & keep) | ((uint32_t)TM * 0x01010101u & ~keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int j = rb * 16 + kgrp * 4 + r;
-              loc[rb][r] = (j < cnt) ? (int)((packed >> (8 * r)) & 0xffu) : TM;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float* cp = Cs + loc[rb][r] * CS_STRIDE + wcol0 + NCT * lrow;
+              const int l = (int)((locp[rb] >> (8 * r)) & 0xffu);
+              const float* cp = Cs + l * CS_STRIDE + wcol0 + NCT * lrow;
               if constexpr (NCT == 2) {
                 const float2 c2 = *reinterpret_cast<const float2*>(cp);
-                acc[rb][0][r] = (loc[rb][r] < TM) ? c2.x : 0.0f;
-                acc[rb][1][r] = (loc[rb][r] < TM) ? c2.y : 0.0f;
+                acc[rb][0][r] = (l < TM) ? c2.x : 0.0f;
+                acc[rb][1][r] = (l < TM) ? c2.y : 0.0f;
               } else {
-                acc[rb][0][r] = (loc[rb][r] < TM) ? cp[0] : 0.0f;
+                acc[rb][0][r] = (l < TM) ? cp[0] : 0.0f;
               }
             }
           }
@@ -450,7 +452,7 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
           if (rb < nrb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float* cp = Cs + loc[rb][r] * CS_STRIDE + wcol0 + NCT * lrow;
+              float* cp = Cs + (int)((locp[rb] >> (8 * r)) & 0xffu) * CS_STRIDE + wcol0 + NCT * lrow;
               if constexpr (NCT == 2) *reinterpret_cast<float2*>(cp) = make_float2(acc[rb][0][r], acc[rb][1][r]);
               else cp[0] = acc[rb][0][r];
             }
@@ -479,7 +481,7 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
 #endif
   }
   FSF_STAMP(4);
-  write_tile<TN, TM, true>(a, Cs, o0, n0, zsplit);
+  write_tile<TN, TM, true, NT>(a, Cs, o0, n0, zsplit);
   if (a.ksplit > 1) {
     // publish the partial tile (write-through stores), then take an arrival ticket: every wave drains its stores,
     // barrier, ONE lane draws the relaxed agent-scope ticket; the last arriver acquires once (drops this CU's stale L1
@@ -493,7 +495,7 @@ __global__ void __launch_bounds__(256, (TM == 64 ? 2 : 1)) spconv_fwd_dma_kernel
       item[3] = ticket;
     }
     __syncthreads();
-    if (item[3] == a.ksplit - 1) fold_tile<TN, TM>(a, Cs, o0, n0, zsplit);
+    if (item[3] == a.ksplit - 1) fold_tile<TN, TM, NT>(a, Cs, o0, n0, zsplit);
   }
   FSF_STAMP(5);
 #ifdef FSF_ABL_TIMING
@@ -746,7 +748,7 @@ extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, 
     grid = dim3((unsigned)(items < slots ? items : slots), 1, 1);
     FSF_HIP_TRY(hipMemsetAsync(queue, 0, spconv_queue_bytes(plan.tiles, plan.cout_blocks, ksplit), stream));
   }
-#define FSF_SPCONV_LAUNCH(KERNEL, SMEM_T)                                                                            \
+#define FSF_SPCONV_LAUNCH(KERNEL, SMEM_T, NTHREADS)                                                                            \
   do {                                                                                                               \
     static bool attr_set = false;                                                                                    \
     const size_t smem_bytes = SMEM_T::bytes();                                                                       \
@@ -754,20 +756,26 @@ extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, 
       FSF_HIP_TRY(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes)); \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL(KERNEL, grid, dim3(256), smem_bytes, stream, a);                                              \
+    hipLaunchKernelGGL(KERNEL, grid, dim3(NTHREADS), smem_bytes, stream, a);                                         \
   } while (0)
   using S64_64 = SpconvSmem<64, 64>;
   using S128_64 = SpconvSmem<128, 64>;
   using S64_128 = SpconvSmem<64, 128>;
   using S128_128 = SpconvSmem<128, 128>;
+  static const int nw_env = [] {  // FSF_SPCONV_NW = 4 | 8 forces the waves per workgroup of the 128-column kernel
+    const char* e = getenv("FSF_SPCONV_NW");
+    return e ? atoi(e) : 0;
+  }();
+  const bool wide = nw_env != 4;
   if (cout <= 64) {
-    if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 128>), S64_128);
-    else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 64>), S64_64);
-    else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<64>), S64_64);
+    if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 128, 4>), S64_128, 256);
+    else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 64, 4>), S64_64, 256);
+    else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<64>), S64_64, 256);
   } else {
-    if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 128>), S128_128);
-    else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 64>), S128_64);
-    else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<128>), S128_64);
+    if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 128, 4>), S128_128, 256);
+    else if (fast && wide) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 64, 8>), S128_64, 512);
+    else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 64, 4>), S128_64, 256);
+    else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<128>), S128_64, 256);
   }
 #undef FSF_SPCONV_LAUNCH
   if (ksplit > 1 && !fast)
