@@ -173,7 +173,7 @@ def spconv_roofline(model, inp, steps, hot_path_only=False):
                 traffic = json.load(f)["spconv_forward"]["hbm_bytes_per_api_launch"]
             traffic_src = "profiles/" + name
             break
-    return dict(bound="mfma", kernel="fsf::spconv_fwd_dma_kernel (+ spconv_reduce_kernel)", achieved=round(achieved, 3),
+    return dict(bound="mfma", kernel="fsf::spconv_fwd_dma_kernel (one fsf_spconv_forward call = queue memset + kernel)", achieved=round(achieved, 3),
                 peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                 traffic=traffic, traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
                 traffic_source=traffic_src,

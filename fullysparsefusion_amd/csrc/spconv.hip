@@ -772,7 +772,8 @@ extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, 
     else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 64, 4>), S64_64, 256);
     else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<64>), S64_64, 256);
   } else {
-    if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 128, 4>), S128_128, 256);
+    if (fast && plan.tm == 128 && wide) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 128, 8>), S128_128, 512);
+    else if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 128, 4>), S128_128, 256);
     else if (fast && wide) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 64, 8>), S128_64, 512);
     else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<128, 64, 4>), S128_64, 256);
     else FSF_SPCONV_LAUNCH((spconv_fwd_generic_kernel<128>), S128_64, 256);
