@@ -306,20 +306,30 @@ __global__ void __launch_bounds__(NW * 64, (TM == 64 ? 2 : 1) * NW / 4) spconv_f
 
   f32x4 bcur[NCT][SC_NSTEPS], bnext[NCT][SC_NSTEPS];
 
-  // LDS-DMA gather of stage s into A buffer `buf`: one wave instruction moves 4 rows (64 lanes x 16 B); wave w
-  // takes row groups w, w+4, ...; a group is issued iff its first row is live (wave-uniform branch)
-  auto issue_gather = [&](int k, int cin0, int buf) {
-    const int cnt = rl_cnt[k];
+  // LDS-DMA gather of a stage into A buffer `buf`: one wave instruction moves 4 rows (64 lanes x 16 B); wave w takes
+  // row groups w, w+NW, ...; a group is issued iff its first row is live (wave-uniform branch).  The lane's source rows
+  // (goff, element offsets) are read from the row list once per OFFSET and reused for all of its cin chunks, and the
+  // (offset, count) pair of the next stage is carried in registers: a stage starts with no LDS round trip in front
+  // of its DMA and B loads.
+  constexpr int NIT = TM / (4 * NW);
+  int goff[NIT];
+  auto load_goff = [&](int k, int cnt) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      int j = 4 * (wave + NW * it) + (lane >> 4);
+      j = j < cnt ? j : cnt - 1;  // rows past cnt re-read the last live row (finite filler)
+      goff[it] = rl_in[k * TM + (j < 0 ? 0 : j)];
+    }
+  };
+  auto issue_gather = [&](int cnt, int cin0, int buf) {
     float* abuf = As + buf * ABUF;
 #pragma unroll
-    for (int it = 0; it < TM / (4 * NW); ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int g = wave + NW * it;  // row group: rows 4g .. 4g+3
       if (4 * g < cnt) {
-        int j = 4 * g + (lane >> 4);
-        const int phys = lane & 15;
-        const int chunk = phys ^ (j & 15);  // logical 16-B chunk that must land at physical slot `phys` of row j
-        j = j < cnt ? j : cnt - 1;          // rows past cnt re-read the last live row (finite filler)
-        const float* src = a.feat + rl_in[k * TM + j] + cin0 + 4 * chunk;
+        const int j = 4 * g + (lane >> 4);
+        const int chunk = (lane & 15) ^ (j & 15);  // logical 16-B chunk that must land at physical slot lane&15 of row j
+        const float* src = a.feat + goff[it] + cin0 + 4 * chunk;
 #ifndef FSF_ABL_NO_GATHER
         __builtin_amdgcn_global_load_lds(src, abuf + 4 * g * SC_AROW, 16, 0, 0);
 #else
@@ -346,9 +356,13 @@ __global__ void __launch_bounds__(NW * 64, (TM == 64 ? 2 : 1) * NW / 4) spconv_f
     }
   };
 
+  int k = 0, cnt = 0;  // offset and live-row count of the current stage
   if (nstages > 0) {
-    issue_gather(act_k[0], 0, 0);
-    load_b(act_k[0], 0, bcur);
+    k = act_k[0];
+    cnt = rl_cnt[k];
+    load_goff(k, cnt);
+    issue_gather(cnt, 0, 0);
+    load_b(k, 0, bcur);
   }
   FSF_STAMP(2);
   // C (incl. the dump row) is zeroed while the first stage is in flight.  The A buffers are NOT cleared: rows past an
@@ -368,10 +382,16 @@ __global__ void __launch_bounds__(NW * 64, (TM == 64 ? 2 : 1) * NW / 4) spconv_f
   int chunk_c = 0, ki = 0;
   for (int s = 0; s < nstages; ++s) {
     const int cur = s & 1;
+    int nk = k, ncnt = cnt;
     if (s + 1 < nstages) {
       const bool same_k = chunk_c + 1 < nchunks;
-      const int nk = act_k[same_k ? ki : ki + 1], ncin0 = same_k ? (chunk_c + 1) * SC_KC : 0;
-      issue_gather(nk, ncin0, cur ^ 1);  // lands in the other A buffer while the matrix cores work on stage s
+      const int ncin0 = same_k ? (chunk_c + 1) * SC_KC : 0;
+      if (!same_k) {
+        nk = act_k[ki + 1];
+        ncnt = rl_cnt[nk];
+        load_goff(nk, ncnt);
+      }
+      issue_gather(ncnt, ncin0, cur ^ 1);  // lands in the other A buffer while the matrix cores work on stage s
 #ifndef FSF_ABL_NO_BLOAD
       load_b(nk, ncin0, bnext);
 #else
@@ -382,8 +402,6 @@ __global__ void __launch_bounds__(NW * 64, (TM == 64 ? 2 : 1) * NW / 4) spconv_f
 #endif
     }
     {
-      const int k = act_k[ki];
-      const int cnt = rl_cnt[k];
       const int nrb = (cnt + 15) >> 4;
       const float* abuf = As + cur * ABUF;
 #ifdef FSF_ABL_NO_CRMW
@@ -464,6 +482,8 @@ __global__ void __launch_bounds__(NW * 64, (TM == 64 ? 2 : 1) * NW / 4) spconv_f
       chunk_c = 0;
       ++ki;
     }
+    k = nk;
+    cnt = ncnt;
     if (s + 1 < nstages) {
       // Pin the first use of the prefetched B fragments HERE (after the MFMA loop): without this hipcc hoists the
       // bcur <- bnext copies above the loop and with them the vmcnt(0) wait, which serialises the prefetch.
