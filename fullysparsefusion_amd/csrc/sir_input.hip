@@ -7,7 +7,7 @@
 //   `features * rel` product: two concat copies, three skinny GEMMs (K = 3|13, 16, 32: far too thin for a GEMM library),
 //   three norm/act passes and a multiply — about ten launches and ~12 trips of the [n, C] activations through HBM per
 //   block, twelve blocks per frame — become one read of the sources and one write of the GEMM input.
-// HBM-bound: 4(P + Cf + Ce + R) B/row read + 4C B/row written (see the kernel for the two-phase lane mapping).
+// Bytes: 4(P + Cf + Ce + R) B/row read + 4C B/row written; the position MLP runs on the fp32 matrix cores.
 #include "common.h"
 
 namespace fsf {
@@ -30,185 +30,262 @@ struct SirInputArgs {
   int64_t n; int c;
 };
 
+// GELU(y) = y/2 * (1 + erf(y / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. float
+// epsilon; the kernel is instruction-bound and libm's two-branch erff is 35 VALU ops + divergence per element, 60
+// elements per lane per 16 rows).  Branch-free: 1 - erf(u) = poly(t) * exp(-u^2), t = 1 / (1 + p u), u = |y| / sqrt 2;
+// for y < 0 the factor (1 + erf) IS that product (no cancellation), for y >= 0 it is 2 - product.
+__device__ __forceinline__ float si_gelu(float y) {
+  const float u = fabsf(y) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(u * u * -1.4426950408889634f);
+  const float pe = p * t * e;
+  return 0.5f * y * (y < 0.0f ? pe : 2.0f - pe);
+}
+
 __device__ __forceinline__ float si_act(float y, int act) {
   if (act == 1) return fmaxf(y, 0.0f);
-  if (act == 2) return 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+  if (act == 2) return si_gelu(y);
   return y;
 }
 
-// A wave owns 64 consecutive rows.  Phase A, lane = row: the two thin layers of the position MLP entirely in registers
-// (weights are wave-uniform LDS broadcasts, LayerNorm needs no cross-lane traffic); the 32 hidden values go to LDS.
-// Phase B, lane = channel: row by row, the last layer (transposed weight in LDS), LayerNorm over the wave, activation,
-// product with the concatenated sources, coalesced store.  Rows of phase B are independent: two are interleaved to hide
-// the reduction latency.
-template <int T>
-__global__ void __launch_bounds__(256) sir_input_kernel(SirInputArgs a) {
-  constexpr int CP = T * 64;
-  __shared__ float w3t[SI_MAX_H2 * CP];  // [hidden unit][channel]: 64 consecutive channels per read, conflict-free
-  __shared__ __attribute__((aligned(16))) float sw1[SI_MAX_H1 * SI_MAX_R], sw2[SI_MAX_H2 * SI_MAX_H1];
-  __shared__ float sg1[SI_MAX_H1], sb1[SI_MAX_H1], sg2[SI_MAX_H2], sb2[SI_MAX_H2];
-  __shared__ __attribute__((aligned(16))) float hs[4][SI_MAX_H2][64];  // [wave][hidden unit of layer 2][row of the wave's tile]
+typedef float si_f32x4 __attribute__((ext_vector_type(4)));
+
+// sum over the 4 lanes that share a point row (lane = row + 16 * group)
+__device__ __forceinline__ float si_row_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// The position MLP on the matrix cores, TRANSPOSED: out^T[channel, row] = W[channel, unit] x h^T[unit, row] with
+// v_mfma_f32_16x16x4_f32, the weights as the A operand and 16 point rows as the B operand.  Lane (row = lane & 15,
+// group = lane >> 4) then holds channels 16 t + 4 group + r (r = 0..3) of its row for every 16-channel tile t — which
+// is exactly the B operand of the NEXT layer if that layer walks its units in the order (t, r): the three layers chain
+// through registers with no cross-lane traffic, LayerNorm is an in-lane sum + two shuffles over the 4 lanes of a row,
+// and the activation runs on 1/4 row per lane.  (Before: lane = row for the two thin layers and lane = channel for the
+// wide one, all on the VALU — 9 k FMAs per row were ~40 % of its ~350 wave instructions per row.)
+// The activated [16, C] tile goes through a per-wave LDS slice so that the product with the concatenated sources and
+// the store run with lane = channel (coalesced rows).
+template <int NT3, int ACT>
+__global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
+  constexpr int TS = NT3 * 16 + 4;  // tile row stride (floats): 16-byte rows, 4-bank skew between rows
+  extern __shared__ __attribute__((aligned(16))) char si_smem[];
+  float* w3f = reinterpret_cast<float*>(si_smem);  // [NT3][2][64 lanes][4]: layer-3 weights in fragment order
+  float* g3s = w3f + NT3 * 2 * 64 * 4;             // [NT3 * 16]
+  float* b3s = g3s + NT3 * 16;
+  float* tiles = b3s + NT3 * 16;                   // [4 waves][16 rows][TS]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int t = threadIdx.x; t < SI_MAX_H1 * SI_MAX_R; t += 256) {
-    const int j = t / SI_MAX_R, r = t % SI_MAX_R;
-    sw1[t] = (j < a.h1 && r < a.r_cols) ? a.w1[j * a.r_cols + r] : 0.0f;
+  const int rowl = lane & 15, grp = lane >> 4;
+
+  for (int idx = threadIdx.x; idx < NT3 * 2 * 64; idx += 256) {
+    const int t3 = idx >> 7, t2 = (idx >> 6) & 1, l = idx & 63;
+    const int out = 16 * t3 + (l & 15), in0 = 16 * t2 + 4 * (l >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      w3f[idx * 4 + r] = (out < a.c && in0 + r < a.h2) ? a.w3[(int64_t)out * a.h2 + in0 + r] : 0.0f;
   }
-  for (int t = threadIdx.x; t < SI_MAX_H2 * SI_MAX_H1; t += 256) {
-    const int j = t / SI_MAX_H1, k = t % SI_MAX_H1;
-    sw2[t] = (j < a.h2 && k < a.h1) ? a.w2[j * a.h1 + k] : 0.0f;
+  for (int t = threadIdx.x; t < NT3 * 16; t += 256) {
+    g3s[t] = t < a.c ? a.g3[t] : 0.0f;
+    b3s[t] = t < a.c ? a.b3[t] : 0.0f;
   }
-  if (threadIdx.x < SI_MAX_H1) {
-    sg1[threadIdx.x] = threadIdx.x < a.h1 ? a.g1[threadIdx.x] : 0.f;
-    sb1[threadIdx.x] = threadIdx.x < a.h1 ? a.b1[threadIdx.x] : 0.f;
+  // layers 1 and 2: weight fragments and LayerNorm affine of this lane's channels, in registers for the whole kernel
+  float w1f[4], g1r[4], b1r[4], w2f[2][4], g2r[2][4], b2r[2][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int in = 4 * grp + r;  // A operand: lane (m = rowl, group) supplies W[m][4 group + r]
+    w1f[r] = (rowl < a.h1 && in < a.r_cols) ? a.w1[rowl * a.r_cols + in] : 0.0f;
+    g1r[r] = in < a.h1 ? a.g1[in] : 0.0f;  // D: the same lane holds channel 4 group + r
+    b1r[r] = in < a.h1 ? a.b1[in] : 0.0f;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      w2f[t2][r] = (16 * t2 + rowl < a.h2 && in < a.h1) ? a.w2[(16 * t2 + rowl) * a.h1 + in] : 0.0f;
+      g2r[t2][r] = 16 * t2 + in < a.h2 ? a.g2[16 * t2 + in] : 0.0f;
+      b2r[t2][r] = 16 * t2 + in < a.h2 ? a.b2[16 * t2 + in] : 0.0f;
+    }
   }
-  if (threadIdx.x < SI_MAX_H2) {
-    sg2[threadIdx.x] = threadIdx.x < a.h2 ? a.g2[threadIdx.x] : 0.f;
-    sb2[threadIdx.x] = threadIdx.x < a.h2 ? a.b2[threadIdx.x] : 0.f;
-  }
-  for (int t = threadIdx.x; t < SI_MAX_H2 * CP; t += 256) {
-    const int k = t / CP, c = t - k * CP;
-    w3t[t] = (c < a.c && k < a.h2) ? a.w3[(int64_t)c * a.h2 + k] : 0.0f;
-  }
-  float g3[T], b3[T];  // last layer: lane owns channels lane + 64 t
+  __syncthreads();
+
+  // lane = channel view of the concatenated sources: column lane + 64 t lives in ONE of the three tensors
+  constexpr int T = (NT3 * 16 + 63) / 64;
+  const float* xsrc[T];
+  int64_t xstride[T];
+  float xdiv[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const int c = lane + 64 * t;
-    g3[t] = c < a.c ? a.g3[c] : 0.f;
-    b3[t] = c < a.c ? a.b3[c] : 0.f;
-  }
-  __syncthreads();
-  const float inv_c = 1.0f / (float)a.c;
-  const int64_t tiles = (a.n + 63) / 64;
-  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
-    const int64_t row0 = tile * 64;
-    const int nrow = (int)min((int64_t)64, a.n - row0);
-    // ---- phase A: lane = row.  Hidden values live in this wave's LDS slice (column = lane: conflict-free), the loops
-    // over hidden units stay rolled — unrolled, the compiler hoists all 768 weight reads into registers and spills.
-    {
-      const int64_t row = row0 + (lane < nrow ? lane : nrow - 1);
-      float fc[SI_MAX_R];
-#pragma unroll
-      for (int r = 0; r < SI_MAX_R; ++r) fc[r] = r < a.r_cols ? __fdiv_rn(a.fcl[row * a.fcl_stride + r], a.rel_div) : 0.0f;
-      float (*u2)[64] = hs[wave];
-      float s = 0.0f;
-#pragma unroll 1
-      for (int j = 0; j < a.h1; ++j) {  // rolled (unrolled, the compiler hoists every weight read and runs out of registers);
-        float acc = 0.0f;               // the raw values wait in this lane's LDS column, rows 0..h1-1 of the layer-2 slice
-#pragma unroll
-        for (int r4 = 0; r4 < SI_MAX_R / 4; ++r4) {
-          const float4 w = reinterpret_cast<const float4*>(sw1)[j * (SI_MAX_R / 4) + r4];  // wave-uniform: LDS broadcast
-          acc = fmaf(w.x, fc[4 * r4], acc);
-          acc = fmaf(w.y, fc[4 * r4 + 1], acc);
-          acc = fmaf(w.z, fc[4 * r4 + 2], acc);
-          acc = fmaf(w.w, fc[4 * r4 + 3], acc);
-        }
-        u2[j][lane] = acc;
-        s += acc;
-      }
-      float h1[SI_MAX_H1];
-#pragma unroll
-      for (int j = 0; j < SI_MAX_H1; ++j) h1[j] = j < a.h1 ? u2[j][lane] : 0.0f;
-      float mean = s / (float)a.h1, q = 0.0f;
-#pragma unroll
-      for (int j = 0; j < SI_MAX_H1; ++j) {
-        const float d = j < a.h1 ? h1[j] - mean : 0.0f;
-        q += d * d;
-      }
-      float rstd = rsqrtf(q / (float)a.h1 + a.eps);
-#pragma unroll
-      for (int j = 0; j < SI_MAX_H1; ++j) h1[j] = j < a.h1 ? si_act((h1[j] - mean) * rstd * sg1[j] + sb1[j], a.act) : 0.0f;
-      s = 0.0f;
-#pragma unroll 2
-      for (int j = 0; j < a.h2; ++j) {  // rolled: unrolled, the compiler hoists all 512 weight reads and spills
-        float acc = 0.0f;
-#pragma unroll
-        for (int k4 = 0; k4 < SI_MAX_H1 / 4; ++k4) {
-          const float4 w = reinterpret_cast<const float4*>(sw2)[j * (SI_MAX_H1 / 4) + k4];
-          acc = fmaf(w.x, h1[4 * k4], acc);  // k order = the GEMM's
-          acc = fmaf(w.y, h1[4 * k4 + 1], acc);
-          acc = fmaf(w.z, h1[4 * k4 + 2], acc);
-          acc = fmaf(w.w, h1[4 * k4 + 3], acc);
-        }
-        u2[j][lane] = acc;
-        s += acc;
-      }
-      mean = s / (float)a.h2;
-      q = 0.0f;
-#pragma unroll 4
-      for (int j = 0; j < a.h2; ++j) {
-        const float d = u2[j][lane] - mean;
-        q += d * d;
-      }
-      rstd = rsqrtf(q / (float)a.h2 + a.eps);
-#pragma unroll 2
-      for (int j = 0; j < a.h2; ++j) u2[j][lane] = si_act((u2[j][lane] - mean) * rstd * sg2[j] + sb2[j], a.act);
+    xsrc[t] = a.points;  // (columns >= c read a valid address and are never stored)
+    xstride[t] = a.points_stride;
+    xdiv[t] = 1.0f;
+    if (c < a.p_cols) {
+      xsrc[t] = a.points + c;
+      if (c < 3) xdiv[t] = a.norm[c];
+    } else if (c < a.p_cols + a.f_cols) {
+      xsrc[t] = a.feats + (c - a.p_cols);
+      xstride[t] = a.feats_stride;
+    } else if (c < a.c) {
+      xsrc[t] = a.extra + (c - a.p_cols - a.f_cols);
+      xstride[t] = a.extra_stride;
+      xdiv[t] = a.extra_div;
     }
-    // (hs[wave] is private to this wave: no workgroup barrier, the LDS writes are ordered before the reads below)
-    // ---- phase B: lane = channel
-    // eight rows of sources are requested before the first of them is needed: with ~0.7 KB per row and a handful of
-    // waves per CU, fewer rows in flight leave the HBM pipe mostly empty
-    constexpr int RB = 8;
-    for (int i0 = 0; i0 < nrow; i0 += RB) {
-      float x[RB][T];
+  }
+  bool xneed[T];  // wave-uniform: does 64-column tile t hold a column that is divided (xyz, or `extra`)?
 #pragma unroll
-      for (int rr = 0; rr < RB; ++rr) {
-        const int64_t row = row0 + min(i0 + rr, nrow - 1);
+  for (int t = 0; t < T; ++t) xneed[t] = t == 0 || (a.e_cols > 0 && 64 * t + 63 >= a.p_cols + a.f_cols && 64 * t < a.c);
+  float* tile = tiles + wave * 16 * TS;
+  const float inv_h1 = 1.0f / (float)a.h1, inv_h2 = 1.0f / (float)a.h2, inv_c = 1.0f / (float)a.c;
+  const int64_t groups = (a.n + 15) / 16;
+  // MFMA-layout load of the layer-1 input (f_cluster) of a group: lane (row, group) reads columns 4 group + r
+  auto load_fcl = [&](int64_t gi, float (&v)[4]) {
+    const int64_t r0 = gi * 16;
+    const int nr = (int)min((int64_t)16, a.n - r0);
+    const int64_t rc = r0 + (rowl < nr ? rowl : nr - 1);  // rows past n repeat the last one (finite, never stored)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = 4 * grp + r < a.r_cols ? a.fcl[rc * a.fcl_stride + 4 * grp + r] : 0.0f;
+  };
+  const int64_t gstep = (int64_t)gridDim.x * 4;
+  float xnext[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((int64_t)blockIdx.x * 4 + wave < groups) load_fcl((int64_t)blockIdx.x * 4 + wave, xnext);
+  for (int64_t gi = (int64_t)blockIdx.x * 4 + wave; gi < groups; gi += gstep) {
+    const int64_t row0 = gi * 16;
+    const int nrow = (int)min((int64_t)16, a.n - row0);
+    // ---- the group's sources are requested first, lane = channel: 16 rows x T loads per lane stay in flight under the
+    // whole position MLP (a wave has only one other wave on its SIMD to hide HBM latency behind)
+    // (the MLP input of the NEXT group is requested here too: it is the first thing a group needs, and waiting for it
+    // with nothing else to do was 40 % of the wave cycles)
+    float xin[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xin[r] = xnext[r];
+    if (gi + gstep < groups) load_fcl(gi + gstep, xnext);
+    float x[16][T];
+    {
+      const float* rp[T];  // row pointers walk down the group: one 64-bit add per load instead of a 64-bit multiply
+#pragma unroll
+      for (int t = 0; t < T; ++t) rp[t] = xsrc[t] + row0 * xstride[t];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const int c = lane + 64 * t;
-          float v = 0.0f;
-          if (c < a.p_cols) v = a.points[row * a.points_stride + c];
-          else if (c < a.p_cols + a.f_cols) v = a.feats[row * a.feats_stride + (c - a.p_cols)];
-          else if (c < a.c) v = a.extra[row * a.extra_stride + (c - a.p_cols - a.f_cols)];
-          x[rr][t] = v;
+          x[i][t] = *rp[t];
+          if (i + 1 < nrow) rp[t] += xstride[t];  // (wave-uniform; rows past n repeat the last one)
         }
       }
-      // last layer for the eight rows at once: one read of the weight column block feeds all of them.  (The kernel is
-      // VALU-bound — a wave64 VALU op occupies its SIMD for 4 cycles, ~300 of them per row — and pairing rows into
-      // v_pk_fma_f32 was measured 2x SLOWER on gfx950, so these stay scalar FMAs.)
-      float y[RB][T];
+    }
+    // ---- layer 1: K = r_cols (<= 16), one MFMA per r
+    si_f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int rr = 0; rr < RB; ++rr)
+    for (int r = 0; r < 4; ++r) xin[r] = 4 * grp + r < a.r_cols ? __fdiv_rn(xin[r], a.rel_div) : 0.0f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) y[rr][t] = 0.0f;
-#pragma unroll 2
-      for (int k = 0; k < a.h2; ++k) {
-        float w[T];
+    for (int r = 0; r < 4; ++r) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1f[r], xin[r], acc1, 0, 0, 0);
+    float h1v[4];
+    {
+      float s = 0.0f;
 #pragma unroll
-        for (int t = 0; t < T; ++t) w[t] = w3t[k * CP + lane + 64 * t];
-        const float4 ha = *reinterpret_cast<const float4*>(&hs[wave][k][i0]);  // rows i0..i0+7 (tile rows past nrow hold
-        const float4 hb = *reinterpret_cast<const float4*>(&hs[wave][k][i0 + 4]);  // the clamped last row: finite)
-        const float hk[RB] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+      for (int r = 0; r < 4; ++r) s += 4 * grp + r < a.h1 ? acc1[r] : 0.0f;
+      const float mean = si_row_sum(s) * inv_h1;
+      float q = 0.0f;
 #pragma unroll
-        for (int rr = 0; rr < RB; ++rr)
-#pragma unroll
-          for (int t = 0; t < T; ++t) y[rr][t] = fmaf(w[t], hk[rr], y[rr][t]);
+      for (int r = 0; r < 4; ++r) {
+        const float d = 4 * grp + r < a.h1 ? acc1[r] - mean : 0.0f;
+        q += d * d;
       }
+      const float rstd = rsqrtf(si_row_sum(q) * inv_h1 + a.eps);
 #pragma unroll
-      for (int rr = 0; rr < RB; ++rr) {
-        const int i = i0 + rr;
-        if (i < nrow) {  // wave-uniform
-          float s = 0.0f;
+      for (int r = 0; r < 4; ++r)
+        h1v[r] = 4 * grp + r < a.h1 ? si_act((acc1[r] - mean) * rstd * g1r[r] + b1r[r], ACT) : 0.0f;
+    }
+    // ---- layer 2: two 16-channel tiles, K = h1
+    si_f32x4 acc2[2];
 #pragma unroll
-          for (int t = 0; t < T; ++t) s += (lane + 64 * t < a.c) ? y[rr][t] : 0.0f;
-          const float mean = fsf_wave_sum(s) * inv_c;
-          float q = 0.0f;
+    for (int t2 = 0; t2 < 2; ++t2) {
+      acc2[t2] = si_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            const float d = (lane + 64 * t < a.c) ? y[rr][t] - mean : 0.0f;
-            q += d * d;
-          }
-          const float rstd = rsqrtf(fsf_wave_sum(q) * inv_c + a.eps);
-          float* orow = a.out + (row0 + i) * a.out_stride;
+      for (int r = 0; r < 4; ++r) acc2[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[t2][r], h1v[r], acc2[t2], 0, 0, 0);
+    }
+    float h2v[2][4];
+    {
+      float s = 0.0f;
 #pragma unroll
-          for (int t = 0; t < T; ++t) {
-            const int c = lane + 64 * t;
-            float xv = x[rr][t];
-            if (t == 0 && c < 3) xv = __fdiv_rn(xv, a.norm[c]);  // true divisions, as the reference's `/`
-            if (a.e_cols > 0 && c >= a.p_cols + a.f_cols) xv = __fdiv_rn(xv, a.extra_div);  // (wave-uniform guard first)
-            if (c < a.c) orow[c] = xv * si_act((y[rr][t] - mean) * rstd * g3[t] + b3[t], a.act);
-          }
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += 16 * t2 + 4 * grp + r < a.h2 ? acc2[t2][r] : 0.0f;
+      const float mean = si_row_sum(s) * inv_h2;
+      float q = 0.0f;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = 16 * t2 + 4 * grp + r < a.h2 ? acc2[t2][r] - mean : 0.0f;
+          q += d * d;
         }
+      const float rstd = rsqrtf(si_row_sum(q) * inv_h2 + a.eps);
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          h2v[t2][r] = 16 * t2 + 4 * grp + r < a.h2 ? si_act((acc2[t2][r] - mean) * rstd * g2r[t2][r] + b2r[t2][r], ACT) : 0.0f;
+    }
+    // ---- layer 3: NT3 tiles, K = h2 walked in (t2, r) order = the order the lanes hold h2v
+    si_f32x4 acc3[NT3];
+#pragma unroll
+    for (int t3 = 0; t3 < NT3; ++t3) {
+      acc3[t3] = si_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const si_f32x4 wf = *reinterpret_cast<const si_f32x4*>(w3f + ((t3 * 2 + t2) * 64 + lane) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc3[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[r], h2v[t2][r], acc3[t3], 0, 0, 0);
+      }
+    }
+    {
+      // channels >= c have zero weights: their accumulators are exactly 0 and drop out of the sum; for the squared
+      // deviations they are masked by a per-lane limit (kept opaque so the 4 NT3 compares are redone per group instead
+      // of living in 2 x 4 NT3 scalar registers for the whole kernel)
+      int lim = a.c - 4 * grp;
+      asm volatile("" : "+v"(lim));
+      float s = 0.0f;
+#pragma unroll
+      for (int t3 = 0; t3 < NT3; ++t3)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc3[t3][r];
+      const float mean = si_row_sum(s) * inv_c;
+      float q = 0.0f;
+#pragma unroll
+      for (int t3 = 0; t3 < NT3; ++t3)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = 16 * t3 + r < lim ? acc3[t3][r] - mean : 0.0f;
+          q += d * d;
+        }
+      const float rstd = rsqrtf(si_row_sum(q) * inv_c + a.eps);
+#pragma unroll
+      for (int t3 = 0; t3 < NT3; ++t3) {
+        const int ch0 = 16 * t3 + 4 * grp;
+        const float4 gv = *reinterpret_cast<const float4*>(g3s + ch0), bv = *reinterpret_cast<const float4*>(b3s + ch0);
+        float4 y;
+        y.x = si_act((acc3[t3][0] - mean) * rstd * gv.x + bv.x, ACT);
+        y.y = si_act((acc3[t3][1] - mean) * rstd * gv.y + bv.y, ACT);
+        y.z = si_act((acc3[t3][2] - mean) * rstd * gv.z + bv.z, ACT);
+        y.w = si_act((acc3[t3][3] - mean) * rstd * gv.w + bv.w, ACT);
+        *reinterpret_cast<float4*>(tile + rowl * TS + ch0) = y;  // (channels >= c: affine 0 -> act(0) = 0, never read)
+      }
+    }
+    // ---- product with the concatenated sources, lane = channel (the tile is private to this wave: its LDS writes are
+    // ordered before these reads)
+    float* orow = a.out + row0 * a.out_stride + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i < nrow) {  // wave-uniform
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          // true divisions, as the reference's `/` (x / 1 is exact), only in the tiles that hold a divided column
+          const float xv = xneed[t] ? __fdiv_rn(x[i][t], xdiv[t]) : x[i][t];
+          if (lane + 64 * t < a.c) orow[64 * t] = xv * tile[i * TS + lane + 64 * t];
+        }
+        orow += a.out_stride;
       }
     }
   }
@@ -245,15 +322,33 @@ extern "C" int fsf_sir_input(const float* points, int64_t points_stride, int32_t
   a.w2 = w2; a.g2 = g2; a.b2 = b2; a.h2 = h2;
   a.w3 = w3; a.g3 = g3; a.b3 = b3;
   a.eps = eps; a.act = act; a.out = out; a.out_stride = out_stride; a.n = n; a.c = c;
-  const int t = (c + 63) / 64;
-  int64_t g = ((n + 63) / 64 + 3) / 4;
-  if (g > 4096) g = 4096;
-#define FSF_SI(T_) hipLaunchKernelGGL((sir_input_kernel<T_>), dim3((unsigned)g), dim3(256), 0, stream, a)
-  if (t == 1) FSF_SI(1);
-  else if (t == 2) FSF_SI(2);
-  else if (t == 3) FSF_SI(3);
-  else FSF_SI(4);
+  const int64_t groups = (n + 15) / 16;
+  int64_t g = (groups + 3) / 4;
+  if (g > 512) g = 512;  // 2 workgroups per CU, each walks its share of the 16-row groups (the weight staging is per workgroup)
+#define FSF_SI2(NT3_, ACT_)                                                                                            \
+  do {                                                                                                                 \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      FSF_HIP_TRY(hipFuncSetAttribute((const void*)sir_input_kernel<NT3_, ACT_>,                                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                         \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((sir_input_kernel<NT3_, ACT_>), dim3((unsigned)g), dim3(256), smem, stream, a);                 \
+  } while (0)
+#define FSF_SI(NT3_)                                                                                                   \
+  do {                                                                                                                 \
+    constexpr size_t smem = (size_t)(NT3_ * 2 * 64 * 4 + 2 * NT3_ * 16 + 4 * 16 * (NT3_ * 16 + 4)) * sizeof(float);    \
+    if (act == 2) FSF_SI2(NT3_, 2);                                                                                    \
+    else if (act == 1) FSF_SI2(NT3_, 1);                                                                               \
+    else FSF_SI2(NT3_, 0);                                                                                             \
+  } while (0)
+  if (c <= 64) FSF_SI(4);
+  else if (c <= 128) FSF_SI(8);
+  else if (c <= 160) FSF_SI(10);
+  else if (c <= 192) FSF_SI(12);
+  else FSF_SI(16);
 #undef FSF_SI
+#undef FSF_SI2
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }
