@@ -339,6 +339,56 @@ class FSF(SingleStageFSD):
         outs = self.bbox_head(cluster_feats) if run_head else None
         return cluster_feats, cluster_xyz, cluster_inds, outs
 
+    def _query_branches(self, camera_branch, lidar_branch):
+        """Run the camera-query and LiDAR-query branches (FSF.py:1127-1144 runs them back to back; they only share the
+        read-only segmentor output) CONCURRENTLY at inference: the camera branch on a side HIP stream driven by a second
+        host thread.  Both are chains of small launches with data-dependent sizes — ~25 host syncs between them, each a
+        drained GPU — so the two streams fill each other's bubbles and idle CUs.  Every C-ABI call takes torch's
+        (thread-local) current stream and a per-stream workspace; ctypes and torch release the GIL while they wait."""
+        on_gpu = torch.cuda.is_available() and next(self.parameters()).is_cuda
+        if self.training or not on_gpu or not (self.test_cfg or {}).get("concurrent_query_branches", True):
+            return camera_branch(), lidar_branch()
+        import threading
+
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        side, device, grad = self._side_stream, torch.cuda.current_device(), torch.is_grad_enabled()
+        side.wait_stream(main)
+        box = {}
+
+        def worker():
+            try:
+                torch.cuda.set_device(device)
+                with torch.set_grad_enabled(grad), torch.cuda.stream(side):
+                    box["out"] = camera_branch()
+            except BaseException as e:  # re-raised on the calling thread
+                box["err"] = e
+
+        th = threading.Thread(target=worker, name="fsf-camera-queries")
+        th.start()
+        try:
+            lidar_out = lidar_branch()
+        finally:
+            th.join()
+        if "err" in box:
+            raise box["err"]
+        main.wait_stream(side)
+
+        def hand_over(o):  # tensors allocated on the side stream are consumed (and later freed) on the main one
+            if torch.is_tensor(o):
+                if o.is_cuda:
+                    o.record_stream(main)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    hand_over(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    hand_over(v)
+
+        hand_over(box["out"])
+        return box["out"], lidar_out
+
     def forward_hot_path(self, points, img_metas, mask_data, mask_anno):
         """Stages 1-3 of simple_test (:1114-1144): segmentation + image fusion, camera queries, LiDAR queries —
         everything on the north-star hot path; returns the query features the heads consume."""
@@ -348,9 +398,10 @@ class FSF(SingleStageFSD):
         points, point_infos = self.split_points_last_3dim(points)
         seg_out_tuple = self.segmentor.simple_test(points, img_metas, extract_feat_only=True, rescale=False)
         seg_out_dict = self.segmentor_feat_inhance_test(seg_out_tuple, point_infos, mask_anno, mask_data, img_metas)
-        f_feats, f_centers, f_coors, _, f_preds_2d = self.frustum_forward(seg_out_dict, mask_anno, mask_data, point_infos,
-                                                                           img_metas, cluster_center=None, run_head=False)
-        l_feats, l_centers, l_coors, _ = self.fsd_forward(seg_out_dict, img_metas, run_head=False)
+        (f_feats, f_centers, f_coors, _, f_preds_2d), (l_feats, l_centers, l_coors, _) = self._query_branches(
+            lambda: self.frustum_forward(seg_out_dict, mask_anno, mask_data, point_infos, img_metas, cluster_center=None,
+                                         run_head=False),
+            lambda: self.fsd_forward(seg_out_dict, img_metas, run_head=False))
         self._gather_cache = None
         return dict(seg=seg_out_dict, frustum_obj_feats=f_feats, frustum_obj_centers=f_centers, frustum_obj_coors=f_coors,
                     frustum_preds_2d=f_preds_2d, fsd_obj_feats=l_feats, fsd_obj_centers=l_centers, fsd_obj_coors=l_coors)
@@ -436,9 +487,9 @@ class FSF(SingleStageFSD):
         points, point_infos = self.split_points_last_3dim(points)
         seg_out_tuple = self.segmentor.simple_test(points, img_metas, extract_feat_only=True, rescale=False)
         seg_out_dict = self.segmentor_feat_inhance_test(seg_out_tuple, point_infos, mask_anno, mask_data, img_metas)
-        f_feats, f_centers, f_coors, f_result, f_preds_2d = self.frustum_forward(seg_out_dict, mask_anno, mask_data, point_infos,
-                                                                                 img_metas, cluster_center=None)
-        l_feats, l_centers, l_coors, l_result = self.fsd_forward(seg_out_dict, img_metas)
+        (f_feats, f_centers, f_coors, f_result, f_preds_2d), (l_feats, l_centers, l_coors, l_result) = self._query_branches(
+            lambda: self.frustum_forward(seg_out_dict, mask_anno, mask_data, point_infos, img_metas, cluster_center=None),
+            lambda: self.fsd_forward(seg_out_dict, img_metas))
         obj_centers, obj_coors, obj_result, obj_feats, preds_2d = self.combine_frustum_and_fsd(
             f_centers, f_coors, f_result, f_feats, f_preds_2d, l_centers, l_coors, l_result, l_feats)
         bbox_list = self.multi_stage_refine_test(obj_centers, obj_coors, obj_result, seg_out_dict["seg_points"], point_infos,
