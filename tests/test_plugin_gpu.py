@@ -542,6 +542,32 @@ def test_simple_test_end_to_end_boxes(fsf_pair, frame1, device):
     assert "frustum_obj_feats" in hot and "fsd_obj_feats" in hot
 
 
+def test_concurrent_query_branches_equal_sequential(fsf_pair, frame1, device):
+    """The camera-query and LiDAR-query branches run on two streams / two host threads at inference
+    (FSF._query_branches); the boxes must be bit-identical to the back-to-back order upstream uses, call after call."""
+    model, _ = fsf_pair
+    pts = [torch.from_numpy(frame1["points"]).to(device)]
+    metas = [dict(lidar2img=torch.from_numpy(frame1["lidar2img"]).to(device))]
+    mask = torch.from_numpy(frame1["mask_data"]).to(device)[None]
+    anno = torch.from_numpy(frame1["mask_anno"]).to(device)[None]
+    cfg = model.test_cfg
+    try:
+        with torch.no_grad():
+            cfg["concurrent_query_branches"] = False
+            seq = model.simple_test(pts, metas, mask, anno)[0]
+            seq_hot = model.simple_test(pts, metas, mask, anno, hot_path_only=True)
+            cfg["concurrent_query_branches"] = True
+            for _ in range(3):
+                con = model.simple_test(pts, metas, mask, anno)[0]
+                assert torch.equal(con["boxes_3d"].tensor, seq["boxes_3d"].tensor)
+                assert torch.equal(con["scores_3d"], seq["scores_3d"]) and torch.equal(con["labels_3d"], seq["labels_3d"])
+            con_hot = model.simple_test(pts, metas, mask, anno, hot_path_only=True)
+            for k in ("frustum_obj_feats", "frustum_obj_centers", "fsd_obj_feats", "fsd_obj_centers", "fsd_obj_coors"):
+                assert torch.equal(con_hot[k], seq_hot[k]), k
+    finally:
+        cfg.pop("concurrent_query_branches", None)
+
+
 def test_av2_full_detector_end_to_end(plugin, device):
     """BASELINE config 5 through the whole detector: +-200 m cloud of 4-d points, 7 cameras, ONE int32 id plane per camera
     (ids > 255), 26 classes, the `is_argo` image branch (box + score + one-hot, FSF.py:540-548), 8-d box code."""
