@@ -127,29 +127,36 @@ class FSF(SingleStageFSD):
 
     # ----------------------------------------------------------------------------- frustum grouping
     def double_overlap_pts(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights):
-        """A point inside k > 1 masks is duplicated k - 1 times (appended), ids taken in topk order (:260-297)."""
+        """A point inside k > 1 masks is duplicated k - 1 times (appended), ids taken in topk order (:260-297).
+
+        Upstream loops over k = 2, 3, ... and compacts five tensors with a boolean mask per k (one host sync each).  Here the
+        appended rows are enumerated at once: every (point, j) with 1 <= j < k(point), ordered by (k, j, point) — the order
+        the loop appends them in — so the result is identical with three syncs instead of ~6 per distinct k."""
         obj_id_tensor = obj_id_tensor.reshape(obj_id_tensor.shape[0], -1)
+        n = obj_id_tensor.shape[0]
         overlaps_tensor = (obj_id_tensor > 0).sum(-1)
-        max_overlap_num = int(overlaps_tensor.max()) + 1
-        src_feat, src_bz, src_pts, src_w = pts_feat, bz_coor, points, point_fg_weights
         raw_obj_id_tensor = obj_id_tensor.max(-1)[0]
-        feats, bzs, pts, ws, ids = [pts_feat], [bz_coor], [points], [point_fg_weights], [raw_obj_id_tensor]
-        for overlap_num in range(2, max_overlap_num):
-            overlaps_mask = overlaps_tensor == overlap_num
-            if not overlaps_mask.any():
-                continue
-            feats.append(src_feat[overlaps_mask].repeat(overlap_num - 1, 1))
-            bzs.append(src_bz[overlaps_mask].repeat(overlap_num - 1, 1))
-            pts.append(src_pts[overlaps_mask].repeat(overlap_num - 1, 1))
-            ws.append(src_w[overlaps_mask].repeat(overlap_num - 1))
-            rows = obj_id_tensor[overlaps_mask]
-            if rows.is_cuda and rows.dtype == torch.int64 and rows.size(1) <= 128:
-                sort_value = hip_ops.row_topk_desc(rows, overlap_num)
-            else:
-                sort_value = rows.topk(overlap_num, dim=-1)[0]
-            for pad_idx in range(1, overlap_num):
-                ids.append(sort_value[:, pad_idx])
-        return torch.cat(feats, 0), torch.cat(bzs, 0), torch.cat(pts, 0), torch.cat(ids, 0), torch.cat(ws, 0)
+        multi = (overlaps_tensor >= 2).nonzero(as_tuple=False).squeeze(1)
+        if multi.numel() == 0:
+            return pts_feat, bz_coor, points, raw_obj_id_tensor, point_fg_weights
+        k_pt = overlaps_tensor.index_select(0, multi)                      # [M] masks per point
+        kmax = int(k_pt.max())
+        rows = obj_id_tensor.index_select(0, multi)
+        if rows.is_cuda and rows.dtype == torch.int64 and rows.size(1) <= 128:
+            sort_value = hip_ops.row_topk_desc(rows, kmax)                # [M, kmax] descending; column j = j-th largest id
+        else:
+            sort_value = rows.topk(kmax, dim=-1)[0]
+        reps = k_pt - 1
+        src = torch.repeat_interleave(torch.arange(multi.numel(), device=multi.device), reps)  # [T] row of `multi`
+        first = torch.cumsum(reps, 0) - reps
+        j = torch.arange(src.numel(), device=src.device) - first.index_select(0, src) + 1      # 1 .. k - 1
+        pt = multi.index_select(0, src)
+        order = torch.argsort((k_pt.index_select(0, src) * (kmax + 1) + j) * n + pt)            # (k, j, point): all distinct
+        pt, src, j = pt.index_select(0, order), src.index_select(0, order), j.index_select(0, order)
+        extra_ids = sort_value[src, j]
+        return (torch.cat([pts_feat, pts_feat.index_select(0, pt)], 0), torch.cat([bz_coor, bz_coor.index_select(0, pt)], 0),
+                torch.cat([points, points.index_select(0, pt)], 0), torch.cat([raw_obj_id_tensor, extra_ids], 0),
+                torch.cat([point_fg_weights, point_fg_weights.index_select(0, pt)], 0))
 
     def extract_fg_pts(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights):
         fg_idx = (obj_id_tensor.sum((-2, -1)) > 0).nonzero(as_tuple=False).squeeze(1)  # one compaction for all five

@@ -209,11 +209,13 @@ class SingleStageFSD(nn.Module):
         groups, class_names = cfg["group_names"], cfg["class_names"]
         ng = len(groups)
         member = torch.zeros((ng, nc), dtype=torch.bool)
-        for gi, g in enumerate(groups):
-            member[gi, [class_names.index(n) for n in g]] = True
+        group_cols = [sorted(class_names.index(n) for n in g) for g in groups]
+        for gi, cols in enumerate(group_cols):
+            member[gi, cols] = True
         member = member.to(dev)
         scores = seg_logits.softmax(1)[:, :-1]
-        grouped_score = torch.stack([scores[:, member[gi]].sum(1) for gi in range(ng)], dim=1)  # the reference's sums
+        # the reference's sums (same columns, same order as its boolean column mask; an index list does not sync the host)
+        grouped_score = torch.stack([scores[:, cols].sum(1) for cols in group_cols], dim=1)
         fg = grouped_score > torch.tensor(cfg["score_thresh"], device=dev, dtype=grouped_score.dtype)[None, :]
         if bsz == 1:
             fg[0] |= ~fg.any(0)  # "at least one point per sample" (:832-834)
