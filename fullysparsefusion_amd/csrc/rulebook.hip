@@ -105,28 +105,44 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// strided conv, pass 1: every (input, offset) proposes an output site; first proposer appends it
+// strided conv, pass 1: every (input, offset) proposes an output site; first proposer appends it.  The append
+// position comes from a workgroup-level count (LDS atomics) and ONE device atomic per workgroup and round: a single
+// device-wide counter bumped by every wave saturates at ~90 increments / us and was the whole cost of this kernel.
 __global__ void __launch_bounds__(256)
     rb_propose_kernel(const int32_t* __restrict__ indices, int64_t m, ConvGeom g, uint64_t* set_keys, uint64_t set_mask,
                       uint64_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+  __shared__ uint32_t s_cnt, s_base;
   const int64_t total = m * g.kvol;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = t / g.kvol;
-    const int k = (int)(t - i * g.kvol);
-    const int kxi = k % g.kx, kyi = (k / g.kx) % g.ky, kzi = k / (g.kx * g.ky);
-    const int4 c = *reinterpret_cast<const int4*>(indices + i * 4);
-    const int nz = c.y + g.pz - kzi * g.dz;
-    const int ny = c.z + g.py - kyi * g.dy;
-    const int nx = c.w + g.px - kxi * g.dx;
-    if (nz < 0 || ny < 0 || nx < 0) continue;
-    if (nz % g.sz || ny % g.sy || nx % g.sx) continue;
-    const int oz = nz / g.sz, oy = ny / g.sy, ox = nx / g.sx;
-    if (oz >= g.OZ || oy >= g.OY || ox >= g.OX) continue;
-    const uint64_t key = lin_out(g, c.x, oz, oy, ox);
-    if (hash_insert_set(set_keys, set_mask, key)) {
-      const uint32_t pos = atomicAdd(list_count, 1u);
-      list[pos] = key;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  const int64_t rounds = (total + step - 1) / step;  // block-uniform trip count (barriers inside)
+  for (int64_t r = 0; r < rounds; ++r) {
+    const int64_t t = r * step + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    bool mine = false;
+    uint64_t key = 0;
+    if (t < total) {
+      const int64_t i = t / g.kvol;
+      const int k = (int)(t - i * g.kvol);
+      const int kxi = k % g.kx, kyi = (k / g.kx) % g.ky, kzi = k / (g.kx * g.ky);
+      const int4 c = *reinterpret_cast<const int4*>(indices + i * 4);
+      const int nz = c.y + g.pz - kzi * g.dz;
+      const int ny = c.z + g.py - kyi * g.dy;
+      const int nx = c.w + g.px - kxi * g.dx;
+      if (nz >= 0 && ny >= 0 && nx >= 0 && !(nz % g.sz || ny % g.sy || nx % g.sx)) {
+        const int oz = nz / g.sz, oy = ny / g.sy, ox = nx / g.sx;
+        if (oz < g.OZ && oy < g.OY && ox < g.OX) {
+          key = lin_out(g, c.x, oz, oy, ox);
+          mine = hash_insert_set(set_keys, set_mask, key);
+        }
+      }
     }
+    uint32_t local = 0;
+    if (mine) local = atomicAdd(&s_cnt, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(list_count, s_cnt);
+    __syncthreads();
+    if (mine) list[s_base + local] = key;
   }
 }
 
