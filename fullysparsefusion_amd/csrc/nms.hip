@@ -194,13 +194,22 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
       uint64_t alive = ~removed[w];
       if (nb < 64) alive &= (1ull << nb) - 1ull;
       uint64_t kept = 0;
-      while (alive) {  // `alive` is the same in every lane; each pass settles its lowest box
-        const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+      while (alive) {  // `alive` is the same in every lane.  A pass settles every box up to the first alive one whose
+        // row still hits an alive box: the ones before it remove nobody and are kept in bulk (a sparse scene settles a
+        // whole word in one pass instead of 64)
+        const bool hits = ((alive >> lane) & 1ull) && (diag & alive) != 0ull;
+        const uint64_t hb = __ballot(hits);
+        if (hb == 0ull) {
+          kept |= alive;
+          break;
+        }
+        const int b = __builtin_ctzll(hb);  // (wave-uniform)
+        const uint64_t upto = alive & ((2ull << b) - 1ull);
         const uint64_t row = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dlo, b) |
                              ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)dhi, b) << 32);
-        kept |= 1ull << b;
+        kept |= upto;
+        alive &= ~upto;
         alive &= ~row;
-        alive &= ~(1ull << b);
       }
       if (lane == 0) {
         kept_word = kept;
