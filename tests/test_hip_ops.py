@@ -383,6 +383,43 @@ def test_spconv_forward_subm_vs_oracle(ops, device, cin, cout):
                                                 shift=shift.to(device), residual=res.to(device), relu=True))
 
 
+@pytest.mark.parametrize("m,cin,cout", [(100000, 128, 128), (36000, 256, 128), (7500, 256, 256), (1500, 512, 512)])
+def test_spconv_forward_full_size_properties(ops, device, m, cin, cout):
+    """BASELINE-size layers (the persistent work-queue kernel with 1..9 offset splits, stealing across XCD queues, in-kernel
+    fold by the last arriver): size-independent properties instead of the CPU oracle —
+    bitwise determinism call after call, linearity in the features, the identity kernel, and a dense-torch check of a
+    random sample of output rows."""
+    rng = np.random.default_rng(m + cin)
+    shape = (40, 512, 512)
+    idx = surface_sites(rng, 1, shape, m)
+    n = idx.shape[0]
+    nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), 1, shape)
+    g = torch.Generator(device="cpu").manual_seed(m)
+    feat = torch.randn(n, cin, generator=g).to(device)
+    feat2 = torch.randn(n, cin, generator=g).to(device)
+    w = (torch.randn(27, cin, cout, generator=g) / (cin * 6) ** 0.5).to(device)
+    wt = ops.spconv_transpose_weight(w)
+    out = ops.spconv_forward(feat, wt, nbr)
+    for _ in range(3):  # the queue order differs from call to call; the result may not
+        assert torch.equal(out, ops.spconv_forward(feat, wt, nbr))
+    # linearity: conv(a x + y) = a conv(x) + conv(y) up to fp32 rounding
+    lhs = ops.spconv_forward(feat * 0.5 + feat2, wt, nbr)
+    rhs = out * 0.5 + ops.spconv_forward(feat2, wt, nbr)
+    assert float((lhs - rhs).abs().max()) <= 2e-4 * max(1.0, float(rhs.abs().max()))
+    # a random sample of output rows against the gather -> matmul definition in float64
+    rows = torch.from_numpy(rng.choice(n, size=min(n, 512), replace=False)).to(device)
+    nb = nbr.index_select(0, rows).long()                                  # [r, 27]
+    gathered = torch.where((nb >= 0)[:, :, None], feat.double()[nb.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=device))
+    want = torch.einsum("rkc,kcd->rd", gathered, w.double())
+    got = out.index_select(0, rows).double()
+    assert float((got - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+    # identity kernel (centre offset = I, cin == cout): output == input, exactly
+    if cin == cout:
+        wi = torch.zeros(27, cin, cout, device=device)
+        wi[13] = torch.eye(cin, device=device)
+        assert torch.equal(ops.spconv_forward(feat, ops.spconv_transpose_weight(wi), nbr), feat)
+
+
 def test_spconv_forward_strided_and_inverse_vs_dense(ops, device):
     rng = np.random.default_rng(9)
     shape = (9, 24, 24)
