@@ -1,0 +1,355 @@
+// K22: per-point Linear (+ bias) -> LayerNorm | eval-BatchNorm affine -> ReLU | GELU in one pass, fp32 in / fp32 out.
+// See include/fsf_hip.h.
+//
+// Replaces (inference): the [Linear, norm, act] blocks that build_mlp (projects/mmdet3d_plugin/ops/sst_ops.py:808-833) and
+// DynamicVFELayer [UNVENDORED] put on every point: a dense fp32 GEMM on the library (70 % of the fp32 matrix-pipe peak
+// at best) + one more pass over the [n, C] activations for norm + act.
+//
+// The fp32 matrix pipe (v_mfma_f32_16x16x4_f32, 157 TFLOP/s) is 1/16 of the bf16 one, so the product is formed on
+// v_mfma_f32_16x16x32_bf16 from an EXACT three-way split of both operands: x = hi + mid + lo with hi = x truncated to
+// its top 8 significant bits (a bf16), mid = the same of x - hi, lo = x - hi - mid (8 bits left: a bf16, exactly) —
+// three 8-bit pieces cover the 24-bit fp32 significand, nothing is rounded away.  a*b is then the sum of nine bf16
+// products (each exact in the fp32 accumulator's input); the six leading ones are issued, the dropped mid*lo, lo*mid,
+// lo*lo terms are < 2^-23 of |a*b| together — the size of ONE fp32 rounding — and the accumulation is fp32 as on the
+// fp32 pipe.  6 x ~17 cycles per 16x16x32 block instead of 8 x 32: the matrix phase is 2.5x shorter at fp32 accuracy
+// (tests: error vs float64 no larger than torch's fp32 F.linear).  This is not a reduced-precision mode.
+//
+// Transposed formulation (as K21): out^T[channel, row] = W[channel, k] x X^T[k, row]; the weights are the A operand
+// (pre-split once per layer into fragment-ordered bf16 planes by fsf_linear_prepare_weight, streamed through LDS in
+// 64-wide k chunks, double-buffered by LDS-DMA), 16 point rows are the B operand (loaded straight from HBM in operand
+// layout — lane (row, g) reads 32 contiguous bytes per k step — and split in registers).  A lane ends up with channels
+// 16 t + 4 g + r of its row: LayerNorm is an in-lane sum + two shuffles, the result leaves as 16-byte stores.
+#include "common.h"
+
+namespace fsf {
+
+typedef __bf16 lna_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float lna_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned lna_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int LNA_KC = 64;        // k per LDS chunk (two MFMA k steps)
+constexpr int LNA_NW = 4;         // waves per workgroup (two workgroups per CU: one wave of each per SIMD)
+constexpr int LNA_RG = 2;         // 16-row groups per wave and iteration
+constexpr int LNA_ROWS = LNA_NW * LNA_RG * 16;  // rows per workgroup iteration
+
+struct LnaArgs {
+  const float* x; int64_t x_stride; int k;
+  const uint4* planes;  // [KP/64][T][2][3][64 lanes] x 16 B
+  const float *bias, *gamma, *beta;
+  float eps; int norm, act;  // norm 0 none / 1 LayerNorm / 2 affine (y * gamma + beta); act 0 / 1 ReLU / 2 GELU(erf)
+  float* out; int64_t out_stride;
+  int64_t n; int c;
+};
+
+__device__ __forceinline__ float lna_row_sum(float v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// exact three-way split of 8 floats into bf16 planes (two bf16 per dword, element 2j in the low half)
+__device__ __forceinline__ void lna_split8(const float (&v)[8], lna_u32x4& hi, lna_u32x4& mid, lna_u32x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    const float ah = __uint_as_float(__float_as_uint(a) & 0xffff0000u), bh = __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+    const float ar = __fsub_rn(a, ah), br = __fsub_rn(b, bh);
+    const float am = __uint_as_float(__float_as_uint(ar) & 0xffff0000u), bm = __uint_as_float(__float_as_uint(br) & 0xffff0000u);
+    const float al = __fsub_rn(ar, am), bl = __fsub_rn(br, bm);
+    hi[j] = __builtin_amdgcn_perm(__float_as_uint(bh), __float_as_uint(ah), 0x07060302u);
+    mid[j] = __builtin_amdgcn_perm(__float_as_uint(bm), __float_as_uint(am), 0x07060302u);
+    lo[j] = __builtin_amdgcn_perm(__float_as_uint(bl), __float_as_uint(al), 0x07060302u);
+  }
+}
+
+// GELU with erf by Abramowitz & Stegun 7.1.26, branch-free (|error| <= 1.5e-7 absolute — float epsilon; the same form as
+// K21's, see sir_input.hip)
+__device__ __forceinline__ float lna_gelu(float y) {
+  const float u = fabsf(y) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float pe = p * t * __builtin_amdgcn_exp2f(u * u * -1.4426950408889634f);
+  return 0.5f * y * (y < 0.0f ? pe : 2.0f - pe);
+}
+
+__device__ __forceinline__ float lna_act(float y, int act) {
+  if (act == 1) return fmaxf(y, 0.0f);
+  if (act == 2) return lna_gelu(y);
+  return y;
+}
+
+// weight [c, k] fp32 -> fragment-ordered bf16 planes (zero padded to T tiles x KP)
+__global__ void __launch_bounds__(256) lna_prepare_kernel(const float* __restrict__ w, int k, int c, int T, int nkc, uint4* planes) {
+  const int64_t total = (int64_t)nkc * T * 2 * 64;  // (chunk, tile, k step, lane): three 16-byte fragments each
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    const int s = (int)((idx >> 6) & 1);
+    const int t = (int)((idx >> 7) % T);
+    const int kc = (int)((idx >> 7) / T);
+    const int col = 16 * t + (lane & 15), k0 = kc * LNA_KC + 32 * s + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (col < c && k0 + e < k) ? w[(int64_t)col * k + k0 + e] : 0.0f;
+    lna_u32x4 hi, mid, lo;
+    lna_split8(v, hi, mid, lo);
+    uint4* dst = planes + (((int64_t)(kc * T + t) * 2 + s) * 3) * 64 + lane;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[64] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+    dst[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
+template <int T>  // 16-channel tiles (c <= 16 T)
+__global__ void __launch_bounds__(LNA_NW * 64, 2) linear_norm_act_kernel(LnaArgs a) {
+  constexpr int CHUNK_U4 = T * 2 * 3 * 64;  // uint4 per weight chunk
+  extern __shared__ __attribute__((aligned(16))) char lna_smem[];
+  uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rowl = lane & 15, grp = lane >> 4;
+  const int nkc = (a.k + LNA_KC - 1) / LNA_KC;
+  const int64_t nblk = (a.n + LNA_ROWS - 1) / LNA_ROWS;
+
+  // weight chunk kc -> LDS buffer by LDS-DMA: fragment order in HBM == fragment order in LDS, 1 KB per wave instruction
+  auto stage_w = [&](int kc, int buf) {
+    const float* src = reinterpret_cast<const float*>(a.planes + (int64_t)kc * CHUNK_U4);
+    float* dst = reinterpret_cast<float*>(wbuf + buf * CHUNK_U4);
+    for (int u = wave * 64; u < CHUNK_U4; u += LNA_NW * 64)
+      __builtin_amdgcn_global_load_lds(src + 4 * (u + lane), dst + 4 * u, 16, 0, 0);
+  };
+
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t row0 = blk * LNA_ROWS + (int64_t)wave * (LNA_RG * 16);
+    lna_f32x4 acc[LNA_RG][T];
+#pragma unroll
+    for (int rg = 0; rg < LNA_RG; ++rg)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[rg][t] = lna_f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xrow[LNA_RG];
+#pragma unroll
+    for (int rg = 0; rg < LNA_RG; ++rg) {
+      int64_t r = row0 + 16 * rg + rowl;
+      if (r >= a.n) r = a.n - 1;  // rows past n repeat the last one (finite, never stored)
+      xrow[rg] = a.x + r * a.x_stride + 8 * grp;
+    }
+    // raw x of one 64-wide chunk: [row group][k step][8 floats]; the NEXT chunk is requested while this one is split and
+    // multiplied (a wave has one other wave on its SIMD: without the prefetch every k step waited for HBM)
+    // Always exactly two 16-byte loads per (row group, k step) — the barrier below counts on it: offsets past the row are
+    // clamped into it (x_stride is a multiple of 4 and >= k, so a quad that holds any column < k is never clamped) and
+    // the columns >= k are zeroed afterwards (what follows the row in memory may be NaN).
+    const int last_quad = (int)a.x_stride - 4;
+    auto load_x = [&](int kc, float (&v)[LNA_RG][2][8]) {
+#pragma unroll
+      for (int rg = 0; rg < LNA_RG; ++rg)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int kq = kc * LNA_KC + 32 * s + 8 * grp;  // this lane's 8 k values
+          const float* base = xrow[rg] - 8 * grp;
+          const float4 p = *reinterpret_cast<const float4*>(base + min(kq, last_quad));
+          const float4 q = *reinterpret_cast<const float4*>(base + min(kq + 4, last_quad));
+          v[rg][s][0] = p.x; v[rg][s][1] = p.y; v[rg][s][2] = p.z; v[rg][s][3] = p.w;
+          v[rg][s][4] = q.x; v[rg][s][5] = q.y; v[rg][s][6] = q.z; v[rg][s][7] = q.w;
+        }
+    };
+    auto mask_tail = [&](int kc, float (&v)[LNA_RG][2][8]) {
+      if ((kc + 1) * LNA_KC > a.k) {  // (uniform: only the last chunk of a k that is not a multiple of 64)
+#pragma unroll
+        for (int rg = 0; rg < LNA_RG; ++rg)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              if (kc * LNA_KC + 32 * s + 8 * grp + e >= a.k) v[rg][s][e] = 0.0f;
+      }
+    };
+    constexpr int X_LOADS = LNA_RG * 2 * 2;  // VMEM instructions of one load_x
+    float xc[LNA_RG][2][8], xn[LNA_RG][2][8];
+    load_x(0, xc);
+    for (int kc = 0; kc < nkc; ++kc) {
+      if (kc + 1 < nkc) load_x(kc + 1, xn);
+      // ONE weight buffer per workgroup (48 KB at 128 channels, so two workgroups fit a CU and drift out of phase: the
+      // norm / activation epilogue and the staging wait of one overlap the matrix phase of the other; with one 8-wave
+      // workgroup per CU every wave of a SIMD was in the same phase).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done reading the previous chunk
+      asm volatile("" ::: "memory");
+      stage_w(kc, 0);
+      // this wave's share of the DMA must have landed, the x prefetch (issued before it) may stay in flight... it cannot:
+      // VMEM retires in order and the prefetch is OLDER than the DMA, so waiting for the DMA waits for it too; the
+      // other workgroup of the CU covers that latency
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everyone's share has landed
+      asm volatile("" ::: "memory");
+      const int buf = 0;
+      mask_tail(kc, xc);
+      const uint4* wc = wbuf + buf * CHUNK_U4;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        lna_u32x4 xh[LNA_RG], xm[LNA_RG], xl[LNA_RG];
+#pragma unroll
+        for (int rg = 0; rg < LNA_RG; ++rg) lna_split8(xc[rg][s], xh[rg], xm[rg], xl[rg]);
+        // Two channel tiles x LNA_RG row groups = 4 independent accumulators per product term: consecutive MFMAs never
+        // hit the same accumulator (a dependent MFMA with anything scheduled in between waits ~43 cycles for its
+        // predecessor; six of them chained on one accumulator ran the kernel 4x slower than the pipe allows)
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+          lna_bf16x8 wfr[2][3];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const uint4* wf = wc + (((t + tt) * 2 + s) * 3) * 64 + lane;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wfr[tt][pl] = __builtin_bit_cast(lna_bf16x8, wf[64 * pl]);
+          }
+          // (weight plane, x plane) of the six leading cross terms, small ones first
+          constexpr int TERM_W[6] = {2, 0, 1, 1, 0, 0};
+          constexpr int TERM_X[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+          for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+              for (int rg = 0; rg < LNA_RG; ++rg) {
+                const lna_u32x4 xb = TERM_X[term] == 0 ? xh[rg] : TERM_X[term] == 1 ? xm[rg] : xl[rg];
+#ifndef FSF_ABL_LNA_NO_MFMA
+                acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[tt][TERM_W[term]], __builtin_bit_cast(lna_bf16x8, xb),
+                                                                          acc[rg][t + tt], 0, 0, 0);
+#else
+                acc[rg][t + tt][term & 3] += __uint_as_float(xb[term & 3]) * __uint_as_float(__builtin_bit_cast(lna_u32x4, wfr[tt][TERM_W[term]])[0]);
+#endif
+              }
+        }
+      }
+      if (kc + 1 < nkc) {
+#pragma unroll
+        for (int rg = 0; rg < LNA_RG; ++rg)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xc[rg][s][e] = xn[rg][s][e];
+      }
+    }
+    // ---- epilogue: lane (row, g) holds channels 16 t + 4 g + r of its row
+    const float inv_c = 1.0f / (float)a.c;
+#pragma unroll
+    for (int rg = 0; rg < LNA_RG; ++rg) {
+      const int64_t row = row0 + 16 * rg + rowl;
+      float mean = 0.0f, rstd = 1.0f;
+      if (a.bias) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int ch0 = 16 * t + 4 * grp;
+          if (ch0 < a.c) {
+            const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
+            acc[rg][t][0] += b.x; acc[rg][t][1] += b.y; acc[rg][t][2] += b.z; acc[rg][t][3] += b.w;
+          }
+        }
+      }
+      if (a.norm == 1) {  // LayerNorm over the c channels (channels >= c are exactly 0: zero weights, no bias)
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s += acc[rg][t][r];
+        mean = lna_row_sum(s) * inv_c;
+        float q = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float d = 16 * t + 4 * grp + r < a.c ? acc[rg][t][r] - mean : 0.0f;
+            q += d * d;
+          }
+        rstd = rsqrtf(lna_row_sum(q) * inv_c + a.eps);
+      }
+      if (row < a.n) {
+        float* orow = a.out + row * a.out_stride;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int ch0 = 16 * t + 4 * grp;
+          if (ch0 < a.c) {
+            float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.norm != 0) {
+              g = *reinterpret_cast<const float4*>(a.gamma + ch0);
+              b = *reinterpret_cast<const float4*>(a.beta + ch0);
+            }
+            float4 y;
+            y.x = lna_act((acc[rg][t][0] - mean) * rstd * g.x + b.x, a.act);
+            y.y = lna_act((acc[rg][t][1] - mean) * rstd * g.y + b.y, a.act);
+            y.z = lna_act((acc[rg][t][2] - mean) * rstd * g.z + b.z, a.act);
+            y.w = lna_act((acc[rg][t][3] - mean) * rstd * g.w + b.w, a.act);
+#ifndef FSF_ABL_LNA_NO_STORE
+            *reinterpret_cast<float4*>(orow + ch0) = y;
+#else
+            if (y.x == 123.456f) *reinterpret_cast<float4*>(orow + ch0) = y;
+#endif
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace fsf
+
+using namespace fsf;
+
+// 16-channel tiles of the launched kernel variant (the prepared weight is laid out for exactly this count)
+static int lna_tiles(int c) {
+  const int t = (c + 15) / 16;
+  return t <= 2 ? 2 : (t <= 4 ? 4 : 8);
+}
+
+extern "C" int64_t fsf_linear_prepared_weight_bytes(int32_t k, int32_t c) {
+  if (k < 1 || c < 1) return 0;
+  const int64_t nkc = (k + LNA_KC - 1) / LNA_KC;
+  return nkc * lna_tiles(c) * 2 * 3 * 64 * 16;
+}
+
+extern "C" int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t c, void* planes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!weight || !planes || k < 1 || c < 1) return FSF_ERR_INVALID_ARG;
+  const int T = lna_tiles(c), nkc = (k + LNA_KC - 1) / LNA_KC;
+  const int64_t total = (int64_t)nkc * T * 2 * 64;
+  hipLaunchKernelGGL(lna_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k, (int)c, T, nkc,
+                     (uint4*)planes);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
+                                   const float* bias, int32_t norm, const float* gamma, const float* beta, float eps,
+                                   int32_t act, float* out, int64_t out_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || k < 1 || c < 1 || !planes || norm < 0 || norm > 2 || act < 0 || act > 2 || (norm != 0 && (!gamma || !beta)) ||
+      (n > 0 && (!x || !out)))
+    return FSF_ERR_INVALID_ARG;
+  // 16-byte row accesses: x rows and out rows must be 16-byte aligned, c a multiple of 4
+  if (c > 128 || (c % 4) != 0 || (x_stride % 4) != 0 || (out_stride % 4) != 0 || ((uintptr_t)x % 16) != 0 ||
+      ((uintptr_t)out % 16) != 0)
+    return FSF_ERR_UNSUPPORTED;
+  if (x_stride < k || out_stride < c) return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c};
+  const int64_t nblk = (n + LNA_ROWS - 1) / LNA_ROWS;
+  const unsigned grid = (unsigned)(nblk < 512 ? nblk : 512);  // two 4-wave workgroups per CU
+#define FSF_LNA(T_)                                                                                                     \
+  do {                                                                                                                 \
+    constexpr size_t smem = (size_t)T_ * 2 * 3 * 64 * 16;                                                          \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      FSF_HIP_TRY(hipFuncSetAttribute((const void*)linear_norm_act_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)smem));                                                                     \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((linear_norm_act_kernel<T_>), dim3(grid), dim3(LNA_NW * 64), smem, stream, a);                  \
+  } while (0)
+  const int T = lna_tiles(c);
+  if (T == 2) FSF_LNA(2);
+  else if (T == 4) FSF_LNA(4);
+  else FSF_LNA(8);
+#undef FSF_LNA
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}

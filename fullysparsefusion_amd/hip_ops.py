@@ -45,6 +45,9 @@ _ARGTYPES = {
     "fsf_row_topk_desc": [_P, c_i64, c_i32, c_i32, _P, _P],
     "fsf_sir_input": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
                       _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
+    "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
+    "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
+    "fsf_linear_norm_act": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
     "fsf_dynamic_point_pool_workspace_bytes": [c_i64, c_i64],
     "fsf_dynamic_point_pool": [_P, c_i64, c_i32, c_i32, c_i32, _P, c_i64, c_i32, _P, _P, c_i32, c_i64, _P, _P, _P, _P, _P,
                                _P, c_i64, _P],
@@ -442,7 +445,9 @@ def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_di
     assert w3.size(0) == c and w1.size(1) == f_cluster.size(1) and w2.size(1) == w1.size(0) and w3.size(1) == w2.size(0)
     for t in (points, feats, f_cluster, extra):
         assert t is None or (t.dtype == torch.float32 and t.dim() == 2 and (t.size(0) == 0 or t.stride(1) == 1))
-    out = torch.empty((n, c), dtype=torch.float32, device=points.device)
+    cpad = (c + 3) // 4 * 4  # rows start 16-byte aligned: the consumer is the fused Linear kernel (K22)
+    out_full = torch.empty((n, cpad), dtype=torch.float32, device=points.device)
+    out = out_full[:, :c]
     rp = lambda t: c_p(t.data_ptr()) if t is not None and t.numel() else c_p(None)  # noqa: E731  row-strided views pass as is
     st = lambda t: t.stride(0) if t is not None and t.size(0) > 1 else (t.size(1) if t is not None else 0)  # noqa: E731
     check(_L().fsf_sir_input(rp(points), st(points), points.size(1), f32_array(xyz_normalizer), rp(feats), st(feats),
@@ -450,7 +455,43 @@ def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_di
                              rp(f_cluster), st(f_cluster), f_cluster.size(1), float(rel_div),
                              ptr(w1.contiguous()), ptr(g1), ptr(b1), w1.size(0), ptr(w2.contiguous()), ptr(g2), ptr(b2), w2.size(0),
                              ptr(w3.contiguous()), ptr(g3), ptr(b3), float(eps), {"none": 0, "relu": 1, "gelu": 2}[act], n,
-                             ptr(out), c, stream_ptr()), "fsf_sir_input")
+                             ptr(out_full), cpad, stream_ptr()), "fsf_sir_input")
+    return out
+
+
+def linear_prepare_weight(weight: torch.Tensor):
+    """fsf_linear_prepare_weight: Linear weight f32 [c, k] -> opaque split-bf16 fragment planes (u8 tensor)."""
+    require_cuda(weight)
+    weight = weight.detach().contiguous()
+    c, k = weight.shape
+    h = _L()
+    planes = torch.empty(h.fsf_linear_prepared_weight_bytes(k, c), dtype=torch.uint8, device=weight.device)
+    check(h.fsf_linear_prepare_weight(ptr(weight), k, c, ptr(planes), stream_ptr()), "fsf_linear_prepare_weight")
+    return planes
+
+
+def linear_norm_act_supported(x: torch.Tensor, out_features: int) -> bool:
+    """Shapes the fused K22 kernel takes: fp32 rows that start 16-byte aligned, at most 128 output channels."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and out_features <= 128 and out_features % 4 == 0
+            and (x.size(0) <= 1 or x.stride(0) % 4 == 0) and x.stride(1) == 1 and x.data_ptr() % 16 == 0)
+
+
+def linear_norm_act(x: torch.Tensor, planes: torch.Tensor, out_features: int, bias=None, norm: str = "none", gamma=None,
+                    beta=None, eps: float = 0.0, act: str = "none", out=None):
+    """fsf_linear_norm_act: act(norm(x @ W^T + bias)) -> f32 [n, c]; `planes` from linear_prepare_weight; norm 'none' | 'ln'
+    | 'affine'.  x (and `out`, if given) may be row-strided views (stride a multiple of 4 floats, 16-byte aligned base)."""
+    require_cuda(x, planes, bias, gamma, beta, out)
+    n, k = x.shape
+    c = int(out_features)
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1
+    xs = x.stride(0) if n > 1 else (k + 3) // 4 * 4
+    os_ = out.stride(0) if n > 1 else (c + 3) // 4 * 4
+    check(_L().fsf_linear_norm_act(c_p(x.data_ptr()) if n else c_p(None), n, k, xs, ptr(planes), c, ptr(bias),
+                                   {"none": 0, "ln": 1, "affine": 2}[norm], ptr(gamma), ptr(beta), float(eps),
+                                   {"none": 0, "relu": 1, "gelu": 2}[act], c_p(out.data_ptr()) if n else c_p(None), os_,
+                                   stream_ptr()), "fsf_linear_norm_act")
     return out
 
 

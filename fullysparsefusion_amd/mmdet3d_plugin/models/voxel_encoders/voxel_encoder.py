@@ -10,8 +10,8 @@ points" gather reuses that sort-once segment plan through the HIP library.
 import torch
 import torch.nn as nn
 
-from ...ops.sst_ops import (build_mlp, fused_norm_act, gather_by_inverse, get_activation_layer, point_group_concat,
-                            point_linear, scatter_v2, unique_with_plan)
+from ...ops.sst_ops import (build_mlp, fused_norm_act, gather_by_inverse, get_activation_layer, linear_norm_act,
+                            point_group_concat, point_linear, scatter_v2, unique_with_plan)
 from ...registry import VOXEL_ENCODERS, build_norm_layer
 
 
@@ -28,7 +28,7 @@ class DynamicVFELayer(nn.Module):
         self.dropout = nn.Dropout(dropout) if dropout > 0 else None
 
     def forward(self, inputs):
-        x = fused_norm_act(point_linear(self.linear, inputs), self.norm, self.act)
+        x = linear_norm_act(self.linear, self.norm, self.act, inputs)
         if self.dropout is not None:
             x = self.dropout(x)
         return x

@@ -80,10 +80,9 @@ def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, wan
     [n, 2C] tensor is written exactly once; the segmented reduce reads the left half through its row stride."""
     no_grad = not (torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in vfe_layer.parameters())))
     if no_grad and want_concat and vfe_layer.dropout is None:
-        lin = point_linear(vfe_layer.linear, features)
-        n, c = lin.shape
-        buf = torch.empty((n, 2 * c), dtype=lin.dtype, device=lin.device)
-        point_feats = fused_norm_act(lin, vfe_layer.norm, vfe_layer.act, out=buf[:, :c])
+        n, c = features.size(0), vfe_layer.linear.out_features
+        buf = torch.empty((n, 2 * c), dtype=features.dtype, device=features.device)
+        point_feats = linear_norm_act(vfe_layer.linear, vfe_layer.norm, vfe_layer.act, features, out=buf[:, :c])
         group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors)
         gather_by_inverse(group_feats, inv, out=buf[:, c:])
         return point_feats, group_feats, group_coors, inv, buf
@@ -227,6 +226,36 @@ class _PointLinearFn(torch.autograd.Function):
         return g_x, g_w, g_b
 
 
+def linear_norm_act(linear, norm, act, x, out=None):
+    """`act(norm(linear(x)))` for the [Linear, norm, act] blocks applied to every point / cluster row.  At inference, for
+    up to 128 output channels with LayerNorm or eval-mode BatchNorm1d and ReLU / exact GELU, this is ONE HIP kernel
+    (fsf_linear_norm_act, K22: the product from an exact 3-way bf16 split on the bf16 matrix cores — fp32-accurate — with
+    the norm and the activation as its epilogue); otherwise the GEMM runs on the library and `fused_norm_act` follows."""
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad)
+    act_code = "relu" if isinstance(act, nn.ReLU) else (
+        "gelu" if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none" else None)
+    if (not needs_grad and act_code is not None and isinstance(linear, nn.Linear) and x.dim() == 2 and x.size(0) >= 1024
+            and hip_ops.linear_norm_act_supported(x, linear.out_features)
+            and (out is None or (out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0))):
+        kind = None
+        if isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1 and norm.elementwise_affine:
+            kind, gamma, beta, eps = "ln", norm.weight, norm.bias, norm.eps
+        elif isinstance(norm, nn.BatchNorm1d) and not norm.training and norm.track_running_stats:
+            from .spconv import _bn_affine
+
+            kind, eps = "affine", 0.0
+            gamma, beta = _bn_affine(norm)
+        if kind is not None:
+            key = (linear.weight.data_ptr(), linear.weight._version, linear.weight.device)
+            cache = linear.__dict__.get("_fsf_planes")
+            if cache is None or cache[0] != key:
+                cache = (key, hip_ops.linear_prepare_weight(linear.weight))
+                linear.__dict__["_fsf_planes"] = cache
+            return hip_ops.linear_norm_act(x, cache[1], linear.out_features, bias=linear.bias, norm=kind, gamma=gamma,
+                                           beta=beta, eps=eps, act=act_code, out=out)
+    return fused_norm_act(point_linear(linear, x), norm, act, out=out)
+
+
 def point_linear(linear, x):
     """`linear(x)` for a per-point nn.Linear; training on the GPU routes the weight gradient through K10."""
     if (torch.is_grad_enabled() and linear.weight.requires_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
@@ -248,7 +277,7 @@ class MLPBlock(nn.Sequential):
 
     def forward(self, x):
         mods = list(self._modules.values())
-        x = fused_norm_act(point_linear(mods[0], x), mods[1], mods[2])
+        x = linear_norm_act(mods[0], mods[1], mods[2], x)
         for m in mods[3:]:
             x = m(x)
         return x

@@ -159,6 +159,26 @@ int fsf_norm_act_backward(const float* x, const float* grad_out, int64_t n, int3
                           int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K22  per-point Linear (+ bias) -> LayerNorm | affine -> ReLU | GELU(erf) in one pass (inference)
+ * Replaces: the [nn.Linear, norm, act] blocks of build_mlp (projects/mmdet3d_plugin/ops/sst_ops.py:808-833) and of
+ *   DynamicVFELayer [UNVENDORED] applied to every point / cluster row: a library fp32 GEMM plus fsf_norm_act.
+ *   x f32 [n, k] (row stride x_stride floats, a multiple of 4; base 16-byte aligned), weight f32 [c, k] in torch Linear
+ *   layout, c <= 128 and a multiple of 4, bias f32 [c] or NULL; norm 0 none / 1 LayerNorm(gamma, beta, eps) /
+ *   2 affine y * gamma + beta (eval BatchNorm1d folded by the caller); act 0 none / 1 ReLU / 2 GELU(erf);
+ *   out f32 [n, c] (row stride out_stride, a multiple of 4).
+ * fsf_linear_prepare_weight splits the weight ONCE per layer into three bf16 planes (x = hi + mid + lo, an EXACT
+ *   split of the fp32 significand) in matrix-core fragment order; fsf_linear_norm_act splits x the same way in
+ *   registers and sums the six leading bf16 cross products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the
+ *   dropped terms are < 2^-23 of each product, i.e. fp32 accuracy (not a reduced-precision mode), at 2.5x the rate of
+ *   the fp32 matrix pipe.  Deterministic.
+ */
+int64_t fsf_linear_prepared_weight_bytes(int32_t k, int32_t c);
+int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t c, void* planes, void* stream);
+int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
+                        const float* bias, int32_t norm, const float* gamma, const float* beta, float eps, int32_t act,
+                        float* out, int64_t out_stride, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K13-K15  LiDAR -> camera projection + per-point instance-mask gather
  * Replaces: FSF.prj_points_2d (projects/mmdet3d_plugin/models/detectors/FSF.py:169-200) and
  *   FSF.points_in_mask (:202-226) for one batch sample; the caller loops samples like frustum_gather (:228-258).

@@ -717,6 +717,48 @@ def test_sir_input_vs_torch_composition(ops, device, p, cf, ce, r, act):
     assert torch.equal(out, ops.sir_input(points, feats, fcl, norm, (*layers, 1e-3), act, 10.0, extra=extra, extra_div=10.0))
 
 
+@pytest.mark.parametrize("n,k,c,norm,act,bias", [(50021, 256, 128, "ln", "gelu", False), (20000, 180, 128, "ln", "relu", False),
+                                                 (7001, 133, 128, "ln", "gelu", True), (30000, 11, 64, "affine", "relu", False),
+                                                 (513, 128, 128, "none", "none", True), (1, 64, 32, "ln", "gelu", False),
+                                                 (40000, 128, 64, "affine", "gelu", True)])
+def test_linear_norm_act_split_bf16_is_fp32_accurate(ops, device, n, k, c, norm, act, bias):
+    """K22: Linear -> LayerNorm / affine -> act with the product formed from the exact 3-way bf16 split (six cross terms).
+    Against float64: the error must be of the size of an fp32 GEMM's own error (compared with torch's fp32 F.linear on the
+    same data), on inputs with a wide dynamic range; row-strided input; deterministic."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(n + k)
+    kpad = (k + 3) // 4 * 4
+    xbuf = torch.full((n, kpad + 4), float("nan"), device=device)  # NaN padding: columns >= k must never be read into the sum
+    x = xbuf[:, :k]
+    x.copy_(torch.randn(n, k, device=device) * torch.exp(torch.randn(n, 1, device=device) * 2.0))
+    w = torch.randn(c, k, device=device) / k ** 0.5
+    b = torch.randn(c, device=device) if bias else None
+    g = torch.rand(c, device=device) + 0.5
+    be = torch.randn(c, device=device) * 0.1
+    planes = ops.linear_prepare_weight(w)
+    assert ops.linear_norm_act_supported(x, c)
+    out = ops.linear_norm_act(x, planes, c, bias=b, norm=norm, gamma=g if norm != "none" else None,
+                              beta=be if norm != "none" else None, eps=1e-3, act=act)
+
+    def tail(y):
+        if norm == "ln":
+            y = F.layer_norm(y, (c,), g.to(y.dtype), be.to(y.dtype), 1e-3)
+        elif norm == "affine":
+            y = y * g.to(y.dtype) + be.to(y.dtype)
+        return F.gelu(y) if act == "gelu" else F.relu(y) if act == "relu" else y
+
+    want = tail(F.linear(x.double(), w.double(), b.double() if bias else None))
+    ref32 = tail(F.linear(x.contiguous(), w, b))                      # what the library path computes in fp32
+    scale = max(1.0, float(want.abs().max()))
+    err = float((out.double() - want).abs().max())
+    err32 = float((ref32.double() - want).abs().max())
+    assert err <= max(2.0 * err32, 2e-6 * scale), (err, err32)
+    assert err <= 2e-5 * scale
+    assert torch.equal(out, ops.linear_norm_act(x, planes, c, bias=b, norm=norm, gamma=g if norm != "none" else None,
+                                                beta=be if norm != "none" else None, eps=1e-3, act=act))
+
+
 @pytest.mark.parametrize("n,w,k", [(20000, 60, 2), (3000, 60, 4), (17, 7, 7), (1, 128, 5)])
 def test_row_topk_desc_equals_torch_topk(ops, device, n, w, k):
     torch.manual_seed(n + w)
