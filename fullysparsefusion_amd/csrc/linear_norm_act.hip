@@ -27,14 +27,14 @@ typedef __bf16 lna_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float lna_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lna_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LNA_KC = 64;        // k per LDS chunk (two MFMA k steps)
+constexpr int LNA_KC = 32;        // k per LDS chunk (one MFMA k step)
 constexpr int LNA_NW = 4;         // waves per workgroup (two workgroups per CU: one wave of each per SIMD)
 constexpr int LNA_RG = 2;         // 16-row groups per wave and iteration
 constexpr int LNA_ROWS = LNA_NW * LNA_RG * 16;  // rows per workgroup iteration
 
 struct LnaArgs {
   const float* x; int64_t x_stride; int k;
-  const uint4* planes;  // [KP/64][T][2][3][64 lanes] x 16 B
+  const uint4* planes;  // [KP/32][T][3][64 lanes] x 16 B
   const float *bias, *gamma, *beta;
   float eps; int norm, act;  // norm 0 none / 1 LayerNorm / 2 affine (y * gamma + beta); act 0 / 1 ReLU / 2 GELU(erf)
   float* out; int64_t out_stride;
@@ -83,19 +83,18 @@ __device__ __forceinline__ float lna_act(float y, int act) {
 
 // weight [c, k] fp32 -> fragment-ordered bf16 planes (zero padded to T tiles x KP)
 __global__ void __launch_bounds__(256) lna_prepare_kernel(const float* __restrict__ w, int k, int c, int T, int nkc, uint4* planes) {
-  const int64_t total = (int64_t)nkc * T * 2 * 64;  // (chunk, tile, k step, lane): three 16-byte fragments each
+  const int64_t total = (int64_t)nkc * T * 64;  // (chunk, tile, lane): three 16-byte fragments each
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
-    const int s = (int)((idx >> 6) & 1);
-    const int t = (int)((idx >> 7) % T);
-    const int kc = (int)((idx >> 7) / T);
-    const int col = 16 * t + (lane & 15), k0 = kc * LNA_KC + 32 * s + 8 * (lane >> 4);
+    const int t = (int)((idx >> 6) % T);
+    const int kc = (int)((idx >> 6) / T);
+    const int col = 16 * t + (lane & 15), k0 = kc * LNA_KC + 8 * (lane >> 4);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (col < c && k0 + e < k) ? w[(int64_t)col * k + k0 + e] : 0.0f;
     lna_u32x4 hi, mid, lo;
     lna_split8(v, hi, mid, lo);
-    uint4* dst = planes + (((int64_t)(kc * T + t) * 2 + s) * 3) * 64 + lane;
+    uint4* dst = planes + ((int64_t)(kc * T + t) * 3) * 64 + lane;
     dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     dst[64] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
     dst[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
@@ -104,7 +103,7 @@ __global__ void __launch_bounds__(256) lna_prepare_kernel(const float* __restric
 
 template <int T>  // 16-channel tiles (c <= 16 T)
 __global__ void __launch_bounds__(LNA_NW * 64, 2) linear_norm_act_kernel(LnaArgs a) {
-  constexpr int CHUNK_U4 = T * 2 * 3 * 64;  // uint4 per weight chunk
+  constexpr int CHUNK_U4 = T * 3 * 64;  // uint4 per weight chunk
   extern __shared__ __attribute__((aligned(16))) char lna_smem[];
   uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -136,98 +135,74 @@ __global__ void __launch_bounds__(LNA_NW * 64, 2) linear_norm_act_kernel(LnaArgs
     }
     // raw x of one 64-wide chunk: [row group][k step][8 floats]; the NEXT chunk is requested while this one is split and
     // multiplied (a wave has one other wave on its SIMD: without the prefetch every k step waited for HBM)
-    // Always exactly two 16-byte loads per (row group, k step) — the barrier below counts on it: offsets past the row are
-    // clamped into it (x_stride is a multiple of 4 and >= k, so a quad that holds any column < k is never clamped) and
-    // the columns >= k are zeroed afterwards (what follows the row in memory may be NaN).
+    // Always exactly two 16-byte loads per row group: offsets past the row are clamped into it (x_stride is a multiple
+    // of 4 and >= k, so a quad that holds any column < k is never clamped) and the columns >= k are zeroed afterwards
+    // (what follows the row in memory may be NaN).
     const int last_quad = (int)a.x_stride - 4;
-    auto load_x = [&](int kc, float (&v)[LNA_RG][2][8]) {
+    auto load_x = [&](int kc, float (&v)[LNA_RG][8]) {
 #pragma unroll
-      for (int rg = 0; rg < LNA_RG; ++rg)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          const int kq = kc * LNA_KC + 32 * s + 8 * grp;  // this lane's 8 k values
-          const float* base = xrow[rg] - 8 * grp;
-          const float4 p = *reinterpret_cast<const float4*>(base + min(kq, last_quad));
-          const float4 q = *reinterpret_cast<const float4*>(base + min(kq + 4, last_quad));
-          v[rg][s][0] = p.x; v[rg][s][1] = p.y; v[rg][s][2] = p.z; v[rg][s][3] = p.w;
-          v[rg][s][4] = q.x; v[rg][s][5] = q.y; v[rg][s][6] = q.z; v[rg][s][7] = q.w;
-        }
-    };
-    auto mask_tail = [&](int kc, float (&v)[LNA_RG][2][8]) {
-      if ((kc + 1) * LNA_KC > a.k) {  // (uniform: only the last chunk of a k that is not a multiple of 64)
-#pragma unroll
-        for (int rg = 0; rg < LNA_RG; ++rg)
-#pragma unroll
-          for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (kc * LNA_KC + 32 * s + 8 * grp + e >= a.k) v[rg][s][e] = 0.0f;
+      for (int rg = 0; rg < LNA_RG; ++rg) {
+        const int kq = kc * LNA_KC + 8 * grp;  // this lane's 8 k values
+        const float* base = xrow[rg] - 8 * grp;
+        const float4 p = *reinterpret_cast<const float4*>(base + min(kq, last_quad));
+        const float4 q = *reinterpret_cast<const float4*>(base + min(kq + 4, last_quad));
+        v[rg][0] = p.x; v[rg][1] = p.y; v[rg][2] = p.z; v[rg][3] = p.w;
+        v[rg][4] = q.x; v[rg][5] = q.y; v[rg][6] = q.z; v[rg][7] = q.w;
       }
     };
-    constexpr int X_LOADS = LNA_RG * 2 * 2;  // VMEM instructions of one load_x
-    float xc[LNA_RG][2][8], xn[LNA_RG][2][8];
+    float xc[LNA_RG][8];
     load_x(0, xc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with both weight buffers of the previous row block
+    asm volatile("" ::: "memory");
+    stage_w(0, 0);
     for (int kc = 0; kc < nkc; ++kc) {
-      if (kc + 1 < nkc) load_x(kc + 1, xn);
-      // ONE weight buffer per workgroup (48 KB at 128 channels, so two workgroups fit a CU and drift out of phase: the
-      // norm / activation epilogue and the staging wait of one overlap the matrix phase of the other; with one 8-wave
-      // workgroup per CU every wave of a SIMD was in the same phase).
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // every wave is done reading the previous chunk
-      asm volatile("" ::: "memory");
-      stage_w(kc, 0);
-      // this wave's share of the DMA must have landed, the x prefetch (issued before it) may stay in flight... it cannot:
-      // VMEM retires in order and the prefetch is OLDER than the DMA, so waiting for the DMA waits for it too; the
-      // other workgroup of the CU covers that latency
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // everyone's share has landed
-      asm volatile("" ::: "memory");
-      const int buf = 0;
-      mask_tail(kc, xc);
-      const uint4* wc = wbuf + buf * CHUNK_U4;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        lna_u32x4 xh[LNA_RG], xm[LNA_RG], xl[LNA_RG];
-#pragma unroll
-        for (int rg = 0; rg < LNA_RG; ++rg) lna_split8(xc[rg][s], xh[rg], xm[rg], xl[rg]);
-        // Two channel tiles x LNA_RG row groups = 4 independent accumulators per product term: consecutive MFMAs never
-        // hit the same accumulator (a dependent MFMA with anything scheduled in between waits ~43 cycles for its
-        // predecessor; six of them chained on one accumulator ran the kernel 4x slower than the pipe allows)
-#pragma unroll
-        for (int t = 0; t < T; t += 2) {
-          lna_bf16x8 wfr[2][3];
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            const uint4* wf = wc + (((t + tt) * 2 + s) * 3) * 64 + lane;
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wfr[tt][pl] = __builtin_bit_cast(lna_bf16x8, wf[64 * pl]);
-          }
-          // (weight plane, x plane) of the six leading cross terms, small ones first
-          constexpr int TERM_W[6] = {2, 0, 1, 1, 0, 0};
-          constexpr int TERM_X[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-          for (int term = 0; term < 6; ++term)
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-              for (int rg = 0; rg < LNA_RG; ++rg) {
-                const lna_u32x4 xb = TERM_X[term] == 0 ? xh[rg] : TERM_X[term] == 1 ? xm[rg] : xl[rg];
-#ifndef FSF_ABL_LNA_NO_MFMA
-                acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[tt][TERM_W[term]], __builtin_bit_cast(lna_bf16x8, xb),
-                                                                          acc[rg][t + tt], 0, 0, 0);
-#else
-                acc[rg][t + tt][term & 3] += __uint_as_float(xb[term & 3]) * __uint_as_float(__builtin_bit_cast(lna_u32x4, wfr[tt][TERM_W[term]])[0]);
-#endif
-              }
-        }
-      }
-      if (kc + 1 < nkc) {
+      const int buf = kc & 1;
+      // split the chunk that arrived while the previous one was multiplied; its registers then take the next prefetch
+      lna_u32x4 xh[LNA_RG], xm[LNA_RG], xl[LNA_RG];
+      if ((kc + 1) * LNA_KC > a.k) {  // (uniform: the last chunk of a k that is not a multiple of 32)
 #pragma unroll
         for (int rg = 0; rg < LNA_RG; ++rg)
 #pragma unroll
-          for (int s = 0; s < 2; ++s)
+          for (int e = 0; e < 8; ++e)
+            if (kc * LNA_KC + 8 * grp + e >= a.k) xc[rg][e] = 0.0f;
+      }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xc[rg][s][e] = xn[rg][s][e];
+      for (int rg = 0; rg < LNA_RG; ++rg) lna_split8(xc[rg], xh[rg], xm[rg], xl[rg]);
+      // chunk kc's weights (DMA issued one iteration ago, before that iteration's MFMAs) have landed; the raw barrier
+      // carries no fence, so nothing else is drained with them
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // + every wave is done reading buffer buf^1
+      asm volatile("" ::: "memory");
+      if (kc + 1 < nkc) {
+        stage_w(kc + 1, buf ^ 1);
+        load_x(kc + 1, xc);
+      }
+      const uint4* wc = wbuf + buf * CHUNK_U4;
+      // Two channel tiles x LNA_RG row groups = 4 independent accumulators per product term: consecutive MFMAs never hit
+      // the same accumulator
+#pragma unroll
+      for (int t = 0; t < T; t += 2) {
+        lna_bf16x8 wfr[2][3];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const uint4* wf = wc + ((t + tt) * 3) * 64 + lane;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) wfr[tt][pl] = __builtin_bit_cast(lna_bf16x8, wf[64 * pl]);
+        }
+        // (weight plane, x plane) of the six leading cross terms, small ones first
+        constexpr int TERM_W[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int TERM_X[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int rg = 0; rg < LNA_RG; ++rg) {
+              const lna_u32x4 xb = TERM_X[term] == 0 ? xh[rg] : TERM_X[term] == 1 ? xm[rg] : xl[rg];
+              acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[tt][TERM_W[term]], __builtin_bit_cast(lna_bf16x8, xb),
+                                                                        acc[rg][t + tt], 0, 0, 0);
+            }
       }
     }
     // ---- epilogue: lane (row, g) holds channels 16 t + 4 g + r of its row
@@ -304,14 +279,14 @@ static int lna_tiles(int c) {
 extern "C" int64_t fsf_linear_prepared_weight_bytes(int32_t k, int32_t c) {
   if (k < 1 || c < 1) return 0;
   const int64_t nkc = (k + LNA_KC - 1) / LNA_KC;
-  return nkc * lna_tiles(c) * 2 * 3 * 64 * 16;
+  return nkc * lna_tiles(c) * 3 * 64 * 16;
 }
 
 extern "C" int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t c, void* planes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!weight || !planes || k < 1 || c < 1) return FSF_ERR_INVALID_ARG;
   const int T = lna_tiles(c), nkc = (k + LNA_KC - 1) / LNA_KC;
-  const int64_t total = (int64_t)nkc * T * 2 * 64;
+  const int64_t total = (int64_t)nkc * T * 64;
   hipLaunchKernelGGL(lna_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k, (int)c, T, nkc,
                      (uint4*)planes);
   FSF_LAUNCH_CHECK();
@@ -336,7 +311,7 @@ extern "C" int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t
   const unsigned grid = (unsigned)(nblk < 512 ? nblk : 512);  // two 4-wave workgroups per CU
 #define FSF_LNA(T_)                                                                                                     \
   do {                                                                                                                 \
-    constexpr size_t smem = (size_t)T_ * 2 * 3 * 64 * 16;                                                          \
+    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16;                                                          \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
       FSF_HIP_TRY(hipFuncSetAttribute((const void*)linear_norm_act_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
