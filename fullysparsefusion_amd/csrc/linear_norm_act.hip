@@ -30,6 +30,9 @@ typedef unsigned lna_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LNA_KC = 32;        // k per LDS chunk (one MFMA k step)
 constexpr int LNA_NW = 4;         // waves per workgroup (two workgroups per CU: one wave of each per SIMD)
 constexpr int LNA_RG = 2;         // 16-row groups per wave and iteration
+#ifndef LNA_WPS
+#define LNA_WPS 3                 // waves per SIMD the register budget is set for (workgroups per CU)
+#endif
 constexpr int LNA_ROWS = LNA_NW * LNA_RG * 16;  // rows per workgroup iteration
 
 struct LnaArgs {
@@ -102,7 +105,7 @@ __global__ void __launch_bounds__(256) lna_prepare_kernel(const float* __restric
 }
 
 template <int T>  // 16-channel tiles (c <= 16 T)
-__global__ void __launch_bounds__(LNA_NW * 64, 2) linear_norm_act_kernel(LnaArgs a) {
+__global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(LnaArgs a) {
   constexpr int CHUNK_U4 = T * 3 * 64;  // uint4 per weight chunk
   extern __shared__ __attribute__((aligned(16))) char lna_smem[];
   uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4]
@@ -308,7 +311,7 @@ extern "C" int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c};
   const int64_t nblk = (n + LNA_ROWS - 1) / LNA_ROWS;
-  const unsigned grid = (unsigned)(nblk < 512 ? nblk : 512);  // two 4-wave workgroups per CU
+  const unsigned grid = (unsigned)(nblk < 256 * LNA_WPS ? nblk : 256 * LNA_WPS);  // LNA_WPS 4-wave workgroups per CU
 #define FSF_LNA(T_)                                                                                                     \
   do {                                                                                                                 \
     constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16;                                                          \
