@@ -37,7 +37,7 @@ constexpr int LNA_ROWS = LNA_NW * LNA_RG * 16;  // rows per workgroup iteration
 
 struct LnaArgs {
   const float* x; int64_t x_stride; int k;
-  const uint4* planes;  // [KP/32][T][3][64 lanes] x 16 B
+  const uint4* planes;  // [slice][KP/32][T][3][64 lanes] x 16 B (slice = 128 output channels)
   const float *bias, *gamma, *beta;
   float eps; int norm, act;  // norm 0 none / 1 LayerNorm / 2 affine (y * gamma + beta); act 0 / 1 ReLU / 2 GELU(erf)
   float* out; int64_t out_stride;
@@ -85,19 +85,21 @@ __device__ __forceinline__ float lna_act(float y, int act) {
 }
 
 // weight [c, k] fp32 -> fragment-ordered bf16 planes (zero padded to T tiles x KP)
-__global__ void __launch_bounds__(256) lna_prepare_kernel(const float* __restrict__ w, int k, int c, int T, int nkc, uint4* planes) {
-  const int64_t total = (int64_t)nkc * T * 64;  // (chunk, tile, lane): three 16-byte fragments each
+__global__ void __launch_bounds__(256)
+    lna_prepare_kernel(const float* __restrict__ w, int k, int c, int T, int nkc, int nslice, uint4* planes) {
+  const int64_t total = (int64_t)nslice * nkc * T * 64;  // (slice, chunk, tile, lane): three 16-byte fragments each
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
     const int t = (int)((idx >> 6) % T);
-    const int kc = (int)((idx >> 6) / T);
-    const int col = 16 * t + (lane & 15), k0 = kc * LNA_KC + 8 * (lane >> 4);
+    const int kc = (int)(((idx >> 6) / T) % nkc);
+    const int slice = (int)((idx >> 6) / ((int64_t)T * nkc));
+    const int col = 128 * slice + 16 * t + (lane & 15), k0 = kc * LNA_KC + 8 * (lane >> 4);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (col < c && k0 + e < k) ? w[(int64_t)col * k + k0 + e] : 0.0f;
     lna_u32x4 hi, mid, lo;
     lna_split8(v, hi, mid, lo);
-    uint4* dst = planes + ((int64_t)(kc * T + t) * 3) * 64 + lane;
+    uint4* dst = planes + (((int64_t)slice * nkc + kc) * T + t) * 3 * 64 + lane;
     dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     dst[64] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
     dst[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
@@ -113,10 +115,14 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
   const int rowl = lane & 15, grp = lane >> 4;
   const int nkc = (a.k + LNA_KC - 1) / LNA_KC;
   const int64_t nblk = (a.n + LNA_ROWS - 1) / LNA_ROWS;
+  // more than 128 output channels: gridDim.y slices of 128, each an independent [rows, 128] product (no LayerNorm then:
+  // its statistics span the slices; the caller runs fsf_norm_act on the result)
+  const int ch_base = 128 * (int)blockIdx.y;
+  const uint4* planes = a.planes + (int64_t)blockIdx.y * nkc * CHUNK_U4;
 
   // weight chunk kc -> LDS buffer by LDS-DMA: fragment order in HBM == fragment order in LDS, 1 KB per wave instruction
   auto stage_w = [&](int kc, int buf) {
-    const float* src = reinterpret_cast<const float*>(a.planes + (int64_t)kc * CHUNK_U4);
+    const float* src = reinterpret_cast<const float*>(planes + (int64_t)kc * CHUNK_U4);
     float* dst = reinterpret_cast<float*>(wbuf + buf * CHUNK_U4);
     for (int u = wave * 64; u < CHUNK_U4; u += LNA_NW * 64)
       __builtin_amdgcn_global_load_lds(src + 4 * (u + lane), dst + 4 * u, 16, 0, 0);
@@ -217,7 +223,7 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
       if (a.bias) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const int ch0 = 16 * t + 4 * grp;
+          const int ch0 = ch_base + 16 * t + 4 * grp;
           if (ch0 < a.c) {
             const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
             acc[rg][t][0] += b.x; acc[rg][t][1] += b.y; acc[rg][t][2] += b.z; acc[rg][t][3] += b.w;
@@ -236,7 +242,7 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
         for (int t = 0; t < T; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float d = 16 * t + 4 * grp + r < a.c ? acc[rg][t][r] - mean : 0.0f;
+            const float d = ch_base + 16 * t + 4 * grp + r < a.c ? acc[rg][t][r] - mean : 0.0f;
             q += d * d;
           }
         rstd = rsqrtf(lna_row_sum(q) * inv_c + a.eps);
@@ -245,7 +251,7 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
         float* orow = a.out + row * a.out_stride;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          const int ch0 = 16 * t + 4 * grp;
+          const int ch0 = ch_base + 16 * t + 4 * grp;
           if (ch0 < a.c) {
             float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.norm != 0) {
@@ -279,19 +285,21 @@ static int lna_tiles(int c) {
   return t <= 2 ? 2 : (t <= 4 ? 4 : 8);
 }
 
+static int lna_slices(int c) { return (c + 127) / 128; }
+
 extern "C" int64_t fsf_linear_prepared_weight_bytes(int32_t k, int32_t c) {
   if (k < 1 || c < 1) return 0;
   const int64_t nkc = (k + LNA_KC - 1) / LNA_KC;
-  return nkc * lna_tiles(c) * 3 * 64 * 16;
+  return lna_slices(c) * nkc * lna_tiles(c) * 3 * 64 * 16;
 }
 
 extern "C" int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t c, void* planes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!weight || !planes || k < 1 || c < 1) return FSF_ERR_INVALID_ARG;
-  const int T = lna_tiles(c), nkc = (k + LNA_KC - 1) / LNA_KC;
-  const int64_t total = (int64_t)nkc * T * 64;
+  const int T = lna_tiles(c), nkc = (k + LNA_KC - 1) / LNA_KC, nslice = lna_slices(c);
+  const int64_t total = (int64_t)nslice * nkc * T * 64;
   hipLaunchKernelGGL(lna_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k, (int)c, T, nkc,
-                     (uint4*)planes);
+                     nslice, (uint4*)planes);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }
@@ -304,14 +312,17 @@ extern "C" int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t
       (n > 0 && (!x || !out)))
     return FSF_ERR_INVALID_ARG;
   // 16-byte row accesses: x rows and out rows must be 16-byte aligned, c a multiple of 4
-  if (c > 128 || (c % 4) != 0 || (x_stride % 4) != 0 || (out_stride % 4) != 0 || ((uintptr_t)x % 16) != 0 ||
+  if ((c > 128 && norm == 1) || (c % 4) != 0 || (x_stride % 4) != 0 || (out_stride % 4) != 0 || ((uintptr_t)x % 16) != 0 ||
       ((uintptr_t)out % 16) != 0)
     return FSF_ERR_UNSUPPORTED;
   if (x_stride < k || out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c};
   const int64_t nblk = (n + LNA_ROWS - 1) / LNA_ROWS;
-  const unsigned grid = (unsigned)(nblk < 256 * LNA_WPS ? nblk : 256 * LNA_WPS);  // LNA_WPS 4-wave workgroups per CU
+  const int nslice = lna_slices(c);
+  int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;  // LNA_WPS 4-wave workgroups per CU in total
+  if (gx > nblk) gx = nblk;
+  const dim3 grid((unsigned)gx, (unsigned)nslice);
 #define FSF_LNA(T_)                                                                                                     \
   do {                                                                                                                 \
     constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16;                                                          \
@@ -321,7 +332,7 @@ extern "C" int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t
                                       (int)smem));                                                                     \
       attr_set = true;                                                                                                 \
     }                                                                                                                  \
-    hipLaunchKernelGGL((linear_norm_act_kernel<T_>), dim3(grid), dim3(LNA_NW * 64), smem, stream, a);                  \
+    hipLaunchKernelGGL((linear_norm_act_kernel<T_>), grid, dim3(LNA_NW * 64), smem, stream, a);                  \
   } while (0)
   const int T = lna_tiles(c);
   if (T == 2) FSF_LNA(2);

@@ -471,8 +471,9 @@ def linear_prepare_weight(weight: torch.Tensor):
 
 
 def linear_norm_act_supported(x: torch.Tensor, out_features: int) -> bool:
-    """Shapes the fused K22 kernel takes: fp32 rows that start 16-byte aligned, at most 128 output channels."""
-    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and out_features <= 128 and out_features % 4 == 0
+    """Shapes the K22 kernel takes: fp32 rows that start 16-byte aligned, output channels a multiple of 4 (LayerNorm inside
+    the kernel only up to 128 channels)."""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and out_features % 4 == 0
             and (x.size(0) <= 1 or x.stride(0) % 4 == 0) and x.stride(1) == 1 and x.data_ptr() % 16 == 0)
 
 

@@ -235,6 +235,11 @@ def linear_norm_act(linear, norm, act, x, out=None):
     act_code = "relu" if isinstance(act, nn.ReLU) else (
         "gelu" if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none" else None)
     if (not needs_grad and act_code is not None and isinstance(linear, nn.Linear) and x.dim() == 2 and x.size(0) >= 1024
+            and x.is_cuda and x.dtype == torch.float32 and linear.in_features <= 64
+            and not hip_ops.linear_norm_act_supported(x, linear.out_features) and linear.out_features % 4 == 0):
+        k = x.size(1)  # thin inputs ([n, 10] image features, [n, 11] VFE decorations): one small copy buys aligned rows
+        x = F.pad(x, (0, (-k) % 4))[:, :k]
+    if (not needs_grad and act_code is not None and isinstance(linear, nn.Linear) and x.dim() == 2 and x.size(0) >= 1024
             and hip_ops.linear_norm_act_supported(x, linear.out_features)
             and (out is None or (out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0))):
         kind = None
@@ -251,6 +256,9 @@ def linear_norm_act(linear, norm, act, x, out=None):
             if cache is None or cache[0] != key:
                 cache = (key, hip_ops.linear_prepare_weight(linear.weight))
                 linear.__dict__["_fsf_planes"] = cache
+            if kind == "ln" and linear.out_features > 128:  # LayerNorm statistics span the kernel's 128-channel slices
+                y = hip_ops.linear_norm_act(x, cache[1], linear.out_features, bias=linear.bias)
+                return fused_norm_act(y, norm, act, out=out)
             return hip_ops.linear_norm_act(x, cache[1], linear.out_features, bias=linear.bias, norm=kind, gamma=gamma,
                                            beta=beta, eps=eps, act=act_code, out=out)
     return fused_norm_act(point_linear(linear, x), norm, act, out=out)

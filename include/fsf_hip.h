@@ -163,7 +163,8 @@ int fsf_norm_act_backward(const float* x, const float* grad_out, int64_t n, int3
  * Replaces: the [nn.Linear, norm, act] blocks of build_mlp (projects/mmdet3d_plugin/ops/sst_ops.py:808-833) and of
  *   DynamicVFELayer [UNVENDORED] applied to every point / cluster row: a library fp32 GEMM plus fsf_norm_act.
  *   x f32 [n, k] (row stride x_stride floats, a multiple of 4; base 16-byte aligned), weight f32 [c, k] in torch Linear
- *   layout, c <= 128 and a multiple of 4, bias f32 [c] or NULL; norm 0 none / 1 LayerNorm(gamma, beta, eps) /
+ *   layout, c a multiple of 4 (LayerNorm: c <= 128; wider layers run as 128-channel slices with norm 0 or 2 and the
+ *   caller applies fsf_norm_act), bias f32 [c] or NULL; norm 0 none / 1 LayerNorm(gamma, beta, eps) /
  *   2 affine y * gamma + beta (eval BatchNorm1d folded by the caller); act 0 none / 1 ReLU / 2 GELU(erf);
  *   out f32 [n, c] (row stride out_stride, a multiple of 4).
  * fsf_linear_prepare_weight splits the weight ONCE per layer into three bf16 planes (x = hi + mid + lo, an EXACT

@@ -720,7 +720,9 @@ def test_sir_input_vs_torch_composition(ops, device, p, cf, ce, r, act):
 @pytest.mark.parametrize("n,k,c,norm,act,bias", [(50021, 256, 128, "ln", "gelu", False), (20000, 180, 128, "ln", "relu", False),
                                                  (7001, 133, 128, "ln", "gelu", True), (30000, 11, 64, "affine", "relu", False),
                                                  (513, 128, 128, "none", "none", True), (1, 64, 32, "ln", "gelu", False),
-                                                 (40000, 128, 64, "affine", "gelu", True)])
+                                                 (40000, 128, 64, "affine", "gelu", True),
+                                                 (10641, 1024, 1024, "none", "none", True), (5000, 768, 1024, "affine", "relu", False),
+                                                 (3001, 128, 132, "none", "none", True)])
 def test_linear_norm_act_split_bf16_is_fp32_accurate(ops, device, n, k, c, norm, act, bias):
     """K22: Linear -> LayerNorm / affine -> act with the product formed from the exact 3-way bf16 split (six cross terms).
     Against float64: the error must be of the size of an fp32 GEMM's own error (compared with torch's fp32 F.linear on the
