@@ -358,6 +358,31 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// decoder shortcut of SimpleSparseUNet: out[i, j] = add[i, j] + sum_{q < r} feat[i, j * r + q]   (r = cin / cout)
+template <int R>
+__global__ void __launch_bounds__(256)
+    channel_group_sum_add_kernel(const float* __restrict__ feat, const float* __restrict__ add, int64_t n, int cout,
+                                 float* __restrict__ out) {
+  const int cv = cout / 4;
+  const int64_t total = n * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / cv;
+    const int j = (int)(t - i * cv) * 4;
+    const float* f = feat + (i * cout + j) * R;
+    float4 o = add ? *reinterpret_cast<const float4*>(add + i * cout + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // torch's sum(dim=2) adds the r values of a group in index order
+      float s = f[e * R];
+#pragma unroll
+      for (int q = 1; q < R; ++q) s = __fadd_rn(s, f[e * R + q]);
+      acc[e] = s;
+    }
+    o.x = __fadd_rn(o.x, acc[0]); o.y = __fadd_rn(o.y, acc[1]); o.z = __fadd_rn(o.z, acc[2]); o.w = __fadd_rn(o.w, acc[3]);
+    *reinterpret_cast<float4*>(out + i * cout + j) = o;
+  }
+}
+
 struct V2PParams {
   float vx, vy, vz, xmin, ymin, zmin, padding;
 };
@@ -537,6 +562,20 @@ extern "C" int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int
   else
     hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(fsf_stream_grid(n * c, 256)), dim3(256), 0, stream, src, idx, n,
                        (int)c, out, out_stride);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t cin, int32_t cout, const float* add, float* out,
+                                         void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || cin < 1 || cout < 1 || (n > 0 && (!feat || !out))) return FSF_ERR_INVALID_ARG;
+  // r = 2 only (every decoder level of the FSF configs): a two-term sum has one order, so the result is bit-identical to
+  // torch's `sum(2)`; wider groups would have to copy ATen's reduction tree to stay so
+  if (cin != 2 * cout || cout % 4 != 0) return FSF_ERR_UNSUPPORTED;
+  if (n == 0) return FSF_OK;
+  const dim3 grid(fsf_stream_grid(n * (cout / 4), 256));
+  hipLaunchKernelGGL((channel_group_sum_add_kernel<2>), grid, dim3(256), 0, stream, feat, add, n, (int)cout, out);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -45,6 +45,7 @@ _ARGTYPES = {
     "fsf_row_topk_desc": [_P, c_i64, c_i32, c_i32, _P, _P],
     "fsf_sir_input": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
                       _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
+    "fsf_channel_group_sum_add": [_P, c_i64, c_i32, c_i32, _P, _P, _P],
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
     "fsf_linear_norm_act": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
@@ -224,6 +225,19 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor
     assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) >= c
     check(_L().fsf_gather_rows(ptr(src), m, c, ptr(idx), n, c_p(out.data_ptr()), out.stride(0), stream_ptr()),
           "fsf_gather_rows")
+    return out
+
+
+def channel_group_sum_add(feat: torch.Tensor, cout: int, add: Optional[torch.Tensor] = None):
+    """fsf_channel_group_sum_add: feat f32 [n, cin] -> add + feat.view(n, cout, cin // cout).sum(2), f32 [n, cout]."""
+    require_cuda(feat, add)
+    feat = feat.contiguous()
+    n, cin = feat.shape
+    if add is not None:
+        add = add.contiguous()
+        assert add.shape == (n, cout)
+    out = torch.empty((n, cout), dtype=torch.float32, device=feat.device)
+    check(_L().fsf_channel_group_sum_add(ptr(feat), n, cin, cout, ptr(add), ptr(out), stream_ptr()), "fsf_channel_group_sum_add")
     return out
 
 

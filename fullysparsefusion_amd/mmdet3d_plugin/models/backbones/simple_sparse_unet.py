@@ -8,6 +8,7 @@ output rows in the input voxel order.  Submodule names follow upstream (`conv_in
 import torch
 import torch.nn as nn
 
+from .... import hip_ops
 from ...ops.spconv import SparseBasicBlock, SparseConvTensor, SparseSequential, make_sparse_convmodule
 from ...registry import BACKBONES
 
@@ -96,8 +97,13 @@ class SimpleSparseUNet(nn.Module):
         x = lateral_layer(x_lateral)
         x = x._like(torch.cat((x_bottom.features, x.features), dim=1))
         x_merge = merge_layer(x)
-        x = self.reduce_channel(x, x_merge.features.shape[1])
-        x = x._like(x_merge.features + x.features)
+        cout, f = x_merge.features.shape[1], x.features
+        if (f.is_cuda and f.dtype == torch.float32 and not (torch.is_grad_enabled() and (f.requires_grad or x_merge.features.requires_grad))
+                and f.shape[1] == 2 * cout and cout % 4 == 0):
+            x = x._like(hip_ops.channel_group_sum_add(f, cout, add=x_merge.features))  # reduce_channel + the add, one pass
+        else:
+            x = self.reduce_channel(x, cout)
+            x = x._like(x_merge.features + x.features)
         return upsample_layer(x)
 
     def forward(self, voxel_info, batch_size=None):

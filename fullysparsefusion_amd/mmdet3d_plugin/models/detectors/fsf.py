@@ -328,7 +328,10 @@ class FSF(SingleStageFSD):
         if not self.training and self.cfg.get("group_sample", False) and not self.test_cfg.get("add_gt_fg_points", False):
             points, seg_logits, seg_vote_preds, seg_feats, center_preds, pts_cluster_inds = \
                 self.grouped_sample_and_cluster(dict_to_sample)
-            pts_feats = torch.cat([seg_logits, seg_vote_preds, seg_feats], dim=1)
+            pts_feats = getattr(self, "_grouped_feats_concat", None)  # the three, already side by side in one buffer
+            self._grouped_feats_concat = None
+            if pts_feats is None:
+                pts_feats = torch.cat([seg_logits, seg_vote_preds, seg_feats], dim=1)
         else:
             sampled_out = self.sample(dict_to_sample, dict_to_sample["vote_offsets"])
             cluster_inds_list, valid_mask_list = self.cluster_assigner(sampled_out["center_preds"], sampled_out["batch_idx"],

@@ -257,6 +257,19 @@ class SingleStageFSD(nn.Module):
         cluster = (labels - base.index_select(0, vox_group)).index_select(0, vox_inv)
         pts_cluster_inds = torch.stack([g_ids, b_pts, cluster], 1)
         take = lambda t: t.index_select(0, p_ids)  # noqa: E731
+        parts = [seg_logits, d["seg_vote_preds"], d["seg_feats"]]
+        if all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 for t in parts):
+            # the caller concatenates the three (FSF.py fsd_forward): gather them straight into one [n, 11 + 33 + 131]
+            # buffer — the rows are written once instead of gathered and then copied again by torch.cat
+            widths = [t.size(1) for t in parts]
+            buf = torch.empty((p_ids.numel(), sum(widths)), dtype=torch.float32, device=dev)
+            views, c0 = [], 0
+            for t, w in zip(parts, widths):
+                views.append(hip_ops.gather_rows(t, p_ids, out=buf[:, c0:c0 + w]))
+                c0 += w
+            self._grouped_feats_concat = buf
+            return take(d["seg_points"]), views[0], views[1], views[2], centers, pts_cluster_inds
+        self._grouped_feats_concat = None
         return (take(d["seg_points"]), take(seg_logits), take(d["seg_vote_preds"]), take(d["seg_feats"]), centers,
                 pts_cluster_inds)
 

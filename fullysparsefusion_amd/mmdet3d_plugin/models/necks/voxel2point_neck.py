@@ -28,6 +28,8 @@ class Voxel2PointScatterNeck(nn.Module):
                 vs = torch.tensor(self.voxel_size, dtype=out.dtype, device=out.device).reshape(1, 3)
                 assert (out[pts_mask][:, -3:].abs() < vs / 2 + 1e-3).all(), \
                     "Holds in training. However, in test, this is not always True because of lack of point range clip"
+            if not self.training and bool(pts_mask.all()):  # no padded voxel row (the usual case): nothing to compact
+                return out, pts_mask
             return out[pts_mask], pts_mask
         dtype, device = voxel_feats.dtype, voxel_feats.device
         pts_feats = gather_by_inverse(voxel_feats, voxel2point_inds)

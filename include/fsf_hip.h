@@ -130,6 +130,13 @@ int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int32_t c, con
 int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
                     int64_t out_stride, void* stream);
 
+/* SimpleSparseUNet decoder shortcut [UNVENDORED; SURVEY App. C decoder_layer_forward]:
+ *   `x.features.view(n, C_out, -1).sum(2) + m.features` in one pass: out[i,j] = add[i,j] + sum_q feat[i, j*r + q],
+ *   r = cin / cout = 2 (every decoder level of the FSF configs; bit-identical to the two torch ops); add may be NULL;
+ *   cout % 4 == 0. */
+int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t cin, int32_t cout, const float* add, float* out,
+                              void* stream);
+
 /* Fused a7: Voxel2PointScatterNeck.forward (voxel2point_neck.py:27-70) without the boolean compaction:
  *   out[i, 0:c]   = voxel_feats[inv[i], :]
  *   out[i, c:c+3] = xyz[i] - ((coors[i,[3,2,1]] + 0.5) * voxel + range_min)

@@ -761,6 +761,17 @@ def test_linear_norm_act_split_bf16_is_fp32_accurate(ops, device, n, k, c, norm,
                                                 beta=be if norm != "none" else None, eps=1e-3, act=act))
 
 
+@pytest.mark.parametrize("n,cin,cout", [(101119, 256, 128), (1517, 1024, 512), (33, 128, 64), (1, 8, 4)])
+def test_channel_group_sum_add_equals_torch(ops, device, n, cin, cout):
+    """The U-Net decoder's `features.view(n, C, -1).sum(2) + merge` in one pass: bit-identical to the two torch ops."""
+    torch.manual_seed(n)
+    f = torch.randn(n, cin, device=device)
+    m = torch.randn(n, cout, device=device)
+    want = m + f.view(n, cout, -1).sum(dim=2)
+    assert torch.equal(ops.channel_group_sum_add(f, cout, add=m), want)
+    assert torch.equal(ops.channel_group_sum_add(f, cout), f.view(n, cout, -1).sum(dim=2))
+
+
 @pytest.mark.parametrize("n,w,k", [(20000, 60, 2), (3000, 60, 4), (17, 7, 7), (1, 128, 5)])
 def test_row_topk_desc_equals_torch_topk(ops, device, n, w, k):
     torch.manual_seed(n + w)
