@@ -1,0 +1,294 @@
+// K9b: sparse convolution forward, ROW-stationary, on the bf16 matrix cores with the exact 3-way bf16 split (fp32-accurate).
+// See include/fsf_hip.h (fsf_spconv_forward_split) and spconv.hip for the fp32-pipe kernel it complements.
+//
+// out[o, :] = act(scale * (sum_k feat[nbr[o, k], :] @ W[k]) + shift + residual).  The fp32-pipe kernel keeps a
+// [64 rows x 128 channels] tile in LDS and compacts, per offset, the rows that have a neighbour; its matrix phase is
+// bound by the fp32 MFMA rate (1/16 of bf16) and the compaction costs an LDS read-modify-write of the tile per offset,
+// row lists, an A tile in LDS and a workgroup barrier per stage.  Here a wave OWNS 32 output rows for all 27 offsets:
+//   * transposed product out^T[channel, row] = W_k^T[channel, cin] x X_k^T[cin, row] — the weights are the A operand
+//     (split once per layer into hi/mid/lo bf16 planes in fragment order, streamed through LDS per (offset, 32-cin chunk),
+//     double-buffered by LDS-DMA), the wave's 2 x 16 rows are the B operand: lane (row, g) reads the 32 bytes of ITS
+//     neighbour row straight from HBM/L2 (no A tile in LDS, no compaction, no row lists) and splits them in registers —
+//     each input value is split by exactly one wave;
+//   * the accumulators (2 row groups x 8 channel tiles) stay in registers over the whole offset loop: no LDS C tile, no
+//     scatter; rows without a neighbour at an offset contribute zeros (their lanes are wasted: 46 % on the 0.4 m level,
+//     80 % on the 0.2 m level — paid for by the 2.5x cheaper six-term bf16 product; a wave skips an offset none of its
+//     32 rows has);
+//   * six leading cross terms of the exact split, fp32 accumulation: fp32 accuracy (see linear_norm_act.hip).
+// Deterministic: fixed (offset, cin) order, no atomics.
+#include "common.h"
+
+namespace fsf {
+
+typedef __bf16 scs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float scs_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned scs_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SCS_KC = 32;   // cin per LDS weight chunk (one MFMA k step)
+constexpr int SCS_NW = 4;    // waves per workgroup
+constexpr int SCS_RG = 2;    // 16-row groups per wave
+constexpr int SCS_ROWS = SCS_NW * SCS_RG * 16;
+#ifndef SCS_WPS
+#define SCS_WPS 3            // workgroups per CU the register budget is set for
+#endif
+
+struct ScsArgs {
+  const float* feat;
+  const uint4* planes;  // [slice][kvol][cin/32][T][3][64 lanes] x 16 B
+  const int32_t* nbr;
+  const float *scale, *shift, *residual;
+  float* out;
+  int64_t m_in, m_out;
+  int cin, cout, kvol, relu;
+};
+
+__device__ __forceinline__ void scs_split8(const float (&v)[8], scs_u32x4& hi, scs_u32x4& mid, scs_u32x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    const float ah = __uint_as_float(__float_as_uint(a) & 0xffff0000u), bh = __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+    const float ar = __fsub_rn(a, ah), br = __fsub_rn(b, bh);
+    const float am = __uint_as_float(__float_as_uint(ar) & 0xffff0000u), bm = __uint_as_float(__float_as_uint(br) & 0xffff0000u);
+    const float al = __fsub_rn(ar, am), bl = __fsub_rn(br, bm);
+    hi[j] = __builtin_amdgcn_perm(__float_as_uint(bh), __float_as_uint(ah), 0x07060302u);
+    mid[j] = __builtin_amdgcn_perm(__float_as_uint(bm), __float_as_uint(am), 0x07060302u);
+    lo[j] = __builtin_amdgcn_perm(__float_as_uint(bl), __float_as_uint(al), 0x07060302u);
+  }
+}
+
+// weight [kvol][cin][cout] fp32 (the spconv v1 layout) -> fragment-ordered bf16 planes of W_k^T
+__global__ void __launch_bounds__(256)
+    scs_prepare_kernel(const float* __restrict__ w, int kvol, int cin, int cout, int T, int nkc, int nslice, uint4* planes) {
+  const int64_t total = (int64_t)nslice * kvol * nkc * T * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t r = idx >> 6;
+    const int t = (int)(r % T); r /= T;
+    const int kc = (int)(r % nkc); r /= nkc;
+    const int k = (int)(r % kvol);
+    const int slice = (int)(r / kvol);
+    const int col = 128 * slice + 16 * t + (lane & 15), c0 = kc * SCS_KC + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (col < cout && c0 + e < cin) ? w[((int64_t)k * cin + c0 + e) * cout + col] : 0.0f;
+    scs_u32x4 hi, mid, lo;
+    scs_split8(v, hi, mid, lo);
+    uint4* dst = planes + ((((int64_t)slice * kvol + k) * nkc + kc) * T + t) * 3 * 64 + lane;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[64] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
+    dst[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
+template <int T>
+__global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(ScsArgs a) {
+  constexpr int CHUNK_U4 = T * 3 * 64;
+  extern __shared__ __attribute__((aligned(16))) char scs_smem[];
+  uint4* wbuf = reinterpret_cast<uint4*>(scs_smem);  // [2][CHUNK_U4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rowl = lane & 15, grp = lane >> 4;
+  const int nkc = (a.cin + SCS_KC - 1) / SCS_KC;
+  const int nchunks = a.kvol * nkc;
+  const int64_t nblk = (a.m_out + SCS_ROWS - 1) / SCS_ROWS;
+  const int ch_base = 128 * (int)blockIdx.y;
+  const uint4* planes = a.planes + (int64_t)blockIdx.y * nchunks * CHUNK_U4;
+  const int last_quad = a.cin - 4;
+
+  auto stage_w = [&](int ci, int buf) {
+    const float* src = reinterpret_cast<const float*>(planes + (int64_t)ci * CHUNK_U4);
+    float* dst = reinterpret_cast<float*>(wbuf + buf * CHUNK_U4);
+    for (int u = wave * 64; u < CHUNK_U4; u += SCS_NW * 64)
+      __builtin_amdgcn_global_load_lds(src + 4 * (u + lane), dst + 4 * u, 16, 0, 0);
+  };
+
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t row0 = blk * SCS_ROWS + (int64_t)wave * (SCS_RG * 16);
+    scs_f32x4 acc[SCS_RG][T];
+#pragma unroll
+    for (int rg = 0; rg < SCS_RG; ++rg)
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[rg][t] = scs_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int32_t* nrow[SCS_RG];  // this lane's row of the neighbour table
+#pragma unroll
+    for (int rg = 0; rg < SCS_RG; ++rg) {
+      int64_t r = row0 + 16 * rg + rowl;
+      if (r >= a.m_out) r = a.m_out - 1;  // rows past m_out repeat the last one (never stored)
+      nrow[rg] = a.nbr + r * a.kvol;
+    }
+    // neighbour ids two offsets ahead of their use, raw x one chunk ahead (a missing neighbour reads row 0 and is zeroed)
+    int idx_cur[SCS_RG], idx_nxt[SCS_RG];
+#pragma unroll
+    for (int rg = 0; rg < SCS_RG; ++rg) {
+      idx_cur[rg] = nrow[rg][0];
+      idx_nxt[rg] = a.kvol > 1 ? nrow[rg][1] : -1;
+    }
+    auto load_x = [&](const int (&idx)[SCS_RG], int kc, float (&v)[SCS_RG][8]) {
+#pragma unroll
+      for (int rg = 0; rg < SCS_RG; ++rg) {
+        const float* base = a.feat + (int64_t)(idx[rg] < 0 ? 0 : idx[rg]) * a.cin;
+        const int cq = kc * SCS_KC + 8 * grp;
+        const float4 p = *reinterpret_cast<const float4*>(base + min(cq, last_quad));
+        const float4 q = *reinterpret_cast<const float4*>(base + min(cq + 4, last_quad));
+        v[rg][0] = p.x; v[rg][1] = p.y; v[rg][2] = p.z; v[rg][3] = p.w;
+        v[rg][4] = q.x; v[rg][5] = q.y; v[rg][6] = q.z; v[rg][7] = q.w;
+      }
+    };
+    float xc[SCS_RG][8];
+    load_x(idx_cur, 0, xc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave is done with both weight buffers of the previous row block
+    asm volatile("" ::: "memory");
+    stage_w(0, 0);
+    int k = 0, kc = 0;
+    for (int ci = 0; ci < nchunks; ++ci) {
+      const int buf = ci & 1;
+      // ---- split the chunk that arrived while the previous one was multiplied
+      scs_u32x4 xh[SCS_RG], xm[SCS_RG], xl[SCS_RG];
+      bool any_live = false;
+#pragma unroll
+      for (int rg = 0; rg < SCS_RG; ++rg) {
+        const bool live = idx_cur[rg] >= 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (!live || kc * SCS_KC + 8 * grp + e >= a.cin) xc[rg][e] = 0.0f;
+        scs_split8(xc[rg], xh[rg], xm[rg], xl[rg]);
+        any_live |= live;
+      }
+      const bool wave_live = __ballot(any_live) != 0ull;  // does any of this wave's 32 rows have a neighbour at offset k?
+      // ---- advance (k, kc) to the next chunk; the neighbour ids of its offset are already in registers
+      const int k_this = k;
+      int nk = k, nkci = kc + 1;
+      if (nkci == nkc) { nkci = 0; nk = k + 1; }
+      if (nk != k) {
+#pragma unroll
+        for (int rg = 0; rg < SCS_RG; ++rg) idx_cur[rg] = idx_nxt[rg];
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // chunk ci's weights have landed everywhere; buffer buf^1 is free
+      asm volatile("" ::: "memory");
+      if (ci + 1 < nchunks) {
+        stage_w(ci + 1, buf ^ 1);
+        load_x(idx_cur, nkci, xc);
+        if (nk != k) {  // first chunk of a new offset: fetch the ids of the offset after it
+#pragma unroll
+          for (int rg = 0; rg < SCS_RG; ++rg) idx_nxt[rg] = nk + 1 < a.kvol ? nrow[rg][nk + 1] : -1;
+        }
+      }
+      k = nk;
+      kc = nkci;
+      (void)k_this;
+      if (wave_live) {
+        const uint4* wc = wbuf + buf * CHUNK_U4;
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+          scs_bf16x8 wfr[2][3];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const uint4* wf = wc + ((t + tt) * 3) * 64 + lane;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wfr[tt][pl] = __builtin_bit_cast(scs_bf16x8, wf[64 * pl]);
+          }
+          constexpr int TERM_W[6] = {2, 0, 1, 1, 0, 0};  // (weight plane, x plane) of the six leading cross terms,
+          constexpr int TERM_X[6] = {0, 2, 1, 0, 1, 0};  // small ones first
+#pragma unroll
+          for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+              for (int rg = 0; rg < SCS_RG; ++rg) {
+                const scs_u32x4 xb = TERM_X[term] == 0 ? xh[rg] : TERM_X[term] == 1 ? xm[rg] : xl[rg];
+                acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[tt][TERM_W[term]], __builtin_bit_cast(scs_bf16x8, xb),
+                                                                          acc[rg][t + tt], 0, 0, 0);
+              }
+        }
+      }
+    }
+    // ---- epilogue: lane (row, g) holds channels ch_base + 16 t + 4 g + r of its row
+#pragma unroll
+    for (int rg = 0; rg < SCS_RG; ++rg) {
+      const int64_t row = row0 + 16 * rg + rowl;
+      if (row < a.m_out) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int ch0 = ch_base + 16 * t + 4 * grp;
+          if (ch0 < a.cout) {
+            float4 y = make_float4(acc[rg][t][0], acc[rg][t][1], acc[rg][t][2], acc[rg][t][3]);
+            if (a.scale) {
+              const float4 sc = *reinterpret_cast<const float4*>(a.scale + ch0), sh = *reinterpret_cast<const float4*>(a.shift + ch0);
+              y.x = __fmaf_rn(y.x, sc.x, sh.x); y.y = __fmaf_rn(y.y, sc.y, sh.y);
+              y.z = __fmaf_rn(y.z, sc.z, sh.z); y.w = __fmaf_rn(y.w, sc.w, sh.w);
+            } else if (a.shift) {
+              const float4 sh = *reinterpret_cast<const float4*>(a.shift + ch0);
+              y.x = __fadd_rn(y.x, sh.x); y.y = __fadd_rn(y.y, sh.y); y.z = __fadd_rn(y.z, sh.z); y.w = __fadd_rn(y.w, sh.w);
+            }
+            if (a.residual) {
+              const float4 rs = *reinterpret_cast<const float4*>(a.residual + row * a.cout + ch0);
+              y.x = __fadd_rn(y.x, rs.x); y.y = __fadd_rn(y.y, rs.y); y.z = __fadd_rn(y.z, rs.z); y.w = __fadd_rn(y.w, rs.w);
+            }
+            if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+            *reinterpret_cast<float4*>(a.out + row * a.cout + ch0) = y;
+          }
+        }
+      }
+    }
+  }
+}
+
+}  // namespace fsf
+
+using namespace fsf;
+
+static int scs_tiles(int cout) { return cout <= 64 ? 4 : 8; }
+static int scs_slices(int cout) { return (cout + 127) / 128; }
+
+extern "C" int64_t fsf_spconv_split_weight_bytes(int32_t kvol, int32_t cin, int32_t cout) {
+  if (kvol < 1 || cin < 1 || cout < 1) return 0;
+  const int64_t nkc = (cin + SCS_KC - 1) / SCS_KC;
+  return (int64_t)scs_slices(cout) * kvol * nkc * scs_tiles(cout) * 3 * 64 * 16;
+}
+
+extern "C" int fsf_spconv_prepare_weight_split(const float* weight, int32_t kvol, int32_t cin, int32_t cout, void* planes,
+                                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!weight || !planes || kvol < 1 || cin < 1 || cout < 1) return FSF_ERR_INVALID_ARG;
+  const int T = scs_tiles(cout), nkc = (cin + SCS_KC - 1) / SCS_KC, nslice = scs_slices(cout);
+  const int64_t total = (int64_t)nslice * kvol * nkc * T * 64;
+  hipLaunchKernelGGL(scs_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)kvol, (int)cin,
+                     (int)cout, T, nkc, nslice, (uint4*)planes);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t cin, const void* planes, int32_t kvol,
+                                        int32_t cout, const int32_t* nbr, int64_t m_out, const float* scale,
+                                        const float* shift, const float* residual, int32_t relu, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m_in < 0 || m_out < 0 || cin < 1 || cout < 1 || kvol < 1 || !planes || (scale && !shift) ||
+      (m_out > 0 && (!nbr || !out)) || (m_in > 0 && !feat))
+    return FSF_ERR_INVALID_ARG;
+  if ((cin % 4) != 0 || (cout % 4) != 0 || ((uintptr_t)feat % 16) != 0 || ((uintptr_t)out % 16) != 0) return FSF_ERR_UNSUPPORTED;
+  if (m_out == 0) return FSF_OK;
+  if (m_in == 0) return FSF_ERR_INVALID_ARG;  // (a missing neighbour reads row 0)
+  ScsArgs a{feat, (const uint4*)planes, nbr, scale, shift, residual, out, m_in, m_out, (int)cin, (int)cout, (int)kvol, (int)relu};
+  const int64_t nblk = (m_out + SCS_ROWS - 1) / SCS_ROWS;
+  const int nslice = scs_slices(cout);
+  int64_t gx = (256 * SCS_WPS + nslice - 1) / nslice;
+  if (gx > nblk) gx = nblk;
+  const dim3 grid((unsigned)gx, (unsigned)nslice);
+#define FSF_SCS(T_)                                                                                                     \
+  do {                                                                                                                 \
+    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16;                                                              \
+    static bool attr_set = false;                                                                                      \
+    if (!attr_set) {                                                                                                   \
+      FSF_HIP_TRY(hipFuncSetAttribute((const void*)spconv_fwd_split_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)smem));                                                                     \
+      attr_set = true;                                                                                                 \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((spconv_fwd_split_kernel<T_>), grid, dim3(SCS_NW * 64), smem, stream, a);                       \
+  } while (0)
+  if (scs_tiles(cout) == 4) FSF_SCS(4);
+  else FSF_SCS(8);
+#undef FSF_SCS
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}

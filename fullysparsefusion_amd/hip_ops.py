@@ -45,6 +45,9 @@ _ARGTYPES = {
     "fsf_row_topk_desc": [_P, c_i64, c_i32, c_i32, _P, _P],
     "fsf_sir_input": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
                       _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
+    "fsf_spconv_split_weight_bytes": [c_i32, c_i32, c_i32],
+    "fsf_spconv_prepare_weight_split": [_P, c_i32, c_i32, c_i32, _P, _P],
+    "fsf_spconv_forward_split": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P],
     "fsf_channel_group_sum_add": [_P, c_i64, c_i32, c_i32, _P, _P, _P],
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
@@ -387,6 +390,38 @@ def spconv_forward(feat: torch.Tensor, weight_t: torch.Tensor, nbr: torch.Tensor
     check(h.fsf_spconv_forward(ptr(feat), m_in, cin, ptr(weight_t), kvol, cout, ptr(nbr), m_out, ptr(scale), ptr(shift),
                                ptr(residual), int(bool(relu)), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_spconv_forward")
+    return out
+
+
+def spconv_prepare_weight_split(weight: torch.Tensor):
+    """fsf_spconv_prepare_weight_split: spconv v1 weight f32 [kvol, cin, cout] -> opaque split-bf16 fragment planes."""
+    require_cuda(weight)
+    weight = weight.detach().contiguous()
+    kvol, cin, cout = weight.shape
+    h = _L()
+    planes = torch.empty(h.fsf_spconv_split_weight_bytes(kvol, cin, cout), dtype=torch.uint8, device=weight.device)
+    check(h.fsf_spconv_prepare_weight_split(ptr(weight), kvol, cin, cout, ptr(planes), stream_ptr()),
+          "fsf_spconv_prepare_weight_split")
+    return planes
+
+
+def spconv_forward_split(feat: torch.Tensor, planes: torch.Tensor, kvol: int, cout: int, nbr: torch.Tensor, scale=None,
+                         shift=None, residual=None, relu=False):
+    """fsf_spconv_forward_split (K9b): feat f32 [m_in,cin], planes from spconv_prepare_weight_split, nbr i32 [m_out,kvol]."""
+    require_cuda(feat, planes, nbr)
+    feat = feat.contiguous()
+    nbr = nbr.contiguous()
+    m_in, cin = feat.shape
+    assert nbr.size(1) == kvol and nbr.dtype == torch.int32
+    m_out = nbr.size(0)
+    out = torch.empty((m_out, cout), dtype=torch.float32, device=feat.device)
+    scale = scale.contiguous() if scale is not None else None
+    shift = shift.contiguous() if shift is not None else None
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == out.shape
+    check(_L().fsf_spconv_forward_split(ptr(feat), m_in, cin, ptr(planes), kvol, cout, ptr(nbr), m_out, ptr(scale), ptr(shift),
+                                        ptr(residual), int(bool(relu)), ptr(out), stream_ptr()), "fsf_spconv_forward_split")
     return out
 
 

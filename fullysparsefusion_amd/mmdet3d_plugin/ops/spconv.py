@@ -172,6 +172,22 @@ class SparseConvolution(SparseModule):
             self._wt_cache = (key, wt)
         return self._wt_cache[1]
 
+    # Which forward kernel: the row-stationary bf16-split kernel (K9b) wins where neighbourhoods are dense and the layer
+    # has enough rows to fill the chip with 128-row workgroups — the submanifold layers of the three finest levels
+    # (measured per layer on the 10-sweep frame: 1.15-1.7x); strided / inverse convolutions (3-9 neighbours per output row)
+    # and the small deep levels stay on the compacting fp32-pipe kernel.
+    SPLIT_MIN_ROWS = 30000
+
+    def _weight_split(self):
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        cache = self.__dict__.get("_wsplit_cache")
+        if cache is None or cache[0] != key:
+            kvol = math.prod(self.kernel_size)
+            cache = (key, hip_ops.spconv_prepare_weight_split(w.detach().reshape(kvol, self.in_channels, self.out_channels)))
+            self.__dict__["_wsplit_cache"] = cache
+        return cache[1]
+
     def forward(self, x, scale=None, shift=None, residual=None, relu=False):
         """x: SparseConvTensor.  The optional epilogue arguments are the eval-mode BN affine / residual / ReLU
         that SparseSequential and SparseBasicBlock fold into the conv launch."""
@@ -196,6 +212,10 @@ class SparseConvolution(SparseModule):
                 out = out + residual
             if relu:
                 out = torch.relu(out)
+        elif (self.subm and nbr.size(0) >= self.SPLIT_MIN_ROWS and self.in_channels % 4 == 0 and self.out_channels % 4 == 0
+              and feat.size(0) > 0):
+            out = hip_ops.spconv_forward_split(feat, self._weight_split(), nbr.size(1), self.out_channels, nbr, scale=scale,
+                                               shift=shift, residual=residual, relu=relu)
         else:
             out = hip_ops.spconv_forward(feat, self._weight_t(), nbr, scale=scale, shift=shift, residual=residual,
                                          relu=relu)

@@ -266,6 +266,19 @@ int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float
                        const float* residual, int32_t relu, float* out, void* workspace, int64_t workspace_bytes,
                        void* stream);
 
+/* K9b  the same convolution, row-stationary on the bf16 matrix cores (inference).  The weight [kvol,cin,cout] is
+ * split ONCE per layer (fsf_spconv_prepare_weight_split) into three bf16 planes — an exact split of the fp32
+ * significand — in matrix-core fragment order; the kernel splits the gathered feature rows the same way in registers
+ * and sums the six leading cross products with fp32 accumulation: fp32 accuracy at 2.5x the fp32 pipe's rate (see
+ * K22).  A wave owns 32 output rows for the whole offset loop (accumulators in registers, no compaction, no LDS tile):
+ * the better choice for layers with >= ~9 neighbours per output row; fsf_spconv_forward stays the choice for sparse
+ * neighbourhoods and small layers.  cin % 4 == 0, cout % 4 == 0.  Deterministic. */
+int64_t fsf_spconv_split_weight_bytes(int32_t kvol, int32_t cin, int32_t cout);
+int fsf_spconv_prepare_weight_split(const float* weight, int32_t kvol, int32_t cin, int32_t cout, void* planes, void* stream);
+int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t cin, const void* planes, int32_t kvol, int32_t cout,
+                             const int32_t* nbr, int64_t m_out, const float* scale, const float* shift,
+                             const float* residual, int32_t relu, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K10  sparse convolution backward (training)
  * Replaces: spconv v1 indice_conv_backward [UNVENDORED mmdet3d.ops.spconv] = per offset

@@ -383,6 +383,45 @@ def test_spconv_forward_subm_vs_oracle(ops, device, cin, cout):
                                                 shift=shift.to(device), residual=res.to(device), relu=True))
 
 
+@pytest.mark.parametrize("m,cin,cout", [(3000, 16, 16), (3000, 64, 64), (3000, 64, 128), (40000, 128, 128), (20000, 256, 128),
+                                        (3000, 128, 256), (1500, 48, 32)])
+def test_spconv_forward_split_vs_oracle_and_fp32_kernel(ops, device, m, cin, cout):
+    """K9b (row-stationary, exact bf16 split on the bf16 matrix cores) against the CPU oracle at small sizes and against the
+    fp32-pipe kernel at large ones, with the fused epilogue; error vs float64 on sampled rows no larger than fp32's."""
+    rng = np.random.default_rng(m + cin + cout)
+    shape = (16, 48, 48) if m <= 3000 else (40, 512, 512)
+    idx = surface_sites(rng, 2 if m <= 3000 else 1, shape, m)
+    n = idx.shape[0]
+    feat = (rng.standard_normal((n, cin)) * np.exp(rng.standard_normal((n, 1)))).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 6)).astype(np.float32)
+    nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), 2 if m <= 3000 else 1, shape)
+    f, wd = torch.from_numpy(feat).to(device), torch.from_numpy(w).to(device)
+    planes = ops.spconv_prepare_weight_split(wd)
+    out = ops.spconv_forward_split(f, planes, 27, cout, nbr)
+    ref = ops.spconv_forward(f, ops.spconv_transpose_weight(wd), nbr) if cin % 16 == 0 else None
+    if m <= 3000:
+        _, pairs, _ = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True)
+        want = osp.indice_conv(feat, w, pairs, n)
+        np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-4)
+    rows = torch.from_numpy(rng.choice(n, size=min(n, 512), replace=False)).to(device)
+    nb = nbr.index_select(0, rows).long()
+    gathered = torch.where((nb >= 0)[:, :, None], f.double()[nb.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=device))
+    want64 = torch.einsum("rkc,kcd->rd", gathered, wd.double())
+    err = float((out.index_select(0, rows).double() - want64).abs().max())
+    scale_ = max(1.0, float(want64.abs().max()))
+    assert err <= 2e-5 * scale_
+    if ref is not None:
+        err32 = float((ref.index_select(0, rows).double() - want64).abs().max())
+        assert err <= max(2.0 * err32, 2e-6 * scale_), (err, err32)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(device)
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(device)
+    out2 = ops.spconv_forward_split(f, planes, 27, cout, nbr, scale=sc, shift=sh, residual=res, relu=True)
+    want2 = torch.relu(out * sc + sh + res)
+    assert float((out2 - want2).abs().max()) <= 1e-5 * max(1.0, float(want2.abs().max()))
+    assert torch.equal(out2, ops.spconv_forward_split(f, planes, 27, cout, nbr, scale=sc, shift=sh, residual=res, relu=True))
+
+
 @pytest.mark.parametrize("m,cin,cout", [(100000, 128, 128), (36000, 256, 128), (7500, 256, 256), (1500, 512, 512)])
 def test_spconv_forward_full_size_properties(ops, device, m, cin, cout):
     """BASELINE-size layers (the persistent work-queue kernel with 1..9 offset splits, stealing across XCD queues, in-kernel
