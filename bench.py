@@ -130,57 +130,77 @@ class TrainStep:
 
 
 def spconv_roofline(model, inp, steps, hot_path_only=False):
-    """Instrumented pass: HIP events (on the launch stream = torch's current stream) around every
-    fsf_spconv_forward launch; algorithmic flops = 2 * P * Cin * Cout with P counted from the rulebook."""
+    """Roofline entry for the dominant op, the sparse convolution (34 layers per frame): every launch of the two forward
+    kernels is timed with HIP events in an instrumented pass (the stream is torch's current stream, which is the one the
+    C ABI launches on), algorithmic flops = 2 * pairs * Cin * Cout, algorithmic bytes = pairs * (Cin + Cout) * 4 +
+    kvol * Cin * Cout * 4 + 8 * pairs.  `achieved` / `frac` are fp32-equivalent flops against the
+    fp32 matrix-pipe peak for the op as a whole; `kernels` splits them by kernel: the fp32-pipe kernel
+    (v_mfma_f32_16x16x4_f32) and the row-stationary kernel that forms the same fp32-accurate product from an exact 3-way
+    bf16 split on v_mfma_f32_16x16x32_bf16 (six MFMAs per fp32-equivalent one: its own hardware ceiling is 2.5 PF / 6)."""
     from fullysparsefusion_amd import hip_ops
 
     records = []
-    orig = hip_ops.spconv_forward
-    pair_cache = {}
+    originals = {"fp32": hip_ops.spconv_forward, "split": hip_ops.spconv_forward_split}
 
-    def timed(feat, weight_t, nbr, **kw):
-        key = (nbr.data_ptr(), nbr.shape)
-        if key not in pair_cache:
-            pair_cache[key] = int((nbr >= 0).sum().item())
+    def wrap_fp32(feat, weight_t, nbr, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = orig(feat, weight_t, nbr, **kw)
+        out = originals["fp32"](feat, weight_t, nbr, **kw)
         e1.record()
-        kvol, cout, cin = weight_t.shape
-        p = pair_cache[key]
-        records.append((e0, e1, 2.0 * p * cin * cout, p * (cin + cout) * 4.0 + kvol * cin * cout * 4.0 + 8.0 * p))
+        records.append(("fp32", e0, e1, nbr, weight_t.size(2), weight_t.size(1)))
         return out
 
-    hip_ops.spconv_forward = timed
+    def wrap_split(feat, planes, kvol, cout, nbr, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = originals["split"](feat, planes, kvol, cout, nbr, **kw)
+        e1.record()
+        records.append(("split", e0, e1, nbr, feat.size(1), cout))
+        return out
+
+    hip_ops.spconv_forward, hip_ops.spconv_forward_split = wrap_fp32, wrap_split
     try:
         for _ in range(steps):
-            pair_cache.clear()
             step(model, inp, hot_path_only)
         torch.cuda.synchronize()
     finally:
-        hip_ops.spconv_forward = orig
-    ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in records)
-    flops = sum(r[2] for r in records)
-    byts = sum(r[3] for r in records)
+        hip_ops.spconv_forward, hip_ops.spconv_forward_split = originals["fp32"], originals["split"]
+    per = {"fp32": [0.0, 0.0, 0], "split": [0.0, 0.0, 0]}  # flops, ms, launches
+    byts = 0.0
+    for kind, e0, e1, nbr, cin, cout in records:
+        pairs = float((nbr >= 0).sum())
+        per[kind][0] += 2.0 * pairs * cin * cout
+        per[kind][1] += e0.elapsed_time(e1)
+        per[kind][2] += 1
+        byts += pairs * (cin + cout) * 4 + nbr.size(1) * cin * cout * 4 + 8 * pairs
+    flops = per["fp32"][0] + per["split"][0]
+    ms = per["fp32"][1] + per["split"][1]
     launches = len(records)
     achieved = flops / (ms * 1e-3) / 1e12
-    # HBM bytes per fsf_spconv_forward call from the committed PMC passes (FETCH_SIZE / WRITE_SIZE cannot be read from
-    # inside the process; scratch/pmc_traffic.sh collects them under rocprofv3 with this same command line)
-    traffic, traffic_src = None, None
-    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+    traffic, source = None, None
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for name in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
         if name.endswith("_pmc_traffic.json"):
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                traffic = json.load(f)["spconv_forward"]["hbm_bytes_per_api_launch"]
-            traffic_src = "profiles/" + name
-            break
-    return dict(bound="mfma", kernel="fsf::spconv_fwd_dma_kernel (one fsf_spconv_forward call = queue memset + kernel)", achieved=round(achieved, 3),
-                peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                traffic=traffic, traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
-                traffic_source=traffic_src,
-                launches_per_step=launches // max(steps, 1), avg_launch_us=round(ms * 1e3 / max(launches, 1), 2),
-                algorithmic_gflop_per_step=round(flops / max(steps, 1) / 1e9, 2),
-                algorithmic_mb_per_step=round(byts / max(steps, 1) / 1e6, 1),
-                ms_per_step_in_kernel=round(ms / max(steps, 1), 3),
+            with open(os.path.join(prof, name)) as f:
+                t = json.load(f)
+            traffic, source = t.get("spconv_forward", {}).get("hbm_bytes_per_api_launch"), f"profiles/{name}"
+    kernels = {
+        "fsf::spconv_fwd_dma_kernel (fp32 MFMA, compacting, output-stationary in LDS)": dict(
+            launches_per_step=per["fp32"][2] // steps, ms_per_step=round(per["fp32"][1] / steps, 3),
+            tflops=round(per["fp32"][0] / max(per["fp32"][1], 1e-9) / 1e9, 2), peak_tflops=157.3),
+        "fsf::spconv_fwd_split_kernel (bf16 MFMA x6 = exact 3-way split, row-stationary in registers)": dict(
+            launches_per_step=per["split"][2] // steps, ms_per_step=round(per["split"][1] / steps, 3),
+            tflops_fp32_equivalent=round(per["split"][0] / max(per["split"][1], 1e-9) / 1e9, 2),
+            peak_tflops_fp32_equivalent=round(2500.0 / 6, 1)),
+    }
+    return dict(bound="mfma", kernel="sparse convolution forward (fsf::spconv_fwd_split_kernel + fsf::spconv_fwd_dma_kernel)",
+                achieved=round(achieved, 3), peak=157.3, unit="TFLOP/s", frac=round(achieved / 157.3, 4),
+                peak_note="fp32 matrix-pipe peak; the split kernel reaches fp32 accuracy on the bf16 pipe, see `kernels`",
+                kernels=kernels, traffic=traffic,
+                traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)", traffic_source=source,
+                launches_per_step=launches // steps, avg_launch_us=round(ms / launches * 1e3, 2),
+                algorithmic_gflop_per_step=round(flops / steps / 1e9, 1), algorithmic_mb_per_step=round(byts / steps / 1e6, 1),
+                ms_per_step_in_kernel=round(ms / steps, 3),
                 note="HIP-event timing in an instrumented pass over the same frames, right after the timed region")
 
 
