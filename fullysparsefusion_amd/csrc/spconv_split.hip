@@ -38,8 +38,9 @@ struct ScsArgs {
   const int32_t* nbr;
   const float *scale, *shift, *residual;
   float* out;
+  float* partial;  // [ksplit][m_out][cout] raw sums when the (offset, cin chunk) sequence is split over gridDim.z
   int64_t m_in, m_out;
-  int cin, cout, kvol, relu;
+  int cin, cout, kvol, relu, ksplit;
 };
 
 __device__ __forceinline__ void scs_split8(const float (&v)[8], scs_u32x4& hi, scs_u32x4& mid, scs_u32x4& lo) {
@@ -89,6 +90,9 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
   const int rowl = lane & 15, grp = lane >> 4;
   const int nkc = (a.cin + SCS_KC - 1) / SCS_KC;
   const int nchunks = a.kvol * nkc;
+  // a small layer (too few 128-row workgroups to fill the chip) splits the chunk sequence over gridDim.z; the slices are
+  // folded in order by scs_fold_kernel
+  const int ci_begin = (int)((int64_t)nchunks * blockIdx.z / a.ksplit), ci_end = (int)((int64_t)nchunks * (blockIdx.z + 1) / a.ksplit);
   const int64_t nblk = (a.m_out + SCS_ROWS - 1) / SCS_ROWS;
   const int ch_base = 128 * (int)blockIdx.y;
   const uint4* planes = a.planes + (int64_t)blockIdx.y * nchunks * CHUNK_U4;
@@ -116,11 +120,12 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
       nrow[rg] = a.nbr + r * a.kvol;
     }
     // neighbour ids two offsets ahead of their use, raw x one chunk ahead (a missing neighbour reads row 0 and is zeroed)
+    int k = ci_begin / nkc, kc = ci_begin - k * nkc;
     int idx_cur[SCS_RG], idx_nxt[SCS_RG];
 #pragma unroll
     for (int rg = 0; rg < SCS_RG; ++rg) {
-      idx_cur[rg] = nrow[rg][0];
-      idx_nxt[rg] = a.kvol > 1 ? nrow[rg][1] : -1;
+      idx_cur[rg] = nrow[rg][k];
+      idx_nxt[rg] = k + 1 < a.kvol ? nrow[rg][k + 1] : -1;
     }
     auto load_x = [&](const int (&idx)[SCS_RG], int kc, float (&v)[SCS_RG][8]) {
 #pragma unroll
@@ -134,14 +139,13 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
       }
     };
     float xc[SCS_RG][8];
-    load_x(idx_cur, 0, xc);
+    load_x(idx_cur, kc, xc);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with both weight buffers of the previous row block
     asm volatile("" ::: "memory");
-    stage_w(0, 0);
-    int k = 0, kc = 0;
-    for (int ci = 0; ci < nchunks; ++ci) {
-      const int buf = ci & 1;
+    stage_w(ci_begin, 0);
+    for (int ci = ci_begin; ci < ci_end; ++ci) {
+      const int buf = (ci - ci_begin) & 1;
       // ---- split the chunk that arrived while the previous one was multiplied
       scs_u32x4 xh[SCS_RG], xm[SCS_RG], xl[SCS_RG];
       bool any_live = false;
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // chunk ci's weights have landed everywhere; buffer buf^1 is free
       asm volatile("" ::: "memory");
-      if (ci + 1 < nchunks) {
+      if (ci + 1 < ci_end) {
         stage_w(ci + 1, buf ^ 1);
         load_x(idx_cur, nkci, xc);
         if (nk != k) {  // first chunk of a new offset: fetch the ids of the offset after it
@@ -213,6 +217,10 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
           const int ch0 = ch_base + 16 * t + 4 * grp;
           if (ch0 < a.cout) {
             float4 y = make_float4(acc[rg][t][0], acc[rg][t][1], acc[rg][t][2], acc[rg][t][3]);
+            if (a.ksplit > 1) {
+              *reinterpret_cast<float4*>(a.partial + ((int64_t)blockIdx.z * a.m_out + row) * a.cout + ch0) = y;
+              continue;
+            }
             if (a.scale) {
               const float4 sc = *reinterpret_cast<const float4*>(a.scale + ch0), sh = *reinterpret_cast<const float4*>(a.shift + ch0);
               y.x = __fmaf_rn(y.x, sc.x, sh.x); y.y = __fmaf_rn(y.y, sc.y, sh.y);
@@ -234,9 +242,53 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
   }
 }
 
+// folds the offset-split slices in order and applies the epilogue
+__global__ void __launch_bounds__(256) scs_fold_kernel(ScsArgs a) {
+  const int64_t total4 = a.m_out * (a.cout / 4);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total4; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t o = t / (a.cout / 4);
+    const int col = (int)(t - o * (a.cout / 4)) * 4;
+    float4 y = *reinterpret_cast<const float4*>(a.partial + o * a.cout + col);
+    for (int z = 1; z < a.ksplit; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(a.partial + ((int64_t)z * a.m_out + o) * a.cout + col);
+      y.x = __fadd_rn(y.x, v.x); y.y = __fadd_rn(y.y, v.y); y.z = __fadd_rn(y.z, v.z); y.w = __fadd_rn(y.w, v.w);
+    }
+    if (a.scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(a.scale + col), sh = *reinterpret_cast<const float4*>(a.shift + col);
+      y.x = __fmaf_rn(y.x, sc.x, sh.x); y.y = __fmaf_rn(y.y, sc.y, sh.y); y.z = __fmaf_rn(y.z, sc.z, sh.z); y.w = __fmaf_rn(y.w, sc.w, sh.w);
+    } else if (a.shift) {
+      const float4 sh = *reinterpret_cast<const float4*>(a.shift + col);
+      y.x = __fadd_rn(y.x, sh.x); y.y = __fadd_rn(y.y, sh.y); y.z = __fadd_rn(y.z, sh.z); y.w = __fadd_rn(y.w, sh.w);
+    }
+    if (a.residual) {
+      const float4 rs = *reinterpret_cast<const float4*>(a.residual + o * a.cout + col);
+      y.x = __fadd_rn(y.x, rs.x); y.y = __fadd_rn(y.y, rs.y); y.z = __fadd_rn(y.z, rs.z); y.w = __fadd_rn(y.w, rs.w);
+    }
+    if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    *reinterpret_cast<float4*>(a.out + o * a.cout + col) = y;
+  }
+}
+
 }  // namespace fsf
 
 using namespace fsf;
+
+// how many ways to split the chunk sequence so that ~all 768 workgroup slots (3 per CU) have work
+static int scs_ksplit(int64_t m_out, int cin, int cout, int kvol) {
+  const int64_t wgs = ((m_out + SCS_ROWS - 1) / SCS_ROWS) * ((cout + 127) / 128);
+  const int nchunks = kvol * ((cin + SCS_KC - 1) / SCS_KC);
+  int64_t s = (256 * SCS_WPS + wgs - 1) / wgs;
+  if (wgs * 2 > 256 * SCS_WPS) s = 1;  // more than half the slots busy already: the fold pass would cost more than it gains
+  if (s > nchunks / 4) s = nchunks / 4;
+  if (s > 32) s = 32;
+  return (int)(s < 1 ? 1 : s);
+}
+
+extern "C" int64_t fsf_spconv_split_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout, int32_t kvol) {
+  if (m_out <= 0 || cin < 1 || cout < 1 || kvol < 1) return 256;
+  const int s = scs_ksplit(m_out, cin, cout, kvol);
+  return s > 1 ? fsf_align_up((int64_t)s * m_out * cout * 4, 256) : 256;
+}
 
 static int scs_tiles(int cout) { return cout <= 64 ? 4 : 8; }
 static int scs_slices(int cout) { return (cout + 127) / 128; }
@@ -261,7 +313,8 @@ extern "C" int fsf_spconv_prepare_weight_split(const float* weight, int32_t kvol
 
 extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t cin, const void* planes, int32_t kvol,
                                         int32_t cout, const int32_t* nbr, int64_t m_out, const float* scale,
-                                        const float* shift, const float* residual, int32_t relu, float* out, void* stream_) {
+                                        const float* shift, const float* residual, int32_t relu, float* out, void* workspace,
+                                        int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (m_in < 0 || m_out < 0 || cin < 1 || cout < 1 || kvol < 1 || !planes || (scale && !shift) ||
       (m_out > 0 && (!nbr || !out)) || (m_in > 0 && !feat))
@@ -269,12 +322,15 @@ extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t
   if ((cin % 4) != 0 || (cout % 4) != 0 || ((uintptr_t)feat % 16) != 0 || ((uintptr_t)out % 16) != 0) return FSF_ERR_UNSUPPORTED;
   if (m_out == 0) return FSF_OK;
   if (m_in == 0) return FSF_ERR_INVALID_ARG;  // (a missing neighbour reads row 0)
-  ScsArgs a{feat, (const uint4*)planes, nbr, scale, shift, residual, out, m_in, m_out, (int)cin, (int)cout, (int)kvol, (int)relu};
+  const int ksplit = scs_ksplit(m_out, cin, cout, kvol);
+  if (ksplit > 1 && (!workspace || workspace_bytes < fsf_spconv_split_workspace_bytes(m_out, cin, cout, kvol))) return FSF_ERR_WORKSPACE;
+  ScsArgs a{feat, (const uint4*)planes, nbr, scale, shift, residual, out, (float*)workspace, m_in, m_out,
+            (int)cin, (int)cout, (int)kvol, (int)relu, ksplit};
   const int64_t nblk = (m_out + SCS_ROWS - 1) / SCS_ROWS;
   const int nslice = scs_slices(cout);
-  int64_t gx = (256 * SCS_WPS + nslice - 1) / nslice;
+  int64_t gx = (256 * SCS_WPS + nslice * ksplit - 1) / (nslice * ksplit);
   if (gx > nblk) gx = nblk;
-  const dim3 grid((unsigned)gx, (unsigned)nslice);
+  const dim3 grid((unsigned)gx, (unsigned)nslice, (unsigned)ksplit);
 #define FSF_SCS(T_)                                                                                                     \
   do {                                                                                                                 \
     constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16;                                                              \
@@ -289,6 +345,8 @@ extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t
   if (scs_tiles(cout) == 4) FSF_SCS(4);
   else FSF_SCS(8);
 #undef FSF_SCS
+  if (ksplit > 1)
+    hipLaunchKernelGGL(scs_fold_kernel, dim3(fsf_stream_grid(m_out * (cout / 4), 256)), dim3(256), 0, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

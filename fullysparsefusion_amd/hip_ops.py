@@ -47,7 +47,8 @@ _ARGTYPES = {
                       _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
     "fsf_spconv_split_weight_bytes": [c_i32, c_i32, c_i32],
     "fsf_spconv_prepare_weight_split": [_P, c_i32, c_i32, c_i32, _P, _P],
-    "fsf_spconv_forward_split": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P],
+    "fsf_spconv_split_workspace_bytes": [c_i64, c_i32, c_i32, c_i32],
+    "fsf_spconv_forward_split": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
     "fsf_channel_group_sum_add": [_P, c_i64, c_i32, c_i32, _P, _P, _P],
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
@@ -420,8 +421,11 @@ def spconv_forward_split(feat: torch.Tensor, planes: torch.Tensor, kvol: int, co
     if residual is not None:
         residual = residual.contiguous()
         assert residual.shape == out.shape
-    check(_L().fsf_spconv_forward_split(ptr(feat), m_in, cin, ptr(planes), kvol, cout, ptr(nbr), m_out, ptr(scale), ptr(shift),
-                                        ptr(residual), int(bool(relu)), ptr(out), stream_ptr()), "fsf_spconv_forward_split")
+    h = _L()
+    ws = _lib.workspace(h.fsf_spconv_split_workspace_bytes(m_out, cin, cout, kvol), feat.device)
+    check(h.fsf_spconv_forward_split(ptr(feat), m_in, cin, ptr(planes), kvol, cout, ptr(nbr), m_out, ptr(scale), ptr(shift),
+                                     ptr(residual), int(bool(relu)), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
+          "fsf_spconv_forward_split")
     return out
 
 

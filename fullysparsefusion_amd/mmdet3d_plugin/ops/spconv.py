@@ -172,11 +172,17 @@ class SparseConvolution(SparseModule):
             self._wt_cache = (key, wt)
         return self._wt_cache[1]
 
-    # Which forward kernel: the row-stationary bf16-split kernel (K9b) wins where neighbourhoods are dense and the layer
-    # has enough rows to fill the chip with 128-row workgroups — the submanifold layers of the three finest levels
-    # (measured per layer on the 10-sweep frame: 1.15-1.7x); strided / inverse convolutions (3-9 neighbours per output row)
-    # and the small deep levels stay on the compacting fp32-pipe kernel.
-    SPLIT_MIN_ROWS = 30000
+    # Which forward kernel (measured per layer on the 10-sweep frame, scratch/scs_layers.py): the row-stationary
+    # bf16-split kernel (K9b) wins on every submanifold layer (dense neighbourhoods: 1.15-1.7x on the fine levels,
+    # 1.5-2x on the deep ones, where it splits the offset loop over more workgroups) and on the strided convolutions
+    # into the deep levels (13+ pairs per output row); inverse convolutions and the strided ones into the fine levels
+    # (3-9 pairs per output row) stay on the compacting fp32-pipe kernel.
+    SPLIT_STRIDED_MAX_ROWS = 10000
+
+    def _use_split_kernel(self, m_out):
+        if self.in_channels % 4 or self.out_channels % 4:
+            return False
+        return self.subm or (not self.inverse and m_out <= self.SPLIT_STRIDED_MAX_ROWS)
 
     def _weight_split(self):
         w = self.weight
@@ -212,8 +218,7 @@ class SparseConvolution(SparseModule):
                 out = out + residual
             if relu:
                 out = torch.relu(out)
-        elif (self.subm and nbr.size(0) >= self.SPLIT_MIN_ROWS and self.in_channels % 4 == 0 and self.out_channels % 4 == 0
-              and feat.size(0) > 0):
+        elif self._use_split_kernel(nbr.size(0)) and feat.size(0) > 0:
             out = hip_ops.spconv_forward_split(feat, self._weight_split(), nbr.size(1), self.out_channels, nbr, scale=scale,
                                                shift=shift, residual=residual, relu=relu)
         else:

@@ -271,13 +271,17 @@ int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, const float
  * significand — in matrix-core fragment order; the kernel splits the gathered feature rows the same way in registers
  * and sums the six leading cross products with fp32 accumulation: fp32 accuracy at 2.5x the fp32 pipe's rate (see
  * K22).  A wave owns 32 output rows for the whole offset loop (accumulators in registers, no compaction, no LDS tile):
- * the better choice for layers with >= ~9 neighbours per output row; fsf_spconv_forward stays the choice for sparse
- * neighbourhoods and small layers.  cin % 4 == 0, cout % 4 == 0.  Deterministic. */
+ * the better choice for submanifold layers (>= ~9 neighbours per output row); fsf_spconv_forward stays the choice for the
+ * sparse neighbourhoods of strided / inverse convolutions.  A layer with too few 128-row workgroups splits the (offset,
+ * cin chunk) sequence over more workgroups and folds the partial sums (workspace) in a fixed order.  cin % 4 == 0,
+ * cout % 4 == 0.  Deterministic. */
 int64_t fsf_spconv_split_weight_bytes(int32_t kvol, int32_t cin, int32_t cout);
 int fsf_spconv_prepare_weight_split(const float* weight, int32_t kvol, int32_t cin, int32_t cout, void* planes, void* stream);
+int64_t fsf_spconv_split_workspace_bytes(int64_t m_out, int32_t cin, int32_t cout, int32_t kvol);
 int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t cin, const void* planes, int32_t kvol, int32_t cout,
                              const int32_t* nbr, int64_t m_out, const float* scale, const float* shift,
-                             const float* residual, int32_t relu, float* out, void* stream);
+                             const float* residual, int32_t relu, float* out, void* workspace, int64_t workspace_bytes,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K10  sparse convolution backward (training)
