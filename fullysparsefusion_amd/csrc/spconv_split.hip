@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
     };
     float xc[SCS_RG][8];
     load_x(idx_cur, kc, xc);
+    const bool tail_chunks = (a.cin % SCS_KC) != 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with both weight buffers of the previous row block
     asm volatile("" ::: "memory");
@@ -153,8 +154,12 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
       for (int rg = 0; rg < SCS_RG; ++rg) {
         const bool live = idx_cur[rg] >= 0;
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (!live || kc * SCS_KC + 8 * grp + e >= a.cin) xc[rg][e] = 0.0f;
+        for (int e = 0; e < 8; ++e) xc[rg][e] = live ? xc[rg][e] : 0.0f;  // a missing neighbour contributes zeros
+        if (tail_chunks) {  // (uniform) a chunk can reach past cin only when cin is not a multiple of 32
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (kc * SCS_KC + 8 * grp + e >= a.cin) xc[rg][e] = 0.0f;
+        }
         scs_split8(xc[rg], xh[rg], xm[rg], xl[rg]);
         any_live |= live;
       }
