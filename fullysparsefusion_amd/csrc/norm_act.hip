@@ -16,7 +16,7 @@ constexpr int NA_MAX_PER_LANE = 8;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int TEAM, int ACT, int NORM>
+template <int TEAM, int ACT, int NORM, int PL = NA_MAX_PER_LANE>  // PL channels per lane (16 for the 1024-wide query MLPs)
 __global__ void __launch_bounds__(256)
     norm_act_kernel(const float* x, int64_t n, int c, const float* __restrict__ gamma,
                     const float* __restrict__ beta, float eps, float* out, int64_t out_stride) {
@@ -26,9 +26,9 @@ __global__ void __launch_bounds__(256)
   for (int64_t row = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / TEAM; row < n;
        row += (int64_t)gridDim.x * teams_per_block) {
     const float* xr = x + row * c;
-    float v[NA_MAX_PER_LANE];
+    float v[PL];
 #pragma unroll
-    for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+    for (int k = 0; k < PL; ++k) {
       const int ch = tl + k * TEAM;
       v[k] = (ch < c) ? xr[ch] : 0.0f;
     }
@@ -36,13 +36,13 @@ __global__ void __launch_bounds__(256)
     if (NORM == NORM_LN) {
       float s = 0.0f;
 #pragma unroll
-      for (int k = 0; k < NA_MAX_PER_LANE; ++k) s += v[k];
+      for (int k = 0; k < PL; ++k) s += v[k];
 #pragma unroll
       for (int o = TEAM >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
       mean = s * inv_c;
       float q = 0.0f;
 #pragma unroll
-      for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+      for (int k = 0; k < PL; ++k) {
         const int ch = tl + k * TEAM;
         const float d = (ch < c) ? v[k] - mean : 0.0f;
         q += d * d;
@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256)
     }
     float* orow = out + row * out_stride;
 #pragma unroll
-    for (int k = 0; k < NA_MAX_PER_LANE; ++k) {
+    for (int k = 0; k < PL; ++k) {
       const int ch = tl + k * TEAM;
       if (ch < c) {
         float y;
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <int TEAM>
+template <int TEAM, int PL = NA_MAX_PER_LANE>
 static int launch_norm_act(const float* x, int64_t n, int c, const float* gamma, const float* beta, float eps, int norm,
                            int act, float* out, int64_t out_stride, hipStream_t stream) {
   const int teams_per_block = 256 / TEAM;
@@ -79,7 +79,7 @@ static int launch_norm_act(const float* x, int64_t n, int c, const float* gamma,
   if (g > 16384) g = 16384;
   if (g < 1) g = 1;
 #define FSF_NA(N_, A_) \
-  hipLaunchKernelGGL((norm_act_kernel<TEAM, A_, N_>), dim3((unsigned)g), dim3(256), 0, stream, x, n, c, gamma, beta, eps, out, out_stride)
+  hipLaunchKernelGGL((norm_act_kernel<TEAM, A_, N_, PL>), dim3((unsigned)g), dim3(256), 0, stream, x, n, c, gamma, beta, eps, out, out_stride)
   if (norm == NORM_LN) {
     if (act == ACT_GELU) FSF_NA(NORM_LN, ACT_GELU);
     else if (act == ACT_RELU) FSF_NA(NORM_LN, ACT_RELU);
@@ -240,10 +240,11 @@ extern "C" int fsf_norm_act(const float* x, int64_t n, int32_t c, const float* g
   if (n < 0 || c < 1 || norm < 0 || norm > 1 || act < 0 || act > 2 || (n > 0 && (!x || !out)) || ((gamma == nullptr) != (beta == nullptr)) ||
       (norm == NORM_AFFINE && !gamma))
     return FSF_ERR_INVALID_ARG;
-  if (c > 64 * NA_MAX_PER_LANE) return FSF_ERR_UNSUPPORTED;
+  if (c > 64 * 16) return FSF_ERR_UNSUPPORTED;
   if (out_stride == 0) out_stride = c;
   if (out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
+  if (c > 64 * NA_MAX_PER_LANE) return launch_norm_act<64, 16>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
   if (c <= 16 * NA_MAX_PER_LANE / 2) return launch_norm_act<16>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
   if (c <= 32 * NA_MAX_PER_LANE / 2) return launch_norm_act<32>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);
   return launch_norm_act<64>(x, n, c, gamma, beta, eps, norm, act, out, out_stride, stream);

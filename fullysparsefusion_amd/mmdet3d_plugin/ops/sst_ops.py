@@ -179,9 +179,9 @@ def fused_norm_act(x, norm, act, out=None):
     elif isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none":
         act_code = "gelu"
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in norm.parameters()))
-    fusable = act_code is not None and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(1) <= 512
+    fusable = act_code is not None and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(1) <= 1024
     if (fusable and needs_grad and out is None and isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1
-            and norm.elementwise_affine and x.size(0) > 0):
+            and norm.elementwise_affine and x.size(0) > 0 and x.size(1) <= 512):
         return _NormActFn.apply(x, norm.weight, norm.bias, norm.eps, act_code)  # training: fused forward AND backward (K12)
     if fusable and not needs_grad:
         x = x.contiguous()

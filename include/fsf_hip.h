@@ -153,7 +153,7 @@ int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* co
  *   norm: 0 = LayerNorm over the c channels of each row (biased variance, eps inside the sqrt; gamma/beta [c] or
  *             both NULL), 1 = per-channel affine y = x * gamma + beta (eval BatchNorm folded by the caller)
  *   act:  0 = none, 1 = ReLU, 2 = GELU (erf form)
- *   x f32 [n,c] -> out f32 [n,c] with row stride out_stride floats (0 = c; out may alias x when dense); c <= 512.
+ *   x f32 [n,c] -> out f32 [n,c] with row stride out_stride floats (0 = c; out may alias x when dense); c <= 1024 (fsf_norm_act_backward: c <= 512).
  */
 int fsf_norm_act(const float* x, int64_t n, int32_t c, const float* gamma, const float* beta, float eps, int32_t norm,
                  int32_t act, float* out, int64_t out_stride, void* stream);

@@ -570,7 +570,7 @@ def test_ingroup_rank(ops, device):
 
 
 # ------------------------------------------------------------------------------------ norm + activation
-@pytest.mark.parametrize("c", [3, 16, 32, 64, 128, 133, 180, 256, 512])
+@pytest.mark.parametrize("c", [3, 16, 32, 64, 128, 133, 180, 256, 512, 640, 1000, 1024])
 @pytest.mark.parametrize("act", ["gelu", "relu", None])
 def test_norm_act_vs_torch(ops, device, c, act):
     torch.manual_seed(c)
