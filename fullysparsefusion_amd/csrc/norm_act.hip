@@ -197,17 +197,44 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// grad_gamma / grad_beta = column sums of the per-workgroup partials, in a fixed order: 16 channels x 16 slices per
+// workgroup, slice s adds partials s, s + 16, ... (four independent chains in flight), then the 16 slice sums are added
+// in slice order.  (One thread per channel walking all 1024 partials serially was a 230 us latency chain.)
 __global__ void __launch_bounds__(256) norm_act_bwd_fold_kernel(const float* __restrict__ part, int blocks, int c,
                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int ch = blockIdx.x * 256 + threadIdx.x;
-  if (ch >= c) return;
-  float a0 = 0.0f, a1 = 0.0f;
-  for (int b = 0; b < blocks; ++b) {
-    a0 += part[((int64_t)b * 2 + 0) * c + ch];
-    a1 += part[((int64_t)b * 2 + 1) * c + ch];
+  __shared__ float red[2][16][17];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ch < c) {
+    int b = sl;
+    for (; b + 48 < blocks; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a0[u] += part[((int64_t)(b + 16 * u) * 2 + 0) * c + ch];
+        a1[u] += part[((int64_t)(b + 16 * u) * 2 + 1) * c + ch];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (b + 16 * u < blocks) {
+        a0[u] += part[((int64_t)(b + 16 * u) * 2 + 0) * c + ch];
+        a1[u] += part[((int64_t)(b + 16 * u) * 2 + 1) * c + ch];
+      }
+    }
   }
-  if (dgamma) dgamma[ch] = a0;
-  if (dbeta) dbeta[ch] = a1;
+  red[0][sl][cl] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+  red[1][sl][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int which = threadIdx.x >> 4;
+    const int oc = blockIdx.x * 16 + cl;
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[which][i][cl];
+    float* dst = which ? dbeta : dgamma;
+    if (oc < c && dst) dst[oc] = s;
+  }
 }
 
 constexpr int NA_BWD_BLOCKS = 1024;
@@ -225,7 +252,7 @@ static int launch_norm_act_bwd(const float* x, const float* gout, int64_t n, int
   else if (act == ACT_RELU) FSF_NAB(ACT_RELU);
   else FSF_NAB(ACT_NONE);
 #undef FSF_NAB
-  hipLaunchKernelGGL(norm_act_bwd_fold_kernel, dim3((unsigned)((c + 255) / 256)), dim3(256), 0, stream, part, (int)g, c, dgamma, dbeta);
+  hipLaunchKernelGGL(norm_act_bwd_fold_kernel, dim3((unsigned)((c + 15) / 16)), dim3(256), 0, stream, part, (int)g, c, dgamma, dbeta);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -40,6 +40,10 @@ _ARGTYPES = {
     "fsf_spconv_backward_weight": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_connected_components_workspace_bytes": [c_i64],
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
+    "fsf_column_stats_workspace_bytes": [c_i32],
+    "fsf_column_stats": [_P, c_i64, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_batch_norm_act_forward": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P],
+    "fsf_batch_norm_act_backward": [_P, _P, c_i64, c_i32, _P, _P, _P, _P, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_norm_act_backward_workspace_bytes": [c_i32],
     "fsf_norm_act_backward": [_P, _P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_row_topk_desc": [_P, c_i64, c_i32, c_i32, _P, _P],
@@ -665,6 +669,59 @@ def norm_act(x: torch.Tensor, gamma, beta, eps: float, norm: str, act, inplace=T
     check(_L().fsf_norm_act(ptr(x), n, c, ptr(gamma), ptr(beta), float(eps), {"ln": 0, "affine": 1}[norm], _ACTS[act],
                             c_p(out.data_ptr()), out.stride(0), stream_ptr()), "fsf_norm_act")
     return out
+
+
+def column_sum(x: torch.Tensor):
+    """fsf_column_stats (sums only): x f32 [n,c] -> f32 [c], fixed summation order (the bias gradient of a per-point Linear)."""
+    require_cuda(x)
+    x = x.contiguous()
+    n, c = x.shape
+    out = torch.empty(c, dtype=torch.float32, device=x.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_column_stats_workspace_bytes(c), x.device)
+    check(h.fsf_column_stats(ptr(x), n, c, ptr(out), None, ptr(ws), ws.numel(), stream_ptr()), "fsf_column_stats")
+    return out
+
+
+def column_mean_var(x: torch.Tensor):
+    """fsf_column_stats: x f32 [n,c] -> (mean [c], biased variance [c]), two passes."""
+    require_cuda(x)
+    x = x.contiguous()
+    n, c = x.shape
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    var = torch.empty(c, dtype=torch.float32, device=x.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_column_stats_workspace_bytes(c), x.device)
+    check(h.fsf_column_stats(ptr(x), n, c, ptr(mean), ptr(var), ptr(ws), ws.numel(), stream_ptr()), "fsf_column_stats")
+    return mean, var
+
+
+def batch_norm_act_forward(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool):
+    """fsf_batch_norm_act_forward: [relu] fma(x, scale, shift); x f32 [n,c]."""
+    require_cuda(x, scale, shift)
+    x = x.contiguous()
+    n, c = x.shape
+    out = torch.empty_like(x)
+    check(_L().fsf_batch_norm_act_forward(ptr(x), n, c, ptr(scale.contiguous()), ptr(shift.contiguous()), int(bool(relu)),
+                                          ptr(out), stream_ptr()), "fsf_batch_norm_act_forward")
+    return out
+
+
+def batch_norm_act_backward(x, grad_out, mean, invstd, scale, shift, relu: bool):
+    """fsf_batch_norm_act_backward -> (grad_x [n,c], grad_gamma [c], grad_beta [c])."""
+    require_cuda(x, grad_out, mean, invstd)
+    x, grad_out = x.contiguous(), grad_out.contiguous()
+    n, c = x.shape
+    gx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_column_stats_workspace_bytes(c), x.device)
+    check(h.fsf_batch_norm_act_backward(ptr(x), ptr(grad_out), n, c, ptr(mean), ptr(invstd),
+                                        ptr(scale.contiguous()) if scale is not None else None,
+                                        ptr(shift.contiguous()) if shift is not None else None, int(bool(relu)), ptr(gx),
+                                        ptr(dg), ptr(db), ptr(ws), ws.numel(), stream_ptr()), "fsf_batch_norm_act_backward")
+    return gx, dg, db
 
 
 def norm_act_backward(x: torch.Tensor, grad_out: torch.Tensor, gamma, beta, eps: float, act):

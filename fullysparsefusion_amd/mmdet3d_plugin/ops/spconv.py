@@ -9,6 +9,7 @@ scatter-add).  In eval mode the BatchNorm affine, the residual add and the ReLU 
 into that launch.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -79,14 +80,18 @@ class Rulebook:
 
 class _SparseConvFn(torch.autograd.Function):
     """out = sum_k feat[table[:, k]] @ W[k] with the K10 backward: data gradient = the same fused kernel over the
-    transposed table, weight gradient = fsf_spconv_backward_weight over the pair lists."""
+    transposed table, weight gradient = fsf_spconv_backward_weight over the pair lists.  `split` picks the
+    row-stationary split-bf16 kernel (K9b, fp32-accurate) for the forward and the data gradient, as in inference."""
 
     @staticmethod
-    def forward(ctx, feat, weight, rb, inverse):
+    def forward(ctx, feat, weight, rb, inverse, split):
         kvol = rb.nbr.size(1)
         w = weight.detach().reshape(kvol, weight.shape[-2], weight.shape[-1])
-        ctx.rb, ctx.inverse = rb, inverse
+        ctx.rb, ctx.inverse, ctx.split = rb, inverse, split
         ctx.save_for_backward(feat, weight)
+        if split and feat.size(0) > 0:
+            return hip_ops.spconv_forward_split(feat, hip_ops.spconv_prepare_weight_split(w), kvol, w.size(2),
+                                                rb.table(inverse))
         return hip_ops.spconv_forward(feat, hip_ops.spconv_transpose_weight(w), rb.table(inverse))
 
     @staticmethod
@@ -99,11 +104,16 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             table_t, flip = rb.table_transposed(inverse)
             w = weight.detach().reshape(kvol, weight.shape[-2], weight.shape[-1])
-            g_feat = hip_ops.spconv_forward(grad, w.flip(0) if flip else w, table_t)
+            w = w.flip(0) if flip else w
+            if ctx.split and grad.size(0) > 0 and feat.size(0) > 0:
+                planes = hip_ops.spconv_prepare_weight_split(w.transpose(1, 2).contiguous())
+                g_feat = hip_ops.spconv_forward_split(grad, planes, kvol, w.size(1), table_t)
+            else:
+                g_feat = hip_ops.spconv_forward(grad, w, table_t)
         if ctx.needs_input_grad[1]:
             pairs, num = rb.pairs(inverse)
             g_w = hip_ops.spconv_backward_weight(feat, grad, pairs, num).reshape(weight.shape)
-        return g_feat, g_w, None, None
+        return g_feat, g_w, None, None, None
 
 
 def _to3(v):
@@ -184,6 +194,12 @@ class SparseConvolution(SparseModule):
             return False
         return self.subm or (not self.inverse and m_out <= self.SPLIT_STRIDED_MAX_ROWS)
 
+    def _use_split_kernel_training(self):
+        """Training uses K9b for the forward AND the data gradient of the submanifold layers (their transposed table
+        has the same row count); strided / inverse layers keep the compacting fp32 kernel in both directions."""
+        return (self.subm and self.in_channels % 4 == 0 and self.out_channels % 4 == 0
+                and os.environ.get("FSF_TRAIN_SPLIT", "1") != "0")
+
     def _weight_split(self):
         w = self.weight
         key = (w._version, w.data_ptr())
@@ -209,7 +225,7 @@ class SparseConvolution(SparseModule):
         feat = x.features
         needs_grad = torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad)
         if needs_grad:  # training: the epilogue stays in autograd-visible torch ops
-            out = _SparseConvFn.apply(feat, self.weight, rb, self.inverse)
+            out = _SparseConvFn.apply(feat, self.weight, rb, self.inverse, self._use_split_kernel_training())
             if scale is not None:
                 out = out * scale
             if shift is not None:
@@ -264,6 +280,12 @@ def _bn_affine(bn):
     return scale, shift
 
 
+def _bn_act_training(bn, feats, relu):
+    from .sst_ops import batch_norm_act_training
+
+    return batch_norm_act_training(bn, feats, relu)
+
+
 def _is_eval_bn(m):
     return isinstance(m, nn.BatchNorm1d) and not m.training and m.track_running_stats
 
@@ -296,6 +318,14 @@ class SparseSequential(SparseModule):
                 x = m(x, scale=scale, shift=shift, relu=relu)
                 i += 3 if relu else 2
                 continue
+            if (isinstance(m, nn.BatchNorm1d) and isinstance(x, SparseConvTensor) and x.indices.size(0) != 0 and m.training
+                    and torch.is_grad_enabled()):  # training: BN (+ the ReLU after it) on K23
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                y = _bn_act_training(m, x.features, relu)
+                if y is not None:
+                    x = x._like(y)
+                    i += 2 if relu else 1
+                    continue
             if isinstance(m, SparseModule):
                 x = m(x)
             elif isinstance(x, SparseConvTensor):
@@ -354,6 +384,8 @@ class SparseBasicBlock(SparseModule):
             s2, b2 = _bn_affine(self.norm2)
             return self.conv2(out, scale=s2, shift=b2, residual=identity, relu=True)
         out = self.conv1(x)
-        out = out._like(self.relu(self.norm1(out.features)))
+        y = _bn_act_training(self.norm1, out.features, True)
+        out = out._like(y if y is not None else self.relu(self.norm1(out.features)))
         out = self.conv2(out)
-        return out._like(self.relu(self.norm2(out.features) + identity))
+        y = _bn_act_training(self.norm2, out.features, False)
+        return out._like(self.relu((y if y is not None else self.norm2(out.features)) + identity))

@@ -4,6 +4,8 @@
 done by the HIP library (no torch_scatter, no TorchEx)."""
 import traceback
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -192,11 +194,56 @@ def fused_norm_act(x, norm, act, out=None):
 
             scale, shift = _bn_affine(norm)
             return hip_ops.norm_act(x, scale, shift, 0.0, "affine", act_code, out=out)
-    y = act(norm(x))
+    y = batch_norm_act_training(norm, x, True) if isinstance(act, nn.ReLU) else None
+    if y is None:
+        y = act(norm(x))
     if out is not None:
         out.copy_(y)
         return out
     return y
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d over the rows of [n, C] (+ ReLU) on K23: two-pass batch statistics, one fused
+    normalise + activate pass, and a backward of two reads of (x, grad) + one write."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn, relu):
+        x = x.contiguous()
+        mean, var = hip_ops.column_mean_var(x)
+        n = x.size(0)
+        invstd = torch.rsqrt(var + bn.eps)
+        scale = weight.detach() * invstd if weight is not None else invstd
+        shift = (bias.detach() if bias is not None else 0.0) - mean * scale
+        if bn.track_running_stats and bn.running_mean is not None:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                bn.running_var.mul_(1 - momentum).add_(var, alpha=momentum * n / max(n - 1, 1))
+        ctx.save_for_backward(x, mean, invstd, scale, shift)
+        ctx.relu, ctx.affine = relu, weight is not None
+        return hip_ops.batch_norm_act_forward(x, scale, shift, relu)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, mean, invstd, scale, shift = ctx.saved_tensors
+        gx, dg, db = hip_ops.batch_norm_act_backward(x, grad, mean, invstd, scale, shift, ctx.relu)
+        return gx, (dg if ctx.affine else None), (db if ctx.affine else None), None, None
+
+
+def batch_norm_act_training(bn, x, relu):
+    """`relu(bn(x))` / `bn(x)` for a training-mode BatchNorm1d (or naiveSyncBN1d on one rank) on the GPU; None when the
+    module / input is not covered (the caller then runs the stock modules)."""
+    import torch.distributed as dist
+
+    if not (isinstance(bn, nn.BatchNorm1d) and bn.training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2
+            and x.dtype == torch.float32 and x.size(0) > 1 and (bn.weight is None) == (bn.bias is None)
+            and os.environ.get("FSF_TRAIN_BN", "1") != "0"):
+        return None
+    if type(bn).__name__ != "BatchNorm1d" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return None  # naiveSyncBN1d across ranks: statistics are all-reduced (ops/norm.py)
+    return _BatchNormActFn.apply(x, bn.weight, bn.bias, bn, relu)
 
 
 class _PointLinearFn(torch.autograd.Function):
@@ -218,11 +265,13 @@ class _PointLinearFn(torch.autograd.Function):
         g_x = grad @ weight if ctx.needs_input_grad[0] else None
         g_w = None
         if ctx.needs_input_grad[1]:
-            cin = x.size(1)
-            if cin % 4:  # the kernel moves 16-byte chunks: pad the channel count (one extra pass over x, still 3x cheaper)
-                x = F.pad(x, (0, 4 - cin % 4))
-            g_w = hip_ops.linear_backward_weight(x, grad)[:cin].t()
-        g_b = grad.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            cin, cout = x.size(1), grad.size(1)
+            # the kernel moves 16-byte chunks: pad the channel counts (one extra pass, still several times cheaper than the
+            # library's [c, n] x [n, k] product: 1.2 ms for the 3 -> 16 layer over 4.9e5 points)
+            xp = F.pad(x, (0, 4 - cin % 4)) if cin % 4 else x
+            gp = F.pad(grad, (0, 4 - cout % 4)) if cout % 4 else grad
+            g_w = hip_ops.linear_backward_weight(xp, gp)[:cin, :cout].t()
+        g_b = hip_ops.column_sum(grad) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return g_x, g_w, g_b
 
 
@@ -267,7 +316,7 @@ def linear_norm_act(linear, norm, act, x, out=None):
 def point_linear(linear, x):
     """`linear(x)` for a per-point nn.Linear; training on the GPU routes the weight gradient through K10."""
     if (torch.is_grad_enabled() and linear.weight.requires_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
-            and x.size(0) >= 16384 and linear.in_features >= 32 and linear.out_features % 4 == 0):
+            and x.size(0) >= 16384):
         return _PointLinearFn.apply(x, linear.weight, linear.bias)
     return F.linear(x, linear.weight, linear.bias)
 

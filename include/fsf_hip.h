@@ -166,6 +166,30 @@ int fsf_norm_act_backward(const float* x, const float* grad_out, int64_t n, int3
                           int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K23  column statistics of a [n, c] matrix + training-mode BatchNorm1d (+ ReLU) forward / backward
+ * Replaces (training only): ATen's batch_norm_collect_statistics / _backward_reduce / _backward_elemt kernels behind the
+ *   `conv -> BN -> ReLU` modules of the sparse U-Net (mmdet3d.ops.make_sparse_convmodule / SparseBasicBlock [UNVENDORED],
+ *   norm_cfg naiveSyncBN1d: projects/configs/nuScenes/FSF_nuScenes_config.py:50,63,85) and the bias gradient
+ *   `grad.sum(0)` of the per-point Linear layers (build_mlp, projects/mmdet3d_plugin/ops/sst_ops.py:808-833).
+ *   fsf_column_stats: var == NULL: mean[c] <- column SUMS of x (a bias gradient); otherwise mean[c] <- column means and
+ *     var[c] <- biased variances, two passes (squared deviations about the mean).  Fixed summation order.
+ *   fsf_batch_norm_act_forward: out = [relu] fma(x, scale, shift) with scale = gamma * invstd, shift = beta - mean * scale.
+ *   fsf_batch_norm_act_backward: batch-statistics backward; with relu != 0 grad_out is first masked by the sign of the
+ *     same fma as the forward.  grad_beta[c] = sum g', grad_gamma[c] = sum g' * xhat,
+ *     grad_x = scale * (g' - (grad_beta + xhat * grad_gamma) / n), xhat = (x - mean) * invstd.  scale / shift both NULL =
+ *     no affine (gamma 1, beta 0).
+ *   workspace: fsf_column_stats_workspace_bytes(c) for both.
+ */
+int64_t fsf_column_stats_workspace_bytes(int32_t c);
+int fsf_column_stats(const float* x, int64_t n, int32_t c, float* mean, float* var, void* workspace, int64_t workspace_bytes,
+                     void* stream);
+int fsf_batch_norm_act_forward(const float* x, int64_t n, int32_t c, const float* scale, const float* shift, int32_t relu,
+                               float* out, void* stream);
+int fsf_batch_norm_act_backward(const float* x, const float* grad_out, int64_t n, int32_t c, const float* mean,
+                                const float* invstd, const float* scale, const float* shift, int32_t relu, float* grad_x,
+                                float* grad_gamma, float* grad_beta, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K22  per-point Linear (+ bias) -> LayerNorm | affine -> ReLU | GELU(erf) in one pass (inference)
  * Replaces: the [nn.Linear, norm, act] blocks of build_mlp (projects/mmdet3d_plugin/ops/sst_ops.py:808-833) and of
  *   DynamicVFELayer [UNVENDORED] applied to every point / cluster row: a library fp32 GEMM plus fsf_norm_act.

@@ -857,3 +857,71 @@ def test_norm_act_backward_vs_torch_autograd(ops, device, c, act):
     assert float((db.double() - bd.grad).abs().max()) <= 1e-4 * max(1.0, float(bd.grad.abs().max()))
     gx2, dg2, db2 = ops.norm_act_backward(x, go, g, b, 1e-3, act)
     assert torch.equal(gx, gx2) and torch.equal(dg, dg2) and torch.equal(db, db2)  # deterministic
+
+
+# ------------------------------------------------------------------------ K23: column statistics / training BatchNorm
+@pytest.mark.parametrize("n,c", [(1, 5), (17, 3), (5000, 1), (4097, 16), (30011, 64), (200003, 128), (60000, 131), (9000, 300)])
+def test_column_stats_vs_float64(ops, device, n, c):
+    torch.manual_seed(n + c)
+    x = torch.randn(n, c, device=device) * 3 + 100.0  # mean^2 >> var: E[x^2] - E[x]^2 would lose the variance
+    s = ops.column_sum(x)
+    want = x.double().sum(0)
+    assert float((s.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) * max(1.0, (n / 1e4) ** 0.5)
+    mean, var = ops.column_mean_var(x)
+    assert float((mean.double() - x.double().mean(0)).abs().max()) <= 2e-6 * 100.0 * max(1.0, (n / 1e4) ** 0.5)
+    wv = x.double().var(0, unbiased=False)
+    assert float((var.double() - wv).abs().max()) <= 1e-4 * max(1.0, float(wv.max()))
+    assert torch.equal(s, ops.column_sum(x))
+    m2, v2 = ops.column_mean_var(x)
+    assert torch.equal(mean, m2) and torch.equal(var, v2)
+
+
+@pytest.mark.parametrize("n,c", [(2, 8), (30011, 64), (101119, 128), (7441, 256), (1517, 512), (5000, 131)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_batch_norm_act_training_vs_torch_autograd(ops, device, n, c, relu):
+    """Training-mode BatchNorm1d (+ ReLU) forward, running statistics and backward against float64 autograd."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops.sst_ops import batch_norm_act_training
+
+    torch.manual_seed(n + c)
+    x = (torch.randn(n, c, device=device) * 2 + 0.7).requires_grad_()
+    go = torch.randn(n, c, device=device)
+    bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(device).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(device).double().train()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    y = batch_norm_act_training(bn, x, relu)
+    assert y is not None
+    y.backward(go)
+    xd = x.detach().double().requires_grad_()
+    yd = ref(xd)
+    yd = torch.relu(yd) if relu else yd
+    yd.backward(go.double())
+    tol = lambda t: 2e-5 * max(1.0, float(t.abs().max()))
+    assert float((y.double() - yd).abs().max()) <= tol(yd)
+    assert float((x.grad.double() - xd.grad).abs().max()) <= tol(xd.grad)
+    assert float((bn.weight.grad.double() - ref.weight.grad).abs().max()) <= 1e-4 * max(1.0, float(ref.weight.grad.abs().max()))
+    assert float((bn.bias.grad.double() - ref.bias.grad).abs().max()) <= 1e-4 * max(1.0, float(ref.bias.grad.abs().max()))
+    assert float((bn.running_mean.double() - ref.running_mean).abs().max()) <= 1e-6
+    assert float((bn.running_var.double() - ref.running_var).abs().max()) <= 1e-5
+    assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("cin,cout,bias", [(3, 16, False), (16, 32, False), (32, 133, False), (128, 131, True), (10, 128, True)])
+def test_point_linear_thin_layers_gradients(ops, device, cin, cout, bias):
+    """The K10 weight-gradient route with padded channel counts + the K23 bias gradient == autograd of nn.Linear."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops.sst_ops import PointLinear
+
+    torch.manual_seed(cin * cout)
+    n = 40003
+    lin = PointLinear(cin, cout, bias=bias).to(device)
+    x = torch.randn(n, cin, device=device, requires_grad=True)
+    go = torch.randn(n, cout, device=device)
+    lin(x).backward(go)
+    want_w = go.double().t() @ x.detach().double()
+    assert float((lin.weight.grad.double() - want_w).abs().max()) <= 2e-5 * float(want_w.abs().max())
+    assert float((x.grad.double() - go.double() @ lin.weight.detach().double()).abs().max()) <= 1e-4
+    if bias:
+        want_b = go.double().sum(0)
+        assert float((lin.bias.grad.double() - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max())
