@@ -208,22 +208,44 @@ __global__ void __launch_bounds__(256, 2) spconv_bwd_weight_kernel(SpconvBwdArgs
   }
 }
 
-// grad_W[k] = sum of the live partial slices in split order (or zero when the offset has no pairs).
+// grad_W[k] = sum of the live partial slices (or zero when the offset has no pairs), in a fixed order: a workgroup owns 16
+// float4 elements x 16 slices; slice s adds partials s, s + 16, ... on four independent chains, then the 16 slice sums are
+// added in slice order.  (One thread per element walking up to ~1000 partials serially was a 100-250 us latency chain.)
 __global__ void __launch_bounds__(256) spconv_bwd_fold_kernel(SpconvBwdArgs a) {
+  __shared__ f32x4 red[16][17];
   const int64_t per_k = (int64_t)a.cin * a.cout / 4;
   const int64_t total = per_k * a.kvol;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int k = (int)(t / per_k);
+  const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (int64_t t0 = (int64_t)blockIdx.x * 16; t0 < total; t0 += (int64_t)gridDim.x * 16) {
+    const int64_t t = t0 + el;
+    const bool ok = t < total;
+    const int k = ok ? (int)(t / per_k) : 0;
     const int64_t e = t - (int64_t)k * per_k;
     const int n = a.num ? a.num[k] : (int)a.cap;
-    const int live = (n + a.range - 1) / a.range;
-    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int live = ok ? (n + a.range - 1) / a.range : 0;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.nsplit > 1) {
+      f32x4 acc[4] = {zero, zero, zero, zero};
       const f32x4* p = reinterpret_cast<const f32x4*>(a.part) + (int64_t)k * a.nsplit * per_k + e;
-      for (int i = 0; i < live; ++i) s += p[(int64_t)i * per_k];
-      reinterpret_cast<f32x4*>(a.gw)[t] = s;
-    } else if (live == 0) {
-      reinterpret_cast<f32x4*>(a.gw)[t] = s;
+      int i = sl;
+      for (; i + 48 < live; i += 64) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += p[(int64_t)(i + 16 * u) * per_k];
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (i + 16 * u < live) acc[u] += p[(int64_t)(i + 16 * u) * per_k];
+      red[sl][el] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      __syncthreads();
+      if (sl == 0 && ok) {
+        f32x4 s = zero;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += red[j][el];
+        reinterpret_cast<f32x4*>(a.gw)[t] = s;
+      }
+      __syncthreads();
+    } else if (ok && live == 0 && sl == 0) {
+      reinterpret_cast<f32x4*>(a.gw)[t] = zero;
     }
   }
 }
@@ -236,7 +258,7 @@ static void bwd_plan(int64_t cap, int cin, int cout, int kvol, int* ta, int* tb,
   // each so the accumulator write-out stays small next to the MFMA work
   // (a dense layer, kvol = 1, has one evenly divisible pair list: fewer, longer ranges keep the fold pass — which reads
   // nsplit x cin x cout floats — negligible)
-  int64_t s = fsf_cdiv(kvol >= 8 ? 3072 : 1024, kvol * tiles);
+  int64_t s = fsf_cdiv(kvol >= 8 ? 3072 : 512, kvol * tiles);
   const int64_t max_s = fsf_cdiv(cap, 8 * BW_RT);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -292,7 +314,7 @@ extern "C" int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32
     else FSF_BWD_LAUNCH(128, 128);
   }
 #undef FSF_BWD_LAUNCH
-  hipLaunchKernelGGL(spconv_bwd_fold_kernel, dim3(fsf_stream_grid((int64_t)kvol * cin * cout / 4, 256)), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(spconv_bwd_fold_kernel, dim3(fsf_stream_grid((int64_t)kvol * cin * cout / 4 * 16, 256)), dim3(256), 0, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }
