@@ -42,6 +42,9 @@ struct LnaArgs {
   float eps; int norm, act;  // norm 0 none / 1 LayerNorm / 2 affine (y * gamma + beta); act 0 / 1 ReLU / 2 GELU(erf)
   float* out; int64_t out_stride;
   int64_t n; int c;
+  // optional per-row addend before the norm: row_add[row_add_index[row]][c] — the right half of a
+  // `cat([point_feats, group_feats[inv]], 1) @ W^T` product, applied to the groups once instead of to every point
+  const float* row_add; const int64_t* row_add_index; int64_t row_add_stride;
 };
 
 __device__ __forceinline__ float lna_row_sum(float v) {
@@ -128,6 +131,40 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
       __builtin_amdgcn_global_load_lds(src + 4 * (u + lane), dst + 4 * u, 16, 0, 0);
   };
 
+  // The (row block, k chunk) sequence of a workgroup is ONE software pipeline: during the last chunk of a block the first
+  // weight chunk and the first x chunk of the NEXT block are already requested, so the epilogue (norm, activation,
+  // stores) runs with them in flight instead of every block starting with an exposed HBM round trip.
+  const float* xrow[LNA_RG];
+  auto set_rows = [&](int64_t blk) {
+#pragma unroll
+    for (int rg = 0; rg < LNA_RG; ++rg) {
+      int64_t r = blk * LNA_ROWS + (int64_t)wave * (LNA_RG * 16) + 16 * rg + rowl;
+      if (r >= a.n) r = a.n - 1;  // rows past n repeat the last one (finite, never stored)
+      xrow[rg] = a.x + r * a.x_stride;
+    }
+  };
+  // raw x of one chunk: [row group][8 floats]; the NEXT chunk is requested while this one is split and multiplied.
+  // Always exactly two 16-byte loads per row group: offsets past the row are clamped into it (x_stride is a multiple
+  // of 4 and >= k, so a quad that holds any column < k is never clamped) and the columns >= k are zeroed afterwards
+  // (what follows the row in memory may be NaN).
+  const int last_quad = (int)a.x_stride - 4;
+  auto load_x = [&](int kc, float (&v)[LNA_RG][8]) {
+#pragma unroll
+    for (int rg = 0; rg < LNA_RG; ++rg) {
+      const int kq = kc * LNA_KC + 8 * grp;  // this lane's 8 k values
+      const float4 p = *reinterpret_cast<const float4*>(xrow[rg] + min(kq, last_quad));
+      const float4 q = *reinterpret_cast<const float4*>(xrow[rg] + min(kq + 4, last_quad));
+      v[rg][0] = p.x; v[rg][1] = p.y; v[rg][2] = p.z; v[rg][3] = p.w;
+      v[rg][4] = q.x; v[rg][5] = q.y; v[rg][6] = q.z; v[rg][7] = q.w;
+    }
+  };
+  float xc[LNA_RG][8];
+  int buf = 0;
+  if ((int64_t)blockIdx.x < nblk) {
+    set_rows(blockIdx.x);
+    load_x(0, xc);
+    stage_w(0, 0);
+  }
   for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const int64_t row0 = blk * LNA_ROWS + (int64_t)wave * (LNA_RG * 16);
     lna_f32x4 acc[LNA_RG][T];
@@ -135,38 +172,17 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
     for (int rg = 0; rg < LNA_RG; ++rg)
 #pragma unroll
       for (int t = 0; t < T; ++t) acc[rg][t] = lna_f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* xrow[LNA_RG];
-#pragma unroll
-    for (int rg = 0; rg < LNA_RG; ++rg) {
-      int64_t r = row0 + 16 * rg + rowl;
-      if (r >= a.n) r = a.n - 1;  // rows past n repeat the last one (finite, never stored)
-      xrow[rg] = a.x + r * a.x_stride + 8 * grp;
+#ifdef FSF_ABL_LNA_NO_XBLK  // ablation: every row block starts with an exposed load (the kernel before the cross-block pipeline)
+    if (blk != (int64_t)blockIdx.x) {
+      set_rows(blk);
+      load_x(0, xc);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stage_w(0, buf);
     }
-    // raw x of one 64-wide chunk: [row group][k step][8 floats]; the NEXT chunk is requested while this one is split and
-    // multiplied (a wave has one other wave on its SIMD: without the prefetch every k step waited for HBM)
-    // Always exactly two 16-byte loads per row group: offsets past the row are clamped into it (x_stride is a multiple
-    // of 4 and >= k, so a quad that holds any column < k is never clamped) and the columns >= k are zeroed afterwards
-    // (what follows the row in memory may be NaN).
-    const int last_quad = (int)a.x_stride - 4;
-    auto load_x = [&](int kc, float (&v)[LNA_RG][8]) {
-#pragma unroll
-      for (int rg = 0; rg < LNA_RG; ++rg) {
-        const int kq = kc * LNA_KC + 8 * grp;  // this lane's 8 k values
-        const float* base = xrow[rg] - 8 * grp;
-        const float4 p = *reinterpret_cast<const float4*>(base + min(kq, last_quad));
-        const float4 q = *reinterpret_cast<const float4*>(base + min(kq + 4, last_quad));
-        v[rg][0] = p.x; v[rg][1] = p.y; v[rg][2] = p.z; v[rg][3] = p.w;
-        v[rg][4] = q.x; v[rg][5] = q.y; v[rg][6] = q.z; v[rg][7] = q.w;
-      }
-    };
-    float xc[LNA_RG][8];
-    load_x(0, xc);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // every wave is done with both weight buffers of the previous row block
-    asm volatile("" ::: "memory");
-    stage_w(0, 0);
-    for (int kc = 0; kc < nkc; ++kc) {
-      const int buf = kc & 1;
+#endif
+    for (int kc = 0; kc < nkc; ++kc, buf ^= 1) {
       // split the chunk that arrived while the previous one was multiplied; its registers then take the next prefetch
       lna_u32x4 xh[LNA_RG], xm[LNA_RG], xl[LNA_RG];
       if ((kc + 1) * LNA_KC > a.k) {  // (uniform: the last chunk of a k that is not a multiple of 32)
@@ -178,7 +194,7 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
       }
 #pragma unroll
       for (int rg = 0; rg < LNA_RG; ++rg) lna_split8(xc[rg], xh[rg], xm[rg], xl[rg]);
-      // chunk kc's weights (DMA issued one iteration ago, before that iteration's MFMAs) have landed; the raw barrier
+      // this chunk's weights (DMA issued one iteration ago, before that iteration's MFMAs) have landed; the raw barrier
       // carries no fence, so nothing else is drained with them
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // + every wave is done reading buffer buf^1
@@ -187,6 +203,13 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
         stage_w(kc + 1, buf ^ 1);
         load_x(kc + 1, xc);
       }
+#ifndef FSF_ABL_LNA_NO_XBLK
+      else if (blk + gridDim.x < nblk) {  // first chunk of the next row block
+        stage_w(0, buf ^ 1);
+        set_rows(blk + gridDim.x);
+        load_x(0, xc);
+      }
+#endif
       const uint4* wc = wbuf + buf * CHUNK_U4;
       // Two channel tiles x LNA_RG row groups = 4 independent accumulators per product term: consecutive MFMAs never hit
       // the same accumulator
@@ -226,6 +249,18 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
           const int ch0 = ch_base + 16 * t + 4 * grp;
           if (ch0 < a.c) {
             const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
+            acc[rg][t][0] += b.x; acc[rg][t][1] += b.y; acc[rg][t][2] += b.z; acc[rg][t][3] += b.w;
+          }
+        }
+      }
+      if (a.row_add) {
+        const int64_t row_c = row0 + 16 * rg + rowl;
+        const float* add = a.row_add + a.row_add_index[row_c < a.n ? row_c : a.n - 1] * a.row_add_stride;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int ch0 = ch_base + 16 * t + 4 * grp;
+          if (ch0 < a.c) {
+            const float4 b = *reinterpret_cast<const float4*>(add + ch0);
             acc[rg][t][0] += b.x; acc[rg][t][1] += b.y; acc[rg][t][2] += b.z; acc[rg][t][3] += b.w;
           }
         }
@@ -304,10 +339,25 @@ extern "C" int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t
   return FSF_OK;
 }
 
+extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
+                                           const float* bias, const float* row_add, const int64_t* row_add_index,
+                                           int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta,
+                                           float eps, int32_t act, float* out, int64_t out_stride, void* stream_);
+
 extern "C" int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
                                    const float* bias, int32_t norm, const float* gamma, const float* beta, float eps,
                                    int32_t act, float* out, int64_t out_stride, void* stream_) {
+  return fsf_linear_norm_act_grouped(x, n, k, x_stride, planes, c, bias, nullptr, nullptr, 0, norm, gamma, beta, eps, act, out,
+                                     out_stride, stream_);
+}
+
+extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
+                                           const float* bias, const float* row_add, const int64_t* row_add_index,
+                                           int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta,
+                                           float eps, int32_t act, float* out, int64_t out_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if ((row_add == nullptr) != (row_add_index == nullptr)) return FSF_ERR_INVALID_ARG;
+  if (row_add && ((row_add_stride % 4) != 0 || row_add_stride < c || ((uintptr_t)row_add % 16) != 0)) return FSF_ERR_UNSUPPORTED;
   if (n < 0 || k < 1 || c < 1 || !planes || norm < 0 || norm > 2 || act < 0 || act > 2 || (norm != 0 && (!gamma || !beta)) ||
       (n > 0 && (!x || !out)))
     return FSF_ERR_INVALID_ARG;
@@ -317,7 +367,8 @@ extern "C" int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t
     return FSF_ERR_UNSUPPORTED;
   if (x_stride < k || out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
-  LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c};
+  LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
+            row_add, row_add_index, row_add_stride};
   const int64_t nblk = (n + LNA_ROWS - 1) / LNA_ROWS;
   const int nslice = lna_slices(c);
   int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;  // LNA_WPS 4-wave workgroups per CU in total

@@ -57,6 +57,8 @@ _ARGTYPES = {
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
     "fsf_linear_norm_act": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
+    "fsf_linear_norm_act_grouped": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P,
+                                    c_i64, _P],
     "fsf_dynamic_point_pool_workspace_bytes": [c_i64, c_i64],
     "fsf_dynamic_point_pool": [_P, c_i64, c_i32, c_i32, c_i32, _P, c_i64, c_i32, _P, _P, c_i32, c_i64, _P, _P, _P, _P, _P,
                                _P, c_i64, _P],
@@ -535,10 +537,11 @@ def linear_norm_act_supported(x: torch.Tensor, out_features: int) -> bool:
 
 
 def linear_norm_act(x: torch.Tensor, planes: torch.Tensor, out_features: int, bias=None, norm: str = "none", gamma=None,
-                    beta=None, eps: float = 0.0, act: str = "none", out=None):
-    """fsf_linear_norm_act: act(norm(x @ W^T + bias)) -> f32 [n, c]; `planes` from linear_prepare_weight; norm 'none' | 'ln'
-    | 'affine'.  x (and `out`, if given) may be row-strided views (stride a multiple of 4 floats, 16-byte aligned base)."""
-    require_cuda(x, planes, bias, gamma, beta, out)
+                    beta=None, eps: float = 0.0, act: str = "none", out=None, row_add=None, row_add_index=None):
+    """fsf_linear_norm_act[_grouped]: act(norm(x @ W^T + bias [+ row_add[row_add_index]])) -> f32 [n, c]; `planes` from
+    linear_prepare_weight; norm 'none' | 'ln' | 'affine'.  x (and `out`, if given) may be row-strided views (stride a
+    multiple of 4 floats, 16-byte aligned base); row_add f32 [g, c] contiguous, row_add_index i64 [n]."""
+    require_cuda(x, planes, bias, gamma, beta, out, row_add, row_add_index)
     n, k = x.shape
     c = int(out_features)
     if out is None:
@@ -546,10 +549,18 @@ def linear_norm_act(x: torch.Tensor, planes: torch.Tensor, out_features: int, bi
     assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1
     xs = x.stride(0) if n > 1 else (k + 3) // 4 * 4
     os_ = out.stride(0) if n > 1 else (c + 3) // 4 * 4
-    check(_L().fsf_linear_norm_act(c_p(x.data_ptr()) if n else c_p(None), n, k, xs, ptr(planes), c, ptr(bias),
-                                   {"none": 0, "ln": 1, "affine": 2}[norm], ptr(gamma), ptr(beta), float(eps),
-                                   {"none": 0, "relu": 1, "gelu": 2}[act], c_p(out.data_ptr()) if n else c_p(None), os_,
-                                   stream_ptr()), "fsf_linear_norm_act")
+    norm_code, act_code = {"none": 0, "ln": 1, "affine": 2}[norm], {"none": 0, "relu": 1, "gelu": 2}[act]
+    if row_add is None:
+        check(_L().fsf_linear_norm_act(c_p(x.data_ptr()) if n else c_p(None), n, k, xs, ptr(planes), c, ptr(bias), norm_code,
+                                       ptr(gamma), ptr(beta), float(eps), act_code,
+                                       c_p(out.data_ptr()) if n else c_p(None), os_, stream_ptr()), "fsf_linear_norm_act")
+        return out
+    assert (row_add.dtype == torch.float32 and row_add.dim() == 2 and row_add.size(1) == c and row_add.is_contiguous()
+            and row_add_index.dtype == torch.int64 and row_add_index.shape == (n,) and row_add_index.is_contiguous())
+    check(_L().fsf_linear_norm_act_grouped(c_p(x.data_ptr()) if n else c_p(None), n, k, xs, ptr(planes), c, ptr(bias),
+                                           ptr(row_add), ptr(row_add_index), row_add.stride(0), norm_code, ptr(gamma),
+                                           ptr(beta), float(eps), act_code, c_p(out.data_ptr()) if n else c_p(None), os_,
+                                           stream_ptr()), "fsf_linear_norm_act_grouped")
     return out
 
 

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from ...ops.sst_ops import (build_mlp, fused_norm_act, gather_by_inverse, get_activation_layer, linear_norm_act,
-                            point_group_concat, point_linear, scatter_v2, unique_with_plan)
+                            GroupedConcat, point_group_concat, point_linear, scatter_v2, unique_with_plan)
 from ...registry import VOXEL_ENCODERS, build_norm_layer
 
 
@@ -198,6 +198,8 @@ class SIRLayer(nn.Module):
             last = i == len(self.vfe_layers) - 1
             if last and self.with_shortcut and vfe.linear.out_features == features.shape[1]:
                 # shortcut (never shape-compatible in the FSF configs): plain path
+                if isinstance(features, GroupedConcat):
+                    features = features.materialize()
                 point_feats = vfe(features) + features
                 voxel_feats, voxel_coors, unq_inv = scatter_v2(point_feats, coors, mode=self.mode, unq_inv=unq_inv_once,
                                                                new_coors=new_coors_once)

@@ -75,19 +75,86 @@ def gather_by_inverse(rows, unq_inv, out=None):
     return _GatherRows.apply(rows, plan)
 
 
+_GROUPED_CONCAT = os.environ.get("FSF_GROUPED_CONCAT", "1") != "0"  # (A/B switch for scratch scripts)
+
+
+class GroupedConcat:
+    """`cat([point_feats, group_feats[inv]], 1)` kept as its three parts (inference).  The only consumer is the next
+    layer's Linear, and `cat(p, g[inv]) W^T = p W_left^T + (g W_right^T)[inv]`: the right half is applied once per group
+    ([g, C] instead of [n, C] rows) and added per row inside K22's epilogue (fsf_linear_norm_act_grouped) — the [n, 2C]
+    tensor is never written and the per-point product is half as deep."""
+
+    def __init__(self, point_feats, group_feats, inv):
+        self.point_feats, self.group_feats, self.inv = point_feats, group_feats, inv
+
+    @property
+    def shape(self):
+        return (self.point_feats.size(0), self.point_feats.size(1) + self.group_feats.size(1))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def materialize(self):
+        n, c = self.point_feats.shape
+        buf = torch.empty((n, c + self.group_feats.size(1)), dtype=self.point_feats.dtype, device=self.point_feats.device)
+        buf[:, :c] = self.point_feats
+        gather_by_inverse(self.group_feats, self.inv, out=buf[:, c:])
+        return buf
+
+
+def _grouped_linear_norm_act(linear, norm, act, gc):
+    """act(norm(linear(cat))) for a GroupedConcat through fsf_linear_norm_act_grouped; None when the layer is not covered."""
+    p, g, inv = gc.point_feats, gc.group_feats, gc.inv
+    c_left = p.size(1)
+    act_code = "relu" if isinstance(act, nn.ReLU) else (
+        "gelu" if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none" else None)
+    if (act_code is None or not isinstance(linear, nn.Linear) or linear.in_features != gc.shape[1] or c_left % 4
+            or linear.out_features % 4 or p.size(0) < 1024 or not hip_ops.linear_norm_act_supported(p, linear.out_features)
+            or inv.dtype != torch.int64):
+        return None
+    if isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1 and norm.elementwise_affine and linear.out_features <= 128:
+        kind, gamma, beta, eps = "ln", norm.weight, norm.bias, norm.eps
+    elif isinstance(norm, nn.BatchNorm1d) and not norm.training and norm.track_running_stats:
+        from .spconv import _bn_affine
+
+        kind, eps = "affine", 0.0
+        gamma, beta = _bn_affine(norm)
+    else:
+        return None
+    key = (linear.weight.data_ptr(), linear.weight._version, linear.weight.device, c_left)
+    cache = linear.__dict__.get("_fsf_planes_grouped")
+    if cache is None or cache[0] != key:
+        w = linear.weight.detach()
+        cache = (key, hip_ops.linear_prepare_weight(w[:, :c_left].contiguous()), w[:, c_left:].contiguous())
+        linear.__dict__["_fsf_planes_grouped"] = cache
+    table = F.linear(g, cache[2])  # [groups, C_out]: the right half, once per group
+    return hip_ops.linear_norm_act(p, cache[1], linear.out_features, bias=linear.bias, norm=kind, gamma=gamma, beta=beta,
+                                   eps=eps, act=act_code, row_add=table, row_add_index=inv.contiguous())
+
+
 def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, want_concat):
     """One `DynamicVFELayer` step of DynamicScatterVFE / SIRLayer: point_feats = act(norm(linear(x))), group feats =
     segmented reduce, and (unless it is the last layer) `cat([point_feats, group_feats[inv]], 1)`.
     Inference: the fused norm+act writes the left half of the concat buffer and the row gather the right half — the
     [n, 2C] tensor is written exactly once; the segmented reduce reads the left half through its row stride."""
-    no_grad = not (torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in vfe_layer.parameters())))
-    if no_grad and want_concat and vfe_layer.dropout is None:
-        n, c = features.size(0), vfe_layer.linear.out_features
-        buf = torch.empty((n, 2 * c), dtype=features.dtype, device=features.device)
-        point_feats = linear_norm_act(vfe_layer.linear, vfe_layer.norm, vfe_layer.act, features, out=buf[:, :c])
+    grouped_in = isinstance(features, GroupedConcat)
+    no_grad = not (torch.is_grad_enabled() and ((not grouped_in and features.requires_grad)
+                                                or any(p.requires_grad for p in vfe_layer.parameters())))
+    point_feats = None
+    if grouped_in:
+        if no_grad and vfe_layer.dropout is None:
+            point_feats = _grouped_linear_norm_act(vfe_layer.linear, vfe_layer.norm, vfe_layer.act, features)
+        if point_feats is None:
+            features = features.materialize()
+    if no_grad and vfe_layer.dropout is None and (want_concat or point_feats is not None):
+        if point_feats is None:
+            point_feats = linear_norm_act(vfe_layer.linear, vfe_layer.norm, vfe_layer.act, features)
         group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors)
-        gather_by_inverse(group_feats, inv, out=buf[:, c:])
-        return point_feats, group_feats, group_coors, inv, buf
+        cat = None
+        if want_concat:
+            cat = GroupedConcat(point_feats, group_feats, inv) if _GROUPED_CONCAT else GroupedConcat(
+                point_feats, group_feats, inv).materialize()
+        return point_feats, group_feats, group_coors, inv, cat
     point_feats = vfe_layer(features)
     group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors)
     cat = torch.cat([point_feats, gather_by_inverse(group_feats, inv)], dim=1) if want_concat else None

@@ -209,6 +209,14 @@ int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t c, void* p
 int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
                         const float* bias, int32_t norm, const float* gamma, const float* beta, float eps, int32_t act,
                         float* out, int64_t out_stride, void* stream);
+/* The same with a per-row addend before the norm: out = act(norm(x W^T + bias + row_add[row_add_index[row]])), row_add f32
+ * [g, row_add_stride >= c] (16-byte aligned rows), row_add_index i64 [n].  With x = point_feats, W = the left half of a
+ * layer's weight and row_add = group_feats W_right^T this is `Linear(cat([point_feats, group_feats[inv]], 1))` of
+ * DynamicVFELayer / SIRLayer [UNVENDORED] without the [n, 2C] concat and with the right half applied once per group. */
+int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
+                                const float* bias, const float* row_add, const int64_t* row_add_index, int64_t row_add_stride,
+                                int32_t norm, const float* gamma, const float* beta, float eps, int32_t act, float* out,
+                                int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K13-K15  LiDAR -> camera projection + per-point instance-mask gather

@@ -925,3 +925,58 @@ def test_point_linear_thin_layers_gradients(ops, device, cin, cout, bias):
     if bias:
         want_b = go.double().sum(0)
         assert float((lin.bias.grad.double() - want_b).abs().max()) <= 2e-5 * float(want_b.abs().max())
+
+
+@pytest.mark.parametrize("n,g,cl,cr,c,norm,act", [(50000, 700, 128, 128, 128, "ln", "gelu"), (30011, 9000, 64, 64, 64, "affine", "relu"),
+                                                  (4099, 1, 128, 128, 128, "ln", "gelu"), (20000, 20000, 64, 32, 128, "none", "none")])
+def test_linear_norm_act_grouped_equals_linear_of_concat(ops, device, n, g, cl, cr, c, norm, act):
+    """fsf_linear_norm_act_grouped: x W_left^T + (groups W_right^T)[inv] == Linear(cat([x, groups[inv]], 1)) (float64
+    yardstick), and the plugin's GroupedConcat path == the materialised concat through the same layer."""
+    import torch.nn.functional as F
+
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import sst_ops
+
+    torch.manual_seed(n + g)
+    x = torch.randn(n, cl, device=device) * 2
+    grp = torch.randn(g, cr, device=device) * 2
+    inv = torch.randint(0, g, (n,), device=device)
+    inv[:min(n, g)] = torch.arange(min(n, g), device=device)
+    w = torch.randn(c, cl + cr, device=device) / (cl + cr) ** 0.5
+    gam, bet = torch.rand(c, device=device) + 0.5, torch.randn(c, device=device) * 0.1
+    planes = ops.linear_prepare_weight(w[:, :cl].contiguous())
+    table = F.linear(grp, w[:, cl:].contiguous())
+    out = ops.linear_norm_act(x, planes, c, norm=norm, gamma=gam if norm != "none" else None,
+                              beta=bet if norm != "none" else None, eps=1e-3, act=act, row_add=table, row_add_index=inv)
+
+    def tail(y):
+        if norm == "ln":
+            y = F.layer_norm(y, (c,), gam.to(y.dtype), bet.to(y.dtype), 1e-3)
+        elif norm == "affine":
+            y = y * gam.to(y.dtype) + bet.to(y.dtype)
+        return F.gelu(y) if act == "gelu" else F.relu(y) if act == "relu" else y
+
+    cat = torch.cat([x, grp[inv]], 1)
+    want = tail(F.linear(cat.double(), w.double()))
+    ref32 = tail(F.linear(cat, w))
+    scale = max(1.0, float(want.abs().max()))
+    err, err32 = float((out.double() - want).abs().max()), float((ref32.double() - want).abs().max())
+    assert err <= max(3.0 * err32, 3e-6 * scale), (err, err32)
+    if norm != "none":
+        lin = torch.nn.Linear(cl + cr, c, bias=False).to(device)
+        with torch.no_grad():
+            lin.weight.copy_(w)
+        if norm == "ln":
+            nm = torch.nn.LayerNorm(c, eps=1e-3).to(device)
+            with torch.no_grad():
+                nm.weight.copy_(gam), nm.bias.copy_(bet)
+        else:
+            nm = torch.nn.BatchNorm1d(c, eps=1e-3).to(device).eval()
+            with torch.no_grad():
+                nm.weight.copy_(gam), nm.bias.copy_(bet), nm.running_var.uniform_(0.5, 2.0), nm.running_mean.normal_()
+        a = torch.nn.GELU() if act == "gelu" else torch.nn.ReLU()
+        with torch.no_grad():
+            gc = sst_ops.GroupedConcat(x, grp, inv)
+            got = sst_ops._grouped_linear_norm_act(lin, nm, a, gc)
+            ref = sst_ops.linear_norm_act(lin, nm, a, gc.materialize())
+        assert got is not None
+        assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
