@@ -232,8 +232,12 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
 #pragma unroll
             for (int rg = 0; rg < LNA_RG; ++rg) {
               const lna_u32x4 xb = TERM_X[term] == 0 ? xh[rg] : TERM_X[term] == 1 ? xm[rg] : xl[rg];
+#ifndef FSF_ABL_LNA_NO_MFMA
               acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[tt][TERM_W[term]], __builtin_bit_cast(lna_bf16x8, xb),
                                                                         acc[rg][t + tt], 0, 0, 0);
+#else  // ablation: one VALU op per product term keeps the operand loads alive without the matrix pipe
+              acc[rg][t + tt][term & 3] += __uint_as_float(xb[term & 3] ^ __builtin_bit_cast(lna_u32x4, wfr[tt][TERM_W[term]])[term & 3]);
+#endif
             }
       }
     }

@@ -206,8 +206,12 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
 #pragma unroll
               for (int rg = 0; rg < SCS_RG; ++rg) {
                 const scs_u32x4 xb = TERM_X[term] == 0 ? xh[rg] : TERM_X[term] == 1 ? xm[rg] : xl[rg];
+#ifndef FSF_ABL_SCS_NO_MFMA
                 acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[tt][TERM_W[term]], __builtin_bit_cast(scs_bf16x8, xb),
                                                                           acc[rg][t + tt], 0, 0, 0);
+#else  // ablation: one VALU op per product term keeps the operand loads alive without the matrix pipe
+                acc[rg][t + tt][term & 3] += __uint_as_float(xb[term & 3] ^ __builtin_bit_cast(scs_u32x4, wfr[tt][TERM_W[term]])[term & 3]);
+#endif
               }
         }
       }
