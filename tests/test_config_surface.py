@@ -115,3 +115,23 @@ def test_reference_av2_config_resolves():
     assert {k: tuple(v.shape) for k, v in ref_model.state_dict().items()} == \
            {k: tuple(v.shape) for k, v in own_model.state_dict().items()}
     assert own_model.bbox_coder.code_size == 8 and own_model.is_argo
+
+
+def test_grouped_concat_host_logic_cpu():
+    """GroupedConcat (the deferred `cat([point_feats, group_feats[inv]], 1)` of SIRLayer / DynamicScatterVFE): shape
+    protocol, and the grouped kernel route declines CPU tensors (the plugin ops themselves have no CPU path and raise)."""
+    import pytest
+    import torch
+
+    from fullysparsefusion_amd._lib import FsfHipError
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import sst_ops
+
+    torch.manual_seed(0)
+    n, g, c = 300, 17, 8
+    p, grp = torch.randn(n, c), torch.randn(g, c)
+    inv = torch.randint(0, g, (n,))
+    gc = sst_ops.GroupedConcat(p, grp, inv)
+    assert gc.shape == (n, 2 * c) and gc.size(1) == 2 * c and gc.size() == (n, 2 * c)
+    assert sst_ops._grouped_linear_norm_act(torch.nn.Linear(2 * c, c), torch.nn.LayerNorm(c), torch.nn.GELU(), gc) is None
+    with pytest.raises(FsfHipError):
+        gc.materialize()  # gathers through the HIP library: loud failure on a CPU tensor, never a silent fallback

@@ -980,3 +980,19 @@ def test_linear_norm_act_grouped_equals_linear_of_concat(ops, device, n, g, cl, 
             ref = sst_ops.linear_norm_act(lin, nm, a, gc.materialize())
         assert got is not None
         assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_column_stats_and_batch_norm_edge_cases(ops, device):
+    """K23 with no rows: sums / statistics / gradients are zeros, nothing is launched on empty inputs; a single row."""
+    x0 = torch.empty(0, 12, device=device)
+    assert torch.equal(ops.column_sum(x0), torch.zeros(12, device=device))
+    m, v = ops.column_mean_var(x0)
+    assert torch.equal(m, torch.zeros(12, device=device)) and torch.equal(v, torch.zeros(12, device=device))
+    one = torch.ones(12, device=device)
+    gx, dg, db = ops.batch_norm_act_backward(x0, x0, one, one, one, one, True)
+    assert gx.shape == (0, 12) and not dg.any() and not db.any()
+    assert ops.batch_norm_act_forward(x0, one, one, True).shape == (0, 12)
+    x1 = torch.randn(1, 12, device=device)
+    m, v = ops.column_mean_var(x1)
+    assert torch.equal(m, x1[0]) and not v.any()
+    assert torch.equal(ops.column_sum(x1), x1[0])

@@ -767,3 +767,31 @@ def test_stage1_gradients_vs_oracle(fsf_pair, device, monkeypatch):
     model.zero_grad(set_to_none=True)
     assert not loose_bad, loose_bad
     assert tight >= 0.4 * len(g64), (tight, len(g64))  # VFE, image MLP, seg head, neck and the two finest U-Net levels
+
+
+def test_sir_layer_deferred_concat_equals_materialised(plugin, device, monkeypatch):
+    """SIRLayer at inference with the concat deferred to fsf_linear_norm_act_grouped == the same layer with the
+    [n, 2C] concat materialised (both through K22): point feats, group feats, group order."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import sst_ops
+
+    torch.manual_seed(5)
+    layer = plugin.registry.build_voxel_encoder(dict(
+        type="SIRLayer", in_channels=133, feat_channels=[128, 128], with_distance=False, with_cluster_center=False,
+        with_rel_mlp=True, rel_mlp_hidden_dims=[16, 32], rel_mlp_in_channel=3, with_voxel_center=False,
+        norm_cfg=dict(type="LN", eps=1e-3), mode="max", return_point_feats=True, rel_dist_scaler=10.0,
+        xyz_normalizer=[20.0, 20.0, 4.0], act="gelu", dropout=0.0)).to(device).eval()
+    n, g = 60000, 900
+    feats = torch.randn(n, 133, device=device)
+    f_cluster = torch.randn(n, 3, device=device)
+    gid = torch.randint(0, g, (n,), device=device)
+    coors = torch.stack([torch.zeros_like(gid), gid % 7, gid], 1)
+    outs = []
+    with torch.no_grad():
+        for deferred in (True, False):
+            monkeypatch.setattr(sst_ops, "_GROUPED_CONCAT", deferred)
+            outs.append(layer(feats, coors, f_cluster=f_cluster, return_both=True))
+    for a, b in zip(outs[0], outs[1]):
+        if a.dtype.is_floating_point:
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+        else:
+            assert torch.equal(a, b)
