@@ -75,6 +75,7 @@ def gather_by_inverse(rows, unq_inv, out=None):
     return _GatherRows.apply(rows, plan)
 
 
+_SMALL_N_MIN = int(os.environ.get("FSF_K22_SMALL_N", "16"))  # (A/B switch: 1024 restores the library for small inputs)
 _GROUPED_CONCAT = os.environ.get("FSF_GROUPED_CONCAT", "1") != "0"  # (A/B switch for scratch scripts)
 
 
@@ -355,7 +356,10 @@ def linear_norm_act(linear, norm, act, x, out=None):
             and not hip_ops.linear_norm_act_supported(x, linear.out_features) and linear.out_features % 4 == 0):
         k = x.size(1)  # thin inputs ([n, 10] image features, [n, 11] VFE decorations): one small copy buys aligned rows
         x = F.pad(x, (0, (-k) % 4))[:, :k]
-    if (not needs_grad and act_code is not None and isinstance(linear, nn.Linear) and x.dim() == 2 and x.size(0) >= 1024
+    # (a few hundred rows — the camera queries — with a shallow product: the kernel is latency-bound at ~10 us, the
+    # library spends 60-150 us of host time per call choosing a GEMM; deep products on few rows stay on the library)
+    if (not needs_grad and act_code is not None and isinstance(linear, nn.Linear) and x.dim() == 2
+            and (x.size(0) >= 1024 or (x.size(0) >= _SMALL_N_MIN and linear.in_features <= 256))
             and hip_ops.linear_norm_act_supported(x, linear.out_features)
             and (out is None or (out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0))):
         kind = None
@@ -367,24 +371,35 @@ def linear_norm_act(linear, norm, act, x, out=None):
             kind, eps = "affine", 0.0
             gamma, beta = _bn_affine(norm)
         if kind is not None:
-            key = (linear.weight.data_ptr(), linear.weight._version, linear.weight.device)
-            cache = linear.__dict__.get("_fsf_planes")
-            if cache is None or cache[0] != key:
-                cache = (key, hip_ops.linear_prepare_weight(linear.weight))
-                linear.__dict__["_fsf_planes"] = cache
+            planes = _prepared_planes(linear)
             if kind == "ln" and linear.out_features > 128:  # LayerNorm statistics span the kernel's 128-channel slices
-                y = hip_ops.linear_norm_act(x, cache[1], linear.out_features, bias=linear.bias)
+                y = hip_ops.linear_norm_act(x, planes, linear.out_features, bias=linear.bias)
                 return fused_norm_act(y, norm, act, out=out)
-            return hip_ops.linear_norm_act(x, cache[1], linear.out_features, bias=linear.bias, norm=kind, gamma=gamma,
+            return hip_ops.linear_norm_act(x, planes, linear.out_features, bias=linear.bias, norm=kind, gamma=gamma,
                                            beta=beta, eps=eps, act=act_code, out=out)
     return fused_norm_act(point_linear(linear, x), norm, act, out=out)
 
 
+def _prepared_planes(linear):
+    """The layer's weight as K22's fragment-ordered bf16 planes, prepared once per weight version."""
+    key = (linear.weight.data_ptr(), linear.weight._version, linear.weight.device)
+    cache = linear.__dict__.get("_fsf_planes")
+    if cache is None or cache[0] != key:
+        cache = (key, hip_ops.linear_prepare_weight(linear.weight))
+        linear.__dict__["_fsf_planes"] = cache
+    return cache[1]
+
+
 def point_linear(linear, x):
-    """`linear(x)` for a per-point nn.Linear; training on the GPU routes the weight gradient through K10."""
-    if (torch.is_grad_enabled() and linear.weight.requires_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+    """`linear(x)` for a per-point nn.Linear; training on the GPU routes the weight gradient through K10, inference on
+    >= 1024 rows runs the product on K22 (no norm, no activation: 10 641 x 1024 -> 1024 158 us vs 225 us on the library)."""
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad)
+    if (needs_grad and linear.weight.requires_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
             and x.size(0) >= 16384):
         return _PointLinearFn.apply(x, linear.weight, linear.bias)
+    if (not needs_grad and x.dim() == 2 and x.size(0) >= 1024 and linear.out_features % 4 == 0
+            and hip_ops.linear_norm_act_supported(x, linear.out_features)):
+        return hip_ops.linear_norm_act(x, _prepared_planes(linear), linear.out_features, bias=linear.bias)
     return F.linear(x, linear.weight, linear.bias)
 
 
