@@ -43,7 +43,7 @@ def lib():
                     "fsf_unique_rows_workspace_bytes",
                     "fsf_segment_plan_workspace_bytes",
                     "fsf_segment_reduce_workspace_bytes",
-                    "fsf_rulebook_workspace_bytes",
+                    "fsf_rulebook_workspace_bytes", "fsf_rulebook_to_pairs_workspace_bytes",
                     "fsf_ingroup_rank_workspace_bytes", "fsf_dynamic_point_pool_workspace_bytes",
                     "fsf_nms_bev_workspace_bytes", "fsf_nms_bev_multiclass_workspace_bytes",
                     "fsf_norm_act_backward_workspace_bytes", "fsf_column_stats_workspace_bytes",

@@ -212,20 +212,50 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// nbr table -> spconv v1 pair lists: for each offset k, the (in,out) pairs in ascending out row
+// nbr table -> spconv v1 pair lists: for each offset k, the (in,out) pairs in ascending out row.
+// Two launches: (1) every 2048-row segment counts its live entries per offset (coalesced walk of the table, LDS counters),
+// (2) workgroup (segment, offset) sums the counts of the segments before it and compacts its own rows in order.
+// (One workgroup per offset walking all rows in 256-row steps with three barriers each was 160 us on a 1e5-row level.)
+constexpr int RBP_SEG = 2048;
+
 __global__ void __launch_bounds__(256)
-    rb_pairs_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int kvol, int32_t* __restrict__ pairs, int64_t cap,
-                    int32_t* __restrict__ num) {
-  // one workgroup per offset: sequential chunks keep ascending-out order without a global scan
+    rb_pairs_count_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int kvol, int32_t* __restrict__ cnt) {
+  extern __shared__ int32_t c_s[];  // [kvol]
+  for (int k = threadIdx.x; k < kvol; k += 256) c_s[k] = 0;
+  __syncthreads();
+  const int64_t e0 = (int64_t)blockIdx.x * RBP_SEG * kvol;
+  const int64_t rows = m_out - (int64_t)blockIdx.x * RBP_SEG < RBP_SEG ? m_out - (int64_t)blockIdx.x * RBP_SEG : RBP_SEG;
+  const int64_t n = rows * kvol;
+  for (int64_t t = threadIdx.x; t < n; t += 256)
+    if (nbr[e0 + t] >= 0) atomicAdd(&c_s[(int)(t % kvol)], 1);
+  __syncthreads();
+  for (int k = threadIdx.x; k < kvol; k += 256) cnt[(int64_t)blockIdx.x * kvol + k] = c_s[k];
+}
+
+__global__ void __launch_bounds__(256)
+    rb_pairs_fill_kernel(const int32_t* __restrict__ nbr, int64_t m_out, int kvol, const int32_t* __restrict__ cnt,
+                         int32_t* __restrict__ pairs, int64_t cap, int32_t* __restrict__ num) {
   __shared__ uint32_t wtot[4];
   __shared__ uint32_t base_s;
-  const int k = blockIdx.x;
+  const int seg = blockIdx.x, k = blockIdx.y, nseg = gridDim.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) base_s = 0;
+  // pairs before this segment (and, for the last segment, the total)
+  uint32_t before = 0;
+  for (int s = threadIdx.x; s < seg; s += 256) before += (uint32_t)cnt[(int64_t)s * kvol + k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+  if (lane == 0) wtot[wave] = before;
   __syncthreads();
-  for (int64_t o0 = 0; o0 < m_out; o0 += 256) {
+  if (threadIdx.x == 0) {
+    base_s = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    if (seg == nseg - 1) num[k] = (int32_t)(base_s + (uint32_t)cnt[(int64_t)seg * kvol + k]);
+  }
+  __syncthreads();
+  const int64_t o_begin = (int64_t)seg * RBP_SEG;
+  const int64_t o_end = o_begin + RBP_SEG < m_out ? o_begin + RBP_SEG : m_out;
+  for (int64_t o0 = o_begin; o0 < o_end; o0 += 256) {
     const int64_t o = o0 + threadIdx.x;
-    const int32_t in = (o < m_out) ? nbr[o * kvol + k] : -1;
+    const int32_t in = (o < o_end) ? nbr[o * kvol + k] : -1;
     const bool has = in >= 0;
     const uint64_t bal = __ballot(has);
     const uint32_t below = (uint32_t)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
@@ -242,7 +272,6 @@ __global__ void __launch_bounds__(256)
     if (threadIdx.x == 0) base_s += wtot[0] + wtot[1] + wtot[2] + wtot[3];
     __syncthreads();
   }
-  if (threadIdx.x == 0) num[k] = (int32_t)base_s;
 }
 
 static uint64_t pow2_at_least(uint64_t v) {
@@ -399,12 +428,27 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
   return FSF_OK;
 }
 
+extern "C" int64_t fsf_rulebook_to_pairs_workspace_bytes(int64_t m_out, int32_t kvol) {
+  const int64_t nseg = (m_out > 0 ? m_out + RBP_SEG - 1 : RBP_SEG) / RBP_SEG;
+  return fsf_align_up(nseg * (kvol > 0 ? kvol : 1) * 4, 256) + 256;
+}
+
 extern "C" int fsf_rulebook_to_pairs(const int32_t* nbr, int64_t m_out, int32_t kvol, int32_t* indice_pairs, int64_t cap,
-                                     int32_t* indice_num, void* stream_) {
+                                     int32_t* indice_num, void* workspace, int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (m_out < 0 || kvol < 1 || cap < 0 || !indice_num || (m_out > 0 && (!nbr || !indice_pairs))) return FSF_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(rb_pairs_kernel, dim3(kvol), dim3(256), 0, stream, nbr, m_out, (int)kvol, indice_pairs, cap,
-                     indice_num);
+  if (m_out == 0) {
+    FSF_HIP_TRY(hipMemsetAsync(indice_num, 0, sizeof(int32_t) * kvol, stream));
+    return FSF_OK;
+  }
+  if (!workspace || workspace_bytes < fsf_rulebook_to_pairs_workspace_bytes(m_out, kvol)) return FSF_ERR_WORKSPACE;
+  const int64_t nseg = (m_out + RBP_SEG - 1) / RBP_SEG;
+  if (nseg > 65535 * 32) return FSF_ERR_UNSUPPORTED;
+  int32_t* cnt = (int32_t*)workspace;
+  hipLaunchKernelGGL(rb_pairs_count_kernel, dim3((unsigned)nseg), dim3(256), sizeof(int32_t) * kvol, stream, nbr, m_out, (int)kvol,
+                     cnt);
+  hipLaunchKernelGGL(rb_pairs_fill_kernel, dim3((unsigned)nseg, (unsigned)kvol), dim3(256), 0, stream, nbr, m_out, (int)kvol, cnt,
+                     indice_pairs, cap, indice_num);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

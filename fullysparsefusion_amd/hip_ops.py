@@ -32,7 +32,8 @@ _ARGTYPES = {
     "fsf_rulebook_workspace_bytes": [c_i64, c_i32],
     "fsf_rulebook_subm": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, c_i64, _P],
     "fsf_rulebook_strided": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P],
-    "fsf_rulebook_to_pairs": [_P, c_i64, c_i32, _P, c_i64, _P, _P],
+    "fsf_rulebook_to_pairs_workspace_bytes": [c_i64, c_i32],
+    "fsf_rulebook_to_pairs": [_P, c_i64, c_i32, _P, c_i64, _P, _P, c_i64, _P],
     "fsf_spconv_transpose_weight": [_P, c_i32, c_i32, c_i32, _P, _P],
     "fsf_spconv_workspace_bytes": [c_i64, c_i32, c_i32, c_i32],
     "fsf_spconv_forward": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
@@ -356,7 +357,9 @@ def rulebook_to_pairs(nbr: torch.Tensor):
     cap = max(m_out, 1)
     pairs = torch.full((kvol, 2, cap), -1, dtype=torch.int32, device=nbr.device)
     num = torch.empty((kvol,), dtype=torch.int32, device=nbr.device)
-    check(_L().fsf_rulebook_to_pairs(ptr(nbr), m_out, kvol, ptr(pairs), cap, ptr(num), stream_ptr()),
+    h = _L()
+    ws = _lib.workspace(h.fsf_rulebook_to_pairs_workspace_bytes(m_out, kvol), nbr.device)
+    check(h.fsf_rulebook_to_pairs(ptr(nbr), m_out, kvol, ptr(pairs), cap, ptr(num), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_rulebook_to_pairs")
     return pairs, num
 

@@ -273,8 +273,9 @@ int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t batch_size, 
                          const int32_t dilation[3], int32_t* out_indices, int64_t cap, int32_t* nbr,
                          int32_t* nbr_inv, int64_t* m_out_dev, int64_t* m_out_host, void* workspace,
                          int64_t workspace_bytes, void* stream);
+int64_t fsf_rulebook_to_pairs_workspace_bytes(int64_t m_out, int32_t kvol);
 int fsf_rulebook_to_pairs(const int32_t* nbr, int64_t m_out, int32_t kvol, int32_t* indice_pairs, int64_t cap,
-                          int32_t* indice_num, void* stream);
+                          int32_t* indice_num, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K9/K11  sparse convolution forward: out[o,:] = act(scale * (sum_k feat[nbr[o,k],:] @ W[k]) + shift + residual)
