@@ -109,11 +109,102 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// epilogue of one row block: lane (row, g) holds channels ch_base + 16 t + 4 g + r of its row
+// bias | gamma | beta of the 128-channel slice at ch_base -> LDS (defaults 0 | 1 | 0 where absent or beyond c)
+__device__ __forceinline__ void lna_stage_vectors(const LnaArgs& a, int ch_base, float* vec) {
+  for (int t = threadIdx.x; t < 384; t += LNA_NW * 64) {
+    const int which = t >> 7, ch = ch_base + (t & 127);
+    const float* src = which == 0 ? a.bias : (a.norm != 0 ? (which == 1 ? a.gamma : a.beta) : nullptr);
+    vec[t] = (src && ch < a.c) ? src[ch] : (which == 1 ? 1.0f : 0.0f);
+  }
+  __syncthreads();
+}
+
+// `vec` = this slice's bias | gamma | beta, 128 floats each, staged in LDS once per workgroup: as ordinary global loads in
+// here every one of them was followed by the `vmcnt(0)` hipcc emits at the first use of a load beside an LDS-DMA — 24-48
+// serialized L2 round trips per row block (and a drain of the next block's prefetch each time).
+template <int T>
+__device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[LNA_RG][T], int64_t row0, int ch_base, int rowl,
+                                             int grp, const float* vec) {
+  const float inv_c = 1.0f / (float)a.c;
+#pragma unroll
+  for (int rg = 0; rg < LNA_RG; ++rg) {
+    const int64_t row = row0 + 16 * rg + rowl;
+    float mean = 0.0f, rstd = 1.0f;
+    if (a.bias) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(vec + 16 * t + 4 * grp);  // (0 beyond c)
+        acc[rg][t][0] += b.x; acc[rg][t][1] += b.y; acc[rg][t][2] += b.z; acc[rg][t][3] += b.w;
+      }
+    }
+    if (a.row_add) {  // all loads of the row first, then the adds: one wait instead of one per tile
+      const int64_t row_c = row0 + 16 * rg + rowl;
+      const float* add = a.row_add + a.row_add_index[row_c < a.n ? row_c : a.n - 1] * a.row_add_stride;
+      constexpr int TB = T < 4 ? T : 4;  // four loads in flight per wait
+#pragma unroll
+      for (int t0 = 0; t0 < T; t0 += TB) {
+        float4 b[TB];
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          const int ch0 = ch_base + 16 * (t0 + t) + 4 * grp;
+          b[t] = *reinterpret_cast<const float4*>(add + (ch0 < a.c ? ch0 : 0));
+        }
+#pragma unroll
+        for (int t = 0; t < TB; ++t) {
+          if (ch_base + 16 * (t0 + t) + 4 * grp < a.c) {
+            acc[rg][t0 + t][0] += b[t].x; acc[rg][t0 + t][1] += b[t].y; acc[rg][t0 + t][2] += b[t].z; acc[rg][t0 + t][3] += b[t].w;
+          }
+        }
+      }
+    }
+    if (a.norm == 1) {  // LayerNorm over the c channels (channels >= c are exactly 0: zero weights, no bias)
+      float s = 0.0f;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[rg][t][r];
+      mean = lna_row_sum(s) * inv_c;
+      float q = 0.0f;
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = ch_base + 16 * t + 4 * grp + r < a.c ? acc[rg][t][r] - mean : 0.0f;
+          q += d * d;
+        }
+      rstd = rsqrtf(lna_row_sum(q) * inv_c + a.eps);
+    }
+    if (row < a.n) {
+      float* orow = a.out + row * a.out_stride;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int ch0 = ch_base + 16 * t + 4 * grp;
+        if (ch0 < a.c) {
+          const float4 g = *reinterpret_cast<const float4*>(vec + 128 + 16 * t + 4 * grp);  // (1 / 0 without a norm)
+          const float4 b = *reinterpret_cast<const float4*>(vec + 256 + 16 * t + 4 * grp);
+          float4 y;
+          y.x = lna_act((acc[rg][t][0] - mean) * rstd * g.x + b.x, a.act);
+          y.y = lna_act((acc[rg][t][1] - mean) * rstd * g.y + b.y, a.act);
+          y.z = lna_act((acc[rg][t][2] - mean) * rstd * g.z + b.z, a.act);
+          y.w = lna_act((acc[rg][t][3] - mean) * rstd * g.w + b.w, a.act);
+#ifndef FSF_ABL_LNA_NO_STORE
+          *reinterpret_cast<float4*>(orow + ch0) = y;
+#else
+          if (y.x == 123.456f) *reinterpret_cast<float4*>(orow + ch0) = y;
+#endif
+        }
+      }
+    }
+  }
+}
+
 template <int T>  // 16-channel tiles (c <= 16 T)
 __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(LnaArgs a) {
   constexpr int CHUNK_U4 = T * 3 * 64;  // uint4 per weight chunk
   extern __shared__ __attribute__((aligned(16))) char lna_smem[];
-  uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4]
+  uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4], then 384 floats of per-channel vectors
+  float* vec = reinterpret_cast<float*>(wbuf + 2 * CHUNK_U4);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rowl = lane & 15, grp = lane >> 4;
   const int nkc = (a.k + LNA_KC - 1) / LNA_KC;
@@ -158,6 +249,7 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
       v[rg][4] = q.x; v[rg][5] = q.y; v[rg][6] = q.z; v[rg][7] = q.w;
     }
   };
+  lna_stage_vectors(a, ch_base, vec);
   float xc[LNA_RG][8];
   int buf = 0;
   if ((int64_t)blockIdx.x < nblk) {
@@ -241,76 +333,7 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
             }
       }
     }
-    // ---- epilogue: lane (row, g) holds channels 16 t + 4 g + r of its row
-    const float inv_c = 1.0f / (float)a.c;
-#pragma unroll
-    for (int rg = 0; rg < LNA_RG; ++rg) {
-      const int64_t row = row0 + 16 * rg + rowl;
-      float mean = 0.0f, rstd = 1.0f;
-      if (a.bias) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int ch0 = ch_base + 16 * t + 4 * grp;
-          if (ch0 < a.c) {
-            const float4 b = *reinterpret_cast<const float4*>(a.bias + ch0);
-            acc[rg][t][0] += b.x; acc[rg][t][1] += b.y; acc[rg][t][2] += b.z; acc[rg][t][3] += b.w;
-          }
-        }
-      }
-      if (a.row_add) {
-        const int64_t row_c = row0 + 16 * rg + rowl;
-        const float* add = a.row_add + a.row_add_index[row_c < a.n ? row_c : a.n - 1] * a.row_add_stride;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int ch0 = ch_base + 16 * t + 4 * grp;
-          if (ch0 < a.c) {
-            const float4 b = *reinterpret_cast<const float4*>(add + ch0);
-            acc[rg][t][0] += b.x; acc[rg][t][1] += b.y; acc[rg][t][2] += b.z; acc[rg][t][3] += b.w;
-          }
-        }
-      }
-      if (a.norm == 1) {  // LayerNorm over the c channels (channels >= c are exactly 0: zero weights, no bias)
-        float s = 0.0f;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s += acc[rg][t][r];
-        mean = lna_row_sum(s) * inv_c;
-        float q = 0.0f;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float d = ch_base + 16 * t + 4 * grp + r < a.c ? acc[rg][t][r] - mean : 0.0f;
-            q += d * d;
-          }
-        rstd = rsqrtf(lna_row_sum(q) * inv_c + a.eps);
-      }
-      if (row < a.n) {
-        float* orow = a.out + row * a.out_stride;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int ch0 = ch_base + 16 * t + 4 * grp;
-          if (ch0 < a.c) {
-            float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.norm != 0) {
-              g = *reinterpret_cast<const float4*>(a.gamma + ch0);
-              b = *reinterpret_cast<const float4*>(a.beta + ch0);
-            }
-            float4 y;
-            y.x = lna_act((acc[rg][t][0] - mean) * rstd * g.x + b.x, a.act);
-            y.y = lna_act((acc[rg][t][1] - mean) * rstd * g.y + b.y, a.act);
-            y.z = lna_act((acc[rg][t][2] - mean) * rstd * g.z + b.z, a.act);
-            y.w = lna_act((acc[rg][t][3] - mean) * rstd * g.w + b.w, a.act);
-#ifndef FSF_ABL_LNA_NO_STORE
-            *reinterpret_cast<float4*>(orow + ch0) = y;
-#else
-            if (y.x == 123.456f) *reinterpret_cast<float4*>(orow + ch0) = y;
-#endif
-          }
-        }
-      }
-    }
+    lna_epilogue<T>(a, acc, row0, ch_base, rowl, grp, vec);
   }
 }
 
@@ -380,7 +403,7 @@ extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k,
   const dim3 grid((unsigned)gx, (unsigned)nslice);
 #define FSF_LNA(T_)                                                                                                     \
   do {                                                                                                                 \
-    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16;                                                          \
+    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4;                                                \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
       FSF_HIP_TRY(hipFuncSetAttribute((const void*)linear_norm_act_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
