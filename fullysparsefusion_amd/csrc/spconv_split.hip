@@ -28,6 +28,9 @@ constexpr int SCS_KC = 32;   // cin per LDS weight chunk (one MFMA k step)
 constexpr int SCS_NW = 4;    // waves per workgroup
 constexpr int SCS_RG = 2;    // 16-row groups per wave
 constexpr int SCS_ROWS = SCS_NW * SCS_RG * 16;
+#ifndef SCS_EPI_TB
+#define SCS_EPI_TB 1  // (4: the whole residual row before the stores — 42 spilled VGPRs, 1.5 % slower)
+#endif
 #ifndef SCS_WPS
 #define SCS_WPS 3            // workgroups per CU the register budget is set for
 #endif
@@ -85,7 +88,8 @@ template <int T>
 __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(ScsArgs a) {
   constexpr int CHUNK_U4 = T * 3 * 64;
   extern __shared__ __attribute__((aligned(16))) char scs_smem[];
-  uint4* wbuf = reinterpret_cast<uint4*>(scs_smem);  // [2][CHUNK_U4]
+  uint4* wbuf = reinterpret_cast<uint4*>(scs_smem);  // [2][CHUNK_U4], then scale | shift of this 128-channel slice
+  float* vec = reinterpret_cast<float*>(wbuf + 2 * CHUNK_U4);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rowl = lane & 15, grp = lane >> 4;
   const int nkc = (a.cin + SCS_KC - 1) / SCS_KC;
@@ -97,6 +101,16 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
   const int ch_base = 128 * (int)blockIdx.y;
   const uint4* planes = a.planes + (int64_t)blockIdx.y * nchunks * CHUNK_U4;
   const int last_quad = a.cin - 4;
+  // The epilogue's per-channel vectors go through LDS, and its residual row is loaded before the first store: as plain
+  // global loads inside the tile loop each one sat behind the previous tile's store (the pointers may alias) — ~48
+  // serialized round trips at the end of every workgroup's chain.
+  {
+    const int t = threadIdx.x;  // 256 threads: scale[128] | shift[128]
+    const int ch = 128 * (int)blockIdx.y + (t & 127);
+    const float* src = t < 128 ? a.scale : a.shift;
+    vec[t] = (src && ch < a.cout) ? src[ch] : (t < 128 ? 1.0f : 0.0f);
+  }
+  __syncthreads();
 
   auto stage_w = [&](int ci, int buf) {
     const float* src = reinterpret_cast<const float*>(planes + (int64_t)ci * CHUNK_U4);
@@ -221,29 +235,47 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
     for (int rg = 0; rg < SCS_RG; ++rg) {
       const int64_t row = row0 + 16 * rg + rowl;
       if (row < a.m_out) {
+        if (a.ksplit > 1) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const int ch0 = ch_base + 16 * t + 4 * grp;
-          if (ch0 < a.cout) {
-            float4 y = make_float4(acc[rg][t][0], acc[rg][t][1], acc[rg][t][2], acc[rg][t][3]);
-            if (a.ksplit > 1) {
-              *reinterpret_cast<float4*>(a.partial + ((int64_t)blockIdx.z * a.m_out + row) * a.cout + ch0) = y;
-              continue;
+          for (int t = 0; t < T; ++t) {
+            const int ch0 = ch_base + 16 * t + 4 * grp;
+            if (ch0 < a.cout)
+              *reinterpret_cast<float4*>(a.partial + ((int64_t)blockIdx.z * a.m_out + row) * a.cout + ch0) =
+                  make_float4(acc[rg][t][0], acc[rg][t][1], acc[rg][t][2], acc[rg][t][3]);
+          }
+          continue;
+        }
+        const bool affine = a.scale || a.shift;
+        constexpr int TB = SCS_EPI_TB < T ? SCS_EPI_TB : T;  // the residual row TB tiles at a time: loads first, then the stores
+#pragma unroll
+        for (int t0 = 0; t0 < T; t0 += TB) {
+          float4 rs[TB];
+          if (a.residual) {
+#pragma unroll
+            for (int t = 0; t < TB; ++t) {
+              const int ch0 = ch_base + 16 * (t0 + t) + 4 * grp;
+              rs[t] = *reinterpret_cast<const float4*>(a.residual + row * a.cout + (ch0 < a.cout ? ch0 : 0));
             }
-            if (a.scale) {
-              const float4 sc = *reinterpret_cast<const float4*>(a.scale + ch0), sh = *reinterpret_cast<const float4*>(a.shift + ch0);
-              y.x = __fmaf_rn(y.x, sc.x, sh.x); y.y = __fmaf_rn(y.y, sc.y, sh.y);
-              y.z = __fmaf_rn(y.z, sc.z, sh.z); y.w = __fmaf_rn(y.w, sc.w, sh.w);
-            } else if (a.shift) {
-              const float4 sh = *reinterpret_cast<const float4*>(a.shift + ch0);
-              y.x = __fadd_rn(y.x, sh.x); y.y = __fadd_rn(y.y, sh.y); y.z = __fadd_rn(y.z, sh.z); y.w = __fadd_rn(y.w, sh.w);
+          }
+#pragma unroll
+          for (int tt = 0; tt < TB; ++tt) {
+            const int t = t0 + tt;
+            const int ch0 = ch_base + 16 * t + 4 * grp;
+            if (ch0 < a.cout) {
+              float4 y = make_float4(acc[rg][t][0], acc[rg][t][1], acc[rg][t][2], acc[rg][t][3]);
+              if (affine) {  // (scale defaults to 1: fma(y, 1, shift) == y + shift exactly)
+                const float4 sc = *reinterpret_cast<const float4*>(vec + 16 * t + 4 * grp);
+                const float4 sh = *reinterpret_cast<const float4*>(vec + 128 + 16 * t + 4 * grp);
+                y.x = __fmaf_rn(y.x, sc.x, sh.x); y.y = __fmaf_rn(y.y, sc.y, sh.y);
+                y.z = __fmaf_rn(y.z, sc.z, sh.z); y.w = __fmaf_rn(y.w, sc.w, sh.w);
+              }
+              if (a.residual) {
+                y.x = __fadd_rn(y.x, rs[tt].x); y.y = __fadd_rn(y.y, rs[tt].y);
+                y.z = __fadd_rn(y.z, rs[tt].z); y.w = __fadd_rn(y.w, rs[tt].w);
+              }
+              if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+              *reinterpret_cast<float4*>(a.out + row * a.cout + ch0) = y;
             }
-            if (a.residual) {
-              const float4 rs = *reinterpret_cast<const float4*>(a.residual + row * a.cout + ch0);
-              y.x = __fadd_rn(y.x, rs.x); y.y = __fadd_rn(y.y, rs.y); y.z = __fadd_rn(y.z, rs.z); y.w = __fadd_rn(y.w, rs.w);
-            }
-            if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-            *reinterpret_cast<float4*>(a.out + row * a.cout + ch0) = y;
           }
         }
       }
@@ -342,7 +374,7 @@ extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t
   const dim3 grid((unsigned)gx, (unsigned)nslice, (unsigned)ksplit);
 #define FSF_SCS(T_)                                                                                                     \
   do {                                                                                                                 \
-    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16;                                                              \
+    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 1024;                                                       \
     static bool attr_set = false;                                                                                      \
     if (!attr_set) {                                                                                                   \
       FSF_HIP_TRY(hipFuncSetAttribute((const void*)spconv_fwd_split_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
