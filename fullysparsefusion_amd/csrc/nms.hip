@@ -151,6 +151,141 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(NmsArgs a) {
   if (bits) atomicOr((unsigned long long*)&a.rowsum[i * a.sum_words + (col_blk >> 6)], 1ull << (col_blk & 63));
 }
 
+// ---- pair bits through a BEV cell grid (n >= NMS_BIN_MIN boxes) ---------------------------------------------------
+// Two boxes can only overlap when their circumscribed circles touch, i.e. when their centres are at most r_i + r_j
+// apart.  Boxes with r <= NMS_CELL / 2 are binned by centre into NMS_CELL-sized cells: an overlapping pair of them lies in
+// the same or in adjacent cells, so each box tests only the boxes of its 3 x 3 cell neighbourhood instead of all n
+// (10.6 k boxes over a 100 m scene: 60 x fewer pair tests than the all-pairs mask kernel).  Larger (or non-finite) boxes
+// go on a short list and are tested against everything.  The bits are a symmetric relation written with atomicOr, so the
+// unordered cell lists do not make the result depend on the run; iou_bev is always called (lower index, higher index)
+// as in the all-pairs kernel: the masks are bit-identical.
+constexpr int NMS_BIN_MIN = 1024;
+constexpr int NMS_GRID = 256;          // cells per axis; coordinates beyond +-NMS_GRID/2 cells are clamped to the border cells
+constexpr float NMS_CELL = 8.0f;       // metres: half of it bounds the radius of a binned box (cars, most trucks)
+
+struct NmsBins {
+  int32_t* cell_cnt;    // [G*G]
+  int32_t* cell_start;  // [G*G + 1]
+  int32_t* box_cell;    // [n]  cell of a small box, -1 = on the big list
+  int32_t* box_slot;    // [n]  position inside its cell
+  int32_t* cell_list;   // [n]  box ids grouped by cell
+  int32_t* big_list;    // [n]
+  int32_t* nbig;        // [1]
+};
+
+__device__ __forceinline__ int nms_cell_coord(float v) {
+  int c = (int)floorf(v * (1.0f / NMS_CELL)) + NMS_GRID / 2;
+  return c < 0 ? 0 : (c >= NMS_GRID ? NMS_GRID - 1 : c);
+}
+
+__global__ void __launch_bounds__(256) nms_bin_count_kernel(NmsArgs a, NmsBins b) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+    const float* bx = a.boxes + i * 5;
+    const float hx = 0.5f * (bx[2] - bx[0]), hy = 0.5f * (bx[3] - bx[1]);
+    const float cx = 0.5f * (bx[0] + bx[2]), cy = 0.5f * (bx[1] + bx[3]);
+    const float r = sqrtf(hx * hx + hy * hy) * 1.0001f;
+    const bool small = r <= 0.5f * NMS_CELL && fabsf(cx) < 1e6f && fabsf(cy) < 1e6f;  // (false for NaN / inf as well)
+    if (small) {
+      const int cell = nms_cell_coord(cy) * NMS_GRID + nms_cell_coord(cx);
+      b.box_cell[i] = cell;
+      b.box_slot[i] = atomicAdd(&b.cell_cnt[cell], 1);
+    } else {
+      b.box_cell[i] = -1;
+      b.big_list[atomicAdd(b.nbig, 1)] = (int32_t)i;
+    }
+  }
+}
+
+// exclusive scan of the NMS_GRID^2 cell counts by one workgroup of 1024 threads (64 cells each)
+__global__ void __launch_bounds__(1024) nms_bin_scan_kernel(NmsBins b) {
+  __shared__ int32_t part[1024];
+  constexpr int PER = NMS_GRID * NMS_GRID / 1024;
+  const int t = threadIdx.x;
+  int32_t s = 0;
+  for (int e = 0; e < PER; ++e) s += b.cell_cnt[t * PER + e];
+  part[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int32_t v = t >= off ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int32_t run = part[t] - s;
+  for (int e = 0; e < PER; ++e) {
+    b.cell_start[t * PER + e] = run;
+    run += b.cell_cnt[t * PER + e];
+  }
+  if (t == 1023) b.cell_start[NMS_GRID * NMS_GRID] = run;
+}
+
+__global__ void __launch_bounds__(256) nms_bin_fill_kernel(NmsArgs a, NmsBins b) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * 256) {
+    const int cell = b.box_cell[i];
+    if (cell >= 0) b.cell_list[b.cell_start[cell] + b.box_slot[i]] = (int32_t)i;
+  }
+}
+
+__device__ __forceinline__ void nms_set_pair(const NmsArgs& a, int64_t lo, int64_t hi) {
+  atomicOr((unsigned long long*)&a.mask[lo * a.words + (hi >> 6)], 1ull << (hi & 63));
+  atomicOr((unsigned long long*)&a.rowsum[lo * a.sum_words + (hi >> 12)], 1ull << ((hi >> 6) & 63));
+}
+
+// one wave per small box: the later boxes of its 3 x 3 cell neighbourhood
+__global__ void __launch_bounds__(256) nms_bin_pairs_kernel(NmsArgs a, NmsBins b) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= a.n) return;
+  const int cell = b.box_cell[i];
+  if (cell < 0) return;
+  float mine[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) mine[t] = a.boxes[i * 5 + t];
+  const float mhx = 0.5f * (mine[2] - mine[0]), mhy = 0.5f * (mine[3] - mine[1]);
+  const float mcx = 0.5f * (mine[0] + mine[2]), mcy = 0.5f * (mine[1] + mine[3]);
+  const float mrad = sqrtf(mhx * mhx + mhy * mhy);
+  const int cy = cell / NMS_GRID, cx = cell - cy * NMS_GRID;
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int y = cy + dy;
+    if (y < 0 || y >= NMS_GRID) continue;
+    const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx < NMS_GRID - 1 ? cx + 1 : NMS_GRID - 1;
+    const int s = b.cell_start[y * NMS_GRID + x0], e = b.cell_start[y * NMS_GRID + x1 + 1];  // the row's cells are contiguous
+    for (int p = s + lane; p < e; p += 64) {
+      const int64_t j = b.cell_list[p];
+      if (j <= i) continue;
+      float other[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) other[t] = a.boxes[j * 5 + t];
+      if (a.rotated) {
+        const float ohx = 0.5f * (other[2] - other[0]), ohy = 0.5f * (other[3] - other[1]);
+        const float dx = 0.5f * (other[0] + other[2]) - mcx, dyc = 0.5f * (other[1] + other[3]) - mcy;
+        const float rr = (sqrtf(ohx * ohx + ohy * ohy) + mrad) * 1.0001f;
+        if (dx * dx + dyc * dyc > rr * rr) continue;
+      }
+      if (iou_bev(mine, other, a.rotated) > a.thresh) nms_set_pair(a, i, j);
+    }
+  }
+}
+
+// one workgroup per big box: every other box (a pair of two big boxes is taken by the one with the lower index)
+__global__ void __launch_bounds__(256) nms_big_pairs_kernel(NmsArgs a, NmsBins b) {
+  const int nbig = *b.nbig;
+  for (int t = blockIdx.x; t < nbig; t += gridDim.x) {
+    const int64_t bi = b.big_list[t];
+    float big[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) big[q] = a.boxes[bi * 5 + q];
+    for (int64_t j = threadIdx.x; j < a.n; j += 256) {
+      if (j == bi || (b.box_cell[j] < 0 && j < bi)) continue;
+      float other[5];
+#pragma unroll
+      for (int q = 0; q < 5; ++q) other[q] = a.boxes[j * 5 + q];
+      const bool first = bi < j;
+      if (iou_bev(first ? big : other, first ? other : big, a.rotated) > a.thresh) nms_set_pair(a, first ? bi : j, first ? j : bi);
+    }
+  }
+}
+
 // One workgroup: greedy scan in score order, one 64-box word at a time.  Inside a word the dependency chain (a kept box
 // removes later boxes of the same word) is resolved by wave 0 on the diagonal mask words held one per lane; the rows
 // of the kept boxes are then OR-ed into the `removed` bits of the later words — only the non-zero words, found through
@@ -280,10 +415,45 @@ __global__ void __launch_bounds__(256) nms_build_kernel(NmsBuildArgs a) {
 
 using namespace fsf;
 
+static int64_t nms_bins_bytes(int64_t n) {
+  if (n < NMS_BIN_MIN) return 0;
+  return fsf_align_up((int64_t)(2 * NMS_GRID * NMS_GRID + 1) * 4, 256) + 4 * fsf_align_up(n * 4, 256) + 256;
+}
+
+// pair bits of all boxes into a.mask / a.rowsum (rowsum must be zero on entry)
+static int nms_launch_mask(const NmsArgs& a, FsfArena& arena, hipStream_t stream) {
+  if (a.n < NMS_BIN_MIN) {
+    // words below the diagonal are never written by the mask kernel and never read by the scan / build (w starts at i / 64)
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)a.words, (unsigned)a.words), dim3(64), 0, stream, a);
+    return FSF_OK;
+  }
+  NmsBins b{};
+  int32_t* cells = arena.take<int32_t>(2 * NMS_GRID * NMS_GRID + 1);
+  b.cell_cnt = cells;
+  b.cell_start = cells + NMS_GRID * NMS_GRID;
+  b.box_cell = arena.take<int32_t>(a.n);
+  b.box_slot = arena.take<int32_t>(a.n);
+  b.cell_list = arena.take<int32_t>(a.n);
+  b.big_list = arena.take<int32_t>(a.n);
+  b.nbig = arena.take<int32_t>(1);
+  if (!arena.ok()) return FSF_ERR_WORKSPACE;
+  FSF_HIP_TRY(hipMemsetAsync(a.mask, 0, (size_t)a.n * a.words * 8, stream));
+  FSF_HIP_TRY(hipMemsetAsync(b.cell_cnt, 0, sizeof(int32_t) * NMS_GRID * NMS_GRID, stream));
+  FSF_HIP_TRY(hipMemsetAsync(b.nbig, 0, sizeof(int32_t), stream));
+  const unsigned g = (unsigned)fsf_stream_grid(a.n, 256);
+  hipLaunchKernelGGL(nms_bin_count_kernel, dim3(g), dim3(256), 0, stream, a, b);
+  hipLaunchKernelGGL(nms_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, b);
+  hipLaunchKernelGGL(nms_bin_fill_kernel, dim3(g), dim3(256), 0, stream, a, b);
+  hipLaunchKernelGGL(nms_bin_pairs_kernel, dim3((unsigned)((a.n + 3) / 4)), dim3(256), 0, stream, a, b);
+  hipLaunchKernelGGL(nms_big_pairs_kernel, dim3((unsigned)(a.n < 1024 ? a.n : 1024)), dim3(256), 0, stream, a, b);
+  return FSF_OK;
+}
+
 extern "C" int64_t fsf_nms_bev_workspace_bytes(int64_t n) {
   const int64_t words = (n + 63) / 64, sum_words = (words + 63) / 64;
   const int64_t n1 = n > 0 ? n : 1;
-  return fsf_align_up(n1 * (words > 0 ? words : 1) * 8, 256) + fsf_align_up(n1 * (sum_words > 0 ? sum_words : 1) * 8, 256) + 512;
+  return fsf_align_up(n1 * (words > 0 ? words : 1) * 8, 256) + fsf_align_up(n1 * (sum_words > 0 ? sum_words : 1) * 8, 256) + 512 +
+         nms_bins_bytes(n);
 }
 
 extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t rotated, int64_t* keep,
@@ -306,8 +476,8 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
   } else {
     NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, ndev, nullptr, 0, 0, 0};
     FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)n * sum_words * 8, stream));
-    // words below the diagonal are never written by the mask kernel and never read by the scan (w starts at i / 64)
-    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, stream, a);
+    const int rc = nms_launch_mask(a, arena, stream);
+    if (rc != FSF_OK) return rc;
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), (size_t)words * 8, stream, a);
     FSF_LAUNCH_CHECK();
   }
@@ -322,7 +492,7 @@ extern "C" int64_t fsf_nms_bev_multiclass_workspace_bytes(int64_t n, int32_t num
   const int64_t words = (n + 63) / 64, sum_words = (words + 63) / 64;
   const int64_t n1 = n > 0 ? n : 1, w1 = words > 0 ? words : 1, s1 = sum_words > 0 ? sum_words : 1;
   const int64_t c1 = num_classes > 0 ? num_classes : 1;
-  return (1 + c1) * (fsf_align_up(n1 * w1 * 8, 256) + fsf_align_up(n1 * s1 * 8, 256)) + 512;
+  return (1 + c1) * (fsf_align_up(n1 * w1 * 8, 256) + fsf_align_up(n1 * s1 * 8, 256)) + 512 + nms_bins_bytes(n);
 }
 
 extern "C" int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank,
@@ -348,7 +518,8 @@ extern "C" int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num
   FSF_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)num_classes * n * words * 8, stream));
   FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)num_classes * n * sum_words * 8, stream));
   NmsArgs a0{boxes, n, thresh, (int)rotated, mask0, rowsum0, (int)words, (int)sum_words, nullptr, nullptr, nullptr, 0, 0, 0};
-  hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)words, (unsigned)words), dim3(64), 0, stream, a0);
+  const int rc = nms_launch_mask(a0, arena, stream);
+  if (rc != FSF_OK) return rc;
   NmsBuildArgs b{mask0, rowsum0, rank, mask, rowsum, n, (int)words, (int)sum_words};
   hipLaunchKernelGGL(nms_build_kernel, dim3((unsigned)fsf_stream_grid(n * sum_words, 256), (unsigned)num_classes), dim3(256), 0,
                      stream, b);

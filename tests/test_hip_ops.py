@@ -996,3 +996,41 @@ def test_column_stats_and_batch_norm_edge_cases(ops, device):
     m, v = ops.column_mean_var(x1)
     assert torch.equal(m, x1[0]) and not v.any()
     assert torch.equal(ops.column_sum(x1), x1[0])
+
+
+@pytest.mark.parametrize("n", [1024, 4000, 12000])
+def test_nms_bev_binned_pairs_equal_all_pairs(ops, device, n):
+    """n >= 1024 builds the pair bits through the BEV cell grid.  Axis-aligned IoU is a handful of fp32 operations that
+    torch reproduces bit for bit, so the greedy result from torch's all-pairs matrix must be matched exactly — with
+    clustered boxes, boxes too large for a cell (the brute-force list), centres far outside the grid (clamped border
+    cells), exact duplicates and NaN boxes."""
+    rng = np.random.default_rng(n)
+    nclu = n // 8
+    ctr = rng.uniform(-50, 50, (nclu, 2))[rng.integers(0, nclu, n)] + rng.normal(0, 0.8, (n, 2))
+    wl = np.stack([rng.uniform(0.5, 2.5, n), rng.uniform(0.5, 5.5, n)], 1)
+    big = rng.choice(n, n // 50, replace=False)
+    wl[big] *= rng.uniform(3, 15, (big.size, 1))                    # r up to ~45 m: the big list
+    far = rng.choice(n, n // 40, replace=False)
+    ctr[far] += rng.choice([-1, 1], (far.size, 2)) * rng.uniform(900, 3000, (far.size, 2))  # clamped border cells
+    dup = rng.choice(n, n // 60, replace=False)
+    ctr[dup], wl[dup] = ctr[(dup + 1) % n], wl[(dup + 1) % n]
+    boxes = np.concatenate([ctr - wl / 2, ctr + wl / 2, np.zeros((n, 1))], 1).astype(np.float32)
+    boxes[rng.choice(n, 5, replace=False)] = np.nan
+    b = torch.from_numpy(boxes).to(device)
+    thresh = 0.3
+    keep = ops.nms_bev(b, thresh, False).cpu().numpy()
+    # all-pairs reference in torch fp32, the kernel's own formula (rect_overlap_normal / iou_bev)
+    # (fmaxf / fminf return the non-NaN operand: torch.fmax / fmin, not maximum / minimum)
+    zero, tiny = b.new_zeros(()), b.new_full((), 1e-8)
+    l = torch.fmax(b[:, None, 0], b[None, :, 0]); r = torch.fmin(b[:, None, 2], b[None, :, 2])
+    t = torch.fmax(b[:, None, 1], b[None, :, 1]); d = torch.fmin(b[:, None, 3], b[None, :, 3])
+    ov = torch.fmax(r - l, zero) * torch.fmax(d - t, zero)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    hit = (ov / torch.fmax(area[:, None] + area[None, :] - ov, tiny) > thresh).cpu().numpy()
+    alive, want = np.ones(n, bool), []
+    for i in range(n):
+        if alive[i]:
+            want.append(i)
+            alive[i + 1:] &= ~hit[i, i + 1:]
+    np.testing.assert_array_equal(keep, np.asarray(want))
+    assert np.array_equal(keep, ops.nms_bev(b, thresh, False).cpu().numpy())
