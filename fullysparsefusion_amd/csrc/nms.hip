@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(64) nms_mask_kernel(NmsArgs a) {
 // unordered cell lists do not make the result depend on the run; iou_bev is always called (lower index, higher index)
 // as in the all-pairs kernel: the masks are bit-identical.
 constexpr int NMS_BIN_MIN = 1024;
-constexpr int NMS_GRID = 256;          // cells per axis; coordinates beyond +-NMS_GRID/2 cells are clamped to the border cells
+constexpr int NMS_GRID = 128;          // cells per axis (+-512 m); coordinates beyond are clamped to the border cells
 constexpr float NMS_CELL = 8.0f;       // metres: half of it bounds the radius of a binned box (cars, most trucks)
 
 struct NmsBins {
@@ -201,8 +201,14 @@ __global__ void __launch_bounds__(1024) nms_bin_scan_kernel(NmsBins b) {
   __shared__ int32_t part[1024];
   constexpr int PER = NMS_GRID * NMS_GRID / 1024;
   const int t = threadIdx.x;
+  int32_t c[PER];
   int32_t s = 0;
-  for (int e = 0; e < PER; ++e) s += b.cell_cnt[t * PER + e];
+#pragma unroll
+  for (int e = 0; e < PER; e += 4) {
+    const int4 v = *reinterpret_cast<const int4*>(b.cell_cnt + t * PER + e);
+    c[e] = v.x; c[e + 1] = v.y; c[e + 2] = v.z; c[e + 3] = v.w;
+    s += v.x + v.y + v.z + v.w;
+  }
   part[t] = s;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -212,9 +218,10 @@ __global__ void __launch_bounds__(1024) nms_bin_scan_kernel(NmsBins b) {
     __syncthreads();
   }
   int32_t run = part[t] - s;
+#pragma unroll
   for (int e = 0; e < PER; ++e) {
     b.cell_start[t * PER + e] = run;
-    run += b.cell_cnt[t * PER + e];
+    run += c[e];
   }
   if (t == 1023) b.cell_start[NMS_GRID * NMS_GRID] = run;
 }
@@ -283,6 +290,31 @@ __global__ void __launch_bounds__(256) nms_big_pairs_kernel(NmsArgs a, NmsBins b
       const bool first = bi < j;
       if (iou_bev(first ? big : other, first ? other : big, a.rotated) > a.thresh) nms_set_pair(a, first ? bi : j, first ? j : bi);
     }
+  }
+}
+
+// OR the mask words named by the set bits of `sbits` (summary word q of row `row`) into the removed bitset, four loads in
+// flight at a time (one at a time, every word was a dependent L2 round trip of the scan's critical path)
+__device__ __forceinline__ void nms_or_row_words(const uint64_t* __restrict__ row, int q, uint64_t sbits, uint64_t* removed) {
+  while (sbits) {
+    int w2[4];
+    uint64_t v[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (sbits) {
+        w2[u] = q * 64 + __builtin_ctzll(sbits);
+        sbits &= sbits - 1;
+        cnt = u + 1;
+      } else {
+        w2[u] = w2[0];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = row[w2[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (u < cnt) atomicOr((unsigned long long*)&removed[w2[u]], (unsigned long long)v[u]);
   }
 }
 
@@ -360,10 +392,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
       if (uq >= q0 && uq < a.sum_words && ((kept >> ub) & 1ull)) {
         uint64_t sbits = sum_cur;
         if (uq == q0) sbits &= ~((2ull << (w & 63)) - 1ull);  // words <= w are already settled
-        for (; sbits; sbits &= sbits - 1) {
-          const int w2 = uq * 64 + __builtin_ctzll(sbits);
-          atomicOr((unsigned long long*)&removed[w2], (unsigned long long)a.mask[(i0 + ub) * row_words + w2]);
-        }
+        nms_or_row_words(a.mask + (i0 + ub) * row_words, uq, sbits, removed);
       }
     } else {
       for (int u = threadIdx.x; u < 64 * (a.sum_words - q0); u += 256) {
@@ -372,10 +401,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
         const int64_t i = i0 + b;
         uint64_t sbits = a.rowsum[i * row_sum + q];
         if (q == q0) sbits &= ~((2ull << (w & 63)) - 1ull);
-        for (; sbits; sbits &= sbits - 1) {
-          const int w2 = q * 64 + __builtin_ctzll(sbits);
-          atomicOr((unsigned long long*)&removed[w2], (unsigned long long)a.mask[i * row_words + w2]);
-        }
+        nms_or_row_words(a.mask + i * row_words, q, sbits, removed);
       }
     }
     __syncthreads();
