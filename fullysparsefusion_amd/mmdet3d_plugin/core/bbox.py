@@ -179,7 +179,15 @@ def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_th
 
 def bbox3d2result(bboxes, scores, labels, attrs=None):
     """mmdet3d.core.bbox3d2result: results on the host, the form the dataset evaluators take."""
-    result = dict(boxes_3d=bboxes.to("cpu"), scores_3d=scores.cpu(), labels_3d=labels.cpu())
+    t = getattr(bboxes, "tensor", None)
+    if t is not None and t.is_cuda and t.dtype == torch.float32 and scores.dtype == torch.float32 and labels.numel() == len(t):
+        # one device -> host transfer instead of three (class indices are exact in fp32)
+        packed = torch.cat([t, scores[:, None], labels[:, None].to(torch.float32)], dim=1).cpu()
+        c = t.size(1)
+        host_boxes = bboxes.to("cpu") if len(t) == 0 else type(bboxes)(packed[:, :c].contiguous(), box_dim=c, with_yaw=getattr(bboxes, "with_yaw", True))
+        result = dict(boxes_3d=host_boxes, scores_3d=packed[:, c].contiguous(), labels_3d=packed[:, c + 1].to(labels.dtype))
+    else:
+        result = dict(boxes_3d=bboxes.to("cpu"), scores_3d=scores.cpu(), labels_3d=labels.cpu())
     if attrs is not None:
         result["attrs_3d"] = attrs.cpu()
     return result

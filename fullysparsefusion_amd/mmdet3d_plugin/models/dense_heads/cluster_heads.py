@@ -205,11 +205,15 @@ class SparseClusterHeadV2(SparseClusterHead):
                                                                   cfg["max_num"], cfg)
         out_bboxes, out_scores = self._strip_debug_columns(out_bboxes, out_scores)
         out_bboxes = box_type(out_bboxes, out_bboxes.size(1))
-        new_labels = torch.zeros_like(out_labels) - 1  # task-local label -> global class index
-        if len(out_labels) > 0:
-            for i, name in enumerate(self.tasks[task_id]["class_names"]):
-                new_labels[out_labels == i] = self.class_names.index(name)
-            assert (new_labels >= 0).all()
+        # task-local label -> global class index: one table gather (the reference loops over the class names with a
+        # masked assignment each — a hidden device sync per class — and asserts on the host that every label was mapped;
+        # with a table every label is mapped by construction)
+        luts = self.__dict__.setdefault("_label_luts", {})
+        lut = luts.get((task_id, out_labels.device))
+        if lut is None:
+            lut = out_labels.new_tensor([self.class_names.index(name) for name in self.tasks[task_id]["class_names"]])
+            luts[(task_id, out_labels.device)] = lut
+        new_labels = lut[out_labels] if len(out_labels) > 0 else torch.zeros_like(out_labels) - 1
         return out_bboxes, out_scores, new_labels
 
     def _append_debug_columns(self, bboxes, preds_2d):

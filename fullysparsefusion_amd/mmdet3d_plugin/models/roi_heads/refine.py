@@ -106,16 +106,22 @@ class FullySparseBboxHead(nn.Module):
         return self.align_roi_feature_and_rois(final_cluster_feats, out_coors, len(rois)), nonempty_roi_mask
 
     def get_nonempty_roi_mask(self, out_coors, num_rois):
-        out_coors = out_coors[out_coors >= 0]
-        mask = torch.zeros(num_rois, dtype=torch.bool, device=out_coors.device)
-        mask[out_coors] = True
-        return mask
+        # (the -1 group of an empty pooling result goes to a spare slot instead of being filtered out with a boolean index:
+        # no device -> host round trip for the survivor count)
+        mask = torch.zeros(num_rois + 1, dtype=torch.bool, device=out_coors.device)
+        mask[torch.where(out_coors >= 0, out_coors, out_coors.new_full((), num_rois))] = True
+        return mask[:num_rois]
 
     def align_roi_feature_and_rois(self, features, out_coors, num_rois):
         """Group features come out in ascending RoI index with a possible leading -1 group (the fake row of an empty
         pooling result); scatter them to one row per RoI."""
-        new_feature = features.new_zeros((num_rois, features.size(1)))
         coors_mask = out_coors >= 0
+        if not (torch.is_grad_enabled() and features.requires_grad):
+            # inference: rows of the -1 group land in a spare row that is cut off (same result, no host syncs)
+            new_feature = features.new_zeros((num_rois + 1, features.size(1)))
+            new_feature.index_copy_(0, torch.where(coors_mask, out_coors, out_coors.new_full((), num_rois)), features)
+            return new_feature[:num_rois]
+        new_feature = features.new_zeros((num_rois, features.size(1)))
         if not coors_mask.any():
             new_feature[:len(features), :] = features * 0  # pseudo gradient, as upstream
             return new_feature

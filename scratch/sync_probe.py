@@ -27,6 +27,13 @@ def gi(self, idx):
     if isb(idx) or (isinstance(idx, tuple) and any(isb(i) for i in idx)): cnt[('bool-index', site())] += 1
     return orig_gi(self, idx)
 torch.Tensor.__getitem__ = gi
+orig_si = torch.Tensor.__setitem__
+def si(self, idx, val):
+    def isb(i): return torch.is_tensor(i) and i.dtype == torch.bool
+    if self.is_cuda and (isb(idx) or (isinstance(idx, tuple) and any(isb(i) for i in idx))): cnt[('bool-setitem', site())] += 1
+    elif self.is_cuda and (torch.is_tensor(idx) or (isinstance(idx, tuple) and any(torch.is_tensor(i) for i in idx))): cnt[('index-setitem', site())] += 1
+    return orig_si(self, idx, val)
+torch.Tensor.__setitem__ = si
 for nm in ('__int__', '__bool__', '__float__', '__index__'):
     o = getattr(torch.Tensor, nm)
     def mk(o, nm):
