@@ -191,7 +191,9 @@ class FSF(SingleStageFSD):
                         cluster_center=None):
         pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights = self.extract_fg_pts(
             pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights)
-        if obj_id_tensor.numel() == 0 or obj_id_tensor.sum() == 0:
+        # (extract_fg_pts keeps exactly the points with a positive id sum, ids are >= 0: a non-empty result has a
+        # positive sum — the reference's `obj_id_tensor.sum() == 0` host test is implied by the row count)
+        if obj_id_tensor.numel() == 0:
             fake_num = 1  # fake an object when the frustum branch has no output (:407-414)
             points = points.new_zeros(fake_num, points.shape[-1])
             pts_feat = pts_feat.new_zeros(fake_num, pts_feat.shape[-1])
@@ -284,7 +286,7 @@ class FSF(SingleStageFSD):
     def segmentor_feat_inhance_test(self, seg_out_tuple, point_infos, mask_anno, mask_data, img_metas):
         (neck_out, pts_coors, points) = seg_out_tuple
         pts_lidar_feats, valid_pts_mask = neck_out[0], neck_out[1]
-        if not bool(valid_pts_mask.all()):
+        if not getattr(valid_pts_mask, "fsf_all_true", False) and not bool(valid_pts_mask.all()):
             # padded (dropped) voxels only exist on the SST path; keep the reference's compaction when they do
             points, pts_coors = points[valid_pts_mask], pts_coors[valid_pts_mask]
             point_infos_valid = None
@@ -315,6 +317,7 @@ class FSF(SingleStageFSD):
         return obj_feat, obj_centers, obj_coors, frustum_obj_result, preds_2d
 
     def fsd_forward(self, seg_out_dict, img_metas, run_head=True):
+        self._batch_size_hint = len(img_metas) if img_metas is not None else None
         dict_to_sample = dict(
             seg_points=seg_out_dict["seg_points"],
             seg_logits=seg_out_dict["seg_logits"].detach(),

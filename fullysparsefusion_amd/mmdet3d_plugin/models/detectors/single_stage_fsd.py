@@ -202,7 +202,8 @@ class SingleStageFSD(nn.Module):
         cfg = self.test_cfg
         ca = self.cluster_assigner  # (upstream pairs group i with class_names[i] to index its per-group tables, :912-916)
         batch_idx = d["batch_idx"]
-        bsz = int(batch_idx.max().item()) + 1
+        # (one sample per forward — the reference's test setting — is known on the host: no device round trip for it)
+        bsz = 1 if getattr(self, "_batch_size_hint", None) == 1 else int(batch_idx.max().item()) + 1
         seg_logits = d["seg_logits"]
         nc = self.num_classes
         dev = seg_logits.device

@@ -29,6 +29,7 @@ class Voxel2PointScatterNeck(nn.Module):
                 assert (out[pts_mask][:, -3:].abs() < vs / 2 + 1e-3).all(), \
                     "Holds in training. However, in test, this is not always True because of lack of point range clip"
             if not self.training and bool(pts_mask.all()):  # no padded voxel row (the usual case): nothing to compact
+                pts_mask.fsf_all_true = True  # (the detector asks the same question: spare it the second round trip)
                 return out, pts_mask
             return out[pts_mask], pts_mask
         dtype, device = voxel_feats.dtype, voxel_feats.device
