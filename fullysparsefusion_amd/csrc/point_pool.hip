@@ -36,7 +36,20 @@ struct PoolArgs {
   int64_t* out_pts;
   int64_t* out_roi;
   float* out_feat;
+  // The count pass runs in chunks of RoI groups (1, 2, 4, ... groups of 256 RoIs): the output keeps only the first
+  // max_all rows in (roi, point) order, so once the chunks before this one have reached that many in-box points the rest
+  // of the RoIs cannot contribute a row — their workgroups return at once and their totals stay 0 (thousands of queries
+  // against max_all = 50 000: the cap falls in the first group and 41 of the 42 groups are never counted).
+  int group0;             // first RoI group of this launch
+  int chunk;              // index of this chunk
+  uint32_t* chunk_total;  // [32] in-box points (capped per RoI) of every chunk so far; chunk i adds into [i]
 };
+
+__device__ __forceinline__ bool pool_cap_reached(const PoolArgs& a) {
+  uint64_t before = 0;
+  for (int i = 0; i < a.chunk; ++i) before += a.chunk_total[i];
+  return before >= (uint64_t)a.max_all;
+}
 
 struct PoolBox {
   float cx, cy, cz, hw, hl, hh, lhw, lhl, lhh, cosa, sina, r2;
@@ -86,13 +99,15 @@ __global__ void __launch_bounds__(256) pool_pass_kernel(PoolArgs a) {
   __shared__ float sred[4][4];
   __shared__ int swave[4];
   __shared__ int s_ns;
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = ((int64_t)blockIdx.x + a.group0) * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (FILL) {
     // rows past the global cap are never written: when the whole RoI tile starts beyond it there is nothing to do
     // (with max_all_pts = 50000 and thousands of queries that is nearly every tile)
-    const int64_t r_first = (int64_t)blockIdx.x * 256;
+    const int64_t r_first = ((int64_t)blockIdx.x + a.group0) * 256;
     if ((int64_t)a.roi_off[r_first] >= a.max_all) return;
+  } else if (pool_cap_reached(a)) {
+    return;
   }
   // This workgroup's 256 RoIs.  Queries arrive cluster by cluster in voxel order, so consecutive RoIs are close in
   // space: the bounding box of their (enlarged) circles is small, and only the tile's points inside it are kept —
@@ -187,16 +202,24 @@ __global__ void __launch_bounds__(256) pool_pass_kernel(PoolArgs a) {
 
 // per RoI: counts per point tile -> exclusive prefix over tiles (in place), capped total
 __global__ void __launch_bounds__(256) pool_prefix_kernel(PoolArgs a, int pt_tiles) {
-  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (r >= a.n_rois) return;
-  uint32_t run = 0;
-  for (int t = 0; t < pt_tiles; ++t) {
-    uint32_t* c = a.cnt + (int64_t)t * a.n_rois + r;
-    const uint32_t v = *c;
-    *c = run;
-    run += v;
+  const int64_t r = ((int64_t)blockIdx.x + a.group0) * 256 + threadIdx.x;
+  if (pool_cap_reached(a)) return;  // (roi_total stays 0: the RoI's rows would lie past max_all)
+  uint32_t tot = 0;
+  if (r < a.n_rois) {
+    uint32_t run = 0;
+    for (int t = 0; t < pt_tiles; ++t) {
+      uint32_t* c = a.cnt + (int64_t)t * a.n_rois + r;
+      const uint32_t v = *c;
+      *c = run;
+      run += v;
+    }
+    tot = min(run, (uint32_t)a.max_inbox);
+    a.roi_total[r] = tot;
   }
-  a.roi_total[r] = min(run, (uint32_t)a.max_inbox);
+  // this chunk's total for the chunks after it (a sum of integers: the order of the atomics does not matter)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&a.chunk_total[a.chunk], tot);
 }
 
 struct PoolScanIn {
@@ -220,7 +243,7 @@ using namespace fsf;
 extern "C" int64_t fsf_dynamic_point_pool_workspace_bytes(int64_t n_pts, int64_t n_rois) {
   const int64_t pt_tiles = n_pts > 0 ? (n_pts + PP_TILE - 1) / PP_TILE : 1;
   const int64_t r = n_rois > 0 ? n_rois : 1;
-  return fsf_align_up(pt_tiles * r * 4, 256) + 2 * fsf_align_up(r * 4, 256) + fsf_align_up(scan_num_tiles(r) * 4, 256) + 512;
+  return fsf_align_up(pt_tiles * r * 4, 256) + 2 * fsf_align_up(r * 4, 256) + fsf_align_up(scan_num_tiles(r) * 4, 256) + 768;
 }
 
 extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t roi_stride, int32_t box_col,
@@ -245,6 +268,7 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
   uint32_t* tile_sums = arena.take<uint32_t>(scan_num_tiles(r1));
   uint32_t* total = arena.take<uint32_t>(1);
   int64_t* count_tmp = arena.take<int64_t>(1);
+  uint32_t* chunk_total = arena.take<uint32_t>(32);
   if (!arena.ok()) return FSF_ERR_WORKSPACE;
   int64_t* cdev = count_dev ? count_dev : count_tmp;
   if (n_rois == 0 || n_pts == 0) {
@@ -252,10 +276,21 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
   } else {
     PoolArgs a{rois, pts, pts_batch, n_rois, n_pts, (int)roi_stride, (int)box_col, (int)batch_col, (int)pts_stride,
                extra_wlh[0], extra_wlh[1], extra_wlh[2], (int)max_inbox_point, max_all_pts, cnt, roi_total, roi_off,
-               out_pts_idx, out_roi_idx, out_pts_feats};
-    const dim3 grid((unsigned)fsf_cdiv(n_rois, 256), (unsigned)pt_tiles);
-    hipLaunchKernelGGL((pool_pass_kernel<false>), grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(pool_prefix_kernel, dim3((unsigned)fsf_cdiv(n_rois, 256)), dim3(256), 0, stream, a, pt_tiles);
+               out_pts_idx, out_roi_idx, out_pts_feats, 0, 0, chunk_total};
+    if (!arena.ok()) return FSF_ERR_WORKSPACE;
+    FSF_HIP_TRY(hipMemsetAsync(roi_total, 0, sizeof(uint32_t) * n_rois, stream));
+    FSF_HIP_TRY(hipMemsetAsync(chunk_total, 0, sizeof(uint32_t) * 32, stream));
+    const int groups = fsf_cdiv(n_rois, 256);
+    for (int g0 = 0, len = 1, chunk = 0; g0 < groups; g0 += len, len = chunk < 30 ? len * 2 : groups, ++chunk) {
+      const int ng = g0 + len <= groups ? len : groups - g0;
+      a.group0 = g0;
+      a.chunk = chunk;
+      hipLaunchKernelGGL((pool_pass_kernel<false>), dim3((unsigned)ng, (unsigned)pt_tiles), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(pool_prefix_kernel, dim3((unsigned)ng), dim3(256), 0, stream, a, pt_tiles);
+    }
+    a.group0 = 0;
+    a.chunk = 0;
+    const dim3 grid((unsigned)groups, (unsigned)pt_tiles);
     int rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums, total, nullptr, stream);
     if (rc != FSF_OK) return rc;
     hipLaunchKernelGGL((pool_pass_kernel<true>), grid, dim3(256), 0, stream, a);

@@ -602,7 +602,9 @@ def random_rois(rng, r, spread=40.0):
 
 
 @pytest.mark.parametrize("r,p,max_inbox,max_all", [(37, 20000, 512, 50000), (300, 60000, 16, 50000), (300, 60000, 512, 700),
-                                                   (1, 5000, 512, 50000), (700, 3000, 512, 50000)])
+                                                   (1, 5000, 512, 50000), (700, 3000, 512, 50000),
+                                                   # several chunks of RoI groups: cap inside an early chunk / never reached
+                                                   (2000, 20000, 32, 3000), (2000, 20000, 512, 10 ** 6), (1100, 8000, 4, 900)])
 def test_dynamic_point_pool_vs_oracle(ops, device, r, p, max_inbox, max_all):
     rng = np.random.default_rng(r * 31 + p)
     rois = random_rois(rng, r)
