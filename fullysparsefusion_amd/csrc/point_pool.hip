@@ -38,8 +38,9 @@ struct PoolArgs {
   float* out_feat;
   // The count pass runs in chunks of RoI groups (1, 2, 4, ... groups of 256 RoIs): the output keeps only the first
   // max_all rows in (roi, point) order, so once the chunks before this one have reached that many in-box points the rest
-  // of the RoIs cannot contribute a row — their workgroups return at once and their totals stay 0 (thousands of queries
-  // against max_all = 50 000: the cap falls in the first group and 41 of the 42 groups are never counted).
+  // of the RoIs cannot contribute a row — their workgroups return at once and their totals stay 0.  (Bench frame: 10.6 k
+  // small RoIs with 5-10 points each reach max_all = 50 000 only in the fifth chunk, so the count pass goes 649 -> 579 us;
+  // well-populated RoIs reach it in the first groups.)
   int group0;             // first RoI group of this launch
   int chunk;              // index of this chunk
   uint32_t* chunk_total;  // [32] in-box points (capped per RoI) of every chunk so far; chunk i adds into [i]
