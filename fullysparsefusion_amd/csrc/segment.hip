@@ -10,7 +10,10 @@
 
 namespace fsf {
 
-constexpr int SEG_CHUNK = 32;
+#ifndef SEG_CHUNK_ROWS
+#define SEG_CHUNK_ROWS 32
+#endif
+constexpr int SEG_CHUNK = SEG_CHUNK_ROWS;
 constexpr int SEG_BLOCK = 256;
 constexpr int SEG_MIN_TEAM = 4;
 constexpr int SEG_LONG_SPAN = 16;  // chunks; longer segments are folded by a whole workgroup
