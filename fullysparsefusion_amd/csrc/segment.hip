@@ -248,9 +248,17 @@ template <int VEC, int MODE>
 __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_long_kernel(SegArgs a) {
   __shared__ float s_val[SEG_BLOCK / SEG_MIN_TEAM][SEG_MIN_TEAM * 4];
   __shared__ int32_t s_arg[SEG_BLOCK / SEG_MIN_TEAM][SEG_MIN_TEAM * 4];
-  const int nteams = SEG_BLOCK / a.team;
-  const int team_id = threadIdx.x / a.team;
-  const int tl = threadIdx.x % a.team;
+  // gridDim.y workgroups share a long segment by channel slice: the one workgroup per segment was the whole kernel's
+  // critical path (a 1e5-point group = 3 000 partials of 128 channels); with narrower slices more lane teams stride the
+  // partials.  (max / argmax do not depend on the fold order; sums keep a fixed one for a given launch shape.)
+  const int csl = (int)((a.c + (int)gridDim.y * VEC - 1) / ((int)gridDim.y * VEC)) * VEC;  // channels per slice
+  const int c_lo = (int)blockIdx.y * csl, c_hi = c_lo + csl < a.c ? c_lo + csl : a.c;
+  if (c_lo >= a.c) return;
+  int team = SEG_MIN_TEAM;
+  while (team * VEC < csl && team < 64) team <<= 1;
+  const int nteams = SEG_BLOCK / team;
+  const int team_id = threadIdx.x / team;
+  const int tl = threadIdx.x % team;
   const float ident = (MODE == MODE_MAX) ? -INFINITY : 0.0f;
   for (int64_t s = blockIdx.x; s < a.m; s += gridDim.x) {
     const int S = a.seg_offsets[s];
@@ -258,9 +266,9 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_long_kernel(SegArgs a) {
     if (E == S) continue;
     const int cs = S / SEG_CHUNK, ce = (E - 1) / SEG_CHUNK;
     if (ce - cs <= SEG_LONG_SPAN) continue;
-    for (int ch0 = 0; ch0 < a.c; ch0 += a.team * VEC) {  // workgroup-uniform trip count (barriers inside)
+    for (int ch0 = c_lo; ch0 < c_hi; ch0 += team * VEC) {  // workgroup-uniform trip count (barriers inside)
       const int ch = ch0 + tl * VEC;
-      const bool act = ch < a.c;
+      const bool act = ch < c_hi;
       Vec<VEC> acc;
       int32_t arg[VEC];
 #pragma unroll
@@ -306,17 +314,17 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_long_kernel(SegArgs a) {
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < VEC; ++q) {
-        (&s_val[0][0])[(team_id * a.team + tl) * VEC + q] = acc.v[q];
-        (&s_arg[0][0])[(team_id * a.team + tl) * VEC + q] = arg[q];
+        (&s_val[0][0])[(team_id * team + tl) * VEC + q] = acc.v[q];
+        (&s_arg[0][0])[(team_id * team + tl) * VEC + q] = arg[q];
       }
       __syncthreads();
       if (team_id == 0 && act) {
         for (int t = 1; t < nteams; ++t) {
 #pragma unroll
           for (int q = 0; q < VEC; ++q) {
-            const float v = (&s_val[0][0])[(t * a.team + tl) * VEC + q];
+            const float v = (&s_val[0][0])[(t * team + tl) * VEC + q];
             if constexpr (MODE == MODE_MAX) {
-              const int32_t va = (&s_arg[0][0])[(t * a.team + tl) * VEC + q];
+              const int32_t va = (&s_arg[0][0])[(t * team + tl) * VEC + q];
               if (v > acc.v[q] || (v == acc.v[q] && va < arg[q])) {
                 acc.v[q] = v;
                 arg[q] = va;
@@ -473,23 +481,26 @@ static int seg_launch(const SegArgs& a, int mode, hipStream_t stream) {
   if (g2 > 4096) g2 = 4096;
   // a segment can only be "long" when the input has more rows than SEG_LONG_SPAN chunks
   const bool has_long = a.n > (int64_t)SEG_LONG_SPAN * SEG_CHUNK;
-  int64_t g3 = a.m < 1024 ? a.m : 1024;
-  if (g3 < 1) g3 = 1;
+  int64_t g3x = a.m < 1024 ? a.m : 1024;
+  if (g3x < 1) g3x = 1;
+  const int groups = (a.c + VEC - 1) / VEC;
+  // (float4 rows only: with one float per lane a 16-lane team moves 64 B per partial and the narrow-row kernel got slower)
+  const dim3 g3((unsigned)g3x, (unsigned)(VEC == 4 ? (groups >= 32 ? 4 : (groups >= 16 ? 2 : 1)) : 1));
   switch (mode) {
     case MODE_SUM:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_SUM>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
       hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_SUM>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
-      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_SUM>), dim3((unsigned)g3), dim3(SEG_BLOCK), 0, stream, a);
+      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_SUM>), g3, dim3(SEG_BLOCK), 0, stream, a);
       break;
     case MODE_MEAN:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_MEAN>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
       hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MEAN>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
-      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_MEAN>), dim3((unsigned)g3), dim3(SEG_BLOCK), 0, stream, a);
+      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_MEAN>), g3, dim3(SEG_BLOCK), 0, stream, a);
       break;
     default:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_MAX>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
       hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MAX>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
-      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_MAX>), dim3((unsigned)g3), dim3(SEG_BLOCK), 0, stream, a);
+      if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_MAX>), g3, dim3(SEG_BLOCK), 0, stream, a);
       break;
   }
   FSF_LAUNCH_CHECK();
