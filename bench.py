@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--sweeps", type=int, default=10, help="10 = BASELINE config 3 input; 1 = config 2 (parity case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-describe", action="store_true",
+                    help="skip the extra untimed stages-1-3 pass that counts the queries (profiling runs: the per-frame "
+                         "kernel table then holds exactly warmup + steps forwards)")
     ap.add_argument("--train", action="store_true",
                     help="time the training step instead (BASELINE configs 3/4): fwd + bwd of a dummy scalar loss over the "
                          "hot-path outputs + bucketed gradient all-reduce over RCCL + AdamW")
@@ -94,6 +97,8 @@ def step(model, inp, hot_path_only=False):
 
 def describe_output(model, inp, out, args):
     """Query / box counts of the timed workload (one extra untimed pass when the timed output does not carry them)."""
+    if args.no_describe:
+        return {}
     if not (args.train or args.hot_path_only):
         hot = step(model, inp, hot_path_only=True)
         extra = {"boxes_out": int(sum(len(r["boxes_3d"]) for r in out))}
