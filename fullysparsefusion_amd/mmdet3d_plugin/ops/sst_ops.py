@@ -126,9 +126,15 @@ def _grouped_linear_norm_act(linear, norm, act, gc):
     cache = linear.__dict__.get("_fsf_planes_grouped")
     if cache is None or cache[0] != key:
         w = linear.weight.detach()
-        cache = (key, hip_ops.linear_prepare_weight(w[:, :c_left].contiguous()), w[:, c_left:].contiguous())
+        w_right = w[:, c_left:].contiguous()
+        cache = (key, hip_ops.linear_prepare_weight(w[:, :c_left].contiguous()), w_right, hip_ops.linear_prepare_weight(w_right))
         linear.__dict__["_fsf_planes_grouped"] = cache
-    table = F.linear(g, cache[2])  # [groups, C_out]: the right half, once per group
+    # [groups, C_out]: the right half, once per group (a few hundred to 1e4 rows: on K22 as well — the library spends
+    # 60 us of host time per call choosing a GEMM for a 244-row input)
+    if g.size(0) >= _SMALL_N_MIN and g.size(1) <= 256 and hip_ops.linear_norm_act_supported(g, linear.out_features):
+        table = hip_ops.linear_norm_act(g, cache[3], linear.out_features)
+    else:
+        table = F.linear(g, cache[2])
     return hip_ops.linear_norm_act(p, cache[1], linear.out_features, bias=linear.bias, norm=kind, gamma=gamma, beta=beta,
                                    eps=eps, act=act_code, row_add=table, row_add_index=inv.contiguous())
 
