@@ -403,7 +403,8 @@ def point_linear(linear, x):
     if (needs_grad and linear.weight.requires_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
             and x.size(0) >= 16384):
         return _PointLinearFn.apply(x, linear.weight, linear.bias)
-    if (not needs_grad and x.dim() == 2 and x.size(0) >= 1024 and linear.out_features % 4 == 0
+    if (not needs_grad and x.dim() == 2 and linear.out_features % 4 == 0
+            and (x.size(0) >= 1024 or (x.size(0) >= _SMALL_N_MIN and linear.in_features <= 256))
             and hip_ops.linear_norm_act_supported(x, linear.out_features)):
         return hip_ops.linear_norm_act(x, _prepared_planes(linear), linear.out_features, bias=linear.bias)
     return F.linear(x, linear.weight, linear.bias)
