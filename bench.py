@@ -2,26 +2,37 @@
 """bench.py — frames/sec of the FSF forward on synthetic nuScenes-shape 10-sweep frames (BASELINE.json metric), one
 process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py                                   # 1 GPU, 20 steps, 5 warm-up
+    python bench.py --gpus N --steps K --warmup W     # N > 1 without a launcher: re-executes itself under
+                                                      # torch.distributed.run (one process per GPU, RCCL), like
+                                                      # tools/dist_train.sh:8-9 of the reference
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one full forward of the detector (FSF.simple_test: voxelize -> DynamicScatterVFE -> SimpleSparseUNet ->
 neck -> projection + mask gather + image fusion + seg head -> camera-query grouping + SIR -> LiDAR-query pre-voxelize,
 sampling, device CCL, SIR -> heads -> query combination -> RoI point pooling + refine SIR -> box decode + rotated BEV
-NMS -> results on the host) over one frame whose inputs are already resident in HBM.  `--hot-path-only` stops after the
-three query-generation stages; `--train` times fwd + bwd of a dummy loss + gradient all-reduce + AdamW instead.
-Frames are independent, so for inference N ranks are N replicas with no data-path collective (weak scaling); the only
-collectives are the barrier and the max-over-ranks of the timed region.  Rank 0 prints ONE JSON line with `roofline`
-(dominant kernel: the fused sparse-conv implicit GEMM on the fp32 MFMA, timed with HIP events in an instrumented pass
-over the same frames) and `cpu_baseline` (the CPU oracle restatement timed on this box's host cores on a bounded
-sample).
+NMS -> results on the host) over ONE frame whose inputs are already resident in HBM; the timed loop rotates over
+`--frames` (default 4) DISTINCT synthetic frames so that no step re-runs the frame whose rulebook-shaped access pattern the
+caches saw last.  `--hot-path-only` stops after the three query-generation stages; `--train` times fwd + bwd of a dummy
+loss + gradient all-reduce + AdamW instead.  Frames are independent, so for inference N ranks are N replicas with no
+data-path collective (weak scaling); the only collectives are the barrier and the max-over-ranks of the timed region.
+
+Rank 0 prints ONE JSON line.  Besides the contract's fields it carries
+  * `roofline`: the dominant kernel (sparse-conv forward) timed with HIP events in an instrumented pass over the same
+    frames, fp32-equivalent flops against the ceiling of the matrix pipe the kernel actually issues on, plus the contract's
+    fp32-pipe peak, per-kernel split, `hbm` = GB/s and fraction of 8 TB/s of the scatter / gather / segmented-reduce /
+    projection / fused-linear kernels (algorithmic bytes of SURVEY.md section 8d / HIP-event time), and `frame_roofline_ms`;
+  * `cpu_baseline`: the CPU oracle (kind "port") on ONE FULL 10-sweep frame through stages 1-3, per-stage times.
 """
 import argparse
 import copy
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,7 +42,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+# /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3      # v_mfma_f32_* dense
+MFMA_16BIT_PEAK_TFLOPS = 2500.0   # v_mfma_f32_16x16x32_{bf16,f16} dense
+HBM_PEAK_GBS = 8000.0
 
 
 def parse():
@@ -40,6 +54,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--sweeps", type=int, default=10, help="10 = BASELINE config 3 input; 1 = config 2 (parity case)")
+    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic frames the timed loop rotates over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-describe", action="store_true",
@@ -71,6 +86,7 @@ def build_model(device, dataset="nuscenes"):
 
 
 def make_inputs(sweeps, seed, device, frames=1, dataset="nuscenes"):
+    """One batch (`frames` frames, normally 1) resident on `device`; returns (first host frame, device batch)."""
     from fullysparsefusion_amd import synthetic
 
     if dataset == "av2":
@@ -134,112 +150,276 @@ class TrainStep:
         return out
 
 
-def spconv_roofline(model, inp, steps, hot_path_only=False):
-    """Roofline entry for the dominant op, the sparse convolution (34 layers per frame): every launch of the two forward
-    kernels is timed with HIP events in an instrumented pass (the stream is torch's current stream, which is the one the
-    C ABI launches on), algorithmic flops = 2 * pairs * Cin * Cout, algorithmic bytes = pairs * (Cin + Cout) * 4 +
-    kvol * Cin * Cout * 4 + 8 * pairs.  `achieved` / `frac` are fp32-equivalent flops against the
-    fp32 matrix-pipe peak for the op as a whole; `kernels` splits them by kernel: the fp32-pipe kernel
-    (v_mfma_f32_16x16x4_f32) and the row-stationary kernel that forms the same fp32-accurate product from an exact 3-way
-    bf16 split on v_mfma_f32_16x16x32_bf16 (six MFMAs per fp32-equivalent one: its own hardware ceiling is 2.5 PF / 6)."""
+# ------------------------------------------------------------------------------------------------ instrumented pass
+class _Probe:
+    """Wraps entry points of `hip_ops` with HIP events (recorded on the calling thread's current stream — the stream the
+    C ABI launches on; the camera branch runs on its own stream / host thread) and books algorithmic work per call."""
+
+    def __init__(self):
+        self.records = []
+        self.lock = threading.Lock()
+        self.saved = {}
+
+    def wrap(self, mod, name, account):
+        orig = getattr(mod, name)
+        self.saved[(mod, name)] = orig
+
+        def wrapped(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(*a, **k)
+            e1.record()
+            with self.lock:
+                self.records.append((name, e0, e1, account, a, k, out))
+            return out
+
+        setattr(mod, name, wrapped)
+
+    def restore(self):
+        for (mod, name), orig in self.saved.items():
+            setattr(mod, name, orig)
+
+    def table(self):
+        """{name: dict(calls, ms, bytes, flops)} — evaluated after a device sync."""
+        agg = {}
+        for name, e0, e1, account, a, k, out in self.records:
+            key, byts, flops = account(a, k, out)
+            d = agg.setdefault(key, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += byts
+            d["flops"] += flops
+        return agg
+
+
+def _n(t):
+    return 0 if t is None else int(t.size(0))
+
+
+def _acc_spconv(kind):
+    def account(a, k, out):
+        if kind == "fp32":
+            feat, weight_t, nbr = a[0], a[1], a[2]
+            cin, cout = weight_t.size(2), weight_t.size(1)
+        else:  # split kernels: (feat, planes, kvol, cout, nbr)
+            feat, cout, nbr = a[0], int(a[3]), a[4]
+            cin = feat.size(1)
+        pairs = float((nbr >= 0).sum())
+        return ("spconv_" + kind, pairs * (cin + cout) * 4 + nbr.size(1) * cin * cout * 4 + 8 * pairs, 2.0 * pairs * cin * cout)
+    return account
+
+
+def _acc_seg_reduce(a, k, out):
+    feat, plan = a[0], a[1]
+    n, c = feat.shape
+    return "seg_reduce", 4.0 * c * n + 8.0 * n + 4.0 * c * plan.m, 0.0       # 4C B/row + 8 B/row + 4C B/segment
+
+
+def _acc_gather_rows(a, k, out):
+    src, idx = a[0], a[1]
+    return "gather_rows", idx.numel() * (8.0 + 8.0 * src.size(1)), 0.0         # 8 B index + 4C read + 4C written per row
+
+
+def _acc_voxel2point(a, k, out):
+    points, voxel_feats = a[0], a[2]
+    n, c = points.size(0), voxel_feats.size(1)
+    return "voxel2point", n * (12.0 + 8.0 + 32.0 + 4.0 * c + 4.0 * (c + 3) + 1.0), 0.0
+
+
+def _acc_project(a, k, out):
+    xyz, mask = a[0], a[2]
+    n, (ncam, ncls) = xyz.size(0), mask.shape[:2]
+    # 12 B/pt of xyz + one mask element per (cam, class) + the int64 id tensor (SURVEY 8d: 552 B/pt at 6 x 10, u8 planes)
+    return "project_gather", n * (12.0 + ncam * ncls * (mask.element_size() + 8.0)), 0.0
+
+
+def _acc_cam_select(a, k, out):
+    obj = a[0]
+    n, ncam, ncls = obj.shape
+    return "cam_select_score", n * (8.0 * ncam * ncls + 4.0 * ncls + (8.0 * ncls if k.get("return_ids") else 0.0)), 0.0
+
+
+def _acc_sir_input(a, k, out):
+    points, feats, f_cluster = a[0], a[1], a[2]
+    extra = k.get("extra", a[7] if len(a) > 7 else None)
+    n = points.size(0)
+    c = points.size(1) + feats.size(1) + (extra.size(1) if extra is not None else 0)
+    return "sir_input", n * 4.0 * (c + f_cluster.size(1)) + n * 4.0 * c, 0.0   # 4(P+Cf+Ce+R) read + 4C written per row
+
+
+def _acc_linear(a, k, out):
+    x, c = a[0], int(a[2])
+    n, kk = x.shape
+    grouped = k.get("row_add") is not None
+    return ("linear_norm_act", n * 4.0 * (kk + c) + (n * (8.0 + 4.0 * c) if grouped else 0.0), 2.0 * n * kk * c)
+
+
+def instrumented_pass(model, pool, steps, hot_path_only):
     from fullysparsefusion_amd import hip_ops
 
-    records = []
-    originals = {"fp32": hip_ops.spconv_forward, "split": hip_ops.spconv_forward_split}
-
-    def wrap_fp32(feat, weight_t, nbr, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = originals["fp32"](feat, weight_t, nbr, **kw)
-        e1.record()
-        records.append(("fp32", e0, e1, nbr, weight_t.size(2), weight_t.size(1)))
-        return out
-
-    def wrap_split(feat, planes, kvol, cout, nbr, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        out = originals["split"](feat, planes, kvol, cout, nbr, **kw)
-        e1.record()
-        records.append(("split", e0, e1, nbr, feat.size(1), cout))
-        return out
-
-    hip_ops.spconv_forward, hip_ops.spconv_forward_split = wrap_fp32, wrap_split
+    p = _Probe()
+    p.wrap(hip_ops, "spconv_forward", _acc_spconv("fp32"))
+    p.wrap(hip_ops, "spconv_forward_split", _acc_spconv("split"))
+    for name in ("spconv_forward_planes",):  # (kernels added later register here)
+        if hasattr(hip_ops, name):
+            p.wrap(hip_ops, name, _acc_spconv("planes"))
+    p.wrap(hip_ops, "segment_reduce", _acc_seg_reduce)
+    p.wrap(hip_ops, "gather_rows", _acc_gather_rows)
+    p.wrap(hip_ops, "voxel2point", _acc_voxel2point)
+    p.wrap(hip_ops, "project_gather_mask", _acc_project)
+    p.wrap(hip_ops, "cam_select_score", _acc_cam_select)
+    p.wrap(hip_ops, "sir_input", _acc_sir_input)
+    p.wrap(hip_ops, "linear_norm_act", _acc_linear)
     try:
-        for _ in range(steps):
-            step(model, inp, hot_path_only)
+        for i in range(steps):
+            step(model, pool[i % len(pool)], hot_path_only)
         torch.cuda.synchronize()
     finally:
-        hip_ops.spconv_forward, hip_ops.spconv_forward_split = originals["fp32"], originals["split"]
-    per = {"fp32": [0.0, 0.0, 0], "split": [0.0, 0.0, 0]}  # flops, ms, launches
-    byts = 0.0
-    for kind, e0, e1, nbr, cin, cout in records:
-        pairs = float((nbr >= 0).sum())
-        per[kind][0] += 2.0 * pairs * cin * cout
-        per[kind][1] += e0.elapsed_time(e1)
-        per[kind][2] += 1
-        byts += pairs * (cin + cout) * 4 + nbr.size(1) * cin * cout * 4 + 8 * pairs
-    flops = per["fp32"][0] + per["split"][0]
-    ms = per["fp32"][1] + per["split"][1]
-    launches = len(records)
-    achieved = flops / (ms * 1e-3) / 1e12
-    traffic, source = None, None
-    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        p.restore()
+    return p.table()
+
+
+SPCONV_KERNELS = {
+    "spconv_fp32": ("fsf::spconv_fwd_dma_kernel (fp32 MFMA, compacting, output-stationary in LDS)", MFMA_F32_PEAK_TFLOPS,
+                    "v_mfma_f32_16x16x4_f32"),
+    "spconv_split": ("fsf::spconv_fwd_split_kernel (bf16 MFMA x6 = exact 3-way split, row-stationary in registers)",
+                     MFMA_16BIT_PEAK_TFLOPS / 6, "v_mfma_f32_16x16x32_bf16, 6 per fp32-equivalent product"),
+    "spconv_planes": ("fsf::spconv_fwd_planes_kernel (f16 MFMA x3 = 2-way scaled-f16 split, pair-dense, output tile in LDS)",
+                      MFMA_16BIT_PEAK_TFLOPS / 3, "v_mfma_f32_16x16x32_f16, 3 per fp32-equivalent product"),
+}
+
+
+def roofline_blocks(table, steps, ms_per_step, traffic):
+    """`roofline` (dominant kernel = the sparse-conv forward kernel with the most time), `hbm` and `frame_roofline_ms`."""
+    conv = {k: v for k, v in table.items() if k.startswith("spconv_")}
+    kernels = {}
+    for k, v in conv.items():
+        title, peak, pipe = SPCONV_KERNELS[k]
+        tf = v["flops"] / max(v["ms"], 1e-9) / 1e9
+        kernels[title] = dict(launches_per_step=v["calls"] // steps, ms_per_step=round(v["ms"] / steps, 3),
+                              tflops_fp32_equivalent=round(tf, 2), pipe=pipe, pipe_peak_tflops_fp32_equivalent=round(peak, 1),
+                              frac_of_pipe_peak=round(tf / peak, 4), frac_of_fp32_pipe_peak=round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                              algorithmic_gflop_per_step=round(v["flops"] / steps / 1e9, 1),
+                              algorithmic_mb_per_launch=round(v["bytes"] / max(v["calls"], 1) / 1e6, 1))
+    dom_key = max(conv, key=lambda k: conv[k]["ms"])
+    dom = conv[dom_key]
+    title, peak, pipe = SPCONV_KERNELS[dom_key]
+    achieved = dom["flops"] / max(dom["ms"], 1e-9) / 1e9
+    all_flops, all_ms = sum(v["flops"] for v in conv.values()), sum(v["ms"] for v in conv.values())
+    hbm = {}
+    hbm_floor_ms = 0.0
+    for k, v in sorted(table.items()):
+        if k.startswith("spconv_"):
+            continue
+        gbs = v["bytes"] / max(v["ms"], 1e-9) / 1e6
+        hbm[k] = dict(calls_per_step=v["calls"] // steps, ms_per_step=round(v["ms"] / steps, 3),
+                      algorithmic_mb_per_step=round(v["bytes"] / steps / 1e6, 1), gb_per_s=round(gbs, 1),
+                      frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
+        if k == "linear_norm_act":
+            hbm[k]["tflops_fp32_equivalent"] = round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)
+        hbm_floor_ms += v["bytes"] / steps / (HBM_PEAK_GBS * 1e6)
+    conv_floor_ms = sum(v["flops"] / steps / (SPCONV_KERNELS[k][1] * 1e9) for k, v in conv.items())
+    frame_floor = conv_floor_ms + hbm_floor_ms
+    roof = dict(
+        bound="mfma", kernel=title, achieved=round(achieved, 3), peak=round(peak, 1), unit="TFLOP/s",
+        frac=round(achieved / peak, 4),
+        peak_note=f"fp32-equivalent flops (2 * pairs * Cin * Cout) against the ceiling of the pipe the kernel issues on ({pipe}); "
+                  f"against the fp32 matrix-pipe peak of {MFMA_F32_PEAK_TFLOPS} TFLOP/s the same kernel is at "
+                  f"{round(achieved / MFMA_F32_PEAK_TFLOPS, 4)}",
+        frac_of_fp32_pipe_peak=round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+        launches_per_step=dom["calls"] // steps, avg_launch_us=round(dom["ms"] / max(dom["calls"], 1) * 1e3, 2),
+        ms_per_step_in_kernel=round(dom["ms"] / steps, 3),
+        sparse_conv_all_kernels=dict(ms_per_step=round(all_ms / steps, 3), launches_per_step=sum(v["calls"] for v in conv.values()) // steps,
+                                     tflops_fp32_equivalent=round(all_flops / max(all_ms, 1e-9) / 1e9, 2),
+                                     algorithmic_gflop_per_step=round(all_flops / steps / 1e9, 1)),
+        kernels=kernels, traffic=traffic.get("value"), traffic_unit=traffic.get("unit"), traffic_source=traffic.get("source"),
+        hbm=hbm,
+        frame_roofline_ms=round(frame_floor, 3),
+        frame_roofline_note="sum over the instrumented kernels of (fp32-equivalent conv flops / the issuing pipe's ceiling) + "
+                            "(algorithmic bytes / 8 TB/s); kernels that are not instrumented (sorts, rulebooks, CCL, pooling, NMS, "
+                            "glue) add nothing, so this is a LOWER bound of the frame's roofline time",
+        frame_roofline_frac=round(frame_floor / ms_per_step, 4),
+        note="HIP-event timing on the launching stream in an instrumented pass over the same frames, right after the timed region")
+    return roof
+
+
+def committed_traffic():
+    """HBM bytes per sparse-conv launch from the committed PMC passes (profiles/*_pmc_traffic.json, newest round last)."""
+    prof = os.path.join(ROOT, "profiles")
+    out = {}
     for name in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
         if name.endswith("_pmc_traffic.json"):
             with open(os.path.join(prof, name)) as f:
                 t = json.load(f)
-            traffic, source = t.get("spconv_forward", {}).get("hbm_bytes_per_api_launch"), f"profiles/{name}"
-    kernels = {
-        "fsf::spconv_fwd_dma_kernel (fp32 MFMA, compacting, output-stationary in LDS)": dict(
-            launches_per_step=per["fp32"][2] // steps, ms_per_step=round(per["fp32"][1] / steps, 3),
-            tflops=round(per["fp32"][0] / max(per["fp32"][1], 1e-9) / 1e9, 2), peak_tflops=157.3),
-        "fsf::spconv_fwd_split_kernel (bf16 MFMA x6 = exact 3-way split, row-stationary in registers)": dict(
-            launches_per_step=per["split"][2] // steps, ms_per_step=round(per["split"][1] / steps, 3),
-            tflops_fp32_equivalent=round(per["split"][0] / max(per["split"][1], 1e-9) / 1e9, 2),
-            peak_tflops_fp32_equivalent=round(2500.0 / 6, 1)),
-    }
-    return dict(bound="mfma", kernel="sparse convolution forward (fsf::spconv_fwd_split_kernel + fsf::spconv_fwd_dma_kernel)",
-                achieved=round(achieved, 3), peak=157.3, unit="TFLOP/s", frac=round(achieved / 157.3, 4),
-                peak_note="fp32 matrix-pipe peak; the split kernel reaches fp32 accuracy on the bf16 pipe, see `kernels`",
-                kernels=kernels, traffic=traffic,
-                traffic_unit="HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)", traffic_source=source,
-                launches_per_step=launches // steps, avg_launch_us=round(ms / launches * 1e3, 2),
-                algorithmic_gflop_per_step=round(flops / steps / 1e9, 1), algorithmic_mb_per_step=round(byts / steps / 1e6, 1),
-                ms_per_step_in_kernel=round(ms / steps, 3),
-                note="HIP-event timing in an instrumented pass over the same frames, right after the timed region")
+            v = t.get("spconv_forward", {}).get("hbm_bytes_per_api_launch")
+            if v is not None:
+                out = dict(value=v, source=f"profiles/{name}",
+                           unit=t.get("unit", "HBM bytes per launch (FETCH_SIZE x correction + WRITE_SIZE, rocprofv3 --pmc, separate passes)"))
+    return out
 
 
-def cpu_baseline(model_cpu):
-    """The CPU oracle (a port of the reference path: torch.unique + scatter_reduce + spconv-v1 restatement) on a
-    bounded sample: ONE synthetic sweep (1/10 of a 10-sweep frame's points), stages 1-3."""
+# ---------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(model_cpu, sweeps):
+    """The CPU oracle (a port of the reference path: torch.unique + scatter_reduce + spconv-v1 restatement + scipy CCL;
+    torch_scatter / spconv / mmcv are not installable) on ONE FULL frame of the timed workload,
+    stages 1-3 (segmentor + fusion, camera queries, LiDAR queries), after an untimed warm-up pass on a 1-sweep frame."""
     from fullysparsefusion_amd import synthetic
     from oracle import modules as omod
 
-    f = synthetic.make_frame(num_sweeps=1, seed=0)
-    full_n = synthetic.make_points(10, 0).shape[0]
-    pts8 = torch.from_numpy(f["points"])
-    mask, anno, L = torch.from_numpy(f["mask_data"]), torch.from_numpy(f["mask_anno"]), torch.from_numpy(f["lidar2img"])
-    cores = torch.get_num_threads()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        s1 = omod.fsf_stage1(model_cpu, pts8, mask, anno, L)
-        omod.fsf_stage2(model_cpu, s1, anno, (900, 1600))
-        omod.fsf_stage3(model_cpu, s1)
-    dt = time.perf_counter() - t0
-    frac = pts8.shape[0] / full_n
-    return dict(value=round(frac / dt, 5), unit="frames/s", cores=cores, kind="port",
-                sample=f"1 of 10 sweeps ({pts8.shape[0]} of {full_n} points) through oracle stages 1-3 (segmentor + fusion, camera "
-                       f"queries, LiDAR queries; the refine stage and NMS are not in the CPU sample, so this over-states the "
-                       f"CPU rate of the full forward) in {dt:.1f} s; value = frame fraction / time")
+    def run(frame):
+        pts8 = torch.from_numpy(frame["points"])
+        mask, anno, L = torch.from_numpy(frame["mask_data"]), torch.from_numpy(frame["mask_anno"]), torch.from_numpy(frame["lidar2img"])
+        t = [time.perf_counter()]
+        with torch.no_grad():
+            s1 = omod.fsf_stage1(model_cpu, pts8, mask, anno, L)
+            t.append(time.perf_counter())
+            omod.fsf_stage2(model_cpu, s1, anno, (900, 1600))
+            t.append(time.perf_counter())
+            omod.fsf_stage3(model_cpu, s1)
+            t.append(time.perf_counter())
+        return pts8.shape[0], [t[i + 1] - t[i] for i in range(3)]
+
+    run(synthetic.make_frame(num_sweeps=1, seed=1))  # warm-up: thread pools, allocator, scipy imports
+    n, (t1, t2, t3) = run(synthetic.make_frame(num_sweeps=sweeps, seed=0))
+    total = t1 + t2 + t3
+    return dict(value=round(1.0 / total, 5), unit="frames/s", cores=torch.get_num_threads(), nproc=os.cpu_count(), kind="port",
+                stage_seconds=dict(segmentor_fusion_seg_head=round(t1, 2), camera_queries=round(t2, 2), lidar_queries=round(t3, 2)),
+                sample=f"ONE full {sweeps}-sweep frame ({n} points, the timed workload's frame 0) through oracle stages 1-3 in "
+                       f"{total:.1f} s after a 1-sweep warm-up pass; the refine stage and NMS are not in the CPU sample, so this "
+                       f"over-states the CPU rate of the full forward")
+
+
+# ------------------------------------------------------------------------------------------------------ launching
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: one process per GPU under torch.distributed.run (RCCL)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (or let bench.py launch them)")
+    if world > torch.cuda.device_count():
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -247,40 +427,47 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=device)  # RCCL; barrier + max-reduce of the timing only
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     model = build_model(device, args.dataset)
     model_cpu = (None if args.no_cpu_baseline or rank != 0 or world != 1 or args.train or args.dataset != "nuscenes"
                  else copy.deepcopy(model).cpu())
-    frame, inp = make_inputs(args.sweeps, seed=rank, device=device, frames=args.frames_per_gpu, dataset=args.dataset)
+    nframes = max(1, args.frames)
+    pool = [make_inputs(args.sweeps, seed=rank * 131 + j, device=device, frames=args.frames_per_gpu, dataset=args.dataset)[1]
+            for j in range(nframes)]
     if args.train:
         train_step = TrainStep(model)
-        run = lambda: train_step(inp)
+        run = lambda i: train_step(pool[i % nframes])  # noqa: E731
     else:
-        run = lambda: step(model, inp, args.hot_path_only)
+        run = lambda i: step(model, pool[i % nframes], args.hot_path_only)  # noqa: E731
 
-    for _ in range(args.warmup):
-        run()
+    for i in range(args.warmup):
+        run(i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = run()
+    for i in range(args.steps):
+        out = run(args.warmup + i)
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank = [args.frames_per_gpu * args.steps / local_elapsed]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        g = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([per_rank[0]], dtype=torch.float64, device=device))
+        per_rank = [float(x.item()) for x in g]
 
     result = None
+    last = pool[(args.warmup + args.steps - 1) % nframes]
     if rank == 0:
-        n_pts = int(inp["points"][0].shape[0])
+        n_pts = [int(p["points"][0].shape[0]) for p in pool]
         result = {
             "metric": (("frames/sec fwd+bwd+allreduce+AdamW nuScenes 10-sweep FSF (dummy loss)" if args.train
                         else "frames/sec fwd nuScenes 10-sweep FSF" + (" (query-generation stages only)" if args.hot_path_only else ""))
@@ -305,29 +492,33 @@ def main():
                     "refinement (RoI point pooling + SIR), box decode + rotated BEV NMS, results to host") +
                     (" (BASELINE config 3 input" if args.dataset == "nuscenes" else " (BASELINE config 5 shape") +
                     ", random-init weights of the reference architecture)"),
-                "points_per_frame": n_pts,
+                "points_per_frame": n_pts[0],
+                "distinct_frames_rotated": nframes,
+                "points_per_frame_all": n_pts,
                 "frames_per_gpu_per_step": args.frames_per_gpu,
                 "mask_data": "u8[1,6,10,900,1600]" if args.dataset == "nuscenes" else "i32[1,7,1,1550,2048]",
-                **describe_output(model, inp, out, args),
+                **describe_output(model, last, out, args),
                 "parallelism": (f"dp{world}: frame-level data parallel, bucketed gradient all-reduce over RCCL" if args.train
                                 else f"replicas x{world} (frames independent, no data-path collective)"),
+                "rccl_world_size": world,
+                "per_rank_frames_per_s": [round(v, 3) for v in per_rank],
             },
         }
     if rank == 0 and not args.no_roofline and not args.train:
-        result["roofline"] = spconv_roofline(model, inp, min(args.steps, 5), args.hot_path_only)
-        if args.dataset != "nuscenes":  # the committed PMC passes were taken on the nuScenes-shape workload
-            result["roofline"].update(traffic=None, traffic_source=None)
+        n = min(args.steps, 2 * nframes)
+        table = instrumented_pass(model, pool, n, args.hot_path_only)
+        traffic = committed_traffic() if args.dataset == "nuscenes" else {}
+        result["roofline"] = roofline_blocks(table, n, result["ms_per_step"], traffic)
         if not args.hot_path_only:  # where the frame time goes: the three query-generation stages vs the rest
-            n = min(args.steps, 5)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(n):
-                step(model, inp, hot_path_only=True)
+            for i in range(n):
+                step(model, pool[i % nframes], hot_path_only=True)
             torch.cuda.synchronize()
             result["stages"] = {"query_generation_ms": round((time.perf_counter() - t0) / n * 1e3, 3),
                                 "full_forward_ms": result["ms_per_step"]}
     if rank == 0 and model_cpu is not None:
-        result["cpu_baseline"] = cpu_baseline(model_cpu)
+        result["cpu_baseline"] = cpu_baseline(model_cpu, args.sweeps)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

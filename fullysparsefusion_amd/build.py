@@ -46,7 +46,7 @@ def _deps_mtime():
 
 
 def _compile_one(src, obj, verbose):
-    extra = os.environ.get("FSF_EXTRA_HIPCC_FLAGS", "").split()  # ablation builds (scratch/ablate.sh), never set in product runs
+    extra = os.environ.get("FSF_EXTRA_HIPCC_FLAGS", "").split()  # ablation builds (profiling ablations), never set in product runs
     cmd = [_hipcc(), *HIPCC_FLAGS, *extra, "-c", src, "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)

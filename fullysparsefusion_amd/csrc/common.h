@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/fsf_hip.h"
 
 #define FSF_WAVE 64
@@ -17,6 +19,20 @@
   do {                                                   \
     if (hipPeekAtLastError() != hipSuccess) return FSF_ERR_HIP; \
   } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: set it once per (kernel, device).
+// `done` is a per-call-site bit mask (bit = device ordinal; devices >= 64 set it on every launch).  Two host threads may
+// race to set the same bit: both set the same attribute value, which is harmless.
+static inline hipError_t fsf_set_max_dynamic_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+  if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
 
 static inline int64_t fsf_align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 static inline int fsf_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -404,12 +404,8 @@ extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k,
 #define FSF_LNA(T_)                                                                                                     \
   do {                                                                                                                 \
     constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4;                                                \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      FSF_HIP_TRY(hipFuncSetAttribute((const void*)linear_norm_act_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)smem));                                                                     \
-      attr_set = true;                                                                                                 \
-    }                                                                                                                  \
+    static std::atomic<uint64_t> attr_done{0};                                                                                      \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_>, (int)smem, attr_done));                                                                                                                  \
     hipLaunchKernelGGL((linear_norm_act_kernel<T_>), grid, dim3(LNA_NW * 64), smem, stream, a);                  \
   } while (0)
   const int T = lna_tiles(c);

@@ -327,12 +327,8 @@ extern "C" int fsf_sir_input(const float* points, int64_t points_stride, int32_t
   if (g > 512) g = 512;  // 2 workgroups per CU, each walks its share of the 16-row groups (the weight staging is per workgroup)
 #define FSF_SI2(NT3_, ACT_)                                                                                            \
   do {                                                                                                                 \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      FSF_HIP_TRY(hipFuncSetAttribute((const void*)sir_input_kernel<NT3_, ACT_>,                                       \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));                         \
-      attr_set = true;                                                                                                 \
-    }                                                                                                                  \
+    static std::atomic<uint64_t> attr_done{0};                                                                                      \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)sir_input_kernel<NT3_, ACT_>, (int)smem, attr_done));                                                                                                                  \
     hipLaunchKernelGGL((sir_input_kernel<NT3_, ACT_>), dim3((unsigned)g), dim3(256), smem, stream, a);                 \
   } while (0)
 #define FSF_SI(NT3_)                                                                                                   \

@@ -770,12 +770,9 @@ extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, 
   }
 #define FSF_SPCONV_LAUNCH(KERNEL, SMEM_T, NTHREADS)                                                                            \
   do {                                                                                                               \
-    static bool attr_set = false;                                                                                    \
+    static std::atomic<uint64_t> attr_done{0};                                                                                    \
     const size_t smem_bytes = SMEM_T::bytes();                                                                       \
-    if (!attr_set) {                                                                                                 \
-      FSF_HIP_TRY(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes)); \
-      attr_set = true;                                                                                               \
-    }                                                                                                                \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)KERNEL, (int)smem_bytes, attr_done));                                                                                                                \
     hipLaunchKernelGGL(KERNEL, grid, dim3(NTHREADS), smem_bytes, stream, a);                                         \
   } while (0)
   using S64_64 = SpconvSmem<64, 64>;

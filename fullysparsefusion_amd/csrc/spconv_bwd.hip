@@ -298,13 +298,9 @@ extern "C" int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32
   const dim3 grid((unsigned)nsplit, (unsigned)kvol, (unsigned)(fsf_cdiv(cin, ta) * fsf_cdiv(cout, tb)));
 #define FSF_BWD_LAUNCH(TA_, TB_)                                                                                         \
   do {                                                                                                                   \
-    static bool attr_set = false;                                                                                        \
+    static std::atomic<uint64_t> attr_done{0};                                                                                        \
     const size_t smem_bytes = BwdSmem<TA_, TB_>::bytes();                                                                \
-    if (!attr_set) {                                                                                                     \
-      FSF_HIP_TRY(hipFuncSetAttribute((const void*)spconv_bwd_weight_kernel<TA_, TB_>,                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes));                     \
-      attr_set = true;                                                                                                   \
-    }                                                                                                                    \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_bwd_weight_kernel<TA_, TB_>, (int)smem_bytes, attr_done));                                                                                                                    \
     hipLaunchKernelGGL((spconv_bwd_weight_kernel<TA_, TB_>), grid, dim3(256), smem_bytes, stream, a);                    \
   } while (0)
   if (cap > 0) {

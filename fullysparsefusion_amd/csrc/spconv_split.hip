@@ -375,12 +375,8 @@ extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t
 #define FSF_SCS(T_)                                                                                                     \
   do {                                                                                                                 \
     constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 1024;                                                       \
-    static bool attr_set = false;                                                                                      \
-    if (!attr_set) {                                                                                                   \
-      FSF_HIP_TRY(hipFuncSetAttribute((const void*)spconv_fwd_split_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)smem));                                                                     \
-      attr_set = true;                                                                                                 \
-    }                                                                                                                  \
+    static std::atomic<uint64_t> attr_done{0};                                                                                      \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_split_kernel<T_>, (int)smem, attr_done));                                                                                                                  \
     hipLaunchKernelGGL((spconv_fwd_split_kernel<T_>), grid, dim3(SCS_NW * 64), smem, stream, a);                       \
   } while (0)
   if (scs_tiles(cout) == 4) FSF_SCS(4);

@@ -12,8 +12,15 @@ launched by tools/dist_train.sh:8-9 with one process per GPU).  Differences that
     is the order gradients become ready;
   * the FSF graph is data dependent (a class group without points skips its layers on one rank only), so parameters
     that received no gradient are treated as zeros and their buckets are reduced in `finish()` — every rank always
-    issues the same collectives in the same order.
+    issues the same BUCKET collectives in the same order.  Where in the backward pass a bucket is launched still differs
+    between ranks on such a step (mid-backward on one, `finish()` on the other), and `naiveSyncBN1d`'s backward issues
+    its own all-reduces in between: RCCL pairs collectives by issue order PER COMMUNICATOR, so the buckets travel on
+    their own process group (`dist.new_group`), never on the one the SyncBN statistics use;
+  * gradient accumulation: `no_sync()` (as in DDP) keeps micro-batch gradients local; the first backward outside it
+    reduces the accumulated sum.  Only `zero_grad()` zeroes the buckets.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -40,8 +47,11 @@ class FrameDataParallel(torch.nn.Module):
     def __init__(self, module, bucket_mb=96, process_group=None):
         super().__init__()
         self.module = module
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if active else 1
+        # a communicator of their own for the gradient buckets (collective call: every rank constructs the wrapper)
+        self.group = process_group if process_group is not None or self.world == 1 else dist.new_group()
+        self._sync = True
         params = [p for p in module.parameters() if p.requires_grad]
         assert all(p.dtype == torch.float32 for p in params), "gradient buckets are fp32"
         cap = int(bucket_mb * (1 << 20)) // 4
@@ -66,8 +76,17 @@ class FrameDataParallel(torch.nn.Module):
         self._armed = False
 
     def forward(self, *args, **kwargs):
-        self._arm()
+        self._arm(zero=False)
         return self.module(*args, **kwargs)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation: backward passes inside this context add into the buckets without any collective."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
 
     def __getattr__(self, name):
         try:
@@ -76,10 +95,14 @@ class FrameDataParallel(torch.nn.Module):
             return getattr(self.module, name)
 
     # ------------------------------------------------------------------------------------------------
-    def _arm(self):
-        """Start of an iteration: zero the buckets, re-point grads at them, reset the ready counters."""
+    def _arm(self, zero=True):
+        """Start of a backward pass: re-point grads at the buckets, reset the ready counters; `zero` (zero_grad only)
+        also clears the accumulated gradients."""
         for b in self.buckets:
-            b.flat.zero_()
+            if b.work is not None:
+                raise RuntimeError("FrameDataParallel: the previous backward was not completed with finish()")
+            if zero:
+                b.flat.zero_()
             b.pending = len(b.params)
             b.work, b.launched = None, False
             for p, v in zip(b.params, b.views):
@@ -88,11 +111,11 @@ class FrameDataParallel(torch.nn.Module):
         self._armed = True
 
     def zero_grad(self, set_to_none=False):
-        self._arm()
+        self._arm(zero=True)
 
     def _launch(self, b):
         b.launched = True
-        if self.world > 1:
+        if self.world > 1 and self._sync:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
@@ -122,12 +145,13 @@ class FrameDataParallel(torch.nn.Module):
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
-            if self.world > 1:
+                b.work = None
+            if self.world > 1 and self._sync:
                 b.flat.div_(self.world)
         self._armed = False
 
     def backward(self, loss):
         if not self._armed:
-            self._arm()
+            self._arm(zero=False)
         loss.backward()
         self.finish()

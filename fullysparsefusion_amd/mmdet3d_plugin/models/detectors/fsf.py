@@ -108,9 +108,15 @@ class FSF(SingleStageFSD):
         return hip_ops.project_gather_mask(points, lidar2img, mask_data)
 
     def frustum_gather(self, batch_idx, points, mask_data, mask_anno, img_metas):
-        key = (batch_idx.data_ptr(), points.data_ptr(), mask_data.data_ptr(), points.size(0), points._version)
-        if self._gather_cache is not None and self._gather_cache[0] == key:
-            return self._gather_cache[1]
+        # the entry KEEPS its key tensors (so their storage cannot be recycled by the caching allocator for an equal-sized
+        # temporary of a later refine stage while the entry lives); a hit = same storage, shape and version
+        def same(a, b):
+            return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+                              and a._version == b._version and a.dtype == b.dtype)
+
+        c = self._gather_cache
+        if c is not None and same(c[0], batch_idx) and same(c[1], points) and same(c[2], mask_data):
+            return c[3]
         device = batch_idx.device
         bz, num_cams, num_classes = mask_data.shape[0:3]
         if bz == 1:
@@ -122,7 +128,7 @@ class FSF(SingleStageFSD):
                 bz_mask = batch_idx == bidx
                 lidar2img = torch.as_tensor(img_metas[bidx]["lidar2img"], dtype=torch.float32, device=device)
                 obj_id_tensor[bz_mask] = self.points_in_mask(points[bz_mask][:, :3].contiguous(), mask_data[bidx], lidar2img)
-        self._gather_cache = (key, obj_id_tensor)
+        self._gather_cache = (batch_idx, points, mask_data, obj_id_tensor)
         return obj_id_tensor
 
     # ----------------------------------------------------------------------------- frustum grouping

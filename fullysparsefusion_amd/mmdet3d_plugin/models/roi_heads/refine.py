@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .... import hip_ops
+from ...ops.dynamic_point_pool_op import dynamic_point_pool
 from ...ops.sst_ops import unique_with_plan
 from ...registry import HEADS, ROI_EXTRACTORS, build_voxel_encoder
 
@@ -28,14 +29,17 @@ class DynamicPointROIExtractor(nn.Module):
         (point indices [k], roi indices [k], dict(local_xyz [k,3], boundary_offset [k,6], is_in_margin [k]))."""
         assert len(pts_xyz) > 0 and len(batch_inds) > 0 and len(rois) > 0
         rois = rois.float()
-        single = rois.size(1) == 7
-        inds, roi_inds, info = hip_ops.dynamic_point_pool(
-            rois, pts_xyz.float(), self.extra_wlh, self.max_inbox_point, self.max_all_pts,
-            roi_batch_col=-1 if single else 0, box_col=0 if single else 1, pts_batch=None if single else batch_inds)
-        if inds.numel() == 0:  # upstream fakes one (-1, -1, zeros) row so that downstream shapes stay non-empty
-            inds = inds.new_full((1,), -1)
-            roi_inds = roi_inds.new_full((1,), -1)
-            info = info.new_zeros((1, 13))
+        if rois.size(1) == 7:  # one sample: the reference's op itself (ops/dynamic_point_pool_op.py), fake row included
+            inds, roi_inds, info = dynamic_point_pool(rois, pts_xyz.float(), self.extra_wlh, self.max_inbox_point,
+                                                      self.max_all_pts)
+        else:  # the per-sample loop of :44-73 as ONE launch: the batch index travels into the kernel
+            inds, roi_inds, info = hip_ops.dynamic_point_pool(
+                rois, pts_xyz.float(), self.extra_wlh, self.max_inbox_point, self.max_all_pts,
+                roi_batch_col=0, box_col=1, pts_batch=batch_inds)
+            if inds.numel() == 0:  # upstream fakes one (-1, -1, zeros) row so that downstream shapes stay non-empty
+                inds = inds.new_full((1,), -1)
+                roi_inds = roi_inds.new_full((1,), -1)
+                info = info.new_zeros((1, 13))
         if self.debug and inds[0] >= 0:
             roi_per_pts = rois[:, -7:][roi_inds]
             assert torch.isclose(pts_xyz[inds], info[:, :3]).all()

@@ -182,7 +182,7 @@ class SparseConvolution(SparseModule):
             self._wt_cache = (key, wt)
         return self._wt_cache[1]
 
-    # Which forward kernel (measured per layer on the 10-sweep frame, scratch/scs_layers.py): the row-stationary
+    # Which forward kernel (measured per layer on the 10-sweep frame, tools/profiling/scs_layers.py): the row-stationary
     # bf16-split kernel (K9b) wins on every submanifold layer (dense neighbourhoods: 1.15-1.7x on the fine levels,
     # 1.5-2x on the deep ones, where it splits the offset loop over more workgroups) and on the strided convolutions
     # into the deep levels (13+ pairs per output row); inverse convolutions and the strided ones into the fine levels

@@ -17,6 +17,33 @@ from . import scatter as oscatter
 from . import spconv as osp
 
 
+# ------------------------------------------------------------------------------- dense layers, restated
+def apply_module(m, x):
+    """Evaluates a dense sub-module from its PARAMETERS ONLY (the product's `forward` is never called): the product's
+    modules are weight containers here.  Structure restated from the reference's `build_mlp`
+    (projects/mmdet3d_plugin/ops/sst_ops.py:808-833): a Sequential of [Linear(bias) -> norm -> act (-> Dropout)] blocks,
+    the last entry a plain Linear(bias=True) when `is_head`; norm = LayerNorm / (naiveSync)BatchNorm1d in eval mode
+    (batch statistics under `unet_forward(train=True)`), act = GELU (erf) / ReLU."""
+    name = type(m).__mro__
+    if isinstance(m, torch.nn.Sequential):
+        for child in m._modules.values():
+            x = apply_module(child, x)
+        return x
+    if isinstance(m, torch.nn.Linear):
+        return F.linear(x, m.weight, m.bias)
+    if isinstance(m, torch.nn.LayerNorm):
+        return F.layer_norm(x, m.normalized_shape, m.weight, m.bias, m.eps)
+    if isinstance(m, torch.nn.BatchNorm1d):
+        return _bn_eval(m, x)
+    if isinstance(m, torch.nn.GELU):
+        return F.gelu(x)
+    if isinstance(m, torch.nn.ReLU):
+        return torch.relu(x)
+    if isinstance(m, (torch.nn.Dropout, torch.nn.Identity)):
+        return x
+    raise TypeError(f"oracle.apply_module: no restatement for {name[0].__name__}")
+
+
 # ------------------------------------------------------------------------------------- DynamicScatterVFE
 def vfe_forward(vfe, features, coors):
     """Published SST `DynamicScatterVFE.forward(features, coors, return_inv=True)`; called at
@@ -35,7 +62,7 @@ def vfe_forward(vfe, features, coors):
         ls.append(f_center)
     x = torch.cat(ls, dim=-1)
     for i, layer in enumerate(vfe.vfe_layers):
-        point_feats = layer.act(layer.norm(layer.linear(x)))
+        point_feats = apply_module(layer.act, apply_module(layer.norm, apply_module(layer.linear, x)))
         voxel_feats, _ = oscatter.segment_max(point_feats, unq_inv, m)
         if i != len(vfe.vfe_layers) - 1:
             x = torch.cat([point_feats, voxel_feats[unq_inv]], dim=1)
@@ -47,11 +74,11 @@ def sir_layer_forward(layer, features, coors, f_cluster, unq_inv, new_coors):
     """Published FSD `SIRLayer.forward` (built by projects/mmdet3d_plugin/models/backbones/sir.py:41-61)."""
     xyz_norm = torch.tensor(layer.xyz_normalizer, dtype=features.dtype)
     x = torch.cat([features[:, :3] / xyz_norm[None, :], features[:, 3:]], dim=1)
-    x = x * layer.rel_mlp(f_cluster / layer.rel_dist_scaler)
+    x = x * apply_module(layer.rel_mlp, f_cluster / layer.rel_dist_scaler)
     m = new_coors.size(0)
     outs = []
     for i, vfe in enumerate(layer.vfe_layers):
-        point_feats = vfe.act(vfe.norm(vfe.linear(x)))
+        point_feats = apply_module(vfe.act, apply_module(vfe.norm, apply_module(vfe.linear, x)))
         grp, _ = oscatter.segment_max(point_feats, unq_inv, m)
         outs.append(grp)
         if i != len(layer.vfe_layers) - 1:
@@ -191,11 +218,11 @@ def fsf_stage1(fsf, points8, mask_data, mask_anno, lidar2img, grad=False, dtype=
     assert bool(ex["mask"].all())
     obj_id, _ = oproj.points_in_mask(infos.numpy(), mask_data.numpy(), lidar2img.numpy())
     ids, score = oproj.cam_select_score(obj_id, mask_anno.numpy())
-    img_feat = fsf.segmentor_updated_mlp(torch.from_numpy(score).to(dtype))
+    img_feat = apply_module(fsf.segmentor_updated_mlp, torch.from_numpy(score).to(dtype))
     pts_feats = ex["neck"] + img_feat
     head = fsf.segmentor.segmentation_head
-    h = head.pre_seg_conv(pts_feats)
-    seg_logits, vote_preds = head.conv_seg(h), head.voting(h)
+    h = apply_module(head.pre_seg_conv, pts_feats)
+    seg_logits, vote_preds = apply_module(head.conv_seg, h), apply_module(head.voting, h)
     return dict(ex=ex, obj_id=torch.from_numpy(obj_id), seg_points=ex["points"], seg_logits=seg_logits,
                 seg_vote_preds=vote_preds, offsets=vote_preds * vote_preds.abs(), seg_feats=pts_feats,
                 batch_idx=ex["coors"][:, 0])
@@ -243,19 +270,37 @@ def fsf_stage2(fsf, s1, mask_anno, img_hw):
     bbox[:, 0::2] /= img_hw[1]
     bbox[:, 1::2] /= img_hw[0]
     enc = torch.cat([bbox, preds[:, 4:5], F.one_hot(preds[:, 5].long(), fsf.num_classes + 1).float()], -1)
-    img_feat = fsf.encode_2d_mlp(enc)
+    img_feat = apply_module(fsf.encode_2d_mlp, enc)
     return dict(obj_feat=torch.cat([cluster_feats, img_feat], -1), obj_coors=out_coors, obj_centers=center,
                 sir_coors=sir_coors, f_cluster=f_cluster, preds_2d=preds)
 
 
 def connected_components_xy(points, dist):
-    """find_connected_componets_single_batch (single_stage_fsd.py:69-82)."""
+    """find_connected_componets_single_batch (single_stage_fsd.py:69-82): the reference builds the dense n x n matrix of
+    fp32 distances `((p_i - p_j) ** 2).sum(2) ** 0.5 < dist` and hands it to scipy.  Beyond a few thousand centres that
+    matrix does not fit (8.4e4 centres on the 10-sweep frame), so the same adjacency is built sparsely: candidate pairs
+    from a k-d tree with a 1 % larger radius, then the reference's own fp32 expression decides each candidate.  scipy labels
+    components in order of their smallest node either way, so the labels are those of the dense call (checked against it in
+    tests/test_oracle_golden.py)."""
+    from scipy.sparse import coo_matrix
     from scipy.sparse.csgraph import connected_components
 
     p = points[:, :2]
-    d = p[:, None, :] - p[None, :, :]
-    d = (d ** 2).sum(2) ** 0.5
-    return torch.from_numpy(connected_components((d < dist).numpy(), directed=False)[1]).int()
+    n = p.shape[0]
+    if n <= 4096:
+        d = p[:, None, :] - p[None, :, :]
+        d = (d ** 2).sum(2) ** 0.5
+        return torch.from_numpy(connected_components((d < dist).numpy(), directed=False)[1]).int()
+    from scipy.spatial import cKDTree
+
+    pn = p.numpy().astype(np.float64)
+    pairs = cKDTree(pn).query_pairs(float(dist) * 1.01 + 1e-6, output_type="ndarray")
+    a, b = torch.from_numpy(pairs[:, 0]), torch.from_numpy(pairs[:, 1])
+    d = ((p[a] - p[b]) ** 2).sum(1) ** 0.5  # fp32, the reference's expression on the candidate pairs
+    keep = (d < dist).numpy()
+    i, j = pairs[keep, 0], pairs[keep, 1]
+    adj = coo_matrix((np.ones(2 * i.size, dtype=bool), (np.concatenate([i, j]), np.concatenate([j, i]))), shape=(n, n)).tocsr()
+    return torch.from_numpy(connected_components(adj, directed=False)[1]).int()
 
 
 def fsf_stage3(fsf, s1):
@@ -360,3 +405,99 @@ def multiclass_nms(boxes, scores, score_thr, nms_thr, max_num, rotated=True):
         top = torch.argsort(scs, descending=True, stable=True)[:max_num]
         rows, scs, labs = rows[top], scs[top], labs[top]
     return rows, scs, labs
+
+
+# ------------------------------------------------------------------ heads -> query combination -> refine -> boxes
+def cluster_head_forward(head, feats):
+    """SparseClusterHeadV2.forward (projects/mmdet3d_plugin/models/dense_heads/sparse_cluster_head_v2.py:134-167): shared
+    MLP, then per task the FSDSeparateHead branches (`:18-60`); regression = cat(center, dim, rot[, vel])."""
+    if head.shared_mlp is not None:
+        feats = apply_module(head.shared_mlp, feats)
+    cls, reg = [], []
+    for h in head.task_heads:
+        ret = {name: apply_module(getattr(h, name), feats) for name in h.attrs}
+        parts = [ret["center"], ret["dim"], ret["rot"]] + ([ret["vel"]] if "vel" in ret else [])
+        reg.append(torch.cat(parts, dim=-1))
+        cls.append(ret["score"])
+    return dict(cls_logits=cls, reg_preds=reg)
+
+
+def coder_decode(reg_preds, base_points, eps=1e-6):
+    """BasePointBBoxCoder.decode (core/bbox/coders/base_point_bbox_coder.py:59-82), code_size 10; pinned bit-exact by
+    tests/golden/refine_glue.npz."""
+    velo = reg_preds[:, -2:]
+    r = reg_preds[:, :8]
+    dims = r[:, 3:6].exp() - eps
+    xyz = r[:, :3] + base_points
+    yaw = torch.atan2(r[:, 6:7], r[:, 7:8])
+    return torch.cat([xyz, dims, yaw, velo], dim=1)
+
+
+def combine_frustum_and_fsd(fsf, f_centers, f_coors, f_result, f_feats, f_preds_2d, l_centers, l_coors, l_result, l_feats):
+    """FSF.combine_frustum_and_fsd (FSF.py:657-692)."""
+    obj_centers = torch.cat([f_centers, l_centers], 0)
+    l_re = l_coors.clone()
+    l_re[:, 0] = l_coors[:, 1]
+    l_re[:, 1] = l_coors[:, 0]
+    l_re[:, 2] += fsf.fsd_begin_idx
+    obj_coors = torch.cat([f_coors, l_re], 0)
+    obj_result = {k: [torch.cat([f_result[k][t], l_result[k][t]], 0) for t in range(len(f_result[k]))] for k in f_result}
+    obj_feats = torch.cat([apply_module(fsf.combine_frustum_feat_mlp, f_feats), apply_module(fsf.combine_fsd_feat_mlp, l_feats)], 0)
+    preds_2d = torch.cat([f_preds_2d, f_preds_2d.new_zeros((l_feats.shape[0], f_preds_2d.shape[1]))], 0)
+    return obj_centers, obj_coors, obj_result, obj_feats, preds_2d
+
+
+def decode_stage_bboxes(obj_centers, bz_coors, reg_preds):
+    """FSF.decode_stage_bboxes (FSF.py:1085-1094) at batch size 1 with one task."""
+    assert len(reg_preds) == 1
+    return torch.cat([bz_coors.unsqueeze(-1).to(obj_centers.dtype), coder_decode(reg_preds[0], obj_centers)], -1)
+
+
+def query_feat_refine(fsf, i_stage, seg_points, seg_feats, obj_id, mask_anno, rois, pool):
+    """FSF.query_feat_refine (FSF.py:1000-1044) on a given pooling result `pool` = (point idx, roi idx, feats [k,13]):
+    per-point image feature of the pooled points (img_cross_attn :694-728 with ext_pts_inds), then FullySparseBboxHead."""
+    inds, roi_inds, info = pool
+    ids, score = oproj.cam_select_score(obj_id.numpy()[inds.numpy()], mask_anno.numpy())
+    img = apply_module(fsf.refine_img_mlp[i_stage], torch.from_numpy(score))
+    feats = torch.cat([seg_feats[inds], img], -1)
+    pts_info = dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1], is_in_margin=info[:, -1])
+    return refine_head_forward(fsf.refine_sir_layers[i_stage], seg_points[inds], feats, pts_info, roi_inds, rois)[0]
+
+
+def refined_query(fsf, i_stage, lidar_img_feat, res_query_feat, obj_centers):
+    """FSF.each_stage_refine (FSF.py:1076-1083): query update + refined head."""
+    cur = apply_module(fsf.lidar_img_mlp[i_stage], lidar_img_feat)
+    pos = apply_module(fsf.position_encoder[i_stage], obj_centers)
+    query = apply_module(fsf.out_proj[i_stage], cur + res_query_feat + pos)
+    return cluster_head_forward(fsf.frustum_refined_head[i_stage], query), query
+
+
+def get_bboxes_single(cfg, cls_logits, reg_preds, cluster_xyz, delta=1e-4):
+    """FrustumClusterHead._get_bboxes_single (frustum_cluster_head.py:587-698), one sample / one task, nms_pre = -1:
+    sigmoid scores, decode, per-class rotated BEV NMS (mmdet3d box3d_multiclass_nms), top max_num.  Returns
+    (row into the queries, score, label, smallest |IoU - thr| over every NMS decision taken)."""
+    from . import refine as orefine
+
+    scores = cls_logits.sigmoid()
+    boxes = coder_decode(reg_preds, cluster_xyz)
+    bev = boxes[:, [0, 1, 3, 4, 6]].double().numpy()
+    xyxyr = np.stack([bev[:, 0] - bev[:, 2] / 2, bev[:, 1] - bev[:, 3] / 2, bev[:, 0] + bev[:, 2] / 2,
+                      bev[:, 1] + bev[:, 3] / 2, bev[:, 4]], 1)
+    rows, scs, labs, margin = [], [], [], np.inf
+    for c in range(scores.shape[1]):
+        sel = torch.nonzero(scores[:, c] > cfg["score_thr"]).squeeze(1)
+        if sel.numel() == 0:
+            continue
+        cand = sel[torch.argsort(scores[sel, c], descending=True, stable=True)]
+        keep, mg = orefine.nms_lazy(xyxyr[cand.numpy()], cfg["nms_thr"], rotated=cfg.get("use_rotate_nms", True))
+        margin = min(margin, mg)
+        rows.append(cand[keep])
+        scs.append(scores[cand[keep], c])
+        labs.append(torch.full((len(keep),), c, dtype=torch.long))
+    if not rows:
+        return torch.zeros(0, dtype=torch.long), torch.zeros(0), torch.zeros(0, dtype=torch.long), boxes, margin
+    rows, scs, labs = torch.cat(rows), torch.cat(scs), torch.cat(labs)
+    if rows.numel() > cfg["max_num"]:
+        top = torch.argsort(scs, descending=True, stable=True)[:cfg["max_num"]]
+        rows, scs, labs = rows[top], scs[top], labs[top]
+    return rows, scs, labs, boxes, margin

@@ -145,3 +145,36 @@ def nms_from_iou(iou, thresh):
         keep.append(i)
         removed[i + 1:] |= iou[i, i + 1:] > thresh
     return np.array(keep, dtype=np.int64)
+
+
+def nms_lazy(boxes, thresh, rotated=True, delta=0.0):
+    """Greedy NMS over boxes [n,5] (x1,y1,x2,y2,yaw) already in descending score order, evaluating the float64 IoU only for
+    the pairs the greedy scan actually decides (kept box vs later, not yet removed box) and only when their circumscribed
+    circles touch (otherwise the overlap is exactly 0).  Same keep set as nms_from_iou(iou_bev_matrix(boxes)) at a fraction
+    of the pair evaluations.  Also returns the smallest |IoU - thresh| over the decisions taken: if it exceeds the
+    perturbation an fp32 implementation can cause, the keep set is the only admissible answer."""
+    b = np.asarray(boxes, dtype=np.float64)
+    n = b.shape[0]
+    cx, cy = (b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2
+    rad = 0.5 * np.hypot(b[:, 2] - b[:, 0], b[:, 3] - b[:, 1])
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    removed = np.zeros(n, dtype=bool)
+    keep, margin = [], np.inf
+    for i in range(n):
+        if removed[i]:
+            continue
+        keep.append(i)
+        later = np.nonzero(~removed[i + 1:])[0] + i + 1
+        if later.size == 0:
+            continue
+        near = later[np.hypot(cx[later] - cx[i], cy[later] - cy[i]) <= rad[later] + rad[i]]
+        for j in near:
+            if rotated:
+                ov = rotated_overlap(b[i], b[j])
+            else:
+                ov = max(min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0]), 0.0) * max(min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1]), 0.0)
+            iou = ov / max(area[i] + area[j] - ov, 1e-8)
+            margin = min(margin, abs(iou - thresh))
+            if iou > thresh:
+                removed[j] = True
+    return np.array(keep, dtype=np.int64), float(margin)

@@ -35,3 +35,37 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+def build_test_fsf():
+    """The FSF detector every module-level parity test uses (CPU, eval mode): reference config, seed 0, the zero-initialised
+    image-branch Linear (FSF.py:142-143) perturbed so that the fusion is exercised, BN running statistics away from (0, 1)
+    so that the fused conv epilogue is really tested.  Deterministic on the CPU generator — the full-size golden
+    (tests/golden/make_fullsize_golden.py) is generated from the same function and stores a parameter checksum."""
+    import torch
+
+    from fullysparsefusion_amd import mmdet3d_plugin
+    from fullysparsefusion_amd.compat import Config
+
+    torch.manual_seed(0)
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "fsf_nuscenes.py"))
+    model = mmdet3d_plugin.build_model(cfg.model).eval()
+    torch.nn.init.normal_(model.segmentor_updated_mlp[-1].weight, std=0.05)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.8, 1.2)
+            m.bias.data.normal_(0, 0.1)
+    return model
+
+
+def param_checksum(model):
+    """float64 sum of |p| over parameters and buffers: detects a model that differs from the one a golden was made with."""
+    import torch
+
+    tot = 0.0
+    for t in list(model.parameters()) + list(model.buffers()):
+        if t.is_floating_point():
+            tot += float(t.detach().double().abs().sum())
+    return tot

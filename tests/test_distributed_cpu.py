@@ -136,3 +136,75 @@ def test_frame_data_parallel_gradient_allreduce_world2_gloo():
         for n, p in model.named_parameters():
             assert np.allclose(got[0][3][it][n], p.grad.numpy(), atol=1e-6), (it, n)
             assert np.array_equal(got[0][3][it][n], got[1][3][it][n]), (it, n)
+
+
+# ------------------------------------------------- bucket collectives vs SyncBN collectives on a data-dependent graph
+def _dp_syncbn_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullysparsefusion_amd.data_parallel import FrameDataParallel
+        from fullysparsefusion_amd.mmdet3d_plugin.registry import build_norm_layer
+
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 8), build_norm_layer(dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), 8)[1],
+                                  torch.nn.ReLU(), torch.nn.Linear(8, 3)).train()
+        # registered last => first bucket; used on rank 0 only: there its bucket is launched mid-backward, BEFORE the
+        # SyncBN backward all-reduce, on rank 1 only in finish(), AFTER it (and every later bucket queues behind it)
+        branch = torch.nn.Linear(6, 3)
+        model = torch.nn.ModuleDict(dict(net=net, branch=branch))
+        dp = FrameDataParallel(model, bucket_mb=0.0001)
+        torch.manual_seed(11)
+        x = torch.randn(2, 16, 6)[rank]
+        grads = []
+        for it in range(2):
+            dp.zero_grad()
+            y = dp.module["net"](x)
+            if rank == 0:
+                y = y + dp.module["branch"](x)
+            dp.backward((y ** 2).sum())
+            grads.append({n: p.grad.numpy().copy() for n, p in model.named_parameters()})
+        # gradient accumulation: two micro-batches under no_sync + one synced == one synced backward of the summed loss
+        xs = torch.randn(3, 16, 6, generator=torch.Generator().manual_seed(20 + rank))
+        # (SyncBN statistics are per forward call, so the accumulation check runs with the norm in eval mode)
+        net.eval()
+        dp.zero_grad()
+        dp.backward(sum((dp.module["net"](xs[i]) ** 2).sum() for i in range(3)))
+        want = {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
+        dp.zero_grad()
+        with dp.no_sync():
+            for i in range(2):
+                dp.backward((dp.module["net"](xs[i]) ** 2).sum())
+        dp.backward((dp.module["net"](xs[2]) ** 2).sum())
+        acc = {n: p.grad.numpy().copy() for n, p in model.named_parameters()}
+        q.put((rank, len(dp.buckets), grads, want, acc))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_buckets_do_not_share_a_communicator_with_syncbn_world2_gloo():
+    """on a step where one rank skips a branch, that rank launches the branch's bucket in finish(),
+    the other mid-backward — on the SyncBN communicator the two ranks would issue [bucket, syncbn-backward] and
+    [syncbn-backward, bucket].  The buckets have their own process group, so the step completes and the ranks agree."""
+    import numpy as np
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert got[0][1] >= 4
+    for it in range(2):
+        for n in got[0][2][it]:
+            a, b = got[0][2][it][n], got[1][2][it][n]
+            assert np.isfinite(a).all() and np.array_equal(a, b), (it, n)
+    assert np.abs(got[0][2][0]["branch.weight"]).max() > 0  # rank 0's contribution / 2 reached rank 1
+    for n in got[0][3]:
+        assert np.allclose(got[0][3][n], got[0][4][n], rtol=1e-5, atol=1e-6), n  # accumulation == summed loss
+        assert np.array_equal(got[0][4][n], got[1][4][n]), n

@@ -1,0 +1,334 @@
+"""GPU parity AT THE SIZE bench.py TIMES (BASELINE.json config 3: the 10-sweep frame, 310 615 points) and through to the
+final boxes (VERDICT r1 "What's missing" 1):
+
+  * stage 1 of `FSF.simple_test` on the 10-sweep frame against the committed oracle fixture
+    (tests/golden/stage1_10sweep.npz, made by tests/golden/make_fullsize_golden.py) — integer outputs by checksum and
+    sampled rows (exact), fp32 tensors on sampled rows within 1e-4 of the tensor scale;
+  * stages 1-3 on the 10-sweep frame against the oracle run in the test (every integer decision exact);
+  * every sparse-conv launch of that frame's U-Net (K9b row blocks up to 101 119 x 128 -> 128 and 256 -> 128, the
+    offset-split + fold of the small levels, the fp32 kernel's strided / inverse layers) checked in situ against float64 on
+    sampled rows, with the fused BN-affine / residual / ReLU epilogue;
+  * K22 at 510 652 rows, the SIR stack at 5e5 points with a 1.2e5-row segment (long-segment fold);
+  * heads -> combine_frustum_and_fsd -> each_stage_refine -> get_bboxes chained on the GPU and compared with the oracle chain
+    (FSF.py:1144-1178, frustum_cluster_head.py:503-698): pre-NMS boxes / scores within 1e-4, final boxes / scores / labels
+    exactly the oracle's when no NMS decision sits within 1e-4 of the IoU threshold.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import build_test_fsf, load_golden, param_checksum
+from oracle import modules as omod
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fsf_pair(device):
+    model = build_test_fsf()
+    cpu = copy.deepcopy(model)
+    return model.to(device), cpu
+
+
+@pytest.fixture(scope="module")
+def frame10():
+    from fullysparsefusion_amd import synthetic
+
+    return synthetic.make_frame(num_sweeps=10, seed=0)
+
+
+@pytest.fixture(scope="module")
+def frame1():
+    from fullysparsefusion_amd import synthetic
+
+    return synthetic.make_frame(num_sweeps=1, seed=0)
+
+
+def close(a, b, tol=1e-4, scale=None):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max())) if scale is None else max(1.0, float(scale))
+    err = float((a - b).abs().max()) if a.numel() else 0.0
+    assert err <= tol * scale, f"max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def to_dev(frame, device):
+    return ([torch.from_numpy(frame["points"]).to(device)], [dict(lidar2img=torch.from_numpy(frame["lidar2img"]).to(device))],
+            torch.from_numpy(frame["mask_data"]).to(device)[None], torch.from_numpy(frame["mask_anno"]).to(device)[None])
+
+
+# --------------------------------------------------------------------------------- stage 1, committed fixture
+def test_stage1_10sweep_vs_committed_oracle_fixture(fsf_pair, frame10, device):
+    model, cpu = fsf_pair
+    g = load_golden("stage1_10sweep.npz")
+    if abs(param_checksum(cpu) - float(g["param_checksum"])) > 1e-6 * float(g["param_checksum"]):
+        pytest.fail("the test detector's random init differs from the one the fixture was generated with: regenerate "
+                    "tests/golden/stage1_10sweep.npz (tests/golden/make_fullsize_golden.py)")
+    pts, metas, mask, anno = to_dev(frame10, device)
+    assert pts[0].shape[0] == int(g["num_points"])
+    seg = model.segmentor
+    with torch.no_grad():
+        p5 = pts[0][:, :5].contiguous()
+        p_dev, coors = seg.voxelize([p5])
+        vf, vc, inv = seg.voxel_encoder(p_dev, coors, return_inv=True)
+        unet = seg.backbone(dict(voxel_feats=vf, voxel_coors=vc, batch_size=1))[0]["voxel_feats"]
+        out = model.forward_hot_path(pts, metas, mask, anno)["seg"]
+        obj_id = model.points_in_mask(pts[0][:, 5:8].contiguous(), mask[0], metas[0]["lidar2img"])
+    prow, vrow = torch.from_numpy(g["point_rows"]).to(device), torch.from_numpy(g["voxel_rows"]).to(device)
+    # integer outputs: whole-tensor checksums + sampled rows, exact
+    assert vc.shape[0] == int(g["num_voxels"])
+    np.testing.assert_array_equal(vc.long().sum(0).cpu().numpy(), g["voxel_coors_colsum"])
+    np.testing.assert_array_equal(vc[vrow].cpu().numpy(), g["voxel_coors_rows"])
+    assert int(inv.long().sum()) == int(g["inv_sum"])
+    np.testing.assert_array_equal(inv[prow].cpu().numpy(), g["inv_rows"])
+    assert int(obj_id.sum()) == int(g["obj_id_sum"]) and int((obj_id > 0).sum()) == int(g["obj_id_nonzero"])
+    np.testing.assert_array_equal(obj_id[prow].cpu().numpy(), g["obj_id_rows"])
+    # fp32 tensors: sampled rows within 1e-4 of the full tensor's scale (BASELINE.json north_star)
+    for name, t, rows in [("voxel_feats", vf, vrow), ("unet", unet, vrow), ("seg_feats", out["seg_feats"], prow),
+                          ("seg_logits", out["seg_logits"], prow), ("seg_vote_preds", out["seg_vote_preds"], prow),
+                          ("offsets", out["offsets"], prow)]:
+        close(t[rows], torch.from_numpy(g[name + "_rows"]), 1e-4, scale=float(g[name + "_scale"]))
+        # and the whole tensor is the same kind of thing (catches a row permutation the sample could miss)
+        assert abs(float(t.abs().double().mean()) - float(g[name + "_abs_mean"])) <= 1e-4 * max(1.0, float(g[name + "_scale"]))
+
+
+# ------------------------------------------------------------------------ stages 1-3 at full size, oracle in the test
+def test_hot_path_10sweep_vs_oracle(fsf_pair, frame10, device):
+    """test_plugin_gpu.py::test_fsf_hot_path_vs_oracle on the frame bench.py times: stage 1 end to end; stages 2 and 3 on the
+    oracle's stage-1 output so that every integer decision (fg thresholds, duplicated points, voxel keys, cluster voxels,
+    connected components of 8e4 centres) sees identical inputs and must match bit-exactly."""
+    model, cpu = fsf_pair
+    f = frame10
+    pts8, mask, anno, L = (torch.from_numpy(f[k]) for k in ("points", "mask_data", "mask_anno", "lidar2img"))
+    metas = [dict(lidar2img=f["lidar2img"])]
+    with torch.no_grad():
+        out = model.forward_hot_path([pts8.to(device)], metas, mask.to(device)[None], anno.to(device)[None])
+        s1 = omod.fsf_stage1(cpu, pts8, mask, anno, L)
+        s2 = omod.fsf_stage2(cpu, s1, anno, (900, 1600))
+        s3 = omod.fsf_stage3(cpu, s1)
+    seg = out["seg"]
+    close(seg["seg_feats"], s1["seg_feats"])
+    close(seg["seg_logits"], s1["seg_logits"])
+    close(seg["offsets"], s1["offsets"])
+    np.testing.assert_array_equal(out["frustum_obj_coors"].cpu().numpy(), s2["obj_coors"].numpy())
+    seg_dev = {k: s1[k].to(device) for k in ["seg_points", "seg_logits", "seg_vote_preds", "offsets", "seg_feats", "batch_idx"]}
+    infos = [pts8[:, -3:].to(device)]
+    with torch.no_grad():
+        model._gather_cache = None
+        f_feats, f_centers, f_coors, _, f_preds = model.frustum_forward(seg_dev, anno.to(device)[None], mask.to(device)[None],
+                                                                        infos, metas, run_head=False)
+        cap = {}
+        sir_fwd = model.backbone.forward
+
+        def capture(points, features, coors, f_cluster=None):
+            cap["in"] = (points, features, coors, f_cluster)
+            return sir_fwd(points, features, coors, f_cluster)
+
+        model.backbone.forward = capture
+        try:
+            l_feats, l_xyz, l_inds, _ = model.fsd_forward(seg_dev, metas, run_head=False)
+        finally:
+            model.backbone.forward = sir_fwd
+        model._gather_cache = None
+    np.testing.assert_array_equal(f_coors.cpu().numpy(), s2["obj_coors"].numpy())
+    np.testing.assert_array_equal(f_preds.cpu().numpy(), s2["preds_2d"].numpy())
+    close(f_centers, s2["obj_centers"])
+    close(f_feats, s2["obj_feat"])
+    np.testing.assert_array_equal(l_inds.cpu().numpy(), s3["cluster_inds"].numpy())
+    np.testing.assert_array_equal(cap["in"][2].cpu().long().numpy(), s3["pts_cluster_inds"].long().numpy())
+    assert float((l_xyz.cpu() - s3["cluster_xyz"]).abs().max()) < 5e-5
+    gp, gfe, gco, gfc = [t.cpu() for t in cap["in"]]
+    with torch.no_grad():
+        _, want_feats, want_coors = omod.sir_forward(cpu.backbone, gp, gfe, gco, gfc)
+    np.testing.assert_array_equal(l_inds.cpu().numpy(), want_coors.numpy())
+    close(l_feats, want_feats)
+    assert s3["cluster_inds"].shape[0] > 1000 and gp.shape[0] > 200000 and s2["obj_coors"].shape[0] > 100
+
+
+# ------------------------------------------------------- every sparse-conv launch of the 10-sweep U-Net, in situ
+def test_every_conv_launch_of_the_10sweep_unet_vs_float64(fsf_pair, frame10, device, monkeypatch):
+    """The forward kernels at exactly the shapes / rulebooks / epilogues the bench runs: each SparseConvolution.forward call
+    of the segmentor on the 10-sweep frame is re-computed in float64 on 384 sampled output rows from the tensors it
+    received (features, neighbour table, weight, BN affine, residual)."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import spconv as sp
+
+    model, _ = fsf_pair
+    calls = []
+    orig = sp.SparseConvolution.forward
+
+    def spy(self, x, scale=None, shift=None, residual=None, relu=False):
+        out = orig(self, x, scale=scale, shift=shift, residual=residual, relu=relu)
+        rb = self._rulebook(x)
+        calls.append(dict(mod=self, feat=x.features, nbr=rb.nbr_inv if self.inverse else rb.nbr, scale=scale, shift=shift,
+                          residual=residual, relu=relu, out=out.features))
+        return out
+
+    monkeypatch.setattr(sp.SparseConvolution, "forward", spy)
+    pts = torch.from_numpy(frame10["points"][:, :5].copy()).to(device)
+    with torch.no_grad():
+        model.segmentor.extract_feat([pts], None)
+    monkeypatch.undo()
+    assert len(calls) == 34
+    rng = np.random.default_rng(0)
+    shapes = set()
+    for c in calls:
+        m = c["mod"]
+        nbr, feat, out = c["nbr"], c["feat"], c["out"]
+        m_out = nbr.size(0)
+        shapes.add((m_out, m.in_channels, m.out_channels))
+        rows = torch.from_numpy(np.sort(rng.choice(m_out, size=min(384, m_out), replace=False))).to(device)
+        nb = nbr[rows].long()                                             # [r, kvol]
+        w = m.weight.detach().reshape(-1, m.in_channels, m.out_channels).double()
+        x = feat.double()[nb.clamp(min=0)] * (nb >= 0).unsqueeze(-1)     # [r, kvol, cin]
+        want = torch.einsum("rkc,kcd->rd", x, w)
+        if c["scale"] is not None:
+            want = want * c["scale"].double()
+        if c["shift"] is not None:
+            want = want + c["shift"].double()
+        if c["residual"] is not None:
+            want = want + c["residual"].double()[rows]
+        if c["relu"]:
+            want = want.relu()
+        scale = max(1.0, float(want.abs().max()))
+        err = float((out[rows].double() - want).abs().max())
+        assert err <= 1e-5 * scale, (m_out, m.in_channels, m.out_channels, m.subm, m.inverse, err, scale)
+    # the shapes VERDICT r1 names are among them
+    assert any(s[0] > 100000 and s[1:] == (128, 128) for s in shapes) and any(s[0] > 100000 and s[1:] == (256, 128) for s in shapes)
+    assert any(30000 < s[0] < 40000 and s[1:] == (256, 128) for s in shapes)
+
+
+# --------------------------------------------------------------------------------------------- K22 at 510 k rows
+@pytest.mark.parametrize("k,c", [(256, 128), (180, 128)])
+def test_linear_norm_act_at_510k_rows(device, k, c):
+    import torch.nn.functional as F
+
+    from fullysparsefusion_amd import hip_ops as ops
+
+    n = 510652
+    torch.manual_seed(k)
+    x = torch.randn(n, k, device=device) * torch.exp(torch.randn(n, 1, device=device))
+    w = torch.randn(c, k, device=device) / k ** 0.5
+    g, be = torch.rand(c, device=device) + 0.5, torch.randn(c, device=device) * 0.1
+    out = ops.linear_norm_act(x, ops.linear_prepare_weight(w), c, norm="ln", gamma=g, beta=be, eps=1e-3, act="gelu")
+    rows = torch.randperm(n, device=device)[:4096]
+    rows = torch.cat([rows, torch.tensor([0, 1, n - 2, n - 1], device=device)])
+    want = F.gelu(F.layer_norm(F.linear(x[rows].double(), w.double()), (c,), g.double(), be.double(), 1e-3))
+    assert float((out[rows].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert bool(torch.isfinite(out).all())
+
+
+# ------------------------------------------------------------- SIR stack at 5e5 points, a 1.2e5-row segment
+def test_sir_stack_at_half_a_million_points_with_a_long_segment(fsf_pair, device):
+    model, cpu = fsf_pair
+    rng = np.random.default_rng(9)
+    n = 500000
+    points = torch.from_numpy(rng.uniform(-30, 30, (n, 5)).astype(np.float32))
+    feats = torch.from_numpy(rng.standard_normal((n, 131)).astype(np.float32))
+    ids = rng.integers(0, 9000, n)
+    ids[100000:220000] = 17       # 1.2e5 rows in one group: the long-segment fold (4 workgroups per segment)
+    ids[300000:330000] = 4242     # and a 3e4-row one
+    coors = torch.from_numpy(np.stack([np.zeros(n), np.zeros(n), ids], 1).astype(np.int64))
+    f_cluster = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32))
+    with torch.no_grad():
+        pf, cf, oc = model.frustum_sir(points.to(device), feats.to(device), coors.to(device), f_cluster.to(device))
+        opf, ocf, ooc = omod.sir_forward(cpu.frustum_sir, points, feats, coors, f_cluster)
+    np.testing.assert_array_equal(oc.cpu().numpy(), ooc.numpy())
+    close(pf, opf)
+    close(cf, ocf)
+
+
+# ------------------------------------------------------------- heads -> combine -> refine -> get_bboxes, chained
+def test_final_boxes_vs_oracle_chain(fsf_pair, frame1, device, monkeypatch):
+    """FSF.simple_test from the query features to the boxes it returns (FSF.py:1144-1178).  The GPU runs the whole forward;
+    the oracle chain restarts from the GPU's query features (the SIR stages upstream are ill-conditioned, see
+    test_fsf_hot_path_vs_oracle) and at each discontinuity (RoI membership of a point, an NMS decision) takes the GPU's
+    inputs to that decision, so that a difference there is the kernel's, not an upstream rounding."""
+    from oracle import refine as orefine
+
+    model, cpu = fsf_pair
+    pts, metas, mask, anno = to_dev(frame1, device)
+    cap = {}
+
+    def tap(obj, name, key):
+        orig = getattr(obj, name)
+
+        def wrapped(*a, **k):
+            out = orig(*a, **k)
+            cap[key] = (a, k, out)
+            return out
+
+        monkeypatch.setattr(obj, name, wrapped)
+
+    tap(model, "segmentor_feat_inhance_test", "seg")
+    tap(model, "combine_frustum_and_fsd", "combine")
+    tap(model.roi_extractor, "forward", "roi")
+    tap(model.frustum_refined_head[0], "forward", "head")
+    tap(model.frustum_refined_head[0], "get_bboxes", "boxes")
+    with torch.no_grad():
+        res = model.simple_test(pts, metas, mask, anno)
+    monkeypatch.undo()
+    c = lambda t: t.detach().cpu()  # noqa: E731
+    seg = {k: c(v) for k, v in cap["seg"][2].items()}
+    f_centers, f_coors, f_result, f_feats, f_p2d, l_centers, l_coors, l_result, l_feats = cap["combine"][0]
+
+    with torch.no_grad():
+        # heads on the queries (frustum_cluster_head.py / sparse_cluster_head_v2.py forward)
+        of = omod.cluster_head_forward(cpu.frustum_obj_head, c(f_feats))
+        ol = omod.cluster_head_forward(cpu.bbox_head, c(l_feats))
+        for got, want in ((f_result, of), (l_result, ol)):
+            close(got["cls_logits"][0], want["cls_logits"][0])
+            close(got["reg_preds"][0], want["reg_preds"][0])
+        # combine_frustum_and_fsd on the GPU's head outputs
+        o_centers, o_coors, o_result, o_feats, o_p2d = omod.combine_frustum_and_fsd(
+            cpu, c(f_centers), c(f_coors), {k: [c(t) for t in v] for k, v in f_result.items()}, c(f_feats), c(f_p2d),
+            c(l_centers), c(l_coors), {k: [c(t) for t in v] for k, v in l_result.items()}, c(l_feats))
+        g_centers, g_coors, g_result, g_feats, g_p2d = cap["combine"][2]
+        np.testing.assert_array_equal(c(g_coors).numpy(), o_coors.numpy())
+        np.testing.assert_array_equal(c(g_centers).numpy(), o_centers.numpy())
+        np.testing.assert_array_equal(c(g_p2d).numpy(), o_p2d.numpy())
+        close(g_feats, o_feats)
+        # stage RoIs (decode_stage_bboxes) and the pooling on the GPU's RoIs
+        rois = omod.decode_stage_bboxes(o_centers, o_coors[:, 0], o_result["reg_preds"])
+        (xyz_in, bidx_in, rois_in), _, (g_inds, g_roi_inds, g_info) = cap["roi"]
+        close(rois_in, rois[:, :8], 1e-5)
+        rois_g = c(rois_in).numpy()
+        wp, wr, wf, margins = orefine.dynamic_point_pool(rois_g[:, 1:], c(xyz_in).numpy(), model.roi_extractor.extra_wlh,
+                                                         model.roi_extractor.max_inbox_point, model.roi_extractor.max_all_pts,
+                                                         return_margin=True)
+        pool_exact = not (margins[:, 2] < 1e-5).any()
+        if pool_exact:
+            np.testing.assert_array_equal(c(g_inds).numpy(), wp)
+            np.testing.assert_array_equal(c(g_roi_inds).numpy(), wr)
+            np.testing.assert_allclose(np.concatenate([c(v).numpy().reshape(len(wp), -1) for v in
+                                                       (g_info["local_xyz"], g_info["boundary_offset"], g_info["is_in_margin"])], 1),
+                                       wf[:, 3:], atol=1e-5)
+        # refine SIR on the GPU's pooling result, query update, refined head
+        obj_id = c(model.points_in_mask(pts[0][:, 5:8].contiguous(), mask[0], metas[0]["lidar2img"]))
+        g_info13 = torch.cat([c(xyz_in)[c(g_inds)], c(g_info["local_xyz"]), c(g_info["boundary_offset"]),
+                              c(g_info["is_in_margin"])[:, None]], 1)
+        lidar_img = omod.query_feat_refine(cpu, 0, seg["seg_points"], seg["seg_feats"], obj_id, c(anno[0]),
+                                           torch.from_numpy(rois_g), (c(g_inds), c(g_roi_inds), g_info13))
+        o_res, o_query = omod.refined_query(cpu, 0, lidar_img, c(g_feats), torch.from_numpy(rois_g[:, 1:4]))
+        (q_in,), _, g_res = cap["head"]
+        close(q_in, o_query)
+        close(g_res["cls_logits"][0], o_res["cls_logits"][0])
+        close(g_res["reg_preds"][0], o_res["reg_preds"][0])
+        # get_bboxes on the GPU's refined head outputs: decode + per-class rotated BEV NMS + top max_num
+        (b_cls, b_reg, b_p2d, b_centers, b_coors, _), _, g_boxes = cap["boxes"]
+        cfg = model.frustum_refined_head[0].test_cfg
+        rows, scs, labs, boxes, margin = omod.get_bboxes_single(cfg, c(b_cls[0]), c(b_reg[0]), c(b_centers))
+    gb, gs, gl = g_boxes[0]
+    assert len(res) == 1 and res[0]["boxes_3d"].tensor.shape[0] == gb.tensor.shape[0] > 0
+    assert torch.equal(res[0]["boxes_3d"].tensor, c(gb.tensor)) and torch.equal(res[0]["scores_3d"], c(gs))
+    if margin > 1e-5:  # no NMS decision within rounding of the IoU threshold: the oracle's answer is the only admissible one
+        assert gb.tensor.shape[0] == rows.numel()
+        np.testing.assert_array_equal(c(gl).numpy(), labs.numpy())
+        close(gs, scs, 1e-6)
+        close(gb.tensor, boxes[rows], 1e-6)
+    else:  # still: every returned box is one of the decoded candidates with its own score / label
+        dec = boxes.numpy()
+        d = np.abs(c(gb.tensor).numpy()[:, None, :7] - dec[None, :, :7]).max(-1)
+        assert float(d.min(1).max()) < 1e-5
+    assert rows.numel() > 0 and len(cap["roi"][2][0]) > 100

@@ -669,6 +669,34 @@ def test_dynamic_point_pool_batched_and_empty(ops, device):
     assert gp.numel() == 0 and gf.shape == (0, 13)
 
 
+def test_ops_dynamic_point_pool_reference_signature(ops, device):
+    """`ops.dynamic_point_pool(rois, pts, extra_wlh, max_inbox_point, max_all_pts=50000)` by the reference's name
+    (projects/mmdet3d_plugin/ops/__init__.py:1, dynamic_point_pool_op.py:10-51): same rows as the oracle, the fake
+    (-1, -1, zeros) row when nothing is inside, non-differentiable outputs, None gradients."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import dynamic_point_pool
+
+    rng = np.random.default_rng(11)
+    rois = random_rois(rng, 30, spread=10.0)
+    pts = np.concatenate([rng.uniform(-12, 12, (6000, 2)), rng.uniform(-3, 2, (6000, 1))], 1).astype(np.float32)
+    wp, wr, wf, margin = orefine.dynamic_point_pool(rois, pts, [0.5, 0.5, 0.5], 64, return_margin=True)
+    r_t = torch.from_numpy(rois).to(device).requires_grad_(True)
+    p_t = torch.from_numpy(pts).to(device).requires_grad_(True)
+    gp, gr, gf = dynamic_point_pool(r_t, p_t, [0.5, 0.5, 0.5], 64)
+    assert gp.dtype == torch.int64 and gr.dtype == torch.int64 and gf.dtype == torch.float32 and gf.shape[1] == 13
+    assert not gp.requires_grad and not gr.requires_grad and not gf.requires_grad
+    if not (margin[:, 2] < 1e-4).any():
+        np.testing.assert_array_equal(gp.cpu().numpy(), wp)
+        np.testing.assert_array_equal(gr.cpu().numpy(), wr)
+        np.testing.assert_allclose(gf.cpu().numpy(), wf, atol=1e-5)
+    # max_all_pts caps the output in (roi, point) order
+    cp, cr, _ = dynamic_point_pool(r_t, p_t, [0.5, 0.5, 0.5], 64, 100)
+    assert cp.numel() == min(100, gp.numel()) and torch.equal(cp, gp[:100]) and torch.equal(cr, gr[:100])
+    # nothing inside any box: the reference's fake non-empty row
+    far = torch.full((100, 3), 500.0, device=device)
+    fp, fr, ff = dynamic_point_pool(torch.from_numpy(rois).to(device), far, [0.5, 0.5, 0.5], 64)
+    assert fp.tolist() == [-1] and fr.tolist() == [-1] and ff.shape == (1, 13) and float(ff.abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize("n,rotated", [(1, True), (70, True), (500, True), (500, False), (1500, True)])
 def test_nms_bev_vs_oracle(ops, device, n, rotated):
     rng = np.random.default_rng(n + int(rotated))

@@ -72,3 +72,23 @@ def test_ingroup_rank_contract():
     for v in g.unique():
         rr = r[g == v]
         assert sorted(rr.tolist()) == list(range(rr.numel()))
+
+
+def test_sparse_connected_components_equal_the_dense_reference_call():
+    """oracle.modules.connected_components_xy switches to a sparse adjacency beyond 4096 centres; the labels must be those
+    of the reference's dense call (single_stage_fsd.py:69-82) — checked on clustered centres with chains."""
+    from scipy.sparse.csgraph import connected_components
+
+    from oracle import modules as omod
+
+    rng = np.random.default_rng(3)
+    n = 5000
+    ctr = rng.uniform(-20, 20, (300, 2))[rng.integers(0, 300, n)] + rng.normal(0, 0.25, (n, 2))
+    pts = torch.from_numpy(np.concatenate([ctr, rng.uniform(-1, 1, (n, 1))], 1).astype(np.float32))
+    for dist in (0.2, 0.6):
+        got = omod.connected_components_xy(pts, dist)
+        p = pts[:, :2]
+        d = ((p[:, None, :] - p[None, :, :]) ** 2).sum(2) ** 0.5
+        want = connected_components((d < dist).numpy(), directed=False)[1]
+        np.testing.assert_array_equal(got.numpy(), want)
+        assert 10 < want.max() < n - 10

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden_cases, load_golden
+from conftest import build_test_fsf, golden_cases, load_golden, param_checksum
 from oracle import modules as omod
 from oracle import scatter as oscatter
 
@@ -27,20 +27,7 @@ def plugin(device):
 @pytest.fixture(scope="module")
 def fsf_pair(plugin, device):
     """(model on the GPU in eval mode, CPU copy used by the oracle as a weight container)."""
-    from fullysparsefusion_amd.compat import Config
-
-    torch.manual_seed(0)
-    cfg = Config.fromfile(os.path.join(ROOT, "configs", "fsf_nuscenes.py"))
-    model = plugin.build_model(cfg.model).eval()
-    # the image branch ends in a zero-initialised Linear (FSF.py:142-143): perturb it so the fusion is exercised
-    torch.nn.init.normal_(model.segmentor_updated_mlp[-1].weight, std=0.05)
-    # BN running stats away from (0, 1) so the fused conv epilogue is really tested
-    for m in model.modules():
-        if isinstance(m, torch.nn.BatchNorm1d):
-            m.running_mean.normal_(0, 0.1)
-            m.running_var.uniform_(0.5, 1.5)
-            m.weight.data.uniform_(0.8, 1.2)
-            m.bias.data.normal_(0, 0.1)
+    model = build_test_fsf()
     cpu = copy.deepcopy(model)
     return model.to(device), cpu
 

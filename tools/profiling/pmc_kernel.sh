@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scratch/pmc_kernel.sh <kernel-substring> <counters...> -- <cmd...>   (prints avg counter values for the kernel)
+# usage: tools/profiling/pmc_kernel.sh <kernel-substring> <counters...> -- <cmd...>   (prints avg counter values for the kernel)
 pat=$1; shift
 ctrs=()
 while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done; shift
