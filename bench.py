@@ -152,20 +152,35 @@ class TrainStep:
 
 # ------------------------------------------------------------------------------------------------ instrumented pass
 class _Probe:
-    """Wraps entry points of `hip_ops` with HIP events (recorded on the calling thread's current stream — the stream the
-    C ABI launches on; the camera branch runs on its own stream / host thread) and books algorithmic work per call."""
+    """Wraps entry points of `hip_ops`.  mode "events": HIP events around every call, recorded on the calling thread's
+    current stream (the stream the C ABI launches on) from a pre-created pool — right for kernels of 100+ us issued back to
+    back while the device is busy (the sparse convolutions of the U-Net).  mode "capture": only remembers (function,
+    arguments); `replay()` then times every remembered call in isolation, REP launches back to back between one event pair,
+    so that the host's launch latency (which an event pair around a single short launch on a drained stream would
+    measure instead of the kernel) is hidden behind the previous launch."""
 
-    def __init__(self):
+    REP = 4
+
+    def __init__(self, mode):
+        self.mode = mode
         self.records = []
         self.lock = threading.Lock()
         self.saved = {}
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2048)] if mode == "events" else []
 
     def wrap(self, mod, name, account):
         orig = getattr(mod, name)
         self.saved[(mod, name)] = orig
 
         def wrapped(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if self.mode == "capture":
+                out = orig(*a, **k)
+                with self.lock:
+                    self.records.append((name, orig, account, a, k, out))
+                return out
+            with self.lock:
+                e0 = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+                e1 = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
             e0.record()
             out = orig(*a, **k)
             e1.record()
@@ -180,8 +195,24 @@ class _Probe:
             setattr(mod, name, orig)
 
     def table(self):
-        """{name: dict(calls, ms, bytes, flops)} — evaluated after a device sync."""
+        """{key: dict(calls, ms, bytes, flops)} — after a device sync."""
         agg = {}
+        if self.mode == "capture":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for name, orig, account, a, k, out in self.records:
+                key, byts, flops = account(a, k, out)
+                orig(*a, **k)  # warm (allocator, workspaces)
+                e0.record()
+                for _ in range(self.REP):
+                    orig(*a, **k)
+                e1.record()
+                e1.synchronize()
+                d = agg.setdefault(key, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
+                d["calls"] += 1
+                d["ms"] += e0.elapsed_time(e1) / self.REP
+                d["bytes"] += byts
+                d["flops"] += flops
+            return agg
         for name, e0, e1, account, a, k, out in self.records:
             key, byts, flops = account(a, k, out)
             d = agg.setdefault(key, dict(calls=0, ms=0.0, bytes=0.0, flops=0.0))
@@ -255,28 +286,38 @@ def _acc_linear(a, k, out):
 
 
 def instrumented_pass(model, pool, steps, hot_path_only):
+    """Two passes over the same frames: the sparse-conv forward kernels with HIP events in situ (`steps` frames); the
+    scatter / gather / segmented-reduce / projection / fused-linear kernels captured on ONE frame and replayed in isolation.
+    Returns ({key: totals}, frames the conv totals cover, frames the hbm totals cover)."""
     from fullysparsefusion_amd import hip_ops
 
-    p = _Probe()
+    p = _Probe("events")
     p.wrap(hip_ops, "spconv_forward", _acc_spconv("fp32"))
     p.wrap(hip_ops, "spconv_forward_split", _acc_spconv("split"))
-    for name in ("spconv_forward_planes",):  # (kernels added later register here)
-        if hasattr(hip_ops, name):
-            p.wrap(hip_ops, name, _acc_spconv("planes"))
-    p.wrap(hip_ops, "segment_reduce", _acc_seg_reduce)
-    p.wrap(hip_ops, "gather_rows", _acc_gather_rows)
-    p.wrap(hip_ops, "voxel2point", _acc_voxel2point)
-    p.wrap(hip_ops, "project_gather_mask", _acc_project)
-    p.wrap(hip_ops, "cam_select_score", _acc_cam_select)
-    p.wrap(hip_ops, "sir_input", _acc_sir_input)
-    p.wrap(hip_ops, "linear_norm_act", _acc_linear)
+    if hasattr(hip_ops, "spconv_forward_planes"):
+        p.wrap(hip_ops, "spconv_forward_planes", _acc_spconv("planes"))
     try:
         for i in range(steps):
             step(model, pool[i % len(pool)], hot_path_only)
         torch.cuda.synchronize()
     finally:
         p.restore()
-    return p.table()
+    conv = p.table()
+    q = _Probe("capture")
+    q.wrap(hip_ops, "segment_reduce", _acc_seg_reduce)
+    q.wrap(hip_ops, "gather_rows", _acc_gather_rows)
+    q.wrap(hip_ops, "voxel2point", _acc_voxel2point)
+    q.wrap(hip_ops, "project_gather_mask", _acc_project)
+    q.wrap(hip_ops, "cam_select_score", _acc_cam_select)
+    q.wrap(hip_ops, "sir_input", _acc_sir_input)
+    q.wrap(hip_ops, "linear_norm_act", _acc_linear)
+    try:
+        step(model, pool[0], hot_path_only)
+        torch.cuda.synchronize()
+    finally:
+        q.restore()
+    hbm = q.table()
+    return conv, hbm
 
 
 SPCONV_KERNELS = {
@@ -289,9 +330,8 @@ SPCONV_KERNELS = {
 }
 
 
-def roofline_blocks(table, steps, ms_per_step, traffic):
+def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic):
     """`roofline` (dominant kernel = the sparse-conv forward kernel with the most time), `hbm` and `frame_roofline_ms`."""
-    conv = {k: v for k, v in table.items() if k.startswith("spconv_")}
     kernels = {}
     for k, v in conv.items():
         title, peak, pipe = SPCONV_KERNELS[k]
@@ -308,16 +348,14 @@ def roofline_blocks(table, steps, ms_per_step, traffic):
     all_flops, all_ms = sum(v["flops"] for v in conv.values()), sum(v["ms"] for v in conv.values())
     hbm = {}
     hbm_floor_ms = 0.0
-    for k, v in sorted(table.items()):
-        if k.startswith("spconv_"):
-            continue
+    for k, v in sorted(hbm_table.items()):  # one frame, every call replayed in isolation
         gbs = v["bytes"] / max(v["ms"], 1e-9) / 1e6
-        hbm[k] = dict(calls_per_step=v["calls"] // steps, ms_per_step=round(v["ms"] / steps, 3),
-                      algorithmic_mb_per_step=round(v["bytes"] / steps / 1e6, 1), gb_per_s=round(gbs, 1),
+        hbm[k] = dict(calls_per_step=v["calls"], ms_per_step=round(v["ms"], 3),
+                      algorithmic_mb_per_step=round(v["bytes"] / 1e6, 1), gb_per_s=round(gbs, 1),
                       frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
         if k == "linear_norm_act":
             hbm[k]["tflops_fp32_equivalent"] = round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)
-        hbm_floor_ms += v["bytes"] / steps / (HBM_PEAK_GBS * 1e6)
+        hbm_floor_ms += v["bytes"] / (HBM_PEAK_GBS * 1e6)
     conv_floor_ms = sum(v["flops"] / steps / (SPCONV_KERNELS[k][1] * 1e9) for k, v in conv.items())
     frame_floor = conv_floor_ms + hbm_floor_ms
     roof = dict(
@@ -339,7 +377,11 @@ def roofline_blocks(table, steps, ms_per_step, traffic):
                             "(algorithmic bytes / 8 TB/s); kernels that are not instrumented (sorts, rulebooks, CCL, pooling, NMS, "
                             "glue) add nothing, so this is a LOWER bound of the frame's roofline time",
         frame_roofline_frac=round(frame_floor / ms_per_step, 4),
-        note="HIP-event timing on the launching stream in an instrumented pass over the same frames, right after the timed region")
+        hbm_note="every call of ONE frame replayed in isolation, 4 launches back to back between one HIP-event pair (an event pair "
+                 "around a single short launch on a drained stream measures the host's launch latency, not the kernel); aggregate "
+                 "GB/s = algorithmic bytes of all calls / their summed time, small launch-bound calls included",
+        note="sparse-conv kernels: HIP-event timing in situ on the launching stream, in an instrumented pass over the same "
+             "frames right after the timed region")
     return roof
 
 
@@ -506,9 +548,9 @@ def main():
         }
     if rank == 0 and not args.no_roofline and not args.train:
         n = min(args.steps, 2 * nframes)
-        table = instrumented_pass(model, pool, n, args.hot_path_only)
+        conv_t, hbm_t = instrumented_pass(model, pool, n, args.hot_path_only)
         traffic = committed_traffic() if args.dataset == "nuscenes" else {}
-        result["roofline"] = roofline_blocks(table, n, result["ms_per_step"], traffic)
+        result["roofline"] = roofline_blocks(conv_t, hbm_t, n, result["ms_per_step"], traffic)
         if not args.hot_path_only:  # where the frame time goes: the three query-generation stages vs the rest
             torch.cuda.synchronize()
             t0 = time.perf_counter()

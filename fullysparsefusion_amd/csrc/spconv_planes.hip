@@ -1,0 +1,538 @@
+// K9c: submanifold sparse convolution forward on the f16 matrix cores from PRE-SPLIT feature planes.
+// See include/fsf_hip.h (fsf_to_planes, fsf_spconv_prepare_weight_planes, fsf_spconv_forward_planes).
+//
+// out[o, :] = act(scale * (sum_k feat[nbr[o, k], :] @ W[k]) + shift + residual), fp32-accurate, deterministic.
+//
+// What K9b (spconv_split.hip) pays for and this kernel does not:
+//   * K9b forms the fp32 product from an exact 3-way bf16 split: SIX MFMAs per fp32-equivalent one, and every wave
+//     re-splits the rows it gathers (27 x per input value).  Here every feature tensor a convolution consumes exists as
+//     two f16 planes hi + lo of (x * s_row), s_row a power of two chosen per row so that the row's largest magnitude lands
+//     in [2^13, 2^14): hi = rn_f16(x s), lo = rn_f16(x s - hi), |x s - hi - lo| <= max(2^-22 |x s|, 2^-25) — 22
+//     significant bits relative to every element that matters at the row's scale, no f16 range hazard.  The weights get
+//     one power-of-two scale per layer.  x w = hi_x hi_w + hi_x lo_w + lo_x hi_w (+ terms <= 3 * 2^-22 |x w|): THREE
+//     v_mfma_f32_16x16x32_f16 per fp32-equivalent one, fp32 accumulation, and the split is done ONCE by the kernel that
+//     produces the tensor (this kernel's epilogue, or fsf_to_planes).
+//   * K9b streams the weights through LDS and every wave reads the whole 24 KB chunk for its 32 rows: 1.2 us of LDS
+//     traffic per step per CU.  Here a wave owns 16*TPW output CHANNELS of the workgroup's whole row block: its slice of
+//     W_k[32-cin chunk] is 16 registers, fetched straight from L2 one step ahead; what goes through LDS is the gathered
+//     input rows — by LDS-DMA (global_load_lds: each lane names its own neighbour row, the 1 KiB lands in MFMA B-fragment
+//     order), two steps ahead, no VGPR cost — read by all four waves.
+//   * K9b multiplies a zero row for every (row, offset) without a neighbour: 46-80 % of its MFMA lanes.  Here the unit is a
+//     CELL = (16-row group, offset): cells without any neighbour (61 % of them on the 0.2 m level, 39 % on the 0.4 m
+//     level) are neither gathered nor multiplied; offsets a whole row block lacks are not visited.
+// The accumulators (RG row groups x TPW channel tiles) stay in registers for all 27 offsets.  Per (offset, source) the
+// products of a cell are collected in a second register set D and folded into the accumulators with the row's inverse
+// scale (exact: powers of two), so rows of different magnitude share an MFMA.
+// One barrier per (offset, 32-cin chunk) step; every global access of the main loop is either an LDS-DMA or an inline-asm
+// load, all waits are counted by hand (s_waitcnt vmcnt(n): the newest n may stay in flight).
+#include "common.h"
+
+namespace fsf {
+
+typedef _Float16 sp_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
+typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sp_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SP_NSLOT = 3;      // gathered-row ring: step s computes slot s % 3 while s + 2 is landing
+constexpr int SP_KVOL_MAX = 27;
+constexpr int SP_HDR_BYTES = 256;  // weight-plane header: [0] inverse weight scale, [1] weight scale, [2] max |w| bits
+
+// power of two s with s * amax in [2^13, 2^14); inv = 1 / s (both exact)
+__device__ __forceinline__ void sp_pick_scale(float amax, float& s, float& inv) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  e = amax > 0.0f ? (e < -100 ? -100 : e > 100 ? 100 : e) : 13;
+  s = __uint_as_float((unsigned)(13 - e + 127) << 23);
+  inv = __uint_as_float((unsigned)(e - 13 + 127) << 23);
+}
+
+__device__ __forceinline__ void sp_split4(const float (&v)[4], float s, sp_u32x2& hi, sp_u32x2& lo) {
+  sp_f16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float xs = __fmul_rn(v[e], s);
+    h[e] = (_Float16)xs;
+    l[e] = (_Float16)__fsub_rn(xs, (float)h[e]);
+  }
+  hi = __builtin_bit_cast(sp_u32x2, h);
+  lo = __builtin_bit_cast(sp_u32x2, l);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 rows -> planes.  planes: [m + 1][c / 8][2][8] f16 (row m = zeros, the neighbour of a missing pair);
+// scales: [m + 1][ceil(c / 128)] f32 = the INVERSE scale of each 128-channel chunk of the row.
+__global__ void __launch_bounds__(256)
+    to_planes_kernel(const float* __restrict__ feat, int64_t m, int c, int64_t stride, uint4* __restrict__ planes,
+                     float* __restrict__ scales) {
+  const int nchunk = (c + 127) / 128;
+  const int tl = threadIdx.x & 15;
+  const int64_t teams = (m + 1) * nchunk;
+  for (int64_t team = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; team < teams; team += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+    const int64_t row = team / nchunk;
+    const int ch = (int)(team - row * nchunk);
+    const int c0 = ch * 128 + tl * 8;
+    const bool active = c0 < c;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    if (active && row < m) {
+      const float4 p = *reinterpret_cast<const float4*>(feat + row * stride + c0);
+      const float4 r = *reinterpret_cast<const float4*>(feat + row * stride + c0 + 4);
+      v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = r.x; v[5] = r.y; v[6] = r.z; v[7] = r.w;
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 16));
+    float s, inv;
+    sp_pick_scale(amax, s, inv);
+    if (active) {
+      sp_u32x2 h0, l0, h1, l1;
+      const float a4[4] = {v[0], v[1], v[2], v[3]}, b4[4] = {v[4], v[5], v[6], v[7]};
+      sp_split4(a4, s, h0, l0);
+      sp_split4(b4, s, h1, l1);
+      uint4* dst = planes + (row * (c / 8) + (c0 >> 3)) * 2;
+      dst[0] = make_uint4(h0[0], h0[1], h1[0], h1[1]);
+      dst[1] = make_uint4(l0[0], l0[1], l1[0], l1[1]);
+    }
+    if (tl == 0) scales[team] = row < m ? inv : 1.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// weights [kvol][cin][cout] fp32 (spconv v1 layout) -> per-wave A-fragment planes of W_k^T, one power-of-two scale per layer
+__global__ void __launch_bounds__(256) sp_weight_absmax_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ hdr) {
+  float amax = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    amax = fmaxf(amax, fabsf(w[i]));
+  amax = fsf_wave_max(amax);
+  if ((threadIdx.x & 63) == 0) atomicMax(hdr + 2, __float_as_uint(amax));  // |x| bit patterns order like the values
+}
+
+__global__ void __launch_bounds__(256)
+    sp_weight_planes_kernel(const float* __restrict__ w, int kvol, int cin, int cout, int tpw, int nslice, float* __restrict__ hdr,
+                            uint4* __restrict__ frag) {
+  float s, inv;
+  sp_pick_scale(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[2]), s, inv);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[0] = inv;
+    hdr[1] = s;
+  }
+  const int nchunks = cin / 32;
+  const int64_t total = (int64_t)nslice * kvol * nchunks * 4 * tpw * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t r = idx >> 6;
+    const int t = (int)(r % tpw); r /= tpw;
+    const int wave = (int)(r & 3); r >>= 2;
+    const int c = (int)(r % nchunks); r /= nchunks;
+    const int k = (int)(r % kvol);
+    const int slice = (int)(r / kvol);
+    const int col = slice * 64 * tpw + wave * 16 * tpw + 16 * t + (lane & 15);
+    const int c0 = c * 32 + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = col < cout ? w[((int64_t)k * cin + c0 + e) * cout + col] : 0.0f;
+    sp_u32x2 h0, l0, h1, l1;
+    const float a4[4] = {v[0], v[1], v[2], v[3]}, b4[4] = {v[4], v[5], v[6], v[7]};
+    sp_split4(a4, s, h0, l0);
+    sp_split4(b4, s, h1, l1);
+    uint4* dst = frag + ((idx >> 6) * 2) * 64 + lane;
+    dst[0] = make_uint4(h0[0], h0[1], h1[0], h1[1]);
+    dst[64] = make_uint4(l0[0], l0[1], l1[0], l1[1]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct SpArgs {
+  const char* x[2];     // source planes (rows of c[s] * 4 bytes), x[1] = nullptr without a second source
+  const float* sx[2];   // inverse row scales [m_in + 1]
+  int c[2];
+  const sp_u32x4* w;    // fragment planes (after the header)
+  const float* w_hdr;
+  const int32_t* nbr;
+  int64_t m_in, m_out;
+  int kvol, cin, cout, relu;
+  const float *scale, *shift, *residual;
+  float* out;
+  uint4* out_planes;
+  float* out_scales;
+};
+
+template <int N>
+__device__ __forceinline__ void sp_wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+__device__ __forceinline__ void sp_wait_vm_n(int n) {  // (uniform) at most n of the newest VMEM operations may stay in flight
+  switch (n) {
+    case 0: sp_wait_vm<0>(); break;
+    case 1: sp_wait_vm<1>(); break;
+    case 2: sp_wait_vm<2>(); break;
+    case 3: sp_wait_vm<3>(); break;
+    case 4: sp_wait_vm<4>(); break;
+    case 5: sp_wait_vm<5>(); break;
+    default: sp_wait_vm<6>(); break;
+  }
+}
+
+template <int RG, int TPW>
+struct SpSmem {
+  static constexpr int R = 16 * RG;
+  static constexpr size_t nbr_bytes = (size_t)R * SP_KVOL_MAX * 4;
+  static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
+  static constexpr size_t xring_bytes = (size_t)SP_NSLOT * RG * 2 * 1024;
+  static constexpr size_t sring_off = xring_off + xring_bytes;
+  static constexpr size_t sring_bytes = (size_t)4 * RG * 64 * 4;
+  static constexpr size_t meta_off = sring_off + sring_bytes;      // klist[32] | cellmask[32] | nk | flags[27 * RG]
+  static constexpr size_t meta_bytes = 32 * 4 + 32 * 4 + 16 + (size_t)SP_KVOL_MAX * RG;
+  static constexpr size_t vec_off = (meta_off + meta_bytes + 15) / 16 * 16;
+  static constexpr size_t vec_bytes = (size_t)2 * 64 * TPW * 4;
+  static constexpr size_t rowmax_off = vec_off + vec_bytes;
+  static constexpr size_t rowmax_bytes = (size_t)4 * R * 4;
+  static constexpr size_t bytes = rowmax_off + rowmax_bytes;
+};
+
+template <int RG, int TPW>
+__global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel(SpArgs a) {
+  using S = SpSmem<RG, TPW>;
+  constexpr int R = S::R;
+  constexpr int CPW = RG / 4;  // cells of a step this wave gathers
+  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+  int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
+  uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
+  float* sring = reinterpret_cast<float*>(sp_smem + S::sring_off);
+  int* klist = reinterpret_cast<int*>(sp_smem + S::meta_off);
+  unsigned* cellmask = reinterpret_cast<unsigned*>(sp_smem + S::meta_off + 128);
+  int* nk_s = reinterpret_cast<int*>(sp_smem + S::meta_off + 256);
+  unsigned char* flags = reinterpret_cast<unsigned char*>(sp_smem + S::meta_off + 272);
+  float* vec = reinterpret_cast<float*>(sp_smem + S::vec_off);
+  float* rowmax = reinterpret_cast<float*>(sp_smem + S::rowmax_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int kvol = a.kvol;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int slice = blockIdx.y;
+  const int chw = slice * 64 * TPW + wave * 16 * TPW;  // first output channel of this wave
+
+  // ---- prologue: this block's rows of the neighbour table, the epilogue's per-channel vectors
+  {
+    const int64_t base = row0 * kvol, lim = a.m_out * kvol;
+    for (int idx = tid; idx < R * kvol; idx += 256) nbr_s[idx] = (base + idx < lim) ? a.nbr[base + idx] : -1;
+    if (tid < 2 * 64 * TPW) {
+      const int which = tid / (64 * TPW), ch = slice * 64 * TPW + tid % (64 * TPW);
+      const float* src = which == 0 ? a.scale : a.shift;
+      vec[tid] = (src && ch < a.cout) ? src[ch] : (which == 0 ? 1.0f : 0.0f);
+    }
+  }
+  __syncthreads();
+  if (tid < kvol * RG) {  // cell (k, g): does any of its 16 rows have a neighbour at offset k?
+    const int k = tid / RG, g = tid - k * RG;
+    bool any = false;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) any |= nbr_s[(16 * g + jj) * kvol + k] >= 0;
+    flags[tid] = any ? 1 : 0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    unsigned mask = 0;
+    if (lane < kvol) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) mask |= (unsigned)flags[lane * RG + g] << g;
+    }
+    const unsigned long long live = __ballot(mask != 0);
+    if (lane < 32) cellmask[lane] = mask;
+    if (mask != 0) klist[__popcll(live & ((1ull << lane) - 1ull))] = lane;
+    if (lane == 0) *nk_s = __popcll(live);
+  }
+  __syncthreads();
+  const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
+  const int nchunks = a.cin / 32;
+  const int nchunks0 = a.c[0] / 32;
+  const int nsrc = a.c[1] > 0 ? 2 : 1;  // scale-ring slot = (offset index, source) & 3: re-used four steps later at the earliest
+  const int nsteps = nk * nchunks;
+  const float w_inv = a.w_hdr[0];
+
+  sp_f32x4 acc[RG][TPW], D[RG][TPW];
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  // ---- the pipeline's two producers
+  auto issue_x = [&](int step) -> int {  // LDS-DMA of this wave's share of step `step`; returns the VMEM operations issued
+    if (step >= nsteps) return 0;
+    const int kidx = step / nchunks, c = step - kidx * nchunks;
+    const int k = __builtin_amdgcn_readfirstlane(klist[kidx]);
+    const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)cellmask[k]);
+    const int src = c < nchunks0 ? 0 : 1;
+    const int kc = src ? c - nchunks0 : c;
+    const int slot = step % SP_NSLOT;
+    const int sslot = (kidx * nsrc + src) & 3;
+    int n = 0;
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      const int cc = wave * CPW + u;
+      if ((mask >> cc) & 1u) {
+        const int i = nbr_s[(16 * cc + j) * kvol + k];
+        const int64_t row = i < 0 ? a.m_in : (int64_t)i;
+        const char* p = a.x[src] + row * ((int64_t)a.c[src] * 4) + (kc * 4 + q) * 32;
+        float* dst = reinterpret_cast<float*>(xring + ((slot * RG + cc) * 2) * 64);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(p), dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(p + 16), dst + 256, 16, 0, 0);
+        n += 2;
+        if (kc == 0) {
+          __builtin_amdgcn_global_load_lds(a.sx[src] + row, sring + (sslot * RG + cc) * 64, 4, 0, 0);
+          n += 1;
+        }
+      }
+    }
+    return n;
+  };
+  auto load_w = [&](int step, sp_u32x4 (&wf)[TPW][2]) {  // this wave's A fragments of step `step` (2 * TPW loads, always)
+    const int st = step < nsteps ? step : (nsteps > 0 ? nsteps - 1 : 0);
+    const int kidx = st / nchunks, c = st - kidx * nchunks;
+    const int k = nsteps > 0 ? __builtin_amdgcn_readfirstlane(klist[kidx]) : 0;
+    const sp_u32x4* p = a.w + ((((int64_t)slice * kvol + k) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[t][pl]) : "v"(p + (t * 2 + pl) * 64) : "memory");
+  };
+  auto compute = [&](int step, sp_u32x4 (&wf)[TPW][2]) {
+    const int kidx = step / nchunks, c = step - kidx * nchunks;
+    const int k = __builtin_amdgcn_readfirstlane(klist[kidx]);
+    const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)cellmask[k]);
+    const int src = c < nchunks0 ? 0 : 1;
+    const int slot = step % SP_NSLOT;
+    const bool fold = (c == nchunks0 - 1) || (c == nchunks - 1);  // last chunk of a source: fold D with the row scales
+    const int sslot = (kidx * nsrc + src) & 3;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      if ((mask >> g) & 1u) {
+        const uint4* xs = xring + ((slot * RG + g) * 2) * 64 + lane;
+        const sp_f16x8 xh = __builtin_bit_cast(sp_f16x8, xs[0]);
+        const sp_f16x8 xl = __builtin_bit_cast(sp_f16x8, xs[64]);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sp_f16x8, wf[t][1]), xh, D[g][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sp_f16x8, wf[t][0]), xl, D[g][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+          D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sp_f16x8, wf[t][0]), xh, D[g][t], 0, 0, 0);
+      }
+    }
+    if (fold) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        if ((mask >> g) & 1u) {
+          const float inv = __fmul_rn(sring[(sslot * RG + g) * 64 + lane], w_inv);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(D[g][t][r], inv, acc[g][t][r]);
+            D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    }
+  };
+
+  // ---- main loop.  VMEM issue order: X(0) W(0) X(1) | step s: W(s+1) X(s+2).  At the top of step s the newest group in
+  // flight is X(s+1): waiting until only that many operations are outstanding has W(s) and X(s) landed.
+  sp_u32x4 wa[TPW][2], wb[TPW][2];
+  issue_x(0);
+  load_w(0, wa);
+  int nx1 = issue_x(1);
+  auto body = [&](int s, sp_u32x4 (&wcur)[TPW][2], sp_u32x4 (&wnext)[TPW][2]) {
+    sp_wait_vm_n(nx1);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) asm volatile("" : "+v"(wcur[t][pl]));
+    __builtin_amdgcn_s_barrier();  // every wave's share of X(s) has landed; slot (s + 2) % 3 (= step s - 1) is free
+    asm volatile("" ::: "memory");
+    load_w(s + 1, wnext);
+    nx1 = issue_x(s + 2);
+    compute(s, wcur);
+  };
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    body(s, wa, wb);
+    body(s + 1, wb, wa);
+  }
+  if (s < nsteps) body(s, wa, wb);
+  sp_wait_vm<0>();  // (the clamped weight loads of the last steps)
+
+  // ---- epilogue: lane (j, q) holds channels chw + 16 t + 4 q + r of rows row0 + 16 g + j
+  const bool affine = a.scale || a.shift;
+  float amax[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const int64_t row = row0 + 16 * g + j;
+    amax[g] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int chl = wave * 16 * TPW + 16 * t + 4 * q;  // channel within the slice
+      const int ch = slice * 64 * TPW + chl;
+      sp_f32x4 y = acc[g][t];
+      if (affine) {
+        const float4 sc = *reinterpret_cast<const float4*>(vec + chl);
+        const float4 sh = *reinterpret_cast<const float4*>(vec + 64 * TPW + chl);
+        y[0] = __fmaf_rn(y[0], sc.x, sh.x); y[1] = __fmaf_rn(y[1], sc.y, sh.y);
+        y[2] = __fmaf_rn(y[2], sc.z, sh.z); y[3] = __fmaf_rn(y[3], sc.w, sh.w);
+      }
+      if (row < a.m_out && ch < a.cout) {
+        if (a.residual) {
+          const float4 rs = *reinterpret_cast<const float4*>(a.residual + row * a.cout + ch);
+          y[0] = __fadd_rn(y[0], rs.x); y[1] = __fadd_rn(y[1], rs.y); y[2] = __fadd_rn(y[2], rs.z); y[3] = __fadd_rn(y[3], rs.w);
+        }
+        if (a.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
+        if (a.out) *reinterpret_cast<float4*>(a.out + row * a.cout + ch) = make_float4(y[0], y[1], y[2], y[3]);
+      } else {
+        y = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      acc[g][t] = y;
+      amax[g] = fmaxf(amax[g], fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+    }
+  }
+  if (a.out_planes) {  // the output as planes for the next convolution: row scale over this 64*TPW-channel slice
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      float m = amax[g];
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (q == 0) rowmax[wave * R + 16 * g + j] = m;
+    }
+    __syncthreads();
+    const int nchunk_out = (a.cout + 64 * TPW - 1) / (64 * TPW);
+    const int blocks_per_row = a.cout / 8;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const int64_t row = row0 + 16 * g + j;
+      const int rl = 16 * g + j;
+      const float m = fmaxf(fmaxf(rowmax[rl], rowmax[R + rl]), fmaxf(rowmax[2 * R + rl], rowmax[3 * R + rl]));
+      float sc, inv;
+      sp_pick_scale(m, sc, inv);
+      if (row < a.m_out) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int ch = chw + 16 * t + 4 * q;
+          if (ch < a.cout) {
+            const float v4[4] = {acc[g][t][0], acc[g][t][1], acc[g][t][2], acc[g][t][3]};
+            sp_u32x2 hi, lo;
+            sp_split4(v4, sc, hi, lo);
+            char* dst = reinterpret_cast<char*>(a.out_planes + (row * blocks_per_row + (ch >> 3)) * 2) + (q & 1) * 8;
+            *reinterpret_cast<sp_u32x2*>(dst) = hi;
+            *reinterpret_cast<sp_u32x2*>(dst + 16) = lo;
+          }
+        }
+        if (wave == 0 && q == 0) a.out_scales[row * nchunk_out + slice] = inv;
+      }
+    }
+    if (blockIdx.x == gridDim.x - 1) {  // the zero row a missing neighbour reads
+      const int nu4 = 64 * TPW / 8 * 2;
+      const int b0 = slice * (64 * TPW / 8);
+      if (tid < nu4 && b0 + tid / 2 < blocks_per_row)
+        a.out_planes[(a.m_out * blocks_per_row + b0) * 2 + tid] = make_uint4(0, 0, 0, 0);
+      if (tid == 0) a.out_scales[a.m_out * nchunk_out + slice] = 1.0f;
+    }
+  }
+}
+
+}  // namespace fsf
+
+using namespace fsf;
+
+static int sp_tpw(int cout) { return cout >= 128 ? 2 : 1; }
+static int sp_nslice(int cout) { return (cout + 64 * sp_tpw(cout) - 1) / (64 * sp_tpw(cout)); }
+
+extern "C" int64_t fsf_planes_bytes(int64_t m, int32_t c) { return m < 0 || c < 8 ? 0 : (m + 1) * (int64_t)c * 4; }
+extern "C" int64_t fsf_planes_scale_count(int64_t m, int32_t c) { return m < 0 || c < 8 ? 0 : (m + 1) * (int64_t)((c + 127) / 128); }
+
+extern "C" int fsf_to_planes(const float* feat, int64_t m, int32_t c, int64_t row_stride, void* planes, float* scales, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || c < 8 || (c % 8) != 0 || row_stride < c || !planes || !scales || (m > 0 && !feat)) return FSF_ERR_INVALID_ARG;
+  if (((uintptr_t)feat % 16) != 0 || (row_stride % 4) != 0) return FSF_ERR_UNSUPPORTED;
+  const int64_t teams = (m + 1) * ((c + 127) / 128);
+  hipLaunchKernelGGL(to_planes_kernel, dim3(fsf_stream_grid(teams * 16, 256)), dim3(256), 0, stream, feat, m, (int)c, row_stride,
+                     (uint4*)planes, scales);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int64_t fsf_spconv_planes_weight_bytes(int32_t kvol, int32_t cin, int32_t cout) {
+  if (kvol < 1 || cin < 32 || (cin % 32) != 0 || cout < 1) return 0;
+  return SP_HDR_BYTES + (int64_t)sp_nslice(cout) * kvol * (cin / 32) * 4 * sp_tpw(cout) * 2 * 64 * 16;
+}
+
+extern "C" int fsf_spconv_prepare_weight_planes(const float* weight, int32_t kvol, int32_t cin, int32_t cout, void* planes,
+                                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!weight || !planes || kvol < 1 || cin < 32 || (cin % 32) != 0 || cout < 1) return FSF_ERR_INVALID_ARG;
+  FSF_HIP_TRY(hipMemsetAsync(planes, 0, SP_HDR_BYTES, stream));
+  const int64_t n = (int64_t)kvol * cin * cout;
+  hipLaunchKernelGGL(sp_weight_absmax_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, weight, n, (unsigned*)planes);
+  const int tpw = sp_tpw(cout), nslice = sp_nslice(cout);
+  const int64_t total = (int64_t)nslice * kvol * (cin / 32) * 4 * tpw * 64;
+  hipLaunchKernelGGL(sp_weight_planes_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)kvol, (int)cin,
+                     (int)cout, tpw, nslice, (float*)planes, (uint4*)((char*)planes + SP_HDR_BYTES));
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_t ca, const void* xb, const float* sb, int32_t cb,
+                                         int64_t m_in, const void* wplanes, int32_t kvol, int32_t cout, const int32_t* nbr,
+                                         int64_t m_out, const float* scale, const float* shift, const float* residual, int32_t relu,
+                                         float* out, void* out_planes, float* out_scales, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m_in < 0 || m_out < 0 || kvol < 1 || cout < 1 || !wplanes || !xa || !sa || ca < 32 || (xb && (!sb || cb < 32)) ||
+      (scale && !shift) || (m_out > 0 && (!nbr || (!out && !out_planes))) || (out_planes && !out_scales))
+    return FSF_ERR_INVALID_ARG;
+  if (!xb) cb = 0;
+  if (kvol > SP_KVOL_MAX || (ca % 32) != 0 || (cb % 32) != 0 || ca > 128 || cb > 128 || (cout != 64 && (cout % 128) != 0) ||
+      ((uintptr_t)out % 16) != 0 || ((uintptr_t)residual % 16) != 0)
+    return FSF_ERR_UNSUPPORTED;
+  if (m_out == 0) return FSF_OK;
+  SpArgs a;
+  a.x[0] = (const char*)xa; a.x[1] = (const char*)xb;
+  a.sx[0] = sa; a.sx[1] = sb;
+  a.c[0] = ca; a.c[1] = cb;
+  a.w = (const sp_u32x4*)((const char*)wplanes + SP_HDR_BYTES);
+  a.w_hdr = (const float*)wplanes;
+  a.nbr = nbr; a.m_in = m_in; a.m_out = m_out;
+  a.kvol = kvol; a.cin = ca + cb; a.cout = cout; a.relu = relu;
+  a.scale = scale; a.shift = shift; a.residual = residual;
+  a.out = out; a.out_planes = (uint4*)out_planes; a.out_scales = out_scales;
+  const int tpw = sp_tpw(cout), nslice = sp_nslice(cout);
+  const bool big = m_out >= 65536;
+#define FSF_SP(RG_, TPW_)                                                                                                   \
+  do {                                                                                                                     \
+    using S = SpSmem<RG_, TPW_>;                                                                                           \
+    static std::atomic<uint64_t> attr_done{0};                                                                             \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_planes_kernel<RG_, TPW_>, (int)S::bytes, attr_done));      \
+    const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                              \
+    hipLaunchKernelGGL((spconv_fwd_planes_kernel<RG_, TPW_>), grid, dim3(256), S::bytes, stream, a);                       \
+  } while (0)
+  if (big && tpw == 2) FSF_SP(8, 2);
+  else if (big) FSF_SP(8, 1);
+  else if (tpw == 2) FSF_SP(4, 2);
+  else FSF_SP(4, 1);
+#undef FSF_SP
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}

@@ -54,6 +54,13 @@ _ARGTYPES = {
     "fsf_spconv_prepare_weight_split": [_P, c_i32, c_i32, c_i32, _P, _P],
     "fsf_spconv_split_workspace_bytes": [c_i64, c_i32, c_i32, c_i32],
     "fsf_spconv_forward_split": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
+    "fsf_planes_bytes": [c_i64, c_i32],
+    "fsf_planes_scale_count": [c_i64, c_i32],
+    "fsf_to_planes": [_P, c_i64, c_i32, c_i64, _P, _P, _P],
+    "fsf_spconv_planes_weight_bytes": [c_i32, c_i32, c_i32],
+    "fsf_spconv_prepare_weight_planes": [_P, c_i32, c_i32, c_i32, _P, _P],
+    "fsf_spconv_forward_planes": [_P, _P, c_i32, _P, _P, c_i32, c_i64, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, _P,
+                                  _P],
     "fsf_channel_group_sum_add": [_P, c_i64, c_i32, c_i32, _P, _P, _P],
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
@@ -436,6 +443,82 @@ def spconv_forward_split(feat: torch.Tensor, planes: torch.Tensor, kvol: int, co
                                      ptr(residual), int(bool(relu)), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_spconv_forward_split")
     return out
+
+
+class Planes:
+    """A feature tensor in K9c's plane form (fsf_to_planes): `data` u8 [(m + 1) * c * 4] = [m + 1][c / 8][2][8] f16 hi / lo of
+    the row-scaled values (row m = zeros), `scales` f32 [m + 1, ceil(c / 128)] = the inverse row scales."""
+
+    __slots__ = ("data", "scales", "m", "c")
+
+    def __init__(self, data, scales, m, c):
+        self.data, self.scales, self.m, self.c = data, scales, int(m), int(c)
+
+
+def planes_empty(m: int, c: int, device):
+    h = _L()
+    data = torch.empty(max(h.fsf_planes_bytes(m, c), 16), dtype=torch.uint8, device=device)
+    scales = torch.empty((m + 1, (c + 127) // 128), dtype=torch.float32, device=device)
+    return Planes(data, scales, m, c)
+
+
+def to_planes(feat: torch.Tensor) -> Planes:
+    """fsf_to_planes: f32 [m, c] (rows may be strided, c % 8 == 0) -> Planes."""
+    require_cuda(feat)
+    assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.size(1) % 8 == 0
+    feat, stride = _rows_view(feat)
+    if stride % 4 or feat.data_ptr() % 16:
+        feat, stride = feat.contiguous(), feat.size(1)
+    m, c = feat.shape
+    out = planes_empty(m, c, feat.device)
+    check(_L().fsf_to_planes(c_p(feat.data_ptr()) if m else c_p(None), m, c, stride, ptr(out.data), ptr(out.scales), stream_ptr()),
+          "fsf_to_planes")
+    return out
+
+
+def spconv_prepare_weight_planes(weight: torch.Tensor):
+    """fsf_spconv_prepare_weight_planes: spconv v1 weight f32 [kvol, cin, cout] -> opaque f16 fragment planes (K9c)."""
+    require_cuda(weight)
+    weight = weight.detach().contiguous()
+    kvol, cin, cout = weight.shape
+    h = _L()
+    planes = torch.empty(h.fsf_spconv_planes_weight_bytes(kvol, cin, cout), dtype=torch.uint8, device=weight.device)
+    check(h.fsf_spconv_prepare_weight_planes(ptr(weight), kvol, cin, cout, ptr(planes), stream_ptr()),
+          "fsf_spconv_prepare_weight_planes")
+    return planes
+
+
+def spconv_planes_supported(cins, cout: int, kvol: int) -> bool:
+    """Shapes K9c takes: one or two sources of 32..128 channels (multiples of 32), cout 64 or a multiple of 128, kvol <= 27."""
+    return (1 <= len(cins) <= 2 and all(32 <= c <= 128 and c % 32 == 0 for c in cins) and (cout == 64 or cout % 128 == 0)
+            and kvol <= 27)
+
+
+def spconv_forward_planes(sources, wplanes: torch.Tensor, kvol: int, cout: int, nbr: torch.Tensor, scale=None, shift=None,
+                          residual=None, relu=False, want_out=True, want_planes=False):
+    """fsf_spconv_forward_planes (K9c): `sources` = [Planes] or [Planes, Planes] (channel concatenation), wplanes from
+    spconv_prepare_weight_planes, nbr i32 [m_out, kvol] -> (out f32 [m_out, cout] or None, Planes of the output or None)."""
+    require_cuda(wplanes, nbr, scale, shift, residual)
+    nbr = nbr.contiguous()
+    assert nbr.size(1) == kvol and nbr.dtype == torch.int32 and 1 <= len(sources) <= 2 and (want_out or want_planes)
+    a = sources[0]
+    b = sources[1] if len(sources) > 1 else None
+    m_in, m_out = a.m, nbr.size(0)
+    assert b is None or b.m == m_in
+    dev = nbr.device
+    out = torch.empty((m_out, cout), dtype=torch.float32, device=dev) if want_out else None
+    op = planes_empty(m_out, cout, dev) if want_planes else None
+    scale = scale.contiguous() if scale is not None else None
+    shift = shift.contiguous() if shift is not None else None
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == (m_out, cout)
+    check(_L().fsf_spconv_forward_planes(ptr(a.data), ptr(a.scales), a.c, ptr(b.data) if b else c_p(None),
+                                         ptr(b.scales) if b else c_p(None), b.c if b else 0, m_in, ptr(wplanes), kvol, cout,
+                                         ptr(nbr), m_out, ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(out),
+                                         ptr(op.data) if op else c_p(None), ptr(op.scales) if op else c_p(None), stream_ptr()),
+          "fsf_spconv_forward_planes")
+    return out, op
 
 
 def linear_backward_weight(x: torch.Tensor, grad_out: torch.Tensor):

@@ -45,6 +45,11 @@ class SimpleSparseUNet(nn.Module):
                                                      indice_key="subm1", conv_type="SubMConv3d", order=self.order)
         enc_out = self.make_encoder_layers(norm_cfg, base_channels)
         self.make_decoder_layers(norm_cfg, enc_out)
+        # plane-form outputs (K9c) are for layers whose consumer is another submanifold convolution: not the merge layers
+        # (their output only meets the channel-reduced concat) nor the last upsample (its output goes to the neck)
+        for lvl in range(1, self.stage_num + 1):
+            getattr(self, f"merge_layer{lvl}")[0].emit_planes = False
+        self.upsample_layer1[0].emit_planes = False
 
     def make_encoder_layers(self, norm_cfg, in_channels):
         self.encoder_layers = SparseSequential()
@@ -95,7 +100,14 @@ class SimpleSparseUNet(nn.Module):
 
     def decoder_layer_forward(self, x_lateral, x_bottom, lateral_layer, merge_layer, upsample_layer):
         x = lateral_layer(x_lateral)
+        lat_planes, bot_planes = x.plane_sources, x_bottom.plane_sources
         x = x._like(torch.cat((x_bottom.features, x.features), dim=1))
+        if lat_planes is not None and len(lat_planes) == 1 and x_bottom.features.size(1) <= 128 and x_bottom.features.size(1) % 32 == 0:
+            # the merge layer reads the concatenation as two plane sources: the lateral block's own plane-form output and
+            # a conversion of the bottom-up features (the fp32 concat above is still what the channel reduction reads)
+            if bot_planes is None or len(bot_planes) != 1:
+                bot_planes = [hip_ops.to_planes(x_bottom.features)]
+            x.plane_sources = [bot_planes[0], lat_planes[0]]
         x_merge = merge_layer(x)
         cout, f = x_merge.features.shape[1], x.features
         if (f.is_cuda and f.dtype == torch.float32 and not (torch.is_grad_enabled() and (f.requires_grad or x_merge.features.requires_grad))

@@ -25,6 +25,8 @@ class SparseConvTensor:
         self.batch_size = int(batch_size)
         self.indice_dict = {}
         self.grid = grid
+        # K9c plane form of `features` (hip_ops.Planes, one per source of a channel concatenation), when a producer emitted it
+        self.plane_sources = None
 
     @property
     def spatial_size(self):
@@ -210,6 +212,40 @@ class SparseConvolution(SparseModule):
             self.__dict__["_wsplit_cache"] = cache
         return cache[1]
 
+    # K9c (pre-split f16 planes, cell skipping): the submanifold layers of the fine levels.  Below ~16 k rows the launch
+    # does not fill the chip and K9b's offset splits win.
+    PLANES_MIN_ROWS = int(os.environ.get("FSF_PLANES_MIN_ROWS", "16384"))
+    emit_planes = True   # plane-form output next to the fp32 one (the consumer is another K9c layer); the U-Net clears it where not
+
+    def _weight_planes(self):
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        cache = self.__dict__.get("_wplanes_cache")
+        if cache is None or cache[0] != key:
+            kvol = math.prod(self.kernel_size)
+            cache = (key, hip_ops.spconv_prepare_weight_planes(w.detach().reshape(kvol, self.in_channels, self.out_channels)))
+            self.__dict__["_wplanes_cache"] = cache
+        return cache[1]
+
+    def _plane_sources(self, x):
+        """The input in plane form: what the producer emitted, else a conversion of the fp32 features (<= 128 channels per
+        source; a 256-channel input is the concatenation of two halves)."""
+        srcs = x.plane_sources
+        if srcs is not None and sum(p.c for p in srcs) == self.in_channels and all(p.m == x.features.size(0) for p in srcs):
+            return srcs
+        f = x.features
+        if self.in_channels <= 128:
+            return [hip_ops.to_planes(f)]
+        half = self.in_channels // 2
+        return [hip_ops.to_planes(f[:, :half]), hip_ops.to_planes(f[:, half:])]
+
+    def _use_planes_kernel(self, x, m_out):
+        if not (self.subm and m_out >= self.PLANES_MIN_ROWS and os.environ.get("FSF_PLANES", "1") != "0"):
+            return False
+        cin = self.in_channels
+        cins = [p.c for p in x.plane_sources] if x.plane_sources is not None else ([cin] if cin <= 128 else [cin // 2, cin - cin // 2])
+        return sum(cins) == cin and hip_ops.spconv_planes_supported(cins, self.out_channels, math.prod(self.kernel_size))
+
     def forward(self, x, scale=None, shift=None, residual=None, relu=False):
         """x: SparseConvTensor.  The optional epilogue arguments are the eval-mode BN affine / residual / ReLU
         that SparseSequential and SparseBasicBlock fold into the conv launch."""
@@ -234,6 +270,13 @@ class SparseConvolution(SparseModule):
                 out = out + residual
             if relu:
                 out = torch.relu(out)
+        elif feat.size(0) > 0 and self._use_planes_kernel(x, nbr.size(0)):
+            out, planes = hip_ops.spconv_forward_planes(self._plane_sources(x), self._weight_planes(), nbr.size(1), self.out_channels,
+                                                        nbr, scale=scale, shift=shift, residual=residual, relu=relu,
+                                                        want_planes=self.emit_planes and self.out_channels <= 128)
+            y = x._like(out, out_indices, out_shape)
+            y.plane_sources = [planes] if planes is not None else None
+            return y
         elif self._use_split_kernel(nbr.size(0)) and feat.size(0) > 0:
             out = hip_ops.spconv_forward_split(feat, self._weight_split(), nbr.size(1), self.out_channels, nbr, scale=scale,
                                                shift=shift, residual=residual, relu=relu)

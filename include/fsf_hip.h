@@ -316,6 +316,35 @@ int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t cin, const
                              const float* residual, int32_t relu, float* out, void* workspace, int64_t workspace_bytes,
                              void* stream);
 
+/* K9c  the submanifold convolution on the f16 matrix cores from PRE-SPLIT FEATURE PLANES (inference; replaces the
+ * gather -> GEMM -> scatter-add loop of spconv v1 `indice_conv`, [UNVENDORED] mmdet3d fork, for the SubMConv3d layers
+ * SimpleSparseUNet runs on its fine levels: FSF_nuScenes_config.py:58-70).
+ *
+ * Plane form of a feature tensor f32 [m, c] (c % 8 == 0): planes = [m + 1][c / 8][2][8] f16 (fsf_planes_bytes(m, c) bytes,
+ * 16-byte aligned) holding hi = rn_f16(x * s_row) and lo = rn_f16(x * s_row - hi) per 8-channel block, s_row the power of two
+ * that puts the largest magnitude of the row's 128-channel chunk into [2^13, 2^14); scales = f32 [m + 1][ceil(c / 128)], the
+ * INVERSE scale (x ~ (hi + lo) * scales).  Row m is all zeros (scale 1): the neighbour of a missing pair.  fsf_to_planes
+ * converts an fp32 tensor (rows may be strided); fsf_spconv_forward_planes can emit its own output in plane form
+ * (out_planes / out_scales non-NULL) so that a chain of convolutions splits every value exactly once.
+ *
+ * fsf_spconv_forward_planes: up to two sources (the channel concatenation [a | b], each 32..128 channels, a multiple of
+ * 32) -> out f32 [m_out, cout] (cout == 64 or cout % 128 == 0), epilogue as K9: out = act(scale * conv + shift + residual).
+ * Weights come from fsf_spconv_prepare_weight_planes (weight [kvol, ca + cb, cout] -> per-wave f16 fragment planes with one
+ * power-of-two scale per layer; fsf_spconv_planes_weight_bytes bytes).  Product = hi hi + hi lo + lo hi on
+ * v_mfma_f32_16x16x32_f16 with fp32 accumulation: relative error <= ~3 * 2^-22 per product, of the order of fp32's own
+ * accumulation error over the 27 * cin terms.  (16-row group, offset) cells without a neighbour are skipped.  No workspace,
+ * no atomics, fixed summation order: deterministic. */
+int64_t fsf_planes_bytes(int64_t m, int32_t c);
+int64_t fsf_planes_scale_count(int64_t m, int32_t c);
+int fsf_to_planes(const float* feat, int64_t m, int32_t c, int64_t row_stride, void* planes, float* scales, void* stream);
+int64_t fsf_spconv_planes_weight_bytes(int32_t kvol, int32_t cin, int32_t cout);
+int fsf_spconv_prepare_weight_planes(const float* weight, int32_t kvol, int32_t cin, int32_t cout, void* planes, void* stream);
+int fsf_spconv_forward_planes(const void* planes_a, const float* scales_a, int32_t ca, const void* planes_b,
+                              const float* scales_b, int32_t cb, int64_t m_in, const void* weight_planes, int32_t kvol,
+                              int32_t cout, const int32_t* nbr, int64_t m_out, const float* scale, const float* shift,
+                              const float* residual, int32_t relu, float* out, void* out_planes, float* out_scales,
+                              void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K10  sparse convolution backward (training)
  * Replaces: spconv v1 indice_conv_backward [UNVENDORED mmdet3d.ops.spconv] = per offset

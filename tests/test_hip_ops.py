@@ -422,6 +422,113 @@ def test_spconv_forward_split_vs_oracle_and_fp32_kernel(ops, device, m, cin, cou
     assert torch.equal(out2, ops.spconv_forward_split(f, planes, 27, cout, nbr, scale=sc, shift=sh, residual=res, relu=True))
 
 
+def decode_planes(pl):
+    """Planes -> f32 [m + 1, c] = (hi + lo) * inverse row scale, on the host (float64 arithmetic)."""
+    m, c = pl.m, pl.c
+    raw = pl.data.cpu().numpy()[: (m + 1) * c * 4].view(np.float16).reshape(m + 1, c // 8, 2, 8).astype(np.float64)
+    inv = pl.scales.cpu().numpy().astype(np.float64)  # [m + 1, nchunk]
+    val = (raw[:, :, 0, :] + raw[:, :, 1, :]).reshape(m + 1, c)
+    chunk = np.minimum(np.arange(c) // 128, inv.shape[1] - 1)
+    return val * inv[:, chunk]
+
+
+@pytest.mark.parametrize("m,c", [(1, 8), (1000, 64), (4097, 128), (300, 256), (257, 72)])
+def test_to_planes_is_a_22_bit_row_scaled_split(ops, device, m, c):
+    """fsf_to_planes: x = (hi + lo) / s_row with s_row a power of two per (row, 128-channel chunk); hi + lo reproduces x to
+    2^-21 of the chunk's largest magnitude (22 bits of every element that matters at the row's scale), the planes stay
+    inside the f16 range whatever the row's magnitude (1e-30 ... 1e30), row m is zeros with scale 1, strided input rows."""
+    rng = np.random.default_rng(m + c)
+    x = rng.standard_normal((m, c)) * np.exp(rng.standard_normal((m, 1)) * 3.0)
+    x[0] *= 1e30 if m > 1 else 1.0
+    if m > 2:
+        x[1] *= 1e-30
+        x[2] = 0.0
+    x = x.astype(np.float32)
+    buf = torch.full((m, c + 12), float("nan"), device=device)
+    view = buf[:, 4:4 + c] if c % 4 == 0 else buf[:, :c]
+    view.copy_(torch.from_numpy(x).to(device))
+    for src in (torch.from_numpy(x).to(device), view):
+        pl = ops.to_planes(src)
+        got = decode_planes(pl)
+        assert np.isfinite(pl.data.cpu().numpy()[: (m + 1) * c * 4].view(np.float16).astype(np.float32)).all()
+        assert not got[m].any() and (pl.scales[m].cpu().numpy() == 1.0).all()
+        for ch in range((c + 127) // 128):
+            sl = slice(128 * ch, min(c, 128 * ch + 128))
+            amax = np.abs(x[:, sl]).max(1, keepdims=True).astype(np.float64)
+            err = np.abs(got[:m, sl] - x[:, sl].astype(np.float64))
+            assert (err <= amax * 2.0 ** -21 + 1e-300).all()
+            inv = pl.scales[:m, ch].cpu().numpy().astype(np.float64)
+            assert (np.log2(inv) == np.round(np.log2(inv))).all()  # powers of two: the scaling is exact
+            top = amax[:, 0] / inv
+            assert ((top >= 2.0 ** 13) & (top < 2.0 ** 14) | (amax[:, 0] == 0)).all()
+
+
+@pytest.mark.parametrize("m,cins,cout", [(70000, (128,), 128), (70000, (128, 128), 128), (90000, (64,), 64), (66000, (64,), 128),
+                                         (20000, (128,), 128), (5000, (64, 128), 128), (3000, (128,), 256), (300, (32,), 64), (17, (128,), 128)])
+def test_spconv_forward_planes_vs_float64(ops, device, m, cins, cout):
+    """K9c (pre-split f16 planes, 3 MFMAs per fp32-equivalent product, cell skipping) against float64 on sampled rows — error
+    of the size of the fp32-pipe kernel's own —, against the K9b kernel, with one and two sources (the decoder's channel
+    concatenation), the fused epilogue, the plane-form output (what the next layer consumes) and bitwise determinism.  Rows
+    of very different magnitude share an MFMA (per-row scales)."""
+    rng = np.random.default_rng(m + sum(cins) + cout)
+    small = m <= 5000
+    shape = (16, 48, 48) if small else (40, 512, 512)
+    bs = 2 if small else 1
+    idx = surface_sites(rng, bs, shape, m)
+    n = idx.shape[0]
+    cin = sum(cins)
+    feat = (rng.standard_normal((n, cin)) * np.exp(rng.standard_normal((n, 1)) * 1.5)).astype(np.float32)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 6)).astype(np.float32)
+    nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), bs, shape)
+    f, wd = torch.from_numpy(feat).to(device), torch.from_numpy(w).to(device)
+    assert ops.spconv_planes_supported(cins, cout, 27)
+    wpl = ops.spconv_prepare_weight_planes(wd)
+    srcs, c0 = [], 0
+    for c in cins:
+        srcs.append(ops.to_planes(f[:, c0:c0 + c]))  # a column slice: row-strided input
+        c0 += c
+    out, opl = ops.spconv_forward_planes(srcs, wpl, 27, cout, nbr, want_planes=True)
+    rows = torch.from_numpy(rng.choice(n, size=min(n, 512), replace=False)).to(device)
+    nb = nbr.index_select(0, rows).long()
+    gathered = torch.where((nb >= 0)[:, :, None], f.double()[nb.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=device))
+    want64 = torch.einsum("rkc,kcd->rd", gathered, wd.double())
+    scale_ = max(1.0, float(want64.abs().max()))
+    err = float((out.index_select(0, rows).double() - want64).abs().max())
+    assert err <= 1e-5 * scale_, (err, scale_)
+    if cin % 16 == 0:
+        ref = ops.spconv_forward(f, ops.spconv_transpose_weight(wd), nbr)
+        err32 = float((ref.index_select(0, rows).double() - want64).abs().max())
+        assert err <= max(4.0 * err32, 4e-6 * scale_), (err, err32)
+        assert float((out - ref).abs().max()) <= 2e-5 * scale_  # every row, against the fp32-pipe kernel
+    # the plane-form output decodes to the fp32 output (22-bit split of it)
+    dec = decode_planes(opl)
+    o64 = out.cpu().numpy().astype(np.float64)
+    for ch in range((cout + 127) // 128):
+        sl = slice(128 * ch, min(cout, 128 * ch + 128))
+        amax = np.abs(o64[:, sl]).max(1, keepdims=True)
+        assert (np.abs(dec[:n, sl] - o64[:, sl]) <= amax * 2.0 ** -21 + 1e-300).all()
+    assert not dec[n].any()
+    # fused epilogue + residual + ReLU, planes only / fp32 only outputs, determinism
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(device)
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(device)
+    out2, opl2 = ops.spconv_forward_planes(srcs, wpl, 27, cout, nbr, scale=sc, shift=sh, residual=res, relu=True, want_planes=True)
+    want2 = torch.relu(out * sc + sh + res)
+    assert float((out2 - want2).abs().max()) <= 1e-5 * max(1.0, float(want2.abs().max()))
+    out3, none = ops.spconv_forward_planes(srcs, wpl, 27, cout, nbr, scale=sc, shift=sh, residual=res, relu=True)
+    assert none is None and torch.equal(out2, out3)
+    none, opl3 = ops.spconv_forward_planes(srcs, wpl, 27, cout, nbr, scale=sc, shift=sh, residual=res, relu=True, want_out=False,
+                                           want_planes=True)
+    assert none is None and torch.equal(opl3.data, opl2.data) and torch.equal(opl3.scales, opl2.scales)
+    # a chain: the plane-form output feeds the next layer exactly like a fresh conversion of the fp32 output
+    if cout in (64, 128):
+        w2 = torch.from_numpy((rng.standard_normal((27, cout, 64)) / np.sqrt(cout * 6)).astype(np.float32)).to(device)
+        wpl2 = ops.spconv_prepare_weight_planes(w2)
+        a_, _ = ops.spconv_forward_planes([opl2], wpl2, 27, 64, nbr)
+        b_, _ = ops.spconv_forward_planes([ops.to_planes(out2)], wpl2, 27, 64, nbr)
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("m,cin,cout", [(100000, 128, 128), (36000, 256, 128), (7500, 256, 256), (1500, 512, 512)])
 def test_spconv_forward_full_size_properties(ops, device, m, cin, cout):
     """BASELINE-size layers (the persistent work-queue kernel with 1..9 offset splits, stealing across XCD queues, in-kernel

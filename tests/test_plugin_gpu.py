@@ -244,6 +244,32 @@ def test_sparse_unet_vs_oracle(fsf_pair, frame1, device):
     close(neck_out, ex["neck"])
 
 
+def test_sparse_unet_on_the_planes_kernel_vs_oracle(fsf_pair, frame1, device, monkeypatch):
+    """The same U-Net comparison with K9c (pre-split f16 planes) forced onto every submanifold layer it supports (the
+    1-sweep levels are below its row threshold otherwise): plane-form hand-over between layers, the two-source merge
+    layers, the 64 / 128 / 256-channel variants, small row blocks."""
+    from fullysparsefusion_amd import hip_ops
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import spconv as sp
+
+    model, cpu = fsf_pair
+    pts = torch.from_numpy(frame1["points"][:, :5].copy())
+    ex = omod.segmentor_extract_feat(cpu.segmentor, [pts])
+    calls = []
+    orig = hip_ops.spconv_forward_planes
+
+    def spy(sources, *a, **k):
+        calls.append(([p.c for p in sources], a[2]))
+        return orig(sources, *a, **k)
+
+    monkeypatch.setattr(hip_ops, "spconv_forward_planes", spy)
+    monkeypatch.setattr(sp.SparseConvolution, "PLANES_MIN_ROWS", 64)
+    with torch.no_grad():
+        out = model.segmentor.backbone(dict(voxel_feats=ex["voxel_feats"].to(device), voxel_coors=ex["voxel_coors"].to(device),
+                                            batch_size=1))[0]["voxel_feats"]
+    close(out, ex["unet"])
+    assert len(calls) >= 20 and ([128, 128], 128) in calls and ([64], 64) in calls and any(c[1] == 256 for c in calls)
+
+
 def test_sparse_unet_training_backward_vs_oracle(plugin, device):
     """Config-3 'fwd+bwd' on the backbone: training-mode SimpleSparseUNet (batch-stat norms) forward and the gradients
     of every conv weight / norm parameter / the input features, against autograd through the CPU restatement."""
