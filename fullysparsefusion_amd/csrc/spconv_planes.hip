@@ -35,14 +35,14 @@ typedef float sp_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned sp_u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SP_NSLOT = 3;      // gathered-row ring: step s computes slot s % 3 while s + 2 is landing
+constexpr int SP_NSLOT = 2;      // gathered-row ring in LDS: step s is multiplied from slot s % 2 while X(s + 1) is written to the other
 constexpr int SP_KVOL_MAX = 27;
 constexpr int SP_HDR_BYTES = 256;  // weight-plane header: [0] inverse weight scale, [1] weight scale, [2] max |w| bits
 
 // power of two s with s * amax in [2^13, 2^14); inv = 1 / s (both exact)
 __device__ __forceinline__ void sp_pick_scale(float amax, float& s, float& inv) {
   int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
-  e = amax > 0.0f ? (e < -100 ? -100 : e > 100 ? 100 : e) : 13;
+  e = amax > 0.0f ? (e < -113 ? -113 : e) : 13;  // (s and inv stay normal fp32 numbers for every finite amax)
   s = __uint_as_float((unsigned)(13 - e + 127) << 23);
   inv = __uint_as_float((unsigned)(e - 13 + 127) << 23);
 }
@@ -161,29 +161,6 @@ struct SpArgs {
   float* out_scales;
 };
 
-template <int N>
-__device__ __forceinline__ void sp_wait_vm() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-}
-
-__device__ __forceinline__ void sp_wait_vm_n(int n) {  // (uniform) at most n of the newest VMEM operations may stay in flight
-  switch (n) {
-    case 0: sp_wait_vm<0>(); break;
-    case 1: sp_wait_vm<1>(); break;
-    case 2: sp_wait_vm<2>(); break;
-    case 3: sp_wait_vm<3>(); break;
-    case 4: sp_wait_vm<4>(); break;
-    case 5: sp_wait_vm<5>(); break;
-    default: sp_wait_vm<6>(); break;
-  }
-}
-
 template <int RG, int TPW>
 struct SpSmem {
   static constexpr int R = 16 * RG;
@@ -191,9 +168,9 @@ struct SpSmem {
   static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
   static constexpr size_t xring_bytes = (size_t)SP_NSLOT * RG * 2 * 1024;
   static constexpr size_t sring_off = xring_off + xring_bytes;
-  static constexpr size_t sring_bytes = (size_t)4 * RG * 64 * 4;
-  static constexpr size_t meta_off = sring_off + sring_bytes;      // klist[32] | cellmask[32] | nk | flags[27 * RG]
-  static constexpr size_t meta_bytes = 32 * 4 + 32 * 4 + 16 + (size_t)SP_KVOL_MAX * RG;
+  static constexpr size_t sring_bytes = (size_t)2 * RG * 64 * 4;
+  static constexpr size_t meta_off = sring_off + sring_bytes;      // sched[32] | nk | flags[27 * RG]
+  static constexpr size_t meta_bytes = 32 * 4 + 16 + (size_t)SP_KVOL_MAX * RG;
   static constexpr size_t vec_off = (meta_off + meta_bytes + 15) / 16 * 16;
   static constexpr size_t vec_bytes = (size_t)2 * 64 * TPW * 4;
   static constexpr size_t rowmax_off = vec_off + vec_bytes;
@@ -201,19 +178,25 @@ struct SpSmem {
   static constexpr size_t bytes = rowmax_off + rowmax_bytes;
 };
 
+// one step of the (live offset, 32-cin chunk) sequence, all scalar
+struct SpStep {
+  int kidx, c, k;
+  unsigned mask;  // live 16-row groups of the block at offset k (0 past the end of the sequence)
+};
+
 template <int RG, int TPW>
 __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel(SpArgs a) {
   using S = SpSmem<RG, TPW>;
   constexpr int R = S::R;
   constexpr int CPW = RG / 4;  // cells of a step this wave gathers
+  constexpr int HB = RG / 2;   // cells per LDS-read batch
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
   int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
   uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
   float* sring = reinterpret_cast<float*>(sp_smem + S::sring_off);
-  int* klist = reinterpret_cast<int*>(sp_smem + S::meta_off);
-  unsigned* cellmask = reinterpret_cast<unsigned*>(sp_smem + S::meta_off + 128);
-  int* nk_s = reinterpret_cast<int*>(sp_smem + S::meta_off + 256);
-  unsigned char* flags = reinterpret_cast<unsigned char*>(sp_smem + S::meta_off + 272);
+  int* sched = reinterpret_cast<int*>(sp_smem + S::meta_off);
+  int* nk_s = reinterpret_cast<int*>(sp_smem + S::meta_off + 128);
+  unsigned char* flags = reinterpret_cast<unsigned char*>(sp_smem + S::meta_off + 144);
   float* vec = reinterpret_cast<float*>(sp_smem + S::vec_off);
   float* rowmax = reinterpret_cast<float*>(sp_smem + S::rowmax_off);
 
@@ -223,7 +206,7 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
   const int slice = blockIdx.y;
   const int chw = slice * 64 * TPW + wave * 16 * TPW;  // first output channel of this wave
 
-  // ---- prologue: this block's rows of the neighbour table, the epilogue's per-channel vectors
+  // ---- prologue: this block's rows of the neighbour table, the epilogue's per-channel vectors, the step schedule
   {
     const int64_t base = row0 * kvol, lim = a.m_out * kvol;
     for (int idx = tid; idx < R * kvol; idx += 256) nbr_s[idx] = (base + idx < lim) ? a.nbr[base + idx] : -1;
@@ -242,141 +225,185 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
     flags[tid] = any ? 1 : 0;
   }
   __syncthreads();
-  if (wave == 0) {
+  if (wave == 0) {  // sched[i] = offset | live-cell mask << 8 of the i-th offset this block has any neighbour at
     unsigned mask = 0;
     if (lane < kvol) {
 #pragma unroll
       for (int g = 0; g < RG; ++g) mask |= (unsigned)flags[lane * RG + g] << g;
     }
     const unsigned long long live = __ballot(mask != 0);
-    if (lane < 32) cellmask[lane] = mask;
-    if (mask != 0) klist[__popcll(live & ((1ull << lane) - 1ull))] = lane;
+    if (lane < 32) sched[lane] = 0;
+    if (mask != 0) sched[__popcll(live & ((1ull << lane) - 1ull))] = lane | (int)(mask << 8);
     if (lane == 0) *nk_s = __popcll(live);
   }
   __syncthreads();
   const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
   const int nchunks = a.cin / 32;
   const int nchunks0 = a.c[0] / 32;
-  const int nsrc = a.c[1] > 0 ? 2 : 1;  // scale-ring slot = (offset index, source) & 3: re-used four steps later at the earliest
   const int nsteps = nk * nchunks;
   const float w_inv = a.w_hdr[0];
+  const int rowbytes0 = a.c[0] * 4, rowbytes1 = a.c[1] * 4;
+  const int nsrc = a.c[1] > 0 ? 2 : 1;
 
-  sp_f32x4 acc[RG][TPW], D[RG][TPW];
-#pragma unroll
-  for (int g = 0; g < RG; ++g)
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-      D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+  auto entry = [&](int kidx, int c) -> SpStep {
+    const int e = kidx < nk ? __builtin_amdgcn_readfirstlane(sched[kidx]) : 0;
+    return SpStep{kidx, c, e & 255, (unsigned)e >> 8};
+  };
+  auto advance = [&](const SpStep& p) -> SpStep {
+    if (p.c + 1 < nchunks) return SpStep{p.kidx, p.c + 1, p.k, p.mask};
+    return entry(p.kidx + 1, 0);
+  };
 
-  // ---- the pipeline's two producers
-  auto issue_x = [&](int step) -> int {  // LDS-DMA of this wave's share of step `step`; returns the VMEM operations issued
-    if (step >= nsteps) return 0;
-    const int kidx = step / nchunks, c = step - kidx * nchunks;
-    const int k = __builtin_amdgcn_readfirstlane(klist[kidx]);
-    const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)cellmask[k]);
-    const int src = c < nchunks0 ? 0 : 1;
-    const int kc = src ? c - nchunks0 : c;
-    const int slot = step % SP_NSLOT;
-    const int sslot = (kidx * nsrc + src) & 3;
-    int n = 0;
+  sp_f32x4 acc[RG][TPW];
+  float inv[RG];  // inverse row scale (x the weight's) of the current (offset, source), per cell, for this lane's row j
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    inv[g] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- this wave's share of a step's gather: global -> registers (a lane without a neighbour loads nothing: zeros)
+  uint4 st_hi[CPW], st_lo[CPW];
+  float st_sc[CPW];
+  auto load_x = [&](const SpStep& st) {
+    const int src = st.c < nchunks0 ? 0 : 1;
+    const int kc = src ? st.c - nchunks0 : st.c;
+    const char* xb = a.x[src];
+    const float* sb = a.sx[src];
+    const int rb = src ? rowbytes1 : rowbytes0;
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
       const int cc = wave * CPW + u;
-      if ((mask >> cc) & 1u) {
-        const int i = nbr_s[(16 * cc + j) * kvol + k];
-        const int64_t row = i < 0 ? a.m_in : (int64_t)i;
-        const char* p = a.x[src] + row * ((int64_t)a.c[src] * 4) + (kc * 4 + q) * 32;
-        float* dst = reinterpret_cast<float*>(xring + ((slot * RG + cc) * 2) * 64);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(p), dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(p + 16), dst + 256, 16, 0, 0);
-        n += 2;
-        if (kc == 0) {
-          __builtin_amdgcn_global_load_lds(a.sx[src] + row, sring + (sslot * RG + cc) * 64, 4, 0, 0);
-          n += 1;
+      st_hi[u] = make_uint4(0, 0, 0, 0);
+      st_lo[u] = make_uint4(0, 0, 0, 0);
+      st_sc[u] = 1.0f;
+      if ((st.mask >> cc) & 1u) {
+        const int i = nbr_s[(16 * cc + j) * kvol + st.k];
+        if (i >= 0) {
+#ifdef SP_ABL_NO_X
+          const char* p = xb + (int64_t)(i & 15) * rb + (kc * 4 + q) * 32;
+#else
+          const char* p = xb + (int64_t)i * rb + (kc * 4 + q) * 32;
+#endif
+          st_hi[u] = *reinterpret_cast<const uint4*>(p);
+          st_lo[u] = *reinterpret_cast<const uint4*>(p + 16);
+          if (kc == 0) st_sc[u] = sb[i];
         }
       }
     }
-    return n;
   };
-  auto load_w = [&](int step, sp_u32x4 (&wf)[TPW][2]) {  // this wave's A fragments of step `step` (2 * TPW loads, always)
-    const int st = step < nsteps ? step : (nsteps > 0 ? nsteps - 1 : 0);
-    const int kidx = st / nchunks, c = st - kidx * nchunks;
-    const int k = nsteps > 0 ? __builtin_amdgcn_readfirstlane(klist[kidx]) : 0;
-    const sp_u32x4* p = a.w + ((((int64_t)slice * kvol + k) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
+  auto store_x = [&](const SpStep& st, int slot) {  // registers -> LDS in B-fragment order (lane-linear: conflict-free)
+    const int src = st.c < nchunks0 ? 0 : 1;
+    const bool first = (src ? st.c - nchunks0 : st.c) == 0;
+    const int sslot = (st.kidx * nsrc + src) & 1;  // consecutive (offset, source) groups alternate
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      const int cc = wave * CPW + u;
+      if ((st.mask >> cc) & 1u) {
+        uint4* dst = xring + ((slot * RG + cc) * 2) * 64 + lane;
+        dst[0] = st_hi[u];
+        dst[64] = st_lo[u];
+        if (first) sring[(sslot * RG + cc) * 64 + lane] = st_sc[u];
+      }
+    }
+  };
+  auto load_w = [&](const SpStep& st, uint4 (&wf)[TPW][2]) {  // this wave's A fragments (16 * TPW channels x 32 cin, hi | lo)
+#ifdef SP_ABL_NO_W
+    if (st.kidx > 0 || st.c > 0) return;
+#endif
+    const int kidx = st.kidx < nk ? st.kidx : 0;
+    (void)kidx;
+    const uint4* p = reinterpret_cast<const uint4*>(a.w) +
+                     ((((int64_t)slice * kvol + st.k) * nchunks + st.c) * 4 + wave) * (TPW * 2 * 64) + lane;
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl)
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(wf[t][pl]) : "v"(p + (t * 2 + pl) * 64) : "memory");
+      for (int pl = 0; pl < 2; ++pl) wf[t][pl] = p[(t * 2 + pl) * 64];
   };
-  auto compute = [&](int step, sp_u32x4 (&wf)[TPW][2]) {
-    const int kidx = step / nchunks, c = step - kidx * nchunks;
-    const int k = __builtin_amdgcn_readfirstlane(klist[kidx]);
-    const unsigned mask = (unsigned)__builtin_amdgcn_readfirstlane((int)cellmask[k]);
-    const int src = c < nchunks0 ? 0 : 1;
-    const int slot = step % SP_NSLOT;
-    const bool fold = (c == nchunks0 - 1) || (c == nchunks - 1);  // last chunk of a source: fold D with the row scales
-    const int sslot = (kidx * nsrc + src) & 3;
+  auto compute = [&](const SpStep& st, int slot, const uint4 (&wf)[TPW][2]) {
+    const int src = st.c < nchunks0 ? 0 : 1;
+    const bool first = (src ? st.c - nchunks0 : st.c) == 0;
+    const int sslot = (st.kidx * nsrc + src) & 1;  // consecutive (offset, source) groups alternate
+    if (first) {  // a new (offset, source): this lane's row scale in every live cell
 #pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      if ((mask >> g) & 1u) {
-        const uint4* xs = xring + ((slot * RG + g) * 2) * 64 + lane;
-        const sp_f16x8 xh = __builtin_bit_cast(sp_f16x8, xs[0]);
-        const sp_f16x8 xl = __builtin_bit_cast(sp_f16x8, xs[64]);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-          D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sp_f16x8, wf[t][1]), xh, D[g][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-          D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sp_f16x8, wf[t][0]), xl, D[g][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-          D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sp_f16x8, wf[t][0]), xh, D[g][t], 0, 0, 0);
-      }
+      for (int g = 0; g < RG; ++g)
+        if ((st.mask >> g) & 1u) inv[g] = __fmul_rn(sring[(sslot * RG + g) * 64 + lane], w_inv);
     }
-    if (fold) {
+    sp_f16x8 wh[TPW], wl[TPW];
 #pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        if ((mask >> g) & 1u) {
-          const float inv = __fmul_rn(sring[(sslot * RG + g) * 64 + lane], w_inv);
+    for (int t = 0; t < TPW; ++t) {
+      wh[t] = __builtin_bit_cast(sp_f16x8, wf[t][0]);
+      wl[t] = __builtin_bit_cast(sp_f16x8, wf[t][1]);
+    }
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) {
+    for (int h = 0; h < 2; ++h) {
+      uint4 xh[HB], xl[HB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(D[g][t][r], inv, acc[g][t][r]);
-            D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+      for (int u = 0; u < HB; ++u) {  // the batch's LDS reads first, then its MFMAs: one exposed LDS latency per batch
+        const int g = h * HB + u;
+        if ((st.mask >> g) & 1u) {
+          const uint4* xs = xring + ((slot * RG + g) * 2) * 64 + lane;
+          xh[u] = xs[0];
+          xl[u] = xs[64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < HB; ++u) {
+        const int g = h * HB + u;
+        if ((st.mask >> g) & 1u) {
+          const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh[u]), bl = __builtin_bit_cast(sp_f16x8, xl[u]);
+          sp_f32x4 d[TPW];
+#ifdef SP_ABL_NO_MFMA
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) d[t] = sp_f32x4{__uint_as_float(xh[u].x ^ wf[t][0].x), __uint_as_float(xl[u].y ^ wf[t][1].y), 0.f, 0.f};
+#else
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+            d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, sp_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, d[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, d[t], 0, 0, 0);
+#endif
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(d[t][r], inv[g], acc[g][t][r]);
         }
       }
     }
   };
 
-  // ---- main loop.  VMEM issue order: X(0) W(0) X(1) | step s: W(s+1) X(s+2).  At the top of step s the newest group in
-  // flight is X(s+1): waiting until only that many operations are outstanding has W(s) and X(s) landed.
-  sp_u32x4 wa[TPW][2], wb[TPW][2];
-  issue_x(0);
-  load_w(0, wa);
-  int nx1 = issue_x(1);
-  auto body = [&](int s, sp_u32x4 (&wcur)[TPW][2], sp_u32x4 (&wnext)[TPW][2]) {
-    sp_wait_vm_n(nx1);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) asm volatile("" : "+v"(wcur[t][pl]));
-    __builtin_amdgcn_s_barrier();  // every wave's share of X(s) has landed; slot (s + 2) % 3 (= step s - 1) is free
-    asm volatile("" ::: "memory");
-    load_w(s + 1, wnext);
-    nx1 = issue_x(s + 2);
-    compute(s, wcur);
+  // ---- main loop.  Step s: [everything loaded during step s-1 has landed] barrier [X(s+1): registers -> LDS slot (s+1)%2]
+  // [load X(s+2) -> registers, W(s+1)] [compute step s from slot s%2].  One barrier per step: it separates the reads of
+  // step s-1 from the writes into the same slot, and the writes of X(s) (during step s-1) from their reads.
+  uint4 wa[TPW][2], wb[TPW][2];
+  SpStep s0 = entry(0, 0);
+  SpStep s1 = advance(s0);
+  load_x(s0);
+  load_w(s0, wa);
+  store_x(s0, 0);
+  load_x(s1);
+  SpStep s2 = advance(s1);
+  auto body = [&](uint4 (&wcur)[TPW][2], uint4 (&wnext)[TPW][2], int par) {
+#ifndef SP_ABL_NO_BARRIER
+    __syncthreads();
+#endif
+    store_x(s1, par ^ 1);     // X(s+1), loaded during the previous step
+    load_x(s2);               // X(s+2)
+    load_w(s1, wnext);        // W(s+1)
+    compute(s0, par, wcur);
+    s0 = s1;
+    s1 = s2;
+    s2 = advance(s2);
   };
   int s = 0;
   for (; s + 1 < nsteps; s += 2) {
-    body(s, wa, wb);
-    body(s + 1, wb, wa);
+    body(wa, wb, 0);
+    body(wb, wa, 1);
   }
-  if (s < nsteps) body(s, wa, wb);
-  sp_wait_vm<0>();  // (the clamped weight loads of the last steps)
+  if (s < nsteps) body(wa, wb, 0);
 
   // ---- epilogue: lane (j, q) holds channels chw + 16 t + 4 q + r of rows row0 + 16 g + j
   const bool affine = a.scale || a.shift;
@@ -426,8 +453,8 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
       const int64_t row = row0 + 16 * g + j;
       const int rl = 16 * g + j;
       const float m = fmaxf(fmaxf(rowmax[rl], rowmax[R + rl]), fmaxf(rowmax[2 * R + rl], rowmax[3 * R + rl]));
-      float sc, inv;
-      sp_pick_scale(m, sc, inv);
+      float sc, inv_s;
+      sp_pick_scale(m, sc, inv_s);
       if (row < a.m_out) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -441,10 +468,10 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
             *reinterpret_cast<sp_u32x2*>(dst + 16) = lo;
           }
         }
-        if (wave == 0 && q == 0) a.out_scales[row * nchunk_out + slice] = inv;
+        if (wave == 0 && q == 0) a.out_scales[row * nchunk_out + slice] = inv_s;
       }
     }
-    if (blockIdx.x == gridDim.x - 1) {  // the zero row a missing neighbour reads
+    if (blockIdx.x == gridDim.x - 1) {  // the zero row (kept for consumers that address it; scale 1)
       const int nu4 = 64 * TPW / 8 * 2;
       const int b0 = slice * (64 * TPW / 8);
       if (tid < nu4 && b0 + tid / 2 < blocks_per_row)
