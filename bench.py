@@ -232,7 +232,10 @@ def _acc_spconv(kind):
         if kind == "fp32":
             feat, weight_t, nbr = a[0], a[1], a[2]
             cin, cout = weight_t.size(2), weight_t.size(1)
-        else:  # split kernels: (feat, planes, kvol, cout, nbr)
+        elif kind == "planes":  # (sources, wplanes, kvol, cout, nbr)
+            cout, nbr = int(a[3]), a[4]
+            cin = sum(p.c for p in a[0])
+        else:  # K9b: (feat, planes, kvol, cout, nbr)
             feat, cout, nbr = a[0], int(a[3]), a[4]
             cin = feat.size(1)
         pairs = float((nbr >= 0).sum())
@@ -325,7 +328,7 @@ SPCONV_KERNELS = {
                     "v_mfma_f32_16x16x4_f32"),
     "spconv_split": ("fsf::spconv_fwd_split_kernel (bf16 MFMA x6 = exact 3-way split, row-stationary in registers)",
                      MFMA_16BIT_PEAK_TFLOPS / 6, "v_mfma_f32_16x16x32_bf16, 6 per fp32-equivalent product"),
-    "spconv_planes": ("fsf::spconv_fwd_planes_kernel (f16 MFMA x3 = 2-way scaled-f16 split, pair-dense, output tile in LDS)",
+    "spconv_planes": ("fsf::spconv_fwd_planes_kernel (f16 MFMA x3 = row-scaled 2-way f16 split, channel-stationary waves, cell skipping)",
                       MFMA_16BIT_PEAK_TFLOPS / 3, "v_mfma_f32_16x16x32_f16, 3 per fp32-equivalent product"),
 }
 

@@ -25,6 +25,8 @@
 // scale (exact: powers of two), so rows of different magnitude share an MFMA.
 // One barrier per (offset, 32-cin chunk) step; every global access of the main loop is either an LDS-DMA or an inline-asm
 // load, all waits are counted by hand (s_waitcnt vmcnt(n): the newest n may stay in flight).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace fsf {
@@ -184,8 +186,11 @@ struct SpStep {
   unsigned mask;  // live 16-row groups of the block at offset k (0 past the end of the sequence)
 };
 
+#ifndef SP_RG4_WPS
+#define SP_RG4_WPS 2  // workgroups per CU the 64-row variant is compiled for (3 and 4 measured 5-7 % slower: the compiler does better with the registers)
+#endif
 template <int RG, int TPW>
-__global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel(SpArgs a) {
+__global__ void __launch_bounds__(256, RG == 8 ? 2 : SP_RG4_WPS) spconv_fwd_planes_kernel(SpArgs a) {
   using S = SpSmem<RG, TPW>;
   constexpr int R = S::R;
   constexpr int CPW = RG / 4;  // cells of a step this wave gathers
@@ -200,7 +205,8 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
   float* vec = reinterpret_cast<float*>(sp_smem + S::vec_off);
   float* rowmax = reinterpret_cast<float*>(sp_smem + S::rowmax_off);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the per-cell tests below become scalar branches)
   const int kvol = a.kvol;
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const int slice = blockIdx.y;
@@ -254,14 +260,16 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
     return entry(p.kidx + 1, 0);
   };
 
-  sp_f32x4 acc[RG][TPW];
-  float inv[RG];  // inverse row scale (x the weight's) of the current (offset, source), per cell, for this lane's row j
+  // acc: the output tile; D: the products of the current (offset, source) group, summed over its cin chunks by the MFMA
+  // itself and folded into acc with the row's inverse scale (x the weight's) when the group ends
+  sp_f32x4 acc[RG][TPW], D[RG][TPW];
 #pragma unroll
-  for (int g = 0; g < RG; ++g) {
-    inv[g] = 0.0f;
+  for (int g = 0; g < RG; ++g)
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+    for (int t = 0; t < TPW; ++t) {
+      acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
   // ---- this wave's share of a step's gather: global -> registers (a lane without a neighbour loads nothing: zeros)
   uint4 st_hi[CPW], st_lo[CPW];
@@ -282,9 +290,9 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
         const int i = nbr_s[(16 * cc + j) * kvol + st.k];
         if (i >= 0) {
 #ifdef SP_ABL_NO_X
-          const char* p = xb + (int64_t)(i & 15) * rb + (kc * 4 + q) * 32;
+          const char* p = xb + (uint32_t)((i & 15) * rb + (kc * 4 + q) * 32);
 #else
-          const char* p = xb + (int64_t)i * rb + (kc * 4 + q) * 32;
+          const char* p = xb + (uint32_t)((uint32_t)i * (uint32_t)rb + (uint32_t)((kc * 4 + q) * 32));  // (planes < 4 GiB: checked by the host)
 #endif
           st_hi[u] = *reinterpret_cast<const uint4*>(p);
           st_lo[u] = *reinterpret_cast<const uint4*>(p + 16);
@@ -323,13 +331,8 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
   };
   auto compute = [&](const SpStep& st, int slot, const uint4 (&wf)[TPW][2]) {
     const int src = st.c < nchunks0 ? 0 : 1;
-    const bool first = (src ? st.c - nchunks0 : st.c) == 0;
+    const bool last = (st.c == nchunks0 - 1) || (st.c == nchunks - 1);  // last chunk of the (offset, source) group
     const int sslot = (st.kidx * nsrc + src) & 1;  // consecutive (offset, source) groups alternate
-    if (first) {  // a new (offset, source): this lane's row scale in every live cell
-#pragma unroll
-      for (int g = 0; g < RG; ++g)
-        if ((st.mask >> g) & 1u) inv[g] = __fmul_rn(sring[(sslot * RG + g) * 64 + lane], w_inv);
-    }
     sp_f16x8 wh[TPW], wl[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -353,23 +356,31 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_planes_kernel
         const int g = h * HB + u;
         if ((st.mask >> g) & 1u) {
           const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh[u]), bl = __builtin_bit_cast(sp_f16x8, xl[u]);
-          sp_f32x4 d[TPW];
 #ifdef SP_ABL_NO_MFMA
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) d[t] = sp_f32x4{__uint_as_float(xh[u].x ^ wf[t][0].x), __uint_as_float(xl[u].y ^ wf[t][1].y), 0.f, 0.f};
+          for (int t = 0; t < TPW; ++t) D[g][t][0] += __uint_as_float(xh[u].x ^ wf[t][0].x ^ xl[u].y ^ wf[t][1].y);
 #else
 #pragma unroll
-          for (int t = 0; t < TPW; ++t)
-            d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, sp_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, D[g][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, d[t], 0, 0, 0);
+          for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, D[g][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) d[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, d[t], 0, 0, 0);
+          for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, D[g][t], 0, 0, 0);
 #endif
+        }
+      }
+    }
+    if (last) {  // fold the group: this lane's row scale in every live cell
 #pragma unroll
-          for (int t = 0; t < TPW; ++t)
+      for (int g = 0; g < RG; ++g) {
+        if ((st.mask >> g) & 1u) {
+          const float inv = __fmul_rn(sring[(sslot * RG + g) * 64 + lane], w_inv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(d[t][r], inv[g], acc[g][t][r]);
+          for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(D[g][t][r], inv, acc[g][t][r]);
+            D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
     }
@@ -546,7 +557,9 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
   a.scale = scale; a.shift = shift; a.residual = residual;
   a.out = out; a.out_planes = (uint4*)out_planes; a.out_scales = out_scales;
   const int tpw = sp_tpw(cout), nslice = sp_nslice(cout);
-  const bool big = m_out >= 65536;
+  static const int64_t rg8_min_rows = getenv("FSF_PLANES_RG8_MIN_ROWS") ? atoll(getenv("FSF_PLANES_RG8_MIN_ROWS")) : ((int64_t)1 << 40);  // 64-row blocks (3 workgroups per CU) win at every size measured
+  const bool big = m_out >= rg8_min_rows;
+  if ((m_in + 1) * (int64_t)(ca > cb ? ca : cb) * 4 >= (int64_t)1 << 32) return FSF_ERR_UNSUPPORTED;  // 32-bit gather offsets
 #define FSF_SP(RG_, TPW_)                                                                                                   \
   do {                                                                                                                     \
     using S = SpSmem<RG_, TPW_>;                                                                                           \

