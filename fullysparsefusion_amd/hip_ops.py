@@ -15,6 +15,8 @@ from ._lib import c_f32, c_i32, c_i64, c_p, check, f32_array, i32_array, i64_arr
 
 _P = c_p
 _ARGTYPES = {
+    "fsf_assemble_sweeps_workspace_bytes": [c_i64],
+    "fsf_assemble_sweeps": [_P, c_i64, c_i32, _P, c_i32, _P, _P, _P, c_f32, _P, c_i32, c_f32, c_f32, _P, _P, _P, _P, c_i64, _P],
     "fsf_voxelize_dynamic": [_P, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P],
     "fsf_voxelize_divfloor": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P],
     "fsf_unique_rows_workspace_bytes": [c_i64, c_i32],
@@ -29,6 +31,8 @@ _ARGTYPES = {
     "fsf_voxel2point": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, _P, _P],
     "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
+    "fsf_project_score": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P, _P],
+    "fsf_project_gather_bilinear": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_rulebook_workspace_bytes": [c_i64, c_i32],
     "fsf_rulebook_subm": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, c_i64, _P],
     "fsf_rulebook_strided": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P, _P, c_i64, _P],
@@ -105,6 +109,29 @@ _MODES = {"sum": MODE_SUM, "mean": MODE_MEAN, "avg": MODE_MEAN, "max": MODE_MAX}
 
 
 # ------------------------------------------------------------------------------------------- voxelize
+def assemble_sweeps(raw: torch.Tensor, offsets, params, transform, remove_close, close_radius=1.0, pc_range=None, norm_col=3,
+                    norm_mean=0.0, norm_std=255.0):
+    """fsf_assemble_sweeps: raw f32 [n, load_dim] (key frame rows, then every sweep's) on the device + per-sweep host metadata
+    -> f32 [count, load_dim + 3] = LoadPointsFromMultiSweeps + SaveNoAugPoints (+ PointsRangeFilter) + NormalizePoints."""
+    require_cuda(raw)
+    assert raw.dtype == torch.float32 and raw.dim() == 2
+    raw = raw.contiguous()
+    n, load_dim = raw.shape
+    ns = len(offsets) - 1
+    out = torch.empty((n, load_dim + 3), dtype=torch.float32, device=raw.device)
+    count = ctypes.c_int64(0)
+    h = _L()
+    ws = _lib.workspace(h.fsf_assemble_sweeps_workspace_bytes(n), raw.device)
+    par = (ctypes.c_double * (ns * 13))(*[float(v) for row in params for v in row])
+    check(h.fsf_assemble_sweeps(ptr(raw), n, load_dim, _lib.i64_array(offsets), ns, par,
+                                (ctypes.c_uint8 * ns)(*[int(bool(v)) for v in transform]),
+                                (ctypes.c_uint8 * ns)(*[int(bool(v)) for v in remove_close]), float(close_radius),
+                                _lib.f32_array(pc_range) if pc_range is not None else c_p(None), int(norm_col), float(norm_mean),
+                                float(norm_std), ptr(out), None, ctypes.cast(ctypes.pointer(count), c_p), ptr(ws), ws.numel(),
+                                stream_ptr()), "fsf_assemble_sweeps")
+    return out[: int(count.value)]
+
+
 def voxelize_dynamic(points: torch.Tensor, voxel_size, pc_range, grid, batch_idx: int = 0, want_zyx=True,
                      want_bzyx=False):
     """fsf_voxelize_dynamic.  points f32 [n, C>=3] -> (coors_zyx i32 [n,3] | None, coors_bzyx i64 [n,4] | None)."""
@@ -294,6 +321,55 @@ def project_gather_mask(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.
     check(_L().fsf_project_gather_mask(ptr(xyz), n, xyz.size(1), ptr(lidar2img), ncam, ptr(mask), mask.element_size(),
                                        ncls, H, W, ptr(obj_id), ptr(pts_2d), stream_ptr()), "fsf_project_gather_mask")
     return (obj_id, pts_2d) if return_pts_2d else obj_id
+
+
+PROJECT_SCORE_MAX_CLS = 16
+
+
+def project_score(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.Tensor, mask_anno: torch.Tensor, score_col=4,
+                  return_ids=False, return_fg=True):
+    """fsf_project_score for ONE sample: xyz f32 [n,>=3], mask u8|i32 [ncam,ncls,H,W], mask_anno f32 [A,D] ->
+    score f32 [n,ncls] (+ ids i64 [n,ncls] of the selected camera) (+ fg bool [n]: inside any mask)."""
+    require_cuda(xyz, lidar2img, mask, mask_anno)
+    assert xyz.dtype == torch.float32 and lidar2img.dtype == torch.float32 and mask.dtype in (torch.uint8, torch.int32)
+    xyz, lidar2img, mask = xyz.contiguous(), lidar2img.contiguous(), mask.contiguous()
+    mask_anno = mask_anno.to(torch.float32).contiguous()
+    n = xyz.size(0)
+    ncam, ncls, H, W = mask.shape
+    score = torch.empty((n, ncls), dtype=torch.float32, device=xyz.device)
+    ids = torch.empty((n, ncls), dtype=torch.int64, device=xyz.device) if return_ids else None
+    fg = torch.empty((n,), dtype=torch.uint8, device=xyz.device) if return_fg else None
+    check(_L().fsf_project_score(ptr(xyz), n, xyz.size(1), ptr(lidar2img), ncam, ptr(mask), mask.element_size(), ncls, H, W,
+                                 ptr(mask_anno), mask_anno.size(0), mask_anno.size(1), int(score_col), ptr(score), ptr(ids),
+                                 ptr(fg), stream_ptr()), "fsf_project_score")
+    out = (score,)
+    if return_ids:
+        out += (ids,)
+    if return_fg:
+        out += (fg.bool(),)
+    return out if len(out) > 1 else score
+
+
+def project_gather_bilinear(xyz: torch.Tensor, lidar2img: torch.Tensor, feat: torch.Tensor, img_hw, channels_last=False,
+                            reduce_cams=False, return_count=False):
+    """fsf_project_gather_bilinear for ONE sample: xyz f32 [n,>=3], lidar2img f32 [ncam,4,4], feat f32 [ncam,C,Hf,Wf]
+    (or [ncam,Hf,Wf,C] with channels_last) -> f32 [n,ncam,C] (or [n,C] summed over the cameras that see the point);
+    grid_sample(bilinear, align_corners=False, zeros) at the projection of FSF.prj_points_2d."""
+    require_cuda(xyz, lidar2img, feat)
+    assert xyz.dtype == torch.float32 and lidar2img.dtype == torch.float32 and feat.dtype == torch.float32 and feat.dim() == 4
+    xyz, lidar2img, feat = xyz.contiguous(), lidar2img.contiguous(), feat.contiguous()
+    n = xyz.size(0)
+    if channels_last:
+        ncam, hf, wf, c = feat.shape
+    else:
+        ncam, c, hf, wf = feat.shape
+    assert lidar2img.shape == (ncam, 4, 4)
+    out = torch.empty((n, c) if reduce_cams else (n, ncam, c), dtype=torch.float32, device=xyz.device)
+    count = torch.empty((n,), dtype=torch.uint8, device=xyz.device) if return_count else None
+    check(_L().fsf_project_gather_bilinear(ptr(xyz), n, xyz.size(1), ptr(lidar2img), ncam, ptr(feat), c, hf, wf,
+                                           int(bool(channels_last)), int(img_hw[0]), int(img_hw[1]), int(bool(reduce_cams)),
+                                           ptr(out), ptr(count), stream_ptr()), "fsf_project_gather_bilinear")
+    return (out, count) if return_count else out
 
 
 def cam_select_score(obj_id: torch.Tensor, mask_anno: torch.Tensor, score_col=4, return_ids=False):

@@ -375,6 +375,61 @@ PIPELINES.register_module("MyMultiScaleFlipAug3D", force=True, module=MultiScale
 PIPELINES.register_module("MyPointsRangeFilter", force=True, module=PointsRangeFilter)
 
 
+class DevicePointAssembler:
+    """The point side of the test pipeline (configs/_base_/datasets/nuscenes_dataloader.py:96-137) with its per-point passes
+    on the device: the raw key-frame and sweep files are read on the host (disk I/O is host work), go to the GPU in ONE
+    host->device copy, and `fsf_assemble_sweeps` (K0) does what LoadPointsFromMultiSweeps
+    (datasets/pipelines/loading.py:825-877), SaveNoAugPoints (:341-354), PointsRangeFilter and NormalizePoints (:537-563) do
+    in numpy / torch on the host — same rows, same order, bit-identical values (tests pin it to input_pipeline.npz through
+    the host classes above).  Returns f32 [N, load_dim + 3] on `device`: what `FSF.simple_test` takes as `points[0]`."""
+
+    def __init__(self, load_dim=5, sweeps_num=9, pad_empty_sweeps=True, remove_close=True, test_mode=False,
+                 point_cloud_range=None, norm_dims=(3,), norm_mean=(0,), norm_std=(255,), close_radius=1.0):
+        assert len(norm_dims) <= 1, "the kernel normalises one column (the reference configs use dims=[3])"
+        self.load_dim, self.sweeps_num = load_dim, sweeps_num
+        self.pad_empty_sweeps, self.remove_close, self.test_mode = pad_empty_sweeps, remove_close, test_mode
+        self.point_cloud_range = None if point_cloud_range is None else [float(v) for v in point_cloud_range]
+        self.norm = (int(norm_dims[0]), float(norm_mean[0]), float(norm_std[0])) if len(norm_dims) else (-1, 0.0, 1.0)
+        self.close_radius = close_radius
+
+    def __call__(self, results, device):
+        from ... import hip_ops
+
+        key = np.copy(_load_float32(results["pts_filename"])).reshape(-1, self.load_dim)
+        ts = results["timestamp"]
+        identity = [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0, 0, 0, 0, 0.0]
+        chunks, params, transform, close = [key], [identity], [False], [False]
+        sweeps = results.get("sweeps", [])
+        if self.pad_empty_sweeps and len(sweeps) == 0:  # the key frame repeated, close points removed from the copies
+            for _ in range(self.sweeps_num):
+                chunks.append(key)
+                params.append(identity)
+                transform.append(False)
+                close.append(self.remove_close)
+        else:
+            if len(sweeps) <= self.sweeps_num:
+                choices = np.arange(len(sweeps))
+            elif self.test_mode:
+                choices = np.arange(self.sweeps_num)
+            else:
+                choices = np.random.choice(len(sweeps), self.sweeps_num, replace=False)
+            for idx in choices:
+                sw = sweeps[idx]
+                chunks.append(np.copy(_load_float32(sw["data_path"])).reshape(-1, self.load_dim))
+                rot = np.asarray(sw["sensor2lidar_rotation"], dtype=np.float64).reshape(9)
+                tr = np.asarray(sw["sensor2lidar_translation"], dtype=np.float64).reshape(3)
+                params.append([*rot, *tr, float(np.float32(ts - sw["timestamp"] / 1e6))])  # (the column it lands in is fp32)
+                transform.append(True)
+                close.append(self.remove_close)
+        offsets = np.concatenate([[0], np.cumsum([c.shape[0] for c in chunks])]).tolist()
+        raw = torch.from_numpy(np.concatenate(chunks, 0))
+        if torch.cuda.is_available():
+            raw = raw.pin_memory()
+        col, mean, std = self.norm
+        return hip_ops.assemble_sweeps(raw.to(device, non_blocking=True), offsets, params, transform, close, self.close_radius,
+                                       self.point_cloud_range, col, mean, std)
+
+
 def frame_to_device(data, device):
     """Pipeline output (one sample, `num_augs == 1`) -> the argument tuple of `FSF.simple_test`: ONE host->device copy per
     tensor; the id planes keep their stored integer type."""

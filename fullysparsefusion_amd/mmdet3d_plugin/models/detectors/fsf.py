@@ -93,6 +93,7 @@ class FSF(SingleStageFSD):
         self.voxel_downsampling_size = voxel_downsampling_size
         self.is_argo = is_argo
         self._gather_cache = None
+        self._fg_cache = None
 
     # ----------------------------------------------------------------------------------- projection
     def prj_points_2d(self, points, lidar2img, img_h, img_w):
@@ -194,9 +195,13 @@ class FSF(SingleStageFSD):
         return sir_coors, obj_id_tensor
 
     def frustum_pooling(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights, img_metas=None,
-                        cluster_center=None):
-        pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights = self.extract_fg_pts(
-            pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights)
+                        cluster_center=None, fg_idx=None):
+        if fg_idx is not None:  # `obj_id_tensor` already holds the rows of the foreground points `fg_idx` (ascending)
+            pts_feat, bz_coor, points, point_fg_weights = (t.index_select(0, fg_idx) for t in (pts_feat, bz_coor, points,
+                                                                                              point_fg_weights))
+        else:
+            pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights = self.extract_fg_pts(
+                pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights)
         # (extract_fg_pts keeps exactly the points with a positive id sum, ids are >= 0: a non-empty result has a
         # positive sum — the reference's `obj_id_tensor.sum() == 0` host test is implied by the row count)
         if obj_id_tensor.numel() == 0:
@@ -277,10 +282,20 @@ class FSF(SingleStageFSD):
         if ext_pts_inds is not None:
             points_info_flat = points_info_flat[ext_pts_inds]
             batch_idx = batch_idx[ext_pts_inds]
+        if (not self.is_argo and not self.encode_label_only and batch_size == 1 and mask_data.shape[2] <= hip_ops.PROJECT_SCORE_MAX_CLS
+                and mask_data.dtype in (torch.uint8, torch.int32) and points_info_flat.is_cuda):
+            # fused: projection + mask gather + argmax-camera select + id -> score lookup in ONE kernel (FSF.py:169-258,
+            # :716-719, :506-535, :472-473): the [n, cams, classes] int64 tensor is never written.  The "inside any mask"
+            # flag it also emits lets frustum_forward gather ids for the foreground points only.
+            lidar2img = torch.as_tensor(img_metas[0]["lidar2img"], dtype=torch.float32, device=points_info_flat.device)
+            score, fg = hip_ops.project_score(points_info_flat[:, :3], lidar2img, mask_data[0], mask_anno[0], score_col=4)
+            if ext_pts_inds is None:
+                self._fg_cache = (points_info_flat, mask_data, fg)
+            return encode_mlp(score)
         obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
         _, num_cams, num_classes = obj_id_tensor.shape
         if not self.is_argo and not self.encode_label_only and batch_size == 1:
-            # fused: argmax-camera select + id -> score lookup (FSF.py:716-719, :506-535, :472-473)
+            # camera select + id -> score lookup on the gathered ids (masks with more classes than the fused kernel takes)
             score = hip_ops.cam_select_score(obj_id_tensor, mask_anno[0], score_col=4)
             return encode_mlp(score)
         cam_select_value = obj_id_tensor.sum(-1).max(-1)[1]
@@ -312,9 +327,19 @@ class FSF(SingleStageFSD):
         point_fg_weights = self.get_point_fg_weights(seg_logits)
         batch_size = mask_anno.shape[0]
         points_info_flat = self.combine_by_batch(point_infos, batch_idx, batch_size)
-        obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
-        lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, obj_id_tensor,
-                                                                  point_fg_weights, img_metas, cluster_center)
+        fgc = getattr(self, "_fg_cache", None)
+        if (fgc is not None and batch_size == 1 and fgc[0].data_ptr() == points_info_flat.data_ptr()
+                and fgc[0].shape == points_info_flat.shape and fgc[1] is mask_data and fgc[0]._version == points_info_flat._version):
+            # img_cross_attn already knows which points lie inside a mask: gather the ids of THOSE points only
+            fg_idx = fgc[2].nonzero(as_tuple=False).squeeze(1)
+            lidar2img = torch.as_tensor(img_metas[0]["lidar2img"], dtype=torch.float32, device=points.device)
+            obj_fg = self.points_in_mask(points_info_flat.index_select(0, fg_idx)[:, :3].contiguous(), mask_data[0], lidar2img)
+            lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, obj_fg,
+                                                                      point_fg_weights, img_metas, cluster_center, fg_idx=fg_idx)
+        else:
+            obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
+            lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, obj_id_tensor,
+                                                                      point_fg_weights, img_metas, cluster_center)
         preds_2d = self.get_single_cls_preds_2d(mask_anno, obj_coors)
         img_feat = self.encode_2d_feats(preds_2d, img_w=mask_data.shape[-1], img_h=mask_data.shape[-2],
                                         encode_mlp=self.encode_2d_mlp)
@@ -412,6 +437,7 @@ class FSF(SingleStageFSD):
         """Stages 1-3 of simple_test (:1114-1144): segmentation + image fusion, camera queries, LiDAR queries —
         everything on the north-star hot path; returns the query features the heads consume."""
         self._gather_cache = None
+        self._fg_cache = None
         if self.voxel_downsampling_size is not None:
             points = self.segmentor.voxel_downsample(points)
         points, point_infos = self.split_points_last_3dim(points)
@@ -501,6 +527,7 @@ class FSF(SingleStageFSD):
     def forward_queries(self, points, img_metas, mask_data, mask_anno):
         """simple_test (:1114-1178) up to the box list: stages 1-3 with their heads, query combination, refinement."""
         self._gather_cache = None
+        self._fg_cache = None
         if self.voxel_downsampling_size is not None:
             points = self.segmentor.voxel_downsample(points)
         points, point_infos = self.split_points_last_3dim(points)

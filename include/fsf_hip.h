@@ -219,6 +219,27 @@ int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_
                                 int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * K0  multi-sweep point-cloud assembly on the device (input side of the path)
+ * Replaces the host passes of the test pipeline (configs/_base_/datasets/nuscenes_dataloader.py:96-137):
+ *   LoadPointsFromMultiSweeps (projects/mmdet3d_plugin/datasets/pipelines/loading.py:825-877), SaveNoAugPoints (:341-354),
+ *   PointsRangeFilter, NormalizePoints (:537-563) — after ONE host->device copy of the raw sweep files.
+ *   raw            f32 [n_rows, load_dim] device: the key frame's rows, then every sweep's, as read from the .bin files
+ *   sweep_offsets  i64 [num_sweeps + 1] HOST: row ranges (sweep 0 = the key frame); num_sweeps <= 16
+ *   sweep_params   f64 [num_sweeps, 13] HOST: sensor2lidar rotation (row-major 3x3) | translation | time lag (ts - sweep ts)
+ *   sweep_transform / sweep_remove_close  u8 [num_sweeps] HOST: apply the transform + time lag / drop |x|,|y| < close_radius
+ *   pc_range       f32 [6] HOST or NULL (strict in-range test on the transformed xyz); norm_col < 0: no normalisation
+ *   out            f32 [n_rows, load_dim + 3] (capacity): surviving rows in input order, columns = the input's with xyz
+ *                  transformed, column 4 = time lag, column norm_col = (v - mean) / std, then the transformed xyz again
+ *   count          rows written (device and/or host; the host copy costs one stream sync)
+ * Bit-identical to the reference's numpy / torch promotions (float64 rotation rounded to fp32, float64 translation add).
+ */
+int64_t fsf_assemble_sweeps_workspace_bytes(int64_t n_rows);
+int fsf_assemble_sweeps(const float* raw, int64_t n_rows, int32_t load_dim, const int64_t* sweep_offsets, int32_t num_sweeps,
+                        const double* sweep_params, const uint8_t* sweep_transform, const uint8_t* sweep_remove_close,
+                        float close_radius, const float* pc_range, int32_t norm_col, float norm_mean, float norm_std, float* out,
+                        int64_t* count_dev, int64_t* count_host, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * K13-K15  LiDAR -> camera projection + per-point instance-mask gather
  * Replaces: FSF.prj_points_2d (projects/mmdet3d_plugin/models/detectors/FSF.py:169-200) and
  *   FSF.points_in_mask (:202-226) for one batch sample; the caller loops samples like frustum_gather (:228-258).
@@ -233,6 +254,30 @@ int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_
 int fsf_project_gather_mask(const float* xyz, int64_t n, int32_t xyz_stride, const float* lidar2img, int32_t ncam,
                             const void* mask, int32_t elem_bytes, int32_t ncls, int32_t img_h, int32_t img_w,
                             int64_t* obj_id, float* pts_2d, void* stream);
+
+/* K13-K16 fused  xyz + id planes -> per-point class scores of the argmax camera (FSF.img_cross_attn, FSF.py:694-728:
+ * frustum_gather :228-258 + cam-select :716-718 + get_all_cls_preds_2d :506-535 + encode_preds_2d :472-473) without the
+ * [n, ncam, ncls] int64 tensor in between; same projection / pixel / tie rules as K13-K16 (results identical to
+ * fsf_project_gather_mask followed by fsf_cam_select_score).  ncls <= 16.
+ *   out_score f32 [n, ncls]; out_ids i64 [n, ncls] or NULL (ids of the selected camera);
+ *   out_fg u8 [n] or NULL: 1 if the point is inside any mask of any camera (obj_id.sum((-2,-1)) > 0, FSF.py:299-308)
+ */
+int fsf_project_score(const float* xyz, int64_t n, int32_t xyz_stride, const float* lidar2img, int32_t ncam, const void* mask,
+                      int32_t elem_bytes, int32_t ncls, int32_t img_h, int32_t img_w, const float* mask_anno, int32_t num_anno,
+                      int32_t anno_dim, int32_t score_col, float* out_score, int64_t* out_ids, uint8_t* out_fg, void* stream);
+
+/* K13b  LiDAR -> camera projection + per-point BILINEAR image-feature gather (BASELINE.json north_star; the reference only
+ * gathers instance ids, FSF.py:216-225 — this is the feature-map counterpart of the same call site: prj_points_2d
+ * (FSF.py:169-200) followed by F.grid_sample(feat, grid, mode='bilinear', align_corners=False, padding_mode='zeros')).
+ *   feat   f32 [ncam, channels, feat_h, feat_w] (channels_last = 0) or [ncam, feat_h, feat_w, channels] (channels_last = 1)
+ *   img_h, img_w: the image size the projection normalises by (the feature map may be a strided version of it)
+ *   out    f32 [n, ncam, channels] (reduce_cams = 0; zeros where the point is not inside the camera's image) or
+ *          f32 [n, channels] = the sum over the cameras that see the point (reduce_cams = 1)
+ *   count  u8 [n] or NULL: number of cameras that see the point
+ */
+int fsf_project_gather_bilinear(const float* xyz, int64_t n, int32_t xyz_stride, const float* lidar2img, int32_t ncam,
+                                const float* feat, int32_t channels, int32_t feat_h, int32_t feat_w, int32_t channels_last,
+                                int32_t img_h, int32_t img_w, int32_t reduce_cams, float* out, uint8_t* count, void* stream);
 
 /* K16  camera select + 2-D prediction lookup for the per-point branch (nuScenes: score column only).
  * Replaces: FSF.img_cross_attn cam-select (FSF.py:716-718) + get_all_cls_preds_2d (:506-535) +

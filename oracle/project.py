@@ -96,3 +96,22 @@ def cam_select_score(obj_id, mask_anno, score_col=4):
     valid = ids > 0
     score[valid] = anno[ids[valid] - 1, score_col]
     return ids, score
+
+
+def gather_bilinear(points, lidar2img, feat, img_h, img_w):
+    """North-star "per-point bilinear image-feature gather": FSF.prj_points_2d (FSF.py:169-200, restated above) followed by
+    what FSF.points_in_mask does with the id planes (:216-225) but on a float feature map and in bilinear mode:
+    torch.nn.functional.grid_sample(feat[cam][None], grid[None, None], mode='bilinear', align_corners=False,
+    padding_mode='zeros') — torch's own fp32 kernel is the reference.  feat f32 [ncam, C, Hf, Wf] -> [n, ncam, C]; invalid
+    projections carry the grid value -2, which samples zero padding."""
+    import torch
+    import torch.nn.functional as F
+
+    pts_2d = prj_points_2d(points, lidar2img, img_h, img_w)  # [ncam, n, 2]
+    feat = torch.as_tensor(np.asarray(feat), dtype=torch.float32)
+    out = []
+    for c in range(feat.shape[0]):
+        grid = torch.from_numpy(pts_2d[c])[None, None]       # [1, 1, n, 2]
+        out.append(F.grid_sample(feat[c][None], grid, mode="bilinear", align_corners=False, padding_mode="zeros")[0, :, 0].T)
+    valid = (pts_2d[:, :, 0] > -1.5).T                        # [n, ncam]
+    return torch.stack(out, 1).numpy(), valid

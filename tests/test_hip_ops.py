@@ -251,6 +251,13 @@ def test_project_gather_golden(ops, device, tag):
         score, cam_ids = ops.cam_select_score(ids, torch.from_numpy(g["mask_anno"]).to(device), return_ids=True)
         np.testing.assert_array_equal(cam_ids.cpu().numpy(), g["cam_ids"])
         np.testing.assert_array_equal(score.cpu().numpy(), g["score"])
+        if g["mask"].shape[1] <= ops.PROJECT_SCORE_MAX_CLS:  # the fused kernel against the reference's own outputs
+            fs, fi, ffg = ops.project_score(torch.from_numpy(g["points"]).to(device), torch.from_numpy(g["lidar2img"]).to(device),
+                                            torch.from_numpy(g["mask"]).to(device), torch.from_numpy(g["mask_anno"]).to(device),
+                                            return_ids=True)
+            np.testing.assert_array_equal(fi.cpu().numpy(), g["cam_ids"])
+            np.testing.assert_array_equal(fs.cpu().numpy(), g["score"])
+            np.testing.assert_array_equal(ffg.cpu().numpy(), g["obj_id"].sum((-2, -1)) > 0)
 
 
 def test_project_gather_full_size_vs_oracle(ops, device):
@@ -274,6 +281,12 @@ def test_project_gather_full_size_vs_oracle(ops, device):
     score, cam_ids = ops.cam_select_score(ids, torch.from_numpy(anno).to(device), return_ids=True)
     np.testing.assert_array_equal(cam_ids.cpu().numpy(), wi)
     np.testing.assert_array_equal(score.cpu().numpy(), ws)
+    # the fused kernel (no [n, 6, 10] int64 tensor in between): same scores, ids and foreground flag
+    fscore, fids, ffg = ops.project_score(torch.from_numpy(pts).to(device), torch.from_numpy(L).to(device),
+                                          torch.from_numpy(mask).to(device), torch.from_numpy(anno).to(device), return_ids=True)
+    np.testing.assert_array_equal(fscore.cpu().numpy(), ws)
+    np.testing.assert_array_equal(fids.cpu().numpy(), wi)
+    np.testing.assert_array_equal(ffg.cpu().numpy(), want.sum((-2, -1)) > 0)
 
 
 def test_project_gather_av2_shape_vs_oracle(ops, device):
@@ -296,6 +309,12 @@ def test_project_gather_av2_shape_vs_oracle(ops, device):
     np.testing.assert_array_equal(p2d.cpu().numpy(), want_p2d)
     np.testing.assert_array_equal(ids.cpu().numpy(), want)
     assert want.max() > 255 and (want > 0).any(-1).any(-1).mean() > 0.05
+    wi, ws = oproj.cam_select_score(want, anno)
+    fscore, fids, ffg = ops.project_score(torch.from_numpy(pts).to(device), torch.from_numpy(L).to(device),
+                                          torch.from_numpy(mask).to(device), torch.from_numpy(anno).to(device), return_ids=True)
+    np.testing.assert_array_equal(fscore.cpu().numpy(), ws)
+    np.testing.assert_array_equal(fids.cpu().numpy(), wi)
+    np.testing.assert_array_equal(ffg.cpu().numpy(), want.sum((-2, -1)) > 0)
 
 
 # ----------------------------------------------------------------------------------------- rulebooks
@@ -774,6 +793,35 @@ def test_dynamic_point_pool_batched_and_empty(ops, device):
     far = torch.full((100, 3), 500.0, device=device)
     gp, gr, gf = ops.dynamic_point_pool(torch.from_numpy(rois).to(device), far, [0.5, 0.5, 0.5], 512)
     assert gp.numel() == 0 and gf.shape == (0, 13)
+
+
+@pytest.mark.parametrize("c,hf,wf", [(32, 57, 100), (64, 113, 200), (3, 900, 1600), (130, 29, 50)])
+def test_project_gather_bilinear_vs_torch_grid_sample(ops, device, c, hf, wf):
+    """fsf_project_gather_bilinear (north_star's per-point bilinear image-feature gather) against
+    F.grid_sample(bilinear, align_corners=False, zeros) at the reference projection (oracle.project.gather_bilinear), 1e-4:
+    NCHW and channels-last feature maps, per-camera and camera-summed outputs, the visible-camera count."""
+    from fullysparsefusion_amd import synthetic
+
+    rng = np.random.default_rng(c + hf)
+    f = synthetic.make_frame(num_sweeps=1, seed=3)
+    pts = f["points"][:20000, 5:8].copy()
+    pts[:50] = rng.uniform(-60, 60, (50, 3))  # some far / behind-camera / out-of-image points
+    L = f["lidar2img"]
+    feat = rng.standard_normal((6, c, hf, wf)).astype(np.float32)
+    want, valid = oproj.gather_bilinear(pts, L, feat, 900, 1600)
+    d_pts, d_L, d_feat = torch.from_numpy(pts).to(device), torch.from_numpy(L).to(device), torch.from_numpy(feat).to(device)
+    got = ops.project_gather_bilinear(d_pts, d_L, d_feat, (900, 1600))
+    assert got.shape == (pts.shape[0], 6, c)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert float(np.abs(got.cpu().numpy() - want).max()) <= 1e-4 * scale
+    assert not got.cpu().numpy()[~valid].any() and valid.sum() > 1000
+    cl = d_feat.permute(0, 2, 3, 1).contiguous()
+    got_cl, count = ops.project_gather_bilinear(d_pts, d_L, cl, (900, 1600), channels_last=True, return_count=True)
+    assert float((got_cl - got).abs().max()) <= 1e-5 * scale
+    np.testing.assert_array_equal(count.cpu().numpy(), valid.sum(1).astype(np.uint8))
+    for layout_feat, last in ((d_feat, False), (cl, True)):
+        red = ops.project_gather_bilinear(d_pts, d_L, layout_feat, (900, 1600), channels_last=last, reduce_cams=True)
+        assert float(np.abs(red.cpu().numpy() - want.sum(1)).max()) <= 2e-4 * scale
 
 
 def test_ops_dynamic_point_pool_reference_signature(ops, device):

@@ -645,6 +645,44 @@ def test_simple_test_edge_cases(fsf_pair, frame1, device):
         assert len(tiny) == 1 and torch.isfinite(tiny[0]["boxes_3d"].tensor).all()
 
 
+def test_device_point_assembly_equals_the_host_pipeline(device, tmp_path):
+    """K0 (`fsf_assemble_sweeps` behind `DevicePointAssembler`): raw .bin sweeps -> ONE host->device copy -> sweep transform,
+    time lag, close-point removal, concatenation, no-aug xyz columns, range filter, intensity normalisation ON THE DEVICE —
+    bit-identical to the host classes, which tests/test_input_pipeline.py pins bit-exactly to the reference's own loaders
+    (tests/golden/input_pipeline.npz); the golden's `normed` rows are compared directly as well."""
+    import json
+
+    from fullysparsefusion_amd.mmdet3d_plugin import datasets as D
+
+    g = load_golden("input_pipeline.npz")
+    g["key"].tofile(tmp_path / "key.bin")
+    meta = json.loads(bytes(g["sweep_meta_json"]).decode())
+    for k, m in enumerate(meta):
+        g["sweeps"][k].tofile(tmp_path / f"sweep{k}.bin")
+        m["data_path"] = str(tmp_path / f"sweep{k}.bin")
+    rng_box = [-51.2, -51.2, -5, 51.2, 51.2, 3]
+
+    def host(sweeps, sweeps_num, pc_range):
+        r = D.LoadPointsFromFile(coord_type="LIDAR", load_dim=5, use_dim=[0, 1, 2, 3, 4])(dict(pts_filename=str(tmp_path / "key.bin")))
+        r.update(timestamp=1.5e9, sweeps=sweeps)
+        r = D.LoadPointsFromMultiSweeps(sweeps_num=sweeps_num, use_dim=[0, 1, 2, 3, 4], pad_empty_sweeps=True, remove_close=True,
+                                        test_mode=True)(r)
+        r = D.SaveNoAugPoints()(r)
+        if pc_range is not None:
+            r = D.PointsRangeFilter(pc_range)(r)
+        return D.NormalizePoints()(r)["points"].tensor.numpy()
+
+    for sweeps, sweeps_num, pc_range in [(meta, 9, None), (meta, 9, rng_box), (meta, 2, rng_box), ([], 2, None), ([], 3, [-20, -20, -5, 20, 20, 3])]:
+        asm = D.DevicePointAssembler(load_dim=5, sweeps_num=sweeps_num, pad_empty_sweeps=True, remove_close=True, test_mode=True,
+                                     point_cloud_range=pc_range)
+        got = asm(dict(pts_filename=str(tmp_path / "key.bin"), timestamp=1.5e9, sweeps=sweeps), device)
+        want = host(sweeps, sweeps_num, pc_range)
+        assert got.is_cuda and got.shape[1] == 8
+        np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got = D.DevicePointAssembler(sweeps_num=9, test_mode=True)(dict(pts_filename=str(tmp_path / "key.bin"), timestamp=1.5e9, sweeps=meta), device)
+    np.testing.assert_array_equal(got.cpu().numpy(), g["normed"])  # the reference's own output, bit for bit
+
+
 def test_files_to_boxes_through_the_input_pipeline(fsf_pair, frame1, device, tmp_path):
     """On-disk formats -> test pipeline -> one host->device copy -> FSF.simple_test: the same boxes as feeding the
     tensors directly (the pipeline's range filter / intensity scaling applied to both)."""
