@@ -1,7 +1,7 @@
 // Stable LSD radix sort of (u64 key, u32 value) pairs, 8 bits per pass, hand-written for wave64.
 // Used by unique-rows (K3), segment plans and the strided-conv output-coordinate unique (K8).
-// Three launches per pass (tile histogram -> digit-major exclusive scan -> stable scatter); only the
-// passes covering [0, key_bits) are run.
+// One launch per pass (one-sweep: global digit histograms upfront + decoupled look-back over per-tile digit counts); only
+// the passes covering [0, key_bits) are run.
 #pragma once
 #include "common.h"
 
@@ -12,7 +12,10 @@ constexpr int RS_ITEMS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;  // 2048 keys per workgroup
 constexpr int RS_BINS = 256;
 
-static inline int64_t radix_num_tiles(int64_t n) { return n > 0 ? (n + RS_TILE - 1) / RS_TILE : 1; }
+static inline int64_t radix_grid_tiles(int64_t n) { return n > 0 ? (n + RS_TILE - 1) / RS_TILE : 1; }
+// tiles' worth of 256-word scratch the sorter's `hist` buffer is sized by: the four-launch form needs tiles + 1, the one-sweep
+// form (8 passes at most) passes * tiles status blocks + the global histograms + the tickets
+static inline int64_t radix_num_tiles(int64_t n) { return 8 * radix_grid_tiles(n) + 10; }
 // bytes of scratch the sorter needs (alternate key/value buffers + per-tile digit histograms)
 int64_t radix_sort_scratch_bytes(int64_t n);
 
