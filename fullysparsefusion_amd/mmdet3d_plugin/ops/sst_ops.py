@@ -316,7 +316,9 @@ def batch_norm_act_training(bn, x, relu):
             and os.environ.get("FSF_TRAIN_BN", "1") != "0"):
         return None
     if type(bn).__name__ != "BatchNorm1d" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return None  # naiveSyncBN1d across ranks: statistics are all-reduced (ops/norm.py)
+        # naiveSyncBN1d across ranks: K23 still does the row passes, the statistics travel as one packed [2C] all-reduce per
+        # direction (ops/norm.py::_SyncBatchNormAct)
+        return bn.forward_act(x, relu) if hasattr(bn, "forward_act") else None
     return _BatchNormActFn.apply(x, bn.weight, bn.bias, bn, relu)
 
 

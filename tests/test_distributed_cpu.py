@@ -208,3 +208,51 @@ def test_buckets_do_not_share_a_communicator_with_syncbn_world2_gloo():
     for n in got[0][3]:
         assert np.allclose(got[0][3][n], got[0][4][n], rtol=1e-5, atol=1e-6), n  # accumulation == summed loss
         assert np.array_equal(got[0][4][n], got[1][4][n]), n
+
+
+# ------------------------------------------ fused SyncBN (+ReLU) node == the upstream formulation through autograd
+def _syncbn_fused_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullysparsefusion_amd.mmdet3d_plugin.registry import build_norm_layer
+
+        out = {}
+        for fused in ("1", "0"):
+            os.environ["FSF_SYNCBN_FUSED"] = fused
+            torch.manual_seed(0)
+            bn = build_norm_layer(dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), 8)[1].double().train()
+            with torch.no_grad():
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.normal_()
+            torch.manual_seed(5)
+            full = torch.randn(3, 40, 8, dtype=torch.float64)  # unequal row counts per rank: 40 vs 25
+            x = (full[rank] if rank == 0 else full[rank][:25]).clone().requires_grad_(True)
+            y = bn.forward_act(x, True) if fused == "1" else torch.relu(bn(x))
+            (y * torch.arange(1, 9, dtype=torch.float64)).sum().backward()
+            out[fused] = [t.detach().numpy().copy() for t in (y, x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)]
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_fused_syncbn_relu_equals_upstream_formulation_world2_gloo():
+    """ops/norm.py::_SyncBatchNormAct (local statistics -> one packed [2C] all-reduce -> normalise + ReLU; hand-written
+    backward with one packed all-reduce of the statistics' gradients) against autograd through the upstream formulation
+    (mean / mean-of-squares all-reduced by `_SyncStats`), float64, world size 2, unequal row counts."""
+    import numpy as np
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_fused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, out in got:
+        for a, b in zip(out["1"], out["0"]):
+            assert np.allclose(a, b, rtol=1e-10, atol=1e-12), rank

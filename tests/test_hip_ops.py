@@ -1093,6 +1093,53 @@ def test_batch_norm_act_training_vs_torch_autograd(ops, device, n, c, relu):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("n,c,relu", [(30011, 64, True), (101119, 128, True), (5000, 131, False)])
+def test_fused_syncbn_relu_on_k23_vs_float64(ops, device, n, c, relu):
+    """naiveSyncBN1d across ranks with the row passes on K23 (ops/norm.py::_SyncBatchNormAct): a one-rank process group on
+    the device exercises the very code the ranks run (statistics kernel, packed all-reduce, fused normalise + ReLU, the
+    single-rank backward kernel + the statistics-gradient correction); with one rank the result must equal training-mode
+    BatchNorm1d, checked against float64 autograd.  (World size 2 is covered on CPU / gloo, tests/test_distributed_cpu.py.)"""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from fullysparsefusion_amd.mmdet3d_plugin.ops.norm import NaiveSyncBatchNorm1d, _SyncBatchNormAct
+
+    own = not dist.is_initialized()
+    if own:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s.getsockname()[1]))
+        s.close()
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        torch.manual_seed(n + c)
+        x = (torch.randn(n, c, device=device) * 2 + 0.7).requires_grad_()
+        go = torch.randn(n, c, device=device)
+        bn = NaiveSyncBatchNorm1d(c, eps=1e-3, momentum=0.01).to(device).train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_()
+        ref = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(device).double().train()
+        ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+        y = _SyncBatchNormAct.apply(x, bn.weight, bn.bias, bn, relu, None)
+        y.backward(go)
+        xd = x.detach().double().requires_grad_()
+        yd = ref(xd)
+        yd = torch.relu(yd) if relu else yd
+        yd.backward(go.double())
+        tol = lambda t: 5e-5 * max(1.0, float(t.detach().abs().max()))  # noqa: E731  (the naive E[x^2] - E[x]^2 variance)
+        assert float((y.detach().double() - yd.detach()).abs().max()) <= tol(yd)
+        assert float((x.grad.double() - xd.grad).abs().max()) <= tol(xd.grad)
+        assert float((bn.weight.grad.double() - ref.weight.grad).abs().max()) <= 2e-4 * max(1.0, float(ref.weight.grad.abs().max()))
+        assert float((bn.bias.grad.double() - ref.bias.grad).abs().max()) <= 2e-4 * max(1.0, float(ref.bias.grad.abs().max()))
+        assert float((bn.running_mean.double() - ref.running_mean).abs().max()) <= 1e-6
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("cin,cout,bias", [(3, 16, False), (16, 32, False), (32, 133, False), (128, 131, True), (10, 128, True)])
 def test_point_linear_thin_layers_gradients(ops, device, cin, cout, bias):
     """The K10 weight-gradient route with padded channel counts + the K23 bias gradient == autograd of nn.Linear."""
