@@ -163,12 +163,14 @@ struct SpArgs {
   float* out_scales;
 };
 
+constexpr int SP_NKC = 4;  // 32-cin chunks per source at most (sources are <= 128 channels wide)
+
 template <int RG, int TPW>
 struct SpSmem {
   static constexpr int R = 16 * RG;
   static constexpr size_t nbr_bytes = (size_t)R * SP_KVOL_MAX * 4;
   static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
-  static constexpr size_t xring_bytes = (size_t)SP_NSLOT * RG * 2 * 1024;
+  static constexpr size_t xring_bytes = (size_t)SP_NSLOT * RG * SP_NKC * 2 * 1024;  // [slot][cell][chunk][hi | lo][64 lanes] x 16 B
   static constexpr size_t sring_off = xring_off + xring_bytes;
   static constexpr size_t sring_bytes = (size_t)2 * RG * 64 * 4;
   static constexpr size_t meta_off = sring_off + sring_bytes;      // sched[32] | nk | flags[27 * RG]
@@ -180,9 +182,9 @@ struct SpSmem {
   static constexpr size_t bytes = rowmax_off + rowmax_bytes;
 };
 
-// one step of the (live offset, 32-cin chunk) sequence, all scalar
+// one step of the (live offset, source) sequence, all scalar
 struct SpStep {
-  int kidx, c, k;
+  int kidx, src, k;
   unsigned mask;  // live 16-row groups of the block at offset k (0 past the end of the sequence)
 };
 
@@ -190,11 +192,10 @@ struct SpStep {
 #define SP_RG4_WPS 2  // workgroups per CU the 64-row variant is compiled for (3 and 4 measured 5-7 % slower: the compiler does better with the registers)
 #endif
 template <int RG, int TPW>
-__global__ void __launch_bounds__(256, RG == 8 ? 2 : SP_RG4_WPS) spconv_fwd_planes_kernel(SpArgs a) {
+__global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_planes_kernel(SpArgs a) {
   using S = SpSmem<RG, TPW>;
   constexpr int R = S::R;
   constexpr int CPW = RG / 4;  // cells of a step this wave gathers
-  constexpr int HB = RG / 2;   // cells per LDS-read batch
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
   int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
   uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
@@ -244,24 +245,28 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : SP_RG4_WPS) spconv_fwd_plan
   }
   __syncthreads();
   const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
-  const int nchunks = a.cin / 32;
-  const int nchunks0 = a.c[0] / 32;
-  const int nsteps = nk * nchunks;
-  const float w_inv = a.w_hdr[0];
-  const int rowbytes0 = a.c[0] * 4, rowbytes1 = a.c[1] * 4;
   const int nsrc = a.c[1] > 0 ? 2 : 1;
+  const int nkc0 = a.c[0] / 32, nkc1 = a.c[1] / 32;
+  const int nchunks = nkc0 + nkc1;  // 32-cin chunks of the concatenated input (the weight fragments are laid out over them)
+#ifdef SP_ABL_NO_LOOP  // ablation: prologue + epilogue only
+  const int nsteps = 0;
+#else
+  const int nsteps = nk * nsrc;
+#endif
+  const float w_inv = a.w_hdr[0];
+  const uint32_t rowbytes0 = (uint32_t)a.c[0] * 4u, rowbytes1 = (uint32_t)a.c[1] * 4u;
 
-  auto entry = [&](int kidx, int c) -> SpStep {
+  auto entry = [&](int kidx, int src) -> SpStep {
     const int e = kidx < nk ? __builtin_amdgcn_readfirstlane(sched[kidx]) : 0;
-    return SpStep{kidx, c, e & 255, (unsigned)e >> 8};
+    return SpStep{kidx, src, e & 255, (unsigned)e >> 8};
   };
   auto advance = [&](const SpStep& p) -> SpStep {
-    if (p.c + 1 < nchunks) return SpStep{p.kidx, p.c + 1, p.k, p.mask};
+    if (p.src + 1 < nsrc) return SpStep{p.kidx, p.src + 1, p.k, p.mask};
     return entry(p.kidx + 1, 0);
   };
 
-  // acc: the output tile; D: the products of the current (offset, source) group, summed over its cin chunks by the MFMA
-  // itself and folded into acc with the row's inverse scale (x the weight's) when the group ends
+  // acc: the output tile; D: the products of the current step (one offset, one source: all its cin chunks summed by the
+  // MFMA itself), folded into acc with the row's inverse scale (x the weight's) when the step ends
   sp_f32x4 acc[RG][TPW], D[RG][TPW];
 #pragma unroll
   for (int g = 0; g < RG; ++g)
@@ -272,149 +277,179 @@ __global__ void __launch_bounds__(256, RG == 8 ? 2 : SP_RG4_WPS) spconv_fwd_plan
     }
 
   // ---- this wave's share of a step's gather: global -> registers (a lane without a neighbour loads nothing: zeros)
-  uint4 st_hi[CPW], st_lo[CPW];
+  uint4 st_hi[CPW][SP_NKC], st_lo[CPW][SP_NKC];
   float st_sc[CPW];
   auto load_x = [&](const SpStep& st) {
-    const int src = st.c < nchunks0 ? 0 : 1;
-    const int kc = src ? st.c - nchunks0 : st.c;
-    const char* xb = a.x[src];
-    const float* sb = a.sx[src];
-    const int rb = src ? rowbytes1 : rowbytes0;
+    const char* xb = a.x[st.src];
+    const float* sb = a.sx[st.src];
+    const uint32_t rb = st.src ? rowbytes1 : rowbytes0;
+    const int nkc = st.src ? nkc1 : nkc0;
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
       const int cc = wave * CPW + u;
-      st_hi[u] = make_uint4(0, 0, 0, 0);
-      st_lo[u] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int kc = 0; kc < SP_NKC; ++kc) {
+        st_hi[u][kc] = make_uint4(0, 0, 0, 0);
+        st_lo[u][kc] = make_uint4(0, 0, 0, 0);
+      }
       st_sc[u] = 1.0f;
       if ((st.mask >> cc) & 1u) {
         const int i = nbr_s[(16 * cc + j) * kvol + st.k];
         if (i >= 0) {
 #ifdef SP_ABL_NO_X
-          const char* p = xb + (uint32_t)((i & 15) * rb + (kc * 4 + q) * 32);
+          const char* p = xb + (uint32_t)(i & 15) * rb + (uint32_t)(q * 32);
 #else
-          const char* p = xb + (uint32_t)((uint32_t)i * (uint32_t)rb + (uint32_t)((kc * 4 + q) * 32));  // (planes < 4 GiB: checked by the host)
+          const char* p = xb + (uint32_t)i * rb + (uint32_t)(q * 32);  // (planes < 4 GiB: checked by the host)
 #endif
-          st_hi[u] = *reinterpret_cast<const uint4*>(p);
-          st_lo[u] = *reinterpret_cast<const uint4*>(p + 16);
-          if (kc == 0) st_sc[u] = sb[i];
+#pragma unroll
+          for (int kc = 0; kc < SP_NKC; ++kc) {
+            if (kc < nkc) {
+              st_hi[u][kc] = *reinterpret_cast<const uint4*>(p + kc * 128);
+              st_lo[u][kc] = *reinterpret_cast<const uint4*>(p + kc * 128 + 16);
+            }
+          }
+          st_sc[u] = sb[i];
         }
       }
     }
   };
   auto store_x = [&](const SpStep& st, int slot) {  // registers -> LDS in B-fragment order (lane-linear: conflict-free)
-    const int src = st.c < nchunks0 ? 0 : 1;
-    const bool first = (src ? st.c - nchunks0 : st.c) == 0;
-    const int sslot = (st.kidx * nsrc + src) & 1;  // consecutive (offset, source) groups alternate
+#ifdef SP_ABL_NO_LDS_WRITE
+    return;
+#endif
+    const int nkc = st.src ? nkc1 : nkc0;
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
       const int cc = wave * CPW + u;
       if ((st.mask >> cc) & 1u) {
-        uint4* dst = xring + ((slot * RG + cc) * 2) * 64 + lane;
-        dst[0] = st_hi[u];
-        dst[64] = st_lo[u];
-        if (first) sring[(sslot * RG + cc) * 64 + lane] = st_sc[u];
+        uint4* dst = xring + (((slot * RG + cc) * SP_NKC) * 2) * 64 + lane;
+#pragma unroll
+        for (int kc = 0; kc < SP_NKC; ++kc) {
+          if (kc < nkc) {
+            dst[(kc * 2) * 64] = st_hi[u][kc];
+            dst[(kc * 2 + 1) * 64] = st_lo[u][kc];
+          }
+        }
+        sring[(slot * RG + cc) * 64 + lane] = st_sc[u];
       }
     }
   };
-  auto load_w = [&](const SpStep& st, uint4 (&wf)[TPW][2]) {  // this wave's A fragments (16 * TPW channels x 32 cin, hi | lo)
+  // this wave's A fragments of chunk kc of step st (16 * TPW channels x 32 cin, hi | lo)
+  auto load_w = [&](const SpStep& st, int kc, uint4 (&wf)[TPW][2]) {
 #ifdef SP_ABL_NO_W
-    if (st.kidx > 0 || st.c > 0) return;
+    if (st.kidx > 0 || st.src > 0 || kc > 0) return;
 #endif
-    const int kidx = st.kidx < nk ? st.kidx : 0;
-    (void)kidx;
+    const int c = (st.src ? nkc0 : 0) + kc;
     const uint4* p = reinterpret_cast<const uint4*>(a.w) +
-                     ((((int64_t)slice * kvol + st.k) * nchunks + st.c) * 4 + wave) * (TPW * 2 * 64) + lane;
+                     ((((int64_t)slice * kvol + st.k) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) wf[t][pl] = p[(t * 2 + pl) * 64];
   };
-  auto compute = [&](const SpStep& st, int slot, const uint4 (&wf)[TPW][2]) {
-    const int src = st.c < nchunks0 ? 0 : 1;
-    const bool last = (st.c == nchunks0 - 1) || (st.c == nchunks - 1);  // last chunk of the (offset, source) group
-    const int sslot = (st.kidx * nsrc + src) & 1;  // consecutive (offset, source) groups alternate
+  uint4 wf[SP_NKC][TPW][2];  // the current step's weights, chunk by chunk; a chunk's registers take the NEXT step's as soon
+                             // as its MFMAs are issued (a rolling prefetch: no second buffer)
+  auto read_x = [&](const SpStep& st, int slot, int kc, uint4 (&xh)[RG], uint4 (&xl)[RG]) {
+#ifdef SP_ABL_NO_LDS_READ
+    return;
+#endif
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      if ((st.mask >> g) & 1u) {
+        const uint4* xs = xring + (((slot * RG + g) * SP_NKC + kc) * 2) * 64 + lane;
+        xh[g] = xs[0];
+        xl[g] = xs[64];
+      }
+    }
+  };
+  auto mma = [&](const SpStep& st, int kc, const uint4 (&xh)[RG], const uint4 (&xl)[RG]) {
     sp_f16x8 wh[TPW], wl[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      wh[t] = __builtin_bit_cast(sp_f16x8, wf[t][0]);
-      wl[t] = __builtin_bit_cast(sp_f16x8, wf[t][1]);
+      wh[t] = __builtin_bit_cast(sp_f16x8, wf[kc][t][0]);
+      wl[t] = __builtin_bit_cast(sp_f16x8, wf[kc][t][1]);
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint4 xh[HB], xl[HB];
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {  // the batch's LDS reads first, then its MFMAs: one exposed LDS latency per batch
-        const int g = h * HB + u;
-        if ((st.mask >> g) & 1u) {
-          const uint4* xs = xring + ((slot * RG + g) * 2) * 64 + lane;
-          xh[u] = xs[0];
-          xl[u] = xs[64];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < HB; ++u) {
-        const int g = h * HB + u;
-        if ((st.mask >> g) & 1u) {
-          const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh[u]), bl = __builtin_bit_cast(sp_f16x8, xl[u]);
+    for (int g = 0; g < RG; ++g) {
+      if ((st.mask >> g) & 1u) {
+        const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh[g]), bl = __builtin_bit_cast(sp_f16x8, xl[g]);
 #ifdef SP_ABL_NO_MFMA
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) D[g][t][0] += __uint_as_float(xh[u].x ^ wf[t][0].x ^ xl[u].y ^ wf[t][1].y);
+        for (int t = 0; t < TPW; ++t) D[g][t][0] += __uint_as_float(xh[g].x ^ wf[kc][t][0].x ^ xl[g].y ^ wf[kc][t][1].y);
 #else
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, D[g][t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, D[g][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, D[g][t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, D[g][t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, D[g][t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, D[g][t], 0, 0, 0);
 #endif
-        }
       }
     }
-    if (last) {  // fold the group: this lane's row scale in every live cell
+  };
+  auto compute = [&](const SpStep& st, const SpStep& nxt, int slot) {
+    const int nkc = st.src ? nkc1 : nkc0;
+    const int nkc_nxt = nxt.src ? nkc1 : nkc0;
+    // software pipeline over the chunks: chunk kc + 1's fragments are read from LDS (and the row scales of the fold) while
+    // chunk kc is multiplied; a chunk's weight registers take the next step's chunk as soon as its MFMAs are issued
+    uint4 xha[RG], xla[RG], xhb[RG], xlb[RG];
+    float inv[RG];
+    read_x(st, slot, 0, xha, xla);
 #pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        if ((st.mask >> g) & 1u) {
-          const float inv = __fmul_rn(sring[(sslot * RG + g) * 64 + lane], w_inv);
+    for (int g = 0; g < RG; ++g)
+      if ((st.mask >> g) & 1u) inv[g] = sring[(slot * RG + g) * 64 + lane];
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) {
+    for (int kc = 0; kc < SP_NKC; kc += 2) {
+      if (kc < nkc) {
+        if (kc + 1 < nkc) read_x(st, slot, kc + 1, xhb, xlb);
+        mma(st, kc, xha, xla);
+      }
+      if (kc < nkc_nxt) load_w(nxt, kc, wf[kc]);
+      if (kc + 1 < nkc) {
+        if (kc + 2 < nkc) read_x(st, slot, kc + 2, xha, xla);
+        mma(st, kc + 1, xhb, xlb);
+      }
+      if (kc + 1 < nkc_nxt) load_w(nxt, kc + 1, wf[kc + 1]);
+    }
+    // fold the step: this lane's row scale in every live cell
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(D[g][t][r], inv, acc[g][t][r]);
-            D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-          }
+    for (int g = 0; g < RG; ++g) {
+      if ((st.mask >> g) & 1u) {
+        const float sc = __fmul_rn(inv[g], w_inv);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(D[g][t][r], sc, acc[g][t][r]);
+          D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
     }
   };
 
-  // ---- main loop.  Step s: [everything loaded during step s-1 has landed] barrier [X(s+1): registers -> LDS slot (s+1)%2]
-  // [load X(s+2) -> registers, W(s+1)] [compute step s from slot s%2].  One barrier per step: it separates the reads of
+  // ---- main loop.  Step s = (live offset, source): [barrier] [X(s+1): registers -> LDS slot (s+1)%2] [load X(s+2) -> registers]
+  // [multiply step s from slot s%2 chunk by chunk, W(s+1) rolling in behind].  One barrier per step: it separates the reads of
   // step s-1 from the writes into the same slot, and the writes of X(s) (during step s-1) from their reads.
-  uint4 wa[TPW][2], wb[TPW][2];
   SpStep s0 = entry(0, 0);
   SpStep s1 = advance(s0);
   load_x(s0);
-  load_w(s0, wa);
+#pragma unroll
+  for (int kc = 0; kc < SP_NKC; ++kc)
+    if (kc < nkc0) load_w(s0, kc, wf[kc]);
   store_x(s0, 0);
   load_x(s1);
   SpStep s2 = advance(s1);
-  auto body = [&](uint4 (&wcur)[TPW][2], uint4 (&wnext)[TPW][2], int par) {
+  for (int s = 0; s < nsteps; ++s) {
 #ifndef SP_ABL_NO_BARRIER
     __syncthreads();
 #endif
-    store_x(s1, par ^ 1);     // X(s+1), loaded during the previous step
-    load_x(s2);               // X(s+2)
-    load_w(s1, wnext);        // W(s+1)
-    compute(s0, par, wcur);
+    const int par = s & 1;
+    store_x(s1, par ^ 1);  // X(s+1), loaded during the previous step
+    load_x(s2);            // X(s+2)
+    compute(s0, s1, par);
     s0 = s1;
     s1 = s2;
     s2 = advance(s2);
-  };
-  int s = 0;
-  for (; s + 1 < nsteps; s += 2) {
-    body(wa, wb, 0);
-    body(wb, wa, 1);
   }
-  if (s < nsteps) body(wa, wb, 0);
 
   // ---- epilogue: lane (j, q) holds channels chw + 16 t + 4 q + r of rows row0 + 16 g + j
   const bool affine = a.scale || a.shift;

@@ -212,9 +212,10 @@ class SparseConvolution(SparseModule):
             self.__dict__["_wsplit_cache"] = cache
         return cache[1]
 
-    # K9c (pre-split f16 planes, cell skipping): the submanifold layers of the fine levels.  Below ~16 k rows the launch
-    # does not fill the chip and K9b's offset splits win.
-    PLANES_MIN_ROWS = int(os.environ.get("FSF_PLANES_MIN_ROWS", "16384"))
+    # K9c (pre-split f16 planes, cell skipping): every layer whose sources are <= 128 channels wide — submanifold, strided and
+    # inverse alike (the kernel only sees a neighbour table).  Below ~4 k output rows the launch does not fill the chip and
+    # K9b's offset splits win.
+    PLANES_MIN_ROWS = int(os.environ.get("FSF_PLANES_MIN_ROWS", "4096"))
     emit_planes = True   # plane-form output next to the fp32 one (the consumer is another K9c layer); the U-Net clears it where not
 
     def _weight_planes(self):
@@ -240,7 +241,9 @@ class SparseConvolution(SparseModule):
         return [hip_ops.to_planes(f[:, :half]), hip_ops.to_planes(f[:, half:])]
 
     def _use_planes_kernel(self, x, m_out):
-        if not (self.subm and m_out >= self.PLANES_MIN_ROWS and os.environ.get("FSF_PLANES", "1") != "0"):
+        if not (m_out >= self.PLANES_MIN_ROWS and os.environ.get("FSF_PLANES", "1") != "0"):
+            return False
+        if not self.subm and os.environ.get("FSF_PLANES_STRIDED", "1") == "0":
             return False
         cin = self.in_channels
         cins = [p.c for p in x.plane_sources] if x.plane_sources is not None else ([cin] if cin <= 128 else [cin // 2, cin - cin // 2])

@@ -548,6 +548,33 @@ def test_spconv_forward_planes_vs_float64(ops, device, m, cins, cout):
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("m", [3000, 60000])
+def test_spconv_forward_planes_strided_and_inverse_tables(ops, device, m):
+    """K9c only sees a neighbour table: the stride-2 convolution (m_in != m_out, 3-9 pairs per output row) and its inverse
+    (the transposed table) against the fp32-pipe kernel and float64 on sampled rows."""
+    rng = np.random.default_rng(m)
+    small = m <= 5000
+    shape = (16, 48, 48) if small else (40, 512, 512)
+    idx = surface_sites(rng, 1, shape, m)
+    n = idx.shape[0]
+    out_idx, nbr, nbr_inv, oshape = ops.rulebook_strided(torch.from_numpy(idx).to(device), 1, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    mo = out_idx.size(0)
+    for table, rows_in, rows_out in ((nbr, n, mo), (nbr_inv, mo, n)):
+        feat = (rng.standard_normal((rows_in, 128)) * np.exp(rng.standard_normal((rows_in, 1)))).astype(np.float32)
+        w = (rng.standard_normal((27, 128, 128)) / np.sqrt(128 * 4)).astype(np.float32)
+        f, wd = torch.from_numpy(feat).to(device), torch.from_numpy(w).to(device)
+        out, _ = ops.spconv_forward_planes([ops.to_planes(f)], ops.spconv_prepare_weight_planes(wd), 27, 128, table)
+        ref = ops.spconv_forward(f, ops.spconv_transpose_weight(wd), table)
+        assert out.shape == (rows_out, 128)
+        scale_ = max(1.0, float(ref.abs().max()))
+        assert float((out - ref).abs().max()) <= 2e-5 * scale_
+        rows = torch.from_numpy(rng.choice(rows_out, size=min(rows_out, 256), replace=False)).to(device)
+        nb = table.index_select(0, rows).long()
+        g = torch.where((nb >= 0)[:, :, None], f.double()[nb.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=device))
+        want = torch.einsum("rkc,kcd->rd", g, wd.double())
+        assert float((out.index_select(0, rows).double() - want).abs().max()) <= 1e-5 * scale_
+
+
 @pytest.mark.parametrize("m,cin,cout", [(100000, 128, 128), (36000, 256, 128), (7500, 256, 256), (1500, 512, 512)])
 def test_spconv_forward_full_size_properties(ops, device, m, cin, cout):
     """BASELINE-size layers (the persistent work-queue kernel with 1..9 offset splits, stealing across XCD queues, in-kernel
