@@ -244,6 +244,37 @@ def test_linear_norm_act_at_510k_rows(device, k, c):
     assert bool(torch.isfinite(out).all())
 
 
+@pytest.mark.parametrize("n,k,c,norm,act", [(510652, 128, 128, "ln", "gelu"), (310615, 64, 64, "affine", "relu"), (70001, 133, 128, "ln", "gelu")])
+def test_linear_norm_act_grouped_at_full_size(device, n, k, c, norm, act):
+    """The weight-resident variant (K22r, n >= 64 k rows) with the per-group addend of the concat-free SIR / VFE layers:
+    x W_left^T + (groups W_right^T)[inv] against float64 on sampled rows; k not a multiple of 4 rows (padded stride)."""
+    import torch.nn.functional as F
+
+    from fullysparsefusion_amd import hip_ops as ops
+
+    torch.manual_seed(n + k)
+    kp = (k + 3) // 4 * 4
+    xbuf = torch.full((n, kp), float("nan"), device=device)
+    x = xbuf[:, :k]
+    x.copy_(torch.randn(n, k, device=device) * 2)
+    g = 9000
+    grp = torch.randn(g, c, device=device)
+    inv = torch.randint(0, g, (n,), device=device)
+    w = torch.randn(c, k, device=device) / k ** 0.5
+    gam, bet = torch.rand(c, device=device) + 0.5, torch.randn(c, device=device) * 0.1
+    bias = torch.randn(c, device=device)
+    out = ops.linear_norm_act(x, ops.linear_prepare_weight(w), c, bias=bias, norm=norm, gamma=gam, beta=bet, eps=1e-3, act=act,
+                              row_add=grp, row_add_index=inv)
+    rows = torch.cat([torch.randperm(n, device=device)[:4096], torch.tensor([0, 15, 16, n - 17, n - 1], device=device)])
+    y = F.linear(x[rows].double(), w.double(), bias.double()) + grp[inv[rows]].double()
+    y = F.layer_norm(y, (c,), gam.double(), bet.double(), 1e-3) if norm == "ln" else y * gam.double() + bet.double()
+    want = F.gelu(y) if act == "gelu" else F.relu(y)
+    assert float((out[rows].double() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    assert bool(torch.isfinite(out).all())
+    assert torch.equal(out, ops.linear_norm_act(x, ops.linear_prepare_weight(w), c, bias=bias, norm=norm, gamma=gam, beta=bet,
+                                                eps=1e-3, act=act, row_add=grp, row_add_index=inv))
+
+
 # ------------------------------------------------------------- SIR stack at 5e5 points, a 1.2e5-row segment
 def test_sir_stack_at_half_a_million_points_with_a_long_segment(fsf_pair, device):
     model, cpu = fsf_pair
