@@ -17,4 +17,14 @@ python tools/profiling/prof_summary.py gpurun_out/prof_tr/fsf_results.db 7 "rocp
 rm -rf gpurun_out/prof_tr
 bash tools/profiling/pmc_traffic.sh $tag > /dev/null 2>&1
 cp gpurun_out/${tag}_pmc_traffic.json $out/pmc_traffic.json
-tail -c 600 $out/bench.json; echo; tail -c 300 $out/bench_train.json; echo; tail -c 300 $out/bench_train_bs2.json; echo; tail -c 300 $out/bench_av2.json
+python tools/profiling/planes_layers.py > $out/spconv_layers_k9b_vs_k9c.txt 2>/dev/null
+{
+  echo "# rocprofv3 --pmc <counters> --kernel-trace (separate passes), averages per launch of fsf::spconv_fwd_planes_kernel on the"
+  echo "# 101 119-row 128 -> 128 submanifold layer of the 10-sweep frame (tools/profiling/planes_one.py 2); wave counters in quad-cycles"
+  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_MFMA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+    bash tools/profiling/pmc_kernel.sh spconv_fwd_planes $set -- python tools/profiling/planes_one.py 2 2>/dev/null
+  done
+} > $out/pmc_stalls_k9c.txt
+bash tools/profiling/planes_ablate.sh > /dev/null 2>&1
+cp gpurun_out/planes_ablate.txt $out/spconv_k9c_ablations.txt
+tail -c 700 $out/bench.json; echo; tail -c 300 $out/bench_train.json; echo; tail -c 300 $out/bench_train_bs2.json; echo; tail -c 300 $out/bench_av2.json

@@ -36,7 +36,7 @@ def calibrate(fetch_db, write_db):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     gib = float(1 << 30)
     out = {}
-    for kind, pat, read_b, write_b in (("stream", "copy", gib, gib), ("gather", "index", gib + 8 * (1 << 20), gib)):
+    for kind, pat, read_b, write_b in (("stream", "copy", gib, gib), ("gather", "gather", gib + 8 * (1 << 20), gib)):
         fk = [(n, v) for n, v in f.items() if pat in n.lower() and v[0] >= 3 and v[1] / v[0] > 1e5]
         wk = [(n, v) for n, v in w.items() if pat in n.lower() and v[0] >= 3 and v[1] / v[0] > 1e5]
         if fk and wk:
