@@ -191,9 +191,11 @@ struct SpStep {
 #ifndef SP_RG4_WPS
 #define SP_RG4_WPS 2  // workgroups per CU the 64-row variant is compiled for (3 and 4 measured 5-7 % slower: the compiler does better with the registers)
 #endif
-template <int RG, int TPW>
+// NKC > 0: every source is NKC * 32 channels wide (compile-time chunk loops, no per-chunk tests); NKC == 0: run-time widths.
+template <int RG, int TPW, int NKC>
 __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_planes_kernel(SpArgs a) {
   using S = SpSmem<RG, TPW>;
+  constexpr bool FIX = NKC > 0;
   constexpr int R = S::R;
   constexpr int CPW = RG / 4;  // cells of a step this wave gathers
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   __syncthreads();
   const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
   const int nsrc = a.c[1] > 0 ? 2 : 1;
-  const int nkc0 = a.c[0] / 32, nkc1 = a.c[1] / 32;
+  const int nkc0 = FIX ? NKC : a.c[0] / 32, nkc1 = FIX ? (nsrc == 2 ? NKC : 0) : a.c[1] / 32;
   const int nchunks = nkc0 + nkc1;  // 32-cin chunks of the concatenated input (the weight fragments are laid out over them)
 #ifdef SP_ABL_NO_LOOP  // ablation: prologue + epilogue only
   const int nsteps = 0;
@@ -280,44 +282,43 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   uint4 st_hi[CPW][SP_NKC], st_lo[CPW][SP_NKC];
   float st_sc[CPW];
   auto load_x = [&](const SpStep& st) {
-    const char* xb = a.x[st.src];
-    const float* sb = a.sx[st.src];
+    const char* xb = st.src ? a.x[1] : a.x[0];  // (a run-time index would put the whole argument block in scratch)
+    const float* sb = st.src ? a.sx[1] : a.sx[0];
     const uint32_t rb = st.src ? rowbytes1 : rowbytes0;
-    const int nkc = st.src ? nkc1 : nkc0;
+    const int nkc = FIX ? NKC : (st.src ? nkc1 : nkc0);
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
       const int cc = wave * CPW + u;
+      // A row without a neighbour at this offset reads the all-zero row m_in (scale 1): no predication and no zero fill.
+      // Dead cells are not skipped here (their 16 lanes all read that one row; store_x drops them): the staging registers
+      // are then assigned on every path — written under a branch they ended up in scratch.
 #pragma unroll
-      for (int kc = 0; kc < SP_NKC; ++kc) {
+      for (int kc = 0; kc < SP_NKC; ++kc) {  // (dead stores, removed by the compiler — but without them the arrays stay in scratch)
         st_hi[u][kc] = make_uint4(0, 0, 0, 0);
         st_lo[u][kc] = make_uint4(0, 0, 0, 0);
       }
-      st_sc[u] = 1.0f;
-      if ((st.mask >> cc) & 1u) {
-        const int i = nbr_s[(16 * cc + j) * kvol + st.k];
-        if (i >= 0) {
+      int i = nbr_s[(16 * cc + j) * kvol + st.k];
+      i = i >= 0 ? i : (int)a.m_in;
 #ifdef SP_ABL_NO_X
-          const char* p = xb + (uint32_t)(i & 15) * rb + (uint32_t)(q * 32);
+      const char* p = xb + (uint32_t)(i & 15) * rb + (uint32_t)(q * 32);
 #else
-          const char* p = xb + (uint32_t)i * rb + (uint32_t)(q * 32);  // (planes < 4 GiB: checked by the host)
+      const char* p = xb + (uint32_t)i * rb + (uint32_t)(q * 32);  // (planes < 4 GiB: checked by the host)
 #endif
 #pragma unroll
-          for (int kc = 0; kc < SP_NKC; ++kc) {
-            if (kc < nkc) {
-              st_hi[u][kc] = *reinterpret_cast<const uint4*>(p + kc * 128);
-              st_lo[u][kc] = *reinterpret_cast<const uint4*>(p + kc * 128 + 16);
-            }
-          }
-          st_sc[u] = sb[i];
+      for (int kc = 0; kc < SP_NKC; ++kc) {
+        if (FIX ? kc < NKC : true) {  // (run-time widths: chunks past the row's end are never stored; the address stays inside the planes of row i + 1 or the zero row's successor — see the host check)
+          st_hi[u][kc] = *reinterpret_cast<const uint4*>(p + (kc < nkc ? kc : 0) * 128);
+          st_lo[u][kc] = *reinterpret_cast<const uint4*>(p + (kc < nkc ? kc : 0) * 128 + 16);
         }
       }
+      st_sc[u] = sb[i];
     }
   };
   auto store_x = [&](const SpStep& st, int slot) {  // registers -> LDS in B-fragment order (lane-linear: conflict-free)
 #ifdef SP_ABL_NO_LDS_WRITE
     return;
 #endif
-    const int nkc = st.src ? nkc1 : nkc0;
+    const int nkc = FIX ? NKC : (st.src ? nkc1 : nkc0);
 #pragma unroll
     for (int u = 0; u < CPW; ++u) {
       const int cc = wave * CPW + u;
@@ -349,20 +350,24 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   };
   uint4 wf[SP_NKC][TPW][2];  // the current step's weights, chunk by chunk; a chunk's registers take the NEXT step's as soon
                              // as its MFMAs are issued (a rolling prefetch: no second buffer)
-  auto read_x = [&](const SpStep& st, int slot, int kc, uint4 (&xh)[RG], uint4 (&xl)[RG]) {
+  // One cell's fragments of chunk kc: the cell's registers are re-read for chunk kc + 1 as soon as its MFMAs are issued (the
+  // other cells' MFMAs cover the LDS latency), so one register set serves the whole step.
+  auto read_cell = [&](int slot, int kc, int g, uint4& xh, uint4& xl) {
 #ifdef SP_ABL_NO_LDS_READ
     return;
 #endif
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      if ((st.mask >> g) & 1u) {
-        const uint4* xs = xring + (((slot * RG + g) * SP_NKC + kc) * 2) * 64 + lane;
-        xh[g] = xs[0];
-        xl[g] = xs[64];
-      }
-    }
+    const uint4* xs = xring + (((slot * RG + g) * SP_NKC + kc) * 2) * 64 + lane;
+    xh = xs[0];
+    xl = xs[64];
   };
-  auto mma = [&](const SpStep& st, int kc, const uint4 (&xh)[RG], const uint4 (&xl)[RG]) {
+  // chunk kc of one cell; the first chunk starts the step's products from zero (no clearing pass over D)
+  auto mma_cell = [&](int kc, int g, const uint4& xh, const uint4& xl) {
+    const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh), bl = __builtin_bit_cast(sp_f16x8, xl);
+#ifdef SP_ABL_NO_MFMA
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+      D[g][t][0] = (kc == 0 ? 0.0f : D[g][t][0]) + __uint_as_float(xh.x ^ wf[kc][t][0].x ^ xl.y ^ wf[kc][t][1].y);
+#else
     sp_f16x8 wh[TPW], wl[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
@@ -370,46 +375,39 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
       wl[t] = __builtin_bit_cast(sp_f16x8, wf[kc][t][1]);
     }
 #pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      if ((st.mask >> g) & 1u) {
-        const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh[g]), bl = __builtin_bit_cast(sp_f16x8, xl[g]);
-#ifdef SP_ABL_NO_MFMA
+    for (int t = 0; t < TPW; ++t)
+      D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, kc == 0 ? sp_f32x4{0.f, 0.f, 0.f, 0.f} : D[g][t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) D[g][t][0] += __uint_as_float(xh[g].x ^ wf[kc][t][0].x ^ xl[g].y ^ wf[kc][t][1].y);
-#else
+    for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, D[g][t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, D[g][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, D[g][t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, D[g][t], 0, 0, 0);
+    for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, D[g][t], 0, 0, 0);
 #endif
-      }
-    }
   };
+  // (A second, test-free instruction stream for steps whose cells are all live was tried: with both streams in the loop the
+  // kernel spills 37-90 registers at two workgroups per CU and is 50 % slower.)
   auto compute = [&](const SpStep& st, const SpStep& nxt, int slot) {
-    const int nkc = st.src ? nkc1 : nkc0;
-    const int nkc_nxt = nxt.src ? nkc1 : nkc0;
-    // software pipeline over the chunks: chunk kc + 1's fragments are read from LDS (and the row scales of the fold) while
-    // chunk kc is multiplied; a chunk's weight registers take the next step's chunk as soon as its MFMAs are issued
-    uint4 xha[RG], xla[RG], xhb[RG], xlb[RG];
+    const int nkc = FIX ? NKC : (st.src ? nkc1 : nkc0);
+    const int nkc_nxt = FIX ? NKC : (nxt.src ? nkc1 : nkc0);
+    uint4 xh[RG], xl[RG];
     float inv[RG];
-    read_x(st, slot, 0, xha, xla);
 #pragma unroll
     for (int g = 0; g < RG; ++g)
-      if ((st.mask >> g) & 1u) inv[g] = sring[(slot * RG + g) * 64 + lane];
+      if ((st.mask >> g) & 1u) {
+        read_cell(slot, 0, g, xh[g], xl[g]);
+        inv[g] = sring[(slot * RG + g) * 64 + lane];
+      }
 #pragma unroll
-    for (int kc = 0; kc < SP_NKC; kc += 2) {
+    for (int kc = 0; kc < SP_NKC; ++kc) {
       if (kc < nkc) {
-        if (kc + 1 < nkc) read_x(st, slot, kc + 1, xhb, xlb);
-        mma(st, kc, xha, xla);
+#pragma unroll
+        for (int g = 0; g < RG; ++g)
+          if ((st.mask >> g) & 1u) {
+            mma_cell(kc, g, xh[g], xl[g]);
+            if (kc + 1 < nkc) read_cell(slot, kc + 1, g, xh[g], xl[g]);
+          }
       }
+      // this chunk's weight registers take the next step's chunk as soon as its MFMAs are issued (a rolling prefetch)
       if (kc < nkc_nxt) load_w(nxt, kc, wf[kc]);
-      if (kc + 1 < nkc) {
-        if (kc + 2 < nkc) read_x(st, slot, kc + 2, xha, xla);
-        mma(st, kc + 1, xhb, xlb);
-      }
-      if (kc + 1 < nkc_nxt) load_w(nxt, kc + 1, wf[kc + 1]);
     }
     // fold the step: this lane's row scale in every live cell
 #pragma unroll
@@ -417,11 +415,9 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
       if ((st.mask >> g) & 1u) {
         const float sc = __fmul_rn(inv[g], w_inv);
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(D[g][t][r], sc, acc[g][t][r]);
-          D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-        }
       }
     }
   };
@@ -595,18 +591,23 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
   static const int64_t rg8_min_rows = getenv("FSF_PLANES_RG8_MIN_ROWS") ? atoll(getenv("FSF_PLANES_RG8_MIN_ROWS")) : ((int64_t)1 << 40);  // 64-row blocks (3 workgroups per CU) win at every size measured
   const bool big = m_out >= rg8_min_rows;
   if ((m_in + 1) * (int64_t)(ca > cb ? ca : cb) * 4 >= (int64_t)1 << 32) return FSF_ERR_UNSUPPORTED;  // 32-bit gather offsets
-#define FSF_SP(RG_, TPW_)                                                                                                   \
+#define FSF_SP(RG_, TPW_, NKC_)                                                                                             \
   do {                                                                                                                     \
     using S = SpSmem<RG_, TPW_>;                                                                                           \
     static std::atomic<uint64_t> attr_done{0};                                                                             \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_planes_kernel<RG_, TPW_>, (int)S::bytes, attr_done));      \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_planes_kernel<RG_, TPW_, NKC_>, (int)S::bytes, attr_done)); \
     const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                              \
-    hipLaunchKernelGGL((spconv_fwd_planes_kernel<RG_, TPW_>), grid, dim3(256), S::bytes, stream, a);                       \
+    hipLaunchKernelGGL((spconv_fwd_planes_kernel<RG_, TPW_, NKC_>), grid, dim3(256), S::bytes, stream, a);                 \
   } while (0)
-  if (big && tpw == 2) FSF_SP(8, 2);
-  else if (big) FSF_SP(8, 1);
-  else if (tpw == 2) FSF_SP(4, 2);
-  else FSF_SP(4, 1);
+  // sources of one width (64 or 128 channels: every layer of the U-Net) get the variant with compile-time chunk loops
+  const int nkc_fix = (cb == 0 || cb == ca) && (ca == 64 || ca == 128) && !getenv("FSF_PLANES_GENERIC") ? ca / 32 : 0;
+  if (big && tpw == 2) FSF_SP(8, 2, 0);
+  else if (big) FSF_SP(8, 1, 0);
+  else if (tpw == 2 && nkc_fix == 4) FSF_SP(4, 2, 4);
+  else if (tpw == 2 && nkc_fix == 2) FSF_SP(4, 2, 2);
+  else if (tpw == 1 && nkc_fix == 2) FSF_SP(4, 1, 2);
+  else if (tpw == 2) FSF_SP(4, 2, 0);
+  else FSF_SP(4, 1, 0);
 #undef FSF_SP
   FSF_LAUNCH_CHECK();
   return FSF_OK;

@@ -33,3 +33,19 @@ for a, k, s in calls:
     rows.append((us, feat.shape[0], feat.shape[1], plan.m, mode, feat.stride(0), cnt, s))
 print(f"{len(rows)} calls, {sum(r[0] for r in rows):.0f} us")
 for r in sorted(rows, reverse=True): print(f"{r[0]:8.1f} us  n={r[1]:7d} c={r[2]:4d} m={r[3]:6d} mode={r[4]:4s} stride={r[5]:4d} longest={r[6]:6d}  {r[7]}")
+# how often are 16 / 32 / 128 consecutive rows one segment (what an in-epilogue segmented max could fold before its atomics)
+seen = set()
+for a, k, s in calls:
+    plan = a[1]
+    if a[2] != 'max' or id(plan) in seen: continue
+    seen.add(id(plan))
+    inv = plan.inv
+    n = inv.numel()
+    line = f"n={n:7d} m={plan.m:6d}"
+    for g in (16, 32, 128):
+        nb = n // g
+        blk = inv[:nb * g].view(nb, g)
+        uni = (blk == blk[:, :1]).all(1).float().mean().item()
+        runs = (blk[:, 1:] != blk[:, :-1]).sum(1).float().mean().item() + 1
+        line += f" | {g}: uniform {uni:.3f} runs/blk {runs:.2f}"
+    print(line, s)
