@@ -385,7 +385,10 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   };
   // (A second, test-free instruction stream for steps whose cells are all live was tried: with both streams in the loop the
   // kernel spills 37-90 registers at two workgroups per CU and is 50 % slower.)
-  auto compute = [&](const SpStep& st, const SpStep& nxt, int slot) {
+  // The staging of the following steps rides inside: X(s+1) registers -> LDS and the X(s+2) gather are issued when the last
+  // chunk's fragments have been requested, so the LDS queue (in order per wave) never has this step's reads behind the writes
+  // and the writes retire under the last chunk's MFMAs (at the top of the step they cost a quarter of the layer).
+  auto compute = [&](const SpStep& st, const SpStep& nxt, const SpStep& nxt2, int slot) {
     const int nkc = FIX ? NKC : (st.src ? nkc1 : nkc0);
     const int nkc_nxt = FIX ? NKC : (nxt.src ? nkc1 : nkc0);
     uint4 xh[RG], xl[RG];
@@ -399,6 +402,12 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
 #pragma unroll
     for (int kc = 0; kc < SP_NKC; ++kc) {
       if (kc < nkc) {
+#ifndef SP_STAGE_EARLY
+        if (kc == nkc - 1) {
+          store_x(nxt, slot ^ 1);
+          load_x(nxt2);
+        }
+#endif
 #pragma unroll
         for (int g = 0; g < RG; ++g)
           if ((st.mask >> g) & 1u) {
@@ -422,9 +431,10 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
     }
   };
 
-  // ---- main loop.  Step s = (live offset, source): [barrier] [X(s+1): registers -> LDS slot (s+1)%2] [load X(s+2) -> registers]
-  // [multiply step s from slot s%2 chunk by chunk, W(s+1) rolling in behind].  One barrier per step: it separates the reads of
-  // step s-1 from the writes into the same slot, and the writes of X(s) (during step s-1) from their reads.
+  // ---- main loop.  Step s = (live offset, source): [barrier] [multiply step s from slot s%2 chunk by chunk, W(s+1) rolling in
+  // behind; before the last chunk's MFMAs: X(s+1) registers -> LDS slot (s+1)%2, then the X(s+2) gather -> registers].  One barrier
+  // per step: it separates the reads of step s-1 from the writes into the same slot, and the writes of X(s) (during step s-1)
+  // from their reads.  (-DSP_STAGE_EARLY: the staging at the top of the step, as it was: 0-3 % slower per layer.)
   SpStep s0 = entry(0, 0);
   SpStep s1 = advance(s0);
   load_x(s0);
@@ -439,9 +449,11 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
     __syncthreads();
 #endif
     const int par = s & 1;
+#ifdef SP_STAGE_EARLY
     store_x(s1, par ^ 1);  // X(s+1), loaded during the previous step
     load_x(s2);            // X(s+2)
-    compute(s0, s1, par);
+#endif
+    compute(s0, s1, s2, par);
     s0 = s1;
     s1 = s2;
     s2 = advance(s2);

@@ -17,8 +17,8 @@ def spy(self, x, scale=None, shift=None, residual=None, relu=False):
 sp.SparseConvolution.forward = spy
 with torch.no_grad(): model.segmentor.extract_feat([inp["points"][0][:, :5].contiguous()], None)
 sp.SparseConvolution.forward = orig
-def t(f, it=10):
-    for _ in range(3): f()
+def t(f, it=40):
+    for _ in range(10): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(it): f()
