@@ -45,6 +45,9 @@ struct LnaArgs {
   // optional per-row addend before the norm: row_add[row_add_index[row]][c] — the right half of a
   // `cat([point_feats, group_feats[inv]], 1) @ W^T` product, applied to the groups once instead of to every point
   const float* row_add; const int64_t* row_add_index; int64_t row_add_stride;
+  // output channels per blockIdx.y slice (128 unless "sliced": independent layers side by side, one per slice), the width a
+  // LayerNorm spans (c, or the slice width), and the column offset between the inputs of consecutive slices
+  int slice_w, norm_w; int64_t x_slice_off;
 };
 
 __device__ __forceinline__ float lna_row_sum(float v) {
@@ -89,17 +92,17 @@ __device__ __forceinline__ float lna_act(float y, int act) {
 
 // weight [c, k] fp32 -> fragment-ordered bf16 planes (zero padded to T tiles x KP)
 __global__ void __launch_bounds__(256)
-    lna_prepare_kernel(const float* __restrict__ w, int k, int c, int T, int nkc, int nslice, uint4* planes) {
+    lna_prepare_kernel(const float* __restrict__ w, int k, int c, int T, int nkc, int nslice, int slice_w, uint4* planes) {
   const int64_t total = (int64_t)nslice * nkc * T * 64;  // (slice, chunk, tile, lane): three 16-byte fragments each
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
     const int t = (int)((idx >> 6) % T);
     const int kc = (int)(((idx >> 6) / T) % nkc);
     const int slice = (int)((idx >> 6) / ((int64_t)T * nkc));
-    const int col = 128 * slice + 16 * t + (lane & 15), k0 = kc * LNA_KC + 8 * (lane >> 4);
+    const int lc = 16 * t + (lane & 15), col = slice_w * slice + lc, k0 = kc * LNA_KC + 8 * (lane >> 4);
     float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (col < c && k0 + e < k) ? w[(int64_t)col * k + k0 + e] : 0.0f;
+    for (int e = 0; e < 8; ++e) v[e] = (lc < slice_w && col < c && k0 + e < k) ? w[(int64_t)col * k + k0 + e] : 0.0f;
     lna_u32x4 hi, mid, lo;
     lna_split8(v, hi, mid, lo);
     uint4* dst = planes + (((int64_t)slice * nkc + kc) * T + t) * 3 * 64 + lane;
@@ -115,7 +118,7 @@ __device__ __forceinline__ void lna_stage_vectors(const LnaArgs& a, int ch_base,
   for (int t = threadIdx.x; t < 384; t += LNA_NW * 64) {
     const int which = t >> 7, ch = ch_base + (t & 127);
     const float* src = which == 0 ? a.bias : (a.norm != 0 ? (which == 1 ? a.gamma : a.beta) : nullptr);
-    vec[t] = (src && ch < a.c) ? src[ch] : (which == 1 ? 1.0f : 0.0f);
+    vec[t] = (src && (t & 127) < a.slice_w && ch < a.c) ? src[ch] : (which == 1 ? 1.0f : 0.0f);
   }
   __syncthreads();
 }
@@ -126,7 +129,7 @@ __device__ __forceinline__ void lna_stage_vectors(const LnaArgs& a, int ch_base,
 template <int T>
 __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[LNA_RG][T], int64_t row0, int ch_base, int rowl,
                                              int grp, const float* vec) {
-  const float inv_c = 1.0f / (float)a.c;
+  const float inv_c = 1.0f / (float)a.norm_w;
 #pragma unroll
   for (int rg = 0; rg < LNA_RG; ++rg) {
     const int64_t row = row0 + 16 * rg + rowl;
@@ -147,12 +150,12 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
         float4 b[TB];
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
-          const int ch0 = ch_base + 16 * (t0 + t) + 4 * grp;
-          b[t] = *reinterpret_cast<const float4*>(add + (ch0 < a.c ? ch0 : 0));
+          const int lc0 = 16 * (t0 + t) + 4 * grp, ch0 = ch_base + lc0;
+          b[t] = *reinterpret_cast<const float4*>(add + (lc0 < a.slice_w && ch0 < a.c ? ch0 : 0));
         }
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
-          if (ch_base + 16 * (t0 + t) + 4 * grp < a.c) {
+          if (16 * (t0 + t) + 4 * grp < a.slice_w && ch_base + 16 * (t0 + t) + 4 * grp < a.c) {
             acc[rg][t0 + t][0] += b[t].x; acc[rg][t0 + t][1] += b[t].y; acc[rg][t0 + t][2] += b[t].z; acc[rg][t0 + t][3] += b[t].w;
           }
         }
@@ -170,7 +173,7 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
       for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float d = ch_base + 16 * t + 4 * grp + r < a.c ? acc[rg][t][r] - mean : 0.0f;
+          const float d = (16 * t + 4 * grp + r < a.slice_w && ch_base + 16 * t + 4 * grp + r < a.c) ? acc[rg][t][r] - mean : 0.0f;
           q += d * d;
         }
       rstd = rsqrtf(lna_row_sum(q) * inv_c + a.eps);
@@ -180,7 +183,7 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const int ch0 = ch_base + 16 * t + 4 * grp;
-        if (ch0 < a.c) {
+        if (16 * t + 4 * grp < a.slice_w && ch0 < a.c) {
           const float4 g = *reinterpret_cast<const float4*>(vec + 128 + 16 * t + 4 * grp);  // (1 / 0 without a norm)
           const float4 b = *reinterpret_cast<const float4*>(vec + 256 + 16 * t + 4 * grp);
           float4 y;
@@ -211,7 +214,7 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
   const int64_t nblk = (a.n + LNA_ROWS - 1) / LNA_ROWS;
   // more than 128 output channels: gridDim.y slices of 128, each an independent [rows, 128] product (no LayerNorm then:
   // its statistics span the slices; the caller runs fsf_norm_act on the result)
-  const int ch_base = 128 * (int)blockIdx.y;
+  const int ch_base = a.slice_w * (int)blockIdx.y;
   const uint4* planes = a.planes + (int64_t)blockIdx.y * nkc * CHUNK_U4;
 
   // weight chunk kc -> LDS buffer by LDS-DMA: fragment order in HBM == fragment order in LDS, 1 KB per wave instruction
@@ -231,14 +234,14 @@ __global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(L
     for (int rg = 0; rg < LNA_RG; ++rg) {
       int64_t r = blk * LNA_ROWS + (int64_t)wave * (LNA_RG * 16) + 16 * rg + rowl;
       if (r >= a.n) r = a.n - 1;  // rows past n repeat the last one (finite, never stored)
-      xrow[rg] = a.x + r * a.x_stride;
+      xrow[rg] = a.x + r * a.x_stride + (int64_t)blockIdx.y * a.x_slice_off;
     }
   };
   // raw x of one chunk: [row group][8 floats]; the NEXT chunk is requested while this one is split and multiplied.
   // Always exactly two 16-byte loads per row group: offsets past the row are clamped into it (x_stride is a multiple
   // of 4 and >= k, so a quad that holds any column < k is never clamped) and the columns >= k are zeroed afterwards
   // (what follows the row in memory may be NaN).
-  const int last_quad = (int)a.x_stride - 4;
+  const int last_quad = (int)a.x_stride - 4 - (int)((int64_t)blockIdx.y * a.x_slice_off);  // (relative to this slice's first column)
   auto load_x = [&](int kc, float (&v)[LNA_RG][8]) {
 #pragma unroll
     for (int rg = 0; rg < LNA_RG; ++rg) {
@@ -361,9 +364,68 @@ extern "C" int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t
   const int T = lna_tiles(c), nkc = (k + LNA_KC - 1) / LNA_KC, nslice = lna_slices(c);
   const int64_t total = (int64_t)nslice * nkc * T * 64;
   hipLaunchKernelGGL(lna_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k, (int)c, T, nkc,
-                     nslice, (uint4*)planes);
+                     nslice, 128, (uint4*)planes);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
+}
+
+// "sliced": nslice independent layers of slice_c output channels each, side by side in one launch (weight rows
+// [s * slice_c, (s + 1) * slice_c) belong to layer s)
+extern "C" int64_t fsf_linear_prepared_weight_sliced_bytes(int32_t k, int32_t nslice, int32_t slice_c) {
+  if (k < 1 || nslice < 1 || slice_c < 1 || slice_c > 128) return 0;
+  const int64_t nkc = (k + LNA_KC - 1) / LNA_KC;
+  return (int64_t)nslice * nkc * lna_tiles(slice_c) * 3 * 64 * 16;
+}
+
+extern "C" int fsf_linear_prepare_weight_sliced(const float* weight, int32_t k, int32_t nslice, int32_t slice_c, void* planes,
+                                                void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!weight || !planes || k < 1 || nslice < 1 || slice_c < 1 || slice_c > 128) return FSF_ERR_INVALID_ARG;
+  const int T = lna_tiles(slice_c), nkc = (k + LNA_KC - 1) / LNA_KC;
+  const int64_t total = (int64_t)nslice * nkc * T * 64;
+  hipLaunchKernelGGL(lna_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k,
+                     (int)(nslice * slice_c), T, nkc, (int)nslice, (int)slice_c, (uint4*)planes);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+static int lna_launch(const LnaArgs& a, int nslice, hipStream_t stream) {
+  const int64_t nblk = (a.n + LNA_ROWS - 1) / LNA_ROWS;
+  int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;  // LNA_WPS 4-wave workgroups per CU in total
+  if (gx > nblk) gx = nblk;
+  const dim3 grid((unsigned)gx, (unsigned)nslice);
+#define FSF_LNA(T_)                                                                                                     \
+  do {                                                                                                                 \
+    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4;                                                    \
+    static std::atomic<uint64_t> attr_done{0};                                                                         \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_>, (int)smem, attr_done));               \
+    hipLaunchKernelGGL((linear_norm_act_kernel<T_>), grid, dim3(LNA_NW * 64), smem, stream, a);                        \
+  } while (0)
+  const int T = lna_tiles(a.slice_w < a.c ? a.slice_w : a.c);
+  if (T == 2) FSF_LNA(2);
+  else if (T == 4) FSF_LNA(4);
+  else FSF_LNA(8);
+#undef FSF_LNA
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_linear_norm_act_sliced(const float* x, int64_t n, int32_t k, int64_t x_stride, int64_t x_slice_offset,
+                                          const void* planes, int32_t nslice, int32_t slice_c, const float* bias, int32_t norm,
+                                          const float* gamma, const float* beta, float eps, int32_t act, float* out,
+                                          int64_t out_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || k < 1 || nslice < 1 || slice_c < 1 || !planes || norm < 0 || norm > 2 || act < 0 || act > 2 ||
+      (norm != 0 && (!gamma || !beta)) || (n > 0 && (!x || !out)) || x_slice_offset < 0)
+    return FSF_ERR_INVALID_ARG;
+  if (slice_c > 128 || (slice_c % 4) != 0 || (x_stride % 4) != 0 || (x_slice_offset % 4) != 0 || (out_stride % 4) != 0 ||
+      ((uintptr_t)x % 16) != 0 || ((uintptr_t)out % 16) != 0)
+    return FSF_ERR_UNSUPPORTED;
+  if (x_stride < (int64_t)(nslice - 1) * x_slice_offset + k || out_stride < (int64_t)nslice * slice_c) return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n,
+            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset};
+  return lna_launch(a, nslice, stream);
 }
 
 extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
@@ -395,24 +457,6 @@ extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k,
   if (x_stride < k || out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
-            row_add, row_add_index, row_add_stride};
-  const int64_t nblk = (n + LNA_ROWS - 1) / LNA_ROWS;
-  const int nslice = lna_slices(c);
-  int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;  // LNA_WPS 4-wave workgroups per CU in total
-  if (gx > nblk) gx = nblk;
-  const dim3 grid((unsigned)gx, (unsigned)nslice);
-#define FSF_LNA(T_)                                                                                                     \
-  do {                                                                                                                 \
-    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4;                                                \
-    static std::atomic<uint64_t> attr_done{0};                                                                                      \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_>, (int)smem, attr_done));                                                                                                                  \
-    hipLaunchKernelGGL((linear_norm_act_kernel<T_>), grid, dim3(LNA_NW * 64), smem, stream, a);                  \
-  } while (0)
-  const int T = lna_tiles(c);
-  if (T == 2) FSF_LNA(2);
-  else if (T == 4) FSF_LNA(4);
-  else FSF_LNA(8);
-#undef FSF_LNA
-  FSF_LAUNCH_CHECK();
-  return FSF_OK;
+            row_add, row_add_index, row_add_stride, 128, (int)c, 0};
+  return lna_launch(a, lna_slices(c), stream);
 }

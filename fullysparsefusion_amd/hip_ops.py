@@ -69,6 +69,9 @@ _ARGTYPES = {
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
     "fsf_linear_norm_act": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
+    "fsf_linear_prepared_weight_sliced_bytes": [c_i32, c_i32, c_i32],
+    "fsf_linear_prepare_weight_sliced": [_P, c_i32, c_i32, c_i32, _P, _P],
+    "fsf_linear_norm_act_sliced": [_P, c_i64, c_i32, c_i64, c_i64, _P, c_i32, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
     "fsf_linear_norm_act_grouped": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P,
                                     c_i64, _P],
     "fsf_dynamic_point_pool_workspace_bytes": [c_i64, c_i64],
@@ -723,6 +726,40 @@ def linear_norm_act(x: torch.Tensor, planes: torch.Tensor, out_features: int, bi
                                            ptr(row_add), ptr(row_add_index), row_add.stride(0), norm_code, ptr(gamma),
                                            ptr(beta), float(eps), act_code, c_p(out.data_ptr()) if n else c_p(None), os_,
                                            stream_ptr()), "fsf_linear_norm_act_grouped")
+    return out
+
+
+def linear_prepare_weight_sliced(weight: torch.Tensor, nslice: int, slice_c: int):
+    """fsf_linear_prepare_weight_sliced: the stacked weights f32 [nslice * slice_c, k] of nslice independent layers -> planes."""
+    require_cuda(weight)
+    weight = weight.detach().contiguous()
+    assert weight.dim() == 2 and weight.size(0) == nslice * slice_c and 1 <= slice_c <= 128
+    k = weight.size(1)
+    h = _L()
+    planes = torch.empty(h.fsf_linear_prepared_weight_sliced_bytes(k, nslice, slice_c), dtype=torch.uint8, device=weight.device)
+    check(h.fsf_linear_prepare_weight_sliced(ptr(weight), k, nslice, slice_c, ptr(planes), stream_ptr()),
+          "fsf_linear_prepare_weight_sliced")
+    return planes
+
+
+def linear_norm_act_sliced(x: torch.Tensor, k: int, x_slice_offset: int, planes: torch.Tensor, nslice: int, slice_c: int, bias=None,
+                           norm: str = "none", gamma=None, beta=None, eps: float = 0.0, act: str = "none", out=None):
+    """fsf_linear_norm_act_sliced: nslice independent `act(norm(x_s @ W_s^T + b_s))` layers in one launch -> f32
+    [n, nslice * slice_c]; layer s reads the k columns of x from s * x_slice_offset (0: all layers share the input), its
+    LayerNorm spans its own slice_c channels.  bias / gamma / beta f32 [nslice * slice_c]."""
+    require_cuda(x, planes, bias, gamma, beta, out)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    n, c = x.size(0), nslice * slice_c
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1
+    xs = x.stride(0) if n > 1 else (x.size(1) + 3) // 4 * 4
+    os_ = out.stride(0) if n > 1 else (c + 3) // 4 * 4
+    norm_code, act_code = {"none": 0, "ln": 1, "affine": 2}[norm], {"none": 0, "relu": 1, "gelu": 2}[act]
+    check(_L().fsf_linear_norm_act_sliced(c_p(x.data_ptr()) if n else c_p(None), n, int(k), xs, int(x_slice_offset), ptr(planes),
+                                          int(nslice), int(slice_c), ptr(bias), norm_code, ptr(gamma), ptr(beta), float(eps),
+                                          act_code, c_p(out.data_ptr()) if n else c_p(None), os_, stream_ptr()),
+          "fsf_linear_norm_act_sliced")
     return out
 
 

@@ -7,10 +7,12 @@ conventions.  The MLPs are the fused Linear -> LayerNorm+GELU blocks of ops/sst_
 core/bbox.py; NMS is the HIP kernel pair K20.  Losses / target assignment (train time) are not built: `loss` raises.
 """
 import copy
+import os
 
 import torch
 import torch.nn as nn
 
+from .... import hip_ops
 from ...core.bbox import LiDARInstance3DBoxes, box3d_multiclass_nms, xywhr2xyxyr
 from ...ops.sst_ops import build_mlp
 from ...registry import BBOX_ASSIGNERS, BBOX_CODERS, HEADS, build_head, build_loss
@@ -32,7 +34,96 @@ class FSDSeparateHead(nn.Module):
             self.add_module(attr_name, build_mlp(in_channels, [hidden_dim] * num_layer + [out_dim], norm_cfg, is_head=True, act=act))
 
     def forward(self, x):
+        fused = self._forward_sliced(x)
+        if fused is not None:
+            return fused
         return {attr_name: getattr(self, attr_name)(x) for attr_name in self.attrs}
+
+    # ---- inference on the GPU: the attribute branches are independent MLPs of one shape on the same input, so layer i of
+    # all of them is ONE K22 launch (fsf_linear_norm_act_sliced) instead of one per attribute — per query head 15 launches
+    # (10 fused blocks + 5 library GEMMs for the 2..10-wide outputs) become 3, and a 10 k-row x 1024 -> 128 layer, which
+    # fills a third of the chip on its own, runs five abreast.  Per branch the arithmetic is unchanged.
+    _OUT_PAD = 16  # output channels per branch in the last (plain Linear) layer's launch: padded with zero weight rows
+
+    def _sliced_plan(self):
+        from ...ops.sst_ops import MLPBlock
+
+        names = list(self.attrs)
+        mlps = [getattr(self, a) for a in names]
+        depth = len(mlps[0])
+        if any(len(m) != depth for m in mlps) or depth < 2:
+            return None
+        params = [p for m in mlps for p in m.parameters()]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = self.__dict__.get("_fsf_sliced")
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        plan = None
+        blocks_ok = True
+        for li in range(depth - 1):
+            layer = [m[li] for m in mlps]
+            if not all(isinstance(b, MLPBlock) and len(b) == 3 and isinstance(b[0], nn.Linear) and isinstance(b[1], nn.LayerNorm)
+                       and b[1].elementwise_affine and len(b[1].normalized_shape) == 1 for b in layer):
+                blocks_ok = False
+                break
+            ref = layer[0]
+            act_code = "relu" if isinstance(ref[2], nn.ReLU) else (
+                "gelu" if isinstance(ref[2], nn.GELU) and getattr(ref[2], "approximate", "none") == "none" else None)
+            if act_code is None or any(type(b[2]) is not type(ref[2]) or b[0].weight.shape != ref[0].weight.shape
+                                       or b[1].eps != ref[1].eps or (b[0].bias is None) != (ref[0].bias is None) for b in layer):
+                blocks_ok = False
+                break
+            if ref[0].out_features % 4 or ref[0].out_features > 128:
+                blocks_ok = False
+                break
+        last = [m[depth - 1] for m in mlps]
+        if blocks_ok and all(isinstance(l, nn.Linear) and l.out_features <= self._OUT_PAD for l in last) \
+                and len({l.in_features for l in last}) == 1:
+            with torch.no_grad():
+                layers = []
+                for li in range(depth - 1):
+                    layer = [m[li] for m in mlps]
+                    h = layer[0][0].out_features
+                    w = torch.cat([b[0].weight for b in layer], 0)
+                    layers.append(dict(
+                        k=layer[0][0].in_features, h=h, planes=hip_ops.linear_prepare_weight_sliced(w, len(names), h),
+                        bias=torch.cat([b[0].bias for b in layer]) if layer[0][0].bias is not None else None,
+                        gamma=torch.cat([b[1].weight for b in layer]), beta=torch.cat([b[1].bias for b in layer]),
+                        eps=layer[0][1].eps,
+                        act="relu" if isinstance(layer[0][2], nn.ReLU) else "gelu"))
+                pad = self._OUT_PAD
+                kin = last[0].in_features
+                w = torch.zeros((len(names) * pad, kin), dtype=torch.float32, device=last[0].weight.device)
+                b = torch.zeros((len(names) * pad,), dtype=torch.float32, device=w.device)
+                for i, l in enumerate(last):
+                    w[i * pad:i * pad + l.out_features] = l.weight
+                    if l.bias is not None:
+                        b[i * pad:i * pad + l.out_features] = l.bias
+                plan = dict(names=names, layers=layers, out_k=kin, out_planes=hip_ops.linear_prepare_weight_sliced(w, len(names), pad),
+                            out_bias=b, out_dims=[l.out_features for l in last])
+        self.__dict__["_fsf_sliced"] = (key, plan)
+        return plan
+
+    def _forward_sliced(self, x):
+        if os.environ.get("FSF_HEAD_SLICED", "1") == "0":
+            return None
+        if (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))) or self.training:
+            return None
+        if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(0) >= 1 and x.stride(1) == 1
+                and (x.size(0) == 1 or x.stride(0) % 4 == 0) and x.data_ptr() % 16 == 0 and len(self.attrs) > 1):
+            return None
+        plan = self._sliced_plan()
+        if plan is None or plan["layers"][0]["k"] != x.size(1):
+            return None
+        ns = len(plan["names"])
+        h_prev = 0
+        for lay in plan["layers"]:
+            x = hip_ops.linear_norm_act_sliced(x, lay["k"], h_prev, lay["planes"], ns, lay["h"], bias=lay["bias"], norm="ln",
+                                               gamma=lay["gamma"], beta=lay["beta"], eps=lay["eps"], act=lay["act"])
+            h_prev = lay["h"]
+        y = hip_ops.linear_norm_act_sliced(x, plan["out_k"], h_prev, plan["out_planes"], ns, self._OUT_PAD, bias=plan["out_bias"])
+        pad = self._OUT_PAD
+        return {a: y[:, i * pad:i * pad + d] for i, (a, d) in enumerate(zip(plan["names"], plan["out_dims"]))}
 
 
 @HEADS.register_module()

@@ -217,6 +217,18 @@ int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_
                                 const float* bias, const float* row_add, const int64_t* row_add_index, int64_t row_add_stride,
                                 int32_t norm, const float* gamma, const float* beta, float eps, int32_t act, float* out,
                                 int64_t out_stride, void* stream);
+/* "Sliced": nslice INDEPENDENT layers of slice_c (<= 128, % 4 == 0) output channels each in ONE launch — the per-attribute
+ * MLPs of FSDSeparateHead (projects/mmdet3d_plugin/models/dense_heads/sparse_cluster_head_v2.py:18-50: center / dim / rot /
+ * vel / score branches, every one `build_mlp(in, [hidden] * num_layer + [out_dim])` on the SAME query features) side by side:
+ * out[:, s * slice_c : (s + 1) * slice_c] = act(norm_s(x[:, s * x_slice_offset : + k] W_s^T + bias_s)), weight rows
+ * [s * slice_c, (s + 1) * slice_c) = W_s, LayerNorm statistics per slice.  x_slice_offset = 0: every layer reads the same k
+ * columns (first layer of the branches); = slice_c of the previous call: layer s reads branch s's activations.  Per slice the
+ * arithmetic is that of fsf_linear_norm_act (results identical to nslice separate calls). */
+int64_t fsf_linear_prepared_weight_sliced_bytes(int32_t k, int32_t nslice, int32_t slice_c);
+int fsf_linear_prepare_weight_sliced(const float* weight, int32_t k, int32_t nslice, int32_t slice_c, void* planes, void* stream);
+int fsf_linear_norm_act_sliced(const float* x, int64_t n, int32_t k, int64_t x_stride, int64_t x_slice_offset, const void* planes,
+                               int32_t nslice, int32_t slice_c, const float* bias, int32_t norm, const float* gamma,
+                               const float* beta, float eps, int32_t act, float* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K0  multi-sweep point-cloud assembly on the device (input side of the path)

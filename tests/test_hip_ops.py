@@ -1241,6 +1241,75 @@ def test_linear_norm_act_grouped_equals_linear_of_concat(ops, device, n, g, cl, 
         assert float((got - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("n,k,ns,sc,off,norm,act", [(10641, 1024, 5, 128, 0, "ln", "gelu"), (3001, 128, 5, 128, 128, "ln", "gelu"),
+                                                    (777, 128, 5, 16, 128, "none", "none"), (5000, 96, 3, 64, 96, "affine", "relu"),
+                                                    (1, 64, 2, 32, 0, "ln", "relu"), (260, 70, 4, 20, 72, "ln", "gelu")])
+def test_linear_norm_act_sliced_equals_separate_calls(ops, device, n, k, ns, sc, off, norm, act):
+    """fsf_linear_norm_act_sliced: nslice independent layers in one launch == the same layers one fsf_linear_norm_act call at a
+    time (bit for bit: per slice the arithmetic is the same), and both == float64 to fp32 accuracy."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(n + k)
+    width = (ns - 1) * off + k
+    x = torch.randn(n, (width + 3) // 4 * 4, device=device) * 2
+    w = torch.randn(ns * sc, k, device=device) / k ** 0.5
+    bias = torch.randn(ns * sc, device=device) * 0.1
+    gam, bet = torch.rand(ns * sc, device=device) + 0.5, torch.randn(ns * sc, device=device) * 0.1
+    kw = dict(norm=norm, gamma=gam if norm != "none" else None, beta=bet if norm != "none" else None, eps=1e-3, act=act)
+    planes = ops.linear_prepare_weight_sliced(w, ns, sc)
+    out = ops.linear_norm_act_sliced(x, k, off, planes, ns, sc, bias=bias, **kw)
+    assert out.shape == (n, ns * sc)
+    for s in range(ns):
+        sl = slice(s * sc, (s + 1) * sc)
+        xs = x[:, s * off:s * off + k]
+        if (s * off) % 4 == 0 and (n == 1 or True):
+            one = ops.linear_norm_act(xs, ops.linear_prepare_weight(w[sl].contiguous()), sc, bias=bias[sl].contiguous(), norm=norm,
+                                      gamma=gam[sl].contiguous() if norm != "none" else None,
+                                      beta=bet[sl].contiguous() if norm != "none" else None, eps=1e-3, act=act)
+            assert torch.equal(out[:, sl], one), s
+        y = F.linear(xs.double(), w[sl].double(), bias[sl].double())
+        y32 = F.linear(xs, w[sl], bias[sl])
+        def tail(t, g=gam[sl], b=bet[sl]):
+            if norm == "ln":
+                t = F.layer_norm(t, (sc,), g.to(t.dtype), b.to(t.dtype), 1e-3)
+            elif norm == "affine":
+                t = t * g.to(t.dtype) + b.to(t.dtype)
+            return F.gelu(t) if act == "gelu" else F.relu(t) if act == "relu" else t
+        want, ref32 = tail(y), tail(y32)
+        scale = max(1.0, float(want.abs().max()))
+        err, err32 = float((out[:, sl].double() - want).abs().max()), float((ref32.double() - want).abs().max())
+        assert err <= max(3.0 * err32, 3e-6 * scale), (s, err, err32)
+
+
+def test_separate_head_branches_in_one_launch_per_layer(ops, device):
+    """FSDSeparateHead at inference: the attribute MLPs run layer by layer as sliced launches; results == the per-attribute
+    modules (fused blocks bit for bit; the 2..10-wide output layer to fp32 GEMM accuracy)."""
+    from fullysparsefusion_amd.mmdet3d_plugin.models.dense_heads.cluster_heads import FSDSeparateHead
+
+    torch.manual_seed(5)
+    attrs = dict(center=(3, 2, 128), dim=(3, 2, 128), rot=(2, 2, 128), vel=(2, 2, 128), score=(10, 2, 128))
+    head = FSDSeparateHead(1024, attrs, norm_cfg=dict(type="LN"), act="gelu").to(device).eval()
+    with torch.no_grad():
+        for p in head.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    x = torch.randn(10397, 1024, device=device)
+    with torch.no_grad():
+        got = head(x)
+        assert head.__dict__["_fsf_sliced"][1] is not None
+        ref = {a: getattr(head, a)(x) for a in attrs}
+        hid = {a: getattr(head, a)[1](getattr(head, a)[0](x)) for a in attrs}
+    for a, (d, _, _) in attrs.items():
+        assert got[a].shape == (x.size(0), d)
+        want = torch.nn.functional.linear(hid[a].double(), getattr(head, a)[2].weight.double(), getattr(head, a)[2].bias.double())
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got[a].double() - want).abs().max()) <= max(3e-6 * scale, 3.0 * float((ref[a].double() - want).abs().max())), a
+    # a training-mode / grad-enabled call keeps the per-attribute modules
+    head.train()
+    out = head(x[:64].requires_grad_(True))
+    assert out["center"].requires_grad
+
+
 def test_column_stats_and_batch_norm_edge_cases(ops, device):
     """K23 with no rows: sums / statistics / gradients are zeros, nothing is launched on empty inputs; a single row."""
     x0 = torch.empty(0, 12, device=device)
