@@ -273,6 +273,14 @@ def _acc_cam_select(a, k, out):
     return "cam_select_score", n * (8.0 * ncam * ncls + 4.0 * ncls + (8.0 * ncls if k.get("return_ids") else 0.0)), 0.0
 
 
+def _acc_project_score(a, k, out):
+    xyz, mask = a[0], a[2]
+    n, (ncam, ncls) = xyz.size(0), mask.shape[:2]
+    # 12 B/pt of xyz + one mask element per (cam, class) read; the f32 score row (+ i64 ids when asked for) + the flag written
+    ids = 8.0 * ncls if k.get("return_ids") else 0.0
+    return "project_score", n * (12.0 + ncam * ncls * mask.element_size() + 4.0 * ncls + ids + 1.0), 0.0
+
+
 def _acc_sir_input(a, k, out):
     points, feats, f_cluster = a[0], a[1], a[2]
     extra = k.get("extra", a[7] if len(a) > 7 else None)
@@ -286,6 +294,13 @@ def _acc_linear(a, k, out):
     n, kk = x.shape
     grouped = k.get("row_add") is not None
     return ("linear_norm_act", n * 4.0 * (kk + c) + (n * (8.0 + 4.0 * c) if grouped else 0.0), 2.0 * n * kk * c)
+
+
+def _acc_linear_sliced(a, k, out):
+    x, kk, nslice, slice_c = a[0], int(a[1]), int(a[4]), int(a[5])
+    n = x.size(0)
+    reads = kk * (nslice if int(a[2]) > 0 else 1)  # distinct input columns (a shared input is read once from HBM)
+    return ("linear_norm_act", n * 4.0 * (reads + nslice * slice_c), 2.0 * n * kk * nslice * slice_c)
 
 
 def instrumented_pass(model, pool, steps, hot_path_only):
@@ -314,6 +329,9 @@ def instrumented_pass(model, pool, steps, hot_path_only):
     q.wrap(hip_ops, "cam_select_score", _acc_cam_select)
     q.wrap(hip_ops, "sir_input", _acc_sir_input)
     q.wrap(hip_ops, "linear_norm_act", _acc_linear)
+    q.wrap(hip_ops, "linear_norm_act_sliced", _acc_linear_sliced)
+    if hasattr(hip_ops, "project_score"):
+        q.wrap(hip_ops, "project_score", _acc_project_score)
     try:
         step(model, pool[0], hot_path_only)
         torch.cuda.synchronize()
