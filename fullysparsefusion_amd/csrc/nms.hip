@@ -28,6 +28,7 @@ struct NmsArgs {
   // multi-class form: one scan workgroup per class over its own (mask, rowsum, keep) slice; boxes per class on the device
   const int32_t* count;
   int64_t mask_stride, sum_stride, keep_stride;
+  int64_t max_keep;  // > 0: a scan stops once it has kept this many boxes (the caller only uses the best max_keep of a class)
 };
 
 struct NmsBuildArgs {
@@ -381,11 +382,13 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
       if (lane == 0) {
         kept_word = kept;
         int64_t k = nkeep;
-        for (uint64_t m = kept; m; m &= m - 1) a.keep[k++] = i0 + __builtin_ctzll(m);
+        const int64_t cap = a.max_keep > 0 ? a.max_keep : a.n;
+        for (uint64_t m = kept; m && k < cap; m &= m - 1) a.keep[k++] = i0 + __builtin_ctzll(m);
         nkeep = k;
       }
     }
     __syncthreads();
+    if (a.max_keep > 0 && nkeep >= a.max_keep) break;  // (uniform: nkeep was written before the barrier)
     const uint64_t kept = kept_word;
     const int q0 = w >> 6;
     if (pre) {
@@ -500,7 +503,7 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
   if (n == 0) {
     FSF_HIP_TRY(hipMemsetAsync(ndev, 0, sizeof(int64_t), stream));
   } else {
-    NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, ndev, nullptr, 0, 0, 0};
+    NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, ndev, nullptr, 0, 0, 0, 0};
     FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)n * sum_words * 8, stream));
     const int rc = nms_launch_mask(a, arena, stream);
     if (rc != FSF_OK) return rc;
@@ -521,9 +524,20 @@ extern "C" int64_t fsf_nms_bev_multiclass_workspace_bytes(int64_t n, int32_t num
   return (1 + c1) * (fsf_align_up(n1 * w1 * 8, 256) + fsf_align_up(n1 * s1 * 8, 256)) + 512 + nms_bins_bytes(n);
 }
 
+extern "C" int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank,
+                                             const int32_t* count, float thresh, int32_t rotated, int64_t max_keep, int64_t* keep,
+                                             int64_t* num_keep, void* workspace, int64_t workspace_bytes, void* stream_);
+
 extern "C" int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank,
                                       const int32_t* count, float thresh, int32_t rotated, int64_t* keep, int64_t* num_keep,
                                       void* workspace, int64_t workspace_bytes, void* stream_) {
+  return fsf_nms_bev_multiclass_capped(boxes, n, num_classes, rank, count, thresh, rotated, 0, keep, num_keep, workspace,
+                                       workspace_bytes, stream_);
+}
+
+extern "C" int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank,
+                                             const int32_t* count, float thresh, int32_t rotated, int64_t max_keep, int64_t* keep,
+                                             int64_t* num_keep, void* workspace, int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || num_classes < 1 || !count || !num_keep || (n > 0 && (!boxes || !rank || !keep))) return FSF_ERR_INVALID_ARG;
   const int64_t words = (n + 63) / 64, sum_words = (words + 63) / 64;
@@ -543,14 +557,14 @@ extern "C" int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num
   FSF_HIP_TRY(hipMemsetAsync(rowsum0, 0, (size_t)n * sum_words * 8, stream));
   FSF_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)num_classes * n * words * 8, stream));
   FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)num_classes * n * sum_words * 8, stream));
-  NmsArgs a0{boxes, n, thresh, (int)rotated, mask0, rowsum0, (int)words, (int)sum_words, nullptr, nullptr, nullptr, 0, 0, 0};
+  NmsArgs a0{boxes, n, thresh, (int)rotated, mask0, rowsum0, (int)words, (int)sum_words, nullptr, nullptr, nullptr, 0, 0, 0, 0};
   const int rc = nms_launch_mask(a0, arena, stream);
   if (rc != FSF_OK) return rc;
   NmsBuildArgs b{mask0, rowsum0, rank, mask, rowsum, n, (int)words, (int)sum_words};
   hipLaunchKernelGGL(nms_build_kernel, dim3((unsigned)fsf_stream_grid(n * sum_words, 256), (unsigned)num_classes), dim3(256), 0,
                      stream, b);
   NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, num_keep, count,
-            n * words, n * sum_words, n};
+            n * words, n * sum_words, n, max_keep};
   hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)num_classes), dim3(256), (size_t)words * 8, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;

@@ -81,6 +81,7 @@ _ARGTYPES = {
     "fsf_nms_bev": [_P, c_i64, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_nms_bev_multiclass_workspace_bytes": [c_i64, c_i32],
     "fsf_nms_bev_multiclass": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_nms_bev_multiclass_capped": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i64, _P, _P, _P, c_i64, _P],
     "fsf_connected_components_grouped": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
@@ -811,9 +812,11 @@ def nms_bev(boxes_sorted: torch.Tensor, thresh: float, rotated: bool = True):
     return keep[: int(num.value)]
 
 
-def nms_bev_multiclass(boxes: torch.Tensor, rank: torch.Tensor, count: torch.Tensor, thresh: float, rotated: bool = True):
-    """fsf_nms_bev_multiclass: boxes f32 [n,5] (caller's order), rank i32 [C,n], count i32 [C] ->
-    (keep i64 [C,n] kept ranks per class, num_keep i64 [C]), all on the device (no sync)."""
+def nms_bev_multiclass(boxes: torch.Tensor, rank: torch.Tensor, count: torch.Tensor, thresh: float, rotated: bool = True,
+                       max_keep: int = 0):
+    """fsf_nms_bev_multiclass[_capped]: boxes f32 [n,5] (caller's order), rank i32 [C,n], count i32 [C] ->
+    (keep i64 [C,n] kept ranks per class, num_keep i64 [C]), all on the device (no sync); max_keep > 0 stops a class after
+    that many kept boxes."""
     require_cuda(boxes, rank, count)
     assert boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.size(1) == 5
     assert rank.dtype == torch.int32 and count.dtype == torch.int32 and rank.dim() == 2 and rank.size(1) == boxes.size(0)
@@ -823,8 +826,8 @@ def nms_bev_multiclass(boxes: torch.Tensor, rank: torch.Tensor, count: torch.Ten
     num = torch.empty((c,), dtype=torch.int64, device=b.device)
     h = _L()
     ws = _lib.workspace(h.fsf_nms_bev_multiclass_workspace_bytes(n, c), b.device)
-    check(h.fsf_nms_bev_multiclass(ptr(b), n, c, ptr(rank), ptr(count), float(thresh), int(bool(rotated)), ptr(keep), ptr(num),
-                                   ptr(ws), ws.numel(), stream_ptr()), "fsf_nms_bev_multiclass")
+    check(h.fsf_nms_bev_multiclass_capped(ptr(b), n, c, ptr(rank), ptr(count), float(thresh), int(bool(rotated)), int(max_keep),
+                                          ptr(keep), ptr(num), ptr(ws), ws.numel(), stream_ptr()), "fsf_nms_bev_multiclass_capped")
     return keep, num
 
 

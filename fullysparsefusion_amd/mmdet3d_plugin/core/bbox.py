@@ -166,7 +166,8 @@ def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_th
     rank = torch.empty_like(pos).scatter_(1, order, pos)
     rank = torch.where(valid, rank, rank.new_full((), -1))
     keep, num = hip_ops.nms_bev_multiclass(mlvl_bboxes_for_nms.float(), rank, count, cfg["nms_thr"],
-                                           rotated=bool(cfg.get("use_rotate_nms", False)))
+                                           rotated=bool(cfg.get("use_rotate_nms", False)),
+                                           max_keep=int(max_num) if max_num is not None and max_num > 0 else 0)  # (only the best max_num survive below)
     kept = (torch.arange(n, device=st.device)[None, :] < num[:, None]).nonzero(as_tuple=False)  # class-major, score order
     labels = kept[:, 0]
     box_idx = order[labels, keep[labels, kept[:, 1]]]

@@ -511,6 +511,14 @@ int64_t fsf_nms_bev_multiclass_workspace_bytes(int64_t n, int32_t num_classes);
 int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank, const int32_t* count,
                            float thresh, int32_t rotated, int64_t* keep, int64_t* num_keep, void* workspace,
                            int64_t workspace_bytes, void* stream);
+/* The same with a cap: a class scan stops after its first max_keep kept boxes (max_keep <= 0: no cap).  box3d_multiclass_nms
+ * [UNVENDORED mmdet3d.core.post_processing] keeps only the max_num best scores over all classes afterwards
+ * (frustum_cluster_head.py:661-663 passes cfg.max_num), and a class's kept boxes come out in descending score order, so
+ * its boxes past the first max_num can never be among them: same result, and the scan — a latency chain of one 64-box word
+ * per step — ends after max_num keeps instead of walking all n boxes. */
+int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank, const int32_t* count,
+                                  float thresh, int32_t rotated, int64_t max_keep, int64_t* keep, int64_t* num_keep,
+                                  void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K18  in-group rank (TorchEx ingroup_indices [UNVENDORED]); sst_ops.py:239-259.

@@ -930,6 +930,13 @@ def test_nms_bev_multiclass_equals_per_class_calls(ops, device):
         assert int(num[k]) == want.numel()
         assert torch.equal(keep[k, : int(num[k])], want)
     assert int(num[3]) == 0
+    # capped: every class scan stops after its first `cap` keeps == the head of the uncapped list
+    for cap in (1, 37, 64, 100000):
+        keep_c, num_c = ops.nms_bev_multiclass(boxes, rank, count, 0.25, True, max_keep=cap)
+        for k in range(c):
+            m = min(int(num[k]), cap)
+            assert int(num_c[k]) == m
+            assert torch.equal(keep_c[k, :m], keep[k, :m])
 
 
 # ------------------------------------------------------------------------------------------ K21 SIR-layer input
