@@ -349,6 +349,83 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_long_kernel(SegArgs a) {
   }
 }
 
+// ---- short segments (voxels: a few rows each, never more than a few hundred): thread = (segment, channel [quad]) walks the
+// segment's rows in sorted order — no chunking, no partials, no fix-up launches; several tensors over the same plan in ONE launch
+// (pre_voxelize reduces five).  Correct for any segment length (a long segment just serialises on its threads).
+constexpr int SEG_SHORT_MAX = 8;
+struct SegShortArgs {
+  const float* feat[SEG_SHORT_MAX];
+  float* out[SEG_SHORT_MAX];
+  int64_t stride[SEG_SHORT_MAX];
+  int c[SEG_SHORT_MAX];
+  int goff[SEG_SHORT_MAX + 1];  // prefix sums of the tensors' channel groups (c / VEC each)
+  int nt;
+  const int32_t* order;
+  const int32_t* seg_offsets;
+  int64_t n, m;
+  int64_t* argmax;  // max over ONE tensor only
+};
+
+template <int VEC, int MODE>
+__global__ void __launch_bounds__(256) seg_short_kernel(SegShortArgs a) {
+  const int gtot = a.goff[a.nt];
+  const int64_t total = a.m * gtot;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t seg = idx / gtot;
+    const int gg = (int)(idx - seg * gtot);
+    int t = 0;
+#pragma unroll
+    for (int u = 1; u < SEG_SHORT_MAX; ++u) t += (u < a.nt && gg >= a.goff[u]) ? 1 : 0;
+    const int ch = (gg - a.goff[t]) * VEC;
+    const float* __restrict__ f = a.feat[t] + ch;
+    const int64_t stride = a.stride[t];
+    const int S = a.seg_offsets[seg], E = a.seg_offsets[seg + 1];
+    Vec<VEC> acc;
+    int32_t arg[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      acc.v[q] = (MODE == MODE_MAX && E > S) ? -INFINITY : 0.0f;
+      arg[q] = -1;
+    }
+    for (int j0 = S; j0 < E; j0 += 4) {
+      int r[4];
+      Vec<VEC> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        r[u] = j0 + u < E ? a.order[j0 + u] : -1;
+        if (r[u] >= 0) v[u] = load_vec<VEC>(f + (int64_t)r[u] * stride);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r[u] < 0) continue;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          if constexpr (MODE == MODE_MAX) {
+            if (v[u].v[q] > acc.v[q] || arg[q] < 0) {
+              acc.v[q] = v[u].v[q];
+              arg[q] = r[u];
+            }
+          } else {
+            acc.v[q] = __fadd_rn(acc.v[q], v[u].v[q]);
+          }
+        }
+      }
+    }
+    if constexpr (MODE == MODE_MEAN) {
+      if (E > S) {
+        const float cntf = (float)(E - S);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc.v[q] = __fdiv_rn(acc.v[q], cntf);
+      }
+    }
+    store_vec<VEC>(a.out[t] + seg * a.c[t] + ch, acc);
+    if (MODE == MODE_MAX && a.argmax) {
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) a.argmax[seg * a.c[t] + ch + q] = E > S ? (int64_t)arg[q] : a.n;
+    }
+  }
+}
+
 static int pick_team(int c, int vec) {
   int groups = (c + vec - 1) / vec;
   int t = SEG_MIN_TEAM;
@@ -534,6 +611,44 @@ extern "C" int fsf_segment_reduce(const float* feat, int64_t feat_stride, int64_
   }
   a.team = pick_team(c, 1);
   return seg_launch<1>(a, mode, stream);
+}
+
+extern "C" int fsf_segment_reduce_short(const float* const* feats, const int64_t* feat_strides, const int32_t* channels,
+                                        int32_t ntensors, int64_t n, const int32_t* order, const int32_t* seg_offsets, int64_t m,
+                                        int32_t mode, float* const* outs, int64_t* argmax, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!feats || !feat_strides || !channels || !outs || ntensors < 1 || ntensors > SEG_SHORT_MAX || n < 0 || m < 0 || mode < 0 ||
+      mode > 2 || !seg_offsets || (n > 0 && !order) || (argmax && (ntensors != 1 || mode != MODE_MAX)))
+    return FSF_ERR_INVALID_ARG;
+  if (m == 0) return FSF_OK;
+  SegShortArgs a;
+  bool vec4 = true;
+  for (int t = 0; t < ntensors; ++t) {
+    const int64_t st = feat_strides[t] > 0 ? feat_strides[t] : channels[t];
+    if (channels[t] < 1 || st < channels[t] || !outs[t] || (n > 0 && !feats[t])) return FSF_ERR_INVALID_ARG;
+    a.feat[t] = feats[t]; a.out[t] = outs[t]; a.stride[t] = st; a.c[t] = channels[t];
+    vec4 = vec4 && (channels[t] % 4) == 0 && (st % 4) == 0 && (((uintptr_t)feats[t] | (uintptr_t)outs[t]) % 16) == 0;
+  }
+  a.goff[0] = 0;
+  for (int t = 0; t < SEG_SHORT_MAX; ++t) {
+    if (t >= ntensors) { a.feat[t] = nullptr; a.out[t] = nullptr; a.stride[t] = 0; a.c[t] = 0; }
+    a.goff[t + 1] = a.goff[t] + (t < ntensors ? channels[t] / (vec4 ? 4 : 1) : 0);
+  }
+  a.nt = ntensors; a.order = order; a.seg_offsets = seg_offsets; a.n = n; a.m = m; a.argmax = argmax;
+  const unsigned grid = (unsigned)fsf_stream_grid(m * a.goff[ntensors], 256);
+#define FSF_SEG_SHORT(V_, M_) hipLaunchKernelGGL((seg_short_kernel<V_, M_>), dim3(grid), dim3(256), 0, stream, a)
+  if (vec4) {
+    if (mode == MODE_SUM) FSF_SEG_SHORT(4, MODE_SUM);
+    else if (mode == MODE_MEAN) FSF_SEG_SHORT(4, MODE_MEAN);
+    else FSF_SEG_SHORT(4, MODE_MAX);
+  } else {
+    if (mode == MODE_SUM) FSF_SEG_SHORT(1, MODE_SUM);
+    else if (mode == MODE_MEAN) FSF_SEG_SHORT(1, MODE_MEAN);
+    else FSF_SEG_SHORT(1, MODE_MAX);
+  }
+#undef FSF_SEG_SHORT
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
 }
 
 extern "C" int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int32_t c, const int64_t* inv,

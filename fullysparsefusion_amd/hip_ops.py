@@ -25,6 +25,7 @@ _ARGTYPES = {
     "fsf_segment_plan_from_inverse": [_P, c_i64, c_i64, _P, _P, _P, _P, c_i64, _P],
     "fsf_segment_reduce_workspace_bytes": [c_i64, c_i64, c_i32],
     "fsf_segment_reduce": [_P, c_i64, c_i64, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_segment_reduce_short": [_P, _P, _P, c_i32, c_i64, _P, _P, c_i64, c_i32, _P, _P, _P],
     "fsf_segment_reduce_backward": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, _P],
     "fsf_gather_rows": [_P, c_i64, c_i32, _P, c_i64, _P, c_i64, _P],
     "fsf_norm_act": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i32, _P, c_i64, _P],
@@ -249,6 +250,31 @@ def segment_reduce(feat: torch.Tensor, plan: SegmentPlan, mode: str, return_argm
     check(h.fsf_segment_reduce(c_p(feat.data_ptr()), feat_stride, n, c, ptr(plan.order), ptr(plan.inv), ptr(plan.seg_offsets), plan.m, md,
                                ptr(out), ptr(argmax), ptr(ws), ws.numel(), stream_ptr()), "fsf_segment_reduce")
     return (out, argmax) if return_argmax else out
+
+
+def segment_reduce_short(feats, plan: SegmentPlan, mode: str, return_argmax=False):
+    """fsf_segment_reduce_short: the reduction of up to 8 tensors f32 [n, c_t] over ONE plan whose segments are short (voxels)
+    in one launch -> list of f32 [m, c_t] (+ argmax i64 [m, c] with a single tensor and mode='max')."""
+    feats = list(feats)
+    require_cuda(*feats)
+    assert 1 <= len(feats) <= 8 and all(f.dtype == torch.float32 and f.dim() == 2 and f.size(0) == plan.n for f in feats)
+    views = [_rows_view(f) for f in feats]
+    dev = feats[0].device
+    outs = [torch.empty((plan.m, f.size(1)), dtype=torch.float32, device=dev) for f in feats]
+    md = _MODES[mode]
+    argmax = None
+    if return_argmax and md == MODE_MAX:
+        assert len(feats) == 1
+        argmax = torch.empty((plan.m, feats[0].size(1)), dtype=torch.int64, device=dev)
+    nt = len(feats)
+    fp = (ctypes.c_void_p * nt)(*[v[0].data_ptr() if v[0].numel() else None for v in views])
+    op = (ctypes.c_void_p * nt)(*[o.data_ptr() if o.numel() else None for o in outs])
+    st = (ctypes.c_int64 * nt)(*[int(v[1]) for v in views])
+    cs = (ctypes.c_int32 * nt)(*[int(f.size(1)) for f in feats])
+    if plan.m > 0:
+        check(_L().fsf_segment_reduce_short(fp, st, cs, nt, plan.n, ptr(plan.order), ptr(plan.seg_offsets), plan.m, md, op,
+                                            ptr(argmax), stream_ptr()), "fsf_segment_reduce_short")
+    return (outs, argmax) if return_argmax else outs
 
 
 def segment_reduce_backward(grad_out: torch.Tensor, plan: SegmentPlan, mode: str, argmax: Optional[torch.Tensor] = None):

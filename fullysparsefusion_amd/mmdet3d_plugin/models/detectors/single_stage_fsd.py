@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .... import hip_ops
-from ...ops.sst_ops import gather_by_inverse, get_inner_win_inds, scatter_v2, unique_with_plan
+from ...ops.sst_ops import gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, unique_with_plan
 from ...ops.voxel import Voxelization
 from ...registry import (DETECTORS, SEGMENTORS, build_backbone, build_detector, build_head, build_middle_encoder,
                          build_neck, build_voxel_encoder)
@@ -253,7 +253,8 @@ class SingleStageFSD(nn.Module):
         v_idx = valid.nonzero(as_tuple=False).squeeze(1)
         g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
         centers = centers.index_select(0, v_idx)
-        vox_centers, vox_keys, vox_inv = scatter_v2(centers, keys.index_select(0, v_idx), mode="avg", return_inv=True)
+        vox_centers, vox_keys, vox_inv = scatter_v2(centers, keys.index_select(0, v_idx), mode="avg", return_inv=True,
+                                                    short_segments=True)
         vox_group = torch.div(vox_keys[:, 0], bsz, rounding_mode="floor")
         dist = torch.tensor([ca._per_class(ca.connected_dist, n) for n in ca.class_names[:ng]], device=dev, dtype=torch.float32)
         # test-time clustering ignores the sample index inside a group (:69-82); components never span groups
@@ -293,12 +294,10 @@ class SingleStageFSD(nn.Module):
         coors = hip_ops.voxelize_divfloor(points, self.cfg["pre_voxelization_size"],
                                           self.cluster_assigner.point_cloud_range[:3], order="zyx", batch_idx=batch_idx)
         new_coors, unq_inv, _ = unique_with_plan(coors)
-        voxelized = {}
+        # (upstream: one scatter_v2(.., mode='avg') per float field over the shared unique; here the fields go through one launch)
+        names = [name for name, data in data_dict.items() if data.dtype in (torch.float, torch.float16)]
+        voxelized = dict(zip(names, scatter_mean_multi([data_dict[n] for n in names], new_coors, unq_inv)))
         voxel_coors = new_coors
-        for name, data in data_dict.items():
-            if data.dtype in (torch.float, torch.float16):
-                voxelized[name], voxel_coors = scatter_v2(data, coors, mode="avg", return_inv=False, new_coors=new_coors,
-                                                          unq_inv=unq_inv)
         voxelized["batch_idx"] = voxel_coors[:, 0]
         return voxelized
 

@@ -89,7 +89,8 @@ class DynamicScatterVFE(nn.Module):
             new_coors = unq_inv = None
         features_ls = [features]
         if self._with_cluster_center:
-            voxel_mean, mean_coors, unq_inv_c = scatter_v2(features, coors, mode="avg", unq_inv=unq_inv, new_coors=new_coors)
+            voxel_mean, mean_coors, unq_inv_c = scatter_v2(features, coors, mode="avg", unq_inv=unq_inv, new_coors=new_coors,
+                                                           short_segments=True)  # (segments = voxels of the detection grid)
             points_mean = gather_by_inverse(voxel_mean, unq_inv_c)
             features_ls.append(features[:, :3] - points_mean[:, :3])
         if self._with_voxel_center:
@@ -104,7 +105,7 @@ class DynamicScatterVFE(nn.Module):
         for i, vfe in enumerate(self.vfe_layers):
             last = i == len(self.vfe_layers) - 1
             point_feats, voxel_feats, voxel_coors, unq_inv_l, cat = point_group_concat(
-                vfe, features, coors, self.mode, unq_inv, new_coors, want_concat=not last)
+                vfe, features, coors, self.mode, unq_inv, new_coors, want_concat=not last, short_segments=True)
             if not last:
                 features = cat
         if self.return_point_feats:

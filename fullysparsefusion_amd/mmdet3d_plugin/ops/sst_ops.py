@@ -20,19 +20,25 @@ class _SegmentReduce(torch.autograd.Function):
     """Differentiable w.r.t. `feat` only, like torch_scatter's scatter / scatter_max (sst_ops.py:168-170)."""
 
     @staticmethod
-    def forward(ctx, feat, plan, mode):
+    def forward(ctx, feat, plan, mode, short=False):
         ctx.plan, ctx.mode = plan, mode
         if mode == "max" and feat.requires_grad:
-            out, arg = hip_ops.segment_reduce(feat, plan, "max", return_argmax=True)
+            if short:
+                outs, arg = hip_ops.segment_reduce_short([feat], plan, "max", return_argmax=True)
+                out = outs[0]
+            else:
+                out, arg = hip_ops.segment_reduce(feat, plan, "max", return_argmax=True)
             ctx.save_for_backward(arg)
             return out
         ctx.save_for_backward()
+        if short:
+            return hip_ops.segment_reduce_short([feat], plan, mode)[0]
         return hip_ops.segment_reduce(feat, plan, mode)
 
     @staticmethod
     def backward(ctx, grad_out):
         arg = ctx.saved_tensors[0] if ctx.mode == "max" else None
-        return hip_ops.segment_reduce_backward(grad_out.contiguous(), ctx.plan, ctx.mode, argmax=arg), None, None
+        return hip_ops.segment_reduce_backward(grad_out.contiguous(), ctx.plan, ctx.mode, argmax=arg), None, None, None
 
 
 class _GatherRows(torch.autograd.Function):
@@ -139,7 +145,7 @@ def _grouped_linear_norm_act(linear, norm, act, gc):
                                    eps=eps, act=act_code, row_add=table, row_add_index=inv.contiguous())
 
 
-def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, want_concat):
+def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, want_concat, short_segments=False):
     """One `DynamicVFELayer` step of DynamicScatterVFE / SIRLayer: point_feats = act(norm(linear(x))), group feats =
     segmented reduce, and (unless it is the last layer) `cat([point_feats, group_feats[inv]], 1)`.
     Inference: the fused norm+act writes the left half of the concat buffer and the row gather the right half — the
@@ -156,19 +162,26 @@ def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, wan
     if no_grad and vfe_layer.dropout is None and (want_concat or point_feats is not None):
         if point_feats is None:
             point_feats = linear_norm_act(vfe_layer.linear, vfe_layer.norm, vfe_layer.act, features)
-        group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors)
+        group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors,
+                                                   short_segments=short_segments)
         cat = None
         if want_concat:
             cat = GroupedConcat(point_feats, group_feats, inv) if _GROUPED_CONCAT else GroupedConcat(
                 point_feats, group_feats, inv).materialize()
         return point_feats, group_feats, group_coors, inv, cat
     point_feats = vfe_layer(features)
-    group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors)
+    group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors,
+                                               short_segments=short_segments)
     cat = torch.cat([point_feats, gather_by_inverse(group_feats, inv)], dim=1) if want_concat else None
     return point_feats, group_feats, group_coors, inv, cat
 
 
-def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, new_coors=None):
+_SHORT_SEGMENTS = os.environ.get("FSF_SEG_SHORT", "1") != "0"  # (A/B switch)
+
+
+def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, new_coors=None, short_segments=False):
+    """`short_segments` (not upstream): the caller knows the segments are voxels — a few rows each — and the reduction takes
+    the thread-per-(segment, channel) kernel (one launch instead of three; results equal up to the fp32 summation order)."""
     assert feat.size(0) == coors.size(0)
     if mode == "avg":
         mode = "mean"
@@ -187,10 +200,21 @@ def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, n
         coors = coors[valid_mask]
         new_coors, unq_inv, unq_cnt = unique_with_plan(coors)
     plan = plan_of(unq_inv, new_coors.size(0))
-    new_feat = _SegmentReduce.apply(feat.float(), plan, mode)
+    new_feat = _SegmentReduce.apply(feat.float(), plan, mode, bool(short_segments) and _SHORT_SEGMENTS)
     if not return_inv:
         return new_feat, new_coors
     return new_feat, new_coors, unq_inv
+
+
+def scatter_mean_multi(feats, new_coors, unq_inv):
+    """The mean of several per-point tensors over ONE short-segment plan (pre_voxelize: every float field of the point dict
+    over the same 0.1 m voxels) — at inference a single launch; otherwise one scatter_v2 per tensor."""
+    plan = plan_of(unq_inv, new_coors.size(0))
+    feats = [f.float() for f in feats]
+    if (_SHORT_SEGMENTS and 1 <= len(feats) <= 8 and all(f.is_cuda and f.dim() == 2 for f in feats)
+            and not (torch.is_grad_enabled() and any(f.requires_grad for f in feats))):
+        return hip_ops.segment_reduce_short(feats, plan, "mean")
+    return [_SegmentReduce.apply(f, plan, "mean", _SHORT_SEGMENTS) for f in feats]
 
 
 @torch.no_grad()

@@ -115,6 +115,15 @@ int fsf_segment_reduce(const float* feat, int64_t feat_stride, int64_t n, int32_
  *   mean: grad_feat[i,:] = grad_out[inv[i],:] / max(cnt[inv[i]],1)
  *   max : grad_feat[argmax[s,ch], ch] = grad_out[s,ch], zero elsewhere (torch_scatter scatter_max backward)
  */
+/* The same reduction for plans whose segments are SHORT (voxels: a few rows each): thread per (segment, channel), rows walked
+ * in sorted order, no workspace, no fix-up launches, and up to 8 tensors over the same plan in one launch (pre_voxelize,
+ * single_stage_fsd.py:585-605, takes the mean of every float field of the point dict over one unique).  Any segment length
+ * is handled (long ones serialise).  feats / feat_strides / channels / outs are HOST arrays of ntensors entries (device
+ * pointers inside); argmax only with ntensors == 1 and mode max.  A sum's order is the sorted order start to end (the chunked
+ * kernel folds chunk partials: the two differ by fp32 rounding on segments that straddle its 32-row chunks). */
+int fsf_segment_reduce_short(const float* const* feats, const int64_t* feat_strides, const int32_t* channels, int32_t ntensors,
+                             int64_t n, const int32_t* order, const int32_t* seg_offsets, int64_t m, int32_t mode,
+                             float* const* outs, int64_t* argmax, void* stream);
 int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int32_t c, const int64_t* inv,
                                 const int32_t* seg_offsets, int64_t m, int32_t mode, const int64_t* argmax,
                                 float* grad_feat, void* stream);

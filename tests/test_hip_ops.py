@@ -162,6 +162,54 @@ def test_segment_reduce_vs_oracle(ops, device, c, mode):
     assert torch.equal(first, out2)
 
 
+@pytest.mark.parametrize("mode", ["sum", "mean", "max"])
+def test_segment_reduce_short_vs_oracle_and_chunked(ops, device, mode):
+    """fsf_segment_reduce_short (thread per (segment, channel), several tensors in one launch) against the oracle and against
+    the chunked kernel: max / argmax bit for bit, sums to the fp32 summation order; empty segments -> 0 / n; a strided view
+    and a 600-row segment among the voxels."""
+    rng = np.random.default_rng(3)
+    n, m = 30000, 9000
+    inv = rng.integers(0, m, n)
+    inv[inv % 11 == 5] = 1        # unused ids (empty segments)
+    inv[:600] = 7                 # one long segment
+    inv = inv[rng.permutation(n)]
+    plan = ops.segment_plan_from_inverse(torch.from_numpy(inv).to(device), m)
+    widths = [131, 33, 11, 5, 64]
+    wide = torch.from_numpy(rng.standard_normal((n, 70)).astype(np.float32)).to(device)
+    feats = [torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(device) for c in widths[:-1]] + [wide[:, 4:68]]
+    outs = ops.segment_reduce_short(feats, plan, mode)
+    tinv = torch.from_numpy(inv)
+    cnt = torch.bincount(tinv, minlength=m)
+    for f, o in zip(feats, outs):
+        chunked = ops.segment_reduce(f, plan, mode)
+        if mode == "max":
+            want, _ = oscatter.segment_max(f.cpu(), tinv, m)
+            np.testing.assert_array_equal(o.cpu().numpy(), want.numpy())
+            assert torch.equal(o, chunked)
+        else:
+            want = oscatter.segment_sum(f.cpu().double(), tinv, m)
+            if mode == "mean":
+                want = want / cnt.clamp(min=1)[:, None]
+            # (segment 1 collects ~2 700 rows: a start-to-end fp32 sum of that length carries ~1e-4 of rounding at |sum| ~ 1e2)
+            np.testing.assert_allclose(o.cpu().numpy(), want.float().numpy(), rtol=1e-5, atol=2e-4 if mode == "sum" else 2e-5)
+            np.testing.assert_allclose(o.cpu().numpy(), chunked.cpu().numpy(), rtol=1e-5, atol=2e-4 if mode == "sum" else 2e-5)
+        assert not o[cnt.to(device) == 0].any()
+    # aligned multiples of four take the float4 variant; argmax with a single tensor
+    f4 = [feats[4].contiguous(), torch.from_numpy(rng.standard_normal((n, 128)).astype(np.float32)).to(device)]
+    o4 = ops.segment_reduce_short(f4, plan, mode)
+    for f, o in zip(f4, o4):
+        ref = ops.segment_reduce(f, plan, mode)
+        if mode == "max":
+            assert torch.equal(o, ref)
+        else:
+            np.testing.assert_allclose(o.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=2e-4 if mode == "sum" else 2e-5)
+    if mode == "max":
+        (o,), arg = ops.segment_reduce_short([f4[1]], plan, "max", return_argmax=True)
+        ref, ref_arg = ops.segment_reduce(f4[1], plan, "max", return_argmax=True)
+        assert torch.equal(o, ref) and torch.equal(arg, ref_arg)
+    assert all(torch.equal(a, b) for a, b in zip(outs, ops.segment_reduce_short(feats, plan, mode)))  # deterministic
+
+
 @pytest.mark.parametrize("case", sorted(golden_cases(load_golden("scatter_v2.npz"))))
 def test_segment_reduce_reference_golden(ops, device, case):
     g = golden_cases(load_golden("scatter_v2.npz"))[case]
