@@ -209,11 +209,22 @@ class SingleStageFSD(nn.Module):
         dev = seg_logits.device
         groups, class_names = cfg["group_names"], cfg["class_names"]
         ng = len(groups)
-        member = torch.zeros((ng, nc), dtype=torch.bool)
         group_cols = [sorted(class_names.index(n) for n in g) for g in groups]
-        for gi, cols in enumerate(group_cols):
-            member[gi, cols] = True
-        member = member.to(dev)
+
+        def const(key, make):  # per-model constants live on the device once (each upload was a blocking pageable copy per frame)
+            cache = self.__dict__.setdefault("_dev_consts", {})
+            t = cache.get((key, dev))
+            if t is None:
+                t = cache[(key, dev)] = make().to(dev)
+            return t
+
+        def _member():
+            mb = torch.zeros((ng, nc), dtype=torch.bool)
+            for gi, cols in enumerate(group_cols):
+                mb[gi, cols] = True
+            return mb
+
+        member = const(("member", ng, nc), _member)
         scores = seg_logits.softmax(1)[:, :-1]
         if max(len(cols) for cols in group_cols) <= 2:
             # every group has one or two classes (the nuScenes grouping): a 0/1 membership matmul adds the same one or two
@@ -222,7 +233,8 @@ class SingleStageFSD(nn.Module):
         else:
             # the reference's sums (same columns, same order as its boolean column mask; an index list does not sync the host)
             grouped_score = torch.stack([scores[:, cols].sum(1) for cols in group_cols], dim=1)
-        fg = grouped_score > torch.tensor(cfg["score_thresh"], device=dev, dtype=grouped_score.dtype)[None, :]
+        fg = grouped_score > const(("score_thresh", tuple(cfg["score_thresh"])),
+                                   lambda: torch.tensor(cfg["score_thresh"], dtype=grouped_score.dtype))[None, :]
         if bsz == 1:
             fg[0] |= ~fg.any(0)  # "at least one point per sample" (:832-834)
         else:
@@ -241,8 +253,9 @@ class SingleStageFSD(nn.Module):
         offset = d["vote_offsets"].reshape(-1, nc + 1, 3).index_select(0, p_ids)[:, :nc, :]
         centers = d["seg_points"][:, :3].index_select(0, p_ids) + (offset * w[:, :, None]).sum(dim=1)
         # cluster voxels: torch.div(.., 'floor') keys (:948-950) with the group's voxel size; group folded into the batch column
-        vsize = torch.tensor([ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]], device=dev, dtype=centers.dtype)
-        rmin = torch.tensor(ca.point_cloud_range[:3], device=dev, dtype=centers.dtype)
+        vsize = const("cluster_vsize", lambda: torch.tensor([ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]],
+                                                            dtype=centers.dtype))
+        rmin = const("cluster_rmin", lambda: torch.tensor(ca.point_cloud_range[:3], dtype=centers.dtype))
         vox = torch.div(centers - rmin[None, :], vsize.index_select(0, g_ids), rounding_mode="floor").long()
         b_pts = batch_idx.index_select(0, p_ids).long()
         keys = torch.cat([(g_ids * bsz + b_pts)[:, None], vox], dim=1)
@@ -256,7 +269,8 @@ class SingleStageFSD(nn.Module):
         vox_centers, vox_keys, vox_inv = scatter_v2(centers, keys.index_select(0, v_idx), mode="avg", return_inv=True,
                                                     short_segments=True)
         vox_group = torch.div(vox_keys[:, 0], bsz, rounding_mode="floor")
-        dist = torch.tensor([ca._per_class(ca.connected_dist, n) for n in ca.class_names[:ng]], device=dev, dtype=torch.float32)
+        dist = const("connected_dist", lambda: torch.tensor([ca._per_class(ca.connected_dist, n) for n in ca.class_names[:ng]],
+                                                            dtype=torch.float32))
         # test-time clustering ignores the sample index inside a group (:69-82); components never span groups
         labels = hip_ops.connected_components_grouped(vox_centers, vox_group, dist).long()
         first = torch.searchsorted(vox_group, torch.arange(ng, device=dev))            # voxels are group-sorted

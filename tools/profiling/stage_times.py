@@ -1,6 +1,6 @@
 """Wall time per stage of FSF.simple_test (sync between stages), 10-sweep frame."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import bench
 dev = torch.device('cuda:0')
 model = bench.build_model(dev)
