@@ -13,7 +13,10 @@
 //   (lx + l/2, ly + w/2, lz + h/2, l/2 - lx, w/2 - ly, h/2 - lz) | is_in_margin (1 = only inside the enlarged box).
 // Work: thread = RoI, workgroup = 256 RoIs x one tile of 2048 points staged in LDS (every lane reads the same point:
 //   LDS broadcast); a cheap enlarged-radius test in the xy-plane rejects almost every pair before the rotation.
+#include <stdlib.h>
+
 #include "common.h"
+#include "radix_sort.h"
 #include "scan.h"
 
 namespace fsf {
@@ -232,6 +235,237 @@ struct PoolScanOut {
   __device__ void operator()(int64_t i, uint32_t excl, uint32_t) const { off[i] = excl; }
 };
 
+// ---- the binned path (default): P x R tests only where they can succeed -------------------------------------------------
+// The brute-force passes above cost P x R pair tests behind a circle pre-test and run as a few hundred latency-bound
+// workgroups (10.6 k RoIs x 3.1e5 points: 1.06 ms).  Here the points are sorted ONCE by BEV cell (1 m cells, stable radix sort:
+// a cell's points stay in ascending index order), and a wave per RoI walks only the cells under its enlarged circle.  The result
+// is the same canonical list: a RoI's hits are gathered in LDS, sorted by point index (bitonic, one wave) and cut at max_inbox.
+// A RoI with more hits than the LDS list holds (a bus-sized box on the dense ground near the sensor) first narrows the point-index
+// range that contains its first max_inbox hits (histogram of the hits' indices over 1024 ranges, at most twice) and then gathers
+// only those.  Same pool_test, same features, same caps, same order as the brute-force passes (tests compare the two bit for bit).
+constexpr int PB_BITS = 10;                 // cells per axis: 1024 x 1024 around the origin, the border cells take everything beyond
+constexpr float PB_INV_CELL = 1.0f;         // 1 / (1 m): +-512 m
+constexpr int PB_NCELL = 1 << (2 * PB_BITS);
+constexpr int PB_CAP = 1024;                // hits per RoI sorted in LDS (>= max_inbox)
+constexpr int PB_BINS = 1024;               // index-range bins of the selection pass for RoIs with more hits than that
+
+__device__ __forceinline__ int pb_coord(float v) {
+  float f = floorf(v * PB_INV_CELL) + (float)(1 << (PB_BITS - 1));
+  f = fminf(fmaxf(f, 0.0f), (float)((1 << PB_BITS) - 1));  // (NaN -> 0: fmaxf returns the other operand)
+  return (int)f;
+}
+
+__global__ void __launch_bounds__(256) pb_keys_kernel(const float* __restrict__ pts, int64_t n, int stride, uint64_t* keys, uint32_t* vals) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* p = pts + i * stride;
+    keys[i] = (uint64_t)((pb_coord(p[1]) << PB_BITS) | pb_coord(p[0]));
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// cell -> [start, end) of its points in the sorted order (tables zeroed beforehand: an empty cell is [0, 0)), and the points
+// themselves in that order (x, y, z, batch index): a RoI's candidates are a few contiguous runs of 16-byte records
+__global__ void __launch_bounds__(256)
+    pb_cells_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ order, int64_t n, const float* __restrict__ pts, int stride,
+                    const int64_t* __restrict__ pts_batch, uint32_t* cell_start, uint32_t* cell_end, float4* sorted) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = keys[i];
+    if (i == 0 || keys[i - 1] != k) cell_start[k] = (uint32_t)i;
+    if (i == n - 1 || keys[i + 1] != k) cell_end[k] = (uint32_t)(i + 1);
+    const uint32_t pi = order[i];
+    const float* p = pts + (int64_t)pi * stride;
+    sorted[i] = make_float4(p[0], p[1], p[2], pts_batch ? (float)pts_batch[pi] : 0.0f);
+  }
+}
+
+struct PoolBinArgs {
+  PoolArgs a;
+  const uint32_t* order;       // point indices sorted by cell (ascending inside a cell)
+  const float4* sorted;        // the points in that order
+  const uint32_t* cell_start;
+  const uint32_t* cell_end;
+  uint32_t* hits_full;         // [n_rois] hits of the RoI before the max_inbox cut (PB_CAP + 1: more than the list holds)
+};
+
+// wave-wide walk over the candidate points of box k, 4 x 64 per round (four loads in flight per lane): f(point index, hit flag
+// 0/1/2) is called by every lane for each of the round's four 64-candidate groups in order (flag 0 past the cell's end and for
+// misses) and returns false (wave-uniform) to stop
+template <typename F>
+__device__ __forceinline__ void pb_for_candidates(const PoolBinArgs& b, const PoolBox& k, int lane, F&& f) {
+  const float rad = sqrtf(k.r2);
+  const int cx0 = pb_coord(k.cx - rad), cx1 = pb_coord(k.cx + rad), cy0 = pb_coord(k.cy - rad), cy1 = pb_coord(k.cy + rad);
+  const float kbatch = (float)k.batch;
+  // a box whose circle covers more than 1024 cells (or is not finite) walks the whole sorted array once instead of the table
+  const bool whole = !((cx1 - cx0 + 1) * (cy1 - cy0 + 1) <= 1024) || !(rad == rad);
+  const int ny = whole ? 1 : cy1 - cy0 + 1, nx = whole ? 1 : cx1 - cx0 + 1;
+  for (int iy = 0; iy < ny; ++iy) {
+    // a row of cells is one contiguous run of the sorted array (keys = y-major): walk [start of the first non-empty, end of the last)
+    uint32_t s = whole ? 0u : 0xffffffffu, e = whole ? (uint32_t)b.a.n_pts : 0u;
+    if (!whole) {
+      const int key0 = ((cy0 + iy) << PB_BITS) | cx0;
+      for (int ix = lane; ix < nx; ix += 64) {
+        const uint32_t cs = b.cell_start[key0 + ix], ce = b.cell_end[key0 + ix];
+        if (ce > cs) {
+          s = min(s, cs);
+          e = max(e, ce);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        s = min(s, (uint32_t)__shfl_xor((int)s, o));
+        e = max(e, (uint32_t)__shfl_xor((int)e, o));
+      }
+    }
+    for (uint32_t j0 = s; j0 < e; j0 += 256) {
+      float4 q[4];
+      uint32_t pi[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t j = j0 + 64 * u + lane;
+        const uint32_t jc = j < e ? j : s;
+        q[u] = b.sorted[jc];
+        pi[u] = b.order[jc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + 64 * u >= e) break;  // (uniform)
+        const uint32_t j = j0 + 64 * u + lane;
+        float lx, ly, lz;
+        const int flag = (j < e && q[u].w == kbatch) ? pool_test(k, q[u].x, q[u].y, q[u].z, lx, ly, lz) : 0;
+        if (!f(pi[u], flag)) return;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) pb_count_kernel(PoolBinArgs b) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= b.a.n_rois) return;
+  const PoolBox k = load_box(b.a, r);
+  uint32_t h = 0;
+  pb_for_candidates(b, k, lane, [&](uint32_t, int flag) {
+    h += (uint32_t)__popcll(__ballot(flag != 0));
+    return h <= (uint32_t)PB_CAP;  // more than the list holds: the fill pass selects by index range, the exact number is not needed
+  });
+  if (lane == 0) {
+    b.hits_full[r] = h <= (uint32_t)PB_CAP ? h : (uint32_t)PB_CAP + 1u;
+    b.a.roi_total[r] = h < (uint32_t)b.a.max_inbox ? h : (uint32_t)b.a.max_inbox;
+  }
+}
+
+__device__ __forceinline__ void pb_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void pb_write_row(const PoolArgs& a, const PoolBox& k, int64_t slot, int64_t r, uint32_t pi) {
+  const float* p = a.pts + (int64_t)pi * a.pts_stride;
+  const float x = p[0], y = p[1], z = p[2];
+  float lx, ly, lz;
+  const int flag = pool_test(k, x, y, z, lx, ly, lz);
+  a.out_pts[slot] = (int64_t)pi;
+  a.out_roi[slot] = r;
+  float* f = a.out_feat + slot * PP_FEAT;
+  f[0] = x; f[1] = y; f[2] = z;
+  f[3] = lx; f[4] = ly; f[5] = lz;
+  f[6] = lx + k.hl; f[7] = ly + k.hw; f[8] = lz + k.hh;
+  f[9] = k.hl - lx; f[10] = k.hw - ly; f[11] = k.hh - lz;
+  f[12] = flag == 2 ? 1.0f : 0.0f;
+}
+
+__global__ void __launch_bounds__(256) pb_fill_kernel(PoolBinArgs b) {
+  __shared__ uint32_t s_list[4][PB_CAP];
+  __shared__ uint32_t s_hist[4][PB_BINS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= b.a.n_rois) return;
+  const uint32_t base = b.a.roi_off[r];
+  const uint32_t keep = b.a.roi_total[r];
+  if (keep == 0 || (int64_t)base >= b.a.max_all) return;  // (wave-uniform)
+  const PoolBox k = load_box(b.a, r);
+  uint32_t* list = s_list[wave];
+  uint32_t limit = 0xffffffffu;  // collect the hits of point index < limit
+  if (b.hits_full[r] > (uint32_t)PB_CAP) {
+    // More hits than the list holds: find an index limit below which at least `keep` (= max_inbox) and at most PB_CAP hits lie —
+    // histogram of the hits' indices over PB_BINS equal ranges of [lo, hi), prefix, the range where the count crosses `keep`;
+    // repeat inside that range while it alone holds too many.
+    uint32_t* hist = s_hist[wave];
+    uint32_t lo = 0, hi = (uint32_t)b.a.n_pts, below = 0;  // `below` hits lie under lo
+    for (;;) {
+      const uint32_t width = (hi - lo + PB_BINS - 1) / PB_BINS;
+      for (int i = lane; i < PB_BINS; i += 64) hist[i] = 0;
+      pb_wave_sync();
+      pb_for_candidates(b, k, lane, [&](uint32_t pi, int flag) {
+        if (flag != 0 && pi >= lo && pi < hi) atomicAdd(&hist[(pi - lo) / width], 1u);
+        return true;
+      });
+      pb_wave_sync();
+      // first bin where the running count reaches `keep`: lane l sums bins [16 l, 16 l + 16)
+      uint32_t mine = 0;
+      for (int i = 0; i < PB_BINS / 64; ++i) mine += hist[lane * (PB_BINS / 64) + i];
+      uint32_t incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= o) incl += v;
+      }
+      const uint64_t reach = __ballot(below + incl >= keep);
+      const int wl = __builtin_ctzll(reach);  // (reach != 0: the RoI has more than PB_CAP >= keep hits)
+      uint32_t run = below + (uint32_t)__shfl((int)(incl - mine), wl);
+      int bin = wl * (PB_BINS / 64);
+      for (;; ++bin) {  // (wave-uniform walk over the 16 bins of lane wl)
+        const uint32_t c = hist[bin];
+        if (run + c >= keep) break;
+        run += c;
+      }
+      const uint32_t c = hist[bin];
+      const uint32_t bin_lo = lo + (uint32_t)bin * width, bin_hi = min(hi, bin_lo + width);
+      if (run + c <= (uint32_t)PB_CAP || width == 1) {  // (width 1: one point per bin, c <= 1)
+        limit = bin_hi;
+        break;
+      }
+      lo = bin_lo;
+      hi = bin_hi;
+      below = run;
+      pb_wave_sync();
+    }
+  }
+  uint32_t n_l = 0;
+  pb_for_candidates(b, k, lane, [&](uint32_t pi, int flag) {
+    const bool hit = flag != 0 && pi < limit;
+    const uint64_t bal = __ballot(hit);
+    if (hit) list[n_l + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = pi;
+    n_l += (uint32_t)__popcll(bal);
+    return true;
+  });
+  uint32_t np2 = 64;
+  while (np2 < n_l) np2 <<= 1;
+  for (uint32_t i = n_l + lane; i < np2; i += 64) list[i] = 0xffffffffu;
+  pb_wave_sync();
+  for (uint32_t kk = 2; kk <= np2; kk <<= 1)
+    for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+      for (uint32_t i = lane; i < np2; i += 64) {
+        const uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          const uint32_t va = list[i], vb = list[ixj];
+          const bool up = (i & kk) == 0;
+          if ((va > vb) == up) {
+            list[i] = vb;
+            list[ixj] = va;
+          }
+        }
+      }
+      pb_wave_sync();
+    }
+  const uint32_t n_out = n_l < keep ? n_l : keep;
+  for (uint32_t t = lane; t < n_out; t += 64) {
+    const int64_t slot = (int64_t)base + t;
+    if (slot >= b.a.max_all) break;
+    pb_write_row(b.a, k, slot, r, list[t]);
+  }
+}
+
 __global__ void pool_count_kernel(const uint32_t* total, int64_t max_all, int64_t* count_dev) {
   const int64_t t = (int64_t)*total;
   *count_dev = t < max_all ? t : max_all;
@@ -244,7 +478,9 @@ using namespace fsf;
 extern "C" int64_t fsf_dynamic_point_pool_workspace_bytes(int64_t n_pts, int64_t n_rois) {
   const int64_t pt_tiles = n_pts > 0 ? (n_pts + PP_TILE - 1) / PP_TILE : 1;
   const int64_t r = n_rois > 0 ? n_rois : 1;
-  return fsf_align_up(pt_tiles * r * 4, 256) + 2 * fsf_align_up(r * 4, 256) + fsf_align_up(scan_num_tiles(r) * 4, 256) + 768;
+  return fsf_align_up(pt_tiles * r * 4, 256) + 3 * fsf_align_up(r * 4, 256) + fsf_align_up(scan_num_tiles(r) * 4, 256) + 768 +
+         radix_sort_scratch_bytes(n_pts) + 2 * fsf_align_up((int64_t)PB_NCELL * 4, 256) +
+         fsf_align_up((n_pts > 0 ? n_pts : 1) * 16, 256);  // (+ the binned path's sort, cell tables and sorted points)
 }
 
 extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t roi_stride, int32_t box_col,
@@ -279,6 +515,43 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
                extra_wlh[0], extra_wlh[1], extra_wlh[2], (int)max_inbox_point, max_all_pts, cnt, roi_total, roi_off,
                out_pts_idx, out_roi_idx, out_pts_feats, 0, 0, chunk_total};
     if (!arena.ok()) return FSF_ERR_WORKSPACE;
+    const char* brute_env = getenv("FSF_POOL_BRUTE");  // (read per call: tests compare the two paths in one process)
+    const bool brute = brute_env && atoi(brute_env) != 0;
+    if (!brute && max_inbox_point <= PB_CAP) {
+      uint32_t* hits_full = arena.take<uint32_t>(r1);
+      uint64_t* keys_a = arena.take<uint64_t>(n_pts);
+      uint64_t* keys_b = arena.take<uint64_t>(n_pts);
+      uint32_t* vals_a = arena.take<uint32_t>(n_pts);
+      uint32_t* vals_b = arena.take<uint32_t>(n_pts);
+      uint32_t* hist = arena.take<uint32_t>((radix_num_tiles(n_pts) + 1) * RS_BINS);
+      uint32_t* cell_start = arena.take<uint32_t>(PB_NCELL);
+      uint32_t* cell_end = arena.take<uint32_t>(PB_NCELL);
+      float4* sorted = arena.take<float4>(n_pts);
+      if (!arena.ok()) return FSF_ERR_WORKSPACE;
+      hipLaunchKernelGGL(pb_keys_kernel, dim3((unsigned)fsf_stream_grid(n_pts, 256)), dim3(256), 0, stream, pts, n_pts, (int)pts_stride,
+                         keys_a, vals_a);
+      uint64_t* keys = nullptr;
+      uint32_t* order = nullptr;
+      int rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, n_pts, 2 * PB_BITS, &keys, &order, stream);
+      if (rc != FSF_OK) return rc;
+      FSF_HIP_TRY(hipMemsetAsync(cell_start, 0, (size_t)PB_NCELL * 4, stream));
+      FSF_HIP_TRY(hipMemsetAsync(cell_end, 0, (size_t)PB_NCELL * 4, stream));
+      hipLaunchKernelGGL(pb_cells_kernel, dim3((unsigned)fsf_stream_grid(n_pts, 256)), dim3(256), 0, stream, keys, order, n_pts, pts,
+                         (int)pts_stride, pts_batch, cell_start, cell_end, sorted);
+      PoolBinArgs b{a, order, sorted, cell_start, cell_end, hits_full};
+      const unsigned wg = (unsigned)((n_rois + 3) / 4);
+      hipLaunchKernelGGL(pb_count_kernel, dim3(wg), dim3(256), 0, stream, b);
+      rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums, total, nullptr, stream);
+      if (rc != FSF_OK) return rc;
+      hipLaunchKernelGGL(pb_fill_kernel, dim3(wg), dim3(256), 0, stream, b);
+      hipLaunchKernelGGL(pool_count_kernel, dim3(1), dim3(1), 0, stream, total, max_all_pts, cdev);
+      FSF_LAUNCH_CHECK();
+      if (count_host) {
+        FSF_HIP_TRY(hipMemcpyAsync(count_host, cdev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+        FSF_HIP_TRY(hipStreamSynchronize(stream));
+      }
+      return FSF_OK;
+    }
     FSF_HIP_TRY(hipMemsetAsync(roi_total, 0, sizeof(uint32_t) * n_rois, stream));
     FSF_HIP_TRY(hipMemsetAsync(chunk_total, 0, sizeof(uint32_t) * 32, stream));
     const int groups = fsf_cdiv(n_rois, 256);

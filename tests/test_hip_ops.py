@@ -847,6 +847,33 @@ def test_dynamic_point_pool_vs_oracle(ops, device, r, p, max_inbox, max_all):
     assert len(gp) > 0
 
 
+@pytest.mark.parametrize("max_inbox,max_all", [(512, 50000), (2048, 10 ** 6), (64, 3000)])
+def test_dynamic_point_pool_binned_equals_brute_force(ops, device, max_inbox, max_all, monkeypatch):
+    """The cell-binned path == the P x R brute-force passes, bit for bit: RoIs with far more hits than the LDS list (bisection on
+    the point index), a box larger than the cell table walk allows, boxes and points beyond the table's border cells, NaN points."""
+    rng = np.random.default_rng(max_inbox)
+    r, p = 1500, 200000
+    rois = random_rois(rng, r, spread=45.0)
+    rois[0] = [0, 0, -2, 30, 60, 4, 0.3]            # ~1/4 of the scene: tens of thousands of hits
+    rois[1] = [3000.0, -2500.0, -2, 4, 9, 3, 1.0]   # beyond the border cells (they collect everything outside +-2 km)
+    rois[2] = [1e6, 1e6, 0, 1e7, 1e7, 1e7, 0.0]     # covers everything: whole-array walk
+    rois[3, :2] = [2.0, 2.0]
+    rois[3, 3:6] = [6.0, 12.0, 4.0]                 # dense centre: > 2048 hits
+    pts = np.concatenate([rng.normal(0, 6, (p // 2, 2)), rng.uniform(-3, 1, (p // 2, 1))], 1)
+    pts = np.concatenate([pts, np.concatenate([rng.uniform(-50, 50, (p - p // 2, 2)), rng.uniform(-3, 1, (p - p // 2, 1))], 1)])
+    pts[:40, :2] = [3000.0, -2500.0] + rng.normal(0, 1, (40, 2))
+    pts[40:45] = np.nan
+    pts = pts[rng.permutation(p)].astype(np.float32)
+    d_rois, d_pts = torch.from_numpy(rois.astype(np.float32)).to(device), torch.from_numpy(pts).to(device)
+    monkeypatch.setenv("FSF_POOL_BRUTE", "1")
+    bp, br, bf = ops.dynamic_point_pool(d_rois, d_pts, [1.0, 1.0, 1.0], max_inbox, max_all)
+    monkeypatch.setenv("FSF_POOL_BRUTE", "0")
+    gp, gr, gf = ops.dynamic_point_pool(d_rois, d_pts, [1.0, 1.0, 1.0], max_inbox, max_all)
+    assert gp.numel() == bp.numel() and gp.numel() > 0
+    assert torch.equal(gp, bp) and torch.equal(gr, br) and torch.equal(gf, bf)
+    assert int((gr == 0).sum()) == min(max_inbox, max_all)
+
+
 def test_dynamic_point_pool_batched_and_empty(ops, device):
     rng = np.random.default_rng(5)
     rois = random_rois(rng, 40, spread=10.0)
