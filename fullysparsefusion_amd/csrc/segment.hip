@@ -370,8 +370,11 @@ template <int VEC, int MODE>
 __global__ void __launch_bounds__(256) seg_short_kernel(SegShortArgs a) {
   const int gtot = a.goff[a.nt];
   const int64_t total = a.m * gtot;
+  const bool small = total <= 0x7fffffff;  // (32-bit index arithmetic where it fits)
+  // (four (segment, channel) items per thread with their first rows' loads issued together was tried: 40-60 % SLOWER —
+  // the extra registers and the divergent folds cost more than the deeper load queue gained)
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t seg = idx / gtot;
+    const int64_t seg = small ? (int64_t)((uint32_t)idx / (uint32_t)gtot) : idx / gtot;
     const int gg = (int)(idx - seg * gtot);
     int t = 0;
 #pragma unroll
@@ -439,6 +442,29 @@ __global__ void __launch_bounds__(256)
                        float* __restrict__ out, int64_t out_stride) {
   const int cv = c / VEC;
   const int64_t total = n * cv;
+  if (total <= 0x7fffffff) {  // (a 64-bit division per element made the 131-channel gather instruction-bound: 315 us for 0.53 GB)
+    // four elements per thread and round: the row index, then the element — two dependent loads — are each in flight four deep
+    const uint32_t tot = (uint32_t)total, step = gridDim.x * blockDim.x, ucv = (uint32_t)cv;
+    for (uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x; t0 < tot; t0 += 4 * step) {
+      uint32_t i[4];
+      int col[4];
+      int64_t row[4];
+      Vec<VEC> v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t t = t0 + u * step;
+        i[u] = (t < tot ? t : t0) / ucv;
+        col[u] = (int)((t < tot ? t : t0) - i[u] * ucv) * VEC;
+        row[u] = idx[i[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = load_vec<VEC>(src + row[u] * c + col[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (t0 + u * step < tot) store_vec<VEC>(out + (int64_t)i[u] * out_stride + col[u], v[u]);
+    }
+    return;
+  }
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / cv;
     const int col = (int)(t - i * cv) * VEC;
@@ -453,8 +479,9 @@ __global__ void __launch_bounds__(256)
                                  float* __restrict__ out) {
   const int cv = cout / 4;
   const int64_t total = n * cv;
+  const bool small = total <= 0x7fffffff;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = t / cv;
+    const int64_t i = small ? (int64_t)((uint32_t)t / (uint32_t)cv) : t / cv;
     const int j = (int)(t - i * cv) * 4;
     const float* f = feat + (i * cout + j) * R;
     float4 o = add ? *reinterpret_cast<const float4*>(add + i * cout + j) : make_float4(0.f, 0.f, 0.f, 0.f);
