@@ -438,7 +438,7 @@ static int pick_team(int c, int vec) {
 
 template <int VEC>
 __global__ void __launch_bounds__(256)
-    gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, int c,
+    gather_rows_kernel(const float* __restrict__ src, int64_t src_stride, const int64_t* __restrict__ idx, int64_t n, int c,
                        float* __restrict__ out, int64_t out_stride) {
   const int cv = c / VEC;
   const int64_t total = n * cv;
@@ -458,7 +458,7 @@ __global__ void __launch_bounds__(256)
         row[u] = idx[i[u]];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = load_vec<VEC>(src + row[u] * c + col[u]);
+      for (int u = 0; u < 4; ++u) v[u] = load_vec<VEC>(src + row[u] * src_stride + col[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (t0 + u * step < tot) store_vec<VEC>(out + (int64_t)i[u] * out_stride + col[u], v[u]);
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256)
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / cv;
     const int col = (int)(t - i * cv) * VEC;
-    store_vec<VEC>(out + i * out_stride + col, load_vec<VEC>(src + idx[i] * c + col));
+    store_vec<VEC>(out + i * out_stride + col, load_vec<VEC>(src + idx[i] * src_stride + col));
   }
 }
 
@@ -703,23 +703,29 @@ extern "C" int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int
   return FSF_OK;
 }
 
-extern "C" int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
-                               int64_t out_stride, void* stream_) {
+extern "C" int fsf_gather_rows_strided(const float* src, int64_t src_stride, int64_t m, int32_t c, const int64_t* idx, int64_t n,
+                                       float* out, int64_t out_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)m;
   if (n < 0 || c < 1 || (n > 0 && (!src || !idx || !out))) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   if (out_stride == 0) out_stride = c;
-  if (out_stride < c) return FSF_ERR_INVALID_ARG;
-  const bool vec4 = (c % 4 == 0) && (out_stride % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
+  if (src_stride == 0) src_stride = c;
+  if (out_stride < c || src_stride < c) return FSF_ERR_INVALID_ARG;
+  const bool vec4 = (c % 4 == 0) && (out_stride % 4 == 0) && (src_stride % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
   if (vec4)
-    hipLaunchKernelGGL((gather_rows_kernel<4>), dim3(fsf_stream_grid(n * (c / 4), 256)), dim3(256), 0, stream, src, idx,
+    hipLaunchKernelGGL((gather_rows_kernel<4>), dim3(fsf_stream_grid(n * (c / 4), 256)), dim3(256), 0, stream, src, src_stride, idx,
                        n, (int)c, out, out_stride);
   else
-    hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(fsf_stream_grid(n * c, 256)), dim3(256), 0, stream, src, idx, n,
+    hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(fsf_stream_grid(n * c, 256)), dim3(256), 0, stream, src, src_stride, idx, n,
                        (int)c, out, out_stride);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
+}
+
+extern "C" int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
+                               int64_t out_stride, void* stream_) {
+  return fsf_gather_rows_strided(src, c, m, c, idx, n, out, out_stride, stream_);
 }
 
 extern "C" int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t cin, int32_t cout, const float* add, float* out,

@@ -28,6 +28,7 @@ _ARGTYPES = {
     "fsf_segment_reduce_short": [_P, _P, _P, c_i32, c_i64, _P, _P, c_i64, c_i32, _P, _P, _P],
     "fsf_segment_reduce_backward": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, _P],
     "fsf_gather_rows": [_P, c_i64, c_i32, _P, c_i64, _P, c_i64, _P],
+    "fsf_gather_rows_strided": [_P, c_i64, c_i64, c_i32, _P, c_i64, _P, c_i64, _P],
     "fsf_norm_act": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i32, _P, c_i64, _P],
     "fsf_voxel2point": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, _P, _P],
     "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
@@ -289,17 +290,18 @@ def segment_reduce_backward(grad_out: torch.Tensor, plan: SegmentPlan, mode: str
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None):
-    """fsf_gather_rows: out[i,:] = src[idx[i],:].  `out` may be a column slice of a wider row-major buffer."""
+    """fsf_gather_rows[_strided]: out[i,:] = src[idx[i],:].  `src` and `out` may be column slices of wider row-major buffers."""
     require_cuda(src, idx, out)
     assert src.dtype == torch.float32 and src.dim() == 2
-    src = src.contiguous()
+    if src.stride(1) != 1 or (src.size(0) > 1 and src.stride(0) < src.size(1)):
+        src = src.contiguous()
     idx = idx.to(torch.int64).contiguous()
     n, (m, c) = idx.numel(), src.shape
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=src.device)
     assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) >= c
-    check(_L().fsf_gather_rows(ptr(src), m, c, ptr(idx), n, c_p(out.data_ptr()), out.stride(0), stream_ptr()),
-          "fsf_gather_rows")
+    check(_L().fsf_gather_rows_strided(c_p(src.data_ptr()) if src.numel() else c_p(None), src.stride(0) if m > 1 else c, m, c, ptr(idx), n,
+                                       c_p(out.data_ptr()), out.stride(0), stream_ptr()), "fsf_gather_rows_strided")
     return out
 
 

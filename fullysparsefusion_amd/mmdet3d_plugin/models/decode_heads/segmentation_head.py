@@ -2,6 +2,8 @@
 projects/mmdet3d_plugin/models/decode_heads/segmentation_head.py:15-104,265-266 — per-point MLP, seg logits and
 vote offsets.  Dense GEMMs on rocBLAS via torch (not a HIP deliverable); target
 generation and losses (train-time, host-side label assignment) are out of scope for this round."""
+import os
+
 import torch
 from torch import nn
 
@@ -55,7 +57,40 @@ class VoteSegHead(nn.Module):
         output = voxel_feat
         if self.pre_seg_conv is not None:
             output = self.pre_seg_conv(voxel_feat)
+        both = self._seg_and_vote(output)
+        if both is not None:
+            return both
         return self.cls_seg(output), self.voting(output)
+
+    def _seg_and_vote(self, feat):
+        """Inference on the GPU: `conv_seg` (-> classes + 1) and `voting` (-> 3 per class) read the same features, so the two
+        Linears are ONE K22 launch on the stacked weight ([11 + 33, 128] for nuScenes: the library ran each of the two thin
+        GEMMs over 3e5 rows in ~160 us); the results are the column blocks of one buffer."""
+        from .... import hip_ops
+        from ...ops.sst_ops import _SMALL_N_MIN
+
+        if os.environ.get("FSF_SEG_HEAD_STACK", "1") == "0":
+            return None
+        if (self.training or (torch.is_grad_enabled() and (feat.requires_grad or self.conv_seg.weight.requires_grad))
+                or not feat.is_cuda or feat.dim() != 2 or feat.size(0) < _SMALL_N_MIN or (self.dropout is not None and self.training)):
+            return None
+        c1, c2 = self.conv_seg.out_features, self.voting.out_features
+        ctot = (c1 + c2 + 3) // 4 * 4
+        if not hip_ops.linear_norm_act_supported(feat, ctot) or self.conv_seg.bias is None or self.voting.bias is None:
+            return None
+        params = (self.conv_seg.weight, self.conv_seg.bias, self.voting.weight, self.voting.bias)
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cache = self.__dict__.get("_fsf_stacked")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                w = torch.zeros((ctot, feat.size(1)), dtype=torch.float32, device=feat.device)
+                b = torch.zeros((ctot,), dtype=torch.float32, device=feat.device)
+                w[:c1], w[c1:c1 + c2] = self.conv_seg.weight, self.voting.weight
+                b[:c1], b[c1:c1 + c2] = self.conv_seg.bias, self.voting.bias
+                cache = (key, hip_ops.linear_prepare_weight(w), b)
+            self.__dict__["_fsf_stacked"] = cache
+        y = hip_ops.linear_norm_act(feat, cache[1], ctot, bias=cache[2])
+        return y[:, :c1], y[:, c1:c1 + c2]
 
     def forward_test(self, inputs, img_metas, test_cfg):
         return self.forward(inputs)

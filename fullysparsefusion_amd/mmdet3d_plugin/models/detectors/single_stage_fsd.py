@@ -278,7 +278,7 @@ class SingleStageFSD(nn.Module):
         cluster = (labels - base.index_select(0, vox_group)).index_select(0, vox_inv)
         pts_cluster_inds = torch.stack([g_ids, b_pts, cluster], 1)
         def take(t):  # rows p_ids of t (ATen's index_select is slow on narrow float rows: 118 us for [510 k, 4])
-            if t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.is_contiguous():
+            if t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1:
                 return hip_ops.gather_rows(t, p_ids)
             return t.index_select(0, p_ids)
 

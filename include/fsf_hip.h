@@ -138,6 +138,9 @@ int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int32_t c, con
  */
 int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
                     int64_t out_stride, void* stream);
+/* The same with a row stride on the source (src rows may be a column block of a wider buffer, src_stride >= c floats). */
+int fsf_gather_rows_strided(const float* src, int64_t src_stride, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
+                            int64_t out_stride, void* stream);
 
 /* SimpleSparseUNet decoder shortcut [UNVENDORED; SURVEY App. C decoder_layer_forward]:
  *   `x.features.view(n, C_out, -1).sum(2) + m.features` in one pass: out[i,j] = add[i,j] + sum_q feat[i, j*r + q],

@@ -1392,6 +1392,31 @@ def test_separate_head_branches_in_one_launch_per_layer(ops, device):
     assert out["center"].requires_grad
 
 
+def test_gather_rows_strided_source_and_seg_head_stack(ops, device):
+    """gather_rows from a column block of a wider buffer (no contiguous copy), and VoteSegHead's two Linears as one launch."""
+    from fullysparsefusion_amd.mmdet3d_plugin.models.decode_heads.segmentation_head import VoteSegHead
+
+    torch.manual_seed(1)
+    wide = torch.randn(5000, 44, device=device)
+    idx = torch.randint(0, 5000, (12345,), device=device)
+    for lo, hi in ((0, 11), (11, 44), (8, 40)):
+        got = ops.gather_rows(wide[:, lo:hi], idx)
+        assert torch.equal(got, wide[:, lo:hi][idx])
+    head = VoteSegHead(131, 10, hidden_dims=[128, 128], dropout_ratio=0.0, norm_cfg=dict(type="naiveSyncBN1d"),
+                       act_cfg=dict(type="ReLU")).to(device).eval()
+    with torch.no_grad():
+        head.voting.bias.normal_()
+        x = torch.randn(30011, 131, device=device)
+        logits, votes = head(x)
+        assert head.__dict__.get("_fsf_stacked") is not None and logits.shape == (30011, 11) and votes.shape == (30011, 33)
+        feat = head.pre_seg_conv(x)
+        for got, lin in ((logits, head.conv_seg), (votes, head.voting)):
+            want = torch.nn.functional.linear(feat.double(), lin.weight.double(), lin.bias.double())
+            ref = torch.nn.functional.linear(feat, lin.weight, lin.bias)
+            scale = max(1.0, float(want.abs().max()))
+            assert float((got.double() - want).abs().max()) <= max(3e-6 * scale, 3.0 * float((ref.double() - want).abs().max()))
+
+
 def test_column_stats_and_batch_norm_edge_cases(ops, device):
     """K23 with no rows: sums / statistics / gradients are zeros, nothing is launched on empty inputs; a single row."""
     x0 = torch.empty(0, 12, device=device)
