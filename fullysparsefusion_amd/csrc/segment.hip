@@ -506,11 +506,10 @@ struct V2PParams {
 __global__ void __launch_bounds__(256)
     voxel2point_kernel(const float* __restrict__ points, int stride, const int64_t* __restrict__ coors,
                        const float* __restrict__ vf, int c, const int64_t* __restrict__ inv, int64_t n, V2PParams p,
-                       float* __restrict__ out, uint8_t* __restrict__ valid, int team) {
+                       float* __restrict__ out, int64_t oc, uint8_t* __restrict__ valid, int team) {
   const int lane = threadIdx.x & 63;
   const int tl = lane % team;
   const int teams_per_block = 256 / team;
-  const int oc = c + 3;
   for (int64_t i = (int64_t)blockIdx.x * teams_per_block + threadIdx.x / team; i < n;
        i += (int64_t)gridDim.x * teams_per_block) {
     const int64_t row = inv[i];
@@ -742,13 +741,13 @@ extern "C" int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t c
   return FSF_OK;
 }
 
-extern "C" int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* coors_bzyx,
-                               const float* voxel_feats, int64_t m, int32_t c, const int64_t* inv, int64_t n,
-                               const float voxel_size[3], const float range_min[3], float padding, float* out,
-                               uint8_t* valid, void* stream_) {
+extern "C" int fsf_voxel2point_strided(const float* points, int32_t point_stride, const int64_t* coors_bzyx,
+                                       const float* voxel_feats, int64_t m, int32_t c, const int64_t* inv, int64_t n,
+                                       const float voxel_size[3], const float range_min[3], float padding, float* out,
+                                       int64_t out_stride, uint8_t* valid, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)m;
-  if (n < 0 || c < 1 || point_stride < 3 || !voxel_size || !range_min ||
+  if (n < 0 || c < 1 || point_stride < 3 || !voxel_size || !range_min || (out_stride != 0 && out_stride < c + 3) ||
       (n > 0 && (!points || !coors_bzyx || !voxel_feats || !inv || !out)))
     return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
@@ -759,7 +758,15 @@ extern "C" int fsf_voxel2point(const float* points, int32_t point_stride, const 
   int64_t g = (n + teams_per_block - 1) / teams_per_block;
   if (g > 16384) g = 16384;
   hipLaunchKernelGGL(voxel2point_kernel, dim3((unsigned)g), dim3(256), 0, stream, points, (int)point_stride, coors_bzyx,
-                     voxel_feats, (int)c, inv, n, p, out, valid, team);
+                     voxel_feats, (int)c, inv, n, p, out, out_stride ? out_stride : (int64_t)c + 3, valid, team);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
+}
+
+extern "C" int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* coors_bzyx,
+                               const float* voxel_feats, int64_t m, int32_t c, const int64_t* inv, int64_t n,
+                               const float voxel_size[3], const float range_min[3], float padding, float* out,
+                               uint8_t* valid, void* stream_) {
+  return fsf_voxel2point_strided(points, point_stride, coors_bzyx, voxel_feats, m, c, inv, n, voxel_size, range_min, padding, out, 0,
+                                 valid, stream_);
 }

@@ -31,6 +31,7 @@ _ARGTYPES = {
     "fsf_gather_rows_strided": [_P, c_i64, c_i64, c_i32, _P, c_i64, _P, c_i64, _P],
     "fsf_norm_act": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i32, _P, c_i64, _P],
     "fsf_voxel2point": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, _P, _P],
+    "fsf_voxel2point_strided": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, c_i64, _P, _P],
     "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_project_score": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P, _P],
@@ -327,12 +328,14 @@ def voxel2point(points, coors_bzyx, voxel_feats, inv, voxel_size, range_min, pad
     inv = inv.to(torch.int64).contiguous()
     n = points.size(0)
     m, c = voxel_feats.shape
-    out = torch.empty((n, c + 3), dtype=torch.float32, device=points.device)
+    # rows padded to a multiple of 4 floats (16-byte aligned rows): the [n, c + 3] view is then a legal K22 operand as it is
+    stride = (c + 3 + 3) // 4 * 4
+    buf = torch.empty((n, stride), dtype=torch.float32, device=points.device)
     valid = torch.empty((n,), dtype=torch.uint8, device=points.device)
-    check(_L().fsf_voxel2point(ptr(points), points.size(1), ptr(coors_bzyx), ptr(voxel_feats), m, c, ptr(inv), n,
-                               f32_array(voxel_size), f32_array(range_min), float(padding), ptr(out), ptr(valid),
-                               stream_ptr()), "fsf_voxel2point")
-    return out, valid.bool()
+    check(_L().fsf_voxel2point_strided(ptr(points), points.size(1), ptr(coors_bzyx), ptr(voxel_feats), m, c, ptr(inv), n,
+                                       f32_array(voxel_size), f32_array(range_min), float(padding), ptr(buf), stride, ptr(valid),
+                                       stream_ptr()), "fsf_voxel2point_strided")
+    return buf[:, :c + 3], valid.bool()
 
 
 # ---------------------------------------------------------------------------------------- projection

@@ -314,7 +314,15 @@ class FSF(SingleStageFSD):
         batch_idx = pts_coors[:, 0]
         pts_updated_feats = self.img_cross_attn(point_infos, batch_idx, mask_anno, mask_data, img_metas,
                                                 encode_mlp=self.segmentor_updated_mlp)
-        pts_feats = pts_lidar_feats + pts_updated_feats
+        if (pts_lidar_feats.is_cuda and pts_lidar_feats.dim() == 2 and pts_lidar_feats.size(1) % 4 != 0
+                and not (torch.is_grad_enabled() and (pts_lidar_feats.requires_grad or pts_updated_feats.requires_grad))):
+            # the sum lands in rows padded to a multiple of 4 floats: the 131-column result is then a legal operand of the fused
+            # Linear kernel (the segmentation head's first layer otherwise falls back to the library GEMM + a norm pass)
+            c = pts_lidar_feats.size(1)
+            pts_feats = torch.add(pts_lidar_feats, pts_updated_feats,
+                                  out=pts_lidar_feats.new_empty((pts_lidar_feats.size(0), (c + 3) // 4 * 4))[:, :c])
+        else:
+            pts_feats = pts_lidar_feats + pts_updated_feats
         seg_logits, vote_preds = self.segmentor.segmentation_head.forward_test(pts_feats, img_metas, self.segmentor.test_cfg)
         offsets = self.segmentor.segmentation_head.decode_vote_targets(vote_preds)
         return dict(seg_points=points, seg_logits=seg_logits, seg_vote_preds=vote_preds, offsets=offsets,

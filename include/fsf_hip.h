@@ -157,6 +157,11 @@ int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t cin, int32_t
 int fsf_voxel2point(const float* points, int32_t point_stride, const int64_t* coors_bzyx, const float* voxel_feats,
                     int64_t m, int32_t c, const int64_t* inv, int64_t n, const float voxel_size[3],
                     const float range_min[3], float padding, float* out, uint8_t* valid, void* stream);
+/* The same with a row stride on `out` (>= c + 3 floats): a stride that is a multiple of 4 keeps the [n, c + 3] result (131
+ * columns in the FSF configs) a legal operand of fsf_linear_norm_act — the segmentation head's first layer reads it in place. */
+int fsf_voxel2point_strided(const float* points, int32_t point_stride, const int64_t* coors_bzyx, const float* voxel_feats,
+                            int64_t m, int32_t c, const int64_t* inv, int64_t n, const float voxel_size[3],
+                            const float range_min[3], float padding, float* out, int64_t out_stride, uint8_t* valid, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K12  fused row normalisation + activation (the tail of every `Linear -> norm -> act` MLP block)
