@@ -846,3 +846,56 @@ def test_sir_layer_deferred_concat_equals_materialised(plugin, device, monkeypat
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
         else:
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_training_step_two_frames_per_gpu_in_a_process_group(device):
+    """BASELINE config 4 on the device, as far as one GPU allows: two frames per GPU through the data-parallel step bench.py times
+    (training-mode norms, flat gradient buckets whose views are the `.grad` tensors, AdamW) inside an initialised RCCL process
+    group of one rank — the wrapper then issues no collective, so the step must equal the plain autograd step: gradients == an
+    undistributed backward of the same loss, AdamW moves the parameters, a second step runs on the re-armed buckets.  (Two ranks
+    need two GPUs; the collectives themselves are covered by the world-size-2 gloo tests.)"""
+    import socket
+
+    import torch.distributed as dist
+
+    import bench
+
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        torch.manual_seed(0)
+        model = bench.build_model(device)
+        _, inp = bench.make_inputs(1, 3, device, frames=2)
+        # reference: the same model, training mode, plain autograd
+        model.train()
+        out = model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+        loss = bench.dummy_loss(out)
+        params = [p for p in model.parameters() if p.requires_grad]
+        want = torch.autograd.grad(loss, params, allow_unused=True)
+        before = [p.detach().clone() for p in params]
+        # bench.py's step (FrameDataParallel buckets + AdamW); BatchNorm running statistics moved once already, which does not
+        # enter training-mode outputs
+        stepper = bench.TrainStep(model)
+        stepper(inp)
+        torch.cuda.synchronize()
+        assert stepper.dp.world == 1
+        n_checked = 0
+        for p, g in zip(params, want):
+            if g is None:
+                assert p.grad is None or not p.grad.any()
+                continue
+            scale = max(float(g.abs().max()), 1e-12)
+            assert float((p.grad - g).abs().max()) <= 1e-5 * scale + 1e-12, "gradient differs from the undistributed backward"
+            n_checked += 1
+        assert n_checked > 100
+        moved = sum(int((p.detach() != b).any()) for p, b in zip(params, before))
+        assert moved > 100
+        loss2 = float(bench.dummy_loss(stepper(inp)).detach())
+        assert loss2 == loss2  # finite: the second step ran on re-armed buckets
+    finally:
+        dist.destroy_process_group()
