@@ -93,6 +93,68 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- vote centres + cluster-voxel keys of the grouped cluster assignment (one pass instead of ~22 torch launches) --------
+// Replaces, for every (class group g, point p) pair of the group-sampled foreground (single_stage_fsd.py:802-865 `group_sample`
+// + ClusterAssigner.forward :903-982, all groups at once):
+//   w = softmax-free "is an arg-max class of the group" weights (ties within 1e-6 split evenly),
+//   centre = xyz[p] + sum_c offsets[p, c, :] * w_c,   vox = floor_div(centre - range_min, cluster_voxel_size[g]),
+//   key = (g * batch_size + batch[p], vox_x, vox_y, vox_z).
+// Same fp32 operations as the torch expressions (sub, abs, compare, div by the tie count, mul, adds in class order,
+// c10::div_floor_floating); with one or two tied classes — every row in practice — the class sum has a single possible value.
+constexpr int VC_MAX_GROUPS = 16;
+struct VoteArgs {
+  const float* logits; int logit_stride;
+  const float* offsets; int offset_stride;
+  const float* points; int point_stride;
+  const int64_t* batch_idx;
+  const int64_t* g_ids; const int64_t* p_ids;
+  int64_t n;
+  int nc, ng, bsz;
+  uint32_t mask[VC_MAX_GROUPS];
+  float vs[VC_MAX_GROUPS][3];
+  float rmin[3];
+  float* centers; int64_t* keys; int64_t* batch_out;
+};
+
+__global__ void __launch_bounds__(256) vote_centers_keys_kernel(VoteArgs a) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)a.g_ids[i];
+    const int64_t p = a.p_ids[i];
+    const uint32_t mem = a.mask[g];
+    const float* lg = a.logits + p * a.logit_stride;
+    float mx = -INFINITY;
+    for (int c = 0; c < a.nc; ++c)
+      if ((mem >> c) & 1u) mx = fmaxf(mx, lg[c]);
+    uint32_t tie = 0;
+    float cnt = 0.0f;
+    for (int c = 0; c < a.nc; ++c)
+      if (((mem >> c) & 1u) && fabsf(__fsub_rn(lg[c], mx)) < 1e-6f) {
+        tie |= 1u << c;
+        cnt = __fadd_rn(cnt, 1.0f);
+      }
+    const float wv = __fdiv_rn(1.0f, cnt);
+    const float* off = a.offsets + p * a.offset_stride;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    for (int c = 0; c < a.nc; ++c) {
+      const float w = ((tie >> c) & 1u) ? wv : 0.0f;
+      sx = __fadd_rn(sx, __fmul_rn(off[3 * c + 0], w));
+      sy = __fadd_rn(sy, __fmul_rn(off[3 * c + 1], w));
+      sz = __fadd_rn(sz, __fmul_rn(off[3 * c + 2], w));
+    }
+    const float* pt = a.points + p * a.point_stride;
+    const float cx = __fadd_rn(pt[0], sx), cy = __fadd_rn(pt[1], sy), cz = __fadd_rn(pt[2], sz);
+    a.centers[3 * i + 0] = cx;
+    a.centers[3 * i + 1] = cy;
+    a.centers[3 * i + 2] = cz;
+    const int64_t b = a.batch_idx ? a.batch_idx[p] : 0;
+    a.keys[4 * i + 0] = (int64_t)g * a.bsz + b;
+    a.keys[4 * i + 1] = (int64_t)div_floor_f32(__fsub_rn(cx, a.rmin[0]), a.vs[g][0]);
+    a.keys[4 * i + 2] = (int64_t)div_floor_f32(__fsub_rn(cy, a.rmin[1]), a.vs[g][1]);
+    a.keys[4 * i + 3] = (int64_t)div_floor_f32(__fsub_rn(cz, a.rmin[2]), a.vs[g][2]);
+    if (a.batch_out) a.batch_out[i] = b;
+  }
+}
+
 }  // namespace fsf
 
 using namespace fsf;
@@ -124,6 +186,32 @@ extern "C" int fsf_voxelize_divfloor(const float* points, int64_t n, int32_t poi
   VoxParams p{voxel_size[0], voxel_size[1], voxel_size[2], range_min[0], range_min[1], range_min[2], 0, 0, 0};
   hipLaunchKernelGGL(voxelize_divfloor_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, points, n,
                      (int)point_stride, p, (int)order, batch_idx_in, coors);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_vote_centers_keys(const float* logits, int32_t logit_stride, const float* offsets, int32_t offset_stride,
+                                     const float* points, int32_t point_stride, const int64_t* batch_idx, const int64_t* g_ids,
+                                     const int64_t* p_ids, int64_t n, int32_t num_classes, int32_t num_groups,
+                                     const uint32_t* group_class_mask, const float* group_voxel_size, const float range_min[3],
+                                     int32_t batch_size, float* centers, int64_t* keys, int64_t* batch_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || num_classes < 1 || num_classes > 32 || num_groups < 1 || num_groups > VC_MAX_GROUPS || batch_size < 1 ||
+      logit_stride < num_classes || offset_stride < 3 * num_classes || point_stride < 3 || !group_class_mask || !group_voxel_size ||
+      !range_min || (n > 0 && (!logits || !offsets || !points || !g_ids || !p_ids || !centers || !keys)))
+    return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  VoteArgs a;
+  a.logits = logits; a.logit_stride = logit_stride; a.offsets = offsets; a.offset_stride = offset_stride;
+  a.points = points; a.point_stride = point_stride; a.batch_idx = batch_idx; a.g_ids = g_ids; a.p_ids = p_ids; a.n = n;
+  a.nc = num_classes; a.ng = num_groups; a.bsz = batch_size;
+  for (int g = 0; g < VC_MAX_GROUPS; ++g) {
+    a.mask[g] = g < num_groups ? group_class_mask[g] : 0u;
+    for (int j = 0; j < 3; ++j) a.vs[g][j] = g < num_groups ? group_voxel_size[3 * g + j] : 1.0f;
+  }
+  for (int j = 0; j < 3; ++j) a.rmin[j] = range_min[j];
+  a.centers = centers; a.keys = keys; a.batch_out = batch_out;
+  hipLaunchKernelGGL(vote_centers_keys_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

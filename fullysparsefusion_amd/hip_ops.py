@@ -18,6 +18,7 @@ _ARGTYPES = {
     "fsf_assemble_sweeps_workspace_bytes": [c_i64],
     "fsf_assemble_sweeps": [_P, c_i64, c_i32, _P, c_i32, _P, _P, _P, c_f32, _P, c_i32, c_f32, c_f32, _P, _P, _P, _P, c_i64, _P],
     "fsf_voxelize_dynamic": [_P, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P],
+    "fsf_vote_centers_keys": [_P, c_i32, _P, c_i32, _P, c_i32, _P, _P, _P, c_i64, c_i32, c_i32, _P, _P, _P, c_i32, _P, _P, _P, _P],
     "fsf_voxelize_divfloor": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P],
     "fsf_unique_rows_workspace_bytes": [c_i64, c_i32],
     "fsf_unique_rows": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_i64, _P],
@@ -168,6 +169,32 @@ def voxelize_divfloor(points: torch.Tensor, voxel_size, range_min, order="zyx", 
                                      {"xyz": 0, "zyx": 1}[order], ptr(batch_idx), ptr(coors), stream_ptr()),
           "fsf_voxelize_divfloor")
     return coors
+
+
+def vote_centers_keys(logits, offsets, points, batch_idx, g_ids, p_ids, num_classes, group_class_masks, group_voxel_sizes,
+                      range_min, batch_size):
+    """fsf_vote_centers_keys: for the (group, point) pairs (g_ids, p_ids i64 [n]) -> (centers f32 [n,3], keys i64 [n,4] =
+    (g * batch_size + batch, vx, vy, vz), batch i64 [n]).  logits f32 [P, >= num_classes], offsets f32 [P, >= 3 * num_classes],
+    points f32 [P, >= 3] (row-strided views allowed); group_class_masks: one bit mask of member classes per group."""
+    require_cuda(logits, offsets, points, batch_idx, g_ids, p_ids)
+    lg, lstride = _rows_view(logits)
+    of, ostride = _rows_view(offsets)
+    pt, pstride = _rows_view(points)
+    assert lg.dtype == of.dtype == pt.dtype == torch.float32
+    g_ids, p_ids = g_ids.to(torch.int64).contiguous(), p_ids.to(torch.int64).contiguous()
+    if batch_idx is not None:
+        batch_idx = batch_idx.to(torch.int64).contiguous()
+    n, ng = p_ids.numel(), len(group_class_masks)
+    dev = pt.device
+    centers = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    keys = torch.empty((n, 4), dtype=torch.int64, device=dev)
+    bout = torch.empty((n,), dtype=torch.int64, device=dev)
+    masks = (ctypes.c_uint32 * ng)(*[int(m) for m in group_class_masks])
+    vs = (ctypes.c_float * (3 * ng))(*[float(v) for row in group_voxel_sizes for v in row])
+    check(_L().fsf_vote_centers_keys(c_p(lg.data_ptr()), int(lstride), c_p(of.data_ptr()), int(ostride), c_p(pt.data_ptr()), int(pstride),
+                                     ptr(batch_idx), ptr(g_ids), ptr(p_ids), n, int(num_classes), ng, masks, vs, f32_array(range_min),
+                                     int(batch_size), ptr(centers), ptr(keys), ptr(bout), stream_ptr()), "fsf_vote_centers_keys")
+    return centers, keys, bout
 
 
 # --------------------------------------------------------------------------------------------- unique

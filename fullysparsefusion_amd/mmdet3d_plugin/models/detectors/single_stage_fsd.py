@@ -6,6 +6,8 @@ group_sample :802-865, get_fg_mask :742-784, ClusterAssigner :903-982).
 Same class / method names and argument meaning; torch.unique / torch_scatter / Voxelization / scipy CCL calls go
 to the HIP library.  Training-only branches (targets, losses, SSG/Hybrid assigners) are outside this round.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -243,25 +245,37 @@ class SingleStageFSD(nn.Module):
                     fg[self.get_sample_beg_position(batch_idx, fg[:, gi]), gi] = True
         gp = fg.t().nonzero(as_tuple=False)                      # (group, point), group-major
         g_ids, p_ids = gp[:, 0], gp[:, 1]
-        # vote centre: the offsets of the group's classes weighted by "is the group's arg-max class" (ties split evenly)
-        logit = seg_logits.index_select(0, p_ids)[:, :nc]
-        mem = member.index_select(0, g_ids)
-        masked = torch.where(mem, logit, logit.new_full((), float("-inf")))
-        w = ((masked - masked.max(1)[0][:, None]).abs() < 1e-6) & mem
-        w = w.float()
-        w = w / w.sum(1)[:, None]
-        offset = d["vote_offsets"].reshape(-1, nc + 1, 3).index_select(0, p_ids)[:, :nc, :]
-        centers = d["seg_points"][:, :3].index_select(0, p_ids) + (offset * w[:, :, None]).sum(dim=1)
-        # cluster voxels: torch.div(.., 'floor') keys (:948-950) with the group's voxel size; group folded into the batch column
-        vsize = const("cluster_vsize", lambda: torch.tensor([ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]],
-                                                            dtype=centers.dtype))
-        rmin = const("cluster_rmin", lambda: torch.tensor(ca.point_cloud_range[:3], dtype=centers.dtype))
-        vox = torch.div(centers - rmin[None, :], vsize.index_select(0, g_ids), rounding_mode="floor").long()
-        b_pts = batch_idx.index_select(0, p_ids).long()
-        keys = torch.cat([(g_ids * bsz + b_pts)[:, None], vox], dim=1)
+        # vote centre (the offsets of the group's classes weighted by "is the group's arg-max class", ties split evenly) and the
+        # cluster-voxel key (torch.div(.., 'floor') with the group's voxel size, :948-950; group folded into the batch column)
+        vs_rows = [ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]]
+        if (seg_logits.is_cuda and nc <= 32 and ng <= 16 and seg_logits.dtype == torch.float32
+                and os.environ.get("FSF_FUSED_VOTE", "1") != "0"):
+            # one pass (fsf_vote_centers_keys) instead of ~22 launches over [n_pairs, classes(, 3)] temporaries
+            masks = [sum(1 << c for c in cols) for cols in group_cols]
+            centers, keys, b_pts = hip_ops.vote_centers_keys(
+                seg_logits, d["vote_offsets"], d["seg_points"], batch_idx, g_ids, p_ids, nc, masks, vs_rows,
+                ca.point_cloud_range[:3], bsz)
+        else:
+            logit = seg_logits.index_select(0, p_ids)[:, :nc]
+            mem = member.index_select(0, g_ids)
+            masked = torch.where(mem, logit, logit.new_full((), float("-inf")))
+            w = ((masked - masked.max(1)[0][:, None]).abs() < 1e-6) & mem
+            w = w.float()
+            w = w / w.sum(1)[:, None]
+            offset = d["vote_offsets"].reshape(-1, nc + 1, 3).index_select(0, p_ids)[:, :nc, :]
+            centers = d["seg_points"][:, :3].index_select(0, p_ids) + (offset * w[:, :, None]).sum(dim=1)
+            vsize = const("cluster_vsize", lambda: torch.tensor(vs_rows, dtype=centers.dtype))
+            rmin = const("cluster_rmin", lambda: torch.tensor(ca.point_cloud_range[:3], dtype=centers.dtype))
+            vox = torch.div(centers - rmin[None, :], vsize.index_select(0, g_ids), rounding_mode="floor").long()
+            b_pts = batch_idx.index_select(0, p_ids).long()
+            keys = torch.cat([(g_ids * bsz + b_pts)[:, None], vox], dim=1)
         _, inv, cnt = unique_with_plan(keys)
         valid = cnt[inv] >= ca.min_points
-        has_valid = torch.zeros(ng, dtype=torch.int32, device=dev).index_add_(0, g_ids, valid.int()) > 0
+        # valid pairs per group: the pairs are group-major, so a running count read at the group boundaries (an index_add_ of
+        # half a million rows into six counters is 120 us of same-address atomics)
+        csum = torch.cat([valid.new_zeros(1, dtype=torch.int64), valid.to(torch.int64).cumsum(0)])
+        bounds = torch.searchsorted(g_ids, torch.arange(ng + 1, device=dev))
+        has_valid = (csum[bounds[1:]] - csum[bounds[:-1]]) > 0
         valid |= ~has_valid.index_select(0, g_ids)             # a group without any dense voxel keeps all its points (:953-954)
         v_idx = valid.nonzero(as_tuple=False).squeeze(1)
         g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)

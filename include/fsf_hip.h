@@ -61,6 +61,21 @@ int fsf_voxelize_divfloor(const float* points, int64_t n, int32_t point_stride, 
                           const float range_min[3], int32_t order, const int64_t* batch_idx_in,
                           int64_t* coors, void* stream);
 
+/* Vote centres + cluster-voxel keys for every (class group, point) pair of the group-sampled foreground, one pass.
+ * Replaces the per-group body of SingleStageFSD.group_sample (single_stage_fsd.py:802-865: arg-max-class weights over the
+ * group's classes, ties within 1e-6 split evenly; centre = xyz + sum_c offsets[:, c] * w_c) and the key computation of
+ * ClusterAssigner.forward_single_class (:945-950: torch.div(centre - range_min, cluster_voxel_size, rounding_mode='floor')),
+ * all groups at once (group id folded into the key's batch column: key = (g * batch_size + b, vx, vy, vz)).
+ *   logits f32 [P, logit_stride >= num_classes]; offsets f32 [P, offset_stride >= 3 * num_classes] (class-major xyz triples);
+ *   points f32 [P, point_stride >= 3]; batch_idx i64 [P] or NULL; g_ids / p_ids i64 [n] (the pairs);
+ *   group_class_mask u32 [num_groups] HOST (bit c: class c belongs to the group; num_classes <= 32, num_groups <= 16);
+ *   group_voxel_size f32 [num_groups, 3] HOST; centers f32 [n, 3]; keys i64 [n, 4]; batch_out i64 [n] or NULL. */
+int fsf_vote_centers_keys(const float* logits, int32_t logit_stride, const float* offsets, int32_t offset_stride,
+                          const float* points, int32_t point_stride, const int64_t* batch_idx, const int64_t* g_ids,
+                          const int64_t* p_ids, int64_t n, int32_t num_classes, int32_t num_groups,
+                          const uint32_t* group_class_mask, const float* group_voxel_size, const float range_min[3],
+                          int32_t batch_size, float* centers, int64_t* keys, int64_t* batch_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K3  unique rows (+ inverse, counts, CSR segment plan)
  * Replaces: torch.unique(coors, return_inverse=True, return_counts=True, dim=0) at

@@ -1417,6 +1417,45 @@ def test_gather_rows_strided_source_and_seg_head_stack(ops, device):
             assert float((got.double() - want).abs().max()) <= max(3e-6 * scale, 3.0 * float((ref.double() - want).abs().max()))
 
 
+def test_vote_centers_keys_equals_the_torch_expressions(ops, device):
+    """fsf_vote_centers_keys against the expressions it replaces (single_stage_fsd.py group_sample + cluster-voxel keys), bit for
+    bit: one- and two-class groups, exact ties (both classes weighted 1/2), voxel boundaries, negative coordinates, strided rows."""
+    torch.manual_seed(11)
+    P, nc, bsz = 60000, 10, 2
+    groups = [[0], [1, 2], [3, 4], [5], [6, 7], [8, 9]]
+    logits = torch.randn(P, nc + 1, device=device)
+    logits[::7, 2] = logits[::7, 1]                    # ties inside group 1
+    offs = torch.randn(P, (nc + 1) * 3, device=device) * 2
+    wide = torch.randn(P, 8, device=device) * 30
+    points = wide[:, 1:6]                              # a row-strided view
+    points[:100, :3] = torch.tensor([-3.2, 0.0, 1.6], device=device)  # exact multiples of the voxel sizes
+    batch = torch.randint(0, bsz, (P,), device=device)
+    n = 200000
+    p_ids = torch.randint(0, P, (n,), device=device)
+    g_ids = torch.randint(0, len(groups), (n,), device=device).sort()[0]
+    vs_rows = [[0.4, 0.4, 0.8], [0.8, 0.8, 1.6], [1.6, 1.6, 3.2], [0.2, 0.2, 0.4], [0.4, 0.4, 0.4], [1.0, 1.0, 6.0]]
+    rmin = [-54.0, -54.0, -5.0]
+    masks = [sum(1 << c for c in cols) for cols in groups]
+    centers, keys, b = ops.vote_centers_keys(logits, offs, points, batch, g_ids, p_ids, nc, masks, vs_rows, rmin, bsz)
+    member = torch.zeros((len(groups), nc), dtype=torch.bool, device=device)
+    for gi, cols in enumerate(groups):
+        member[gi, cols] = True
+    logit = logits.index_select(0, p_ids)[:, :nc]
+    mem = member.index_select(0, g_ids)
+    masked = torch.where(mem, logit, logit.new_full((), float("-inf")))
+    w = ((masked - masked.max(1)[0][:, None]).abs() < 1e-6) & mem
+    assert int((w.sum(1) == 2).sum()) > 100            # the ties are really there
+    w = w.float()
+    w = w / w.sum(1)[:, None]
+    offset = offs.reshape(-1, nc + 1, 3).index_select(0, p_ids)[:, :nc, :]
+    want_c = points[:, :3].index_select(0, p_ids) + (offset * w[:, :, None]).sum(dim=1)
+    vsize = torch.tensor(vs_rows, device=device)
+    want_v = torch.div(want_c - torch.tensor(rmin, device=device)[None, :], vsize.index_select(0, g_ids), rounding_mode="floor").long()
+    want_b = batch.index_select(0, p_ids)
+    assert torch.equal(centers, want_c)
+    assert torch.equal(keys[:, 1:], want_v) and torch.equal(keys[:, 0], g_ids * bsz + want_b) and torch.equal(b, want_b)
+
+
 def test_column_stats_and_batch_norm_edge_cases(ops, device):
     """K23 with no rows: sums / statistics / gradients are zeros, nothing is launched on empty inputs; a single row."""
     x0 = torch.empty(0, 12, device=device)
