@@ -351,7 +351,7 @@ SPCONV_KERNELS = {
 }
 
 
-def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic):
+def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic_of):
     """`roofline` (dominant kernel = the sparse-conv forward kernel with the most time), `hbm` and `frame_roofline_ms`."""
     kernels = {}
     for k, v in conv.items():
@@ -365,6 +365,7 @@ def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic):
     dom_key = max(conv, key=lambda k: conv[k]["ms"])
     dom = conv[dom_key]
     title, peak, pipe = SPCONV_KERNELS[dom_key]
+    traffic = traffic_of(title.split(" ")[0]) if traffic_of else {}  # (the kernel's C++ name up to its template arguments)
     achieved = dom["flops"] / max(dom["ms"], 1e-9) / 1e9
     all_flops, all_ms = sum(v["flops"] for v in conv.values()), sum(v["ms"] for v in conv.values())
     hbm = {}
@@ -392,6 +393,7 @@ def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic):
                                      tflops_fp32_equivalent=round(all_flops / max(all_ms, 1e-9) / 1e9, 2),
                                      algorithmic_gflop_per_step=round(all_flops / steps / 1e9, 1)),
         kernels=kernels, traffic=traffic.get("value"), traffic_unit=traffic.get("unit"), traffic_source=traffic.get("source"),
+        traffic_kernel=traffic.get("kernel"),
         hbm=hbm,
         frame_roofline_ms=round(frame_floor, 3),
         frame_roofline_note="sum over the instrumented kernels of (fp32-equivalent conv flops / the issuing pipe's ceiling) + "
@@ -406,18 +408,26 @@ def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic):
     return roof
 
 
-def committed_traffic():
-    """HBM bytes per sparse-conv launch from the committed PMC passes (profiles/*_pmc_traffic.json, newest round last)."""
+def committed_traffic(kernel_prefix=None):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_traffic.json, newest round
+    last): the per-kernel table's entries whose name starts with `kernel_prefix` (all template variants, launch-weighted), else
+    the average over every sparse-conv launch."""
     prof = os.path.join(ROOT, "profiles")
     out = {}
     for name in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
         if name.endswith("_pmc_traffic.json"):
             with open(os.path.join(prof, name)) as f:
                 t = json.load(f)
+            unit = t.get("unit", "HBM bytes per launch (FETCH_SIZE x correction + WRITE_SIZE, rocprofv3 --pmc, separate passes)")
+            rows = [k for k in t.get("kernels", []) if kernel_prefix and k.get("kernel", "").startswith(kernel_prefix)]
+            launches = sum(k.get("launches_per_step", 0.0) for k in rows)
+            if launches > 0:
+                v = sum(k.get("hbm_mb_per_step", 0.0) for k in rows) * 1e6 / launches
+                out = dict(value=round(v, 1), source=f"profiles/{name}", unit=unit, kernel=kernel_prefix)
+                continue
             v = t.get("spconv_forward", {}).get("hbm_bytes_per_api_launch")
             if v is not None:
-                out = dict(value=v, source=f"profiles/{name}",
-                           unit=t.get("unit", "HBM bytes per launch (FETCH_SIZE x correction + WRITE_SIZE, rocprofv3 --pmc, separate passes)"))
+                out = dict(value=v, source=f"profiles/{name}", unit=unit, kernel="all sparse-conv launches (average)")
     return out
 
 
@@ -570,8 +580,8 @@ def main():
     if rank == 0 and not args.no_roofline and not args.train:
         n = min(args.steps, 2 * nframes)
         conv_t, hbm_t = instrumented_pass(model, pool, n, args.hot_path_only)
-        traffic = committed_traffic() if args.dataset == "nuscenes" else {}
-        result["roofline"] = roofline_blocks(conv_t, hbm_t, n, result["ms_per_step"], traffic)
+        result["roofline"] = roofline_blocks(conv_t, hbm_t, n, result["ms_per_step"],
+                                             committed_traffic if args.dataset == "nuscenes" else None)
         if not args.hot_path_only:  # where the frame time goes: the three query-generation stages vs the rest
             torch.cuda.synchronize()
             t0 = time.perf_counter()
