@@ -45,7 +45,7 @@ def lib():
                     "fsf_segment_reduce_workspace_bytes",
                     "fsf_rulebook_workspace_bytes", "fsf_rulebook_to_pairs_workspace_bytes",
                     "fsf_ingroup_rank_workspace_bytes", "fsf_dynamic_point_pool_workspace_bytes",
-                    "fsf_nms_bev_workspace_bytes", "fsf_nms_bev_multiclass_workspace_bytes",
+                    "fsf_nms_bev_workspace_bytes", "fsf_nms_bev_multiclass_workspace_bytes", "fsf_nms_bev_multiclass_capped_workspace_bytes",
                     "fsf_norm_act_backward_workspace_bytes", "fsf_column_stats_workspace_bytes",
                     "fsf_connected_components_workspace_bytes",
                     "fsf_spconv_workspace_bytes", "fsf_spconv_backward_weight_workspace_bytes",

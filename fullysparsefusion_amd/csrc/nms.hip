@@ -29,16 +29,20 @@ struct NmsArgs {
   const int32_t* count;
   int64_t mask_stride, sum_stride, keep_stride;
   int64_t max_keep;  // > 0: a scan stops once it has kept this many boxes (the caller only uses the best max_keep of a class)
+  int64_t window;    // > 0: only the `window` best-scoring boxes of a class are in its mask (rows / bits >= window do not exist)
+  int32_t* incomplete;  // set to 1 when a windowed class ran out of boxes before max_keep keeps (the caller reruns without a window)
 };
 
 struct NmsBuildArgs {
   const uint64_t* mask0;    // pair bits in the original box order (upper triangle)
   const uint64_t* rowsum0;
   const int32_t* rank;      // [C][n] position of box i in class c's descending-score order, -1 = below the threshold
-  uint64_t* mask;           // [C][n][words]
-  uint64_t* rowsum;         // [C][n][sum_words]
+  uint64_t* mask;           // [C][rows][cwords]      rows = window (or n), cwords = ceil(rows / 64)
+  uint64_t* rowsum;         // [C][rows][csum_words]
   int64_t n;
-  int words, sum_words;
+  int words, sum_words;     // of mask0 / rowsum0 (all n boxes)
+  int64_t rows;
+  int cwords, csum_words;
 };
 
 __device__ __forceinline__ float rect_overlap_rotated(const float* a, const float* b) {
@@ -330,6 +334,7 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
   if (a.count) {  // class slice; the row strides (a.words, a.sum_words) are those of the full box count
     const int c = blockIdx.x;
     a.n = a.count[c];
+    if (a.window > 0 && a.n > a.window) a.n = a.window;
     a.mask += c * a.mask_stride;
     a.rowsum += c * a.sum_stride;
     a.keep += c * a.keep_stride;
@@ -409,7 +414,10 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *a.num_keep = nkeep;
+  if (threadIdx.x == 0) {
+    *a.num_keep = nkeep;
+    if (a.incomplete && a.window > 0 && a.count && nkeep < a.max_keep && (int64_t)a.count[blockIdx.x] > a.window) *a.incomplete = 1;
+  }
 }
 
 // Multi-class: the pair bits were computed once in the original box order; class c's scan needs them in ITS score order.
@@ -418,23 +426,23 @@ __global__ void __launch_bounds__(256) nms_scan_kernel(NmsArgs a) {
 __global__ void __launch_bounds__(256) nms_build_kernel(NmsBuildArgs a) {
   const int c = blockIdx.y;
   const int32_t* rank = a.rank + (int64_t)c * a.n;
-  uint64_t* mask = a.mask + (int64_t)c * a.n * a.words;
-  uint64_t* rowsum = a.rowsum + (int64_t)c * a.n * a.sum_words;
+  uint64_t* mask = a.mask + (int64_t)c * a.rows * a.cwords;
+  uint64_t* rowsum = a.rowsum + (int64_t)c * a.rows * a.csum_words;
   const int64_t total = a.n * a.sum_words;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int64_t i = t / a.sum_words;
     const int q = (int)(t - i * a.sum_words);
     const int ri = rank[i];
-    if (ri < 0) continue;
+    if (ri < 0 || ri >= a.rows) continue;
     for (uint64_t sb = a.rowsum0[t]; sb; sb &= sb - 1) {
       const int w = q * 64 + __builtin_ctzll(sb);
       for (uint64_t bits = a.mask0[i * a.words + w]; bits; bits &= bits - 1) {
         const int64_t j = (int64_t)w * 64 + __builtin_ctzll(bits);
         const int rj = rank[j];
-        if (rj < 0) continue;
+        if (rj < 0 || rj >= a.rows) continue;
         const int lo = min(ri, rj), hi = max(ri, rj);
-        atomicOr((unsigned long long*)&mask[(int64_t)lo * a.words + (hi >> 6)], 1ull << (hi & 63));
-        atomicOr((unsigned long long*)&rowsum[(int64_t)lo * a.sum_words + (hi >> 12)], 1ull << ((hi >> 6) & 63));
+        atomicOr((unsigned long long*)&mask[(int64_t)lo * a.cwords + (hi >> 6)], 1ull << (hi & 63));
+        atomicOr((unsigned long long*)&rowsum[(int64_t)lo * a.csum_words + (hi >> 12)], 1ull << ((hi >> 6) & 63));
       }
     }
   }
@@ -503,7 +511,7 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
   if (n == 0) {
     FSF_HIP_TRY(hipMemsetAsync(ndev, 0, sizeof(int64_t), stream));
   } else {
-    NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, ndev, nullptr, 0, 0, 0, 0};
+    NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, ndev, nullptr, 0, 0, 0, 0, 0, nullptr};
     FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)n * sum_words * 8, stream));
     const int rc = nms_launch_mask(a, arena, stream);
     if (rc != FSF_OK) return rc;
@@ -517,32 +525,58 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
   return FSF_OK;
 }
 
-extern "C" int64_t fsf_nms_bev_multiclass_workspace_bytes(int64_t n, int32_t num_classes) {
+static int64_t nms_window(int64_t n, int64_t max_keep, bool windowed) {
+  if (!windowed || max_keep <= 0) return n;
+  int64_t k = 4 * max_keep > 2048 ? 4 * max_keep : 2048;
+  k = (k + 63) / 64 * 64;
+  return k < n ? k : n;
+}
+
+static int64_t nms_multiclass_bytes(int64_t n, int32_t num_classes, int64_t rows) {
   const int64_t words = (n + 63) / 64, sum_words = (words + 63) / 64;
+  const int64_t cw = (rows + 63) / 64, cs = (cw + 63) / 64;
   const int64_t n1 = n > 0 ? n : 1, w1 = words > 0 ? words : 1, s1 = sum_words > 0 ? sum_words : 1;
+  const int64_t r1 = rows > 0 ? rows : 1, cw1 = cw > 0 ? cw : 1, cs1 = cs > 0 ? cs : 1;
   const int64_t c1 = num_classes > 0 ? num_classes : 1;
-  return (1 + c1) * (fsf_align_up(n1 * w1 * 8, 256) + fsf_align_up(n1 * s1 * 8, 256)) + 512 + nms_bins_bytes(n);
+  return fsf_align_up(n1 * w1 * 8, 256) + fsf_align_up(n1 * s1 * 8, 256) + fsf_align_up(c1 * r1 * cw1 * 8, 256) +
+         fsf_align_up(c1 * r1 * cs1 * 8, 256) + 512 + nms_bins_bytes(n);
+}
+
+extern "C" int64_t fsf_nms_bev_multiclass_workspace_bytes(int64_t n, int32_t num_classes) {
+  return nms_multiclass_bytes(n, num_classes, n);
+}
+
+// with a cap AND an `incomplete` flag the per-class masks only hold each class's best window = max(4 max_keep, 2048) boxes:
+// (1 + C (window / n)^2) n^2 / 8 bytes instead of (1 + C) n^2 / 8
+extern "C" int64_t fsf_nms_bev_multiclass_capped_workspace_bytes(int64_t n, int32_t num_classes, int64_t max_keep) {
+  return nms_multiclass_bytes(n, num_classes, nms_window(n, max_keep, true));
 }
 
 extern "C" int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank,
                                              const int32_t* count, float thresh, int32_t rotated, int64_t max_keep, int64_t* keep,
-                                             int64_t* num_keep, void* workspace, int64_t workspace_bytes, void* stream_);
+                                             int64_t* num_keep, int32_t* incomplete, void* workspace, int64_t workspace_bytes,
+                                             void* stream_);
 
 extern "C" int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank,
                                       const int32_t* count, float thresh, int32_t rotated, int64_t* keep, int64_t* num_keep,
                                       void* workspace, int64_t workspace_bytes, void* stream_) {
-  return fsf_nms_bev_multiclass_capped(boxes, n, num_classes, rank, count, thresh, rotated, 0, keep, num_keep, workspace,
+  return fsf_nms_bev_multiclass_capped(boxes, n, num_classes, rank, count, thresh, rotated, 0, keep, num_keep, nullptr, workspace,
                                        workspace_bytes, stream_);
 }
 
 extern "C" int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank,
                                              const int32_t* count, float thresh, int32_t rotated, int64_t max_keep, int64_t* keep,
-                                             int64_t* num_keep, void* workspace, int64_t workspace_bytes, void* stream_) {
+                                             int64_t* num_keep, int32_t* incomplete, void* workspace, int64_t workspace_bytes,
+                                             void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || num_classes < 1 || !count || !num_keep || (n > 0 && (!boxes || !rank || !keep))) return FSF_ERR_INVALID_ARG;
   const int64_t words = (n + 63) / 64, sum_words = (words + 63) / 64;
   if (words * 8 > 60 * 1024) return FSF_ERR_UNSUPPORTED;
-  if (workspace_bytes < fsf_nms_bev_multiclass_workspace_bytes(n, num_classes) || !workspace) return FSF_ERR_WORKSPACE;
+  const bool windowed = incomplete != nullptr && max_keep > 0;
+  const int64_t rows = nms_window(n, max_keep, windowed);
+  const int64_t cwords = (rows + 63) / 64, csum = (cwords + 63) / 64;
+  if (workspace_bytes < nms_multiclass_bytes(n, num_classes, rows) || !workspace) return FSF_ERR_WORKSPACE;
+  if (incomplete) FSF_HIP_TRY(hipMemsetAsync(incomplete, 0, sizeof(int32_t), stream));
   if (n == 0) {
     FSF_HIP_TRY(hipMemsetAsync(num_keep, 0, sizeof(int64_t) * num_classes, stream));
     return FSF_OK;
@@ -550,22 +584,22 @@ extern "C" int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int3
   FsfArena arena(workspace, workspace_bytes);
   uint64_t* mask0 = arena.take<uint64_t>(n * words);
   uint64_t* rowsum0 = arena.take<uint64_t>(n * sum_words);
-  uint64_t* mask = arena.take<uint64_t>((int64_t)num_classes * n * words);
-  uint64_t* rowsum = arena.take<uint64_t>((int64_t)num_classes * n * sum_words);
+  uint64_t* mask = arena.take<uint64_t>((int64_t)num_classes * rows * cwords);
+  uint64_t* rowsum = arena.take<uint64_t>((int64_t)num_classes * rows * csum);
   if (!arena.ok()) return FSF_ERR_WORKSPACE;
   // the build kernel walks mask0 through rowsum0, so the lower-triangle words the mask kernel skips are never read
   FSF_HIP_TRY(hipMemsetAsync(rowsum0, 0, (size_t)n * sum_words * 8, stream));
-  FSF_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)num_classes * n * words * 8, stream));
-  FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)num_classes * n * sum_words * 8, stream));
-  NmsArgs a0{boxes, n, thresh, (int)rotated, mask0, rowsum0, (int)words, (int)sum_words, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+  FSF_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)num_classes * rows * cwords * 8, stream));
+  FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)num_classes * rows * csum * 8, stream));
+  NmsArgs a0{boxes, n, thresh, (int)rotated, mask0, rowsum0, (int)words, (int)sum_words, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr};
   const int rc = nms_launch_mask(a0, arena, stream);
   if (rc != FSF_OK) return rc;
-  NmsBuildArgs b{mask0, rowsum0, rank, mask, rowsum, n, (int)words, (int)sum_words};
+  NmsBuildArgs b{mask0, rowsum0, rank, mask, rowsum, n, (int)words, (int)sum_words, rows, (int)cwords, (int)csum};
   hipLaunchKernelGGL(nms_build_kernel, dim3((unsigned)fsf_stream_grid(n * sum_words, 256), (unsigned)num_classes), dim3(256), 0,
                      stream, b);
-  NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)words, (int)sum_words, keep, num_keep, count,
-            n * words, n * sum_words, n, max_keep};
-  hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)num_classes), dim3(256), (size_t)words * 8, stream, a);
+  NmsArgs a{boxes, n, thresh, (int)rotated, mask, rowsum, (int)cwords, (int)csum, keep, num_keep, count,
+            rows * cwords, rows * csum, n, max_keep, windowed ? rows : 0, incomplete};
+  hipLaunchKernelGGL(nms_scan_kernel, dim3((unsigned)num_classes), dim3(256), (size_t)cwords * 8, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

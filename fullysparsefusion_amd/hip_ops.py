@@ -85,7 +85,8 @@ _ARGTYPES = {
     "fsf_nms_bev": [_P, c_i64, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_nms_bev_multiclass_workspace_bytes": [c_i64, c_i32],
     "fsf_nms_bev_multiclass": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, c_i64, _P],
-    "fsf_nms_bev_multiclass_capped": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i64, _P, _P, _P, c_i64, _P],
+    "fsf_nms_bev_multiclass_capped": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i64, _P, _P, _P, _P, c_i64, _P],
+    "fsf_nms_bev_multiclass_capped_workspace_bytes": [c_i64, c_i32, c_i64],
     "fsf_connected_components_grouped": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
@@ -871,10 +872,11 @@ def nms_bev(boxes_sorted: torch.Tensor, thresh: float, rotated: bool = True):
 
 
 def nms_bev_multiclass(boxes: torch.Tensor, rank: torch.Tensor, count: torch.Tensor, thresh: float, rotated: bool = True,
-                       max_keep: int = 0):
+                       max_keep: int = 0, windowed: bool = False):
     """fsf_nms_bev_multiclass[_capped]: boxes f32 [n,5] (caller's order), rank i32 [C,n], count i32 [C] ->
     (keep i64 [C,n] kept ranks per class, num_keep i64 [C]), all on the device (no sync); max_keep > 0 stops a class after
-    that many kept boxes."""
+    that many kept boxes.  `windowed` (with max_keep): the per-class masks hold only each class's best max(4 max_keep, 2048)
+    boxes and a third result, `incomplete` i32 [1], says whether some class ran out of window first (then call again without)."""
     require_cuda(boxes, rank, count)
     assert boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.size(1) == 5
     assert rank.dtype == torch.int32 and count.dtype == torch.int32 and rank.dim() == 2 and rank.size(1) == boxes.size(0)
@@ -883,10 +885,15 @@ def nms_bev_multiclass(boxes: torch.Tensor, rank: torch.Tensor, count: torch.Ten
     keep = torch.empty((c, max(n, 1)), dtype=torch.int64, device=b.device)
     num = torch.empty((c,), dtype=torch.int64, device=b.device)
     h = _L()
-    ws = _lib.workspace(h.fsf_nms_bev_multiclass_workspace_bytes(n, c), b.device)
+    windowed = bool(windowed) and max_keep > 0
+    flag = torch.empty((1,), dtype=torch.int32, device=b.device) if windowed else None
+    nbytes = (h.fsf_nms_bev_multiclass_capped_workspace_bytes(n, c, int(max_keep)) if windowed
+              else h.fsf_nms_bev_multiclass_workspace_bytes(n, c))
+    ws = _lib.workspace(nbytes, b.device)
     check(h.fsf_nms_bev_multiclass_capped(ptr(b), n, c, ptr(rank), ptr(count), float(thresh), int(bool(rotated)), int(max_keep),
-                                          ptr(keep), ptr(num), ptr(ws), ws.numel(), stream_ptr()), "fsf_nms_bev_multiclass_capped")
-    return keep, num
+                                          ptr(keep), ptr(num), ptr(flag), ptr(ws), ws.numel(), stream_ptr()),
+          "fsf_nms_bev_multiclass_capped")
+    return (keep, num, flag) if windowed else (keep, num)
 
 
 # ------------------------------------------------------------------------------ connected components

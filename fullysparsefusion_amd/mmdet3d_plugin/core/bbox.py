@@ -165,10 +165,21 @@ def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_th
     pos = torch.arange(n, device=st.device, dtype=torch.int32).expand(num_classes, n)
     rank = torch.empty_like(pos).scatter_(1, order, pos)
     rank = torch.where(valid, rank, rank.new_full((), -1))
-    keep, num = hip_ops.nms_bev_multiclass(mlvl_bboxes_for_nms.float(), rank, count, cfg["nms_thr"],
-                                           rotated=bool(cfg.get("use_rotate_nms", False)),
-                                           max_keep=int(max_num) if max_num is not None and max_num > 0 else 0)  # (only the best max_num survive below)
+    cap = int(max_num) if max_num is not None and max_num > 0 else 0  # (only the best max_num survive below)
+    boxes_nms = mlvl_bboxes_for_nms.float()
+    rotated = bool(cfg.get("use_rotate_nms", False))
+    if cap > 0:
+        # per-class masks over each class's best-scoring window only; a class that runs out of window before `cap` keeps
+        # (checked after the host sync the compaction below needs anyway) repeats the call on full masks
+        keep, num, incomplete = hip_ops.nms_bev_multiclass(boxes_nms, rank, count, cfg["nms_thr"], rotated=rotated, max_keep=cap,
+                                                           windowed=True)
+    else:
+        keep, num = hip_ops.nms_bev_multiclass(boxes_nms, rank, count, cfg["nms_thr"], rotated=rotated)
+        incomplete = None
     kept = (torch.arange(n, device=st.device)[None, :] < num[:, None]).nonzero(as_tuple=False)  # class-major, score order
+    if incomplete is not None and bool(incomplete.item()):
+        keep, num = hip_ops.nms_bev_multiclass(boxes_nms, rank, count, cfg["nms_thr"], rotated=rotated, max_keep=cap)
+        kept = (torch.arange(n, device=st.device)[None, :] < num[:, None]).nonzero(as_tuple=False)
     labels = kept[:, 0]
     box_idx = order[labels, keep[labels, kept[:, 1]]]
     bboxes, scores = mlvl_bboxes[box_idx], st[labels, box_idx]

@@ -547,10 +547,15 @@ int fsf_nms_bev_multiclass(const float* boxes, int64_t n, int32_t num_classes, c
  * [UNVENDORED mmdet3d.core.post_processing] keeps only the max_num best scores over all classes afterwards
  * (frustum_cluster_head.py:661-663 passes cfg.max_num), and a class's kept boxes come out in descending score order, so
  * its boxes past the first max_num can never be among them: same result, and the scan — a latency chain of one 64-box word
- * per step — ends after max_num keeps instead of walking all n boxes. */
+ * per step — ends after max_num keeps instead of walking all n boxes.
+ * With `incomplete` (device i32, written 0 / 1) the per-class masks only hold each class's best max(4 max_keep, 2048) boxes
+ * (workspace: fsf_nms_bev_multiclass_capped_workspace_bytes — (1 + C w^2 / n^2) n^2 / 8 bytes instead of (1 + C) n^2 / 8); a class
+ * that runs out of window before max_keep keeps sets *incomplete = 1 and the caller repeats the call with incomplete = NULL
+ * (full masks, fsf_nms_bev_multiclass_workspace_bytes). */
+int64_t fsf_nms_bev_multiclass_capped_workspace_bytes(int64_t n, int32_t num_classes, int64_t max_keep);
 int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank, const int32_t* count,
                                   float thresh, int32_t rotated, int64_t max_keep, int64_t* keep, int64_t* num_keep,
-                                  void* workspace, int64_t workspace_bytes, void* stream);
+                                  int32_t* incomplete, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K18  in-group rank (TorchEx ingroup_indices [UNVENDORED]); sst_ops.py:239-259.

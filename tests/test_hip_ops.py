@@ -1012,6 +1012,36 @@ def test_nms_bev_multiclass_equals_per_class_calls(ops, device):
             m = min(int(num[k]), cap)
             assert int(num_c[k]) == m
             assert torch.equal(keep_c[k, :m], keep[k, :m])
+        keep_w, num_w, flag = ops.nms_bev_multiclass(boxes, rank, count, 0.25, True, max_keep=cap, windowed=True)
+        assert int(flag) == 0  # (900 boxes: the window of max(4 cap, 2048) covers every class)
+        assert torch.equal(num_w, num_c) and all(torch.equal(keep_w[k, :int(num_c[k])], keep_c[k, :int(num_c[k])]) for k in range(c))
+
+
+def test_nms_bev_multiclass_window_and_incomplete_flag(ops, device):
+    """Windowed per-class masks (each class's best max(4 cap, 2048) boxes): with spread-out boxes the first `cap` keeps lie inside
+    the window and the result equals the full-mask call; with 6 000 copies of a few boxes a class keeps fewer than `cap` inside its
+    window although it has more boxes — the flag is raised (the caller repeats on full masks)."""
+    rng = np.random.default_rng(2)
+    n, c, cap = 6000, 3, 100
+    def make(ctr):
+        wl = np.stack([rng.uniform(1.5, 2.5, n), rng.uniform(3.5, 5.5, n)], 1)
+        return torch.from_numpy(np.concatenate([ctr - wl / 2, ctr + wl / 2, rng.uniform(-np.pi, np.pi, (n, 1))], 1).astype(np.float32)).to(device)
+    scores = torch.from_numpy(rng.random((c, n)).astype(np.float32)).to(device)
+    valid = scores > 0.05
+    order = torch.where(valid, scores, scores.new_full((), float("-inf"))).sort(dim=1, descending=True, stable=True)[1]
+    count = valid.sum(1, dtype=torch.int32)
+    pos = torch.arange(n, device=device, dtype=torch.int32).expand(c, n)
+    rank = torch.where(valid, torch.empty_like(pos).scatter_(1, order, pos), pos.new_full((), -1))
+    spread = make(rng.uniform(-300, 300, (n, 2)))
+    full_k, full_n = ops.nms_bev_multiclass(spread, rank, count, 0.25, True, max_keep=cap)
+    win_k, win_n, flag = ops.nms_bev_multiclass(spread, rank, count, 0.25, True, max_keep=cap, windowed=True)
+    assert int(flag) == 0 and torch.equal(win_n, full_n)
+    assert all(torch.equal(win_k[k, :int(full_n[k])], full_k[k, :int(full_n[k])]) for k in range(c))
+    stacked = make(rng.uniform(-20, 20, (40, 2))[rng.integers(0, 40, n)] + rng.normal(0, 0.05, (n, 2)))
+    full_k, full_n = ops.nms_bev_multiclass(stacked, rank, count, 0.25, True, max_keep=cap)
+    assert int(full_n.max()) < cap                       # ~40 survivors per class: the cap is never reached
+    _, win_n, flag = ops.nms_bev_multiclass(stacked, rank, count, 0.25, True, max_keep=cap, windowed=True)
+    assert int(flag) == 1                                # 6 000 boxes per class > the 2 048-box window
 
 
 # ------------------------------------------------------------------------------------------ K21 SIR-layer input
