@@ -5,6 +5,8 @@ projects/mmdet3d_plugin/models/detectors/single_stage_fsd.py:234.  Restated from
 (lateral SparseBasicBlock, concat, merge SubM, channel-reduce-add, SparseInverseConv3d / final SubM upsample),
 output rows in the input voxel order.  Submodule names follow upstream (`conv_input`,
 `encoder_layers.encoder_layerN`, `lateral_layerN`, `merge_layerN`, `upsample_layerN`)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -98,8 +100,8 @@ class SimpleSparseUNet(nn.Module):
         assert in_channels % out_channels == 0 and in_channels >= out_channels
         return x._like(features.view(n, out_channels, -1).sum(dim=2))
 
-    def decoder_layer_forward(self, x_lateral, x_bottom, lateral_layer, merge_layer, upsample_layer):
-        x = lateral_layer(x_lateral)
+    def decoder_layer_forward(self, x_lateral, x_bottom, lateral_layer, merge_layer, upsample_layer, lateral_out=None):
+        x = lateral_out if lateral_out is not None else lateral_layer(x_lateral)
         lat_planes, bot_planes = x.plane_sources, x_bottom.plane_sources
         x = x._like(torch.cat((x_bottom.features, x.features), dim=1))
         if lat_planes is not None and len(lat_planes) == 1 and x_bottom.features.size(1) <= 128 and x_bottom.features.size(1) % 32 == 0:
@@ -131,11 +133,37 @@ class SimpleSparseUNet(nn.Module):
         x = SparseConvTensor(voxel_features, coors.contiguous(), self.sparse_shape, batch_size)
         x = self.conv_input(x)
         encode_features = []
-        for encoder_layer in self.encoder_layers._modules.values():
+        # Inference: the lateral blocks of the FINE levels (two big submanifold convolutions each, independent of everything below
+        # them) go to a side stream once the encoder has left those levels: they fill the CUs that the small deep levels — a few
+        # dozen workgroups per launch — leave idle, instead of running alone after them.
+        side_levels = 0
+        if (voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training
+                and os.environ.get("FSF_UNET_LATERAL_STREAM", "1") != "0"):
+            side_levels = min(int(os.environ.get("FSF_UNET_LATERAL_LEVELS", "3")), self.stage_num - 1)
+        lateral_out, lateral_done = {}, {}
+        for level, encoder_layer in enumerate(self.encoder_layers._modules.values(), start=1):
             x = encoder_layer(x)
             encode_features.append(x)
+            if side_levels > 0 and level == side_levels:
+                main = torch.cuda.current_stream()
+                if getattr(self, "_lateral_stream", None) is None:
+                    self._lateral_stream = torch.cuda.Stream()
+                side = self._lateral_stream
+                side.wait_stream(main)  # the encoder outputs of levels 1..side_levels exist
+                with torch.cuda.stream(side):
+                    for lv in range(side_levels, 0, -1):  # the decoder needs the deepest of them first
+                        y = getattr(self, f"lateral_layer{lv}")(encode_features[lv - 1])
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        lateral_out[lv], lateral_done[lv] = y, ev
         x = encode_features[-1]
         for i in range(self.stage_num, 0, -1):
+            lat = lateral_out.get(i)
+            if lat is not None:
+                main = torch.cuda.current_stream()
+                main.wait_event(lateral_done[i])
+                for t in [lat.features] + [u for pl in (lat.plane_sources or []) for u in (pl.data, pl.scales)]:
+                    t.record_stream(main)  # allocated on the side stream, consumed (and later freed) on this one
             x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f"lateral_layer{i}"),
-                                           getattr(self, f"merge_layer{i}"), getattr(self, f"upsample_layer{i}"))
+                                           getattr(self, f"merge_layer{i}"), getattr(self, f"upsample_layer{i}"), lateral_out=lat)
         return [{"voxel_feats": x.features}]
