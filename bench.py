@@ -314,12 +314,22 @@ def instrumented_pass(model, pool, steps, hot_path_only):
     p.wrap(hip_ops, "spconv_forward_split", _acc_spconv("split"))
     if hasattr(hip_ops, "spconv_forward_planes"):
         p.wrap(hip_ops, "spconv_forward_planes", _acc_spconv("planes"))
+    # The conv launches are timed with the U-Net's side stream off (FSF_UNET_LATERAL_STREAM=0): with it, the fine lateral blocks run
+    # beside the small deep levels and an event pair on one stream brackets time its kernel shares with the other stream's —
+    # the frame gets shorter while every overlapped launch looks longer.  (profiles/*_kernel_stats_full_forward_serial_unet.txt is
+    # the rocprofv3 summary of the same setting.)
+    prev = os.environ.get("FSF_UNET_LATERAL_STREAM")
+    os.environ["FSF_UNET_LATERAL_STREAM"] = "0"
     try:
         for i in range(steps):
             step(model, pool[i % len(pool)], hot_path_only)
         torch.cuda.synchronize()
     finally:
         p.restore()
+        if prev is None:
+            os.environ.pop("FSF_UNET_LATERAL_STREAM", None)
+        else:
+            os.environ["FSF_UNET_LATERAL_STREAM"] = prev
     conv = p.table()
     q = _Probe("capture")
     q.wrap(hip_ops, "segment_reduce", _acc_seg_reduce)

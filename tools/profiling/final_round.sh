@@ -11,6 +11,8 @@ python bench.py --dataset av2 --no-cpu-baseline > $out/bench_av2.json 2>> $out/b
 bash tools/profiling/run_prof.sh fwd_$tag > /dev/null 2>&1
 cp gpurun_out/fwd_${tag}_kernels.txt $out/kernel_stats_full_forward.txt
 cp gpurun_out/fwd_${tag}_bench.json $out/bench_under_rocprof.json
+FSF_UNET_LATERAL_STREAM=0 bash tools/profiling/run_prof.sh fwdserial_$tag > /dev/null 2>&1   # the setting bench.py's conv events are taken in
+cp gpurun_out/fwdserial_${tag}_kernels.txt $out/kernel_stats_full_forward_serial_unet.txt
 rm -rf gpurun_out/prof_tr
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tr -o fsf -- python bench.py --train --steps 5 --warmup 2 > $out/bench_train_under_rocprof.json 2>> $out/bench.err
 python tools/profiling/prof_summary.py gpurun_out/prof_tr/fsf_results.db 7 "rocprofv3 --kernel-trace --stats -- python bench.py --train --steps 5 --warmup 2 ($tag)" > $out/kernel_stats_train_step.txt
