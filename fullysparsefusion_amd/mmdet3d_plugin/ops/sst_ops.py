@@ -213,6 +213,26 @@ def scatter_mean_multi(feats, new_coors, unq_inv):
     feats = [f.float() for f in feats]
     if (_SHORT_SEGMENTS and 1 <= len(feats) <= 8 and all(f.is_cuda and f.dim() == 2 for f in feats)
             and not (torch.is_grad_enabled() and any(f.requires_grad for f in feats))):
+        # Tensors whose rows sit in 16-byte-aligned, padded storage (the 131-column point features in their 132-float rows) are
+        # reduced as their padded width with float4 lanes — the pad column's mean is computed and dropped — in one launch, the
+        # odd-width rest in another; four-byte lanes over all 213 columns took 324 us on the 0.1 m voxels of the 10-sweep frame.
+        def padded_view(f):
+            c4 = (f.size(1) + 3) // 4 * 4
+            if (f.size(1) >= 64 and f.stride(1) == 1 and f.size(0) > 1 and f.stride(0) % 4 == 0 and f.stride(0) >= c4
+                    and f.data_ptr() % 16 == 0):
+                return f.as_strided((f.size(0), c4), (f.stride(0), 1))
+            return None
+
+        wide = [(i, padded_view(f)) for i, f in enumerate(feats)]
+        wide = [(i, v) for i, v in wide if v is not None]
+        if wide and len(wide) < len(feats):
+            out = [None] * len(feats)
+            for (i, _), o in zip(wide, hip_ops.segment_reduce_short([v for _, v in wide], plan, "mean")):
+                out[i] = o[:, :feats[i].size(1)]
+            rest = [i for i in range(len(feats)) if out[i] is None]
+            for i, o in zip(rest, hip_ops.segment_reduce_short([feats[i] for i in rest], plan, "mean")):
+                out[i] = o
+            return out
         return hip_ops.segment_reduce_short(feats, plan, "mean")
     return [_SegmentReduce.apply(f, plan, "mean", _SHORT_SEGMENTS) for f in feats]
 
