@@ -256,3 +256,22 @@ def test_fused_syncbn_relu_equals_upstream_formulation_world2_gloo():
     for rank, out in got:
         for a, b in zip(out["1"], out["0"]):
             assert np.allclose(a, b, rtol=1e-10, atol=1e-12), rank
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher re-launches itself under torch.distributed.run on 127.0.0.1: here (no HIP
+    device) both ranks must come up with RANK / WORLD_SIZE set and stop at the device check — not at an assertion about the
+    environment, and not hang."""
+    import subprocess
+    import sys
+
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher (on a GPU box the command would start the benchmark)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    out = r.stdout + r.stderr
+    assert r.returncode != 0
+    assert out.count("needs a HIP device") >= 2, out[-2000:]
+    assert "WORLD_SIZE=" not in out  # (the mismatch message of a rank that was not launched per GPU)
