@@ -1486,6 +1486,39 @@ def test_vote_centers_keys_equals_the_torch_expressions(ops, device):
     assert torch.equal(keys[:, 1:], want_v) and torch.equal(keys[:, 0], g_ids * bsz + want_b) and torch.equal(b, want_b)
 
 
+def test_round2_entry_points_on_empty_and_tiny_inputs(ops, device):
+    """No rows / one row through the entry points added this round: nothing is launched on empty inputs, shapes stay right."""
+    z128 = torch.empty((0, 128), device=device)
+    w = torch.randn(256, 128, device=device)
+    pl = ops.linear_prepare_weight_sliced(w, 2, 128)
+    assert ops.linear_norm_act_sliced(z128, 128, 0, pl, 2, 128).shape == (0, 256)
+    one = ops.linear_norm_act_sliced(torch.randn(1, 128, device=device), 128, 0, pl, 2, 128)
+    assert one.shape == (1, 256) and bool(torch.isfinite(one).all())
+    # short-segment reduce: no rows, segments all empty
+    plan = ops.segment_plan_from_inverse(torch.empty((0,), dtype=torch.int64, device=device), 3)
+    outs = ops.segment_reduce_short([torch.empty((0, 5), device=device), torch.empty((0, 8), device=device)], plan, "mean")
+    assert [tuple(o.shape) for o in outs] == [(3, 5), (3, 8)] and not any(bool(o.any()) for o in outs)
+    # gather from a strided source with no indices / vote centres with no pairs
+    wide = torch.randn(10, 12, device=device)
+    assert ops.gather_rows(wide[:, 2:9], torch.empty((0,), dtype=torch.int64, device=device)).shape == (0, 7)
+    e = torch.empty((0,), dtype=torch.int64, device=device)
+    c, k, b = ops.vote_centers_keys(torch.randn(4, 11, device=device), torch.randn(4, 33, device=device), torch.randn(4, 5, device=device),
+                                    torch.zeros(4, dtype=torch.int64, device=device), e, e, 10, [1, 6], [[0.4, 0.4, 0.8]] * 2, [-54, -54, -5], 1)
+    assert c.shape == (0, 3) and k.shape == (0, 4) and b.shape == (0,)
+    # pooling through the cell-binned path with a single point / a single RoI, and with none inside
+    rois = torch.tensor([[0.0, 0.0, -1.0, 2.0, 4.0, 2.0, 0.3]], device=device)
+    p1 = torch.tensor([[0.1, 0.2, 0.0]], device=device)
+    gp, gr, gf = ops.dynamic_point_pool(rois, p1, [0.5, 0.5, 0.5], 512)
+    assert gp.tolist() == [0] and gr.tolist() == [0] and gf.shape == (1, 13)
+    gp, gr, gf = ops.dynamic_point_pool(rois, p1 + 100.0, [0.5, 0.5, 0.5], 512)
+    assert gp.numel() == 0 and gf.shape == (0, 13)
+    # windowed multi-class NMS with nothing above the threshold
+    boxes = torch.tensor([[0.0, 0.0, 1.0, 1.0, 0.0], [5.0, 5.0, 6.0, 6.0, 0.0]], device=device)
+    rank = torch.full((2, 2), -1, dtype=torch.int32, device=device)
+    keep, num, flag = ops.nms_bev_multiclass(boxes, rank, torch.zeros(2, dtype=torch.int32, device=device), 0.25, True, max_keep=10, windowed=True)
+    assert num.tolist() == [0, 0] and int(flag) == 0
+
+
 def test_column_stats_and_batch_norm_edge_cases(ops, device):
     """K23 with no rows: sums / statistics / gradients are zeros, nothing is launched on empty inputs; a single row."""
     x0 = torch.empty(0, 12, device=device)
