@@ -182,14 +182,9 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_reduce_kernel(SegArgs a) {
 }
 
 // second pass: segments that straddle a chunk boundary (fold the partials in chunk order) and empty
-// segments (torch_scatter: out = 0, arg = n).
+// segments (torch_scatter: out = 0, arg = n).  `team_id` of `teams_total` lane teams walks the segments.
 template <int VEC, int MODE>
-__global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_kernel(SegArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int teams_per_wave = 64 / a.team;
-  const int tl = lane % a.team;
-  const int64_t team_id = ((int64_t)blockIdx.x * (SEG_BLOCK / 64) + (threadIdx.x >> 6)) * teams_per_wave + lane / a.team;
-  const int64_t teams_total = (int64_t)gridDim.x * (SEG_BLOCK / 64) * teams_per_wave;
+__device__ __forceinline__ void seg_fixup_short(const SegArgs& a, int64_t team_id, int64_t teams_total, int tl) {
   for (int64_t s = team_id; s < a.m; s += teams_total) {
     const int S = a.seg_offsets[s];
     const int E = a.seg_offsets[s + 1];
@@ -204,7 +199,7 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_kernel(SegArgs a) {
       continue;
     }
     const int cs = S / SEG_CHUNK, ce = (E - 1) / SEG_CHUNK;
-    if (cs == ce || ce - cs > SEG_LONG_SPAN) continue;  // long segments: seg_fixup_long_kernel
+    if (cs == ce || ce - cs > SEG_LONG_SPAN) continue;  // long segments: the workgroup-wide fold
     for (int ch = tl * VEC; ch < a.c; ch += a.team * VEC) {
       Vec<VEC> acc = load_vec<VEC>(a.part_val + ((int64_t)cs * 2 + 1) * a.c + ch);
       int32_t arg[VEC];
@@ -241,6 +236,14 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_kernel(SegArgs a) {
   }
 }
 
+template <int VEC, int MODE>
+__global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_kernel(SegArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int teams_per_wave = 64 / a.team;
+  seg_fixup_short<VEC, MODE>(a, ((int64_t)blockIdx.x * (SEG_BLOCK / 64) + (threadIdx.x >> 6)) * teams_per_wave + lane / a.team,
+                             (int64_t)gridDim.x * (SEG_BLOCK / 64) * teams_per_wave, lane % a.team);
+}
+
 // segments spanning more than SEG_LONG_SPAN chunks (SIR groups with 1e3..1e5 points): one workgroup per
 // segment; its lane teams stride over the chunk partials, then the team results are folded in team order
 // through LDS.  Ties in max keep the smaller point index (= first in the stable sorted order).
@@ -251,6 +254,13 @@ __global__ void __launch_bounds__(SEG_BLOCK) seg_fixup_long_kernel(SegArgs a) {
   // gridDim.y workgroups share a long segment by channel slice: the one workgroup per segment was the whole kernel's
   // critical path (a 1e5-point group = 3 000 partials of 128 channels); with narrower slices more lane teams stride the
   // partials.  (max / argmax do not depend on the fold order; sums keep a fixed one for a given launch shape.)
+  {  // the short straddlers and the empty segments first (what seg_fixup_kernel does when no segment can be long): one launch
+    const int lane = threadIdx.x & 63;
+    const int teams_per_wave = 64 / a.team;
+    const int64_t blk = (int64_t)blockIdx.y * gridDim.x + blockIdx.x, nblk = (int64_t)gridDim.x * gridDim.y;
+    seg_fixup_short<VEC, MODE>(a, (blk * (SEG_BLOCK / 64) + (threadIdx.x >> 6)) * teams_per_wave + lane / a.team,
+                               nblk * (SEG_BLOCK / 64) * teams_per_wave, lane % a.team);
+  }
   const int csl = (int)((a.c + (int)gridDim.y * VEC - 1) / ((int)gridDim.y * VEC)) * VEC;  // channels per slice
   const int c_lo = (int)blockIdx.y * csl, c_hi = c_lo + csl < a.c ? c_lo + csl : a.c;
   if (c_lo >= a.c) return;
@@ -592,18 +602,18 @@ static int seg_launch(const SegArgs& a, int mode, hipStream_t stream) {
   switch (mode) {
     case MODE_SUM:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_SUM>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
-      hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_SUM>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
       if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_SUM>), g3, dim3(SEG_BLOCK), 0, stream, a);
+      else hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_SUM>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
       break;
     case MODE_MEAN:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_MEAN>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
-      hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MEAN>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
       if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_MEAN>), g3, dim3(SEG_BLOCK), 0, stream, a);
+      else hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MEAN>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
       break;
     default:
       if (a.n > 0) hipLaunchKernelGGL((seg_reduce_kernel<VEC, MODE_MAX>), dim3((unsigned)g1), dim3(SEG_BLOCK), 0, stream, a);
-      hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MAX>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
       if (has_long) hipLaunchKernelGGL((seg_fixup_long_kernel<VEC, MODE_MAX>), g3, dim3(SEG_BLOCK), 0, stream, a);
+      else hipLaunchKernelGGL((seg_fixup_kernel<VEC, MODE_MAX>), dim3((unsigned)g2), dim3(SEG_BLOCK), 0, stream, a);
       break;
   }
   FSF_LAUNCH_CHECK();
