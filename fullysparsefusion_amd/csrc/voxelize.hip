@@ -155,6 +155,44 @@ __global__ void __launch_bounds__(256) vote_centers_keys_kernel(VoteArgs a) {
   }
 }
 
+// ---- DynamicScatterVFE input decoration in one pass (the reference builds it from ~20 elementwise launches) ------------------
+// out[i] = [ features[i, :P] | features[i, :3] - voxel_mean[inv[i], :3] (with_cluster_center) | features[i, :3] - centre of the
+// point's voxel = coor * voxel_size + offset, coordinate order x <- coors[:, 3], y <- coors[:, 2], z <- coors[:, 1]
+// (with_voxel_center) ], the fp32 operations of the torch expressions in their order (int -> float, mul, add, sub).
+struct VfeDecoArgs {
+  const float* feat; int feat_stride; int p;
+  const float* vmean; int vmean_stride; const int64_t* inv;
+  const int64_t* coors;
+  float vx, vy, vz, ox, oy, oz;
+  int with_cluster, with_center;
+  float* out; int out_stride;
+  int64_t n;
+};
+
+__global__ void __launch_bounds__(256) vfe_decorate_kernel(VfeDecoArgs a) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* f = a.feat + i * a.feat_stride;
+    float* o = a.out + i * a.out_stride;
+    for (int c = 0; c < a.p; ++c) o[c] = f[c];
+    int col = a.p;
+    const float x = f[0], y = f[1], z = f[2];
+    if (a.with_cluster) {
+      const float* m = a.vmean + a.inv[i] * a.vmean_stride;
+      o[col + 0] = __fsub_rn(x, m[0]);
+      o[col + 1] = __fsub_rn(y, m[1]);
+      o[col + 2] = __fsub_rn(z, m[2]);
+      col += 3;
+    }
+    if (a.with_center) {
+      const int64_t* c = a.coors + 4 * i;
+      o[col + 0] = __fsub_rn(x, __fadd_rn(__fmul_rn((float)c[3], a.vx), a.ox));
+      o[col + 1] = __fsub_rn(y, __fadd_rn(__fmul_rn((float)c[2], a.vy), a.oy));
+      o[col + 2] = __fsub_rn(z, __fadd_rn(__fmul_rn((float)c[1], a.vz), a.oz));
+      col += 3;
+    }
+  }
+}
+
 }  // namespace fsf
 
 using namespace fsf;
@@ -212,6 +250,25 @@ extern "C" int fsf_vote_centers_keys(const float* logits, int32_t logit_stride, 
   for (int j = 0; j < 3; ++j) a.rmin[j] = range_min[j];
   a.centers = centers; a.keys = keys; a.batch_out = batch_out;
   hipLaunchKernelGGL(vote_centers_keys_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, a);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_vfe_decorate(const float* features, int64_t n, int32_t feat_stride, int32_t p, const float* voxel_mean,
+                                int32_t vmean_stride, const int64_t* inv, const int64_t* coors_bzyx, const float voxel_size[3],
+                                const float offset[3], int32_t with_cluster_center, int32_t with_voxel_center, float* out,
+                                int32_t out_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int width = p + (with_cluster_center ? 3 : 0) + (with_voxel_center ? 3 : 0);
+  if (n < 0 || p < 3 || feat_stride < p || out_stride < width || (with_cluster_center && (!voxel_mean || !inv || vmean_stride < 3)) ||
+      (with_voxel_center && (!coors_bzyx || !voxel_size || !offset)) || (n > 0 && (!features || !out)))
+    return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  VfeDecoArgs a{features, (int)feat_stride, (int)p, voxel_mean, (int)vmean_stride, inv, coors_bzyx,
+                with_voxel_center ? voxel_size[0] : 0.f, with_voxel_center ? voxel_size[1] : 0.f, with_voxel_center ? voxel_size[2] : 0.f,
+                with_voxel_center ? offset[0] : 0.f, with_voxel_center ? offset[1] : 0.f, with_voxel_center ? offset[2] : 0.f,
+                (int)with_cluster_center, (int)with_voxel_center, out, (int)out_stride, n};
+  hipLaunchKernelGGL(vfe_decorate_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -18,6 +18,7 @@ _ARGTYPES = {
     "fsf_assemble_sweeps_workspace_bytes": [c_i64],
     "fsf_assemble_sweeps": [_P, c_i64, c_i32, _P, c_i32, _P, _P, _P, c_f32, _P, c_i32, c_f32, c_f32, _P, _P, _P, _P, c_i64, _P],
     "fsf_voxelize_dynamic": [_P, c_i64, c_i32, c_i32, _P, _P, _P, _P, _P, _P],
+    "fsf_vfe_decorate": [_P, c_i64, c_i32, c_i32, _P, c_i32, _P, _P, _P, _P, c_i32, c_i32, _P, c_i32, _P],
     "fsf_vote_centers_keys": [_P, c_i32, _P, c_i32, _P, c_i32, _P, _P, _P, c_i64, c_i32, c_i32, _P, _P, _P, c_i32, _P, _P, _P, _P],
     "fsf_voxelize_divfloor": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P],
     "fsf_unique_rows_workspace_bytes": [c_i64, c_i32],
@@ -170,6 +171,23 @@ def voxelize_divfloor(points: torch.Tensor, voxel_size, range_min, order="zyx", 
                                      {"xyz": 0, "zyx": 1}[order], ptr(batch_idx), ptr(coors), stream_ptr()),
           "fsf_voxelize_divfloor")
     return coors
+
+
+def vfe_decorate(features, voxel_mean, inv, coors_bzyx, voxel_size, offset, with_cluster_center=True, with_voxel_center=True):
+    """fsf_vfe_decorate: features f32 [n, P] -> f32 [n, P (+3) (+3)] as a view of a buffer with 16-byte rows."""
+    require_cuda(features, voxel_mean, inv, coors_bzyx)
+    f, fstride = _rows_view(features)
+    n, p = f.shape
+    width = p + (3 if with_cluster_center else 0) + (3 if with_voxel_center else 0)
+    stride = (width + 3) // 4 * 4
+    buf = torch.empty((n, stride), dtype=torch.float32, device=f.device)
+    vm, vstride = _rows_view(voxel_mean) if with_cluster_center else (None, 3)
+    inv = inv.to(torch.int64).contiguous() if with_cluster_center else None
+    coors = coors_bzyx.to(torch.int64).contiguous() if with_voxel_center else None
+    check(_L().fsf_vfe_decorate(c_p(f.data_ptr()) if n else c_p(None), n, int(fstride), p, ptr(vm), int(vstride), ptr(inv), ptr(coors),
+                                f32_array(voxel_size), f32_array(offset), int(bool(with_cluster_center)), int(bool(with_voxel_center)),
+                                ptr(buf), stride, stream_ptr()), "fsf_vfe_decorate")
+    return buf[:, :width]
 
 
 def vote_centers_keys(logits, offsets, points, batch_idx, g_ids, p_ids, num_classes, group_class_masks, group_voxel_sizes,

@@ -7,9 +7,12 @@ projects/mmdet3d_plugin/models/backbones/sir.py:41-61.  Restated from the publis
 Per call: ONE packed-key radix sort (unique_once), then every segmented mean/max and every "map back to the
 points" gather reuses that sort-once segment plan through the HIP library.
 """
+import os
+
 import torch
 import torch.nn as nn
 
+from .... import hip_ops
 from ...ops.sst_ops import (build_mlp, fused_norm_act, gather_by_inverse, get_activation_layer, linear_norm_act,
                             GroupedConcat, point_group_concat, point_linear, scatter_v2, unique_with_plan)
 from ...registry import VOXEL_ENCODERS, build_norm_layer
@@ -87,6 +90,21 @@ class DynamicScatterVFE(nn.Module):
             new_coors, unq_inv, _ = unique_with_plan(coors, cmin, cmax)
         else:
             new_coors = unq_inv = None
+        if (features.is_cuda and features.dtype == torch.float32 and not self._with_distance and features.size(1) >= 3
+                and (self._with_cluster_center or self._with_voxel_center)
+                and not (torch.is_grad_enabled() and features.requires_grad) and os.environ.get("FSF_VFE_DECORATE", "1") != "0"):
+            # inference: the decorated input in one pass (fsf_vfe_decorate) instead of a gather, a dozen elementwise launches and
+            # a cat; its rows are padded to 16 bytes, so the first layer's fused Linear reads them in place
+            voxel_mean = unq_inv_c = None
+            if self._with_cluster_center:
+                voxel_mean, _, unq_inv_c = scatter_v2(features, coors, mode="avg", unq_inv=unq_inv, new_coors=new_coors,
+                                                      short_segments=True)
+                if unq_inv is None:
+                    unq_inv, new_coors = unq_inv_c, _
+            features = hip_ops.vfe_decorate(features, voxel_mean, unq_inv_c, coors, (self.vx, self.vy, self.vz),
+                                            (self.x_offset, self.y_offset, self.z_offset), self._with_cluster_center,
+                                            self._with_voxel_center)
+            return self._vfe_stack(features, coors, unq_inv, new_coors, return_inv)
         features_ls = [features]
         if self._with_cluster_center:
             voxel_mean, mean_coors, unq_inv_c = scatter_v2(features, coors, mode="avg", unq_inv=unq_inv, new_coors=new_coors,
@@ -102,6 +120,9 @@ class DynamicScatterVFE(nn.Module):
         if self._with_distance:
             features_ls.append(torch.norm(features[:, :3], 2, 1, keepdim=True))
         features = torch.cat(features_ls, dim=-1)
+        return self._vfe_stack(features, coors, unq_inv, new_coors, return_inv)
+
+    def _vfe_stack(self, features, coors, unq_inv, new_coors, return_inv):
         for i, vfe in enumerate(self.vfe_layers):
             last = i == len(self.vfe_layers) - 1
             point_feats, voxel_feats, voxel_coors, unq_inv_l, cat = point_group_concat(

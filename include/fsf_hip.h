@@ -61,6 +61,15 @@ int fsf_voxelize_divfloor(const float* points, int64_t n, int32_t point_stride, 
                           const float range_min[3], int32_t order, const int64_t* batch_idx_in,
                           int64_t* coors, void* stream);
 
+/* DynamicScatterVFE's input decoration [UNVENDORED mmdet3d DynamicVFE.forward: with_cluster_center / with_voxel_center] in one
+ * pass: out[i] = [features[i, :p] | xyz - voxel_mean[inv[i], :3] | xyz - (coor * voxel_size + offset)] (x <- coors[:, 3],
+ * y <- coors[:, 2], z <- coors[:, 1]); out rows may be padded (out_stride >= width) so that the result feeds
+ * fsf_linear_norm_act in place.  features f32 [n, feat_stride >= p], voxel_mean f32 [m, vmean_stride >= 3], inv i64 [n],
+ * coors_bzyx i64 [n, 4]. */
+int fsf_vfe_decorate(const float* features, int64_t n, int32_t feat_stride, int32_t p, const float* voxel_mean, int32_t vmean_stride,
+                     const int64_t* inv, const int64_t* coors_bzyx, const float voxel_size[3], const float offset[3],
+                     int32_t with_cluster_center, int32_t with_voxel_center, float* out, int32_t out_stride, void* stream);
+
 /* Vote centres + cluster-voxel keys for every (class group, point) pair of the group-sampled foreground, one pass.
  * Replaces the per-group body of SingleStageFSD.group_sample (single_stage_fsd.py:802-865: arg-max-class weights over the
  * group's classes, ties within 1e-6 split evenly; centre = xyz + sum_c offsets[:, c] * w_c) and the key computation of
