@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import hip_ops
-from ...ops.sst_ops import build_mlp, gather_by_inverse, scatter_v2
+from ...ops.sst_ops import build_mlp, clear_unique_cache, gather_by_inverse, scatter_v2
 from ...core.bbox import bbox3d2result
 from ...registry import BBOX_CODERS, DETECTORS, build_head, build_roi_extractor
 from .single_stage_fsd import SingleStageFSD
@@ -456,6 +456,7 @@ class FSF(SingleStageFSD):
                                          run_head=False),
             lambda: self.fsd_forward(seg_out_dict, img_metas, run_head=False))
         self._gather_cache = None
+        clear_unique_cache()
         return dict(seg=seg_out_dict, frustum_obj_feats=f_feats, frustum_obj_centers=f_centers, frustum_obj_coors=f_coors,
                     frustum_preds_2d=f_preds_2d, fsd_obj_feats=l_feats, fsd_obj_centers=l_centers, fsd_obj_coors=l_coors)
 
@@ -550,6 +551,7 @@ class FSF(SingleStageFSD):
                                                  seg_out_dict["seg_feats"], seg_out_dict["batch_idx"], mask_data, mask_anno,
                                                  preds_2d, img_metas, obj_feats)
         self._gather_cache = None
+        clear_unique_cache()
         return bbox_list
 
     def simple_test(self, points, img_metas, mask_data, mask_anno, **kwargs):

@@ -54,14 +54,48 @@ class _GatherRows(torch.autograd.Function):
         return hip_ops.segment_reduce(grad_out.contiguous(), ctx.plan, "sum"), None
 
 
+import threading
+
+_UNIQUE_TLS = threading.local()  # .entries: (coors tensor, _version, bounds, result) of this thread's last few calls, newest last
+_UNIQUE_CACHE_SIZE = int(os.environ.get("FSF_UNIQUE_CACHE", "2"))
+
+
+def _unique_entries():
+    e = getattr(_UNIQUE_TLS, "entries", None)
+    if e is None:
+        e = _UNIQUE_TLS.entries = []
+    return e
+
+
 def unique_with_plan(coors, col_min=None, col_max=None):
     """torch.unique(coors, return_inverse=True, return_counts=True, dim=0) + the sort-once segment plan.
     The plan rides on the returned inverse tensor so that the `unq_inv=`/`new_coors=` path of scatter_v2
-    (used by unique_once VFE / SIR blocks) reuses it instead of sorting again."""
+    (used by unique_once VFE / SIR blocks) reuses it instead of sorting again.
+
+    The reference calls scatter_v2 on the SAME key tensor from different places without passing the inverse along
+    (SingleStageFSD.extract_feat takes the cluster means, then SIR.forward runs its own unique on `pts_cluster_inds`;
+    get_cluster_delta_weighted, then the frustum SIR on `sir_coors`): the result of the last calls is kept, keyed on the tensor
+    OBJECT and its version counter (the tensor is held, so its storage cannot be recycled under the key), at inference only."""
+    cache_ok = _UNIQUE_CACHE_SIZE > 0 and coors.is_cuda and not torch.is_grad_enabled()
+    key = (None if col_min is None else tuple(col_min), None if col_max is None else tuple(col_max))
+    if cache_ok:  # (per thread: the two query branches run on two host threads and streams)
+        for t, ver, k, res in reversed(_unique_entries()):
+            if t is coors and ver == coors._version and k == key:
+                return res
     new_coors, plan = hip_ops.unique_rows(coors, col_min=col_min, col_max=col_max)
     inv = plan.inv.detach()  # a second tensor object on the same storage: tensor -> plan -> tensor would be a cycle
     setattr(inv, _PLAN_ATTR, plan)
-    return new_coors, inv, plan.cnt
+    res = (new_coors, inv, plan.cnt)
+    if cache_ok:
+        entries = _unique_entries()
+        entries.append((coors, coors._version, key, res))
+        del entries[:-_UNIQUE_CACHE_SIZE]
+    return res
+
+
+def clear_unique_cache():
+    """Drop the cached uniques (and the key / result tensors they hold): the detector calls this at the end of a frame."""
+    del _unique_entries()[:]
 
 
 def plan_of(unq_inv, num_segments):
