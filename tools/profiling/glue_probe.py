@@ -1,6 +1,6 @@
 """Largest torch glue ops of a frame (cat / index_select / gather / boolean & long indexing): shapes, time, call sites."""
 import os, sys, torch, collections, traceback
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import bench
 dev = torch.device('cuda:0')
 model = bench.build_model(dev)

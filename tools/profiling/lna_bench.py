@@ -1,6 +1,6 @@
 """K22 fused Linear+LN+GELU vs the library GEMM + fsf_norm_act, at the SIR shapes."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from fullysparsefusion_amd import hip_ops as ops
 import torch.nn.functional as F
 dev = torch.device('cuda:0')

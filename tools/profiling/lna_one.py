@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 from fullysparsefusion_amd import hip_ops as ops
 dev = torch.device('cuda:0')
 n, k, c = 510652, 256, 128

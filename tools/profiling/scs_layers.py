@@ -1,6 +1,6 @@
 """Per-layer timing of the row-stationary split-bf16 conv (K9b) vs the fp32-pipe kernel on the frame's U-Net layers."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import bench
 from fullysparsefusion_amd import hip_ops
 dev = torch.device('cuda:0')

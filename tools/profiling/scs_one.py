@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import bench
 from fullysparsefusion_amd import hip_ops
 dev = torch.device('cuda:0')

@@ -1,6 +1,6 @@
 """Where do the host syncs (nonzero / item / boolean-mask indexing) of one frame come from?  (GPU box)"""
 import os, sys, torch, collections, traceback
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import bench
 dev = torch.device('cuda:0')
 model = bench.build_model(dev)
