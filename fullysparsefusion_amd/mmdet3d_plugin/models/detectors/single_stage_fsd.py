@@ -269,19 +269,40 @@ class SingleStageFSD(nn.Module):
             vox = torch.div(centers - rmin[None, :], vsize.index_select(0, g_ids), rounding_mode="floor").long()
             b_pts = batch_idx.index_select(0, p_ids).long()
             keys = torch.cat([(g_ids * bsz + b_pts)[:, None], vox], dim=1)
-        _, inv, cnt = unique_with_plan(keys)
-        valid = cnt[inv] >= ca.min_points
-        # valid pairs per group: the pairs are group-major, so a running count read at the group boundaries (an index_add_ of
-        # half a million rows into six counters is 120 us of same-address atomics)
-        csum = torch.cat([valid.new_zeros(1, dtype=torch.int64), valid.to(torch.int64).cumsum(0)])
-        bounds = torch.searchsorted(g_ids, torch.arange(ng + 1, device=dev))
-        has_valid = (csum[bounds[1:]] - csum[bounds[:-1]]) > 0
-        valid |= ~has_valid.index_select(0, g_ids)             # a group without any dense voxel keeps all its points (:953-954)
-        v_idx = valid.nonzero(as_tuple=False).squeeze(1)
-        g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
-        centers = centers.index_select(0, v_idx)
-        vox_centers, vox_keys, vox_inv = scatter_v2(centers, keys.index_select(0, v_idx), mode="avg", return_inv=True,
-                                                    short_segments=True)
+        new_keys, inv, cnt = unique_with_plan(keys)
+        if os.environ.get("FSF_CLUSTER_ONE_UNIQUE", "1") != "0":
+            # Whether a pair survives is a property of its voxel key (dense enough, or its whole group has no dense voxel, :953-954),
+            # so the voxels of the surviving pairs are a SUBSET of the unique just taken: their keys, the pair -> voxel map and the
+            # voxel means (same rows in the same order per voxel) follow from it — upstream runs a second unique on the survivors.
+            key_ok = cnt >= ca.min_points
+            key_group = torch.div(new_keys[:, 0], bsz, rounding_mode="floor")           # ascending: keys sort by (group, batch) first
+            kcs = torch.cat([key_ok.new_zeros(1, dtype=torch.int64), key_ok.to(torch.int64).cumsum(0)])
+            kb = torch.searchsorted(key_group, torch.arange(ng + 1, device=dev))
+            has_valid = (kcs[kb[1:]] - kcs[kb[:-1]]) > 0
+            key_keep = key_ok | ~has_valid.index_select(0, key_group)
+            valid = key_keep.index_select(0, inv)
+            v_idx = valid.nonzero(as_tuple=False).squeeze(1)
+            k_idx = key_keep.nonzero(as_tuple=False).squeeze(1)
+            remap = key_keep.to(torch.int64).cumsum(0) - 1
+            all_means, _, _ = scatter_v2(centers, keys, mode="avg", return_inv=True, unq_inv=inv, new_coors=new_keys,
+                                         short_segments=True)
+            vox_centers, vox_keys = all_means.index_select(0, k_idx), new_keys.index_select(0, k_idx)
+            vox_inv = remap.index_select(0, inv.index_select(0, v_idx))
+            g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
+            centers = centers.index_select(0, v_idx)
+        else:
+            valid = cnt[inv] >= ca.min_points
+            # valid pairs per group: the pairs are group-major, so a running count read at the group boundaries (an index_add_ of
+            # half a million rows into six counters is 120 us of same-address atomics)
+            csum = torch.cat([valid.new_zeros(1, dtype=torch.int64), valid.to(torch.int64).cumsum(0)])
+            bounds = torch.searchsorted(g_ids, torch.arange(ng + 1, device=dev))
+            has_valid = (csum[bounds[1:]] - csum[bounds[:-1]]) > 0
+            valid |= ~has_valid.index_select(0, g_ids)             # a group without any dense voxel keeps all its points (:953-954)
+            v_idx = valid.nonzero(as_tuple=False).squeeze(1)
+            g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
+            centers = centers.index_select(0, v_idx)
+            vox_centers, vox_keys, vox_inv = scatter_v2(centers, keys.index_select(0, v_idx), mode="avg", return_inv=True,
+                                                        short_segments=True)
         vox_group = torch.div(vox_keys[:, 0], bsz, rounding_mode="floor")
         dist = const("connected_dist", lambda: torch.tensor([ca._per_class(ca.connected_dist, n) for n in ca.class_names[:ng]],
                                                             dtype=torch.float32))
