@@ -18,7 +18,13 @@ constexpr int SI_MAX_H2 = 32;
 
 struct SirInputArgs {
   const float* points; int64_t points_stride; int p_cols;
-  const float* feats;  int64_t feats_stride;  int f_cols;
+  const float* feats;  int64_t feats_stride;  int f_cols;   // f_cols = all feature columns (the sum over the parts below)
+  // the feature columns may come from up to three tensors side by side (parts 1, 2 follow part 0), and their rows may be taken
+  // through an index (row i of the layer input = row feats_index[i] of every part): the gather of the group-sampled points and
+  // the [n, 11 + 33 + 131] concat the reference materialises before its first SIR layer happen in this kernel's loads
+  const float* feats1; int64_t feats1_stride; int f0_cols, f1_cols;
+  const float* feats2; int64_t feats2_stride;
+  const int64_t* feats_index;
   const float* extra;  int64_t extra_stride;  int e_cols; float extra_div;
   const float* fcl;    int64_t fcl_stride;    int r_cols; float rel_div;
   float norm[3];
@@ -114,9 +120,11 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
   const float* xsrc[T];
   int64_t xstride[T];
   float xdiv[T];
+  bool xgath[T];  // this lane's column of tile t is read through feats_index
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const int c = lane + 64 * t;
+    xgath[t] = false;
     xsrc[t] = a.points;  // (columns >= c read a valid address and are never stored)
     xstride[t] = a.points_stride;
     xdiv[t] = 1.0f;
@@ -124,8 +132,18 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
       xsrc[t] = a.points + c;
       if (c < 3) xdiv[t] = a.norm[c];
     } else if (c < a.p_cols + a.f_cols) {
-      xsrc[t] = a.feats + (c - a.p_cols);
-      xstride[t] = a.feats_stride;
+      const int fc = c - a.p_cols;
+      if (fc < a.f0_cols) {
+        xsrc[t] = a.feats + fc;
+        xstride[t] = a.feats_stride;
+      } else if (fc < a.f0_cols + a.f1_cols) {
+        xsrc[t] = a.feats1 + (fc - a.f0_cols);
+        xstride[t] = a.feats1_stride;
+      } else {
+        xsrc[t] = a.feats2 + (fc - a.f0_cols - a.f1_cols);
+        xstride[t] = a.feats2_stride;
+      }
+      xgath[t] = a.feats_index != nullptr;
     } else if (c < a.c) {
       xsrc[t] = a.extra + (c - a.p_cols - a.f_cols);
       xstride[t] = a.extra_stride;
@@ -146,9 +164,20 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = 4 * grp + r < a.r_cols ? a.fcl[rc * a.fcl_stride + 4 * grp + r] : 0.0f;
   };
+  // the group's feature-row indices, lane (row, .) holds its row's: requested one group ahead like the MLP input
+  auto load_idx = [&](int64_t gi) -> int {
+    if (!a.feats_index) return 0;
+    const int64_t r0 = gi * 16;
+    const int nr = (int)min((int64_t)16, a.n - r0);
+    return (int)a.feats_index[r0 + (rowl < nr ? rowl : nr - 1)];
+  };
   const int64_t gstep = (int64_t)gridDim.x * 4;
   float xnext[4] = {0.f, 0.f, 0.f, 0.f};
-  if ((int64_t)blockIdx.x * 4 + wave < groups) load_fcl((int64_t)blockIdx.x * 4 + wave, xnext);
+  int inext = 0;
+  if ((int64_t)blockIdx.x * 4 + wave < groups) {
+    load_fcl((int64_t)blockIdx.x * 4 + wave, xnext);
+    inext = load_idx((int64_t)blockIdx.x * 4 + wave);
+  }
   for (int64_t gi = (int64_t)blockIdx.x * 4 + wave; gi < groups; gi += gstep) {
     const int64_t row0 = gi * 16;
     const int nrow = (int)min((int64_t)16, a.n - row0);
@@ -159,9 +188,21 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
     float xin[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) xin[r] = xnext[r];
-    if (gi + gstep < groups) load_fcl(gi + gstep, xnext);
+    const int icur = inext;
+    if (gi + gstep < groups) {
+      load_fcl(gi + gstep, xnext);
+      inext = load_idx(gi + gstep);
+    }
     float x[16][T];
-    {
+    if (a.feats_index) {  // (wave-uniform) gathered feature rows: row i of the group reads row readlane(icur, i) of the feature parts
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t ri = (int64_t)__builtin_amdgcn_readlane(icur, i);   // (rows past n repeat the last one: see load_idx)
+        const int64_t rr = row0 + (i < nrow ? i : nrow - 1);
+#pragma unroll
+        for (int t = 0; t < T; ++t) x[i][t] = xsrc[t][(xgath[t] ? ri : rr) * xstride[t]];
+      }
+    } else {
       const float* rp[T];  // row pointers walk down the group: one 64-bit add per load instead of a 64-bit multiply
 #pragma unroll
       for (int t = 0; t < T; ++t) rp[t] = xsrc[t] + row0 * xstride[t];
@@ -295,6 +336,15 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
 
 using namespace fsf;
 
+extern "C" int fsf_sir_input_gather(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3],
+                                    const float* const* feat_parts, const int64_t* feat_strides, const int32_t* feat_cols,
+                                    int32_t num_parts, const int64_t* feats_index, const float* extra, int64_t extra_stride,
+                                    int32_t e_cols, float extra_div, const float* f_cluster, int64_t f_cluster_stride,
+                                    int32_t r_cols, float rel_div, const float* w1, const float* g1, const float* b1, int32_t h1,
+                                    const float* w2, const float* g2, const float* b2, int32_t h2, const float* w3,
+                                    const float* g3, const float* b3, float eps, int32_t act, int64_t n, float* out,
+                                    int64_t out_stride, void* stream_);
+
 extern "C" int fsf_sir_input(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3],
                              const float* feats, int64_t feats_stride, int32_t f_cols, const float* extra,
                              int64_t extra_stride, int32_t e_cols, float extra_div, const float* f_cluster,
@@ -302,6 +352,30 @@ extern "C" int fsf_sir_input(const float* points, int64_t points_stride, int32_t
                              const float* b1, int32_t h1, const float* w2, const float* g2, const float* b2, int32_t h2,
                              const float* w3, const float* g3, const float* b3, float eps, int32_t act, int64_t n,
                              float* out, int64_t out_stride, void* stream_) {
+  const float* parts[1] = {feats};
+  const int64_t strides[1] = {feats_stride};
+  const int32_t cols[1] = {f_cols};
+  return fsf_sir_input_gather(points, points_stride, p_cols, xyz_normalizer, parts, strides, cols, f_cols > 0 ? 1 : 0, nullptr, extra,
+                              extra_stride, e_cols, extra_div, f_cluster, f_cluster_stride, r_cols, rel_div, w1, g1, b1, h1, w2, g2,
+                              b2, h2, w3, g3, b3, eps, act, n, out, out_stride, stream_);
+}
+
+extern "C" int fsf_sir_input_gather(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3],
+                                    const float* const* feat_parts, const int64_t* feat_strides, const int32_t* feat_cols,
+                                    int32_t num_parts, const int64_t* feats_index, const float* extra, int64_t extra_stride,
+                                    int32_t e_cols, float extra_div, const float* f_cluster, int64_t f_cluster_stride,
+                                    int32_t r_cols, float rel_div, const float* w1, const float* g1, const float* b1, int32_t h1,
+                                    const float* w2, const float* g2, const float* b2, int32_t h2, const float* w3,
+                                    const float* g3, const float* b3, float eps, int32_t act, int64_t n, float* out,
+                                    int64_t out_stride, void* stream_) {
+  if (num_parts < 0 || num_parts > 3 || (num_parts > 0 && (!feat_parts || !feat_strides || !feat_cols))) return FSF_ERR_INVALID_ARG;
+  int32_t f_cols = 0;
+  for (int i = 0; i < num_parts; ++i) {
+    if (feat_cols[i] < 1 || feat_strides[i] < feat_cols[i] || (n > 0 && !feat_parts[i])) return FSF_ERR_INVALID_ARG;
+    f_cols += feat_cols[i];
+  }
+  const float* feats = num_parts > 0 ? feat_parts[0] : nullptr;
+  const int64_t feats_stride = num_parts > 0 ? feat_strides[0] : 0;
   hipStream_t stream = (hipStream_t)stream_;
   const int c = p_cols + f_cols + e_cols;
   if (n < 0 || p_cols < 3 || f_cols < 0 || e_cols < 0 || r_cols < 1 || h1 < 1 || h2 < 1 || act < 0 || act > 2 ||
@@ -315,6 +389,11 @@ extern "C" int fsf_sir_input(const float* points, int64_t points_stride, int32_t
   SirInputArgs a;
   a.points = points; a.points_stride = points_stride; a.p_cols = p_cols;
   a.feats = feats; a.feats_stride = feats_stride; a.f_cols = f_cols;
+  a.f0_cols = num_parts > 0 ? feat_cols[0] : 0;
+  a.feats1 = num_parts > 1 ? feat_parts[1] : nullptr; a.feats1_stride = num_parts > 1 ? feat_strides[1] : 0;
+  a.f1_cols = num_parts > 1 ? feat_cols[1] : 0;
+  a.feats2 = num_parts > 2 ? feat_parts[2] : nullptr; a.feats2_stride = num_parts > 2 ? feat_strides[2] : 0;
+  a.feats_index = num_parts > 0 ? feats_index : nullptr;
   a.extra = extra; a.extra_stride = extra_stride; a.e_cols = e_cols; a.extra_div = extra_div;
   a.fcl = f_cluster; a.fcl_stride = f_cluster_stride; a.r_cols = r_cols; a.rel_div = rel_div;
   for (int i = 0; i < 3; ++i) a.norm[i] = xyz_normalizer[i];

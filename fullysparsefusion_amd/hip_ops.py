@@ -57,6 +57,8 @@ _ARGTYPES = {
     "fsf_norm_act_backward_workspace_bytes": [c_i32],
     "fsf_norm_act_backward": [_P, _P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_row_topk_desc": [_P, c_i64, c_i32, c_i32, _P, _P],
+    "fsf_sir_input_gather": [_P, c_i64, c_i32, _P, _P, _P, _P, c_i32, _P, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
+                             _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
     "fsf_sir_input": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
                       _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
     "fsf_spconv_split_weight_bytes": [c_i32, c_i32, c_i32],
@@ -737,27 +739,41 @@ def row_topk_desc(x: torch.Tensor, k: int):
 
 
 # ------------------------------------------------------------------------------------- SIR-layer input
-def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_div: float, extra=None, extra_div: float = 1.0):
-    """fsf_sir_input: cat(points / normalizer, feats[, extra / extra_div]) * rel_mlp(f_cluster / rel_div) -> f32 [n, C].
-    `layers` = three (linear_weight, ln_weight, ln_bias) triples of the position MLP; one eps (taken by the caller)."""
-    require_cuda(points, feats, f_cluster, extra)
+def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_div: float, extra=None, extra_div: float = 1.0,
+              feats_index=None):
+    """fsf_sir_input[_gather]: cat(points / normalizer, feats[, extra / extra_div]) * rel_mlp(f_cluster / rel_div) -> f32 [n, C].
+    `layers` = three (linear_weight, ln_weight, ln_bias) triples of the position MLP; one eps (taken by the caller).
+    `feats` may be a list of up to three tensors standing side by side, and with `feats_index` (i64 [n]) row i of the input takes row
+    feats_index[i] of every part — the gather and the concat happen in the kernel's loads."""
+    parts = list(feats) if isinstance(feats, (list, tuple)) else [feats]
+    require_cuda(points, f_cluster, extra, feats_index, *parts)
     n = points.size(0)
     (w1, g1, b1), (w2, g2, b2), (w3, g3, b3), eps = layers
-    c = points.size(1) + feats.size(1) + (extra.size(1) if extra is not None else 0)
+    fcols = sum(t.size(1) for t in parts)
+    c = points.size(1) + fcols + (extra.size(1) if extra is not None else 0)
     assert w3.size(0) == c and w1.size(1) == f_cluster.size(1) and w2.size(1) == w1.size(0) and w3.size(1) == w2.size(0)
-    for t in (points, feats, f_cluster, extra):
+    for t in [points, f_cluster, extra] + parts:
         assert t is None or (t.dtype == torch.float32 and t.dim() == 2 and (t.size(0) == 0 or t.stride(1) == 1))
+    assert 1 <= len(parts) <= 3 and (feats_index is not None or all(t.size(0) == n for t in parts))
+    if feats_index is not None:
+        feats_index = feats_index.to(torch.int64).contiguous()
+        assert feats_index.numel() == n
     cpad = (c + 3) // 4 * 4  # rows start 16-byte aligned: the consumer is the fused Linear kernel (K22)
     out_full = torch.empty((n, cpad), dtype=torch.float32, device=points.device)
     out = out_full[:, :c]
     rp = lambda t: c_p(t.data_ptr()) if t is not None and t.numel() else c_p(None)  # noqa: E731  row-strided views pass as is
     st = lambda t: t.stride(0) if t is not None and t.size(0) > 1 else (t.size(1) if t is not None else 0)  # noqa: E731
-    check(_L().fsf_sir_input(rp(points), st(points), points.size(1), f32_array(xyz_normalizer), rp(feats), st(feats),
-                             feats.size(1), rp(extra), st(extra), extra.size(1) if extra is not None else 0, float(extra_div),
-                             rp(f_cluster), st(f_cluster), f_cluster.size(1), float(rel_div),
-                             ptr(w1.contiguous()), ptr(g1), ptr(b1), w1.size(0), ptr(w2.contiguous()), ptr(g2), ptr(b2), w2.size(0),
-                             ptr(w3.contiguous()), ptr(g3), ptr(b3), float(eps), {"none": 0, "relu": 1, "gelu": 2}[act], n,
-                             ptr(out_full), cpad, stream_ptr()), "fsf_sir_input")
+    k = len(parts)
+    fp = (ctypes.c_void_p * k)(*[t.data_ptr() if t.numel() else None for t in parts])
+    fs = (ctypes.c_int64 * k)(*[int(st(t)) for t in parts])
+    fc = (ctypes.c_int32 * k)(*[int(t.size(1)) for t in parts])
+    check(_L().fsf_sir_input_gather(rp(points), st(points), points.size(1), f32_array(xyz_normalizer), fp, fs, fc, k, ptr(feats_index),
+                                    rp(extra), st(extra), extra.size(1) if extra is not None else 0, float(extra_div),
+                                    rp(f_cluster), st(f_cluster), f_cluster.size(1), float(rel_div),
+                                    ptr(w1.contiguous()), ptr(g1), ptr(b1), w1.size(0), ptr(w2.contiguous()), ptr(g2), ptr(b2),
+                                    w2.size(0), ptr(w3.contiguous()), ptr(g3), ptr(b3), float(eps),
+                                    {"none": 0, "relu": 1, "gelu": 2}[act], n, ptr(out_full), cpad, stream_ptr()),
+          "fsf_sir_input_gather")
     return out
 
 

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .... import hip_ops
-from ...ops.sst_ops import gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, unique_with_plan
+from ...ops.sst_ops import GatheredRows, gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, unique_with_plan
 from ...ops.voxel import Voxelization
 from ...registry import (DETECTORS, SEGMENTORS, build_backbone, build_detector, build_head, build_middle_encoder,
                          build_neck, build_voxel_encoder)
@@ -318,17 +318,13 @@ class SingleStageFSD(nn.Module):
             return t.index_select(0, p_ids)
 
         parts = [seg_logits, d["seg_vote_preds"], d["seg_feats"]]
-        if all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 for t in parts):
-            # the caller concatenates the three (FSF.py fsd_forward): gather them straight into one [n, 11 + 33 + 131]
-            # buffer — the rows are written once instead of gathered and then copied again by torch.cat
-            widths = [t.size(1) for t in parts]
-            buf = torch.empty((p_ids.numel(), sum(widths)), dtype=torch.float32, device=dev)
-            views, c0 = [], 0
-            for t, w in zip(parts, widths):
-                views.append(hip_ops.gather_rows(t, p_ids, out=buf[:, c0:c0 + w]))
-                c0 += w
-            self._grouped_feats_concat = buf
-            return take(d["seg_points"]), views[0], views[1], views[2], centers, pts_cluster_inds
+        if all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 for t in parts):
+            # the caller concatenates the three (FSF.py fsd_forward) and hands the result to the first SIR layer only: the rows stay
+            # where they are, the layer's input kernel reads them through `p_ids` side by side (sst_ops.GatheredRows; materialised —
+            # gathered straight into one [n, 11 + 33 + 131] buffer — by anything else that wants the matrix)
+            lazy = GatheredRows(parts, p_ids)
+            self._grouped_feats_concat = lazy if os.environ.get("FSF_SIR_GATHER", "1") != "0" else lazy.materialize()
+            return take(d["seg_points"]), None, None, None, centers, pts_cluster_inds
         self._grouped_feats_concat = None
         return (take(d["seg_points"]), take(seg_logits), take(d["seg_vote_preds"]), take(d["seg_feats"]), centers,
                 pts_cluster_inds)

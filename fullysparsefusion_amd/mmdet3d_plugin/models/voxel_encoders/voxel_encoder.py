@@ -14,7 +14,7 @@ import torch.nn as nn
 
 from .... import hip_ops
 from ...ops.sst_ops import (build_mlp, fused_norm_act, gather_by_inverse, get_activation_layer, linear_norm_act,
-                            GroupedConcat, point_group_concat, point_linear, scatter_v2, unique_with_plan)
+                            GatheredRows, GroupedConcat, point_group_concat, point_linear, scatter_v2, unique_with_plan)
 from ...registry import VOXEL_ENCODERS, build_norm_layer
 
 
@@ -196,14 +196,19 @@ class SIRLayer(nn.Module):
                                                   any(p.requires_grad for p in self.parameters()))
         if not needs_grad and feats.is_cuda and feats.dtype == torch.float32 and feats.size(0) > 0:
             fused = self._fused_input_layers()
+        gathered = isinstance(feats, GatheredRows)
+        if gathered and (fused is None or len(feats.sources) > 3):
+            feats, gathered = feats.materialize(), False
         if fused is None:
             parts = [points, feats] + ([extra / extra_div] if extra is not None else [])
             return self.forward(torch.cat(parts, 1), coors, f_cluster, **kwargs)
-        from .... import hip_ops
-
         layers, eps, act = fused
-        features = hip_ops.sir_input(points, feats, f_cluster, self.xyz_normalizer, (*layers, eps), act, self.rel_dist_scaler,
-                                     extra=extra, extra_div=extra_div)
+        if gathered:  # rows of the source tensors through the sampling index, parts side by side: no gather, no concat
+            features = hip_ops.sir_input(points, feats.sources, f_cluster, self.xyz_normalizer, (*layers, eps), act,
+                                         self.rel_dist_scaler, extra=extra, extra_div=extra_div, feats_index=feats.index)
+        else:
+            features = hip_ops.sir_input(points, feats, f_cluster, self.xyz_normalizer, (*layers, eps), act, self.rel_dist_scaler,
+                                         extra=extra, extra_div=extra_div)
         return self._run_vfe(features, coors, **kwargs)
 
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None, return_both=False,

@@ -143,6 +143,38 @@ class GroupedConcat:
         return buf
 
 
+class GatheredRows:
+    """`torch.cat([t.index_select(0, index) for t in sources], 1)` kept as its parts (inference).  The only consumer of the
+    group-sampled points' features is the first SIR layer's input kernel, which reads rows through an index and several
+    tensors side by side (fsf_sir_input_gather): the [n_pairs, 11 + 33 + 131] matrix is never written."""
+
+    def __init__(self, sources, index):
+        self.sources, self.index = list(sources), index
+
+    @property
+    def shape(self):
+        return (self.index.numel(), sum(t.size(1) for t in self.sources))
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def __len__(self):
+        return self.index.numel()
+
+    is_cuda = property(lambda self: self.sources[0].is_cuda)
+    dtype = property(lambda self: self.sources[0].dtype)
+    requires_grad = property(lambda self: any(t.requires_grad for t in self.sources))
+
+    def materialize(self):
+        n, widths = self.index.numel(), [t.size(1) for t in self.sources]
+        buf = torch.empty((n, sum(widths)), dtype=self.sources[0].dtype, device=self.sources[0].device)
+        c0 = 0
+        for t, w in zip(self.sources, widths):
+            hip_ops.gather_rows(t, self.index, out=buf[:, c0:c0 + w])
+            c0 += w
+        return buf
+
+
 def _grouped_linear_norm_act(linear, norm, act, gc):
     """act(norm(linear(cat))) for a GroupedConcat through fsf_linear_norm_act_grouped; None when the layer is not covered."""
     p, g, inv = gc.point_feats, gc.group_feats, gc.inv

@@ -121,7 +121,7 @@ def test_hot_path_10sweep_vs_oracle(fsf_pair, frame10, device):
         fsir_fwd = model.frustum_sir.forward
 
         def fcapture(points, features, coors, f_cluster=None):
-            fcap["in"] = (points, features, coors, f_cluster)
+            fcap["in"] = (points, features.materialize() if hasattr(features, "materialize") else features, coors, f_cluster)
             fcap["out"] = fsir_fwd(points, features, coors, f_cluster=f_cluster)
             return fcap["out"]
 
@@ -135,7 +135,7 @@ def test_hot_path_10sweep_vs_oracle(fsf_pair, frame10, device):
         sir_fwd = model.backbone.forward
 
         def capture(points, features, coors, f_cluster=None):
-            cap["in"] = (points, features, coors, f_cluster)
+            cap["in"] = (points, features.materialize() if hasattr(features, "materialize") else features, coors, f_cluster)
             return sir_fwd(points, features, coors, f_cluster)
 
         model.backbone.forward = capture

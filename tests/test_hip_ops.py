@@ -1519,6 +1519,34 @@ def test_round2_entry_points_on_empty_and_tiny_inputs(ops, device):
     assert num.tolist() == [0, 0] and int(flag) == 0
 
 
+@pytest.mark.parametrize("n,act", [(50003, "gelu"), (17, "relu")])
+def test_sir_input_gathered_parts_equal_materialised_rows(ops, device, n, act):
+    """fsf_sir_input_gather: three feature tensors side by side, rows through an index == the same kernel on the gathered and
+    concatenated [n, 11 + 33 + 131] matrix, bit for bit (strided part views included)."""
+    torch.manual_seed(n)
+    P = 30000
+    both = torch.randn(P, 44, device=device)
+    logits, votes = both[:, :11], both[:, 11:]
+    wide = torch.randn(P, 132, device=device)
+    feats = wide[:, :131]
+    idx = torch.randint(0, P, (n,), device=device)
+    points = torch.randn(n, 5, device=device)
+    fcl = torch.randn(n, 3, device=device)
+    c = 5 + 175
+    dims = [3, 16, 32, c]
+    layers = []
+    for i in range(3):
+        layers.append((torch.randn(dims[i + 1], dims[i], device=device) / dims[i] ** 0.5,
+                       torch.rand(dims[i + 1], device=device) + 0.5, torch.randn(dims[i + 1], device=device) * 0.1))
+    norm = [20.0, 20.0, 4.0]
+    mat = torch.cat([logits[idx], votes[idx], feats[idx]], 1).contiguous()
+    want = ops.sir_input(points, mat, fcl, norm, (*layers, 1e-3), act, 10.0)
+    got = ops.sir_input(points, [logits, votes, feats], fcl, norm, (*layers, 1e-3), act, 10.0, feats_index=idx)
+    assert torch.equal(got, want)
+    got2 = ops.sir_input(points, [mat[:, :11].contiguous(), mat[:, 11:]], fcl, norm, (*layers, 1e-3), act, 10.0)  # parts, no index
+    assert torch.equal(got2, want)
+
+
 def test_column_stats_and_batch_norm_edge_cases(ops, device):
     """K23 with no rows: sums / statistics / gradients are zeros, nothing is launched on empty inputs; a single row."""
     x0 = torch.empty(0, 12, device=device)

@@ -386,7 +386,7 @@ def test_fsf_hot_path_vs_oracle(fsf_pair, frame1, device):
         sir_fwd = model.backbone.forward
 
         def capture(points, features, coors, f_cluster=None):
-            cap["in"] = (points, features, coors, f_cluster)
+            cap["in"] = (points, features.materialize() if hasattr(features, "materialize") else features, coors, f_cluster)
             return sir_fwd(points, features, coors, f_cluster)
 
         model.backbone.forward = capture
