@@ -17,12 +17,14 @@ Same method names and return conventions.  What changes underneath:
 `simple_test` = stages 1-3, query combination, the refine stage (K17 point pooling + SIR layers) and box decoding with
 BEV NMS (K20); `forward_hot_path` stops after the three query-generation stages (what bench.py's headline times).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import hip_ops
-from ...ops.sst_ops import build_mlp, clear_unique_cache, gather_by_inverse, scatter_v2
+from ...ops.sst_ops import GatheredRows, build_mlp, clear_unique_cache, gather_by_inverse, scatter_v2
 from ...core.bbox import bbox3d2result
 from ...registry import BBOX_CODERS, DETECTORS, build_head, build_roi_extractor
 from .single_stage_fsd import SingleStageFSD
@@ -196,9 +198,16 @@ class FSF(SingleStageFSD):
 
     def frustum_pooling(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights, img_metas=None,
                         cluster_center=None, fg_idx=None):
+        lazy_src = None
         if fg_idx is not None:  # `obj_id_tensor` already holds the rows of the foreground points `fg_idx` (ascending)
-            pts_feat, bz_coor, points, point_fg_weights = (t.index_select(0, fg_idx) for t in (pts_feat, bz_coor, points,
-                                                                                              point_fg_weights))
+            if (pts_feat.is_cuda and pts_feat.dtype == torch.float32 and pts_feat.stride(1) == 1 and not torch.is_grad_enabled()
+                    and os.environ.get("FSF_SIR_GATHER", "1") != "0"):
+                # the 131-wide point features are not gathered here: their row INDEX travels through the selection / duplication
+                # steps in their place, and the first SIR layer's input kernel reads the rows through it (sst_ops.GatheredRows)
+                lazy_src, pts_feat = pts_feat, fg_idx.unsqueeze(1)
+            else:
+                pts_feat = pts_feat.index_select(0, fg_idx)
+            bz_coor, points, point_fg_weights = (t.index_select(0, fg_idx) for t in (bz_coor, points, point_fg_weights))
         else:
             pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights = self.extract_fg_pts(
                 pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights)
@@ -207,7 +216,10 @@ class FSF(SingleStageFSD):
         if obj_id_tensor.numel() == 0:
             fake_num = 1  # fake an object when the frustum branch has no output (:407-414)
             points = points.new_zeros(fake_num, points.shape[-1])
-            pts_feat = pts_feat.new_zeros(fake_num, pts_feat.shape[-1])
+            if lazy_src is not None:
+                pts_feat, lazy_src = lazy_src.new_zeros(fake_num, lazy_src.shape[-1]), None
+            else:
+                pts_feat = pts_feat.new_zeros(fake_num, pts_feat.shape[-1])
             sir_coors = bz_coor.new_zeros(fake_num, 3)
             points_delta = points.new_zeros(fake_num, 3)
             cluster_center = points.new_zeros(fake_num, 3)
@@ -220,6 +232,8 @@ class FSF(SingleStageFSD):
                                                                                   point_fg_weights.unsqueeze(-1))
             else:
                 points_delta = self.get_cluster_delta_from_center(points, sir_coors, cluster_center)
+        if lazy_src is not None:
+            pts_feat = GatheredRows([lazy_src], pts_feat.squeeze(1))
         out_feats, final_cluster_feats, out_coors = self.frustum_sir(points, pts_feat, sir_coors, f_cluster=points_delta)
         if out_coors.shape[0] == 0:
             out_coors = out_coors.new_zeros((0, 3))
