@@ -285,7 +285,8 @@ def _acc_sir_input(a, k, out):
     points, feats, f_cluster = a[0], a[1], a[2]
     extra = k.get("extra", a[7] if len(a) > 7 else None)
     n = points.size(0)
-    c = points.size(1) + feats.size(1) + (extra.size(1) if extra is not None else 0)
+    fcols = sum(t.size(1) for t in feats) if isinstance(feats, (list, tuple)) else feats.size(1)  # (parts read through an index)
+    c = points.size(1) + fcols + (extra.size(1) if extra is not None else 0)
     return "sir_input", n * 4.0 * (c + f_cluster.size(1)) + n * 4.0 * c, 0.0   # 4(P+Cf+Ce+R) read + 4C written per row
 
 
