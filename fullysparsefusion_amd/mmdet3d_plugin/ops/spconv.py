@@ -80,21 +80,38 @@ class Rulebook:
         return self._pairs[inverse]
 
 
+def _plane_srcs(feat):
+    """fp32 rows -> K9c plane sources (<= 128 channels each; a wider tensor is the concatenation of its two halves)."""
+    c = feat.size(1)
+    if c <= 128:
+        return [hip_ops.to_planes(feat)]
+    return [hip_ops.to_planes(feat[:, :c // 2]), hip_ops.to_planes(feat[:, c // 2:])]
+
+
+def _planes_shape_ok(cin, cout, kvol, rows):
+    cins = [cin] if cin <= 128 else [cin // 2, cin - cin // 2]
+    return rows >= SparseConvolution.PLANES_MIN_ROWS and hip_ops.spconv_planes_supported(cins, cout, kvol)
+
+
 class _SparseConvFn(torch.autograd.Function):
     """out = sum_k feat[table[:, k]] @ W[k] with the K10 backward: data gradient = the same fused kernel over the
     transposed table, weight gradient = fsf_spconv_backward_weight over the pair lists.  `split` picks the
-    row-stationary split-bf16 kernel (K9b, fp32-accurate) for the forward and the data gradient, as in inference."""
+    row-stationary split-bf16 kernel (K9b, fp32-accurate) for the forward and the data gradient, as in inference;
+    `planes` the f16-plane kernel (K9c) wherever the direction's shape is one it takes (the operand — features forward,
+    grad_out backward — is converted by fsf_to_planes, the weights of the step by fsf_spconv_prepare_weight_planes)."""
 
     @staticmethod
-    def forward(ctx, feat, weight, rb, inverse, split):
+    def forward(ctx, feat, weight, rb, inverse, split, planes=False):
         kvol = rb.nbr.size(1)
         w = weight.detach().reshape(kvol, weight.shape[-2], weight.shape[-1])
-        ctx.rb, ctx.inverse, ctx.split = rb, inverse, split
+        ctx.rb, ctx.inverse, ctx.split, ctx.planes = rb, inverse, split, planes
         ctx.save_for_backward(feat, weight)
+        table = rb.table(inverse)
+        if planes and feat.size(0) > 0 and _planes_shape_ok(w.size(1), w.size(2), kvol, table.size(0)):
+            return hip_ops.spconv_forward_planes(_plane_srcs(feat), hip_ops.spconv_prepare_weight_planes(w), kvol, w.size(2), table)[0]
         if split and feat.size(0) > 0:
-            return hip_ops.spconv_forward_split(feat, hip_ops.spconv_prepare_weight_split(w), kvol, w.size(2),
-                                                rb.table(inverse))
-        return hip_ops.spconv_forward(feat, hip_ops.spconv_transpose_weight(w), rb.table(inverse))
+            return hip_ops.spconv_forward_split(feat, hip_ops.spconv_prepare_weight_split(w), kvol, w.size(2), table)
+        return hip_ops.spconv_forward(feat, hip_ops.spconv_transpose_weight(w), table)
 
     @staticmethod
     def backward(ctx, grad):
@@ -107,7 +124,11 @@ class _SparseConvFn(torch.autograd.Function):
             table_t, flip = rb.table_transposed(inverse)
             w = weight.detach().reshape(kvol, weight.shape[-2], weight.shape[-1])
             w = w.flip(0) if flip else w
-            if ctx.split and grad.size(0) > 0 and feat.size(0) > 0:
+            if (ctx.planes and grad.size(0) > 0 and feat.size(0) > 0
+                    and _planes_shape_ok(w.size(2), w.size(1), kvol, table_t.size(0))):
+                wt = hip_ops.spconv_prepare_weight_planes(w.transpose(1, 2).contiguous())
+                g_feat = hip_ops.spconv_forward_planes(_plane_srcs(grad), wt, kvol, w.size(1), table_t)[0]
+            elif ctx.split and grad.size(0) > 0 and feat.size(0) > 0:
                 planes = hip_ops.spconv_prepare_weight_split(w.transpose(1, 2).contiguous())
                 g_feat = hip_ops.spconv_forward_split(grad, planes, kvol, w.size(1), table_t)
             else:
@@ -115,7 +136,7 @@ class _SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             pairs, num = rb.pairs(inverse)
             g_w = hip_ops.spconv_backward_weight(feat, grad, pairs, num).reshape(weight.shape)
-        return g_feat, g_w, None, None, None
+        return g_feat, g_w, None, None, None, None
 
 
 def _to3(v):
@@ -264,7 +285,8 @@ class SparseConvolution(SparseModule):
         feat = x.features
         needs_grad = torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad)
         if needs_grad:  # training: the epilogue stays in autograd-visible torch ops
-            out = _SparseConvFn.apply(feat, self.weight, rb, self.inverse, self._use_split_kernel_training())
+            out = _SparseConvFn.apply(feat, self.weight, rb, self.inverse, self._use_split_kernel_training(),
+                                      os.environ.get("FSF_TRAIN_PLANES", "1") != "0" and os.environ.get("FSF_PLANES", "1") != "0")
             if scale is not None:
                 out = out * scale
             if shift is not None:

@@ -722,6 +722,64 @@ def test_spconv_backward_vs_oracle_autograd(ops, device, kind, cin, cout):
     assert torch.equal(g_w, ops.spconv_backward_weight(feat.detach().to(device), gout.to(device), ip, num))  # deterministic
 
 
+@pytest.mark.parametrize("cin,cmid,cout", [(128, 128, 128), (64, 128, 64), (256, 128, 128)])
+def test_conv_modules_training_on_the_plane_kernel_vs_oracle_autograd(ops, device, cin, cmid, cout, monkeypatch):
+    """Training mode of the conv MODULES at >= 4096 rows (ops/spconv.py `_SparseConvFn`, planes=True): the forward and the data
+    gradient of a SubM -> strided -> inverse chain run on K9c (features / grad_out through fsf_to_planes, the step's weights
+    through fsf_spconv_prepare_weight_planes), the weight gradients on K10; oracle = autograd through the per-offset
+    gather / mm / index_add restatement.  Also equal within tolerance to the FSF_TRAIN_PLANES=0 path."""
+    from fullysparsefusion_amd import hip_ops
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import spconv as sp
+
+    rng = np.random.default_rng(cin + 3 * cmid + 7 * cout)
+    shape = (12, 96, 96)
+    idx = surface_sites(rng, 2, shape, 16000)
+    m = idx.shape[0]
+    torch.manual_seed(cin)
+    mods = [sp.SubMConv3d(cin, cmid, 3, padding=1, bias=False, indice_key="subm"),
+            sp.SparseConv3d(cmid, cmid, 3, stride=2, padding=1, bias=False, indice_key="down"),
+            sp.SparseInverseConv3d(cmid, cout, 3, indice_key="down", bias=False)]
+    for mod in mods:
+        mod.to(device).train()
+    feat = torch.from_numpy(rng.standard_normal((m, cin)).astype(np.float32))
+    probe = torch.from_numpy(rng.standard_normal((m, cout)).astype(np.float32))
+    calls = []
+    real = hip_ops.spconv_forward_planes
+    monkeypatch.setattr(hip_ops, "spconv_forward_planes", lambda *a, **k: (calls.append(a[4].size(0)), real(*a, **k))[1])
+
+    def run():
+        f = feat.to(device).requires_grad_()
+        x = sp.SparseConvTensor(f, torch.from_numpy(idx).to(device), list(shape), 2)
+        for mod in mods:
+            mod.zero_grad()
+            x = mod(x)
+        (x.features * probe.to(device)).sum().backward()
+        return [x.features.detach().cpu(), f.grad.cpu()] + [mod.weight.grad.cpu().clone() for mod in mods]
+
+    got = run()
+    m_down = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), False)[0].shape[0]
+    assert m_down >= 4096, m_down
+    assert len(calls) == 6 and sorted(calls) == sorted([m, m_down, m, m, m_down, m]), calls  # 3 forwards + 3 data gradients
+    monkeypatch.setenv("FSF_TRAIN_PLANES", "0")
+    other = run()
+    assert len(calls) == 6
+    # oracle
+    _, pairs_subm, _ = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True)
+    _, pairs_down, _ = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), False)
+    f = feat.clone().requires_grad_()
+    ws = [mod.weight.detach().cpu().reshape(27, mod.in_channels, mod.out_channels).clone().requires_grad_() for mod in mods]
+    y = osp.indice_conv(f, ws[0], pairs_subm, m)
+    y = osp.indice_conv(y, ws[1], pairs_down, m_down)
+    y = osp.indice_conv(y, ws[2], pairs_down, m, inverse=True)
+    (y * probe).sum().backward()
+    want = [y.detach(), f.grad] + [w.grad for w in ws]
+    for name, a, b, c in zip(["out", "grad_in", "gw_subm", "gw_down", "gw_inv"], got, other, want):
+        c = c.reshape(a.shape)
+        scale = float(c.abs().max())
+        assert float((a - c).abs().max()) <= 1e-4 * scale, (name, float((a - c).abs().max()), scale)
+        assert float((a - b).abs().max()) <= 1e-4 * scale, (name, "vs FSF_TRAIN_PLANES=0")
+
+
 def test_spconv_backward_weight_large_and_empty_offsets(ops, device):
     """Many pair-range splits (partials folded in split order), offsets with zero pairs (isolated sites) and a pair
     count that is not a multiple of the 32-pair stage."""
