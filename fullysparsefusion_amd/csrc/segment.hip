@@ -449,7 +449,7 @@ static int pick_team(int c, int vec) {
 template <int VEC>
 __global__ void __launch_bounds__(256)
     gather_rows_kernel(const float* __restrict__ src, int64_t src_stride, const int64_t* __restrict__ idx, int64_t n, int c,
-                       float* __restrict__ out, int64_t out_stride) {
+                       float* __restrict__ out, int64_t out_stride, const float* __restrict__ add = nullptr, int64_t add_stride = 0) {
   const int cv = c / VEC;
   const int64_t total = n * cv;
   if (total <= 0x7fffffff) {  // (a 64-bit division per element made the 131-channel gather instruction-bound: 315 us for 0.53 GB)
@@ -469,6 +469,14 @@ __global__ void __launch_bounds__(256)
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = load_vec<VEC>(src + row[u] * src_stride + col[u]);
+      if (add) {  // out = add + src[idx]  (the per-group half of a Linear over cat([point, group[inv]]), training forward)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const Vec<VEC> a = load_vec<VEC>(add + (int64_t)i[u] * add_stride + col[u]);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[u].v[e] = a.v[e] + v[u].v[e];
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (t0 + u * step < tot) store_vec<VEC>(out + (int64_t)i[u] * out_stride + col[u], v[u]);
@@ -478,7 +486,13 @@ __global__ void __launch_bounds__(256)
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / cv;
     const int col = (int)(t - i * cv) * VEC;
-    store_vec<VEC>(out + i * out_stride + col, load_vec<VEC>(src + idx[i] * src_stride + col));
+    Vec<VEC> v = load_vec<VEC>(src + idx[i] * src_stride + col);
+    if (add) {
+      const Vec<VEC> a = load_vec<VEC>(add + i * add_stride + col);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v.v[e] = a.v[e] + v.v[e];
+    }
+    store_vec<VEC>(out + i * out_stride + col, v);
   }
 }
 
@@ -712,24 +726,37 @@ extern "C" int fsf_segment_reduce_backward(const float* grad_out, int64_t n, int
   return FSF_OK;
 }
 
-extern "C" int fsf_gather_rows_strided(const float* src, int64_t src_stride, int64_t m, int32_t c, const int64_t* idx, int64_t n,
-                                       float* out, int64_t out_stride, void* stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  (void)m;
+static int gather_rows_launch(const float* src, int64_t src_stride, int32_t c, const int64_t* idx, int64_t n, const float* add,
+                              int64_t add_stride, float* out, int64_t out_stride, hipStream_t stream) {
   if (n < 0 || c < 1 || (n > 0 && (!src || !idx || !out))) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   if (out_stride == 0) out_stride = c;
   if (src_stride == 0) src_stride = c;
-  if (out_stride < c || src_stride < c) return FSF_ERR_INVALID_ARG;
-  const bool vec4 = (c % 4 == 0) && (out_stride % 4 == 0) && (src_stride % 4 == 0) && (((uintptr_t)src | (uintptr_t)out) % 16 == 0);
+  if (add_stride == 0) add_stride = c;
+  if (out_stride < c || src_stride < c || add_stride < c) return FSF_ERR_INVALID_ARG;
+  const bool vec4 = (c % 4 == 0) && (out_stride % 4 == 0) && (src_stride % 4 == 0) && (add_stride % 4 == 0) &&
+                    (((uintptr_t)src | (uintptr_t)out | (uintptr_t)add) % 16 == 0);
   if (vec4)
     hipLaunchKernelGGL((gather_rows_kernel<4>), dim3(fsf_stream_grid(n * (c / 4), 256)), dim3(256), 0, stream, src, src_stride, idx,
-                       n, (int)c, out, out_stride);
+                       n, (int)c, out, out_stride, add, add_stride);
   else
     hipLaunchKernelGGL((gather_rows_kernel<1>), dim3(fsf_stream_grid(n * c, 256)), dim3(256), 0, stream, src, src_stride, idx, n,
-                       (int)c, out, out_stride);
+                       (int)c, out, out_stride, add, add_stride);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
+}
+
+extern "C" int fsf_gather_rows_strided(const float* src, int64_t src_stride, int64_t m, int32_t c, const int64_t* idx, int64_t n,
+                                       float* out, int64_t out_stride, void* stream_) {
+  (void)m;
+  return gather_rows_launch(src, src_stride, c, idx, n, nullptr, 0, out, out_stride, (hipStream_t)stream_);
+}
+
+extern "C" int fsf_gather_rows_add(const float* src, int64_t src_stride, int64_t m, int32_t c, const int64_t* idx, int64_t n,
+                                   const float* add, int64_t add_stride, float* out, int64_t out_stride, void* stream_) {
+  (void)m;
+  if (n > 0 && !add) return FSF_ERR_INVALID_ARG;
+  return gather_rows_launch(src, src_stride, c, idx, n, add, add_stride, out, out_stride, (hipStream_t)stream_);
 }
 
 extern "C" int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,

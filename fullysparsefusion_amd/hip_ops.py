@@ -31,6 +31,7 @@ _ARGTYPES = {
     "fsf_segment_reduce_backward": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, _P],
     "fsf_gather_rows": [_P, c_i64, c_i32, _P, c_i64, _P, c_i64, _P],
     "fsf_gather_rows_strided": [_P, c_i64, c_i64, c_i32, _P, c_i64, _P, c_i64, _P],
+    "fsf_gather_rows_add": [_P, c_i64, c_i64, c_i32, _P, c_i64, _P, c_i64, _P, c_i64, _P],
     "fsf_norm_act": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i32, _P, c_i64, _P],
     "fsf_voxel2point": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, _P, _P],
     "fsf_voxel2point_strided": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, c_i64, _P, _P],
@@ -351,6 +352,19 @@ def gather_rows(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor
     assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) >= c
     check(_L().fsf_gather_rows_strided(c_p(src.data_ptr()) if src.numel() else c_p(None), src.stride(0) if m > 1 else c, m, c, ptr(idx), n,
                                        c_p(out.data_ptr()), out.stride(0), stream_ptr()), "fsf_gather_rows_strided")
+    return out
+
+
+def gather_rows_add(src: torch.Tensor, idx: torch.Tensor, add: torch.Tensor):
+    """fsf_gather_rows_add: add[i,:] + src[idx[i],:] -> f32 [n, c] (new tensor)."""
+    require_cuda(src, idx, add)
+    assert src.dtype == torch.float32 and src.dim() == 2 and add.dtype == torch.float32
+    src, add = src.contiguous(), add.contiguous()
+    idx = idx.to(torch.int64).contiguous()
+    n, (m, c) = idx.numel(), src.shape
+    assert add.shape == (n, c)
+    out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    check(_L().fsf_gather_rows_add(ptr(src), c, m, c, ptr(idx), n, ptr(add), c, ptr(out), c, stream_ptr()), "fsf_gather_rows_add")
     return out
 
 

@@ -120,10 +120,11 @@ _GROUPED_CONCAT = os.environ.get("FSF_GROUPED_CONCAT", "1") != "0"  # (A/B switc
 
 
 class GroupedConcat:
-    """`cat([point_feats, group_feats[inv]], 1)` kept as its three parts (inference).  The only consumer is the next
+    """`cat([point_feats, group_feats[inv]], 1)` kept as its three parts.  The only consumer is the next
     layer's Linear, and `cat(p, g[inv]) W^T = p W_left^T + (g W_right^T)[inv]`: the right half is applied once per group
     ([g, C] instead of [n, C] rows) and added per row inside K22's epilogue (fsf_linear_norm_act_grouped) — the [n, 2C]
-    tensor is never written and the per-point product is half as deep."""
+    tensor is never written and the per-point product is half as deep.  In training the same identity is taken through autograd
+    (`_grouped_linear_training`): the adjoint of the per-row add is a deterministic segmented sum."""
 
     def __init__(self, point_feats, group_feats, inv):
         self.point_feats, self.group_feats, self.inv = point_feats, group_feats, inv
@@ -137,6 +138,8 @@ class GroupedConcat:
 
     def materialize(self):
         n, c = self.point_feats.shape
+        if torch.is_grad_enabled() and (self.point_feats.requires_grad or self.group_feats.requires_grad):
+            return torch.cat([self.point_feats, gather_by_inverse(self.group_feats, self.inv)], dim=1)
         buf = torch.empty((n, c + self.group_feats.size(1)), dtype=self.point_feats.dtype, device=self.point_feats.device)
         buf[:, :c] = self.point_feats
         gather_by_inverse(self.group_feats, self.inv, out=buf[:, c:])
@@ -211,18 +214,56 @@ def _grouped_linear_norm_act(linear, norm, act, gc):
                                    eps=eps, act=act_code, row_add=table, row_add_index=inv.contiguous())
 
 
+class _AddGatheredFn(torch.autograd.Function):
+    """y + t[inv] in one pass (fsf_gather_rows_add); d/dy = identity, d/dt = segmented sum over the plan of `inv`."""
+
+    @staticmethod
+    def forward(ctx, y, t, plan):
+        ctx.plan = plan
+        return hip_ops.gather_rows_add(t, plan.inv, y)
+
+    @staticmethod
+    def backward(ctx, grad):
+        g_t = hip_ops.segment_reduce(grad.contiguous(), ctx.plan, "sum") if ctx.needs_input_grad[1] else None
+        return grad, g_t, None
+
+
+_TRAIN_GROUPED = os.environ.get("FSF_TRAIN_GROUPED", "1") != "0"  # (A/B switch)
+
+
+def _grouped_linear_training(linear, gc):
+    """`linear(cat([p, g[inv]], 1))` with gradients, without the concat: p W_left^T (per point; weight gradient on K10) +
+    (g W_right^T (+ b))[inv] (per group, then one gather-add pass).  None when the input is not covered."""
+    p, g = gc.point_feats, gc.group_feats
+    if not (_TRAIN_GROUPED and isinstance(linear, nn.Linear) and p.is_cuda and p.dtype == torch.float32 and p.dim() == 2
+            and g.dtype == torch.float32 and linear.in_features == p.size(1) + g.size(1) and p.size(0) >= 16384 and g.size(0) > 0):
+        return None
+    c = p.size(1)
+    w = linear.weight
+    t = F.linear(g, w[:, c:], linear.bias)
+    y = _PointLinearFn.apply(p, w[:, :c], None)
+    return _AddGatheredFn.apply(y, t, plan_of(gc.inv, g.size(0)))
+
+
 def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, want_concat, short_segments=False):
     """One `DynamicVFELayer` step of DynamicScatterVFE / SIRLayer: point_feats = act(norm(linear(x))), group feats =
     segmented reduce, and (unless it is the last layer) `cat([point_feats, group_feats[inv]], 1)`.
     Inference: the fused norm+act writes the left half of the concat buffer and the row gather the right half — the
     [n, 2C] tensor is written exactly once; the segmented reduce reads the left half through its row stride."""
     grouped_in = isinstance(features, GroupedConcat)
-    no_grad = not (torch.is_grad_enabled() and ((not grouped_in and features.requires_grad)
+    no_grad = not (torch.is_grad_enabled() and ((features.point_feats.requires_grad or features.group_feats.requires_grad
+                                                 if grouped_in else features.requires_grad)
                                                 or any(p.requires_grad for p in vfe_layer.parameters())))
     point_feats = None
     if grouped_in:
         if no_grad and vfe_layer.dropout is None:
             point_feats = _grouped_linear_norm_act(vfe_layer.linear, vfe_layer.norm, vfe_layer.act, features)
+        elif not no_grad:
+            pre = _grouped_linear_training(vfe_layer.linear, features)
+            if pre is not None:
+                point_feats = fused_norm_act(pre, vfe_layer.norm, vfe_layer.act)
+                if vfe_layer.dropout is not None:
+                    point_feats = vfe_layer.dropout(point_feats)
         if point_feats is None:
             features = features.materialize()
     if no_grad and vfe_layer.dropout is None and (want_concat or point_feats is not None):
@@ -235,10 +276,17 @@ def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, wan
             cat = GroupedConcat(point_feats, group_feats, inv) if _GROUPED_CONCAT else GroupedConcat(
                 point_feats, group_feats, inv).materialize()
         return point_feats, group_feats, group_coors, inv, cat
-    point_feats = vfe_layer(features)
+    if point_feats is None:
+        point_feats = vfe_layer(features)
     group_feats, group_coors, inv = scatter_v2(point_feats, coors, mode=mode, unq_inv=unq_inv, new_coors=new_coors,
                                                short_segments=short_segments)
-    cat = torch.cat([point_feats, gather_by_inverse(group_feats, inv)], dim=1) if want_concat else None
+    cat = None
+    if want_concat:
+        if (_TRAIN_GROUPED and _GROUPED_CONCAT and not no_grad and point_feats.is_cuda and point_feats.dtype == torch.float32
+                and point_feats.size(0) >= 16384):
+            cat = GroupedConcat(point_feats, group_feats, inv)  # consumed by the next layer's _grouped_linear_training
+        else:
+            cat = torch.cat([point_feats, gather_by_inverse(group_feats, inv)], dim=1)
     return point_feats, group_feats, group_coors, inv, cat
 
 

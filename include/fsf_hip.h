@@ -165,6 +165,12 @@ int fsf_gather_rows(const float* src, int64_t m, int32_t c, const int64_t* idx, 
 /* The same with a row stride on the source (src rows may be a column block of a wider buffer, src_stride >= c floats). */
 int fsf_gather_rows_strided(const float* src, int64_t src_stride, int64_t m, int32_t c, const int64_t* idx, int64_t n, float* out,
                             int64_t out_stride, void* stream);
+/* out[i,:] = add[i,:] + src[idx[i],:].  The per-group half of a Linear over the VFE / SIR layers'
+ * cat([point_feats, group_feats[inv]], 1) in TRAINING: cat(p, g[inv]) W^T = p W_left^T + (g W_right^T)[inv], so the [n, 2C]
+ * concat and its gather are never written and the adjoint of this op is the identity for `add` plus the deterministic segmented
+ * sum (fsf_segment_reduce, mode sum) for `src`. */
+int fsf_gather_rows_add(const float* src, int64_t src_stride, int64_t m, int32_t c, const int64_t* idx, int64_t n, const float* add,
+                        int64_t add_stride, float* out, int64_t out_stride, void* stream);
 
 /* SimpleSparseUNet decoder shortcut [UNVENDORED; SURVEY App. C decoder_layer_forward]:
  *   `x.features.view(n, C_out, -1).sum(2) + m.features` in one pass: out[i,j] = add[i,j] + sum_q feat[i, j*r + q],

@@ -270,6 +270,67 @@ def test_sparse_unet_on_the_planes_kernel_vs_oracle(fsf_pair, frame1, device, mo
     assert len(calls) >= 20 and ([128, 128], 128) in calls and ([64], 64) in calls and any(c[1] == 256 for c in calls)
 
 
+@pytest.mark.parametrize("norm,act", [(dict(type="LN", eps=1e-3), "gelu"), (dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), "relu")])
+def test_grouped_concat_training_equals_the_concat_path(plugin, device, monkeypatch, norm, act):
+    """Training: two DynamicVFELayer steps where the second layer's Linear over cat([point, group[inv]], 1) is taken as
+    p W_left^T + (g W_right^T)[inv] (sst_ops._grouped_linear_training, fsf_gather_rows_add + segmented-sum adjoint).  Outputs and
+    every gradient equal the materialised-concat path (itself pinned by the oracle tests) within fp32 rounding, and a float64
+    torch restatement of the two layers within 1e-4."""
+    from fullysparsefusion_amd.mmdet3d_plugin.models.voxel_encoders.voxel_encoder import DynamicVFELayer
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import sst_ops
+
+    torch.manual_seed(5)
+    rng = np.random.default_rng(6)
+    n, cin, c = 40000, 32, 64
+    l1, l2 = DynamicVFELayer(cin, c, norm, act=act).to(device).train(), DynamicVFELayer(2 * c, c, norm, act=act).to(device).train()
+    coors = torch.from_numpy(rng.integers(0, 14, size=(n, 3)).astype(np.int64)).to(device)
+    x0 = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32))
+    probe = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(device)
+
+    def run(grouped):
+        monkeypatch.setattr(sst_ops, "_TRAIN_GROUPED", grouped)
+        for m in (l1, l2):
+            m.zero_grad()
+        x = x0.to(device).requires_grad_()
+        _, _, gcoors, inv, cat = sst_ops.point_group_concat(l1, x, coors, "max", None, None, want_concat=True)
+        assert isinstance(cat, sst_ops.GroupedConcat) == grouped
+        pf, gf, _, _, _ = sst_ops.point_group_concat(l2, cat, coors, "max", inv, gcoors, want_concat=False)
+        ((pf * probe).sum() + gf.sum()).backward()
+        return [pf.detach(), gf.detach(), x.grad] + [p.grad.clone() for m in (l1, l2) for p in m.parameters()], inv
+
+    got, inv = run(True)
+    want, _ = run(False)
+    for a, b in zip(got, want):
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (a.shape, float((a - b).abs().max()), scale)
+    # float64 restatement (training-mode norms: LayerNorm per row / batch statistics per column)
+    d1, d2 = copy.deepcopy(l1).double().cpu(), copy.deepcopy(l2).double().cpu()
+    for m in (d1, d2):
+        m.zero_grad()
+    x = x0.double().requires_grad_()
+    inv_c = inv.cpu()
+    ngroups = int(inv_c.max()) + 1
+
+    def seg_max(t):
+        out = torch.full((ngroups, t.size(1)), -float("inf"), dtype=t.dtype)
+        return out.scatter_reduce(0, inv_c[:, None].expand(-1, t.size(1)), t, "amax", include_self=True)
+
+    p1 = d1.act(d1.norm(d1.linear(x)))
+    p2 = d2.act(d2.norm(d2.linear(torch.cat([p1, seg_max(p1)[inv_c]], 1))))
+    ((p2 * probe.cpu().double()).sum() + seg_max(p2).sum()).backward()
+    ref = [p2.detach(), seg_max(p2).detach(), x.grad] + [p.grad for m in (d1, d2) for p in m.parameters()]
+    # (a group maximum whose two largest candidates differ by fp32 rounding picks another row in float64: the gradient of that
+    # (group, channel) moves to a different point — a handful of rows may differ, the parameter gradients barely notice)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        scale = max(float(b.abs().max()), 1e-6)
+        err = (a.cpu().double() - b).abs()
+        if i == 2:
+            bad_rows = int((err.max(1)[0] > 1e-4 * scale).sum())
+            assert bad_rows <= n // 500, (bad_rows, n)
+        else:
+            assert float(err.max()) <= (1e-4 if i < 2 else 2e-3) * scale, (i, a.shape, float(err.max()), scale)
+
+
 def test_sparse_unet_training_backward_vs_oracle(plugin, device):
     """Config-3 'fwd+bwd' on the backbone: training-mode SimpleSparseUNet (batch-stat norms) forward and the gradients
     of every conv weight / norm parameter / the input features, against autograd through the CPU restatement."""

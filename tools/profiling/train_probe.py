@@ -2,7 +2,7 @@
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from torch.profiler import ProfilerActivity, profile
 
@@ -20,6 +20,6 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     ts(inp)
     torch.cuda.synchronize()
-tab = prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=40,
+tab = prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=80, max_name_column_width=40,
                                                          max_shapes_column_width=70)
 print(tab)
