@@ -17,6 +17,8 @@
 //
 // Stages of 32 pairs are gathered by LDS-DMA (global_load_lds_dwordx4), double-buffered, one barrier per stage; the
 // pair indices of stage s+2 are prefetched into registers while stage s computes.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace fsf {
@@ -258,7 +260,8 @@ static void bwd_plan(int64_t cap, int cin, int cout, int kvol, int* ta, int* tb,
   // each so the accumulator write-out stays small next to the MFMA work
   // (a dense layer, kvol = 1, has one evenly divisible pair list: fewer, longer ranges keep the fold pass — which reads
   // nsplit x cin x cout floats — negligible)
-  int64_t s = fsf_cdiv(kvol >= 8 ? 3072 : 512, kvol * tiles);
+  static const int target_env = getenv("FSF_BWD_TARGET_WGS") ? atoi(getenv("FSF_BWD_TARGET_WGS")) : 0;  // (A/B switch)
+  int64_t s = fsf_cdiv(target_env > 0 ? target_env : (kvol >= 8 ? 6144 : 512), kvol * tiles);
   const int64_t max_s = fsf_cdiv(cap, 8 * BW_RT);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
