@@ -214,20 +214,6 @@ def _grouped_linear_norm_act(linear, norm, act, gc):
                                    eps=eps, act=act_code, row_add=table, row_add_index=inv.contiguous())
 
 
-class _AddGatheredFn(torch.autograd.Function):
-    """y + t[inv] in one pass (fsf_gather_rows_add); d/dy = identity, d/dt = segmented sum over the plan of `inv`."""
-
-    @staticmethod
-    def forward(ctx, y, t, plan):
-        ctx.plan = plan
-        return hip_ops.gather_rows_add(t, plan.inv, y)
-
-    @staticmethod
-    def backward(ctx, grad):
-        g_t = hip_ops.segment_reduce(grad.contiguous(), ctx.plan, "sum") if ctx.needs_input_grad[1] else None
-        return grad, g_t, None
-
-
 _TRAIN_GROUPED = os.environ.get("FSF_TRAIN_GROUPED", "1") != "0"  # (A/B switch)
 
 
@@ -241,8 +227,7 @@ def _grouped_linear_training(linear, gc):
     c = p.size(1)
     w = linear.weight
     t = F.linear(g, w[:, c:], linear.bias)
-    y = _PointLinearFn.apply(p, w[:, :c], None)
-    return _AddGatheredFn.apply(y, t, plan_of(gc.inv, g.size(0)))
+    return _PointLinearFn.apply(p, w[:, :c], None, t, plan_of(gc.inv, g.size(0)))
 
 
 def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, want_concat, short_segments=False):
@@ -487,16 +472,27 @@ class _PointLinearFn(torch.autograd.Function):
     pairing instead."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, row_add=None, plan=None):
+        """`row_add` f32 [g, c_out] with `plan` (segment plan of the row -> group index): y += row_add[plan.inv] — the per-group
+        half of a Linear over cat([point, group[inv]], 1); its adjoint is the segmented sum of grad over the plan."""
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return F.linear(x, weight, bias)
+        ctx.has_bias, ctx.plan = bias is not None, plan
+        if _train_k22(x, weight.size(0)):  # the product on K22 (split-bf16 matrix cores, fp32-accurate; no norm, no activation)
+            return hip_ops.linear_norm_act(x, hip_ops.linear_prepare_weight(weight), weight.size(0), bias=bias,
+                                           row_add=row_add, row_add_index=plan.inv if row_add is not None else None)
+        y = F.linear(x, weight, bias)
+        return hip_ops.gather_rows_add(row_add, plan.inv, y) if row_add is not None else y
 
     @staticmethod
     def backward(ctx, grad):
         x, weight = ctx.saved_tensors
         grad = grad.contiguous()
-        g_x = grad @ weight if ctx.needs_input_grad[0] else None
+        g_x = None
+        if ctx.needs_input_grad[0]:
+            if _train_k22(grad, weight.size(1)):
+                g_x = hip_ops.linear_norm_act(grad, hip_ops.linear_prepare_weight(weight.t()), weight.size(1))
+            else:
+                g_x = grad @ weight
         g_w = None
         if ctx.needs_input_grad[1]:
             cin, cout = x.size(1), grad.size(1)
@@ -506,7 +502,16 @@ class _PointLinearFn(torch.autograd.Function):
             gp = F.pad(grad, (0, 4 - cout % 4)) if cout % 4 else grad
             g_w = hip_ops.linear_backward_weight(xp, gp)[:cin, :cout].t()
         g_b = hip_ops.column_sum(grad) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        return g_x, g_w, g_b
+        g_t = hip_ops.segment_reduce(grad, ctx.plan, "sum") if (len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3]) else None
+        return g_x, g_w, g_b, g_t, None
+
+
+_TRAIN_K22 = os.environ.get("FSF_TRAIN_K22", "1") != "0"  # (A/B switch)
+
+
+def _train_k22(x, out_features):
+    return (_TRAIN_K22 and x.size(0) >= 16384 and x.size(1) % 4 == 0 and x.size(1) >= 32
+            and hip_ops.linear_norm_act_supported(x, out_features))
 
 
 def linear_norm_act(linear, norm, act, x, out=None):
