@@ -270,8 +270,9 @@ def test_sparse_unet_on_the_planes_kernel_vs_oracle(fsf_pair, frame1, device, mo
     assert len(calls) >= 20 and ([128, 128], 128) in calls and ([64], 64) in calls and any(c[1] == 256 for c in calls)
 
 
-@pytest.mark.parametrize("norm,act", [(dict(type="LN", eps=1e-3), "gelu"), (dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), "relu")])
-def test_grouped_concat_training_equals_the_concat_path(plugin, device, monkeypatch, norm, act):
+@pytest.mark.parametrize("norm,act,c", [(dict(type="LN", eps=1e-3), "gelu", 64), (dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), "relu", 64),
+                                        (dict(type="LN", eps=1e-3), "gelu", 16)])  # 16 channels: the library product + fsf_gather_rows_add
+def test_grouped_concat_training_equals_the_concat_path(plugin, device, monkeypatch, norm, act, c):
     """Training: two DynamicVFELayer steps where the second layer's Linear over cat([point, group[inv]], 1) is taken as
     p W_left^T + (g W_right^T)[inv] (sst_ops._grouped_linear_training, fsf_gather_rows_add + segmented-sum adjoint).  Outputs and
     every gradient equal the materialised-concat path (itself pinned by the oracle tests) within fp32 rounding, and a float64
@@ -281,7 +282,7 @@ def test_grouped_concat_training_equals_the_concat_path(plugin, device, monkeypa
 
     torch.manual_seed(5)
     rng = np.random.default_rng(6)
-    n, cin, c = 40000, 32, 64
+    n, cin = 40000, 32
     l1, l2 = DynamicVFELayer(cin, c, norm, act=act).to(device).train(), DynamicVFELayer(2 * c, c, norm, act=act).to(device).train()
     coors = torch.from_numpy(rng.integers(0, 14, size=(n, 3)).astype(np.int64)).to(device)
     x0 = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32))
