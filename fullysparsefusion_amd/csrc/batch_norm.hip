@@ -129,6 +129,50 @@ __global__ void __launch_bounds__(256) column_fold_kernel(const float* __restric
   }
 }
 
+// The second fold of a training-mode BatchNorm's statistics with everything that hangs on it: biased variance -> invstd,
+// scale = weight * invstd, shift = bias - mean * scale, and the running-statistics update (momentum form) — one launch instead of
+// the fold + ~10 tiny ATen kernels per layer (38 layers per training step).  Same fold order as column_fold_kernel.
+struct BnFinalArgs {
+  const float *mean, *weight, *bias;
+  float eps, keep, momentum, var_alpha;  // running = running * keep + batch * momentum (variance: * var_alpha = momentum * n / (n - 1))
+  float *running_mean, *running_var;     // nullable
+  float *var, *invstd, *scale, *shift;   // var nullable
+};
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ part, int blocks, int c, float mul, BnFinalArgs f) {
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int ch = blockIdx.x * 16 + cl;
+  float a0[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ch < c) {
+    int b = sl;
+    for (; b + 48 < blocks; b += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a0[u] += part[((int64_t)(b + 16 * u) * 2 + 0) * c + ch];
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+      if (b + 16 * u < blocks) a0[u] += part[((int64_t)(b + 16 * u) * 2 + 0) * c + ch];
+  }
+  red[sl][cl] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+  __syncthreads();
+  if (threadIdx.x < 16 && ch < c) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][cl];
+    const float var = s * mul, mean = f.mean[ch];
+    const float invstd = (float)(1.0 / sqrt((double)var + (double)f.eps));  // (correctly rounded; ATen's rsqrt is within 1 ulp of it)
+    const float scale = f.weight ? f.weight[ch] * invstd : invstd;
+    const float shift = (f.bias ? f.bias[ch] : 0.0f) - mean * scale;
+    if (f.var) f.var[ch] = var;
+    f.invstd[ch] = invstd;
+    f.scale[ch] = scale;
+    f.shift[ch] = shift;
+    if (f.running_mean) f.running_mean[ch] = __fmaf_rn(f.momentum, mean, f.running_mean[ch] * f.keep);
+    if (f.running_var) f.running_var[ch] = __fmaf_rn(f.var_alpha, var, f.running_var[ch] * f.keep);
+  }
+}
+
 struct BnArgs {
   const float* x;
   const float* g;
@@ -224,6 +268,29 @@ extern "C" int fsf_column_stats(const float* x, int64_t n, int32_t c, float* mea
     hipLaunchKernelGGL(column_fold_kernel, dim3(fold_grid), dim3(256), 0, stream, a.part, blocks, c, 1.0f / (float)n, var,
                        (float*)nullptr);
   }
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_batch_norm_train_stats(const float* x, int64_t n, int32_t c, const float* weight, const float* bias, float eps,
+                                          float keep, float momentum, float var_alpha, float* running_mean, float* running_var,
+                                          float* mean, float* var, float* invstd, float* scale, float* shift, void* workspace,
+                                          int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 1 || c < 1 || !x || !mean || !invstd || !scale || !shift || ((weight == nullptr) != (bias == nullptr)))
+    return FSF_ERR_INVALID_ARG;
+  if (workspace_bytes < fsf_column_stats_workspace_bytes(c) || !workspace) return FSF_ERR_WORKSPACE;
+  CsArgs a{};
+  a.x = x; a.n = n; a.c = c; a.cw_log2 = cs_cw_log2(c); a.part = (float*)workspace;
+  const int blocks = cs_blocks(n, a.cw_log2, &a.rows_per_block);
+  const unsigned fold_grid = (unsigned)((c + 15) / 16);
+  hipLaunchKernelGGL((column_stats_kernel<CS_SUM>), dim3(blocks), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(column_fold_kernel, dim3(fold_grid), dim3(256), 0, stream, a.part, blocks, c, 1.0f / (float)n, mean,
+                     (float*)nullptr);
+  a.mean = mean;
+  hipLaunchKernelGGL((column_stats_kernel<CS_SQDEV>), dim3(blocks), dim3(256), 0, stream, a);
+  BnFinalArgs f{mean, weight, bias, eps, keep, momentum, var_alpha, running_mean, running_var, var, invstd, scale, shift};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(fold_grid), dim3(256), 0, stream, a.part, blocks, c, 1.0f / (float)n, f);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

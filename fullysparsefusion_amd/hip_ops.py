@@ -53,6 +53,7 @@ _ARGTYPES = {
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
     "fsf_column_stats_workspace_bytes": [c_i32],
     "fsf_column_stats": [_P, c_i64, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_batch_norm_train_stats": [_P, c_i64, c_i32, _P, _P, c_f32, c_f32, c_f32, c_f32, _P, _P, _P, _P, _P, _P, _P, _P, c_i64, _P],
     "fsf_batch_norm_act_forward": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P],
     "fsf_batch_norm_act_backward": [_P, _P, c_i64, c_i32, _P, _P, _P, _P, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_norm_act_backward_workspace_bytes": [c_i32],
@@ -1020,6 +1021,25 @@ def column_mean_var(x: torch.Tensor):
     ws = _lib.workspace(h.fsf_column_stats_workspace_bytes(c), x.device)
     check(h.fsf_column_stats(ptr(x), n, c, ptr(mean), ptr(var), ptr(ws), ws.numel(), stream_ptr()), "fsf_column_stats")
     return mean, var
+
+
+def batch_norm_train_stats(x: torch.Tensor, weight, bias, eps: float, momentum: float, running_mean=None, running_var=None):
+    """fsf_batch_norm_train_stats: x f32 [n,c] -> (mean, invstd, scale, shift) [c] each; running_mean / running_var (if given) are
+    updated in place with `momentum` (variance unbiased by n / (n - 1))."""
+    require_cuda(x, weight, bias, running_mean, running_var)
+    x = x.contiguous()
+    n, c = x.shape
+    assert n >= 1
+    mean, invstd, scale, shift = (torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(4))
+    h = _L()
+    ws = _lib.workspace(h.fsf_column_stats_workspace_bytes(c), x.device)
+    for t in (weight, bias, running_mean, running_var):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == c)
+    check(h.fsf_batch_norm_train_stats(ptr(x), n, c, ptr(weight), ptr(bias), float(eps), float(1.0 - momentum), float(momentum),
+                                       float(momentum * n / max(n - 1, 1)), ptr(running_mean), ptr(running_var), ptr(mean), c_p(None),
+                                       ptr(invstd), ptr(scale), ptr(shift), ptr(ws), ws.numel(), stream_ptr()),
+          "fsf_batch_norm_train_stats")
+    return mean, invstd, scale, shift
 
 
 def batch_norm_act_forward(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, relu: bool):

@@ -420,6 +420,9 @@ def fused_norm_act(x, norm, act, out=None):
     return y
 
 
+_BN_FUSED_STATS = os.environ.get("FSF_BN_FUSED_STATS", "1") != "0"  # (A/B switch)
+
+
 class _BatchNormActFn(torch.autograd.Function):
     """Training-mode BatchNorm1d over the rows of [n, C] (+ ReLU) on K23: two-pass batch statistics, one fused
     normalise + activate pass, and a backward of two reads of (x, grad) + one write."""
@@ -427,17 +430,26 @@ class _BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, bn, relu):
         x = x.contiguous()
-        mean, var = hip_ops.column_mean_var(x)
         n = x.size(0)
-        invstd = torch.rsqrt(var + bn.eps)
-        scale = weight.detach() * invstd if weight is not None else invstd
-        shift = (bias.detach() if bias is not None else 0.0) - mean * scale
-        if bn.track_running_stats and bn.running_mean is not None:
+        track = bn.track_running_stats and bn.running_mean is not None
+        if track:
             with torch.no_grad():
                 bn.num_batches_tracked += 1
-                momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                bn.running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                bn.running_var.mul_(1 - momentum).add_(var, alpha=momentum * n / max(n - 1, 1))
+        if _BN_FUSED_STATS and (not track or bn.momentum is not None):
+            # statistics, invstd / scale / shift and the running-statistics update in four launches (fsf_batch_norm_train_stats)
+            mean, invstd, scale, shift = hip_ops.batch_norm_train_stats(
+                x, weight.detach() if weight is not None else None, bias.detach() if bias is not None else None, bn.eps,
+                bn.momentum if track else 0.0, bn.running_mean if track else None, bn.running_var if track else None)
+        else:
+            mean, var = hip_ops.column_mean_var(x)
+            invstd = torch.rsqrt(var + bn.eps)
+            scale = weight.detach() * invstd if weight is not None else invstd
+            shift = (bias.detach() if bias is not None else 0.0) - mean * scale
+            if track:
+                with torch.no_grad():
+                    momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                    bn.running_var.mul_(1 - momentum).add_(var, alpha=momentum * n / max(n - 1, 1))
         ctx.save_for_backward(x, mean, invstd, scale, shift)
         ctx.relu, ctx.affine = relu, weight is not None
         return hip_ops.batch_norm_act_forward(x, scale, shift, relu)

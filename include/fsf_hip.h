@@ -230,6 +230,14 @@ int fsf_norm_act_backward(const float* x, const float* grad_out, int64_t n, int3
 int64_t fsf_column_stats_workspace_bytes(int32_t c);
 int fsf_column_stats(const float* x, int64_t n, int32_t c, float* mean, float* var, void* workspace, int64_t workspace_bytes,
                      void* stream);
+/* Training-mode BatchNorm1d statistics of x f32 [n, c] with everything that hangs on them, four launches: column mean, biased
+ * variance about it (two passes, fixed fold order), then in the last fold invstd = rsqrt(var + eps), scale = weight * invstd,
+ * shift = bias - mean * scale and the running-statistics update running = running * keep + batch * momentum (variance with
+ * var_alpha = momentum * n / (n - 1); running_* nullable).  Replaces the statistics + ~10 elementwise ATen kernels per layer of
+ * nn.BatchNorm1d / naiveSyncBN1d on one rank [UNVENDORED mmdet3d norm layers; cfg norm_cfg, FSF_nuScenes_config.py:63]. */
+int fsf_batch_norm_train_stats(const float* x, int64_t n, int32_t c, const float* weight, const float* bias, float eps, float keep,
+                               float momentum, float var_alpha, float* running_mean, float* running_var, float* mean, float* var,
+                               float* invstd, float* scale, float* shift, void* workspace, int64_t workspace_bytes, void* stream);
 int fsf_batch_norm_act_forward(const float* x, int64_t n, int32_t c, const float* scale, const float* shift, int32_t relu,
                                float* out, void* stream);
 int fsf_batch_norm_act_backward(const float* x, const float* grad_out, int64_t n, int32_t c, const float* mean,

@@ -384,10 +384,17 @@ def test_sparse_unet_training_backward_vs_oracle(plugin, device):
             loose[name] = (ours, cpu32)
             # ... except downstream of a ReLU input within rounding of zero that lands on the other side of it than on
             # the CPU (the split-bf16 kernel sums in a different order than the fp32 one): that perturbs the gradients
-            # behind it by a few 1e-4.  A wiring error is O(1); bound those by relative L2 <= 2e-3 and allow them on at
-            # most a fifth of the parameters (seen: the four tensors of lateral_layer1).
-            if rel_l2(got[name], g) > 2e-3:
-                bad[name] = (ours, cpu32)
+            # behind it by a few 1e-4 — and ONE entry of a bias / norm gradient (a 6000-row column sum) by the flipped element's
+            # own upstream gradient, 1-2 % of that entry (which element flips changes with any 1-ulp change upstream, e.g. the
+            # rsqrt of the batch variance).  A wiring error is O(1) everywhere; bound those by relative L2 <= 5e-3 with at most
+            # 5 % of the entries (2 at least) off by more than 1e-3 of the scale, and allow them on at most a fifth of the
+            # parameters (seen: the four tensors of lateral_layer1).
+            l2 = rel_l2(got[name], g)
+            err = (got[name].double().cpu() - g.double()).abs()
+            off = int((err > 1e-3 * float(g.double().abs().max())).sum())
+            print(f"loose {name}: max-rel {ours:.2e} (cpu fp32 {cpu32:.2e}), rel-L2 {l2:.2e}, {off} of {err.numel()} entries off")
+            if l2 > 5e-3 or off > max(2, err.numel() // 20):
+                bad[name] = (ours, cpu32, l2, off)
     assert not bad, bad
     assert len(loose) <= len(g64) // 5, loose
 
