@@ -296,9 +296,15 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
     }
 
   // ---- this wave's share of a step's gather: global -> registers (a lane without a neighbour loads nothing: zeros)
-  uint4 st_hi[CPW][SP_NKC], st_lo[CPW][SP_NKC];
-  float st_sc[CPW];
-  auto load_x = [&](const SpStep& st) {
+  struct XStage {
+    uint4 hi[CPW][SP_NKC], lo[CPW][SP_NKC];
+    float sc[CPW];
+  };
+  XStage xs_a;
+#ifdef SP_DEEP
+  XStage xs_b;  // second staging set: the gather runs THREE steps ahead of its use (an L2 miss outlasts one step)
+#endif
+  auto load_x = [&](const SpStep& st, XStage& xs) {
     const char* xb = st.src ? a.x[1] : a.x[0];  // (a run-time index would put the whole argument block in scratch)
     const float* sb = st.src ? a.sx[1] : a.sx[0];
     const uint32_t rb = st.src ? rowbytes1 : rowbytes0;
@@ -311,8 +317,8 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
       // are then assigned on every path — written under a branch they ended up in scratch.
 #pragma unroll
       for (int kc = 0; kc < SP_NKC; ++kc) {  // (dead stores, removed by the compiler — but without them the arrays stay in scratch)
-        st_hi[u][kc] = make_uint4(0, 0, 0, 0);
-        st_lo[u][kc] = make_uint4(0, 0, 0, 0);
+        xs.hi[u][kc] = make_uint4(0, 0, 0, 0);
+        xs.lo[u][kc] = make_uint4(0, 0, 0, 0);
       }
       int i = nbr_s[(16 * cc + j) * kvol + st.k];
       i = i >= 0 ? i : (int)a.m_in;
@@ -324,14 +330,14 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
 #pragma unroll
       for (int kc = 0; kc < SP_NKC; ++kc) {
         if (FIX ? kc < NKC : true) {  // (run-time widths: chunks past the row's end are never stored; the address stays inside the planes of row i + 1 or the zero row's successor — see the host check)
-          st_hi[u][kc] = *reinterpret_cast<const uint4*>(p + (kc < nkc ? kc : 0) * 128);
-          st_lo[u][kc] = *reinterpret_cast<const uint4*>(p + (kc < nkc ? kc : 0) * 128 + 16);
+          xs.hi[u][kc] = *reinterpret_cast<const uint4*>(p + (kc < nkc ? kc : 0) * 128);
+          xs.lo[u][kc] = *reinterpret_cast<const uint4*>(p + (kc < nkc ? kc : 0) * 128 + 16);
         }
       }
-      st_sc[u] = sb[i];
+      xs.sc[u] = sb[i];
     }
   };
-  auto store_x = [&](const SpStep& st, int slot) {  // registers -> LDS in B-fragment order (lane-linear: conflict-free)
+  auto store_x = [&](const SpStep& st, int slot, const XStage& xs) {  // registers -> LDS in B-fragment order (lane-linear: conflict-free)
 #ifdef SP_ABL_NO_LDS_WRITE
     return;
 #endif
@@ -344,11 +350,11 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
 #pragma unroll
         for (int kc = 0; kc < SP_NKC; ++kc) {
           if (kc < nkc) {
-            dst[(kc * 2) * 64] = st_hi[u][kc];
-            dst[(kc * 2 + 1) * 64] = st_lo[u][kc];
+            dst[(kc * 2) * 64] = xs.hi[u][kc];
+            dst[(kc * 2 + 1) * 64] = xs.lo[u][kc];
           }
         }
-        sring[(slot * RG + cc) * 64 + lane] = st_sc[u];
+        sring[(slot * RG + cc) * 64 + lane] = xs.sc[u];
       }
     }
   };
@@ -405,7 +411,7 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   // The staging of the following steps rides inside: X(s+1) registers -> LDS and the X(s+2) gather are issued when the last
   // chunk's fragments have been requested, so the LDS queue (in order per wave) never has this step's reads behind the writes
   // and the writes retire under the last chunk's MFMAs (at the top of the step they cost a quarter of the layer).
-  auto compute = [&](const SpStep& st, const SpStep& nxt, const SpStep& nxt2, int slot) {
+  auto compute = [&](const SpStep& st, const SpStep& nxt, const SpStep& nxt2, int slot, XStage& xs) {
     const int nkc = FIX ? NKC : (st.src ? nkc1 : nkc0);
     const int nkc_nxt = FIX ? NKC : (nxt.src ? nkc1 : nkc0);
     uint4 xh[RG], xl[RG];
@@ -421,8 +427,8 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
       if (kc < nkc) {
 #ifndef SP_STAGE_EARLY
         if (kc == nkc - 1) {
-          store_x(nxt, slot ^ 1);
-          load_x(nxt2);
+          store_x(nxt, slot ^ 1, xs);
+          load_x(nxt2, xs);
         }
 #endif
 #pragma unroll
@@ -454,27 +460,47 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   // from their reads.  (-DSP_STAGE_EARLY: the staging at the top of the step, as it was: 0-3 % slower per layer.)
   SpStep s0 = entry(0, 0);
   SpStep s1 = advance(s0);
-  load_x(s0);
+  load_x(s0, xs_a);
 #pragma unroll
   for (int kc = 0; kc < SP_NKC; ++kc)
     if (kc < nkc0) load_w(s0, kc, wf[kc]);
-  store_x(s0, 0);
-  load_x(s1);
+  store_x(s0, 0, xs_a);
   SpStep s2 = advance(s1);
+#ifdef SP_DEEP
+  // X(s + 1) lives in set B for even s and in set A for odd s; when it has gone to LDS its set takes the gather of X(s + 3)
+  load_x(s1, xs_b);
+  load_x(s2, xs_a);
+  SpStep s3 = advance(s2);
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    __syncthreads();
+    compute(s0, s1, s3, 0, xs_b);
+    s0 = s1; s1 = s2; s2 = s3; s3 = advance(s3);
+    __syncthreads();
+    compute(s0, s1, s3, 1, xs_a);
+    s0 = s1; s1 = s2; s2 = s3; s3 = advance(s3);
+  }
+  if (s < nsteps) {
+    __syncthreads();
+    compute(s0, s1, s3, 0, xs_b);
+  }
+#else
+  load_x(s1, xs_a);
   for (int s = 0; s < nsteps; ++s) {
 #ifndef SP_ABL_NO_BARRIER
     __syncthreads();
 #endif
     const int par = s & 1;
 #ifdef SP_STAGE_EARLY
-    store_x(s1, par ^ 1);  // X(s+1), loaded during the previous step
-    load_x(s2);            // X(s+2)
+    store_x(s1, par ^ 1, xs_a);  // X(s+1), loaded during the previous step
+    load_x(s2, xs_a);            // X(s+2)
 #endif
-    compute(s0, s1, s2, par);
+    compute(s0, s1, s2, par, xs_a);
     s0 = s1;
     s1 = s2;
     s2 = advance(s2);
   }
+#endif
 
   // ---- epilogue: lane (j, q) holds channels chw + 16 t + 4 q + r of rows row0 + 16 g + j
   const bool affine = a.scale || a.shift;
