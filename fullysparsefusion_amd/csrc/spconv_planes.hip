@@ -27,7 +27,6 @@
 // load, all waits are counted by hand (s_waitcnt vmcnt(n): the newest n may stay in flight).
 #include <stdlib.h>
 #include <algorithm>
-#include <type_traits>
 
 #include "common.h"
 
@@ -579,302 +578,6 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   }
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Two 64-row blocks per workgroup sharing one weight fetch (K9c-rb2).  The single-factor ablations of the 64-row kernel say that its
-// per-step WEIGHT loads are what it waits for (64 KB per (offset, 128-cin) step against 32 KB of gathered rows, both through the CU's
-// 64 B/clk return path; the gathers and the MFMAs are hidden).  Here the step sequence is (offset, source, block): the two blocks of a
-// workgroup alternate, block b multiplies from LDS slot b while the other block's next rows are staged into the other slot — the
-// same two-slot ring, the same barrier count per 64 rows — and the weight fragments of an (offset, source) are fetched once for both.
-// The neighbour table is not kept in LDS (two workgroups per CU would not fit): the flag scan and the gathers read it from L2, the
-// gather's row index one half-step ahead of the gather.  Accumulation order per output row is the 64-row kernel's: bit-identical.
-template <int TPW, int NKC>
-__global__ void __launch_bounds__(256, 2) spconv_fwd_planes_rb2_kernel(SpArgs a) {
-  constexpr int RG = 4, R = 64;
-  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
-  uint4* xring = reinterpret_cast<uint4*>(sp_smem);                                      // [2 blocks][RG][SP_NKC][hi | lo][64] x 16 B
-  float* sring = reinterpret_cast<float*>(sp_smem + 2 * RG * SP_NKC * 2 * 1024);        // [2][RG][64]
-  int* sched = reinterpret_cast<int*>(sp_smem + 2 * RG * SP_NKC * 2 * 1024 + 2 * RG * 64 * 4);
-  int* nk_s = sched + 32;
-  unsigned char* flags = reinterpret_cast<unsigned char*>(sched + 36);                   // [27][8]
-  float* vec = reinterpret_cast<float*>(sp_smem + 2 * RG * SP_NKC * 2 * 1024 + 2 * RG * 64 * 4 + 36 * 4 + 256);
-  float* rowmax = vec + 2 * 64 * TPW;                                                    // [4][R]
-
-  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kvol = a.kvol;
-  const int64_t row0 = (int64_t)blockIdx.x * (2 * R);
-  const int slice = blockIdx.y;
-  const int chw = slice * 64 * TPW + wave * 16 * TPW;
-
-  if (tid < 2 * 64 * TPW) {
-    const int which = tid / (64 * TPW), ch = slice * 64 * TPW + tid % (64 * TPW);
-    const float* src = which == 0 ? a.scale : a.shift;
-    vec[tid] = (src && ch < a.cout) ? src[ch] : (which == 0 ? 1.0f : 0.0f);
-  }
-  if (tid < kvol * 8) {  // cell (k, block, g): does any of its 16 rows have a neighbour at offset k?
-    const int k = tid >> 3, c8 = tid & 7;
-    const int64_t r0 = row0 + 16 * c8;
-    bool any = false;
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) any |= (r0 + jj < a.m_out) && a.nbr[(r0 + jj) * kvol + k] >= 0;
-    flags[tid] = any ? 1 : 0;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    unsigned mask = 0;
-    if (lane < kvol) {
-#pragma unroll
-      for (int c8 = 0; c8 < 8; ++c8) mask |= (unsigned)flags[lane * 8 + c8] << c8;
-    }
-    const unsigned long long live = __ballot(mask != 0);
-    if (lane < 32) sched[lane] = 0;
-    if (mask != 0) sched[__popcll(live & ((1ull << lane) - 1ull))] = lane | (int)(mask << 8);
-    if (lane == 0) *nk_s = __popcll(live);
-  }
-  __syncthreads();
-  const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
-  const int nsrc = a.c[1] > 0 ? 2 : 1;
-  const int nchunks = NKC * nsrc;
-  const int npairs = nk * nsrc;  // (offset, source) pairs; every pair is two half-steps (block 0, block 1)
-  const float w_inv = a.w_hdr[0];
-  const uint32_t rowbytes = (uint32_t)NKC * 128u;
-
-  struct HStep {
-    int kidx, src, k, blk;
-    unsigned mask;
-  };
-  auto entry = [&](int kidx, int src, int blk) -> HStep {
-    const int e = kidx < nk ? __builtin_amdgcn_readfirstlane(sched[kidx]) : 0;
-    return HStep{kidx, src, e & 255, blk, (((unsigned)e >> 8) >> (4 * blk)) & 15u};
-  };
-  auto advance = [&](const HStep& p) -> HStep {
-    if (p.blk == 0) return entry(p.kidx, p.src, 1);
-    if (p.src + 1 < nsrc) return entry(p.kidx, p.src + 1, 0);
-    return entry(p.kidx + 1, 0, 0);
-  };
-
-  sp_f32x4 acc[2][RG][TPW], D[RG][TPW];
-#pragma unroll
-  for (int b = 0; b < 2; ++b)
-#pragma unroll
-    for (int g = 0; g < RG; ++g)
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) acc[b][g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int g = 0; g < RG; ++g)
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // this wave's share of a half-step's gather: cell `wave` of the step's block, lane (j, q): row j, 32-byte piece q of every chunk
-  uint4 st_hi[NKC], st_lo[NKC];
-  float st_sc;
-  auto load_idx = [&](const HStep& st) -> int {
-    const int64_t row = row0 + 64 * st.blk + 16 * wave + j;
-    const int i = row < a.m_out ? a.nbr[row * kvol + st.k] : -1;
-    return i >= 0 ? i : (int)a.m_in;  // (no neighbour: the all-zero row)
-  };
-  auto load_x = [&](const HStep& st, int i) {
-    const char* xb = st.src ? a.x[1] : a.x[0];
-    const float* sb = st.src ? a.sx[1] : a.sx[0];
-    const char* p = xb + (uint32_t)i * rowbytes + (uint32_t)(q * 32);
-#pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) {  // (dead stores: without them the arrays stay in scratch, as in the 64-row kernel)
-      st_hi[kc] = make_uint4(0, 0, 0, 0);
-      st_lo[kc] = make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) {
-      st_hi[kc] = *reinterpret_cast<const uint4*>(p + kc * 128);
-      st_lo[kc] = *reinterpret_cast<const uint4*>(p + kc * 128 + 16);
-    }
-    st_sc = sb[i];
-  };
-  auto store_x = [&](const HStep& st) {  // -> the block's LDS slot, B-fragment order
-    if ((st.mask >> wave) & 1u) {
-      uint4* dst = xring + (((st.blk * RG + wave) * SP_NKC) * 2) * 64 + lane;
-#pragma unroll
-      for (int kc = 0; kc < NKC; ++kc) {
-        dst[(kc * 2) * 64] = st_hi[kc];
-        dst[(kc * 2 + 1) * 64] = st_lo[kc];
-      }
-      sring[(st.blk * RG + wave) * 64 + lane] = st_sc;
-    }
-  };
-  uint4 wf[NKC][TPW][2];
-  auto load_w = [&](const HStep& st, int kc) {
-    const int c = (st.src ? NKC : 0) + kc;
-    const uint4* p = reinterpret_cast<const uint4*>(a.w) +
-                     ((((int64_t)slice * kvol + st.k) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) wf[kc][t][pl] = p[(t * 2 + pl) * 64];
-  };
-  auto read_cell = [&](int blk, int kc, int g, uint4& xh, uint4& xl) {
-    const uint4* xs = xring + (((blk * RG + g) * SP_NKC + kc) * 2) * 64 + lane;
-    xh = xs[0];
-    xl = xs[64];
-  };
-  auto mma_cell = [&](int kc, int g, const uint4& xh, const uint4& xl) {
-    const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh), bl = __builtin_bit_cast(sp_f16x8, xl);
-    sp_f16x8 wh[TPW], wl[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      wh[t] = __builtin_bit_cast(sp_f16x8, wf[kc][t][0]);
-      wl[t] = __builtin_bit_cast(sp_f16x8, wf[kc][t][1]);
-    }
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-      D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, kc == 0 ? sp_f32x4{0.f, 0.f, 0.f, 0.f} : D[g][t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, D[g][t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, D[g][t], 0, 0, 0);
-  };
-  // one half-step: multiply block BLK's rows of step `st` from its slot; before the last chunk's MFMAs the next half-step's rows
-  // (the other block's, gathered during the previous half-step) go to the other slot and the gather after it is issued; the
-  // weight registers of a chunk take the next (offset, source)'s as soon as block 1 has issued its MFMAs on them
-  int idx_ahead = (int)a.m_in;
-  auto compute = [&](auto blk_tag, const HStep& st, const HStep& nxt, const HStep& nxt2, const HStep& nxt3) {
-    constexpr int BLK = decltype(blk_tag)::value;
-    uint4 xh[RG], xl[RG];
-    float inv[RG];
-#pragma unroll
-    for (int g = 0; g < RG; ++g)
-      if ((st.mask >> g) & 1u) {
-        read_cell(BLK, 0, g, xh[g], xl[g]);
-        inv[g] = sring[(BLK * RG + g) * 64 + lane];
-      }
-#pragma unroll
-    for (int kc = 0; kc < NKC; ++kc) {
-      if (kc == NKC - 1) {
-        store_x(nxt);
-        load_x(nxt2, idx_ahead);
-        idx_ahead = load_idx(nxt3);
-      }
-#pragma unroll
-      for (int g = 0; g < RG; ++g)
-        if ((st.mask >> g) & 1u) {
-          mma_cell(kc, g, xh[g], xl[g]);
-          if (kc + 1 < NKC) read_cell(BLK, kc + 1, g, xh[g], xl[g]);
-        }
-      if (BLK == 1) load_w(nxt, kc);  // (block 0's successor is block 1 of the same (offset, source): same fragments)
-    }
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      if ((st.mask >> g) & 1u) {
-        const float sc = __fmul_rn(inv[g], w_inv);
-#pragma unroll
-        for (int t = 0; t < TPW; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[BLK][g][t][r] = __fmaf_rn(D[g][t][r], sc, acc[BLK][g][t][r]);
-      }
-    }
-  };
-
-  HStep h0 = entry(0, 0, 0), h1 = advance(h0), h2 = advance(h1), h3 = advance(h2);
-  load_x(h0, load_idx(h0));
-#pragma unroll
-  for (int kc = 0; kc < NKC; ++kc) load_w(h0, kc);
-  store_x(h0);
-  load_x(h1, load_idx(h1));
-  idx_ahead = load_idx(h2);
-  for (int pr = 0; pr < npairs; ++pr) {
-    __syncthreads();
-    compute(std::integral_constant<int, 0>{}, h0, h1, h2, h3);
-    h0 = h1; h1 = h2; h2 = h3; h3 = advance(h3);
-    __syncthreads();
-    compute(std::integral_constant<int, 1>{}, h0, h1, h2, h3);
-    h0 = h1; h1 = h2; h2 = h3; h3 = advance(h3);
-  }
-
-  // ---- epilogue, block by block (the 64-row kernel's)
-  const bool affine = a.scale || a.shift;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int64_t rowb = row0 + 64 * b;
-    float amax[RG];
-#pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      const int64_t row = rowb + 16 * g + j;
-      amax[g] = 0.0f;
-#pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        const int chl = wave * 16 * TPW + 16 * t + 4 * q;
-        const int ch = slice * 64 * TPW + chl;
-        sp_f32x4 y = acc[b][g][t];
-        if (affine) {
-          const float4 sc = *reinterpret_cast<const float4*>(vec + chl);
-          const float4 sh = *reinterpret_cast<const float4*>(vec + 64 * TPW + chl);
-          y[0] = __fmaf_rn(y[0], sc.x, sh.x); y[1] = __fmaf_rn(y[1], sc.y, sh.y);
-          y[2] = __fmaf_rn(y[2], sc.z, sh.z); y[3] = __fmaf_rn(y[3], sc.w, sh.w);
-        }
-        if (row < a.m_out && ch < a.cout) {
-          if (a.residual) {
-            const float4 rs = *reinterpret_cast<const float4*>(a.residual + row * a.cout + ch);
-            y[0] = __fadd_rn(y[0], rs.x); y[1] = __fadd_rn(y[1], rs.y); y[2] = __fadd_rn(y[2], rs.z); y[3] = __fadd_rn(y[3], rs.w);
-          }
-          if (a.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
-          if (a.out) *reinterpret_cast<float4*>(a.out + row * a.cout + ch) = make_float4(y[0], y[1], y[2], y[3]);
-        } else {
-          y = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        acc[b][g][t] = y;
-        amax[g] = fmaxf(amax[g], fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
-      }
-    }
-    if (a.out_planes) {
-      __syncthreads();  // (the previous block's readers of rowmax are done)
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        float m = amax[g];
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        if (q == 0) rowmax[wave * R + 16 * g + j] = m;
-      }
-      __syncthreads();
-      const int nchunk_out = (a.cout + 64 * TPW - 1) / (64 * TPW);
-      const int blocks_per_row = a.cout / 8;
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        const int64_t row = rowb + 16 * g + j;
-        const int rl = 16 * g + j;
-        const float m = fmaxf(fmaxf(rowmax[rl], rowmax[R + rl]), fmaxf(rowmax[2 * R + rl], rowmax[3 * R + rl]));
-        float sc, inv_s;
-        sp_pick_scale(m, sc, inv_s);
-        if (row < a.m_out) {
-#pragma unroll
-          for (int t = 0; t < TPW; ++t) {
-            const int ch = chw + 16 * t + 4 * q;
-            if (ch < a.cout) {
-              const float v4[4] = {acc[b][g][t][0], acc[b][g][t][1], acc[b][g][t][2], acc[b][g][t][3]};
-              sp_u32x2 hi, lo;
-              sp_split4(v4, sc, hi, lo);
-              char* dst = reinterpret_cast<char*>(a.out_planes + (row * blocks_per_row + (ch >> 3)) * 2) + (q & 1) * 8;
-              *reinterpret_cast<sp_u32x2*>(dst) = hi;
-              *reinterpret_cast<sp_u32x2*>(dst + 16) = lo;
-            }
-          }
-          if (wave == 0 && q == 0) a.out_scales[row * nchunk_out + slice] = inv_s;
-        }
-      }
-    }
-  }
-  if (a.out_planes && blockIdx.x == gridDim.x - 1) {  // the zero row
-    const int blocks_per_row = a.cout / 8, nchunk_out = (a.cout + 64 * TPW - 1) / (64 * TPW);
-    const int nu4 = 64 * TPW / 8 * 2;
-    const int b0 = slice * (64 * TPW / 8);
-    if (tid < nu4 && b0 + tid / 2 < blocks_per_row) a.out_planes[(a.m_out * blocks_per_row + b0) * 2 + tid] = make_uint4(0, 0, 0, 0);
-    if (tid == 0) a.out_scales[a.m_out * nchunk_out + slice] = 1.0f;
-  }
-}
-
-template <int TPW>
-constexpr size_t sp_rb2_smem_bytes() {
-  return (size_t)2 * 4 * SP_NKC * 2 * 1024 + 2 * 4 * 64 * 4 + 36 * 4 + 256 + (size_t)2 * 64 * TPW * 4 + 4 * 64 * 4;
-}
-
 }  // namespace fsf
 
 using namespace fsf;
@@ -954,21 +657,7 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
   } while (0)
   // sources of one width (64 or 128 channels: every layer of the U-Net) get the variant with compile-time chunk loops
   const int nkc_fix = (cb == 0 || cb == ca) && (ca == 64 || ca == 128) && !getenv("FSF_PLANES_GENERIC") ? ca / 32 : 0;
-#define FSF_SP_RB2(TPW_, NKC_)                                                                                              \
-  do {                                                                                                                     \
-    static std::atomic<uint64_t> attr_done{0};                                                                             \
-    const size_t smem = sp_rb2_smem_bytes<TPW_>();                                                                         \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_planes_rb2_kernel<TPW_, NKC_>, (int)smem, attr_done));     \
-    const dim3 grid((unsigned)((m_out + 127) / 128), (unsigned)nslice);                                                    \
-    hipLaunchKernelGGL((spconv_fwd_planes_rb2_kernel<TPW_, NKC_>), grid, dim3(256), smem, stream, a);                      \
-  } while (0)
-  static const int rb2_env = getenv("FSF_PLANES_RB2") ? atoi(getenv("FSF_PLANES_RB2")) : 0;  // (A/B switch: two 64-row blocks per weight fetch)
-  static const int64_t rb2_min_rows = getenv("FSF_PLANES_RB2_MIN_ROWS") ? atoll(getenv("FSF_PLANES_RB2_MIN_ROWS")) : 0;
-  const bool rb2 = rb2_env != 0 && !big && m_out >= rb2_min_rows;
-  if (rb2 && tpw == 2 && nkc_fix == 4) FSF_SP_RB2(2, 4);
-  else if (rb2 && tpw == 2 && nkc_fix == 2) FSF_SP_RB2(2, 2);
-  else if (rb2 && tpw == 1 && nkc_fix == 2) FSF_SP_RB2(1, 2);
-  else if (big && tpw == 2) FSF_SP(8, 2, 0);
+  if (big && tpw == 2) FSF_SP(8, 2, 0);
   else if (big) FSF_SP(8, 1, 0);
   else if (tpw == 2 && nkc_fix == 4) FSF_SP(4, 2, 4);
   else if (tpw == 2 && nkc_fix == 2) FSF_SP(4, 2, 2);
@@ -976,7 +665,6 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
   else if (tpw == 2) FSF_SP(4, 2, 0);
   else FSF_SP(4, 1, 0);
 #undef FSF_SP
-#undef FSF_SP_RB2
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }
