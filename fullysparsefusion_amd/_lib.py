@@ -25,6 +25,19 @@ class FsfHipError(RuntimeError):
     pass
 
 
+def _header_abi_version():
+    """FSF_ABI_VERSION of include/fsf_hip.h (None when the header does not travel with the package)."""
+    import re
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fsf_hip.h")
+    try:
+        with open(path) as f:
+            m = re.search(r"#define\s+FSF_ABI_VERSION\s+(\d+)", f.read())
+        return int(m.group(1)) if m else None
+    except OSError:
+        return None
+
+
 def lib():
     """Load (once) and return the ctypes handle.  Fails loudly when the extension has not been built."""
     global _lib
@@ -37,6 +50,10 @@ def lib():
                         "Run `python -m fullysparsefusion_amd.build` (needs hipcc); there is no CPU fallback."
                     )
                 h = ctypes.CDLL(LIB_PATH)
+                want = _header_abi_version()
+                if want is not None and int(h.fsf_abi_version()) != want:
+                    raise FsfHipError(f"{LIB_PATH} has ABI version {int(h.fsf_abi_version())}, include/fsf_hip.h declares {want}: "
+                                      "stale build, run `python -m fullysparsefusion_amd.build`")
                 h.fsf_status_string.restype = ctypes.c_char_p
                 h.fsf_status_string.argtypes = [ctypes.c_int]
                 for name in (

@@ -14,4 +14,4 @@ extern "C" const char* fsf_status_string(int status) {
   }
 }
 
-extern "C" int fsf_abi_version(void) { return 1; }
+extern "C" int fsf_abi_version(void) { return FSF_ABI_VERSION; }

@@ -29,7 +29,9 @@ extern "C" {
 #define FSF_ERR_UNSUPPORTED (-6)   /* shape outside what the kernels are built for */
 
 const char* fsf_status_string(int status);
-/* ABI version, bumped whenever a signature changes. */
+/* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
+ * library it found with the FSF_ABI_VERSION of the header it was written against. */
+#define FSF_ABI_VERSION 2
 int fsf_abi_version(void);
 
 /* ------------------------------------------------------------------------------------------------

@@ -34,7 +34,8 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, f"declared in include/fsf_hip.h but not exported: {missing}"
     lib.fsf_status_string.restype = ctypes.c_char_p
     assert lib.fsf_status_string(0) == b"ok"
-    assert lib.fsf_abi_version() >= 1
+    header = int(re.search(r"#define\s+FSF_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "fsf_hip.h")).read()).group(1))
+    assert lib.fsf_abi_version() == header  # (the loader in fullysparsefusion_amd/_lib.py refuses a library of another version)
 
 
 def test_wrapper_argtypes_cover_the_header():
