@@ -151,10 +151,12 @@ __global__ void __launch_bounds__(256, 2) spconv_bwd_weight_kernel(SpconvBwdArgs
   const int aoff = wa * 64 + 4 * l16, boff = BW_RT * TA + wb * 64 + 4 * l16;
   for (int s = 0; s < nstages; ++s) {
     __syncthreads();  // stage s landed (each wave drains its own DMA before the barrier); buffer (s+1)&1 is free
+#ifndef BW_ABL_NO_DMA  // (ablation builds: tools/profiling/bwd_weight_layers.py with FSF_EXTRA_HIPCC_FLAGS)
     if (s + 1 < nstages) {
       issue_stage(s + 1);
       if (s + 2 < nstages) load_indices(s + 2);
     }
+#endif
     const float* As = S + (s & 1) * SM::STAGE_FLOATS;
     f32x4 av[NSTEP], bv[NSTEP];
 #pragma unroll
@@ -169,7 +171,11 @@ __global__ void __launch_bounds__(256, 2) spconv_bwd_weight_kernel(SpconvBwdArgs
       for (int qa = 0; qa < 4; ++qa)
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb)
+#ifdef BW_ABL_NO_MFMA
+          acc[qa][qb][0] += av[i][qa] * bv[i][qb];
+#else
           acc[qa][qb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][qa], bv[i][qb], acc[qa][qb], 0, 0, 0);
+#endif
   }
 
   // fold the in-block k-step split through LDS in fixed order (ks = 1, 2, 3 onto ks = 0)
