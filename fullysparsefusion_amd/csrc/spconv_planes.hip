@@ -364,8 +364,13 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
     if (st.kidx > 0 || st.src > 0 || kc > 0) return;
 #endif
     const int c = (st.src ? nkc0 : 0) + kc;
+#ifdef SP_ABL_W_SAME  // ablation: every step fetches offset 0's fragments (same instructions, the lines stay in the CU's L1)
+    const int wk = 0;
+#else
+    const int wk = st.k;
+#endif
     const uint4* p = reinterpret_cast<const uint4*>(a.w) +
-                     ((((int64_t)slice * kvol + st.k) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
+                     ((((int64_t)slice * kvol + wk) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
 #pragma unroll
