@@ -27,6 +27,7 @@
 // load, all waits are counted by hand (s_waitcnt vmcnt(n): the newest n may stay in flight).
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -376,7 +377,8 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
 #pragma unroll
       for (int pl = 0; pl < 2; ++pl) wf[t][pl] = p[(t * 2 + pl) * 64];
   };
-  uint4 wf[SP_NKC][TPW][2];  // the current step's weights, chunk by chunk; a chunk's registers take the NEXT step's as soon
+  typedef uint4 WSet[SP_NKC][TPW][2];
+  WSet wf;  // the current step's weights, chunk by chunk; a chunk's registers take the NEXT step's as soon
                              // as its MFMAs are issued (a rolling prefetch: no second buffer)
   // One cell's fragments of chunk kc: the cell's registers are re-read for chunk kc + 1 as soon as its MFMAs are issued (the
   // other cells' MFMAs cover the LDS latency), so one register set serves the whole step.
@@ -389,18 +391,18 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
     xl = xs[64];
   };
   // chunk kc of one cell; the first chunk starts the step's products from zero (no clearing pass over D)
-  auto mma_cell = [&](int kc, int g, const uint4& xh, const uint4& xl) {
+  auto mma_cell = [&](int kc, int g, const uint4& xh, const uint4& xl, uint4 (&wk)[TPW][2]) {
     const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh), bl = __builtin_bit_cast(sp_f16x8, xl);
 #ifdef SP_ABL_NO_MFMA
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
-      D[g][t][0] = (kc == 0 ? 0.0f : D[g][t][0]) + __uint_as_float(xh.x ^ wf[kc][t][0].x ^ xl.y ^ wf[kc][t][1].y);
+      D[g][t][0] = (kc == 0 ? 0.0f : D[g][t][0]) + __uint_as_float(xh.x ^ wk[t][0].x ^ xl.y ^ wk[t][1].y);
 #else
     sp_f16x8 wh[TPW], wl[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      wh[t] = __builtin_bit_cast(sp_f16x8, wf[kc][t][0]);
-      wl[t] = __builtin_bit_cast(sp_f16x8, wf[kc][t][1]);
+      wh[t] = __builtin_bit_cast(sp_f16x8, wk[t][0]);
+      wl[t] = __builtin_bit_cast(sp_f16x8, wk[t][1]);
     }
 #pragma unroll
     for (int t = 0; t < TPW; ++t)
@@ -416,7 +418,18 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   // The staging of the following steps rides inside: X(s+1) registers -> LDS and the X(s+2) gather are issued when the last
   // chunk's fragments have been requested, so the LDS queue (in order per wave) never has this step's reads behind the writes
   // and the writes retire under the last chunk's MFMAs (at the top of the step they cost a quarter of the layer).
-  auto compute = [&](const SpStep& st, const SpStep& nxt, const SpStep& nxt2, int slot, XStage& xs) {
+#ifndef SP_WD
+#define SP_WD 0
+#endif
+  // -DSP_WD=n (experiment, off): the first n chunks of a step's weights double-buffered and requested TWO steps ahead (set A in even
+  // steps, set B in odd ones, each refilled for step s + 2 behind its own MFMAs), the rest on the one-step rolling refill.  n = 2 fits the
+  // 128-channel variant's registers (254 VGPRs, no spills) and changes nothing (+-1 % per layer): the weight loads' distance is not what
+  // the kernel waits on either.  What did pay is the loop below running two steps per trip with the LDS slot and this parity as
+  // compile-time constants: -2.5 ... 3.5 % on every layer.
+  constexpr int WD = FIX ? (SP_WD < NKC ? SP_WD : NKC) : 0;
+  uint4 wf_b[WD > 0 ? WD : 1][TPW][2];
+  auto compute = [&](auto odd_tag, const SpStep& st, const SpStep& nxt, const SpStep& nxt2, int slot, XStage& xs) {
+    constexpr bool ODD = decltype(odd_tag)::value;
     const int nkc = FIX ? NKC : (st.src ? nkc1 : nkc0);
     const int nkc_nxt = FIX ? NKC : (nxt.src ? nkc1 : nkc0);
     uint4 xh[RG], xl[RG];
@@ -439,12 +452,13 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
 #pragma unroll
         for (int g = 0; g < RG; ++g)
           if ((st.mask >> g) & 1u) {
-            mma_cell(kc, g, xh[g], xl[g]);
+            mma_cell(kc, g, xh[g], xl[g], (ODD && kc < WD) ? wf_b[kc < WD ? kc : 0] : wf[kc]);
             if (kc + 1 < nkc) read_cell(slot, kc + 1, g, xh[g], xl[g]);
           }
       }
       // this chunk's weight registers take the next step's chunk as soon as its MFMAs are issued (a rolling prefetch)
-      if (kc < nkc_nxt) load_w(nxt, kc, wf[kc]);
+      if (kc < WD) load_w(nxt2, kc, ODD ? wf_b[kc < WD ? kc : 0] : wf[kc]);  // (two steps ahead, into the set this step has just used)
+      else if (kc < nkc_nxt) load_w(nxt, kc, wf[kc]);
     }
     // fold the step: this lane's row scale in every live cell
 #pragma unroll
@@ -471,7 +485,7 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
     if (kc < nkc0) load_w(s0, kc, wf[kc]);
   store_x(s0, 0, xs_a);
   SpStep s2 = advance(s1);
-#ifdef SP_DEEP
+#if defined(SP_DEEP)
   // X(s + 1) lives in set B for even s and in set A for odd s; when it has gone to LDS its set takes the gather of X(s + 3)
   load_x(s1, xs_b);
   load_x(s2, xs_a);
@@ -479,31 +493,52 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   int s = 0;
   for (; s + 1 < nsteps; s += 2) {
     __syncthreads();
-    compute(s0, s1, s3, 0, xs_b);
+    compute(std::false_type{}, s0, s1, s3, 0, xs_b);
     s0 = s1; s1 = s2; s2 = s3; s3 = advance(s3);
     __syncthreads();
-    compute(s0, s1, s3, 1, xs_a);
+    compute(std::true_type{}, s0, s1, s3, 1, xs_a);
     s0 = s1; s1 = s2; s2 = s3; s3 = advance(s3);
   }
   if (s < nsteps) {
     __syncthreads();
-    compute(s0, s1, s3, 0, xs_b);
+    compute(std::false_type{}, s0, s1, s3, 0, xs_b);
   }
 #else
   load_x(s1, xs_a);
-  for (int s = 0; s < nsteps; ++s) {
+  if (WD > 0) {
+#pragma unroll
+    for (int kc = 0; kc < WD; ++kc) load_w(s1, kc, wf_b[kc < WD ? kc : 0]);
+  }
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {  // (two steps per trip: the weight set of the leading chunks alternates at compile time)
 #ifndef SP_ABL_NO_BARRIER
     __syncthreads();
 #endif
-    const int par = s & 1;
 #ifdef SP_STAGE_EARLY
-    store_x(s1, par ^ 1, xs_a);  // X(s+1), loaded during the previous step
-    load_x(s2, xs_a);            // X(s+2)
+    store_x(s1, 1, xs_a);
+    load_x(s2, xs_a);
 #endif
-    compute(s0, s1, s2, par, xs_a);
-    s0 = s1;
-    s1 = s2;
-    s2 = advance(s2);
+    compute(std::false_type{}, s0, s1, s2, 0, xs_a);
+    s0 = s1; s1 = s2; s2 = advance(s2);
+#ifndef SP_ABL_NO_BARRIER
+    __syncthreads();
+#endif
+#ifdef SP_STAGE_EARLY
+    store_x(s1, 0, xs_a);
+    load_x(s2, xs_a);
+#endif
+    compute(std::true_type{}, s0, s1, s2, 1, xs_a);
+    s0 = s1; s1 = s2; s2 = advance(s2);
+  }
+  if (s < nsteps) {
+#ifndef SP_ABL_NO_BARRIER
+    __syncthreads();
+#endif
+#ifdef SP_STAGE_EARLY
+    store_x(s1, 1, xs_a);
+    load_x(s2, xs_a);
+#endif
+    compute(std::false_type{}, s0, s1, s2, 0, xs_a);
   }
 #endif
 
