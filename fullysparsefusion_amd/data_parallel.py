@@ -17,7 +17,10 @@ launched by tools/dist_train.sh:8-9 with one process per GPU).  Differences that
     its own all-reduces in between: RCCL pairs collectives by issue order PER COMMUNICATOR, so the buckets travel on
     their own process group (`dist.new_group`), never on the one the SyncBN statistics use;
   * gradient accumulation: `no_sync()` (as in DDP) keeps micro-batch gradients local; the first backward outside it
-    reduces the accumulated sum.  Only `zero_grad()` zeroes the buckets.
+    reduces the accumulated sum.  The buckets are cleared by `zero_grad()` — or by the optimizer's own
+    `zero_grad()`: with `set_to_none=False` it zeroes the views in place, with `set_to_none=True` (torch's default) it drops
+    `param.grad`, and the next forward / backward then zeroes that parameter's slice before re-pointing `param.grad` at it
+    (a dropped gradient means "cleared", never "resume from what the bucket last held").
 """
 import contextlib
 
@@ -105,8 +108,18 @@ class FrameDataParallel(torch.nn.Module):
                 b.flat.zero_()
             b.pending = len(b.params)
             b.work, b.launched = None, False
+            if not zero:
+                dropped = [v for p, v in zip(b.params, b.views) if p.grad is None]
+                if len(dropped) == len(b.params):
+                    b.flat.zero_()  # optimizer.zero_grad(set_to_none=True) on the whole bucket: one fill
+                else:
+                    for v in dropped:
+                        v.zero_()
             for p, v in zip(b.params, b.views):
-                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                if p.grad is None:
+                    p.grad = v
+                elif p.grad.data_ptr() != v.data_ptr():  # a gradient tensor the caller put there: keep its values
+                    v.copy_(p.grad)
                     p.grad = v
         self._armed = True
 

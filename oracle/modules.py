@@ -472,10 +472,14 @@ def refined_query(fsf, i_stage, lidar_img_feat, res_query_feat, obj_centers):
     return cluster_head_forward(fsf.frustum_refined_head[i_stage], query), query
 
 
-def get_bboxes_single(cfg, cls_logits, reg_preds, cluster_xyz, delta=1e-4):
+def get_bboxes_single(cfg, cls_logits, reg_preds, cluster_xyz, delta=1e-4, near_tol=1e-3):
     """FrustumClusterHead._get_bboxes_single (frustum_cluster_head.py:587-698), one sample / one task, nms_pre = -1:
     sigmoid scores, decode, per-class rotated BEV NMS (mmdet3d box3d_multiclass_nms), top max_num.  Returns
-    (row into the queries, score, label, smallest |IoU - thr| over every NMS decision taken)."""
+    (row into the queries, score, label, decoded boxes, margin).  `margin` = the smallest |IoU - thr| over the NMS decisions
+    that can reach the output: a class scan settles its boxes in descending score order and a box's fate depends only on
+    boxes scored above it, so when the `max_num` cut keeps scores >= s*, only decisions between boxes scored >= s* matter
+    (with ~1e4 boxes per class the scan takes ~1e6 decisions per class, of which some always sit within 1e-5 of the
+    threshold — far behind the cut).  Reported exactly below `near_tol`, as `near_tol` otherwise."""
     from . import refine as orefine
 
     scores = cls_logits.sigmoid()
@@ -483,21 +487,31 @@ def get_bboxes_single(cfg, cls_logits, reg_preds, cluster_xyz, delta=1e-4):
     bev = boxes[:, [0, 1, 3, 4, 6]].double().numpy()
     xyxyr = np.stack([bev[:, 0] - bev[:, 2] / 2, bev[:, 1] - bev[:, 3] / 2, bev[:, 0] + bev[:, 2] / 2,
                       bev[:, 1] + bev[:, 3] / 2, bev[:, 4]], 1)
-    rows, scs, labs, margin = [], [], [], np.inf
+    rows, scs, labs, close = [], [], [], []
     for c in range(scores.shape[1]):
         sel = torch.nonzero(scores[:, c] > cfg["score_thr"]).squeeze(1)
         if sel.numel() == 0:
             continue
         cand = sel[torch.argsort(scores[sel, c], descending=True, stable=True)]
-        keep, mg = orefine.nms_lazy(xyxyr[cand.numpy()], cfg["nms_thr"], rotated=cfg.get("use_rotate_nms", True))
-        margin = min(margin, mg)
+        keep, _, near = orefine.nms_lazy(xyxyr[cand.numpy()], cfg["nms_thr"], rotated=cfg.get("use_rotate_nms", True),
+                                         near_tol=near_tol)
+        if near.shape[0]:  # (score of the LATER box of the decision, distance from the threshold)
+            close.append(np.stack([scores[cand[near[:, 1].astype(np.int64)], c].double().numpy(), near[:, 2]], 1))
         rows.append(cand[keep])
         scs.append(scores[cand[keep], c])
         labs.append(torch.full((len(keep),), c, dtype=torch.long))
     if not rows:
-        return torch.zeros(0, dtype=torch.long), torch.zeros(0), torch.zeros(0, dtype=torch.long), boxes, margin
+        return torch.zeros(0, dtype=torch.long), torch.zeros(0), torch.zeros(0, dtype=torch.long), boxes, np.inf
     rows, scs, labs = torch.cat(rows), torch.cat(scs), torch.cat(labs)
+    cut = -np.inf
     if rows.numel() > cfg["max_num"]:
         top = torch.argsort(scs, descending=True, stable=True)[:cfg["max_num"]]
         rows, scs, labs = rows[top], scs[top], labs[top]
+        cut = float(scs.min())
+    margin = near_tol
+    if close:
+        close = np.concatenate(close)
+        reach = close[close[:, 0] >= cut]
+        if reach.shape[0]:
+            margin = float(reach[:, 1].min())
     return rows, scs, labs, boxes, margin

@@ -12,18 +12,26 @@ import numpy as np
 
 
 # ------------------------------------------------------------------------------------- K17 dynamic point pool
-def dynamic_point_pool(rois, pts, extra_wlh, max_inbox_point, max_all_pts=50000, return_margin=False):
+def dynamic_point_pool(rois, pts, extra_wlh, max_inbox_point, max_all_pts=50000, return_margin=False, near_tol=None,
+                       stop_at_cap=False):
     """rois [R,7] (cx,cy,cz_bottom,w,l,h,rz), pts [P,3] -> (pts_idx i64 [k], roi_idx i64 [k], feats f32 [k,13]) in
     ascending (roi, point) order, first `max_inbox_point` per roi, first `max_all_pts` overall
     (dynamic_point_pool_op.py:10-51 semantics with the atomics replaced by a canonical order).
     return_margin: also the distance of every kept (point, roi) decision from the nearest decision boundary, and the
-    same for the closest rejected pairs — lets tests skip pairs that sit within rounding of a box face."""
+    same for the closest rejected pairs — lets tests skip pairs that sit within rounding of a box face.
+    near_tol: keep only the margin rows closer than this to a face (the full table is [R * P, 3]: 79 GB at 10.6 k RoIs x
+    3.1e5 points).  stop_at_cap: leave the RoI loop once `max_all_pts` pairs are collected — the rows a later RoI would add
+    are cut by the final `[:max_all_pts]` anyway, so the result is the same (at the 10-sweep frame's 10.6 k RoIs the cap
+    is reached after a few hundred)."""
     rois = np.asarray(rois, dtype=np.float32)
     pts = np.asarray(pts, dtype=np.float32)
     ew, el, eh = [np.float32(v) for v in extra_wlh]
     out_p, out_r, out_f, near = [], [], [], []
     half = np.float32(0.5)
+    total = 0
     for r in range(rois.shape[0]):
+        if stop_at_cap and total >= max_all_pts:
+            break
         cx, cy, czb, w, l, h, rz = rois[r, :7]
         cz = czb + h * half
         rot = np.float32(rz + np.float32(np.pi / 2))
@@ -39,12 +47,14 @@ def dynamic_point_pool(rois, pts, extra_wlh, max_inbox_point, max_all_pts=50000,
         if return_margin:
             d_large = np.minimum.reduce([lhh - np.abs(lz), lhl - np.abs(lx), lhw - np.abs(ly)])
             d_box = np.minimum.reduce([hh - np.abs(lz), hl - np.abs(lx), hw - np.abs(ly)])
-            near.append(np.stack([np.full(pts.shape[0], r), np.arange(pts.shape[0]),
-                                  np.minimum(np.abs(d_large), np.abs(d_box))], 1))
+            mg = np.minimum(np.abs(d_large), np.abs(d_box))
+            sel = np.arange(pts.shape[0]) if near_tol is None else np.nonzero(mg < near_tol)[0]
+            near.append(np.stack([np.full(sel.shape[0], r, dtype=np.float64), sel.astype(np.float64), mg[sel].astype(np.float64)], 1))
         idx = np.nonzero(in_large)[0][:max_inbox_point]
         feats = np.stack([pts[idx, 0], pts[idx, 1], pts[idx, 2], lx[idx], ly[idx], lz[idx],
                           lx[idx] + hl, ly[idx] + hw, lz[idx] + hh, hl - lx[idx], hw - ly[idx], hh - lz[idx],
                           (~in_box[idx]).astype(np.float32)], 1).astype(np.float32)
+        total += idx.shape[0]
         out_p.append(idx)
         out_r.append(np.full(idx.shape[0], r, dtype=np.int64))
         out_f.append(feats)
@@ -118,6 +128,70 @@ def rotated_overlap(a, b):
     return 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
 
 
+def _corners_batch(b):
+    """[m, 5] (x1, y1, x2, y2, yaw) -> [m, 4, 2], the same expression as `_corners`."""
+    cx, cy = (b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2
+    c, s = np.cos(b[:, 4]), np.sin(b[:, 4])
+    out = np.empty((b.shape[0], 4, 2))
+    for k, (ix, iy) in enumerate(((0, 1), (2, 1), (2, 3), (0, 3))):
+        dx, dy = b[:, ix] - cx, b[:, iy] - cy
+        out[:, k, 0] = dx * c + dy * s + cx
+        out[:, k, 1] = -dx * s + dy * c + cy
+    return out
+
+
+def _inside_batch(poly, p, eps=1e-9):
+    """poly [m, 4, 2], p [m, q, 2] -> bool [m, q]: `_inside` for every (polygon, point) pair."""
+    a = poly[:, None, :, :]                                   # [m, 1, 4, 2]
+    b = np.roll(poly, -1, axis=1)[:, None, :, :]
+    cr = (b[..., 0] - a[..., 0]) * (p[:, :, None, 1] - a[..., 1]) - (b[..., 1] - a[..., 1]) * (p[:, :, None, 0] - a[..., 0])
+    live = np.abs(cr) >= eps
+    pos, neg = live & (cr > 0), live & (cr <= 0)
+    return ~(pos.any(-1) & neg.any(-1))
+
+
+def rotated_overlap_batch(a, b):
+    """`rotated_overlap(a, b[k])` for every row of b [m, 5], float64, the same recipe vectorised over the pairs: the 16 edge
+    intersections + the 8 contained corners as a masked candidate list, angular sort around the centroid of the valid
+    ones, shoelace.  Checked against the scalar function in tests/test_oracle_golden.py."""
+    b = np.asarray(b, dtype=np.float64).reshape(-1, 5)
+    m = b.shape[0]
+    if m == 0:
+        return np.zeros(0)
+    pb = _corners_batch(b)
+    pa = np.broadcast_to(_corners(a)[None], (m, 4, 2))
+    cand = np.zeros((m, 24, 2))
+    valid = np.zeros((m, 24), dtype=bool)
+    k = 0
+    for i in range(4):
+        p0, p1 = pa[:, i], pa[:, (i + 1) % 4]
+        d1 = p1 - p0
+        for j in range(4):
+            q0, q1 = pb[:, j], pb[:, (j + 1) % 4]
+            d2 = q1 - q0
+            den = d1[:, 0] * d2[:, 1] - d1[:, 1] * d2[:, 0]
+            ok = np.abs(den) >= 1e-14
+            sden = np.where(ok, den, 1.0)
+            t = ((q0[:, 0] - p0[:, 0]) * d2[:, 1] - (q0[:, 1] - p0[:, 1]) * d2[:, 0]) / sden
+            u = ((q0[:, 0] - p0[:, 0]) * d1[:, 1] - (q0[:, 1] - p0[:, 1]) * d1[:, 0]) / sden
+            ok &= (t >= 0.0) & (t <= 1.0) & (u >= 0.0) & (u <= 1.0)
+            cand[:, k] = p0 + t[:, None] * d1
+            valid[:, k] = ok
+            k += 1
+    cand[:, 16:20], valid[:, 16:20] = pa, _inside_batch(pb, pa)
+    cand[:, 20:24], valid[:, 20:24] = pb, _inside_batch(pa, pb)
+    cnt = valid.sum(1)
+    ctr = (cand * valid[..., None]).sum(1) / np.maximum(cnt, 1)[:, None]
+    ang = np.where(valid, np.arctan2(cand[..., 1] - ctr[:, None, 1], cand[..., 0] - ctr[:, None, 0]), np.inf)
+    order = np.argsort(ang, axis=1, kind="stable")
+    poly = np.take_along_axis(cand, order[..., None], axis=1)
+    pv = np.take_along_axis(valid, order, axis=1)
+    poly = np.where(pv[..., None], poly, poly[:, :1])  # the invalid tail collapses onto the first vertex: zero-area edges
+    x, y = poly[..., 0], poly[..., 1]
+    area = 0.5 * np.abs((x * np.roll(y, -1, axis=1)).sum(1) - (y * np.roll(x, -1, axis=1)).sum(1))
+    return np.where(cnt >= 3, area, 0.0)
+
+
 def iou_bev_matrix(boxes, rotated=True):
     boxes = np.asarray(boxes, dtype=np.float64)
     n = boxes.shape[0]
@@ -147,19 +221,22 @@ def nms_from_iou(iou, thresh):
     return np.array(keep, dtype=np.int64)
 
 
-def nms_lazy(boxes, thresh, rotated=True, delta=0.0):
+def nms_lazy(boxes, thresh, rotated=True, delta=0.0, near_tol=None):
     """Greedy NMS over boxes [n,5] (x1,y1,x2,y2,yaw) already in descending score order, evaluating the float64 IoU only for
     the pairs the greedy scan actually decides (kept box vs later, not yet removed box) and only when their circumscribed
     circles touch (otherwise the overlap is exactly 0).  Same keep set as nms_from_iou(iou_bev_matrix(boxes)) at a fraction
-    of the pair evaluations.  Also returns the smallest |IoU - thresh| over the decisions taken: if it exceeds the
-    perturbation an fp32 implementation can cause, the keep set is the only admissible answer."""
+    of the pair evaluations (one `rotated_overlap_batch` call per kept box).  Also returns the smallest |IoU - thresh| over
+    the decisions taken: if it exceeds the perturbation an fp32 implementation can cause, the keep set is the only
+    admissible answer.  With `near_tol` a third result lists the decisions closer than that to the threshold as rows
+    (kept box, later box, |IoU - thresh|): a caller that only needs a score prefix of the keep list can ignore close calls
+    among boxes behind it."""
     b = np.asarray(boxes, dtype=np.float64)
     n = b.shape[0]
     cx, cy = (b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2
     rad = 0.5 * np.hypot(b[:, 2] - b[:, 0], b[:, 3] - b[:, 1])
     area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
     removed = np.zeros(n, dtype=bool)
-    keep, margin = [], np.inf
+    keep, margin, close = [], np.inf, []
     for i in range(n):
         if removed[i]:
             continue
@@ -168,13 +245,21 @@ def nms_lazy(boxes, thresh, rotated=True, delta=0.0):
         if later.size == 0:
             continue
         near = later[np.hypot(cx[later] - cx[i], cy[later] - cy[i]) <= rad[later] + rad[i]]
-        for j in near:
-            if rotated:
-                ov = rotated_overlap(b[i], b[j])
-            else:
-                ov = max(min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0]), 0.0) * max(min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1]), 0.0)
-            iou = ov / max(area[i] + area[j] - ov, 1e-8)
-            margin = min(margin, abs(iou - thresh))
-            if iou > thresh:
-                removed[j] = True
-    return np.array(keep, dtype=np.int64), float(margin)
+        if near.size == 0:
+            continue
+        if rotated:
+            ov = rotated_overlap_batch(b[i], b[near])
+        else:
+            ov = np.maximum(np.minimum(b[i, 2], b[near, 2]) - np.maximum(b[i, 0], b[near, 0]), 0.0) * \
+                 np.maximum(np.minimum(b[i, 3], b[near, 3]) - np.maximum(b[i, 1], b[near, 1]), 0.0)
+        iou = ov / np.maximum(area[i] + area[near] - ov, 1e-8)
+        d = np.abs(iou - thresh)
+        margin = min(margin, float(d.min()))
+        if near_tol is not None:
+            for j in np.nonzero(d < near_tol)[0]:
+                close.append((i, int(near[j]), float(d[j])))
+        removed[near[iou > thresh]] = True
+    keep = np.array(keep, dtype=np.int64)
+    if near_tol is not None:
+        return keep, float(margin), np.array(close, dtype=np.float64).reshape(-1, 3)
+    return keep, float(margin)

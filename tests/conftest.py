@@ -60,6 +60,24 @@ def build_test_fsf():
     return model
 
 
+def build_av2_fsf():
+    """The Argoverse-2 detector (configs/fsf_av2.py = the model part of the reference's FSF_AV2_config.py) behind
+    tests/golden/av2_segmentor_150k.npz: fixed seed, BN running statistics away from (0, 1)."""
+    import torch
+
+    from fullysparsefusion_amd import mmdet3d_plugin
+    from fullysparsefusion_amd.compat import Config
+
+    torch.manual_seed(11)
+    cfg = Config.fromfile(os.path.join(ROOT, "configs", "fsf_av2.py"))
+    model = mmdet3d_plugin.build_model(cfg.model).eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    return model
+
+
 def param_checksum(model):
     """float64 sum of |p| over parameters and buffers: detects a model that differs from the one a golden was made with."""
     import torch

@@ -10,7 +10,10 @@ committed: data only (sampled rows of the expected tensors, full-tensor scales a
 checksum of the model so that a drifted random init is detected instead of silently compared).  The GPU test
 (tests/test_fullsize_gpu.py) runs the HIP path on the same frame and compares the same rows.
 
-    python tests/golden/make_fullsize_golden.py
+    python tests/golden/make_fullsize_golden.py            # stage1_10sweep.npz
+    python tests/golden/make_fullsize_golden.py av2        # av2_segmentor_150k.npz: BASELINE config 5's segmentor (VoteSegmentor.extract_feat,
+                                                           # single_stage_fsd.py:228-245, configs/Argoverse2/FSF_AV2_config.py:84-94 U-Net) on the
+                                                           # 150 k-point +-200 m frame `bench.py --dataset av2` times
 """
 import os
 import sys
@@ -24,7 +27,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from conftest import build_test_fsf, param_checksum  # noqa: E402
+from conftest import build_av2_fsf, build_test_fsf, param_checksum  # noqa: E402
 from fullysparsefusion_amd import synthetic  # noqa: E402
 from oracle import modules as omod  # noqa: E402
 
@@ -72,5 +75,32 @@ def main():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def main_av2():
+    model = build_av2_fsf()
+    f = synthetic.make_frame_av2(seed=0)
+    pts = torch.from_numpy(f["points"][:, :4].copy())
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ex = omod.segmentor_extract_feat(model.segmentor, [pts])
+    print(f"oracle AV2 segmentor on {pts.shape[0]} points: {time.perf_counter() - t0:.1f} s", flush=True)
+    n, m = pts.shape[0], ex["voxel_coors"].shape[0]
+    prow, vrow = sample_rows(n, N_ROWS, 3), sample_rows(m, N_ROWS, 4)
+    out = dict(
+        param_checksum=np.float64(param_checksum(model.segmentor)),
+        num_points=np.int64(n), num_voxels=np.int64(m), point_rows=prow, voxel_rows=vrow,
+        coors_rows=ex["coors"].numpy()[prow], coors_colsum=ex["coors"].numpy().astype(np.int64).sum(0),
+        voxel_coors_rows=ex["voxel_coors"].numpy()[vrow], voxel_coors_colsum=ex["voxel_coors"].numpy().astype(np.int64).sum(0),
+        inv_rows=ex["inv"].numpy()[prow], inv_sum=np.int64(ex["inv"].numpy().astype(np.int64).sum()),
+    )
+    for name, t, rows in [("voxel_feats", ex["voxel_feats"], vrow), ("unet", ex["unet"], vrow), ("neck", ex["neck"], prow)]:
+        a = t.numpy()
+        out[name + "_rows"] = a[rows]
+        out[name + "_scale"] = np.float32(np.abs(a).max())
+        out[name + "_abs_mean"] = np.float64(np.abs(a).astype(np.float64).mean())
+    path = os.path.join(HERE, "av2_segmentor_150k.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    main_av2() if "av2" in sys.argv[1:] else main()

@@ -138,6 +138,67 @@ def test_frame_data_parallel_gradient_allreduce_world2_gloo():
             assert np.array_equal(got[0][3][it][n], got[1][3][it][n]), (it, n)
 
 
+def _dp_optimizer_zero_grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullysparsefusion_amd.data_parallel import FrameDataParallel
+
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+        branch = torch.nn.Linear(6, 3)  # receives a gradient in the first iteration only
+        model = torch.nn.ModuleDict(dict(net=net, branch=branch))
+        dp = FrameDataParallel(model, bucket_mb=0.0005)
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)  # lr 0: the parameters stay put, iterations are comparable
+        torch.manual_seed(7)
+        x = torch.randn(2, 5, 6)[rank]
+        out = []
+        for it, set_to_none in enumerate([True, True, False, True]):
+            opt.zero_grad(set_to_none=set_to_none)  # the standard loop: NOT dp.zero_grad()
+            y = dp.module["net"](x)
+            if it == 0:
+                y = y + dp.module["branch"](x)
+            dp.backward((y ** 2).sum())
+            opt.step()
+            out.append({n: (None if p.grad is None else p.grad.numpy().copy()) for n, p in model.named_parameters()})
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_frame_data_parallel_with_the_optimizers_own_zero_grad_world2_gloo():
+    """a standard loop clears gradients with `optimizer.zero_grad()` (set_to_none=True by default), which
+    drops `param.grad`; the wrapper must then start the next backward from zeros, not from the averaged gradient the bucket
+    still holds — also for parameters that receive no gradient in that step (they ship zeros, not last step's values)."""
+    import numpy as np
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_optimizer_zero_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=90) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    out = got[0][1]
+    for n in out[1]:
+        if n.startswith("net."):
+            # iterations 1..3 compute the same thing: no carry-over from the previous step in any zeroing mode
+            for it in (2, 3):
+                assert np.array_equal(out[1][n], out[it][n]), (n, it)
+            assert np.abs(out[1][n]).max() > 0
+        else:
+            assert np.abs(out[0][n]).max() > 0       # the branch had a gradient in iteration 0 ...
+            for it in (1, 2, 3):
+                assert not np.any(out[it][n]), (n, it)  # ... and ships zeros afterwards, not iteration 0's average
+    for it in range(4):
+        for n in out[it]:
+            assert np.array_equal(out[it][n], got[1][1][it][n])
+
+
 # ------------------------------------------------- bucket collectives vs SyncBN collectives on a data-dependent graph
 def _dp_syncbn_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

@@ -10,8 +10,15 @@ final boxes (VERDICT r1 "What's missing" 1):
     sampled rows, with the fused BN-affine / residual / ReLU epilogue;
   * K22 at 510 652 rows, the SIR stack at 5e5 points with a 1.2e5-row segment (long-segment fold);
   * heads -> combine_frustum_and_fsd -> each_stage_refine -> get_bboxes chained on the GPU and compared with the oracle chain
-    (FSF.py:1144-1178, frustum_cluster_head.py:503-698): pre-NMS boxes / scores within 1e-4, final boxes / scores / labels
-    exactly the oracle's when no NMS decision sits within 1e-4 of the IoU threshold.
+    (FSF.py:1144-1178, frustum_cluster_head.py:503-698) on the 1-sweep AND the 10-sweep frame (10.6 k RoIs x 3.1e5 points
+    through the cell-binned pooling, 10.4 k boxes per class through the capped / windowed multi-class NMS): pre-NMS boxes /
+    scores within 1e-4, final boxes / scores / labels exactly the oracle's when no NMS decision that can reach the output
+    sits within 1e-5 of the IoU threshold;
+  * the BACKWARD of the path at 10 sweeps: one training-mode forward + backward of stages 1-3 with every autograd node of the
+    HIP path (sparse-conv data / weight gradient, LayerNorm / BatchNorm + activation backward, per-point Linear products and
+    weight gradients, segmented-reduce and gather adjoints) checked in situ against float64; the same with two frames per
+    GPU (BASELINE config 4 on one rank);
+  * the Argoverse-2 segmentor at 150 k points against a committed sampled-row oracle fixture.
 """
 import copy
 
@@ -19,7 +26,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import build_test_fsf, load_golden, param_checksum
+from conftest import build_av2_fsf, build_test_fsf, load_golden, param_checksum
 from oracle import modules as omod
 
 pytestmark = pytest.mark.gpu
@@ -296,15 +303,38 @@ def test_sir_stack_at_half_a_million_points_with_a_long_segment(fsf_pair, device
 
 
 # ------------------------------------------------------------- heads -> combine -> refine -> get_bboxes, chained
-def test_final_boxes_vs_oracle_chain(fsf_pair, frame1, device, monkeypatch):
-    """FSF.simple_test from the query features to the boxes it returns (FSF.py:1144-1178).  The GPU runs the whole forward;
-    the oracle chain restarts from the GPU's query features (the SIR stages upstream are ill-conditioned, see
-    test_fsf_hot_path_vs_oracle) and at each discontinuity (RoI membership of a point, an NMS decision) takes the GPU's
-    inputs to that decision, so that a difference there is the kernel's, not an upstream rounding."""
+def _compare_pool(got, want, near, tol=1e-5):
+    """RoI point pooling result (point idx, roi idx, 13 floats) in canonical (roi, point) order against the oracle's.
+    Membership of a point within `tol` of a box face may differ (fp32 sin / cos of the box yaw); behind such a pair the
+    per-RoI and overall caps shift every later row, so the lists are compared exactly up to the first close call (the whole
+    list when there is none)."""
+    (g_inds, g_roi, g_f), (wp, wr, wf) = got, want
+    n = len(wp)
+    bad = near[near[:, 2] < tol] if len(near) else near
+    if len(bad):
+        first = bad[np.lexsort((bad[:, 1], bad[:, 0]))[0]]
+        n = int(np.searchsorted(wr * (1 << 32) + wp, int(first[0]) * (1 << 32) + int(first[1])))
+    else:
+        assert len(g_inds) == len(wp)
+    np.testing.assert_array_equal(g_inds[:n], wp[:n])
+    np.testing.assert_array_equal(g_roi[:n], wr[:n])
+    np.testing.assert_allclose(g_f[:n], wf[:n, 3:], atol=1e-5)
+    return n
+
+
+@pytest.mark.parametrize("which", ["frame1", "frame10"])
+def test_final_boxes_vs_oracle_chain(fsf_pair, which, request, device, monkeypatch):
+    """FSF.simple_test from the query features to the boxes it returns (FSF.py:1144-1178), on the 1-sweep frame AND on the
+    10-sweep frame bench.py times (10.4 k queries -> 10.6 k RoIs against 3.1e5 points through the cell-binned
+    `fsf_dynamic_point_pool`, 10.4 k boxes per class through `fsf_nms_bev_multiclass_capped` with windowed masks).  The GPU
+    runs the whole forward; the oracle chain restarts from the GPU's query features (the SIR stages upstream are
+    ill-conditioned, see test_fsf_hot_path_vs_oracle) and at each discontinuity (RoI membership of a point, an NMS decision)
+    takes the GPU's inputs to that decision, so that a difference there is the kernel's, not an upstream rounding."""
     from oracle import refine as orefine
 
     model, cpu = fsf_pair
-    pts, metas, mask, anno = to_dev(frame1, device)
+    frame = request.getfixturevalue(which)
+    pts, metas, mask, anno = to_dev(frame, device)
     cap = {}
 
     def tap(obj, name, key):
@@ -350,16 +380,13 @@ def test_final_boxes_vs_oracle_chain(fsf_pair, frame1, device, monkeypatch):
         (xyz_in, bidx_in, rois_in), _, (g_inds, g_roi_inds, g_info) = cap["roi"]
         close(rois_in, rois[:, :8], 1e-5)
         rois_g = c(rois_in).numpy()
-        wp, wr, wf, margins = orefine.dynamic_point_pool(rois_g[:, 1:], c(xyz_in).numpy(), model.roi_extractor.extra_wlh,
-                                                         model.roi_extractor.max_inbox_point, model.roi_extractor.max_all_pts,
-                                                         return_margin=True)
-        pool_exact = not (margins[:, 2] < 1e-5).any()
-        if pool_exact:
-            np.testing.assert_array_equal(c(g_inds).numpy(), wp)
-            np.testing.assert_array_equal(c(g_roi_inds).numpy(), wr)
-            np.testing.assert_allclose(np.concatenate([c(v).numpy().reshape(len(wp), -1) for v in
-                                                       (g_info["local_xyz"], g_info["boundary_offset"], g_info["is_in_margin"])], 1),
-                                       wf[:, 3:], atol=1e-5)
+        ext = model.roi_extractor
+        wp, wr, wf, near = orefine.dynamic_point_pool(rois_g[:, 1:], c(xyz_in).numpy(), ext.extra_wlh, ext.max_inbox_point,
+                                                      ext.max_all_pts, return_margin=True, near_tol=1e-3, stop_at_cap=True)
+        g13 = np.concatenate([c(v).numpy().reshape(len(g_inds), -1) for v in
+                              (g_info["local_xyz"], g_info["boundary_offset"], g_info["is_in_margin"])], 1)
+        n_pool_exact = _compare_pool((c(g_inds).numpy(), c(g_roi_inds).numpy(), g13), (wp, wr, wf), near)
+        assert n_pool_exact >= min(len(wp), 1000), (n_pool_exact, len(wp))
         # refine SIR on the GPU's pooling result, query update, refined head
         obj_id = c(model.points_in_mask(pts[0][:, 5:8].contiguous(), mask[0], metas[0]["lidar2img"]))
         g_info13 = torch.cat([c(xyz_in)[c(g_inds)], c(g_info["local_xyz"]), c(g_info["boundary_offset"]),
@@ -378,8 +405,8 @@ def test_final_boxes_vs_oracle_chain(fsf_pair, frame1, device, monkeypatch):
     gb, gs, gl = g_boxes[0]
     assert len(res) == 1 and res[0]["boxes_3d"].tensor.shape[0] == gb.tensor.shape[0] > 0
     assert torch.equal(res[0]["boxes_3d"].tensor, c(gb.tensor)) and torch.equal(res[0]["scores_3d"], c(gs))
-    if margin > 1e-5:  # no NMS decision within rounding of the IoU threshold: the oracle's answer is the only admissible one
-        assert gb.tensor.shape[0] == rows.numel()
+    if margin > 1e-5:  # no NMS decision that can reach the output sits within rounding of the IoU threshold: the oracle's
+        assert gb.tensor.shape[0] == rows.numel()  # answer is the only admissible one
         np.testing.assert_array_equal(c(gl).numpy(), labs.numpy())
         close(gs, scs, 1e-6)
         close(gb.tensor, boxes[rows], 1e-6)
@@ -387,4 +414,48 @@ def test_final_boxes_vs_oracle_chain(fsf_pair, frame1, device, monkeypatch):
         dec = boxes.numpy()
         d = np.abs(c(gb.tensor).numpy()[:, None, :7] - dec[None, :, :7]).max(-1)
         assert float(d.min(1).max()) < 1e-5
-    assert rows.numel() > 0 and len(cap["roi"][2][0]) > 100
+    assert rows.numel() > 0 and len(g_inds) > 100
+    if which == "frame10":  # the sizes the docs quote
+        assert rois_g.shape[0] > 8000 and len(g_inds) == ext.max_all_pts and b_cls[0].shape[0] > 8000
+
+
+# ------------------------------------------------------------------ Argoverse-2 segmentor at 150 k points (config 5)
+def test_av2_segmentor_at_150k_points_vs_oracle(device):
+    """BASELINE config 5's segmentor (VoteSegmentor.extract_feat: dynamic voxelization on the 2048 x 2048 x 32 grid, 4-d
+    DynamicScatterVFE, the 4-stage 64-channel SimpleSparseUNet of configs/Argoverse2/FSF_AV2_config.py:84-94, neck) on the
+    150 k-point +-200 m frame `bench.py --dataset av2` times: against the oracle run in the test on every row, and against the
+    committed sampled-row fixture (tests/golden/av2_segmentor_150k.npz, written by make_fullsize_golden.py av2 in the build
+    container) so that the in-test oracle itself is pinned to what was reviewed."""
+    from fullysparsefusion_amd import synthetic
+    g = load_golden("av2_segmentor_150k.npz")
+    model = build_av2_fsf()
+    cpu = copy.deepcopy(model.segmentor)
+    if abs(param_checksum(cpu) - float(g["param_checksum"])) > 1e-6 * float(g["param_checksum"]):
+        pytest.fail("regenerate tests/golden/av2_segmentor_150k.npz (python tests/golden/make_fullsize_golden.py av2)")
+    seg = model.segmentor.to(device)
+    f = synthetic.make_frame_av2(seed=0)
+    pts = torch.from_numpy(f["points"][:, :4].copy())
+    assert pts.shape[0] == int(g["num_points"]) >= 149000
+    with torch.no_grad():
+        ex = omod.segmentor_extract_feat(cpu, [pts])
+        p_dev, coors = seg.voxelize([pts.to(device)])
+        vf, vc, inv = seg.voxel_encoder(p_dev, coors, return_inv=True)
+        unet = seg.backbone(dict(voxel_feats=vf, voxel_coors=vc, batch_size=1))[0]["voxel_feats"]
+        (neck, mask), coors2, _ = seg.extract_feat([pts.to(device)], None)
+    # integer structure: exact, everywhere
+    np.testing.assert_array_equal(coors.cpu().numpy(), ex["coors"].numpy())
+    np.testing.assert_array_equal(vc.cpu().numpy(), ex["voxel_coors"].numpy())
+    np.testing.assert_array_equal(inv.cpu().numpy(), ex["inv"].numpy())
+    assert int(ex["coors"][:, 3].max()) > 1900 and int(ex["coors"][:, 2].max()) > 1900 and bool(mask.all())
+    close(vf, ex["voxel_feats"])
+    close(unet, ex["unet"])
+    close(neck, ex["neck"])
+    # the committed fixture
+    prow, vrow = torch.from_numpy(g["point_rows"]).to(device), torch.from_numpy(g["voxel_rows"]).to(device)
+    assert vc.shape[0] == int(g["num_voxels"])
+    np.testing.assert_array_equal(vc.long().sum(0).cpu().numpy(), g["voxel_coors_colsum"])
+    np.testing.assert_array_equal(vc[vrow].cpu().numpy(), g["voxel_coors_rows"])
+    np.testing.assert_array_equal(coors[prow].cpu().numpy(), g["coors_rows"])
+    assert int(inv.long().sum()) == int(g["inv_sum"])
+    for name, t, rows in [("voxel_feats", vf, vrow), ("unet", unet, vrow), ("neck", neck, prow)]:
+        close(t[rows], torch.from_numpy(g[name + "_rows"]), 1e-4, scale=float(g[name + "_scale"]))

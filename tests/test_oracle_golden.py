@@ -92,3 +92,48 @@ def test_sparse_connected_components_equal_the_dense_reference_call():
         want = connected_components((d < dist).numpy(), directed=False)[1]
         np.testing.assert_array_equal(got.numpy(), want)
         assert 10 < want.max() < n - 10
+
+
+# ------------------------------------------------------------- the oracle's own fast paths against its plain ones
+def test_oracle_rotated_overlap_batch_equals_scalar():
+    """`rotated_overlap_batch` / the vectorised `nms_lazy` (what makes the 10 k-box-per-class oracle NMS of the 10-sweep frame
+    affordable) against the scalar intersect-and-sort polygon and the all-pairs greedy NMS they restate."""
+    from oracle import refine as R
+
+    rng = np.random.default_rng(0)
+    n = 300
+    c, wl, yaw = rng.uniform(-8, 8, (n, 2)), rng.uniform(0.5, 5, (n, 2)), rng.uniform(-4, 4, n)
+    b = np.stack([c[:, 0] - wl[:, 0] / 2, c[:, 1] - wl[:, 1] / 2, c[:, 0] + wl[:, 0] / 2, c[:, 1] + wl[:, 1] / 2, yaw], 1)
+    b[1] = b[0]                       # identical boxes
+    b[2, 4] = b[3, 4] = 0.0           # axis-aligned
+    b[4] = b[2]
+    b[4, [0, 2]] += 0.5               # shifted copy: collinear edges
+    b[5] = b[2]
+    b[5, [0, 2]] += b[2, 2] - b[2, 0]  # touching along an edge
+    for i in range(12):
+        got = R.rotated_overlap_batch(b[i], b)
+        want = np.array([R.rotated_overlap(b[i], b[j]) for j in range(n)])
+        np.testing.assert_allclose(got, want, atol=1e-11)
+    assert R.rotated_overlap_batch(b[0], np.zeros((0, 5))).shape == (0,)
+    keep, margin, close = R.nms_lazy(b, 0.2, near_tol=1e-2)
+    assert np.array_equal(keep, R.nms_from_iou(R.iou_bev_matrix(b), 0.2))
+    assert margin <= close[:, 2].min() + 1e-15 if len(close) else margin >= 1e-2
+    keep_a, _ = R.nms_lazy(b, 0.3, rotated=False)
+    assert np.array_equal(keep_a, R.nms_from_iou(R.iou_bev_matrix(b, rotated=False), 0.3))
+
+
+def test_oracle_point_pool_stop_at_cap_is_the_plain_result():
+    from oracle import refine as R
+
+    rng = np.random.default_rng(1)
+    pts = rng.uniform(-10, 10, (4000, 3)).astype(np.float32)
+    rois = np.concatenate([rng.uniform(-8, 8, (40, 2)), rng.uniform(-3, 0, (40, 1)), rng.uniform(1, 4, (40, 3)),
+                           rng.uniform(-3, 3, (40, 1))], 1).astype(np.float32)
+    for cap in (50, 400, 100000):
+        a = R.dynamic_point_pool(rois, pts, [1.0, 1.0, 1.0], 64, cap)
+        b = R.dynamic_point_pool(rois, pts, [1.0, 1.0, 1.0], 64, cap, stop_at_cap=True)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    full = R.dynamic_point_pool(rois, pts, [1.0, 1.0, 1.0], 64, 100000, return_margin=True)[3]
+    near = R.dynamic_point_pool(rois, pts, [1.0, 1.0, 1.0], 64, 100000, return_margin=True, near_tol=0.05)[3]
+    np.testing.assert_array_equal(near, full[full[:, 2] < 0.05])
