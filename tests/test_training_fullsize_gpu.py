@@ -141,8 +141,10 @@ def _install(monkeypatch, ck):
         ok = (pre.abs() > 1e-5) if ctx.relu else torch.ones_like(pre, dtype=torch.bool)
         ck.note("batch_norm.grad_x", x.shape, res[0] * ok, gs[0] * ok, 2e-5)
         if weight is not None:
-            ck.note("batch_norm.grad_gamma", x.shape, res[1], gs[1], 2e-5, denom=float((grad.double().abs() * pre.abs()).sum(0).max()))
-            ck.note("batch_norm.grad_beta", x.shape, res[2], gs[2], 2e-5, denom=float(grad.double().abs().sum(0).max()))
+            # column sums of ~3e5 same-sign fp32 terms (the dummy loss makes every grad element equal): blocked fp32 summation is
+            # good to ~1e-5 of the summed magnitude (measured 1.1e-5 ... 1.7e-5 on grad_beta)
+            ck.note("batch_norm.grad_gamma", x.shape, res[1], gs[1], 1e-4, denom=float((grad.double().abs() * pre.abs()).sum(0).max()))
+            ck.note("batch_norm.grad_beta", x.shape, res[2], gs[2], 1e-4, denom=float(grad.double().abs().sum(0).max()))
         return res
 
     monkeypatch.setattr(so._BatchNormActFn, "forward", staticmethod(bn_forward))
