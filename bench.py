@@ -323,18 +323,16 @@ def instrumented_pass(model, pool, steps, hot_path_only):
     # beside the small deep levels and an event pair on one stream brackets time its kernel shares with the other stream's —
     # the frame gets shorter while every overlapped launch looks longer.  (profiles/*_kernel_stats_full_forward_serial_unet.txt is
     # the rocprofv3 summary of the same setting.)
-    prev = os.environ.get("FSF_UNET_LATERAL_STREAM")
-    os.environ["FSF_UNET_LATERAL_STREAM"] = "0"
+    from fullysparsefusion_amd import switches
+
+    prev, switches.UNET_LATERAL_STREAM = switches.UNET_LATERAL_STREAM, False
     try:
         for i in range(steps):
             step(model, pool[i % len(pool)], hot_path_only)
         torch.cuda.synchronize()
     finally:
         p.restore()
-        if prev is None:
-            os.environ.pop("FSF_UNET_LATERAL_STREAM", None)
-        else:
-            os.environ["FSF_UNET_LATERAL_STREAM"] = prev
+        switches.UNET_LATERAL_STREAM = prev
     conv = p.table()
     q = _Probe("capture")
     q.wrap(hip_ops, "segment_reduce", _acc_seg_reduce)

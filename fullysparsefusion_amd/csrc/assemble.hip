@@ -57,18 +57,22 @@ __device__ __forceinline__ bool as_row(const AsArgs& a, int64_t i, int s, float 
   return true;
 }
 
+// The functors hold a POINTER to the argument block (a copy in the workspace): by value the block (~1.9 KB: 16 sweeps x 13
+// doubles) rode in the kernel arguments twice (In and Out), ~3.9 KB against the 4 KB kernarg limit.
 struct AsIn {
-  AsArgs a;
+  const AsArgs* ap;
   __device__ uint32_t operator()(int64_t i) const {
+    const AsArgs& a = *ap;
     float xyz[3];
     return as_row(a, i, as_sweep_of(a, i), xyz) ? 1u : 0u;
   }
 };
 
 struct AsOut {
-  AsArgs a;
+  const AsArgs* ap;
   __device__ void operator()(int64_t i, uint32_t pos, uint32_t keep) const {
     if (!keep) return;
+    const AsArgs& a = *ap;
     const int s = as_sweep_of(a, i);
     float xyz[3];
     as_row(a, i, s, xyz);
@@ -90,7 +94,9 @@ struct AsOut {
 
 using namespace fsf;
 
-extern "C" int64_t fsf_assemble_sweeps_workspace_bytes(int64_t n_rows) { return fsf_align_up(scan_num_tiles(n_rows) * 4, 256) + 256; }
+extern "C" int64_t fsf_assemble_sweeps_workspace_bytes(int64_t n_rows) {
+  return fsf_align_up(scan_num_tiles(n_rows) * 4, 256) + 256 + fsf_align_up((int64_t)sizeof(AsArgs), 256);
+}
 
 extern "C" int fsf_assemble_sweeps(const float* raw, int64_t n_rows, int32_t load_dim, const int64_t* sweep_offsets, int32_t num_sweeps,
                                    const double* sweep_params, const uint8_t* sweep_transform, const uint8_t* sweep_remove_close,
@@ -120,9 +126,11 @@ extern "C" int fsf_assemble_sweeps(const float* raw, int64_t n_rows, int32_t loa
   FsfArena arena(workspace, workspace_bytes);
   uint32_t* tile_sums = arena.take<uint32_t>(scan_num_tiles(n_rows));
   int64_t* total = arena.take<int64_t>(1);
+  AsArgs* a_dev = reinterpret_cast<AsArgs*>(arena.take<char>((int64_t)sizeof(AsArgs)));
   if (!arena.ok()) return FSF_ERR_WORKSPACE;
   int64_t* tot = count_dev ? count_dev : total;
-  int rc = exclusive_scan_u32(AsIn{a}, AsOut{a}, n_rows, tile_sums, nullptr, tot, stream);
+  FSF_HIP_TRY(hipMemcpyAsync(a_dev, &a, sizeof(AsArgs), hipMemcpyHostToDevice, stream));  // (pageable source: staged before the call returns)
+  int rc = exclusive_scan_u32(AsIn{a_dev}, AsOut{a_dev}, n_rows, tile_sums, nullptr, tot, stream);
   if (rc != FSF_OK) return rc;
   if (count_host) {
     FSF_HIP_TRY(hipMemcpyAsync(count_host, tot, sizeof(int64_t), hipMemcpyDeviceToHost, stream));

@@ -20,6 +20,7 @@
 #include "scan.h"
 
 namespace fsf {
+extern std::atomic<int64_t> g_opt_pool_brute;  // status.hip
 
 constexpr int PP_TILE = 2048;
 constexpr int PP_FEAT = 13;
@@ -515,8 +516,7 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
                extra_wlh[0], extra_wlh[1], extra_wlh[2], (int)max_inbox_point, max_all_pts, cnt, roi_total, roi_off,
                out_pts_idx, out_roi_idx, out_pts_feats, 0, 0, chunk_total};
     if (!arena.ok()) return FSF_ERR_WORKSPACE;
-    const char* brute_env = getenv("FSF_POOL_BRUTE");  // (read per call: tests compare the two paths in one process)
-    const bool brute = brute_env && atoi(brute_env) != 0;
+    const bool brute = g_opt_pool_brute.load(std::memory_order_relaxed) != 0;  // (fsf_set_option: tests compare the two paths in one process)
     if (!brute && max_inbox_point <= PB_CAP) {
       uint32_t* hits_full = arena.take<uint32_t>(r1);
       uint64_t* keys_a = arena.take<uint64_t>(n_pts);
@@ -541,7 +541,7 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
       PoolBinArgs b{a, order, sorted, cell_start, cell_end, hits_full};
       const unsigned wg = (unsigned)((n_rois + 3) / 4);
       hipLaunchKernelGGL(pb_count_kernel, dim3(wg), dim3(256), 0, stream, b);
-      rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums, total, nullptr, stream);
+      rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums, total, nullptr, stream, (int64_t)max_inbox_point);
       if (rc != FSF_OK) return rc;
       hipLaunchKernelGGL(pb_fill_kernel, dim3(wg), dim3(256), 0, stream, b);
       hipLaunchKernelGGL(pool_count_kernel, dim3(1), dim3(1), 0, stream, total, max_all_pts, cdev);
@@ -565,7 +565,7 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
     a.group0 = 0;
     a.chunk = 0;
     const dim3 grid((unsigned)groups, (unsigned)pt_tiles);
-    int rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums, total, nullptr, stream);
+    int rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums, total, nullptr, stream, (int64_t)max_inbox_point);
     if (rc != FSF_OK) return rc;
     hipLaunchKernelGGL((pool_pass_kernel<true>), grid, dim3(256), 0, stream, a);
     hipLaunchKernelGGL(pool_count_kernel, dim3(1), dim3(1), 0, stream, total, max_all_pts, cdev);

@@ -158,10 +158,14 @@ __global__ void __launch_bounds__(SC_THREADS)
 }
 
 // tile_sums: u32[scan_num_tiles(n)] scratch.
+// max_item: an upper bound of every scanned value (1 for flag scans).  The one-launch look-back form carries running totals in 30
+// bits next to the 2 flag bits of a status word, so it is taken only when n * max_item cannot reach 2^30; beyond that the
+// three-launch form (32-bit sums) runs.
 template <class In, class Out>
 static inline int exclusive_scan_u32(In in, Out out, int64_t n, uint32_t* tile_sums, uint32_t* total_u32,
-                                     int64_t* total_i64, hipStream_t stream) {
-  if (n < (int64_t)SC_VALUE_MASK) {  // (every value is 0 or 1 in this library's scans except the RoI totals, which are capped)
+                                     int64_t* total_i64, hipStream_t stream, int64_t max_item = 1) {
+  if (max_item < 1) max_item = 1;
+  if (n < (int64_t)SC_VALUE_MASK / max_item) {
     const int64_t tiles = scan_grid_tiles(n);
     if (hipMemsetAsync(tile_sums, 0, (size_t)(tiles + 1) * 4, stream) != hipSuccess) return FSF_ERR_HIP;
     hipLaunchKernelGGL((scan_lookback_kernel<In, Out>), dim3((unsigned)tiles), dim3(SC_THREADS), 0, stream, in, out, n, tile_sums,

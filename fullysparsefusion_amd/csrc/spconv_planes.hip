@@ -43,6 +43,10 @@ constexpr int SP_NSLOT = 2;      // gathered-row ring in LDS: step s is multipli
 constexpr int SP_KVOL_MAX = 27;
 constexpr int SP_HDR_BYTES = 256;  // weight-plane header: [0] inverse weight scale, [1] weight scale, [2] max |w| bits
 
+// Which 8-wide k group of a 32-cin chunk lane group q = lane / 16 multiplies: sigma = (0, 3, 1, 2).  The MFMA sums over k, so any
+// assignment works as long as the weight fragments (sp_weight_planes_kernel) and the X fragments agree; THIS one makes K9d's
+// row-major LDS tile (written by line-coalesced gathers, swizzled per row) readable by ds_read_b128 without bank conflicts.
+__device__ __forceinline__ int sp_kgroup(int q) { return (0x9C >> (2 * q)) & 3; }
 // power of two s with s * amax in [2^13, 2^14); inv = 1 / s (both exact)
 __device__ __forceinline__ void sp_pick_scale(float amax, float& s, float& inv) {
   int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(256)
     const int k = (int)(r % kvol);
     const int slice = (int)(r / kvol);
     const int col = slice * 64 * tpw + wave * 16 * tpw + 16 * t + (lane & 15);
-    const int c0 = c * 32 + 8 * (lane >> 4);
+    const int c0 = c * 32 + 8 * sp_kgroup(lane >> 4);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = col < cout ? w[((int64_t)k * cin + c0 + e) * cout + col] : 0.0f;
@@ -180,6 +184,90 @@ struct SpArgs {
   uint4* out_planes;
   float* out_scales;
 };
+
+// ---- epilogue shared by the forward kernels: lane (j, q) holds channels chw + 16 t + 4 q + r of rows row0 + 16 g + j.
+// BN affine, residual, ReLU, fp32 store and — when the consumer is another plane kernel — the output planes (row-chunk
+// absmax across the four waves through `rowmax`, scale pick, split, 32-byte stores) plus the zero row.
+template <int RG, int TPW>
+__device__ __forceinline__ void sp_epilogue(const SpArgs& a, sp_f32x4 (&acc)[RG][TPW], const float* vec, float* rowmax, int64_t row0,
+                                            int slice, int wave, int tid) {
+  constexpr int R = 16 * RG;
+  const int lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int chw = slice * 64 * TPW + wave * 16 * TPW;
+  const bool affine = a.scale || a.shift;
+  float amax[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const int64_t row = row0 + 16 * g + j;
+    amax[g] = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int chl = wave * 16 * TPW + 16 * t + 4 * q;  // channel within the slice
+      const int ch = slice * 64 * TPW + chl;
+      sp_f32x4 y = acc[g][t];
+      if (affine) {
+        const float4 sc = *reinterpret_cast<const float4*>(vec + chl);
+        const float4 sh = *reinterpret_cast<const float4*>(vec + 64 * TPW + chl);
+        y[0] = __fmaf_rn(y[0], sc.x, sh.x); y[1] = __fmaf_rn(y[1], sc.y, sh.y);
+        y[2] = __fmaf_rn(y[2], sc.z, sh.z); y[3] = __fmaf_rn(y[3], sc.w, sh.w);
+      }
+      if (row < a.m_out && ch < a.cout) {
+        if (a.residual) {
+          const float4 rs = *reinterpret_cast<const float4*>(a.residual + row * a.cout + ch);
+          y[0] = __fadd_rn(y[0], rs.x); y[1] = __fadd_rn(y[1], rs.y); y[2] = __fadd_rn(y[2], rs.z); y[3] = __fadd_rn(y[3], rs.w);
+        }
+        if (a.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
+        if (a.out) *reinterpret_cast<float4*>(a.out + row * a.cout + ch) = make_float4(y[0], y[1], y[2], y[3]);
+      } else {
+        y = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      acc[g][t] = y;
+      amax[g] = fmaxf(amax[g], fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+    }
+  }
+  if (a.out_planes) {  // the output as planes for the next convolution: row scale over this 64*TPW-channel slice
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      float m = amax[g];
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (q == 0) rowmax[wave * R + 16 * g + j] = m;
+    }
+    __syncthreads();
+    const int nchunk_out = (a.cout + 64 * TPW - 1) / (64 * TPW);
+    const int blocks_per_row = a.cout / 8;
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      const int64_t row = row0 + 16 * g + j;
+      const int rl = 16 * g + j;
+      const float m = fmaxf(fmaxf(rowmax[rl], rowmax[R + rl]), fmaxf(rowmax[2 * R + rl], rowmax[3 * R + rl]));
+      float sc, inv_s;
+      sp_pick_scale(m, sc, inv_s);
+      if (row < a.m_out) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int ch = chw + 16 * t + 4 * q;
+          if (ch < a.cout) {
+            const float v4[4] = {acc[g][t][0], acc[g][t][1], acc[g][t][2], acc[g][t][3]};
+            sp_u32x2 hi, lo;
+            sp_split4(v4, sc, hi, lo);
+            char* dst = reinterpret_cast<char*>(a.out_planes + (row * blocks_per_row + (ch >> 3)) * 2) + (q & 1) * 8;
+            *reinterpret_cast<sp_u32x2*>(dst) = hi;
+            *reinterpret_cast<sp_u32x2*>(dst + 16) = lo;
+          }
+        }
+        if (wave == 0 && q == 0) a.out_scales[row * nchunk_out + slice] = inv_s;
+      }
+    }
+    if (blockIdx.x == gridDim.x - 1) {  // the zero row (kept for consumers that address it; scale 1)
+      const int nu4 = 64 * TPW / 8 * 2;
+      const int b0 = slice * (64 * TPW / 8);
+      if (tid < nu4 && b0 + tid / 2 < blocks_per_row)
+        a.out_planes[(a.m_out * blocks_per_row + b0) * 2 + tid] = make_uint4(0, 0, 0, 0);
+      if (tid == 0) a.out_scales[a.m_out * nchunk_out + slice] = 1.0f;
+    }
+  }
+}
 
 constexpr int SP_NKC = 4;  // 32-cin chunks per source at most (sources are <= 128 channels wide)
 
@@ -324,9 +412,9 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
       int i = nbr_s[(16 * cc + j) * kvol + st.k];
       i = i >= 0 ? i : (int)a.m_in;
 #ifdef SP_ABL_NO_X
-      const char* p = xb + (uint32_t)(i & 15) * rb + (uint32_t)(q * 32);
+      const char* p = xb + (uint32_t)(i & 15) * rb + (uint32_t)(sp_kgroup(q) * 32);
 #else
-      const char* p = xb + (uint32_t)i * rb + (uint32_t)(q * 32);  // (planes < 4 GiB: checked by the host)
+      const char* p = xb + (uint32_t)i * rb + (uint32_t)(sp_kgroup(q) * 32);  // (planes < 4 GiB: checked by the host; k group: see sp_kgroup)
 #endif
 #pragma unroll
       for (int kc = 0; kc < SP_NKC; ++kc) {
@@ -542,80 +630,619 @@ __global__ void __launch_bounds__(256, RG == 8 ? 1 : SP_RG4_WPS) spconv_fwd_plan
   }
 #endif
 
-  // ---- epilogue: lane (j, q) holds channels chw + 16 t + 4 q + r of rows row0 + 16 g + j
-  const bool affine = a.scale || a.shift;
-  float amax[RG];
+  sp_epilogue<RG, TPW>(a, acc, vec, rowmax, row0, slice, wave, tid);
+}
+
+
+// =====================================================================================================================
+// K9d: the same product on a CHUNK-granular software pipeline (round 3).
+//
+// K9c above moves a whole (offset, source) step at a time: a wave holds the step's weight fragments (64 registers), the step's
+// gathered rows in staging registers (33) and all four cells' X fragments (32) at once — 211-220 VGPRs, two waves per SIMD — and
+// its LDS ring holds two whole steps (64 KB per workgroup: two workgroups per CU).  Its counters (profiles/r2_pmc_stalls_k9c.txt)
+// show waves issuing 25 % of their cycles and parked or issue-stalled the rest, the matrix pipe a third busy, and a lone
+// workgroup per CU needs 2.5 us for a step whose MFMAs take 0.64 us: the step is a chain of exposed latencies (barrier -> LDS
+// fragment reads -> MFMAs -> weight wait -> ...) and with two waves per SIMD there is nobody to fill them.
+// Here the unit of the pipeline is ONE 32-cin chunk of a step (24 MFMAs per wave with 128 output channels):
+//   iteration i:  [barrier]  X(i+2): staging registers -> LDS slot (i+2)%4;  gather X(i+3) -> staging registers;
+//                 W(i+1) -> the other weight register set;  multiply chunk i from the X fragments that were read from LDS during
+//                 iteration i-1 and the weight set loaded during i-1, and behind each cell's MFMAs re-fill its fragment registers
+//                 with chunk i+1 from slot (i+1)%4.
+// Nothing an iteration multiplies was requested in that iteration: after the barrier the MFMAs start at once.  A wave holds
+// one chunk of weights twice (32 registers), one chunk of X fragments (32), one chunk of its own cell's gather (9): <= 168 VGPRs,
+// THREE waves per SIMD; the ring is four 8 KB chunk slots (slot = chunk index: a compile-time constant) = 32 KB, 44 KB per
+// workgroup with the table: three workgroups per CU.  One barrier per iteration: slot (i+2)%4 was last read during
+// iteration i-2 (its reads were waited for before that iteration's MFMAs, i.e. before barrier i-1); what iteration i reads
+// was written during i-1.
+// Operand layouts, cell skipping, per-row scales (D folded into acc at the end of a step) and the epilogue are K9c's.
+template <int TPW>
+struct SpPipeSmem {
+  static constexpr int R = 64;
+  static constexpr size_t nbr_bytes = (size_t)R * SP_KVOL_MAX * 4;
+  static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
+  static constexpr size_t xring_bytes = (size_t)4 * 4 * 2 * 1024;  // [slot][cell][row][piece ^ swizzle(row)] x 16 B
+  static constexpr size_t sring_off = xring_off + xring_bytes;
+  static constexpr size_t sring_bytes = (size_t)2 * 4 * 16 * 4;    // [step parity][cell][row]
+  static constexpr size_t meta_off = sring_off + sring_bytes;
+  static constexpr size_t meta_bytes = 32 * 4 + 16 + (size_t)SP_KVOL_MAX * 4;
+  static constexpr size_t vec_off = (meta_off + meta_bytes + 15) / 16 * 16;
+  static constexpr size_t vec_bytes = (size_t)2 * 64 * TPW * 4;
+  static constexpr size_t rowmax_off = vec_off + vec_bytes;
+  static constexpr size_t rowmax_bytes = (size_t)4 * R * 4;
+  static constexpr size_t bytes = rowmax_off + rowmax_bytes;
+};
+
+#ifndef SP_PIPE_WPS
+#define SP_PIPE_WPS 3
+#endif
+template <int TPW, int NKC>
+__global__ void __launch_bounds__(256, SP_PIPE_WPS) spconv_fwd_pipe_kernel(SpArgs a) {
+  using S = SpPipeSmem<TPW>;
+  constexpr int RG = 4, R = 64;
+  static_assert(NKC == 2 || NKC == 4, "sources of 64 or 128 channels");
+  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+  int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
+  uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
+  float* sring = reinterpret_cast<float*>(sp_smem + S::sring_off);
+  int* sched = reinterpret_cast<int*>(sp_smem + S::meta_off);
+  int* nk_s = reinterpret_cast<int*>(sp_smem + S::meta_off + 128);
+  unsigned char* flags = reinterpret_cast<unsigned char*>(sp_smem + S::meta_off + 144);
+  float* vec = reinterpret_cast<float*>(sp_smem + S::vec_off);
+  float* rowmax = reinterpret_cast<float*>(sp_smem + S::rowmax_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kvol = a.kvol;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int slice = blockIdx.y;
+
+  // ---- prologue (as K9c): the block's rows of the neighbour table, the epilogue's per-channel vectors, the step schedule
+  {
+    const int64_t base = row0 * kvol, lim = a.m_out * kvol;
+    for (int idx = tid; idx < R * kvol; idx += 256) nbr_s[idx] = (base + idx < lim) ? a.nbr[base + idx] : -1;
+    if (tid < 2 * 64 * TPW) {
+      const int which = tid / (64 * TPW), ch = slice * 64 * TPW + tid % (64 * TPW);
+      const float* src = which == 0 ? a.scale : a.shift;
+      vec[tid] = (src && ch < a.cout) ? src[ch] : (which == 0 ? 1.0f : 0.0f);
+    }
+  }
+  __syncthreads();
+  if (tid < kvol * RG) {
+    const int k = tid / RG, g = tid - k * RG;
+    bool any = false;
 #pragma unroll
-  for (int g = 0; g < RG; ++g) {
-    const int64_t row = row0 + 16 * g + j;
-    amax[g] = 0.0f;
+    for (int jj = 0; jj < 16; ++jj) any |= nbr_s[(16 * g + jj) * kvol + k] >= 0;
+    flags[tid] = any ? 1 : 0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    unsigned mask = 0;
+    if (lane < kvol) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) mask |= (unsigned)flags[lane * RG + g] << g;
+    }
+    const unsigned long long live = __ballot(mask != 0);
+    if (lane < 32) sched[lane] = 0;
+    if (mask != 0) sched[__popcll(live & ((1ull << lane) - 1ull))] = lane | (int)(mask << 8);
+    if (lane == 0) *nk_s = __popcll(live);
+  }
+  __syncthreads();
+  const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
+  const int nsrc = a.c[1] > 0 ? 2 : 1;
+  const int nchunks = NKC * nsrc;
+#ifdef PD_ABL_NO_LOOP
+  const int nsteps = 0;
+#else
+  const int nsteps = nk * nsrc;
+#endif
+  const float w_inv = a.w_hdr[0];
+  const uint32_t rowbytes = (uint32_t)NKC * 128u;  // both sources are NKC * 32 channels wide
+
+  auto entry = [&](int kidx, int src) -> SpStep {
+    const int e = kidx < nk ? __builtin_amdgcn_readfirstlane(sched[kidx]) : 0;
+    return SpStep{kidx, src, e & 255, (unsigned)e >> 8};
+  };
+  auto advance = [&](const SpStep& p) -> SpStep {
+    if (p.src + 1 < nsrc) return SpStep{p.kidx, p.src + 1, p.k, p.mask};
+    return entry(p.kidx + 1, 0);
+  };
+
+  sp_f32x4 acc[RG][TPW], D[RG][TPW];
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-      const int chl = wave * 16 * TPW + 16 * t + 4 * q;  // channel within the slice
-      const int ch = slice * 64 * TPW + chl;
-      sp_f32x4 y = acc[g][t];
-      if (affine) {
-        const float4 sc = *reinterpret_cast<const float4*>(vec + chl);
-        const float4 sh = *reinterpret_cast<const float4*>(vec + 64 * TPW + chl);
-        y[0] = __fmaf_rn(y[0], sc.x, sh.x); y[1] = __fmaf_rn(y[1], sc.y, sh.y);
-        y[2] = __fmaf_rn(y[2], sc.z, sh.z); y[3] = __fmaf_rn(y[3], sc.w, sh.w);
-      }
-      if (row < a.m_out && ch < a.cout) {
-        if (a.residual) {
-          const float4 rs = *reinterpret_cast<const float4*>(a.residual + row * a.cout + ch);
-          y[0] = __fadd_rn(y[0], rs.x); y[1] = __fadd_rn(y[1], rs.y); y[2] = __fadd_rn(y[2], rs.z); y[3] = __fadd_rn(y[3], rs.w);
-        }
-        if (a.relu) { y[0] = fmaxf(y[0], 0.f); y[1] = fmaxf(y[1], 0.f); y[2] = fmaxf(y[2], 0.f); y[3] = fmaxf(y[3], 0.f); }
-        if (a.out) *reinterpret_cast<float4*>(a.out + row * a.cout + ch) = make_float4(y[0], y[1], y[2], y[3]);
-      } else {
-        y = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-      acc[g][t] = y;
-      amax[g] = fmaxf(amax[g], fmaxf(fmaxf(fabsf(y[0]), fabsf(y[1])), fmaxf(fabsf(y[2]), fabsf(y[3]))));
+      acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+      D[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  }
-  if (a.out_planes) {  // the output as planes for the next convolution: row scale over this 64*TPW-channel slice
+
+  // ---- this wave's share of the gather: cell `wave` (16 rows), one chunk (128 bytes per row) at a time, as TWO line-coalesced loads:
+  // lane l reads the 16-byte piece l % 8 of row l / 8 (first load) and of row 8 + l / 8 (second load), so eight consecutive lanes
+  // cover one whole 128-byte line.  (K9c's mapping — lane (j, q) on bytes [32 q, 32 q + 32) of row j — puts consecutive lanes on
+  // DIFFERENT rows: tools/profiling/gather_pattern_probe.hip measures 10.4 B/clk/CU for it against 24 for this one, cache-resident
+  // or not: the vector-memory address path, not the bytes, was what the gather cost.)  The tile goes to LDS row-major, piece p of
+  // row r at piece slot p ^ ((r >> 1) & 7): the writes of eight consecutive lanes fall on eight different bank groups, and a
+  // fragment read — lane (j, q) takes pieces 2 sigma(q) (hi) and 2 sigma(q) + 1 (lo) of row j — is conflict-free for
+  // sigma = sp_kgroup (every ds_read_b128 lane group sees 16 different piece slots modulo 16).
+  // (Plain locals, not a struct: handed around by reference as a struct the 16-byte members went through scratch.)
+  uint4 g_a = make_uint4(0, 0, 0, 0), g_b = make_uint4(0, 0, 0, 0);
+  float g_sc = 1.0f;
+  uint32_t g_off0 = 0, g_off1 = 0;  // byte offsets of this lane's piece in its two rows, for the gather cursor's step
+  const int grow = lane >> 3, gpiece = lane & 7;
+  auto gather_row = [&](const SpStep& st, uint32_t& off0, uint32_t& off1, float& sc) {  // first chunk of a step: which rows, their scale
+    const int32_t* col = nbr_s + (16 * wave) * kvol + st.k;
+    int i0 = col[grow * kvol], i1 = col[(8 + grow) * kvol], is = col[j * kvol];
+    const int zero = (int)a.m_in;  // (no neighbour: the all-zero row m_in, scale 1)
+    i0 = i0 >= 0 ? i0 : zero;
+    i1 = i1 >= 0 ? i1 : zero;
+    is = is >= 0 ? is : zero;
+    off0 = (uint32_t)i0 * rowbytes + (uint32_t)(gpiece * 16);
+    off1 = (uint32_t)i1 * rowbytes + (uint32_t)(gpiece * 16);
+    sc = (st.src ? a.sx[1] : a.sx[0])[is];
+  };
+  auto gather_chunk = [&](const SpStep& st, int kc, uint32_t off0, uint32_t off1, uint4& va, uint4& vb) {
+#ifdef PD_ABL_NO_G
+    return;
+#endif
+    const char* p = (st.src ? a.x[1] : a.x[0]) + (uint32_t)(kc * 128);
+    va = *reinterpret_cast<const uint4*>(p + off0);
+    vb = *reinterpret_cast<const uint4*>(p + off1);
+  };
+  // LDS tile of one (slot, cell): 16 rows x 8 pieces x 16 B = 2 KB
+  const int wr_a = grow * 8 + (gpiece ^ ((grow >> 1) & 7)), wr_b = (8 + grow) * 8 + (gpiece ^ (((8 + grow) >> 1) & 7));
+  auto stage_to_lds = [&](const SpStep& st, int kc, int slot, int parity, const uint4& va, const uint4& vb, float sc) {
+#ifdef PD_ABL_NO_LDS_WRITE
+    return;
+#endif
+    if ((st.mask >> wave) & 1u) {
+      uint4* dst = xring + (slot * RG + wave) * 128;
+      dst[wr_a] = va;
+      dst[wr_b] = vb;
+      if (kc == 0 && q == 0) sring[(parity * RG + wave) * 16 + j] = sc;
+    }
+  };
+  const int rd_hi = j * 8 + ((2 * sp_kgroup(q)) ^ ((j >> 1) & 7)), rd_lo = j * 8 + ((2 * sp_kgroup(q) + 1) ^ ((j >> 1) & 7));
+  auto load_w = [&](const SpStep& st, int kc, uint4 (&wf)[TPW][2]) {
+#ifdef PD_ABL_NO_W
+    if (st.kidx > 0 || st.src > 0 || kc > 0) return;
+#endif
+    const int c = (st.src ? NKC : 0) + kc;
+    const uint4* p = reinterpret_cast<const uint4*>(a.w) + ((((int64_t)slice * kvol + st.k) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
 #pragma unroll
-    for (int g = 0; g < RG; ++g) {
-      float m = amax[g];
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
-      if (q == 0) rowmax[wave * R + 16 * g + j] = m;
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) wf[t][pl] = p[(t * 2 + pl) * 64];
+  };
+  auto read_cell = [&](int slot, int g, uint4& xh, uint4& xl) {
+#ifdef PD_ABL_NO_LDS_READ
+    return;
+#endif
+    const uint4* xs = xring + (slot * RG + g) * 128;
+    xh = xs[rd_hi];
+    xl = xs[rd_lo];
+  };
+  auto mma_cell = [&](bool first, int g, const uint4& xh, const uint4& xl, uint4 (&wk)[TPW][2]) {
+    const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh), bl = __builtin_bit_cast(sp_f16x8, xl);
+    sp_f16x8 wh[TPW], wl[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      wh[t] = __builtin_bit_cast(sp_f16x8, wk[t][0]);
+      wl[t] = __builtin_bit_cast(sp_f16x8, wk[t][1]);
     }
+#ifdef PD_ABL_NO_MFMA
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+      D[g][t][0] = (first ? 0.0f : D[g][t][0]) + __uint_as_float(xh.x ^ wk[t][0].x ^ xl.y ^ wk[t][1].y);
+    return;
+#endif
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+      D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, first ? sp_f32x4{0.f, 0.f, 0.f, 0.f} : D[g][t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, D[g][t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) D[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, D[g][t], 0, 0, 0);
+  };
+
+  // ---- pipeline state
+  uint4 wA[TPW][2], wB[TPW][2];
+  uint4 xh[RG], xl[RG];
+  float inv[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    xh[g] = xl[g] = make_uint4(0, 0, 0, 0);
+    inv[g] = 0.0f;
+  }
+
+  // the step `d` chunks after chunk kc of step r0 is r<(kc + d) / NKC>, its chunk (kc + d) % NKC
+  SpStep r0 = entry(0, 0);
+  SpStep r1 = advance(r0);
+  SpStep r2 = advance(r1);
+
+  // ---- fill: X(0), X(1) -> LDS slots 0, 1; X(2) -> staging registers; W(0) -> set A; then the fragments of chunk 0
+  {
+    uint4 a0, b0, a1, b1;
+    gather_row(r0, g_off0, g_off1, g_sc);
+    gather_chunk(r0, 0, g_off0, g_off1, a0, b0);
+    gather_chunk(r0, 1, g_off0, g_off1, a1, b1);   // (NKC >= 2: chunk 1 belongs to the same step)
+    const float sc0 = g_sc;
+    if constexpr (NKC > 2) {
+      gather_chunk(r0, 2, g_off0, g_off1, g_a, g_b);
+    } else {
+      gather_row(r1, g_off0, g_off1, g_sc);
+      gather_chunk(r1, 0, g_off0, g_off1, g_a, g_b);
+    }
+    load_w(r0, 0, wA);
+    stage_to_lds(r0, 0, 0, 0, a0, b0, sc0);
+    stage_to_lds(r0, 1, 1, 0, a1, b1, sc0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+    if ((r0.mask >> g) & 1u) read_cell(0, g, xh[g], xl[g]);
+
+  // one iteration: chunk KC of the step r0; ODD = parity of that step (which half of sring, and for NKC == 2 which pair of slots)
+  auto iteration = [&](auto kc_tag, auto odd_tag) {
+    constexpr int KC = decltype(kc_tag)::value;
+    constexpr int ODD = decltype(odd_tag)::value;
+    constexpr int I = (NKC == 4) ? KC : (2 * ODD + KC);  // chunk counter modulo 4 = LDS slot of chunk i
+    constexpr int d1 = (KC + 1) / NKC, d2 = (KC + 2) / NKC, d3 = (KC + 3) / NKC;
+    static_assert(d3 <= 2, "three step records suffice");
+    const SpStep st = r0;
+    const SpStep st1 = d1 == 0 ? r0 : r1;
+    const SpStep st2 = d2 == 0 ? r0 : r1;
+    const SpStep st3 = d3 == 0 ? r0 : (d3 == 1 ? r1 : r2);
+    constexpr int kc1 = (KC + 1) % NKC, kc2 = (KC + 2) % NKC, kc3 = (KC + 3) % NKC;
+#ifndef PD_ABL_NO_BARRIER
     __syncthreads();
-    const int nchunk_out = (a.cout + 64 * TPW - 1) / (64 * TPW);
-    const int blocks_per_row = a.cout / 8;
+#endif
+    // staging of the chunks ahead
+    stage_to_lds(st2, kc2, (I + 2) % 4, (ODD + d2) & 1, g_a, g_b, g_sc);
+    if (kc3 == 0) gather_row(st3, g_off0, g_off1, g_sc);
+    gather_chunk(st3, kc3, g_off0, g_off1, g_a, g_b);
+    // next chunk's weights into the set the previous iteration multiplied from
+    if (KC % 2 == 0) load_w(st1, kc1, wB);
+    else load_w(st1, kc1, wA);
+    if (KC == 0) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g)
+        if ((st.mask >> g) & 1u) inv[g] = sring[(ODD * RG + g) * 16 + j];
+    }
+    // multiply chunk KC; each cell's fragment registers take chunk KC + 1 as soon as its MFMAs are issued
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
-      const int64_t row = row0 + 16 * g + j;
-      const int rl = 16 * g + j;
-      const float m = fmaxf(fmaxf(rowmax[rl], rowmax[R + rl]), fmaxf(rowmax[2 * R + rl], rowmax[3 * R + rl]));
-      float sc, inv_s;
-      sp_pick_scale(m, sc, inv_s);
-      if (row < a.m_out) {
+      if ((st.mask >> g) & 1u) mma_cell(KC == 0, g, xh[g], xl[g], (KC % 2 == 0) ? wA : wB);
+      if ((st1.mask >> g) & 1u) read_cell((I + 1) % 4, g, xh[g], xl[g]);
+    }
+    if (KC == NKC - 1) {  // fold the step: this lane's row scale in every live cell
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-          const int ch = chw + 16 * t + 4 * q;
-          if (ch < a.cout) {
-            const float v4[4] = {acc[g][t][0], acc[g][t][1], acc[g][t][2], acc[g][t][3]};
-            sp_u32x2 hi, lo;
-            sp_split4(v4, sc, hi, lo);
-            char* dst = reinterpret_cast<char*>(a.out_planes + (row * blocks_per_row + (ch >> 3)) * 2) + (q & 1) * 8;
-            *reinterpret_cast<sp_u32x2*>(dst) = hi;
-            *reinterpret_cast<sp_u32x2*>(dst + 16) = lo;
-          }
+      for (int g = 0; g < RG; ++g) {
+        if ((st.mask >> g) & 1u) {
+          const float sc = __fmul_rn(inv[g], w_inv);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmaf_rn(D[g][t][r], sc, acc[g][t][r]);
         }
-        if (wave == 0 && q == 0) a.out_scales[row * nchunk_out + slice] = inv_s;
       }
     }
-    if (blockIdx.x == gridDim.x - 1) {  // the zero row (kept for consumers that address it; scale 1)
-      const int nu4 = 64 * TPW / 8 * 2;
-      const int b0 = slice * (64 * TPW / 8);
-      if (tid < nu4 && b0 + tid / 2 < blocks_per_row)
-        a.out_planes[(a.m_out * blocks_per_row + b0) * 2 + tid] = make_uint4(0, 0, 0, 0);
-      if (tid == 0) a.out_scales[a.m_out * nchunk_out + slice] = 1.0f;
+  };
+  auto next_step = [&]() {
+    r0 = r1;
+    r1 = r2;
+    r2 = advance(r2);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  auto whole_step = [&](auto odd_tag) {
+    iteration(I0{}, odd_tag);
+    iteration(I1{}, odd_tag);
+    if constexpr (NKC == 4) {
+      iteration(I2{}, odd_tag);
+      iteration(I3{}, odd_tag);
+    }
+  };
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    whole_step(I0{});
+    next_step();
+    whole_step(I1{});
+    next_step();
+  }
+  if (s < nsteps) whole_step(I0{});
+  __syncthreads();  // (the ring's last reads precede the epilogue's use of `rowmax`; the gathers still in flight are dropped)
+  sp_epilogue<RG, TPW>(a, acc, vec, rowmax, row0, slice, wave, tid);
+}
+
+
+// =====================================================================================================================
+// K9e: K9d's pipeline on 128-row blocks, accumulating straight into the output tile.
+//
+// What bounds K9c / K9d (profiles/r3_vmem_return_probe.txt, r3_spconv_k9d_ablations.txt): a CU takes in vector-memory data at
+// ~25 B/clk however the request looks and wherever it hits (1 KB contiguous per instruction, L1-resident or not: 24-25 B/clk/CU;
+// K9c's row-per-lane gather 10.4) — a tenth of what LDS delivers.  A 64-row block pays 16 KB of weight fragments per chunk next to
+// 8 KB of gathered rows, and three such workgroups per CU fetch the SAME fragments three times: 4 GB through the vector memory path
+// for the 101 k-row 128 -> 128 layer = the kernel's duration at that rate.  The lever is bytes taken in per row: here a workgroup
+// owns 128 rows (eight 16-row cells) x 128 output channels, a wave all eight cells of its 32 channels, so a chunk's 16 KB of
+// fragments serve twice the rows (375 -> 250 bytes per row and chunk).
+// The 16 accumulator tiles of a wave leave no room for K9d's per-step product registers D, and they are not needed: the row
+// scales are powers of two, so a lane keeps each cell's accumulators in the unit of the row it is currently multiplying —
+// before a step's first MFMA the cell's accumulators are multiplied by (old unit / new unit), exactly, and the MFMAs accumulate
+// into them directly; the epilogue multiplies the last unit back out.  (Exact as long as no intermediate leaves the fp32
+// range: the rows of one 27-neighbourhood may differ by up to ~2^80 in magnitude.)
+// Ring: three chunk slots of 16 KB (slot index carried at run time), two workgroups per CU.
+template <int TPW>
+struct SpWideSmem {
+  static constexpr int RG = 8, R = 128;
+  static constexpr size_t nbr_bytes = (size_t)R * SP_KVOL_MAX * 4;
+  static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
+  static constexpr size_t xring_bytes = (size_t)3 * RG * 2048;  // [slot][cell][row][piece ^ swizzle(row)] x 16 B
+  static constexpr size_t sring_off = xring_off + xring_bytes;
+  static constexpr size_t sring_bytes = (size_t)2 * RG * 16 * 4;  // [step parity][cell][row]
+  static constexpr size_t meta_off = sring_off + sring_bytes;
+  static constexpr size_t meta_bytes = 32 * 4 + 16 + (size_t)SP_KVOL_MAX * RG;
+  static constexpr size_t vec_off = (meta_off + meta_bytes + 15) / 16 * 16;
+  static constexpr size_t vec_bytes = (size_t)2 * 64 * TPW * 4;
+  static constexpr size_t rowmax_off = vec_off + vec_bytes;
+  static constexpr size_t rowmax_bytes = (size_t)4 * R * 4;
+  static constexpr size_t bytes = rowmax_off + rowmax_bytes;
+};
+
+template <int TPW, int NKC>
+__global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
+  using S = SpWideSmem<TPW>;
+  constexpr int RG = 8, R = 128, CPW = 2;
+  static_assert(NKC == 2 || NKC == 4, "sources of 64 or 128 channels");
+  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+  int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
+  uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
+  float* sring = reinterpret_cast<float*>(sp_smem + S::sring_off);
+  int* sched = reinterpret_cast<int*>(sp_smem + S::meta_off);
+  int* nk_s = reinterpret_cast<int*>(sp_smem + S::meta_off + 128);
+  unsigned char* flags = reinterpret_cast<unsigned char*>(sp_smem + S::meta_off + 144);
+  float* vec = reinterpret_cast<float*>(sp_smem + S::vec_off);
+  float* rowmax = reinterpret_cast<float*>(sp_smem + S::rowmax_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kvol = a.kvol;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int slice = blockIdx.y;
+
+  // ---- prologue (as K9c, eight cells)
+  {
+    const int64_t base = row0 * kvol, lim = a.m_out * kvol;
+    for (int idx = tid; idx < R * kvol; idx += 256) nbr_s[idx] = (base + idx < lim) ? a.nbr[base + idx] : -1;
+    if (tid < 2 * 64 * TPW) {
+      const int which = tid / (64 * TPW), ch = slice * 64 * TPW + tid % (64 * TPW);
+      const float* src = which == 0 ? a.scale : a.shift;
+      vec[tid] = (src && ch < a.cout) ? src[ch] : (which == 0 ? 1.0f : 0.0f);
     }
   }
+  __syncthreads();
+  if (tid < kvol * RG) {
+    const int k = tid / RG, g = tid - k * RG;
+    bool any = false;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) any |= nbr_s[(16 * g + jj) * kvol + k] >= 0;
+    flags[tid] = any ? 1 : 0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    unsigned mask = 0;
+    if (lane < kvol) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) mask |= (unsigned)flags[lane * RG + g] << g;
+    }
+    const unsigned long long live = __ballot(mask != 0);
+    if (lane < 32) sched[lane] = 0;
+    if (mask != 0) sched[__popcll(live & ((1ull << lane) - 1ull))] = lane | (int)(mask << 8);
+    if (lane == 0) *nk_s = __popcll(live);
+  }
+  __syncthreads();
+  const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
+  const int nsrc = a.c[1] > 0 ? 2 : 1;
+  const int nchunks = NKC * nsrc;
+  const int nsteps = nk * nsrc;
+  const uint32_t rowbytes = (uint32_t)NKC * 128u;
+
+  auto entry = [&](int kidx, int src) -> SpStep {
+    const int e = kidx < nk ? __builtin_amdgcn_readfirstlane(sched[kidx]) : 0;
+    return SpStep{kidx, src, e & 255, (unsigned)e >> 8};
+  };
+  auto advance = [&](const SpStep& p) -> SpStep {
+    if (p.src + 1 < nsrc) return SpStep{p.kidx, p.src + 1, p.k, p.mask};
+    return entry(p.kidx + 1, 0);
+  };
+
+  // acc[g][t]: the output tile of cell g in the unit 1 / cinv[g] (x the weight scale); cinv[g] = inverse scale of the row this lane is
+  // multiplying in cell g
+  sp_f32x4 acc[RG][TPW];
+  float cinv[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    cinv[g] = 1.0f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- this wave's share of the gather: cells 2 wave and 2 wave + 1, line-coalesced (see K9d): per cell and chunk two loads
+  uint4 g_v[CPW][2];
+  uint32_t g_off[CPW][2];
+  float g_sc = 1.0f;
+#pragma unroll
+  for (int u = 0; u < CPW; ++u)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      g_v[u][h] = make_uint4(0, 0, 0, 0);
+      g_off[u][h] = 0;
+    }
+  const int grow = lane >> 3, gpiece = lane & 7;
+  auto gather_row = [&](const SpStep& st) {  // first chunk of a step: which rows, their scale
+    const int32_t* col = nbr_s + (16 * CPW * wave) * kvol + st.k;
+    const int zero = (int)a.m_in;  // (no neighbour: the all-zero row m_in, scale 1)
+#pragma unroll
+    for (int u = 0; u < CPW; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int i = col[(16 * u + 8 * h + grow) * kvol];
+        i = i >= 0 ? i : zero;
+        g_off[u][h] = (uint32_t)i * rowbytes + (uint32_t)(gpiece * 16);
+      }
+    int is = col[(16 * (q & 1) + j) * kvol];  // lanes of q = 0 / 1 fetch the scales of the first / second cell's rows
+    is = is >= 0 ? is : zero;
+    g_sc = (st.src ? a.sx[1] : a.sx[0])[is];
+  };
+  auto gather_chunk = [&](const SpStep& st, int kc) {
+    const char* p = (st.src ? a.x[1] : a.x[0]) + (uint32_t)(kc * 128);
+#pragma unroll
+    for (int u = 0; u < CPW; ++u)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) g_v[u][h] = *reinterpret_cast<const uint4*>(p + g_off[u][h]);
+  };
+  const int wr0 = grow * 8 + (gpiece ^ ((grow >> 1) & 7)), wr1 = (8 + grow) * 8 + (gpiece ^ (((8 + grow) >> 1) & 7));
+  auto stage_to_lds = [&](const SpStep& st, int kc, int slot, int parity) {
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) {
+      const int cc = CPW * wave + u;
+      if ((st.mask >> cc) & 1u) {
+        uint4* dst = xring + (slot * RG + cc) * 128;
+        dst[wr0] = g_v[u][0];
+        dst[wr1] = g_v[u][1];
+      }
+    }
+    if (kc == 0 && q < 2) sring[(parity * RG + CPW * wave + q) * 16 + j] = g_sc;  // (dead cells too: never read)
+  };
+  auto load_w = [&](const SpStep& st, int kc, uint4 (&wf)[TPW][2]) {
+    const int c = (st.src ? NKC : 0) + kc;
+    const uint4* p = reinterpret_cast<const uint4*>(a.w) + ((((int64_t)slice * kvol + st.k) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) wf[t][pl] = p[(t * 2 + pl) * 64];
+  };
+  const int rd_hi = j * 8 + ((2 * sp_kgroup(q)) ^ ((j >> 1) & 7)), rd_lo = j * 8 + ((2 * sp_kgroup(q) + 1) ^ ((j >> 1) & 7));
+  auto read_cell = [&](int slot, int g, uint4& xh, uint4& xl) {
+    const uint4* xs = xring + (slot * RG + g) * 128;
+    xh = xs[rd_hi];
+    xl = xs[rd_lo];
+  };
+  auto mma_cell = [&](int g, const uint4& xh, const uint4& xl, uint4 (&wk)[TPW][2]) {
+    const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh), bl = __builtin_bit_cast(sp_f16x8, xl);
+    sp_f16x8 wh[TPW], wl[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      wh[t] = __builtin_bit_cast(sp_f16x8, wk[t][0]);
+      wl[t] = __builtin_bit_cast(sp_f16x8, wk[t][1]);
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, acc[g][t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, acc[g][t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, acc[g][t], 0, 0, 0);
+  };
+
+  // ---- pipeline state
+  uint4 wA[TPW][2], wB[TPW][2];
+  uint4 xh[RG], xl[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) xh[g] = xl[g] = make_uint4(0, 0, 0, 0);
+
+  SpStep r0 = entry(0, 0);
+  SpStep r1 = advance(r0);
+  SpStep r2 = advance(r1);
+
+  // ---- fill: X(0), X(1) -> LDS slots 0, 1; X(2) -> staging registers; W(0) -> set A; then the fragments of chunk 0
+  gather_row(r0);
+  gather_chunk(r0, 0);
+  load_w(r0, 0, wA);
+  stage_to_lds(r0, 0, 0, 0);
+  gather_chunk(r0, 1);  // (NKC >= 2: chunk 1 belongs to the same step)
+  stage_to_lds(r0, 1, 1, 0);
+  if constexpr (NKC > 2) {
+    gather_chunk(r0, 2);
+  } else {
+    gather_row(r1);
+    gather_chunk(r1, 0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+    if ((r0.mask >> g) & 1u) read_cell(0, g, xh[g], xl[g]);
+
+  int slot = 0;    // LDS slot of the chunk being multiplied (chunk counter modulo 3)
+  int parity = 0;  // parity of the step being multiplied (which half of sring)
+  auto iteration = [&](auto kc_tag) {
+    constexpr int KC = decltype(kc_tag)::value;
+    constexpr int d1 = (KC + 1) / NKC, d2 = (KC + 2) / NKC, d3 = (KC + 3) / NKC;
+    static_assert(d3 <= 2, "three step records suffice");
+    const SpStep st = r0;
+    const SpStep st1 = d1 == 0 ? r0 : r1;
+    const SpStep st2 = d2 == 0 ? r0 : r1;
+    const SpStep st3 = d3 == 0 ? r0 : (d3 == 1 ? r1 : r2);
+    constexpr int kc1 = (KC + 1) % NKC, kc2 = (KC + 2) % NKC, kc3 = (KC + 3) % NKC;
+    const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+    __syncthreads();
+    // staging of the chunks ahead
+    stage_to_lds(st2, kc2, slot2, (parity + d2) & 1);
+    if (kc3 == 0) gather_row(st3);
+    gather_chunk(st3, kc3);
+    // next chunk's weights into the set the previous iteration multiplied from
+    if (KC % 2 == 0) load_w(st1, kc1, wB);
+    else load_w(st1, kc1, wA);
+    if (KC == 0) {  // a new step: every live cell's accumulators into the unit of the row this lane multiplies now (exact: powers of two)
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        if ((st.mask >> g) & 1u) {
+          const float v = sring[(parity * RG + g) * 16 + j];
+          const float f = __fmul_rn(cinv[g], __uint_as_float(0x7F000000u - __float_as_uint(v)));  // old unit / new unit = cinv_old * (1 / v)
+          cinv[g] = v;
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmul_rn(acc[g][t][r], f);
+        }
+      }
+    }
+    // multiply chunk KC; each cell's fragment registers take chunk KC + 1 as soon as its MFMAs are issued
+#pragma unroll
+    for (int g = 0; g < RG; ++g) {
+      if ((st.mask >> g) & 1u) mma_cell(g, xh[g], xl[g], (KC % 2 == 0) ? wA : wB);
+      if ((st1.mask >> g) & 1u) read_cell(slot1, g, xh[g], xl[g]);
+    }
+    slot = slot1;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  for (int s = 0; s < nsteps; ++s) {
+    iteration(I0{});
+    iteration(I1{});
+    if constexpr (NKC == 4) {
+      iteration(I2{});
+      iteration(I3{});
+    }
+    r0 = r1;
+    r1 = r2;
+    r2 = advance(r2);
+    parity ^= 1;
+  }
+  // the accumulators back into true units (x the weight's inverse scale)
+  const float w_inv = a.w_hdr[0];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    const float sc = __fmul_rn(cinv[g], w_inv);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmul_rn(acc[g][t][r], sc);
+  }
+  __syncthreads();  // (the ring's last reads precede the epilogue's use of `rowmax`; the gathers still in flight are dropped)
+  sp_epilogue<RG, TPW>(a, acc, vec, rowmax, row0, slice, wave, tid);
 }
 
 }  // namespace fsf
@@ -695,9 +1322,39 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
     const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                              \
     hipLaunchKernelGGL((spconv_fwd_planes_kernel<RG_, TPW_, NKC_>), grid, dim3(256), S::bytes, stream, a);                 \
   } while (0)
-  // sources of one width (64 or 128 channels: every layer of the U-Net) get the variant with compile-time chunk loops
-  const int nkc_fix = (cb == 0 || cb == ca) && (ca == 64 || ca == 128) && !getenv("FSF_PLANES_GENERIC") ? ca / 32 : 0;
-  if (big && tpw == 2) FSF_SP(8, 2, 0);
+  // sources of one width (64 or 128 channels: every layer of the U-Net) get the variants with compile-time chunk loops
+  // (A/B switches, latched at the first call: the library is driven from two host threads and getenv is not safe against setenv)
+  static const bool generic_only = getenv("FSF_PLANES_GENERIC") != nullptr;
+  static const bool pipe_on = !(getenv("FSF_PLANES_PIPE") && atoi(getenv("FSF_PLANES_PIPE")) == 0);
+  const int nkc_fix = (cb == 0 || cb == ca) && (ca == 64 || ca == 128) && !generic_only ? ca / 32 : 0;
+#define FSF_SPP(TPW_, NKC_)                                                                                              \
+  do {                                                                                                                  \
+    using S = SpPipeSmem<TPW_>;                                                                                         \
+    static std::atomic<uint64_t> attr_done{0};                                                                          \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_pipe_kernel<TPW_, NKC_>, (int)S::bytes, attr_done));    \
+    const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                           \
+    hipLaunchKernelGGL((spconv_fwd_pipe_kernel<TPW_, NKC_>), grid, dim3(256), S::bytes, stream, a);                     \
+  } while (0)
+  // K9e (128-row blocks: half the weight bytes per row) is OFF by default: measured 12-30 % slower than K9d on every layer of the
+  // frame — two waves per SIMD cover the pipeline's latencies worse than three; FSF_PLANES_WIDE_MIN_ROWS=<rows>
+  // turns it on from that many output rows x channel slices
+  static const int64_t wide_min_rows = getenv("FSF_PLANES_WIDE_MIN_ROWS") ? atoll(getenv("FSF_PLANES_WIDE_MIN_ROWS")) : ((int64_t)1 << 40);
+  const bool wide = pipe_on && !big && nkc_fix > 0 && m_out * nslice >= wide_min_rows;
+#define FSF_SPW(TPW_, NKC_)                                                                                              \
+  do {                                                                                                                  \
+    using S = SpWideSmem<TPW_>;                                                                                         \
+    static std::atomic<uint64_t> attr_done{0};                                                                          \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_wide_kernel<TPW_, NKC_>, (int)S::bytes, attr_done));    \
+    const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                           \
+    hipLaunchKernelGGL((spconv_fwd_wide_kernel<TPW_, NKC_>), grid, dim3(256), S::bytes, stream, a);                     \
+  } while (0)
+  if (wide && nkc_fix == 4 && tpw == 2) FSF_SPW(2, 4);
+  else if (wide && nkc_fix == 2 && tpw == 2) FSF_SPW(2, 2);
+  else if (wide && nkc_fix == 2 && tpw == 1) FSF_SPW(1, 2);
+  else if (pipe_on && !big && nkc_fix == 4 && tpw == 2) FSF_SPP(2, 4);   // K9d: the chunk-granular pipeline
+  else if (pipe_on && !big && nkc_fix == 2 && tpw == 2) FSF_SPP(2, 2);
+  else if (pipe_on && !big && nkc_fix == 2 && tpw == 1) FSF_SPP(1, 2);
+  else if (big && tpw == 2) FSF_SP(8, 2, 0);
   else if (big) FSF_SP(8, 1, 0);
   else if (tpw == 2 && nkc_fix == 4) FSF_SP(4, 2, 4);
   else if (tpw == 2 && nkc_fix == 2) FSF_SP(4, 2, 2);
@@ -705,6 +1362,8 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
   else if (tpw == 2) FSF_SP(4, 2, 0);
   else FSF_SP(4, 1, 0);
 #undef FSF_SP
+#undef FSF_SPP
+#undef FSF_SPW
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -95,6 +95,8 @@ _ARGTYPES = {
     "fsf_connected_components_grouped": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
+    "fsf_set_option": [c_i32, c_i64],
+    "fsf_get_option": [c_i32],
 }
 _configured = False
 
@@ -873,6 +875,17 @@ def linear_norm_act_sliced(x: torch.Tensor, k: int, x_slice_offset: int, planes:
 
 
 # ----------------------------------------------------------------------------------- refine-stage ops
+OPT_POOL_BRUTE = 1
+
+
+def set_option(option: int, value: int) -> int:
+    """fsf_set_option: a process-wide algorithm switch of the library; returns the previous value."""
+    h = _L()
+    old = int(h.fsf_get_option(int(option)))
+    check(h.fsf_set_option(int(option), int(value)), "fsf_set_option")
+    return old
+
+
 def dynamic_point_pool(rois: torch.Tensor, pts: torch.Tensor, extra_wlh, max_inbox_point: int, max_all_pts: int = 50000,
                        roi_batch_col: int = -1, box_col: int = 0, pts_batch: Optional[torch.Tensor] = None):
     """fsf_dynamic_point_pool: rois f32 [R, >=7] (box at box_col.., optional batch column), pts f32 [P, >=3] ->

@@ -10,7 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .... import hip_ops
+from .... import hip_ops, switches
 from ...ops.spconv import SparseBasicBlock, SparseConvTensor, SparseSequential, make_sparse_convmodule
 from ...registry import BACKBONES
 
@@ -137,9 +137,9 @@ class SimpleSparseUNet(nn.Module):
         # them) go to a side stream once the encoder has left those levels: they fill the CUs that the small deep levels — a few
         # dozen workgroups per launch — leave idle, instead of running alone after them.
         side_levels = 0
-        if (voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training
-                and os.environ.get("FSF_UNET_LATERAL_STREAM", "1") != "0"):
-            side_levels = min(int(os.environ.get("FSF_UNET_LATERAL_LEVELS", "3")), self.stage_num - 1)
+        if (voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training and switches.UNET_LATERAL_STREAM
+                and not torch.cuda.is_current_stream_capturing()):
+            side_levels = min(switches.UNET_LATERAL_LEVELS, self.stage_num - 1)
         lateral_out, lateral_done = {}, {}
         for level, encoder_layer in enumerate(self.encoder_layers._modules.values(), start=1):
             x = encoder_layer(x)
@@ -152,18 +152,28 @@ class SimpleSparseUNet(nn.Module):
                 side.wait_stream(main)  # the encoder outputs of levels 1..side_levels exist
                 with torch.cuda.stream(side):
                     for lv in range(side_levels, 0, -1):  # the decoder needs the deepest of them first
-                        y = getattr(self, f"lateral_layer{lv}")(encode_features[lv - 1])
+                        src = encode_features[lv - 1]
+                        # allocated on the main stream, read by the side stream: the allocator must not hand the blocks to a later
+                        # main-stream allocation before the side kernels are through with them (an exception between here and the
+                        # decoder loop would otherwise free them for reuse)
+                        for t in [src.features] + [u for pl in (src.plane_sources or []) for u in (pl.data, pl.scales)]:
+                            t.record_stream(side)
+                        y = getattr(self, f"lateral_layer{lv}")(src)
                         ev = torch.cuda.Event()
                         ev.record(side)
                         lateral_out[lv], lateral_done[lv] = y, ev
         x = encode_features[-1]
-        for i in range(self.stage_num, 0, -1):
-            lat = lateral_out.get(i)
-            if lat is not None:
-                main = torch.cuda.current_stream()
-                main.wait_event(lateral_done[i])
-                for t in [lat.features] + [u for pl in (lat.plane_sources or []) for u in (pl.data, pl.scales)]:
-                    t.record_stream(main)  # allocated on the side stream, consumed (and later freed) on this one
-            x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f"lateral_layer{i}"),
-                                           getattr(self, f"merge_layer{i}"), getattr(self, f"upsample_layer{i}"), lateral_out=lat)
+        try:
+            for i in range(self.stage_num, 0, -1):
+                lat = lateral_out.get(i)
+                if lat is not None:
+                    main = torch.cuda.current_stream()
+                    main.wait_event(lateral_done[i])
+                    for t in [lat.features] + [u for pl in (lat.plane_sources or []) for u in (pl.data, pl.scales)]:
+                        t.record_stream(main)  # allocated on the side stream, consumed (and later freed) on this one
+                x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f"lateral_layer{i}"),
+                                               getattr(self, f"merge_layer{i}"), getattr(self, f"upsample_layer{i}"), lateral_out=lat)
+        finally:
+            if lateral_done:  # whatever happens in the decoder, the main stream ends behind the side stream's work
+                torch.cuda.current_stream().wait_stream(self._lateral_stream)
         return [{"voxel_feats": x.features}]

@@ -2,6 +2,7 @@
 projects/mmdet3d_plugin/models/decode_heads/segmentation_head.py:15-104,265-266 — per-point MLP, seg logits and
 vote offsets.  Dense GEMMs on rocBLAS via torch (not a HIP deliverable); target
 generation and losses (train-time, host-side label assignment) are out of scope for this round."""
+from .... import switches
 import os
 
 import torch
@@ -69,7 +70,7 @@ class VoteSegHead(nn.Module):
         from .... import hip_ops
         from ...ops.sst_ops import _SMALL_N_MIN
 
-        if os.environ.get("FSF_SEG_HEAD_STACK", "1") == "0":
+        if not switches.SEG_HEAD_STACK:
             return None
         if (self.training or (torch.is_grad_enabled() and (feat.requires_grad or self.conv_seg.weight.requires_grad))
                 or not feat.is_cuda or feat.dim() != 2 or feat.size(0) < _SMALL_N_MIN or (self.dropout is not None and self.training)):

@@ -6,6 +6,7 @@ Same constructor arguments, sub-module names (state-dict keys `shared_mlp.*`, `t
 conventions.  The MLPs are the fused Linear -> LayerNorm+GELU blocks of ops/sst_ops.py; box decoding is the coder of
 core/bbox.py; NMS is the HIP kernel pair K20.  Losses / target assignment (train time) are not built: `loss` raises.
 """
+from .... import switches
 import copy
 import os
 
@@ -105,7 +106,7 @@ class FSDSeparateHead(nn.Module):
         return plan
 
     def _forward_sliced(self, x):
-        if os.environ.get("FSF_HEAD_SLICED", "1") == "0":
+        if not switches.HEAD_SLICED:
             return None
         if (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))) or self.training:
             return None

@@ -17,6 +17,7 @@ Same method names and return conventions.  What changes underneath:
 `simple_test` = stages 1-3, query combination, the refine stage (K17 point pooling + SIR layers) and box decoding with
 BEV NMS (K20); `forward_hot_path` stops after the three query-generation stages (what bench.py's headline times).
 """
+from .... import switches
 import os
 
 import torch
@@ -201,7 +202,7 @@ class FSF(SingleStageFSD):
         lazy_src = None
         if fg_idx is not None:  # `obj_id_tensor` already holds the rows of the foreground points `fg_idx` (ascending)
             if (pts_feat.is_cuda and pts_feat.dtype == torch.float32 and pts_feat.stride(1) == 1 and not torch.is_grad_enabled()
-                    and os.environ.get("FSF_SIR_GATHER", "1") != "0"):
+                    and switches.SIR_GATHER):
                 # the 131-wide point features are not gathered here: their row INDEX travels through the selection / duplication
                 # steps in their place, and the first SIR layer's input kernel reads the rows through it (sst_ops.GatheredRows)
                 lazy_src, pts_feat = pts_feat, fg_idx.unsqueeze(1)

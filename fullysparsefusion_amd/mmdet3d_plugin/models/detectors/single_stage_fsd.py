@@ -6,6 +6,7 @@ group_sample :802-865, get_fg_mask :742-784, ClusterAssigner :903-982).
 Same class / method names and argument meaning; torch.unique / torch_scatter / Voxelization / scipy CCL calls go
 to the HIP library.  Training-only branches (targets, losses, SSG/Hybrid assigners) are outside this round.
 """
+from .... import switches
 import os
 
 import torch
@@ -249,7 +250,7 @@ class SingleStageFSD(nn.Module):
         # cluster-voxel key (torch.div(.., 'floor') with the group's voxel size, :948-950; group folded into the batch column)
         vs_rows = [ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]]
         if (seg_logits.is_cuda and nc <= 32 and ng <= 16 and seg_logits.dtype == torch.float32
-                and os.environ.get("FSF_FUSED_VOTE", "1") != "0"):
+                and switches.FUSED_VOTE):
             # one pass (fsf_vote_centers_keys) instead of ~22 launches over [n_pairs, classes(, 3)] temporaries
             masks = [sum(1 << c for c in cols) for cols in group_cols]
             centers, keys, b_pts = hip_ops.vote_centers_keys(
@@ -270,7 +271,7 @@ class SingleStageFSD(nn.Module):
             b_pts = batch_idx.index_select(0, p_ids).long()
             keys = torch.cat([(g_ids * bsz + b_pts)[:, None], vox], dim=1)
         new_keys, inv, cnt = unique_with_plan(keys)
-        if os.environ.get("FSF_CLUSTER_ONE_UNIQUE", "1") != "0":
+        if switches.CLUSTER_ONE_UNIQUE:
             # Whether a pair survives is a property of its voxel key (dense enough, or its whole group has no dense voxel, :953-954),
             # so the voxels of the surviving pairs are a SUBSET of the unique just taken: their keys, the pair -> voxel map and the
             # voxel means (same rows in the same order per voxel) follow from it — upstream runs a second unique on the survivors.
@@ -323,7 +324,7 @@ class SingleStageFSD(nn.Module):
             # where they are, the layer's input kernel reads them through `p_ids` side by side (sst_ops.GatheredRows; materialised —
             # gathered straight into one [n, 11 + 33 + 131] buffer — by anything else that wants the matrix)
             lazy = GatheredRows(parts, p_ids)
-            self._grouped_feats_concat = lazy if os.environ.get("FSF_SIR_GATHER", "1") != "0" else lazy.materialize()
+            self._grouped_feats_concat = lazy if switches.SIR_GATHER else lazy.materialize()
             return take(d["seg_points"]), None, None, None, centers, pts_cluster_inds
         self._grouped_feats_concat = None
         return (take(d["seg_points"]), take(seg_logits), take(d["seg_vote_preds"]), take(d["seg_feats"]), centers,

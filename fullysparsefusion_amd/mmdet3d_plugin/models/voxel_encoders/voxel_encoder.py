@@ -7,6 +7,7 @@ projects/mmdet3d_plugin/models/backbones/sir.py:41-61.  Restated from the publis
 Per call: ONE packed-key radix sort (unique_once), then every segmented mean/max and every "map back to the
 points" gather reuses that sort-once segment plan through the HIP library.
 """
+from .... import switches
 import os
 
 import torch
@@ -92,7 +93,7 @@ class DynamicScatterVFE(nn.Module):
             new_coors = unq_inv = None
         if (features.is_cuda and features.dtype == torch.float32 and not self._with_distance and features.size(1) >= 3
                 and (self._with_cluster_center or self._with_voxel_center)
-                and not (torch.is_grad_enabled() and features.requires_grad) and os.environ.get("FSF_VFE_DECORATE", "1") != "0"):
+                and not (torch.is_grad_enabled() and features.requires_grad) and switches.VFE_DECORATE):
             # inference: the decorated input in one pass (fsf_vfe_decorate) instead of a gather, a dozen elementwise launches and
             # a cat; its rows are padded to 16 bytes, so the first layer's fused Linear reads them in place
             voxel_mean = unq_inv_c = None

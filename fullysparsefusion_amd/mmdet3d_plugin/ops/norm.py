@@ -7,6 +7,7 @@ regardless of its row count — and the backward all-reduces the matching gradie
 whatever backend torch.distributed was initialised with: RCCL over xGMI on the GPU box ("nccl"), gloo in the
 CPU tests.  The two [C] statistics travel as ONE packed [2C] message (latency-bound).
 """
+from ... import switches
 import os
 
 import torch
@@ -125,7 +126,7 @@ class NaiveSyncBatchNorm1d(nn.BatchNorm1d):
         if not (self.training and distributed):
             return super().forward(x)
         assert x.dim() == 2, "naiveSyncBN1d expects [rows, C]"
-        if self.affine and self.track_running_stats and os.environ.get("FSF_SYNCBN_FUSED", "1") != "0":
+        if self.affine and self.track_running_stats and switches.SYNCBN_FUSED:
             return _SyncBatchNormAct.apply(x, self.weight, self.bias, self, False, None)
         mean = x.mean(0)
         meansqr = (x * x).mean(0)

@@ -8,6 +8,7 @@ grid) and each conv layer is ONE fused gather -> fp32 MFMA -> epilogue launch in
 scatter-add).  In eval mode the BatchNorm affine, the residual add and the ReLU that follow a conv are folded
 into that launch.
 """
+from ... import switches
 import math
 import os
 
@@ -221,7 +222,7 @@ class SparseConvolution(SparseModule):
         """Training uses K9b for the forward AND the data gradient of the submanifold layers (their transposed table
         has the same row count); strided / inverse layers keep the compacting fp32 kernel in both directions."""
         return (self.subm and self.in_channels % 4 == 0 and self.out_channels % 4 == 0
-                and os.environ.get("FSF_TRAIN_SPLIT", "1") != "0")
+                and switches.TRAIN_SPLIT)
 
     def _weight_split(self):
         w = self.weight
@@ -236,7 +237,7 @@ class SparseConvolution(SparseModule):
     # K9c (pre-split f16 planes, cell skipping): every layer whose sources are <= 128 channels wide — submanifold, strided and
     # inverse alike (the kernel only sees a neighbour table).  Below ~4 k output rows the launch does not fill the chip and
     # K9b's offset splits win.
-    PLANES_MIN_ROWS = int(os.environ.get("FSF_PLANES_MIN_ROWS", "4096"))
+    PLANES_MIN_ROWS = switches.PLANES_MIN_ROWS
     emit_planes = True   # plane-form output next to the fp32 one (the consumer is another K9c layer); the U-Net clears it where not
 
     def _weight_planes(self):
@@ -262,9 +263,9 @@ class SparseConvolution(SparseModule):
         return [hip_ops.to_planes(f[:, :half]), hip_ops.to_planes(f[:, half:])]
 
     def _use_planes_kernel(self, x, m_out):
-        if not (m_out >= self.PLANES_MIN_ROWS and os.environ.get("FSF_PLANES", "1") != "0"):
+        if not (m_out >= self.PLANES_MIN_ROWS and switches.PLANES):
             return False
-        if not self.subm and os.environ.get("FSF_PLANES_STRIDED", "1") == "0":
+        if not self.subm and not switches.PLANES_STRIDED:
             return False
         cin = self.in_channels
         cins = [p.c for p in x.plane_sources] if x.plane_sources is not None else ([cin] if cin <= 128 else [cin // 2, cin - cin // 2])
@@ -286,7 +287,7 @@ class SparseConvolution(SparseModule):
         needs_grad = torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad)
         if needs_grad:  # training: the epilogue stays in autograd-visible torch ops
             out = _SparseConvFn.apply(feat, self.weight, rb, self.inverse, self._use_split_kernel_training(),
-                                      os.environ.get("FSF_TRAIN_PLANES", "1") != "0" and os.environ.get("FSF_PLANES", "1") != "0")
+                                      switches.TRAIN_PLANES and switches.PLANES)
             if scale is not None:
                 out = out * scale
             if shift is not None:

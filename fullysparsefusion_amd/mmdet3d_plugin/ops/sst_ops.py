@@ -2,6 +2,7 @@
 `scatter_v2` (:150-177), `get_inner_win_inds` (:239-259), `build_mlp` (:808-833),
 `get_activation` / `get_activation_layer` (:835-864).  Same names, arguments and error behaviour; the work is
 done by the HIP library (no torch_scatter, no TorchEx)."""
+from ... import switches
 import traceback
 
 import os
@@ -468,7 +469,7 @@ def batch_norm_act_training(bn, x, relu):
 
     if not (isinstance(bn, nn.BatchNorm1d) and bn.training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2
             and x.dtype == torch.float32 and x.size(0) > 1 and (bn.weight is None) == (bn.bias is None)
-            and os.environ.get("FSF_TRAIN_BN", "1") != "0"):
+            and switches.TRAIN_BN):
         return None
     if type(bn).__name__ != "BatchNorm1d" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         # naiveSyncBN1d across ranks: K23 still does the row passes, the statistics travel as one packed [2C] all-reduce per

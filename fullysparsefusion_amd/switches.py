@@ -1,0 +1,31 @@
+"""A/B switches of the host side.  Every `FSF_*` environment variable of DESIGN.md section 6 is read ONCE, here, when the package is
+imported: the 900-launch frame pays attribute lookups instead of `os.environ` lookups, and a switch cannot change under a frame that
+is running on another host thread.  Scratch scripts set the environment before importing the package
+(`tools/profiling/ab_bench.sh "VAR=0" "VAR=1"` starts one process per setting); tests and bench.py that need both settings in one
+process assign the attribute (`monkeypatch.setattr(switches, "TRAIN_PLANES", False)`).  Default = the fast path."""
+import os
+
+
+def _on(name):
+    return os.environ.get(name, "1") != "0"
+
+
+def _int(name, default):
+    return int(os.environ.get(name, str(default)))
+
+
+PLANES = _on("FSF_PLANES")                          # K9c / K9d dispatch (off: K9b / the fp32 kernel)
+PLANES_STRIDED = _on("FSF_PLANES_STRIDED")          # ... also for strided / inverse convolutions
+PLANES_MIN_ROWS = _int("FSF_PLANES_MIN_ROWS", 4096)
+TRAIN_SPLIT = _on("FSF_TRAIN_SPLIT")                # training: K9b for forward / data gradient of the submanifold layers
+TRAIN_PLANES = _on("FSF_TRAIN_PLANES")              # training: K9c / K9d wherever the direction's shape fits
+TRAIN_BN = _on("FSF_TRAIN_BN")                      # training-mode BatchNorm (+ ReLU) on K23
+SYNCBN_FUSED = _on("FSF_SYNCBN_FUSED")              # naiveSyncBN1d across ranks as one autograd node
+UNET_LATERAL_STREAM = _on("FSF_UNET_LATERAL_STREAM")  # the fine lateral blocks on a side stream
+UNET_LATERAL_LEVELS = _int("FSF_UNET_LATERAL_LEVELS", 3)
+HEAD_SLICED = _on("FSF_HEAD_SLICED")                # the head's attribute branches as one sliced K22 launch per layer
+SEG_HEAD_STACK = _on("FSF_SEG_HEAD_STACK")          # the segmentation head's two output Linears as one launch
+SIR_GATHER = _on("FSF_SIR_GATHER")                  # first SIR layer reads the point features in place through an index
+FUSED_VOTE = _on("FSF_FUSED_VOTE")                  # vote centres + cluster-voxel keys in one kernel
+CLUSTER_ONE_UNIQUE = _on("FSF_CLUSTER_ONE_UNIQUE")  # a single unique in the cluster assignment
+VFE_DECORATE = _on("FSF_VFE_DECORATE")              # the VFE input decoration in one kernel

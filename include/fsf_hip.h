@@ -31,8 +31,17 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 2
+#define FSF_ABI_VERSION 3
 int fsf_abi_version(void);
+
+/* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
+ * fast paths.  Stored atomically inside the library: entry points read them instead of the environment, so a call never
+ * touches getenv (the library is driven from several host threads).  Returns FSF_ERR_INVALID_ARG for an unknown option.
+ *   FSF_OPT_POOL_BRUTE (1): fsf_dynamic_point_pool through the P x R brute-force passes instead of the cell-binned path
+ *                           (initial value: the environment variable FSF_POOL_BRUTE at load time, else 0). */
+#define FSF_OPT_POOL_BRUTE 1
+int fsf_set_option(int32_t option, int64_t value);
+int64_t fsf_get_option(int32_t option);
 
 /* ------------------------------------------------------------------------------------------------
  * K1+K2  dynamic voxelization

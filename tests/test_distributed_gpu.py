@@ -139,7 +139,9 @@ def _syncbn_rank(rank, world):
     res = {}
     rows = [70001, 41234][rank]
     for fused in ("1", "0"):
-        os.environ["FSF_SYNCBN_FUSED"] = fused
+        from fullysparsefusion_amd import switches
+
+        switches.SYNCBN_FUSED = fused == "1"
         torch.manual_seed(0)
         bn = build_norm_layer(dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), 64)[1].to(device).train()
         with torch.no_grad():

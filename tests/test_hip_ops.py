@@ -760,7 +760,9 @@ def test_conv_modules_training_on_the_plane_kernel_vs_oracle_autograd(ops, devic
     m_down = osp.build_rulebook(idx, 2, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), False)[0].shape[0]
     assert m_down >= 4096, m_down
     assert len(calls) == 6 and sorted(calls) == sorted([m, m_down, m, m, m_down, m]), calls  # 3 forwards + 3 data gradients
-    monkeypatch.setenv("FSF_TRAIN_PLANES", "0")
+    from fullysparsefusion_amd import switches
+
+    monkeypatch.setattr(switches, "TRAIN_PLANES", False)
     other = run()
     assert len(calls) == 6
     # oracle
@@ -923,10 +925,13 @@ def test_dynamic_point_pool_binned_equals_brute_force(ops, device, max_inbox, ma
     pts[40:45] = np.nan
     pts = pts[rng.permutation(p)].astype(np.float32)
     d_rois, d_pts = torch.from_numpy(rois.astype(np.float32)).to(device), torch.from_numpy(pts).to(device)
-    monkeypatch.setenv("FSF_POOL_BRUTE", "1")
-    bp, br, bf = ops.dynamic_point_pool(d_rois, d_pts, [1.0, 1.0, 1.0], max_inbox, max_all)
-    monkeypatch.setenv("FSF_POOL_BRUTE", "0")
-    gp, gr, gf = ops.dynamic_point_pool(d_rois, d_pts, [1.0, 1.0, 1.0], max_inbox, max_all)
+    old = ops.set_option(ops.OPT_POOL_BRUTE, 1)  # (fsf_set_option: the library reads no environment variable per call)
+    try:
+        bp, br, bf = ops.dynamic_point_pool(d_rois, d_pts, [1.0, 1.0, 1.0], max_inbox, max_all)
+        ops.set_option(ops.OPT_POOL_BRUTE, 0)
+        gp, gr, gf = ops.dynamic_point_pool(d_rois, d_pts, [1.0, 1.0, 1.0], max_inbox, max_all)
+    finally:
+        ops.set_option(ops.OPT_POOL_BRUTE, old)
     assert gp.numel() == bp.numel() and gp.numel() > 0
     assert torch.equal(gp, bp) and torch.equal(gr, br) and torch.equal(gf, bf)
     assert int((gr == 0).sum()) == min(max_inbox, max_all)
