@@ -19,6 +19,8 @@
 // 64-wide k chunks, double-buffered by LDS-DMA), 16 point rows are the B operand (loaded straight from HBM in operand
 // layout — lane (row, g) reads 32 contiguous bytes per k step — and split in registers).  A lane ends up with channels
 // 16 t + 4 g + r of its row: LayerNorm is an in-lane sum + two shuffles, the result leaves as 16-byte stores.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace fsf {
@@ -33,7 +35,7 @@ constexpr int LNA_RG = 2;         // 16-row groups per wave and iteration
 #ifndef LNA_WPS
 #define LNA_WPS 3                 // waves per SIMD the register budget is set for (workgroups per CU)
 #endif
-constexpr int LNA_ROWS = LNA_NW * LNA_RG * 16;  // rows per workgroup iteration
+constexpr int LNA_ROWS = LNA_NW * LNA_RG * 16;  // rows per workgroup iteration (4-wave workgroups)
 
 struct LnaArgs {
   const float* x; int64_t x_stride; int k;
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256)
 // epilogue of one row block: lane (row, g) holds channels ch_base + 16 t + 4 g + r of its row
 // bias | gamma | beta of the 128-channel slice at ch_base -> LDS (defaults 0 | 1 | 0 where absent or beyond c)
 __device__ __forceinline__ void lna_stage_vectors(const LnaArgs& a, int ch_base, float* vec) {
-  for (int t = threadIdx.x; t < 384; t += LNA_NW * 64) {
+  for (int t = threadIdx.x; t < 384; t += blockDim.x) {
     const int which = t >> 7, ch = ch_base + (t & 127);
     const float* src = which == 0 ? a.bias : (a.norm != 0 ? (which == 1 ? a.gamma : a.beta) : nullptr);
     vec[t] = (src && (t & 127) < a.slice_w && ch < a.c) ? src[ch] : (which == 1 ? 1.0f : 0.0f);
@@ -202,8 +204,15 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
   }
 }
 
-template <int T>  // 16-channel tiles (c <= 16 T)
-__global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_kernel(LnaArgs a) {
+// NW waves per workgroup.  A weight chunk enters the CU once per WORKGROUP and chunk (LDS-DMA), so three 4-wave workgroups per CU
+// take the same 24 KB in three times per 128 rows each; ONE 12-wave workgroup per CU (same 12 waves, same registers) takes it in
+// once per 384 rows.  Measured (round 3, same box): no faster in isolation (510 k x 256 -> 128: 277 vs 279 us; k = 128 .. 180: 5-15 %
+// SLOWER — a barrier over twelve waves per chunk) and 7 % slower in the frame (a 768-thread workgroup shuts the other stream's kernels
+// out of its CU) — so the weight stream is not what this kernel waits for.  Kept behind FSF_K22_WIDE_MIN_ROWS=<rows> (default: never).
+template <int T, int NW>  // 16-channel tiles (c <= 16 T)
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_act_kernel(LnaArgs a) {
+  constexpr int LNA_NW = NW;
+  constexpr int LNA_ROWS = NW * LNA_RG * 16;
   constexpr int CHUNK_U4 = T * 3 * 64;  // uint4 per weight chunk
   extern __shared__ __attribute__((aligned(16))) char lna_smem[];
   uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4], then 384 floats of per-channel vectors
@@ -390,21 +399,26 @@ extern "C" int fsf_linear_prepare_weight_sliced(const float* weight, int32_t k, 
 }
 
 static int lna_launch(const LnaArgs& a, int nslice, hipStream_t stream) {
-  const int64_t nblk = (a.n + LNA_ROWS - 1) / LNA_ROWS;
-  int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;  // LNA_WPS 4-wave workgroups per CU in total
+  // FSF_K22_WIDE_MIN_ROWS (A/B, latched): from how many rows the 12-wave workgroups run; 0 = never (the default)
+  static const int64_t wide_min_rows = getenv("FSF_K22_WIDE_MIN_ROWS") ? atoll(getenv("FSF_K22_WIDE_MIN_ROWS")) : 0;
+  const int T = lna_tiles(a.slice_w < a.c ? a.slice_w : a.c);
+  const bool wide = T == 8 && wide_min_rows > 0 && a.n * nslice >= wide_min_rows;
+  const int rows = (wide ? 12 : LNA_NW) * LNA_RG * 16;
+  const int64_t nblk = (a.n + rows - 1) / rows;
+  int64_t gx = ((wide ? 256 : 256 * LNA_WPS) + nslice - 1) / nslice;  // 12 waves per CU in total either way
   if (gx > nblk) gx = nblk;
   const dim3 grid((unsigned)gx, (unsigned)nslice);
-#define FSF_LNA(T_)                                                                                                     \
+#define FSF_LNA(T_, NW_)                                                                                                \
   do {                                                                                                                 \
     constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4;                                                    \
     static std::atomic<uint64_t> attr_done{0};                                                                         \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_>, (int)smem, attr_done));               \
-    hipLaunchKernelGGL((linear_norm_act_kernel<T_>), grid, dim3(LNA_NW * 64), smem, stream, a);                        \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_, NW_>, (int)smem, attr_done));          \
+    hipLaunchKernelGGL((linear_norm_act_kernel<T_, NW_>), grid, dim3(NW_ * 64), smem, stream, a);                      \
   } while (0)
-  const int T = lna_tiles(a.slice_w < a.c ? a.slice_w : a.c);
-  if (T == 2) FSF_LNA(2);
-  else if (T == 4) FSF_LNA(4);
-  else FSF_LNA(8);
+  if (wide) FSF_LNA(8, 12);
+  else if (T == 2) FSF_LNA(2, 4);
+  else if (T == 4) FSF_LNA(4, 4);
+  else FSF_LNA(8, 4);
 #undef FSF_LNA
   FSF_LAUNCH_CHECK();
   return FSF_OK;
