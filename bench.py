@@ -67,6 +67,12 @@ def parse():
     ap.add_argument("--dataset", choices=["nuscenes", "av2"], default="nuscenes",
                     help="nuscenes = BASELINE config 3 input (the headline); av2 = config 5 shape (+-204.8 m, 2048^2 x 32 grid, 7 cams, "
                          "int32 id planes, 26 classes)")
+    ap.add_argument("--trained-like", action="store_true",
+                    help="time the trained-like variant INSTEAD of the headline workload: 40 small 2-D instances per frame and "
+                         "segmentation / classification biases calibrated so that ~5 %% of the points are foreground and a few hundred "
+                         "boxes reach the NMS (what FSF_nuScenes_config.py:22-30,377-384 thresholds leave with trained weights); "
+                         "the default run reports it BESIDE the headline (`trained_like`)")
+    ap.add_argument("--no-trained-like", action="store_true", help="skip the trained-like side measurement of the default run")
     ap.add_argument("--hot-path-only", action="store_true",
                     help="time stages 1-3 only (segmentor + fusion, camera queries, LiDAR queries), no heads / refine / NMS")
     return ap.parse_args()
@@ -85,12 +91,14 @@ def build_model(device, dataset="nuscenes"):
     return model.to(device)
 
 
-def make_inputs(sweeps, seed, device, frames=1, dataset="nuscenes"):
+def make_inputs(sweeps, seed, device, frames=1, dataset="nuscenes", trained_like=False):
     """One batch (`frames` frames, normally 1) resident on `device`; returns (first host frame, device batch)."""
     from fullysparsefusion_amd import synthetic
 
     if dataset == "av2":
         fs = [synthetic.make_frame_av2(seed=seed * 97 + i) for i in range(frames)]
+    elif trained_like:
+        fs = [synthetic.make_frame(num_sweeps=sweeps, seed=seed * 97 + i, mask_instances=40, mask_max_area=0.02) for i in range(frames)]
     else:
         fs = [synthetic.make_frame(num_sweeps=sweeps, seed=seed * 97 + i) for i in range(frames)]
     dev = dict(
@@ -121,6 +129,65 @@ def describe_output(model, inp, out, args):
     else:
         hot, extra = out, {}
     return dict(camera_queries=int(hot["frustum_obj_feats"].shape[0]), lidar_queries=int(hot["fsd_obj_feats"].shape[0]), **extra)
+
+
+def calibrate_trained_like(model, inp, fg_fraction=0.05, nms_candidates=600):
+    """Random-init weights make 91 % of the points foreground and every query a box candidate in every class — conservative, but
+    not the stage mix of a deployed model.  This shifts TWO biases of the (otherwise unchanged) random-init model, calibrated on
+    one frame, so that the reference's own thresholds cut like they do with trained weights:
+      * the background logit of the segmentation head (`VoteSegHead.conv_seg`), until the share of points whose class-group score
+        passes `score_thresh` (FSF_nuScenes_config.py:22-30: 0.1 per group) is `fg_fraction`;
+      * the class-score branch of the refined head (`FSDSeparateHead.score`), until `nms_candidates` (query, class) pairs pass
+        `score_thr` (0.01, FSF_nuScenes_config.py:377-384) and enter the per-class NMS.
+    The foreground points are still scattered (random logits have no spatial structure), so the LiDAR-query clustering sees many
+    small clusters; the camera branch gets its realism from the frame (40 instances instead of 250).  Returns what was achieved."""
+    cfg = model.cfg
+    names = list(cfg["class_names"])
+    groups = [[names.index(n) for n in g] for g in cfg["group_names"]]
+    thr = cfg["score_thresh"]
+    head = model.segmentor.segmentation_head
+    with torch.no_grad():
+        lg = model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])["seg"]["seg_logits"].float()
+
+        def frac(delta):
+            z = lg.clone()
+            z[:, -1] += delta
+            p = z.softmax(1)
+            fg = torch.zeros(lg.size(0), dtype=torch.bool, device=lg.device)
+            for gi, idx in enumerate(groups):
+                fg |= p[:, idx].sum(1) > thr[gi]
+            return float(fg.float().mean())
+
+        lo, hi = 0.0, 40.0
+        for _ in range(40):
+            mid = 0.5 * (lo + hi)
+            lo, hi = (mid, hi) if frac(mid) > fg_fraction else (lo, mid)
+        head.conv_seg.bias[-1] += hi
+        got_fg = frac(hi)
+        # refined head: capture its class logits on this frame
+        rh = model.frustum_refined_head[0]
+        cap = {}
+        orig = rh.forward
+
+        def tap(*a, **k):
+            out = orig(*a, **k)
+            cap["cls"] = out["cls_logits"][0]
+            return out
+
+        rh.forward = tap
+        try:
+            model.simple_test(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+        finally:
+            rh.forward = orig
+        cls = cap["cls"].float().flatten()
+        k = min(nms_candidates, cls.numel())
+        kth = float(torch.topk(cls, k).values[-1])
+        logit_thr = float(np.log(rh.test_cfg["score_thr"] / (1.0 - rh.test_cfg["score_thr"])))
+        score_mlp = rh.task_heads[0].score
+        last = [m for m in score_mlp.modules() if isinstance(m, torch.nn.Linear)][-1]
+        last.bias += (logit_thr - kth)
+    return dict(fg_fraction_target=fg_fraction, fg_fraction_points=round(got_fg, 4), seg_background_bias_shift=round(hi, 3),
+                nms_candidates_target=int(k), refined_score_bias_shift=round(logit_thr - kth, 3), queries=int(cap["cls"].shape[0]))
 
 
 def dummy_loss(out):
@@ -245,6 +312,94 @@ def _acc_spconv(kind):
         pairs = float((nbr >= 0).sum())
         return ("spconv_" + kind, pairs * (cin + cout) * 4 + nbr.size(1) * cin * cout * 4 + 8 * pairs, 2.0 * pairs * cin * cout)
     return account
+
+
+def _acc_bwd_weight(a, k, out):
+    feat, grad_out, num = a[0], a[1], a[3]   # hip_ops.spconv_backward_weight(feat, grad_out, pairs, num)
+    pairs = float(num.sum())
+    cin, cout = feat.size(1), grad_out.size(1)
+    return "spconv_bwd_weight", pairs * (cin + cout) * 4 + 8 * pairs + num.numel() * cin * cout * 4, 2.0 * pairs * cin * cout
+
+
+def train_extras(train_step, pool, steps, world, dist, device):
+    """What a `--train` line says beyond frames/s (every rank takes part: the collectives are real).
+      * `roofline`: the step's dominant kernel — K10, `fsf::spconv_bwd_weight_kernel`, on the fp32 matrix pipe — timed with HIP
+        events in situ over `n` instrumented steps: flops 2 P Cin Cout of the pair lists it received / time, against 157.3 TFLOP/s;
+        the K9 forward / data-gradient launches of the same steps beside it;
+      * `allreduce`: the step timed again under `no_sync()` (no collective at all) — the difference to the timed step is the all-reduce
+        time the backward pass did NOT hide; the buckets' all-reduces timed in isolation (back to back, nothing else running) are the
+        collective's full cost; overlap = 1 - exposed / isolated."""
+    from fullysparsefusion_amd import hip_ops
+
+    nframes = len(pool)
+    n = max(2, min(steps, 4))
+    p = _Probe("events")
+    p.wrap(hip_ops, "spconv_backward_weight", _acc_bwd_weight)
+    p.wrap(hip_ops, "spconv_forward_planes", _acc_spconv("planes"))
+    p.wrap(hip_ops, "spconv_forward_split", _acc_spconv("split"))
+    p.wrap(hip_ops, "spconv_forward", _acc_spconv("fp32"))
+    try:
+        for i in range(n):
+            train_step(pool[i % nframes])
+        torch.cuda.synchronize()
+    finally:
+        p.restore()
+    t = p.table()
+    kern = {}
+    peaks = {"spconv_bwd_weight": MFMA_F32_PEAK_TFLOPS, "spconv_planes": MFMA_16BIT_PEAK_TFLOPS / 3, "spconv_split": MFMA_16BIT_PEAK_TFLOPS / 6,
+             "spconv_fp32": MFMA_F32_PEAK_TFLOPS}
+    for key, d in t.items():
+        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        kern[key] = dict(launches_per_step=round(d["calls"] / n, 1), ms_per_step=round(d["ms"] / n, 3), tflops_fp32_equivalent=round(tf, 2),
+                         pipe_peak_tflops_fp32_equivalent=round(peaks[key], 1), frac_of_pipe_peak=round(tf / peaks[key], 4),
+                         algorithmic_gflop_per_step=round(d["flops"] / n / 1e9, 1))
+    k10 = kern.get("spconv_bwd_weight", dict(tflops_fp32_equivalent=0.0, frac_of_pipe_peak=0.0))
+    roof = dict(bound="mfma", kernel="fsf::spconv_bwd_weight_kernel (K10: weight gradient over the spconv-v1 pair lists, fp32 matrix pipe)",
+                achieved=k10["tflops_fp32_equivalent"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=k10["frac_of_pipe_peak"], traffic=None,
+                kernels=kern, note="HIP events in situ on the launching stream over %d instrumented training steps; forward / data-gradient "
+                                   "launches (K9c/K9d, K9b, fp32 kernel) of the same steps listed beside the dominant kernel" % n)
+    # --- the collective: exposed vs isolated
+    dp = train_step.dp
+
+    def timed(k, sync):
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(k):
+            if sync:
+                train_step(pool[i % nframes])
+            else:
+                with dp.no_sync():
+                    train_step(pool[i % nframes])
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k * 1e3
+
+    k = max(2, min(steps, 4))
+    t_sync, t_local = timed(k, True), timed(k, False)
+    iso = 0.0
+    if dist is not None and world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for b in dp.buckets:
+                dist.all_reduce(b.flat, group=dp.group)
+        torch.cuda.synchronize()
+        iso = (time.perf_counter() - t0) / 3 * 1e3
+        dp.zero_grad()
+    vals = torch.tensor([t_sync, t_local, iso], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+    t_sync, t_local, iso = [float(v) for v in vals]
+    exposed = max(0.0, t_sync - t_local)
+    nbytes = sum(b.flat.numel() for b in dp.buckets) * 4
+    allreduce = dict(world_size=world, gradient_bytes=nbytes, buckets=len(dp.buckets), step_ms=round(t_sync, 3), step_ms_no_sync=round(t_local, 3),
+                     exposed_ms=round(exposed, 3), isolated_ms=round(iso, 3),
+                     overlap_fraction=(round(1.0 - min(1.0, exposed / iso), 3) if iso > 0 else None),
+                     bus_gb_per_s_isolated=(round(2.0 * (world - 1) / world * nbytes / (iso * 1e-3) / 1e9, 1) if iso > 0 else None),
+                     note="max over ranks; world size 1 issues no collective (exposed = run-to-run noise)")
+    return roof, allreduce
 
 
 def _acc_seg_reduce(a, k, out):
@@ -518,8 +673,9 @@ def main():
     model_cpu = (None if args.no_cpu_baseline or rank != 0 or world != 1 or args.train or args.dataset != "nuscenes"
                  else copy.deepcopy(model).cpu())
     nframes = max(1, args.frames)
-    pool = [make_inputs(args.sweeps, seed=rank * 131 + j, device=device, frames=args.frames_per_gpu, dataset=args.dataset)[1]
-            for j in range(nframes)]
+    pool = [make_inputs(args.sweeps, seed=rank * 131 + j, device=device, frames=args.frames_per_gpu, dataset=args.dataset,
+                        trained_like=args.trained_like)[1] for j in range(nframes)]
+    tl_info = calibrate_trained_like(model, pool[0]) if args.trained_like else None
     if args.train:
         train_step = TrainStep(model)
         run = lambda i: train_step(pool[i % nframes])  # noqa: E731
@@ -588,8 +744,15 @@ def main():
                                 else f"replicas x{world} (frames independent, no data-path collective)"),
                 "rccl_world_size": world,
                 "per_rank_frames_per_s": [round(v, 3) for v in per_rank],
+                **({"trained_like": tl_info} if tl_info is not None else {}),
             },
         }
+        if args.trained_like:
+            result["metric"] += " (trained-like variant: calibrated foreground / candidate counts, 40 masks per frame)"
+    if args.train and not args.no_roofline:  # (all ranks: the measurement runs real collectives)
+        roof, allreduce = train_extras(train_step, pool, args.steps, world, dist, device)
+        if rank == 0:
+            result["roofline"], result["allreduce"] = roof, allreduce
     if rank == 0 and not args.no_roofline and not args.train:
         n = min(args.steps, 2 * nframes)
         conv_t, hbm_t = instrumented_pass(model, pool, n, args.hot_path_only)
@@ -603,6 +766,30 @@ def main():
             torch.cuda.synchronize()
             result["stages"] = {"query_generation_ms": round((time.perf_counter() - t0) / n * 1e3, 3),
                                 "full_forward_ms": result["ms_per_step"]}
+    if (rank == 0 and world == 1 and not (args.train or args.hot_path_only or args.trained_like or args.no_trained_like)
+            and args.dataset == "nuscenes" and args.frames_per_gpu == 1):
+        # BESIDE the headline: the same forward on the trained-like variant (see calibrate_trained_like)
+        m2 = build_model(device, args.dataset)  # (same seed -> the same random-init weights; the timed model stays untouched)
+        pool2 = [make_inputs(args.sweeps, seed=977 + j, device=device, trained_like=True)[1] for j in range(2)]
+        info = calibrate_trained_like(m2, pool2[0])
+        for i in range(3):
+            out2 = step(m2, pool2[i % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k2 = 10
+        for i in range(k2):
+            out2 = step(m2, pool2[i % 2])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k2
+        hot2 = step(m2, pool2[(k2 - 1) % 2], hot_path_only=True)
+        result["trained_like"] = dict(
+            value=round(1.0 / dt, 3), unit="frames/s", ms_per_step=round(dt * 1e3, 3), steps=k2,
+            note="reported beside the headline, never instead of it: same model and kernels, 40 small 2-D instances per frame, two bias "
+                 "shifts calibrated on one frame so that the config's own thresholds keep ~5 % of the points and a few hundred box "
+                 "candidates (bench.py::calibrate_trained_like)",
+            camera_queries=int(hot2["frustum_obj_feats"].shape[0]), lidar_queries=int(hot2["fsd_obj_feats"].shape[0]),
+            boxes_out=int(sum(len(r["boxes_3d"]) for r in out2)), **info)
+        del m2, pool2
     if rank == 0 and model_cpu is not None:
         result["cpu_baseline"] = cpu_baseline(model_cpu, args.sweeps)
     if dist is not None:

@@ -1,58 +1,35 @@
-"""Registered-by-name stand-ins for the config types that are OUT OF SCOPE of the hot path (SURVEY.md §2.1 rows
-6-12): unused head variants, label assigners, losses, dataset pipelines and hooks.  They exist so
-that `projects/configs/nuScenes/FSF_nuScenes_config.py` resolves every `type=` and the model builds; calling one
-raises, naming what is missing — they never compute anything (no silent fallbacks)."""
+"""Config `type=` names that are OUT OF SCOPE of the hot path (unused head variants, label
+assigners, losses, dataset classes and hooks) resolve to ONE generic stand-in, so that
+`projects/configs/nuScenes/FSF_nuScenes_config.py` loads and the model builds; using one raises, naming what is missing.
+Nothing here computes anything (no silent fallbacks)."""
 import torch.nn as nn
 
-from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, DATASETS, HOOKS, MODELS, PIPELINES, VOXEL_ENCODERS
+from ..registry import BBOX_ASSIGNERS, BBOX_CODERS, DATASETS, HOOKS, MODELS, PIPELINES
 
 
-def _module_placeholder(name, where):
-    class _P(nn.Module):
-        OUT_OF_SCOPE = True
+def out_of_scope(name, where, module=False):
+    """A class called `name` whose instances only remember their config and raise when used."""
+    def fail(self, *a, **k):
+        raise NotImplementedError(f"{name} ({where}) is outside the MI355X hot path built so far")
 
-        def __init__(self, **kwargs):
-            super().__init__()
-            self.cfg = kwargs
+    def init(self, *args, **kwargs):
+        if module:
+            nn.Module.__init__(self)
+        self.args, self.cfg = args, kwargs
 
-        def forward(self, *a, **k):
-            raise NotImplementedError(f"{name} ({where}) is outside the MI355X hot path built so far")
-
-    _P.__name__ = _P.__qualname__ = name
-    return _P
-
-
-def _plain_placeholder(name, where):
-    class _P:
-        OUT_OF_SCOPE = True
-
-        def __init__(self, *args, **kwargs):
-            self.args, self.cfg = args, kwargs
-
-        def __call__(self, *a, **k):
-            raise NotImplementedError(f"{name} ({where}) is outside the MI355X hot path built so far")
-
-    _P.__name__ = _P.__qualname__ = name
-    return _P
+    return type(name, (nn.Module,) if module else (object,),
+                {"OUT_OF_SCOPE": True, "__init__": init, "forward" if module else "__call__": fail})
 
 
-_HEADS = {
-    "MultiStageRefineHead": "models/dense_heads/multi_stage_refine_head.py",
-    "GroupCorrectionHead": "models/roi_heads/fsd_roi_head.py",
-    "FocalLoss": "mmdet loss", "L1Loss": "mmdet loss", "SmoothL1Loss": "mmdet loss", "CrossEntropyLoss": "mmdet loss",
-}
-for _n, _w in _HEADS.items():
-    MODELS.register_module(_n, module=_module_placeholder(_n, _w))
-for _n in ("ABSPointBBoxCoder",):
-    BBOX_CODERS.register_module(_n, module=_plain_placeholder(_n, "core/bbox/coders"))
-for _n in ("HybridAssigner", "FrustumAssigner", "PointInBoxAssigner", "DistAssigner", "MaxIoUAssigner"):
-    BBOX_ASSIGNERS.register_module(_n, module=_plain_placeholder(_n, "core/bbox/assigners"))
-for _n in ("MyLoadPointsFromMultiSweeps",
-           "LoadAnnotations3D", "ObjectSample",
-           "ObjectRangeFilter", "ObjectNameFilter", "PointShuffle",
-           "MyObjectSample", "MyObjectRangeFilter", "MyGlobalRotScaleTrans", "MyRandomFlip3D", "MyPointShuffle"):
-    PIPELINES.register_module(_n, module=_plain_placeholder(_n, "datasets/pipelines"))
-for _n in ("NuScenesDataset", "CBGSDataset", "Argo2Dataset", "My_Resample_Dataset", "RepeatDataset"):
-    DATASETS.register_module(_n, module=_plain_placeholder(_n, "datasets"))
-for _n in ("DisableAugmentationHook", "EnableFSDDetectionHook", "EnableFSDDetectionHookIter"):
-    HOOKS.register_module(_n, module=_plain_placeholder(_n, "core/hook/fsd_hooks.py"))
+for _reg, _where, _module, _names in (
+        (MODELS, "heads / losses of the training path", True,
+         "MultiStageRefineHead GroupCorrectionHead FocalLoss L1Loss SmoothL1Loss CrossEntropyLoss"),
+        (BBOX_CODERS, "core/bbox/coders", False, "ABSPointBBoxCoder"),
+        (BBOX_ASSIGNERS, "core/bbox/assigners", False, "HybridAssigner FrustumAssigner PointInBoxAssigner DistAssigner MaxIoUAssigner"),
+        (PIPELINES, "datasets/pipelines (training augmentations)", False,
+         "MyLoadPointsFromMultiSweeps LoadAnnotations3D ObjectSample ObjectRangeFilter ObjectNameFilter PointShuffle MyObjectSample "
+         "MyObjectRangeFilter MyGlobalRotScaleTrans MyRandomFlip3D MyPointShuffle"),
+        (DATASETS, "datasets", False, "NuScenesDataset CBGSDataset Argo2Dataset My_Resample_Dataset RepeatDataset"),
+        (HOOKS, "core/hook/fsd_hooks.py", False, "DisableAugmentationHook EnableFSDDetectionHook EnableFSDDetectionHookIter")):
+    for _n in _names.split():
+        _reg.register_module(_n, module=out_of_scope(_n, _where, _module))

@@ -77,15 +77,16 @@ def make_lidar2img(ncam=6, fx=1266.0, cx=800.0, cy=450.0):
     return np.ascontiguousarray(np.stack(mats))
 
 
-def make_mask_data(rng, ncam=6, ncls=10, H=900, W=1600, num_inst=250, dtype=np.uint8):
+def make_mask_data(rng, ncam=6, ncls=10, H=900, W=1600, num_inst=250, dtype=np.uint8, painted=None, max_area=0.05):
     """Instance-id planes painted as axis-aligned rectangles (0.1-5 % of the image) + the matching anno rows
-    sorted by obj_id."""
+    sorted by obj_id.  `painted` < num_inst: only that many instances exist, the remaining anno rows are the zero padding
+    (valid = 0) the reference's loader appends (datasets/pipelines/loading.py:301-339)."""
     mask = np.zeros((ncam, ncls, H, W), dtype=dtype)
     anno = np.zeros((num_inst, 9), dtype=np.float32)
-    for inst in range(1, num_inst + 1):
+    for inst in range(1, (num_inst if painted is None else min(painted, num_inst)) + 1):
         cam = int(rng.integers(ncam))
         cls = int(rng.integers(ncls))
-        area = rng.uniform(0.001, 0.05) * H * W
+        area = rng.uniform(0.001, max_area) * H * W
         aspect = rng.uniform(0.4, 2.5)
         w = int(min(W - 1, max(2, math.sqrt(area * aspect))))
         h = int(min(H - 1, max(2, area / max(w, 1))))
@@ -96,11 +97,13 @@ def make_mask_data(rng, ncam=6, ncls=10, H=900, W=1600, num_inst=250, dtype=np.u
     return mask, anno
 
 
-def make_frame(num_sweeps=10, seed=0):
-    """One synthetic frame of BASELINE.json config 3 (10 sweeps) or config 2 (1 sweep)."""
+def make_frame(num_sweeps=10, seed=0, mask_instances=None, mask_max_area=0.05):
+    """One synthetic frame of BASELINE.json config 3 (10 sweeps) or config 2 (1 sweep).  `mask_instances` / `mask_max_area`: fewer,
+    smaller 2-D instances (bench.py's trained-like variant: a real frame has a few dozen masks covering a few % of the pixels, not
+    250 covering most of them)."""
     rng = np.random.default_rng(seed + 1000)
     pts = make_points(num_sweeps, seed)
-    mask, anno = make_mask_data(rng)
+    mask, anno = make_mask_data(rng, painted=mask_instances, max_area=mask_max_area)
     return dict(points=pts, mask_data=mask, mask_anno=anno, lidar2img=make_lidar2img())
 
 
