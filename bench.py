@@ -514,7 +514,8 @@ SPCONV_KERNELS = {
                     "v_mfma_f32_16x16x4_f32"),
     "spconv_split": ("fsf::spconv_fwd_split_kernel (bf16 MFMA x6 = exact 3-way split, row-stationary in registers)",
                      MFMA_16BIT_PEAK_TFLOPS / 6, "v_mfma_f32_16x16x32_bf16, 6 per fp32-equivalent product"),
-    "spconv_planes": ("fsf::spconv_fwd_planes_kernel (f16 MFMA x3 = row-scaled 2-way f16 split, channel-stationary waves, cell skipping)",
+    "spconv_planes": ("fsf::spconv_fwd_pipe_kernel (K9d: f16 MFMA x3 = row-scaled 2-way f16 split, channel-stationary waves, cell skipping, "
+                      "chunk-granular pipeline; layers it does not take run fsf::spconv_fwd_planes_kernel, K9c)",
                       MFMA_16BIT_PEAK_TFLOPS / 3, "v_mfma_f32_16x16x32_f16, 3 per fp32-equivalent product"),
 }
 
