@@ -95,6 +95,9 @@ _ARGTYPES = {
     "fsf_connected_components_grouped": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
+    "fsf_order_by_neighbor_mask_workspace_bytes": [c_i64],
+    "fsf_order_by_neighbor_mask": [_P, c_i64, c_i32, _P, _P, _P, _P, c_i64, _P],
+    "fsf_remap_indices": [_P, c_i64, _P, _P, _P],
     "fsf_set_option": [c_i32, c_i64],
     "fsf_get_option": [c_i32],
 }
@@ -530,6 +533,30 @@ def rulebook_strided(indices: torch.Tensor, batch_size: int, spatial_shape, ksiz
                                  ws.numel(), stream_ptr()), "fsf_rulebook_strided")
     m_out = int(m_out_host.value)
     return out_indices[:m_out], nbr[:m_out], nbr_inv, out_shape
+
+
+def order_by_neighbor_mask(indices: torch.Tensor, batch_size: int, spatial_shape):
+    """fsf_order_by_neighbor_mask: coordinates i32 [m, 4] (b, z, y, x) of a level -> (perm i32 [m], inv_perm i32 [m]): position i of the
+    new order holds row perm[i]: descending 16-bit neighbourhood key (in-plane 3x3 mask | counts below / above), stable."""
+    require_cuda(indices)
+    assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.size(1) == 4 and indices.is_contiguous()
+    m = indices.size(0)
+    perm = torch.empty((m,), dtype=torch.int32, device=indices.device)
+    inv = torch.empty((m,), dtype=torch.int32, device=indices.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_order_by_neighbor_mask_workspace_bytes(m), indices.device)
+    check(h.fsf_order_by_neighbor_mask(ptr(indices), m, int(batch_size), i32_array(spatial_shape), ptr(perm), ptr(inv), ptr(ws),
+                                       ws.numel(), stream_ptr()), "fsf_order_by_neighbor_mask")
+    return perm, inv
+
+
+def remap_indices(table: torch.Tensor, index_map: torch.Tensor):
+    """fsf_remap_indices: out = table >= 0 ? index_map[table] : -1 (i32, any shape)."""
+    require_cuda(table, index_map)
+    assert table.dtype == torch.int32 and index_map.dtype == torch.int32 and table.is_contiguous() and index_map.is_contiguous()
+    out = torch.empty_like(table)
+    check(_L().fsf_remap_indices(ptr(table), table.numel(), ptr(index_map), ptr(out), stream_ptr()), "fsf_remap_indices")
+    return out
 
 
 def rulebook_to_pairs(nbr: torch.Tensor):

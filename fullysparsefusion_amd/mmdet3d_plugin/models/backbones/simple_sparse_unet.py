@@ -52,6 +52,11 @@ class SimpleSparseUNet(nn.Module):
         for lvl in range(1, self.stage_num + 1):
             getattr(self, f"merge_layer{lvl}")[0].emit_planes = False
         self.upsample_layer1[0].emit_planes = False
+        # neighbour-mask row order of the fine levels (inference, see forward): the strided convolution INTO level l hands its
+        # output rows over in that order and registers the level's submanifold rulebook under this key
+        for lvl in range(2, self.stage_num + 1):
+            first = list(getattr(self.encoder_layers, f"encoder_layer{lvl}")._modules.values())[0][0]
+            first.reorder_output_key = f"subm{lvl}" if lvl <= switches.UNET_MASK_ORDER_LEVELS else None
 
     def make_encoder_layers(self, norm_cfg, in_channels):
         self.encoder_layers = SparseSequential()
@@ -130,7 +135,22 @@ class SimpleSparseUNet(nn.Module):
             batch_size = voxel_info.get("batch_size")
         if batch_size is None:
             batch_size = int(coors[:, 0].max().item()) + 1  # upstream's host sync; callers that know B pass it
-        x = SparseConvTensor(voxel_features, coors.contiguous(), self.sparse_shape, batch_size)
+        # Row order INSIDE the network (inference): the plane kernels visit a (64-row block, kernel offset) pair only if a row of the
+        # block has a neighbour there; with rows of equal neighbour mask adjacent (fsf_order_by_neighbor_mask: more neighbours first) a
+        # block of the 0.2 m level touches 8.1 of 27 offsets instead of 16.8 and its live cells are 80 % full instead of 39 % (0.4 m
+        # level: 24.8 -> 17.1, 61 -> 93 %).  The level's rows are permuted on the way in, every rulebook is built on the permuted
+        # coordinates (so tables and features agree by construction), and the output goes back to the input order.
+        reorder = (switches.UNET_MASK_ORDER and voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training
+                   and voxel_features.size(0) >= switches.UNET_MASK_ORDER_MIN_ROWS)
+        inv_perm = None
+        coors = coors.contiguous()
+        if reorder:
+            perm, inv_perm = hip_ops.order_by_neighbor_mask(coors, batch_size, self.sparse_shape)
+            perm64, inv_perm = perm.long(), inv_perm.long()
+            coors = coors.index_select(0, perm64)
+            voxel_features = voxel_features.index_select(0, perm64)
+        x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        x.indice_dict["__mask_order__"] = reorder  # (the dict is shared by every tensor derived from x)
         x = self.conv_input(x)
         encode_features = []
         # Inference: the lateral blocks of the FINE levels (two big submanifold convolutions each, independent of everything below
@@ -176,4 +196,7 @@ class SimpleSparseUNet(nn.Module):
         finally:
             if lateral_done:  # whatever happens in the decoder, the main stream ends behind the side stream's work
                 torch.cuda.current_stream().wait_stream(self._lateral_stream)
-        return [{"voxel_feats": x.features}]
+        out = x.features
+        if inv_perm is not None:
+            out = out.index_select(0, inv_perm)  # back to the caller's voxel order
+        return [{"voxel_feats": out}]

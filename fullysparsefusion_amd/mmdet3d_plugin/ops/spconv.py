@@ -192,6 +192,18 @@ class SparseConvolution(SparseModule):
         else:
             out_idx, nbr, nbr_inv, out_shape = hip_ops.rulebook_strided(
                 x.indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding, self.dilation)
+            key = getattr(self, "reorder_output_key", None)
+            if (key is not None and x.indice_dict.get("__mask_order__", False) and out_idx.size(0) >= switches.UNET_MASK_ORDER_MIN_ROWS
+                    and x.find_indice_pair(key) is None):
+                # the coarse level in neighbour-mask order (SimpleSparseUNet.forward): output rows permuted, the inverse table's
+                # VALUES (coarse rows) remapped, and the level's submanifold rulebook registered on the permuted coordinates
+                perm, inv_perm = hip_ops.order_by_neighbor_mask(out_idx, x.batch_size, out_shape)
+                perm64 = perm.long()
+                out_idx = out_idx.index_select(0, perm64)
+                nbr = nbr.index_select(0, perm64)
+                nbr_inv = hip_ops.remap_indices(nbr_inv, inv_perm)
+                x.indice_dict[key] = Rulebook("subm", hip_ops.rulebook_subm(out_idx, x.batch_size, out_shape), out_idx, out_shape,
+                                              out_idx, out_shape)
             rb = Rulebook("strided", nbr, x.indices, x.spatial_shape, out_idx, out_shape, nbr_inv)
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = rb

@@ -29,3 +29,6 @@ SIR_GATHER = _on("FSF_SIR_GATHER")                  # first SIR layer reads the 
 FUSED_VOTE = _on("FSF_FUSED_VOTE")                  # vote centres + cluster-voxel keys in one kernel
 CLUSTER_ONE_UNIQUE = _on("FSF_CLUSTER_ONE_UNIQUE")  # a single unique in the cluster assignment
 VFE_DECORATE = _on("FSF_VFE_DECORATE")              # the VFE input decoration in one kernel
+UNET_MASK_ORDER = _on("FSF_UNET_MASK_ORDER")          # inference: the U-Net's fine levels in neighbour-mask row order
+UNET_MASK_ORDER_LEVELS = _int("FSF_UNET_MASK_ORDER_LEVELS", 2)  # how many levels from the finest (1 = the input level only)
+UNET_MASK_ORDER_MIN_ROWS = _int("FSF_UNET_MASK_ORDER_MIN_ROWS", 16384)

@@ -459,3 +459,58 @@ def test_av2_segmentor_at_150k_points_vs_oracle(device):
     assert int(inv.long().sum()) == int(g["inv_sum"])
     for name, t, rows in [("voxel_feats", vf, vrow), ("unet", unet, vrow), ("neck", neck, prow)]:
         close(t[rows], torch.from_numpy(g[name + "_rows"]), 1e-4, scale=float(g[name + "_scale"]))
+
+
+# ------------------------------------------------------------- neighbour-mask row order inside the U-Net
+def test_order_by_neighbor_mask_is_a_stable_sort_by_its_key(device):
+    from fullysparsefusion_amd import hip_ops as ops
+    from oracle import spconv as osp
+
+    rng = np.random.default_rng(3)
+    for m, shape, bs in [(1, (8, 16, 16), 1), (700, (8, 24, 24), 2), (60000, (40, 512, 512), 1)]:
+        idx = surface_like_sites(rng, bs, shape, m)
+        n = idx.shape[0]
+        perm, inv = ops.order_by_neighbor_mask(torch.from_numpy(idx).to(device), bs, shape)
+        perm, inv = perm.cpu().numpy(), inv.cpu().numpy()
+        _, pairs, _ = osp.build_rulebook(idx, bs, list(shape), (3, 3, 3), (1, 1, 1), (1, 1, 1), (1, 1, 1), True)
+        nbr = osp.pairs_to_nbr(pairs, n)                      # the oracle's submanifold table: its masks are the yardstick
+        mask = ((nbr >= 0).astype(np.int64) << np.arange(27)).sum(1)
+        popc = lambda v: np.array([bin(int(t)).count("1") for t in v])  # noqa: E731
+        key = (((mask >> 9) & 511) << 7) | (np.minimum(popc(mask & 511), 7) << 4) | np.minimum(popc(mask >> 18), 15)
+        want = np.lexsort((np.arange(n), -key))               # descending key (in-plane mask | counts below / above), ties in row order
+        np.testing.assert_array_equal(perm, want)
+        np.testing.assert_array_equal(inv[perm], np.arange(n))
+        table = torch.from_numpy(nbr.astype(np.int32)).to(device)
+        got = ops.remap_indices(table, torch.from_numpy(inv).to(device)).cpu().numpy()
+        np.testing.assert_array_equal(got, np.where(nbr >= 0, inv[np.clip(nbr, 0, None)], -1))
+
+
+def surface_like_sites(rng, bs, shape, m):
+    """Distinct (b, z, y, x) sites clustered on a few z layers (LiDAR-like occupancy), lexicographically sorted."""
+    z = rng.integers(0, min(shape[0], 6), 4 * m)
+    y, x = rng.integers(0, shape[1], 4 * m), rng.integers(0, shape[2], 4 * m)
+    b = rng.integers(0, bs, 4 * m)
+    sites = np.unique(np.stack([b, z, y, x], 1), axis=0)
+    keep = np.sort(rng.choice(len(sites), size=min(m, len(sites)), replace=False))
+    return sites[keep].astype(np.int32)
+
+
+def test_unet_in_mask_order_equals_the_reference_row_order_bit_for_bit(fsf_pair, frame10, device, monkeypatch):
+    """SimpleSparseUNet with its two fine levels in neighbour-mask row order (the default at inference) against the same network
+    in the reference's lexicographic order: every output row is the same sum in the same order (a block that visits an offset a row
+    has no neighbour at adds an exact zero), so the results must be IDENTICAL — and the rulebooks it used are permutations of
+    the reference's."""
+    from fullysparsefusion_amd import switches
+
+    model, _ = fsf_pair
+    seg = model.segmentor
+    pts = torch.from_numpy(frame10["points"][:, :5].copy()).to(device)
+    with torch.no_grad():
+        p_dev, coors = seg.voxelize([pts])
+        vf, vc, _ = seg.voxel_encoder(p_dev, coors, return_inv=True)
+        outs = {}
+        for on in (True, False):
+            monkeypatch.setattr(switches, "UNET_MASK_ORDER", on)
+            outs[on] = seg.backbone(dict(voxel_feats=vf, voxel_coors=vc, batch_size=1))[0]["voxel_feats"]
+    assert vf.shape[0] > 90000
+    assert torch.equal(outs[True], outs[False])
