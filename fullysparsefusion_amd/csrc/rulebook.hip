@@ -454,7 +454,13 @@ __global__ void __launch_bounds__(256)
       // 0.2 m level 13.2 k against 11.6 k; lexicographic order 39.1 k / 24.3 k).  Ascending sort of the complement: full rows first.
       const uint32_t mid = (mask >> 9) & 511u;
       const uint32_t lo = min(__popc(mask & 511u), 7), hi = min(__popc(mask >> 18), 15);
-      keys[r] = (uint64_t)(0xffffu & ~((mid << 7) | (lo << 4) | hi));
+      // ... and the parity of (z, y, x) as the LEAST significant digit (a third pass): a stride-2 inverse convolution reaches a fine
+      // row only through the kernel offsets its parity admits, so rows of one neighbourhood key are kept together by parity — the
+      // inverse convolutions into the level then walk 17.5 k / 21.9 k steps instead of 33.5 k / 35.4 k (lexicographic 20.2 k / 19.6 k)
+      // and the submanifold layers are unchanged (13.3 k / 28.0 k)
+      const int4 c0 = *reinterpret_cast<const int4*>(indices + r * 4);
+      const uint32_t parity = (uint32_t)(((c0.y & 1) << 2) | ((c0.z & 1) << 1) | (c0.w & 1));
+      keys[r] = ((uint64_t)(0xffffu & ~((mid << 7) | (lo << 4) | hi)) << 3) | parity;
       vals[r] = (uint32_t)r;
     }
   }
@@ -511,7 +517,7 @@ extern "C" int fsf_order_by_neighbor_mask(const int32_t* indices, int64_t m, int
                      (uint64_t)(cap - 1), keys_a, vals_a);
   uint64_t* keys = nullptr;
   uint32_t* order = nullptr;
-  rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, m, 16, &keys, &order, stream);
+  rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, m, 19, &keys, &order, stream);
   if (rc != FSF_OK) return rc;
   hipLaunchKernelGGL(mo_finish_kernel, dim3((unsigned)fsf_stream_grid(m, 256)), dim3(256), 0, stream, order, m, perm, inv_perm);
   FSF_LAUNCH_CHECK();

@@ -537,7 +537,7 @@ def rulebook_strided(indices: torch.Tensor, batch_size: int, spatial_shape, ksiz
 
 def order_by_neighbor_mask(indices: torch.Tensor, batch_size: int, spatial_shape):
     """fsf_order_by_neighbor_mask: coordinates i32 [m, 4] (b, z, y, x) of a level -> (perm i32 [m], inv_perm i32 [m]): position i of the
-    new order holds row perm[i]: descending 16-bit neighbourhood key (in-plane 3x3 mask | counts below / above), stable."""
+    new order holds row perm[i]: descending 16-bit neighbourhood key (in-plane 3x3 mask | counts below / above), then coordinate parity, stable."""
     require_cuda(indices)
     assert indices.dtype == torch.int32 and indices.dim() == 2 and indices.size(1) == 4 and indices.is_contiguous()
     m = indices.size(0)

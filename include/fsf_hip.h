@@ -401,11 +401,12 @@ int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t batch_size, 
  * a neighbour at that offset; in the reference's lexicographic voxel order a block of the 0.2 m level touches 16.8 of 27 offsets with
  * its cells 39 % full, with rows of equal 3x3x3 neighbour mask adjacent 8.1 offsets and 80 % (0.4 m level: 24.8 -> 17.1, 61 -> 93 %).
  * fsf_order_by_neighbor_mask: from the level's coordinates (indices i32 [m, 4] b,z,y,x) — a hash of the sites, 27 probes per row —
- * perm[i] = the row that goes to position i under a 16-bit key (two radix passes): the 9 in-plane neighbours of the row exactly, the
- * planes below / above by their neighbour counts (clipped to 7 / 15); descending, ties in ascending row order (stable:
- * deterministic); inv_perm[perm[i]] = i.  The full 27-bit mask groups no better on LiDAR occupancy (see rulebook.hip) and costs four
- * passes.  (Grouping by coordinate parity first — what a stride-2 inverse convolution's blocks would like — was measured: the
- * inverse convolutions gain 80 us, the submanifold layers lose 190.)
+ * perm[i] = the row that goes to position i under a 19-bit key (three radix passes): the 9 in-plane neighbours of the row exactly, the
+ * planes below / above by their neighbour counts (clipped to 7 / 15), descending — then, inside one such neighbourhood key, the parity
+ * of (z, y, x) ascending (a stride-2 inverse convolution reaches a fine row only through the kernel offsets its parity admits);
+ * ties in ascending row order (stable: deterministic); inv_perm[perm[i]] = i.  The full 27-bit mask groups no better on LiDAR
+ * occupancy (see rulebook.hip) and costs a fourth pass; parity as the MOST significant digit was measured: the inverse
+ * convolutions gain 80 us, the submanifold layers lose 190.
  * fsf_remap_indices: out[j] = in[j] >= 0 ? map[in[j]] : -1 (a table whose VALUES are rows of the reordered level).
  * SimpleSparseUNet [UNVENDORED] applies the order to its fine levels at inference and restores the input order on the way out. */
 int64_t fsf_order_by_neighbor_mask_workspace_bytes(int64_t m);

@@ -477,7 +477,8 @@ def test_order_by_neighbor_mask_is_a_stable_sort_by_its_key(device):
         mask = ((nbr >= 0).astype(np.int64) << np.arange(27)).sum(1)
         popc = lambda v: np.array([bin(int(t)).count("1") for t in v])  # noqa: E731
         key = (((mask >> 9) & 511) << 7) | (np.minimum(popc(mask & 511), 7) << 4) | np.minimum(popc(mask >> 18), 15)
-        want = np.lexsort((np.arange(n), -key))               # descending key (in-plane mask | counts below / above), ties in row order
+        parity = (idx[:, 1] & 1) * 4 + (idx[:, 2] & 1) * 2 + (idx[:, 3] & 1)
+        want = np.lexsort((np.arange(n), parity, -key))       # descending key (in-plane mask | counts below / above), parity, row order
         np.testing.assert_array_equal(perm, want)
         np.testing.assert_array_equal(inv[perm], np.arange(n))
         table = torch.from_numpy(nbr.astype(np.int32)).to(device)
