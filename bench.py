@@ -119,6 +119,76 @@ def step(model, inp, hot_path_only=False):
         return model.simple_test(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
 
 
+def count_launch_sources(model, inp, hot_path_only=False):
+    """How many things one frame asks the device / the host for, counted in ONE extra untimed frame: C-ABI calls
+    of libfsf_hip (each 1-12 kernel launches), ATen ops that do device work (non-view ops seen by a TorchDispatchMode, ~1 launch each)
+    and host synchronisations the Python side can see (`.item()` / `bool()` / `int()` of a device tensor, `nonzero`, boolean-mask
+    indexing, `torch.cuda.synchronize`, and the C-ABI calls that read a count back: fsf_unique_rows, fsf_rulebook_strided).  The exact
+    kernel-launch count needs a trace: `kernel_launches_per_frame_rocprof` is read from the newest committed
+    profiles/*_kernel_stats_full_forward.txt."""
+    import collections
+    import re
+
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    from fullysparsefusion_amd import _lib, hip_ops
+
+    counts = collections.Counter()
+    view = {"view", "slice", "select", "unsqueeze", "squeeze", "expand", "t", "transpose", "permute", "alias", "detach", "as_strided",
+            "_unsafe_view", "reshape", "empty", "empty_strided", "size", "stride", "lift_fresh", "unbind", "split", "narrow", "new_empty",
+            "empty_like", "unfold", "sym_size", "sym_stride", "sym_numel", "is_pinned", "split_with_sizes", "diagonal", "resize_",
+            "record_stream"}
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func).replace("aten.", "").split(".")[0]
+            if name not in view:
+                counts["aten"] += 1
+            if name in ("_local_scalar_dense", "nonzero", "masked_select"):
+                counts["sync"] += 1
+            return func(*args, **(kwargs or {}))
+
+    orig_check, orig_sync = _lib.check, torch.cuda.synchronize
+    sync_calls = {"fsf_unique_rows", "fsf_rulebook_strided"}
+
+    def check(status, what):
+        counts["cabi"] += 1
+        if what in sync_calls:
+            counts["sync"] += 1
+        return orig_check(status, what)
+
+    def sync(*a, **k):
+        counts["sync"] += 1
+        return orig_sync(*a, **k)
+
+    _lib.check = hip_ops.check = check
+    torch.cuda.synchronize = sync
+    was = model.test_cfg.get("concurrent_query_branches", None)
+    model.test_cfg["concurrent_query_branches"] = False  # (a dispatch mode is per thread: count on one)
+    try:
+        with Spy():
+            step(model, inp, hot_path_only)
+    finally:
+        _lib.check = hip_ops.check = orig_check
+        torch.cuda.synchronize = orig_sync
+        if was is None:
+            model.test_cfg.pop("concurrent_query_branches", None)
+        else:
+            model.test_cfg["concurrent_query_branches"] = was
+    orig_sync()
+    traced = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir) if os.path.isdir(pdir) else [], reverse=True):
+        if name.endswith("_kernel_stats_full_forward.txt"):
+            m = re.search(r"(\d+) launches/frame", open(os.path.join(pdir, name)).read(400))
+            if m:
+                traced = dict(value=int(m.group(1)), source=f"profiles/{name}")
+                break
+    return dict(c_abi_calls_per_frame=counts["cabi"], aten_device_ops_per_frame=counts["aten"], host_syncs_per_frame=counts["sync"],
+                kernel_launches_per_frame_rocprof=traced,
+                note="counted in one extra untimed frame with both query branches on one host thread; a C-ABI call is 1-12 launches")
+
+
 def describe_output(model, inp, out, args):
     """Query / box counts of the timed workload (one extra untimed pass when the timed output does not carry them)."""
     if args.no_describe:
@@ -755,6 +825,7 @@ def main():
         if rank == 0:
             result["roofline"], result["allreduce"] = roof, allreduce
     if rank == 0 and not args.no_roofline and not args.train:
+        result["launches"] = count_launch_sources(model, last, args.hot_path_only)
         n = min(args.steps, 2 * nframes)
         conv_t, hbm_t = instrumented_pass(model, pool, n, args.hot_path_only)
         result["roofline"] = roofline_blocks(conv_t, hbm_t, n, result["ms_per_step"],
