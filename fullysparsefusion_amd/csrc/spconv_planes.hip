@@ -784,6 +784,8 @@ __global__ void __launch_bounds__(256, SP_PIPE_WPS) spconv_fwd_pipe_kernel(SpArg
 #ifdef PD_ABL_NO_G
     return;
 #endif
+    // (a dead cell's rows are fetched all the same: `if (!live) return` here measured 5-10 % SLOWER on every layer, 30 % on the
+    // 256 -> 256 one — the branch keeps the compiler from hoisting the loads over the staging writes)
     const char* p = (st.src ? a.x[1] : a.x[0]) + (uint32_t)(kc * 128);
     va = *reinterpret_cast<const uint4*>(p + off0);
     vb = *reinterpret_cast<const uint4*>(p + off1);
@@ -1245,6 +1247,314 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
   sp_epilogue<RG, TPW>(a, acc, vec, rowmax, row0, slice, wave, tid);
 }
 
+// =====================================================================================================================
+// K9f: K9d's pipeline with the weight fragments SHARED by three 64-row blocks (round 3).
+//
+// K9d's three workgroups per CU fetch the same 16 KB of weight fragments per chunk three times, next to 8 KB of gathered rows
+// each: 72 KB through a vector-memory path that takes in ~25 B/clk per CU (profiles/r3_vmem_return_probe.txt), and the kernel's
+// duration is that intake plus the rest (profiles/r3_spconv_k9d_ablations.txt).  Here ONE workgroup of twelve waves owns 192 rows:
+// wave (rb, cs) is K9d's wave cs of row block rb — same cells, same accumulators, same X ring (one per row block) — but a
+// chunk's weight fragments enter the CU once: the waves of one row block (rotating with the chunk index) load them to staging
+// registers (chunk i+3 during iteration i), write them to a two-slot LDS ring the iteration after, and every wave refills its
+// single fragment register set from the ring behind the MFMAs that used it (the t = 0 tiles of all cells first, then t = 1, so
+// a half set is free while the other multiplies).  40 KB per chunk instead of 72 KB.
+// The price: the step sequence is the union of the three row blocks' live offsets (a row block idles through steps none of its
+// cells needs), one barrier spans twelve waves, and the workgroup has a CU to itself (157 KB of LDS).
+// Twelve waves of 168 registers leave no room for K9d's per-step product tiles D next to the weight staging registers: the
+// accumulators are kept in the unit of the row being multiplied, as in K9e (exact power-of-two rescaling at every step).
+template <int TPW>
+struct SpTriSmem {
+  static constexpr int NRB = 3, R = 64 * NRB, NCELL = 4 * NRB;
+  static constexpr size_t nbr_bytes = (size_t)R * SP_KVOL_MAX * 4;
+  static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
+  static constexpr size_t xring_bytes = (size_t)4 * NCELL * 2048;  // [slot][row block][cell][row][piece ^ swizzle(row)] x 16 B
+  static constexpr size_t wring_off = xring_off + xring_bytes;
+  static constexpr size_t wring_bytes = (size_t)2 * 4 * TPW * 2 * 1024;  // [chunk parity][wave's slice][tile][hi | lo][lane] x 16 B
+  static constexpr size_t sring_off = wring_off + wring_bytes;
+  static constexpr size_t sring_bytes = (size_t)2 * NCELL * 16 * 4;  // [step parity][cell][row]
+  static constexpr size_t meta_off = sring_off + sring_bytes;
+  static constexpr size_t meta_bytes = 32 * 4 + 16 + (size_t)SP_KVOL_MAX * NCELL;
+  static constexpr size_t vec_off = (meta_off + meta_bytes + 15) / 16 * 16;
+  static constexpr size_t vec_bytes = (size_t)2 * 64 * TPW * 4;
+  static constexpr size_t rowmax_off = vec_off + vec_bytes;
+  static constexpr size_t rowmax_bytes = (size_t)4 * R * 4;
+  static constexpr size_t bytes = rowmax_off + rowmax_bytes;
+};
+
+template <int TPW, int NKC>
+__global__ void __launch_bounds__(768, 1) spconv_fwd_tri_kernel(SpArgs a) {
+  using S = SpTriSmem<TPW>;
+  constexpr int RG = 4, R = S::R, NCELL = S::NCELL, NT = 768;
+  static_assert(NKC == 2 || NKC == 4, "sources of 64 or 128 channels");
+  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
+  int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
+  uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
+  uint4* wring = reinterpret_cast<uint4*>(sp_smem + S::wring_off);
+  float* sring = reinterpret_cast<float*>(sp_smem + S::sring_off);
+  int* sched = reinterpret_cast<int*>(sp_smem + S::meta_off);
+  int* nk_s = reinterpret_cast<int*>(sp_smem + S::meta_off + 128);
+  unsigned char* flags = reinterpret_cast<unsigned char*>(sp_smem + S::meta_off + 144);
+  float* vec = reinterpret_cast<float*>(sp_smem + S::vec_off);
+  float* rowmax = reinterpret_cast<float*>(sp_smem + S::rowmax_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wave >> 2, cs = wave & 3;  // row block, 16*TPW-channel share of the slice
+  const int kvol = a.kvol;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int slice = blockIdx.y;
+
+  // ---- prologue: the 192 rows of the neighbour table, the epilogue's vectors, the union schedule with a 12-cell mask per offset
+  {
+    const int64_t base = row0 * kvol, lim = a.m_out * kvol;
+    for (int idx = tid; idx < R * kvol; idx += NT) nbr_s[idx] = (base + idx < lim) ? a.nbr[base + idx] : -1;
+    if (tid < 2 * 64 * TPW) {
+      const int which = tid / (64 * TPW), ch = slice * 64 * TPW + tid % (64 * TPW);
+      const float* src = which == 0 ? a.scale : a.shift;
+      vec[tid] = (src && ch < a.cout) ? src[ch] : (which == 0 ? 1.0f : 0.0f);
+    }
+  }
+  __syncthreads();
+  if (tid < kvol * NCELL) {
+    const int k = tid / NCELL, g = tid - k * NCELL;
+    bool any = false;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) any |= nbr_s[(16 * g + jj) * kvol + k] >= 0;
+    flags[tid] = any ? 1 : 0;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    unsigned mask = 0;
+    if (lane < kvol) {
+#pragma unroll
+      for (int g = 0; g < NCELL; ++g) mask |= (unsigned)flags[lane * NCELL + g] << g;
+    }
+    const unsigned long long live = __ballot(mask != 0);
+    if (lane < 32) sched[lane] = 0;
+    if (mask != 0) sched[__popcll(live & ((1ull << lane) - 1ull))] = lane | (int)(mask << 8);
+    if (lane == 0) *nk_s = __popcll(live);
+  }
+  __syncthreads();
+  const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
+  const int nsrc = a.c[1] > 0 ? 2 : 1;
+  const int nchunks = NKC * nsrc;
+  const int nsteps = nk * nsrc;
+  const float w_inv = a.w_hdr[0];
+  const uint32_t rowbytes = (uint32_t)NKC * 128u;
+
+  auto entry = [&](int kidx, int src) -> SpStep {  // (the mask of a step record is this wave's row block's four cells)
+    const int e = kidx < nk ? __builtin_amdgcn_readfirstlane(sched[kidx]) : 0;
+    return SpStep{kidx, src, e & 255, ((unsigned)e >> (8 + 4 * rb)) & 15u};
+  };
+  auto advance = [&](const SpStep& p) -> SpStep {
+    if (p.src + 1 < nsrc) return SpStep{p.kidx, p.src + 1, p.k, p.mask};
+    return entry(p.kidx + 1, 0);
+  };
+
+  // acc[g][t]: the output tile of cell g in the unit 1 / cinv[g] (x the weight scale), cinv[g] = inverse scale of the row this lane
+  // multiplies in cell g at the moment (K9e's scheme)
+  sp_f32x4 acc[RG][TPW];
+  float cinv[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {
+    cinv[g] = 1.0f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- the gather of cell cs of row block rb: K9d's (two line-coalesced loads per chunk, swizzled row-major LDS tile)
+  uint4 g_a = make_uint4(0, 0, 0, 0), g_b = make_uint4(0, 0, 0, 0);
+  float g_sc = 1.0f;
+  uint32_t g_off0 = 0, g_off1 = 0;
+  const int grow = lane >> 3, gpiece = lane & 7;
+  const int cell = rb * RG + cs;
+  auto gather_row = [&](const SpStep& st, uint32_t& off0, uint32_t& off1, float& sc) {
+    const int32_t* col = nbr_s + (16 * cell) * kvol + st.k;
+    int i0 = col[grow * kvol], i1 = col[(8 + grow) * kvol], is = col[j * kvol];
+    const int zero = (int)a.m_in;
+    i0 = i0 >= 0 ? i0 : zero;
+    i1 = i1 >= 0 ? i1 : zero;
+    is = is >= 0 ? is : zero;
+    off0 = (uint32_t)i0 * rowbytes + (uint32_t)(gpiece * 16);
+    off1 = (uint32_t)i1 * rowbytes + (uint32_t)(gpiece * 16);
+    sc = (st.src ? a.sx[1] : a.sx[0])[is];
+  };
+  auto gather_chunk = [&](const SpStep& st, int kc, uint32_t off0, uint32_t off1, uint4& va, uint4& vb) {
+#ifdef PT_SKIP_DEAD
+    if (!((st.mask >> cs) & 1u)) return;
+#endif
+    const char* p = (st.src ? a.x[1] : a.x[0]) + (uint32_t)(kc * 128);
+    va = *reinterpret_cast<const uint4*>(p + off0);
+    vb = *reinterpret_cast<const uint4*>(p + off1);
+  };
+  const int wr_a = grow * 8 + (gpiece ^ ((grow >> 1) & 7)), wr_b = (8 + grow) * 8 + (gpiece ^ (((8 + grow) >> 1) & 7));
+  auto stage_to_lds = [&](const SpStep& st, int kc, int slot, int parity, const uint4& va, const uint4& vb, float sc) {
+    if ((st.mask >> cs) & 1u) {
+      uint4* dst = xring + (slot * NCELL + cell) * 128;
+      dst[wr_a] = va;
+      dst[wr_b] = vb;
+      if (kc == 0 && q == 0) sring[(parity * NCELL + cell) * 16 + j] = sc;
+    }
+  };
+  const int rd_hi = j * 8 + ((2 * sp_kgroup(q)) ^ ((j >> 1) & 7)), rd_lo = j * 8 + ((2 * sp_kgroup(q) + 1) ^ ((j >> 1) & 7));
+  auto read_cell = [&](int slot, int g, uint4& xh, uint4& xl) {
+    const uint4* xs = xring + (slot * NCELL + rb * RG + g) * 128;
+    xh = xs[rd_hi];
+    xl = xs[rd_lo];
+  };
+  // ---- weights: global -> registers (the duty waves) -> LDS ring -> every wave's fragment registers
+  auto load_w = [&](const SpStep& st, int kc, uint4 (&wf)[TPW][2]) {
+    const int c = (st.src ? NKC : 0) + kc;
+    const uint4* p = reinterpret_cast<const uint4*>(a.w) + ((((int64_t)slice * kvol + st.k) * nchunks + c) * 4 + cs) * (TPW * 2 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) wf[t][pl] = p[(t * 2 + pl) * 64];
+  };
+  auto w_to_lds = [&](int wslot, const uint4 (&wf)[TPW][2]) {
+    uint4* dst = wring + (wslot * 4 + cs) * (TPW * 2 * 64) + lane;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) dst[(t * 2 + pl) * 64] = wf[t][pl];
+  };
+  auto w_from_lds = [&](int wslot, int t, uint4 (&wf)[TPW][2]) {
+    const uint4* src = wring + (wslot * 4 + cs) * (TPW * 2 * 64) + lane;
+    wf[t][0] = src[(t * 2) * 64];
+    wf[t][1] = src[(t * 2 + 1) * 64];
+  };
+  auto mma_tile = [&](int g, int t, const uint4& xh, const uint4& xl, const uint4 (&wk)[TPW][2]) {
+    const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh), bl = __builtin_bit_cast(sp_f16x8, xl);
+    const sp_f16x8 wh = __builtin_bit_cast(sp_f16x8, wk[t][0]), wl = __builtin_bit_cast(sp_f16x8, wk[t][1]);
+    acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc[g][t], 0, 0, 0);
+    acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, acc[g][t], 0, 0, 0);
+    acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc[g][t], 0, 0, 0);
+  };
+
+  uint4 wK[TPW][2], wS[TPW][2];
+  uint4 xh[RG], xl[RG];
+#pragma unroll
+  for (int g = 0; g < RG; ++g) xh[g] = xl[g] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) wS[t][0] = wS[t][1] = make_uint4(0, 0, 0, 0);
+
+  SpStep r0 = entry(0, 0);
+  SpStep r1 = advance(r0);
+  SpStep r2 = advance(r1);
+
+  // ---- fill: X(0), X(1) -> slots 0, 1; X(2) -> staging; W(0) -> registers; W(1) -> ring slot 1 (row block 1); W(2) -> row block 2's staging
+  {
+    uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0;
+    gather_row(r0, g_off0, g_off1, g_sc);
+    gather_chunk(r0, 0, g_off0, g_off1, a0, b0);
+    gather_chunk(r0, 1, g_off0, g_off1, a1, b1);
+    const float sc0 = g_sc;
+    if constexpr (NKC > 2) {
+      gather_chunk(r0, 2, g_off0, g_off1, g_a, g_b);
+    } else {
+      gather_row(r1, g_off0, g_off1, g_sc);
+      gather_chunk(r1, 0, g_off0, g_off1, g_a, g_b);
+    }
+    load_w(r0, 0, wK);
+    if (rb == 1) {
+      load_w(r0, 1, wS);
+      w_to_lds(1, wS);
+    }
+    if (rb == 2) {
+      if constexpr (NKC > 2) load_w(r0, 2, wS);
+      else load_w(r1, 0, wS);
+    }
+    stage_to_lds(r0, 0, 0, 0, a0, b0, sc0);
+    stage_to_lds(r0, 1, 1, 0, a1, b1, sc0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < RG; ++g)
+    if ((r0.mask >> g) & 1u) read_cell(0, g, xh[g], xl[g]);
+
+  int ph = 0;  // chunk counter modulo 3: row block (c % 3) carries chunk c's weights into the CU
+  const int ph_store = rb == 2 ? 0 : rb + 1;
+  auto iteration = [&](auto kc_tag, auto odd_tag) {
+    constexpr int KC = decltype(kc_tag)::value;
+    constexpr int ODD = decltype(odd_tag)::value;
+    constexpr int I = (NKC == 4) ? KC : (2 * ODD + KC);
+    constexpr int d1 = (KC + 1) / NKC, d2 = (KC + 2) / NKC, d3 = (KC + 3) / NKC;
+    static_assert(d3 <= 2, "three step records suffice");
+    const SpStep st = r0;
+    const SpStep st1 = d1 == 0 ? r0 : r1;
+    const SpStep st2 = d2 == 0 ? r0 : r1;
+    const SpStep st3 = d3 == 0 ? r0 : (d3 == 1 ? r1 : r2);
+    constexpr int kc1 = (KC + 1) % NKC, kc2 = (KC + 2) % NKC, kc3 = (KC + 3) % NKC;
+    (void)kc1;
+    __syncthreads();
+    stage_to_lds(st2, kc2, (I + 2) % 4, (ODD + d2) & 1, g_a, g_b, g_sc);
+    if (kc3 == 0) gather_row(st3, g_off0, g_off1, g_sc);
+    gather_chunk(st3, kc3, g_off0, g_off1, g_a, g_b);
+    if (ph == ph_store) w_to_lds(I % 2, wS);     // chunk i + 2, fetched by this wave during iteration i - 1
+    if (ph == rb) load_w(st3, kc3, wS);          // chunk i + 3
+    ph = ph == 2 ? 0 : ph + 1;
+    if (KC == 0) {  // a new step: every live cell's accumulators into the unit of the row this lane multiplies now (exact: powers of two)
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        if ((st.mask >> g) & 1u) {
+          const float v = sring[(ODD * NCELL + rb * RG + g) * 16 + j];
+          const float f = __fmul_rn(cinv[g], __uint_as_float(0x7F000000u - __float_as_uint(v)));  // old unit / new unit
+          cinv[g] = v;
+#pragma unroll
+          for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmul_rn(acc[g][t][r], f);
+        }
+      }
+    }
+    // multiply chunk KC tile-major; a tile's weight registers and (after the last tile) a cell's X registers take chunk KC + 1
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+      for (int g = 0; g < RG; ++g) {
+        if ((st.mask >> g) & 1u) mma_tile(g, t, xh[g], xl[g], wK);
+        if (t == TPW - 1 && ((st1.mask >> g) & 1u)) read_cell((I + 1) % 4, g, xh[g], xl[g]);
+      }
+      w_from_lds((I + 1) % 2, t, wK);
+    }
+  };
+  auto next_step = [&]() {
+    r0 = r1;
+    r1 = r2;
+    r2 = advance(r2);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  auto whole_step = [&](auto odd_tag) {
+    iteration(I0{}, odd_tag);
+    iteration(I1{}, odd_tag);
+    if constexpr (NKC == 4) {
+      iteration(I2{}, odd_tag);
+      iteration(I3{}, odd_tag);
+    }
+  };
+  int s = 0;
+  for (; s + 1 < nsteps; s += 2) {
+    whole_step(I0{});
+    next_step();
+    whole_step(I1{});
+    next_step();
+  }
+  if (s < nsteps) whole_step(I0{});
+#pragma unroll
+  for (int g = 0; g < RG; ++g) {  // the accumulators back into true units (x the weight's inverse scale)
+    const float sc = __fmul_rn(cinv[g], w_inv);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmul_rn(acc[g][t][r], sc);
+  }
+  __syncthreads();
+  sp_epilogue<RG, TPW>(a, acc, vec, rowmax + rb * 4 * 64, row0 + 64 * rb, slice, cs, tid & 255);
+}
+
 }  // namespace fsf
 
 using namespace fsf;
@@ -1348,7 +1658,21 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
     const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                           \
     hipLaunchKernelGGL((spconv_fwd_wide_kernel<TPW_, NKC_>), grid, dim3(256), S::bytes, stream, a);                     \
   } while (0)
-  if (wide && nkc_fix == 4 && tpw == 2) FSF_SPW(2, 4);
+  // K9f (192-row workgroups sharing the weight fragments) from FSF_PLANES_TRI_MIN_ROWS output rows
+  static const int64_t tri_min_rows = getenv("FSF_PLANES_TRI_MIN_ROWS") ? atoll(getenv("FSF_PLANES_TRI_MIN_ROWS")) : ((int64_t)1 << 40);
+  const bool tri = pipe_on && !big && !wide && nkc_fix > 0 && m_out >= tri_min_rows;
+#define FSF_SPT(TPW_, NKC_)                                                                                              \
+  do {                                                                                                                  \
+    using S = SpTriSmem<TPW_>;                                                                                          \
+    static std::atomic<uint64_t> attr_done{0};                                                                          \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_tri_kernel<TPW_, NKC_>, (int)S::bytes, attr_done));     \
+    const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                           \
+    hipLaunchKernelGGL((spconv_fwd_tri_kernel<TPW_, NKC_>), grid, dim3(768), S::bytes, stream, a);                      \
+  } while (0)
+  if (tri && nkc_fix == 4 && tpw == 2) FSF_SPT(2, 4);
+  else if (tri && nkc_fix == 2 && tpw == 2) FSF_SPT(2, 2);
+  else if (tri && nkc_fix == 2 && tpw == 1) FSF_SPT(1, 2);
+  else if (wide && nkc_fix == 4 && tpw == 2) FSF_SPW(2, 4);
   else if (wide && nkc_fix == 2 && tpw == 2) FSF_SPW(2, 2);
   else if (wide && nkc_fix == 2 && tpw == 1) FSF_SPW(1, 2);
   else if (pipe_on && !big && nkc_fix == 4 && tpw == 2) FSF_SPP(2, 4);   // K9d: the chunk-granular pipeline
@@ -1364,6 +1688,7 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
 #undef FSF_SP
 #undef FSF_SPP
 #undef FSF_SPW
+#undef FSF_SPT
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

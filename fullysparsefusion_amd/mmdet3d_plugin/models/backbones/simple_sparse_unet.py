@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .... import hip_ops, switches
-from ...ops.spconv import SparseBasicBlock, SparseConvTensor, SparseSequential, make_sparse_convmodule
+from ...ops.spconv import SparseBasicBlock, SparseConvolution, SparseConvTensor, SparseSequential, make_sparse_convmodule
 from ...registry import BACKBONES
 
 
@@ -125,16 +125,29 @@ class SimpleSparseUNet(nn.Module):
             x = x._like(x_merge.features + x.features)
         return upsample_layer(x)
 
+    @staticmethod
+    def _plan_modules(meta, module):
+        """The rulebooks `module` will ask for, built from coordinates alone (`meta` carries no features); returns the
+        coordinate-only tensor of the module's output."""
+        for m in module.modules():
+            if isinstance(m, SparseConvolution) and not m.inverse:
+                rb = m._rulebook(meta)
+                if not m.subm:
+                    meta = meta._like(None, rb.out_indices, rb.out_shape)
+        return meta
+
     def forward(self, voxel_info, batch_size=None):
-        coors = voxel_info["voxel_coors"]
-        if self.keep_coors_dims is not None:
-            coors = coors[:, self.keep_coors_dims]
+        raw_coors = voxel_info["voxel_coors"]
         voxel_features = voxel_info["voxel_feats"]
-        coors = coors.int()
+
+        def own_coors():  # (launches: on whichever stream is current)
+            c = raw_coors if self.keep_coors_dims is None else raw_coors[:, self.keep_coors_dims]
+            return c.int().contiguous()
+
         if batch_size is None:
             batch_size = voxel_info.get("batch_size")
         if batch_size is None:
-            batch_size = int(coors[:, 0].max().item()) + 1  # upstream's host sync; callers that know B pass it
+            batch_size = int(raw_coors[:, 0].max().item()) + 1  # upstream's host sync; callers that know B pass it
         # Row order INSIDE the network (inference): the plane kernels visit a (64-row block, kernel offset) pair only if a row of the
         # block has a neighbour there; with rows of equal neighbour mask adjacent (fsf_order_by_neighbor_mask: more neighbours first) a
         # block of the 0.2 m level touches 8.1 of 27 offsets instead of 16.8 and its live cells are 80 % full instead of 39 % (0.4 m
@@ -142,17 +155,15 @@ class SimpleSparseUNet(nn.Module):
         # coordinates (so tables and features agree by construction), and the output goes back to the input order.
         reorder = (switches.UNET_MASK_ORDER and voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training
                    and voxel_features.size(0) >= switches.UNET_MASK_ORDER_MIN_ROWS)
+        # The index plan (inference): everything below that depends on the voxel COORDINATES only — the row order, every level's
+        # rulebooks (hash build, strided proposal + sort with its host read-back, neighbour tables) — is a chain of ~25 small
+        # launches per level.  On the main stream it stood between the levels' convolutions (1.2 ms per 10-sweep frame); here a
+        # plan stream builds level k + 1's tables while the main stream runs level k's convolutions, and the first two levels' while
+        # the voxel encoder is still at work (the coordinates carry the event of their creation).
+        plan_on = (switches.UNET_PLAN_STREAM and voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training
+                   and not torch.cuda.is_current_stream_capturing())
         inv_perm = None
-        coors = coors.contiguous()
-        if reorder:
-            perm, inv_perm = hip_ops.order_by_neighbor_mask(coors, batch_size, self.sparse_shape)
-            perm64, inv_perm = perm.long(), inv_perm.long()
-            coors = coors.index_select(0, perm64)
-            voxel_features = voxel_features.index_select(0, perm64)
-        x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
-        x.indice_dict["__mask_order__"] = reorder  # (the dict is shared by every tensor derived from x)
-        x = self.conv_input(x)
-        encode_features = []
+        levels = list(self.encoder_layers._modules.values())
         # Inference: the lateral blocks of the FINE levels (two big submanifold convolutions each, independent of everything below
         # them) go to a side stream once the encoder has left those levels: they fill the CUs that the small deep levels — a few
         # dozen workgroups per launch — leave idle, instead of running alone after them.
@@ -160,14 +171,72 @@ class SimpleSparseUNet(nn.Module):
         if (voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training and switches.UNET_LATERAL_STREAM
                 and not torch.cuda.is_current_stream_capturing()):
             side_levels = min(switches.UNET_LATERAL_LEVELS, self.stage_num - 1)
+            if getattr(self, "_lateral_stream", None) is None:
+                self._lateral_stream = torch.cuda.Stream()
+        if plan_on:
+            main = torch.cuda.current_stream()
+            if getattr(self, "_plan_stream", None) is None:
+                self._plan_stream = torch.cuda.Stream()
+            ps = self._plan_stream
+            ready = getattr(raw_coors, "_fsf_ready_event", None)
+            if ready is not None:
+                ps.wait_event(ready)
+            else:
+                ps.wait_stream(main)
+            published = set()
+
+            def publish(meta, extra=()):
+                """the plan stream's tensors are consumed (and outlive their Python owners) on the main and lateral streams"""
+                ts = list(extra)
+                for rb in meta.indice_dict.values():
+                    if not isinstance(rb, bool):
+                        ts += [rb.nbr, rb.nbr_inv, rb.in_indices, rb.out_indices]
+                users = [main] + ([self._lateral_stream] if side_levels > 0 else [])
+                for t in ts:
+                    if t is not None and id(t) not in published:
+                        published.add(id(t))
+                        for st in users:
+                            t.record_stream(st)
+                ev = torch.cuda.Event()
+                ev.record(ps)
+                main.wait_event(ev)
+
+            with torch.cuda.stream(ps):
+                coors = own_coors()
+                perm64 = None
+                if reorder:
+                    perm, inv_perm = hip_ops.order_by_neighbor_mask(coors, batch_size, self.sparse_shape)
+                    perm64, inv_perm = perm.long(), inv_perm.long()
+                    coors = coors.index_select(0, perm64)
+                meta = SparseConvTensor(None, coors, self.sparse_shape, batch_size)
+                meta.indice_dict["__mask_order__"] = reorder
+                meta = self._plan_modules(self._plan_modules(meta, self.conv_input), levels[0])
+            publish(meta, [coors, perm64, inv_perm])
+            if perm64 is not None:
+                voxel_features = voxel_features.index_select(0, perm64)
+            x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+            x.indice_dict = meta.indice_dict
+        else:
+            coors = own_coors()
+            if reorder:
+                perm, inv_perm = hip_ops.order_by_neighbor_mask(coors, batch_size, self.sparse_shape)
+                perm64, inv_perm = perm.long(), inv_perm.long()
+                coors = coors.index_select(0, perm64)
+                voxel_features = voxel_features.index_select(0, perm64)
+            x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+            x.indice_dict["__mask_order__"] = reorder  # (the dict is shared by every tensor derived from x)
+        x = self.conv_input(x)
+        encode_features = []
         lateral_out, lateral_done = {}, {}
-        for level, encoder_layer in enumerate(self.encoder_layers._modules.values(), start=1):
+        for level, encoder_layer in enumerate(levels, start=1):
             x = encoder_layer(x)
             encode_features.append(x)
+            if plan_on and level < len(levels):  # the next level's tables, while the main stream runs this level's convolutions
+                with torch.cuda.stream(ps):
+                    meta = self._plan_modules(meta, levels[level])
+                publish(meta)
             if side_levels > 0 and level == side_levels:
                 main = torch.cuda.current_stream()
-                if getattr(self, "_lateral_stream", None) is None:
-                    self._lateral_stream = torch.cuda.Stream()
                 side = self._lateral_stream
                 side.wait_stream(main)  # the encoder outputs of levels 1..side_levels exist
                 with torch.cuda.stream(side):

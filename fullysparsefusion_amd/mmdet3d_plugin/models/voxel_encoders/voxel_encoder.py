@@ -89,6 +89,12 @@ class DynamicScatterVFE(nn.Module):
         if self.unique_once:
             cmin, cmax = self._key_bounds(coors)
             new_coors, unq_inv, _ = unique_with_plan(coors, cmin, cmax)
+            if new_coors.is_cuda and not torch.is_grad_enabled():
+                # the voxel coordinates exist from here on: a consumer that only needs THEM (SimpleSparseUNet's index plan) may start
+                # on another stream while this stream still runs the VFE layers
+                ev = torch.cuda.Event()
+                ev.record()
+                new_coors._fsf_ready_event = ev
         else:
             new_coors = unq_inv = None
         if (features.is_cuda and features.dtype == torch.float32 and not self._with_distance and features.size(1) >= 3

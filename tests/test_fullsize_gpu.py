@@ -515,3 +515,28 @@ def test_unet_in_mask_order_equals_the_reference_row_order_bit_for_bit(fsf_pair,
             outs[on] = seg.backbone(dict(voxel_feats=vf, voxel_coors=vc, batch_size=1))[0]["voxel_feats"]
     assert vf.shape[0] > 90000
     assert torch.equal(outs[True], outs[False])
+
+
+def test_unet_with_the_index_plan_on_its_own_stream_is_bit_identical(fsf_pair, frame10, device, monkeypatch):
+    """SimpleSparseUNet with every level's rulebooks built one level ahead on the plan stream (the default at inference) against the
+    same network building them in line on the main stream: same tables, same launches, so the output must be IDENTICAL — run
+    several times back to back, with the coordinates' ready event (recorded before the voxel encoder's layers) and without."""
+    from fullysparsefusion_amd import switches
+
+    model, _ = fsf_pair
+    seg = model.segmentor
+    pts = torch.from_numpy(frame10["points"][:, :5].copy()).to(device)
+    with torch.no_grad():
+        p_dev, coors = seg.voxelize([pts])
+        monkeypatch.setattr(switches, "UNET_PLAN_STREAM", False)
+        vf, vc, _ = seg.voxel_encoder(p_dev, coors, return_inv=True)
+        want = seg.backbone(dict(voxel_feats=vf, voxel_coors=vc, batch_size=1))[0]["voxel_feats"].clone()
+        monkeypatch.setattr(switches, "UNET_PLAN_STREAM", True)
+        for rep in range(4):
+            vf, vc, _ = seg.voxel_encoder(p_dev, coors, return_inv=True)  # (enqueued, not finished, when the plan starts)
+            assert getattr(vc, "_fsf_ready_event", None) is not None
+            if rep == 3:
+                vc = vc.clone()  # no event: the plan waits for the whole main stream
+            got = seg.backbone(dict(voxel_feats=vf, voxel_coors=vc, batch_size=1))[0]["voxel_feats"]
+            assert torch.equal(got, want), rep
+    assert seg.backbone._plan_stream is not None

@@ -3,6 +3,8 @@ the parity tests of the default kernels are re-run in a child process with the v
 
   * K9e (`spconv_fwd_wide_kernel`: 128-row blocks, accumulators kept in the unit of the row being multiplied) —
     FSF_PLANES_WIDE_MIN_ROWS=1;
+  * K9f (`spconv_fwd_tri_kernel`: 192-row workgroups of twelve waves sharing the weight fragments through LDS) —
+    FSF_PLANES_TRI_MIN_ROWS=1;
   * K9c as the only plane kernel (K9d off) — FSF_PLANES_PIPE=0;
   * K22b (`linear_norm_act_f16_kernel`: f16 planes x3, line-coalesced x through a wave-private LDS tile) — FSF_K22_F16=1;
   * 12-wave K22 workgroups — FSF_K22_WIDE_MIN_ROWS=1.
@@ -26,7 +28,8 @@ def run_child(env_extra, select):
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
 
 
-@pytest.mark.parametrize("env", [dict(FSF_PLANES_WIDE_MIN_ROWS="1"), dict(FSF_PLANES_PIPE="0")], ids=["K9e", "K9c"])
+@pytest.mark.parametrize("env", [dict(FSF_PLANES_WIDE_MIN_ROWS="1"), dict(FSF_PLANES_PIPE="0"), dict(FSF_PLANES_TRI_MIN_ROWS="1")],
+                         ids=["K9e", "K9c", "K9f"])
 def test_plane_kernel_variants(device, env):
     run_child(env, "spconv_forward_planes")
 
