@@ -160,6 +160,15 @@ class SimpleSparseUNet(nn.Module):
         # launches per level.  On the main stream it stood between the levels' convolutions (1.2 ms per 10-sweep frame); here a
         # plan stream builds level k + 1's tables while the main stream runs level k's convolutions, and the first two levels' while
         # the voxel encoder is still at work (the coordinates carry the event of their creation).
+        trace = getattr(self, "_trace", None)  # profiling hook (tools/profiling/plan_stream_trace.py): timed events on a stream
+
+        def mark(tag, stream=None):
+            if trace is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream if stream is not None else torch.cuda.current_stream())
+                trace.append((tag, e))
+
+        mark("forward enters")
         plan_on = (switches.UNET_PLAN_STREAM and voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training
                    and not torch.cuda.is_current_stream_capturing())
         inv_perm = None
@@ -200,6 +209,7 @@ class SimpleSparseUNet(nn.Module):
                 ev = torch.cuda.Event()
                 ev.record(ps)
                 main.wait_event(ev)
+                mark("plan published", ps)
 
             with torch.cuda.stream(ps):
                 coors = own_coors()
@@ -225,10 +235,12 @@ class SimpleSparseUNet(nn.Module):
                 voxel_features = voxel_features.index_select(0, perm64)
             x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
             x.indice_dict["__mask_order__"] = reorder  # (the dict is shared by every tensor derived from x)
+        mark("conv_input starts")
         x = self.conv_input(x)
         encode_features = []
         lateral_out, lateral_done = {}, {}
         for level, encoder_layer in enumerate(levels, start=1):
+            mark(f"encoder level {level} starts")
             x = encoder_layer(x)
             encode_features.append(x)
             if plan_on and level < len(levels):  # the next level's tables, while the main stream runs this level's convolutions
@@ -252,6 +264,7 @@ class SimpleSparseUNet(nn.Module):
                         ev.record(side)
                         lateral_out[lv], lateral_done[lv] = y, ev
         x = encode_features[-1]
+        mark("decoder starts")
         try:
             for i in range(self.stage_num, 0, -1):
                 lat = lateral_out.get(i)
@@ -265,6 +278,7 @@ class SimpleSparseUNet(nn.Module):
         finally:
             if lateral_done:  # whatever happens in the decoder, the main stream ends behind the side stream's work
                 torch.cuda.current_stream().wait_stream(self._lateral_stream)
+        mark("decoder done")
         out = x.features
         if inv_perm is not None:
             out = out.index_select(0, inv_perm)  # back to the caller's voxel order
