@@ -92,6 +92,11 @@ _ARGTYPES = {
     "fsf_nms_bev_multiclass": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_nms_bev_multiclass_capped": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i64, _P, _P, _P, _P, c_i64, _P],
     "fsf_nms_bev_multiclass_capped_workspace_bytes": [c_i64, c_i32, c_i64],
+    "fsf_decode_cluster_boxes": [_P, _P, _P, c_i64, c_i32, c_i32, c_f32, _P, _P, _P, _P],
+    "fsf_class_rank_desc_workspace_bytes": [c_i64, c_i32],
+    "fsf_class_rank_desc": [_P, c_i64, c_i32, c_f32, _P, _P, _P, _P, c_i64, _P],
+    "fsf_nms_select_capacity": [],
+    "fsf_nms_select": [_P, c_i32, _P, _P, _P, c_i64, _P, c_i64, c_i32, c_i64, c_i32, _P, _P, _P, _P, _P],
     "fsf_connected_components_grouped": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
@@ -983,6 +988,64 @@ def nms_bev_multiclass(boxes: torch.Tensor, rank: torch.Tensor, count: torch.Ten
                                           ptr(keep), ptr(num), ptr(flag), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_nms_bev_multiclass_capped")
     return (keep, num, flag) if windowed else (keep, num)
+
+
+def decode_cluster_boxes(cls_logits: torch.Tensor, reg_preds: torch.Tensor, cluster_xyz: torch.Tensor, eps: float):
+    """fsf_decode_cluster_boxes: cls_logits f32 [n, C], reg_preds f32 [n, 8 | 10], cluster_xyz f32 [n, 3] ->
+    (boxes f32 [n, code - 1], boxes_nms f32 [n, 5] = (x1, y1, x2, y2, yaw), scores_t f32 [C, n] = sigmoid scores, class-major)."""
+    require_cuda(cls_logits, reg_preds, cluster_xyz)
+    assert cls_logits.dtype == reg_preds.dtype == cluster_xyz.dtype == torch.float32
+    n, c, code = cls_logits.size(0), cls_logits.size(1), reg_preds.size(1)
+    assert reg_preds.size(0) == n and cluster_xyz.shape == (n, 3)
+    cls_logits, reg_preds, cluster_xyz = cls_logits.contiguous(), reg_preds.contiguous(), cluster_xyz.contiguous()
+    dev = cls_logits.device
+    boxes = torch.empty((n, code - 1), dtype=torch.float32, device=dev)
+    boxes_nms = torch.empty((n, 5), dtype=torch.float32, device=dev)
+    scores_t = torch.empty((c, n), dtype=torch.float32, device=dev)
+    check(_L().fsf_decode_cluster_boxes(ptr(cls_logits), ptr(reg_preds), ptr(cluster_xyz), n, c, code, float(eps), ptr(boxes),
+                                        ptr(boxes_nms), ptr(scores_t), stream_ptr()), "fsf_decode_cluster_boxes")
+    return boxes, boxes_nms, scores_t
+
+
+def class_rank_desc(scores_t: torch.Tensor, score_thr: float):
+    """fsf_class_rank_desc: scores_t f32 [C, n] -> (order i32 [C, n], rank i32 [C, n], count i32 [C]) — per class the stable
+    descending score order of the boxes above score_thr (then the others, by index), each box's position in it (-1 under the
+    threshold) and the number of boxes above it."""
+    require_cuda(scores_t)
+    assert scores_t.dtype == torch.float32 and scores_t.dim() == 2 and scores_t.is_contiguous()
+    c, n = scores_t.shape
+    dev = scores_t.device
+    order = torch.empty((c, n), dtype=torch.int32, device=dev)
+    rank = torch.empty((c, n), dtype=torch.int32, device=dev)
+    count = torch.empty((c,), dtype=torch.int32, device=dev)
+    h = _L()
+    ws = _lib.workspace(h.fsf_class_rank_desc_workspace_bytes(n, c), dev)
+    check(h.fsf_class_rank_desc(ptr(scores_t), n, c, float(score_thr), ptr(order), ptr(rank), ptr(count), ptr(ws), ws.numel(),
+                                stream_ptr()), "fsf_class_rank_desc")
+    return order, rank, count
+
+
+def nms_select_capacity() -> int:
+    return int(_L().fsf_nms_select_capacity())
+
+
+def nms_select(boxes: torch.Tensor, scores_t: torch.Tensor, order: torch.Tensor, keep: torch.Tensor, num_keep: torch.Tensor,
+               max_keep: int, max_num: int, label_lut: Optional[torch.Tensor] = None, incomplete: Optional[torch.Tensor] = None):
+    """fsf_nms_select: the kept boxes of every class (keep / num_keep of nms_bev_multiclass run with the cap max_keep) -> ONE f32
+    buffer of max_num * (box_dim + 2) + 4 words: rows (box | score | label) and, in the last four words (as i32), rows written, boxes
+    kept over all classes, the `incomplete` flag.  No sync: bring it to the host with one copy."""
+    require_cuda(boxes, scores_t, order, keep, num_keep, label_lut, incomplete)
+    assert boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.is_contiguous() and scores_t.is_contiguous()
+    assert order.dtype == torch.int32 and order.is_contiguous() and keep.dtype == torch.int64 and keep.stride(1) == 1
+    assert num_keep.dtype == torch.int64 and (label_lut is None or (label_lut.dtype == torch.int64 and label_lut.is_contiguous()))
+    c, n = scores_t.shape
+    d = boxes.size(1)
+    w = d + 2
+    buf = torch.empty((int(max_num) * w + 4,), dtype=torch.float32, device=boxes.device)
+    meta = buf[int(max_num) * w:].view(torch.int32)
+    check(_L().fsf_nms_select(ptr(boxes), d, ptr(scores_t), ptr(order), ptr(keep), keep.stride(0), ptr(num_keep), n, c, int(max_keep),
+                              int(max_num), ptr(label_lut), ptr(incomplete), ptr(buf), ptr(meta), stream_ptr()), "fsf_nms_select")
+    return buf
 
 
 # ------------------------------------------------------------------------------ connected components

@@ -66,6 +66,13 @@ class LiDARInstance3DBoxes:
         if tuple(origin) != (0.5, 0.5, 0):
             self.tensor[:, :3] += self.tensor[:, 3:6] * (self.tensor.new_tensor((0.5, 0.5, 0)) - self.tensor.new_tensor(origin))
 
+    @classmethod
+    def _wrap(cls, tensor, box_dim, with_yaw=True):
+        """The boxes AS `tensor` (no copy, no origin shift): for rows that were just produced for this object alone."""
+        self = cls.__new__(cls)
+        self.box_dim, self.with_yaw, self.tensor = box_dim, with_yaw, tensor
+        return self
+
     @property
     def bev(self):
         return self.tensor[:, [0, 1, 3, 4, 6]]
@@ -192,6 +199,11 @@ def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_th
 def bbox3d2result(bboxes, scores, labels, attrs=None):
     """mmdet3d.core.bbox3d2result: results on the host, the form the dataset evaluators take."""
     t = getattr(bboxes, "tensor", None)
+    host = getattr(bboxes, "_host_rows", None)  # (boxes | score | label) rows already on the host (the fused box tail's one read-back)
+    if host is not None and t is not None and host.size(0) == len(t) == scores.numel() == labels.numel() and attrs is None:
+        c = t.size(1)
+        return dict(boxes_3d=type(bboxes)._wrap(host[:, :c].contiguous(), c, getattr(bboxes, "with_yaw", True)),
+                    scores_3d=host[:, c].contiguous(), labels_3d=host[:, c + 1].to(labels.dtype))
     if t is not None and t.is_cuda and t.dtype == torch.float32 and scores.dtype == torch.float32 and labels.numel() == len(t):
         # one device -> host transfer instead of three (class indices are exact in fp32)
         packed = torch.cat([t, scores[:, None], labels[:, None].to(torch.float32)], dim=1).cpu()

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .... import hip_ops
-from ...core.bbox import LiDARInstance3DBoxes, box3d_multiclass_nms, xywhr2xyxyr
+from ...core.bbox import BasePointBBoxCoder, LiDARInstance3DBoxes, box3d_multiclass_nms, xywhr2xyxyr
 from ...ops.sst_ops import build_mlp
 from ...registry import BBOX_ASSIGNERS, BBOX_CODERS, HEADS, build_head, build_loss
 
@@ -246,6 +246,8 @@ class SparseClusterHeadV2(SparseClusterHead):
                     for i in range(len(self.tasks))]
         batch_size = len(input_metas)
         assert len(per_task[0]) <= batch_size
+        if len(per_task) == 1:  # one task (the nuScenes / AV2 configs): nothing to concatenate
+            return [tuple(per_task[0][b_idx]) for b_idx in range(batch_size)]
         out = []
         for b_idx in range(batch_size):
             out.append((LiDARInstance3DBoxes.cat([t[b_idx][0] for t in per_task]),
@@ -281,6 +283,9 @@ class SparseClusterHeadV2(SparseClusterHead):
         if len(cls_logits) == 0:
             empty = reg_preds.new_zeros((0, self.EMPTY_BOX_DIM))
             return box_type(empty, box_dim=self.EMPTY_BOX_DIM), reg_preds.new_zeros(0), reg_preds.new_zeros(0)
+        fused = self._box_tail_fused(task_id, cfg, box_type, cls_logits, iou_logits, reg_preds, cluster_xyz)
+        if fused is not None:
+            return fused
         scores = cls_logits.sigmoid()
         if iou_logits is not None:
             a = cfg.get("iou_score_weight", 0.5)
@@ -300,13 +305,48 @@ class SparseClusterHeadV2(SparseClusterHead):
         # task-local label -> global class index: one table gather (the reference loops over the class names with a
         # masked assignment each — a hidden device sync per class — and asserts on the host that every label was mapped;
         # with a table every label is mapped by construction)
-        luts = self.__dict__.setdefault("_label_luts", {})
-        lut = luts.get((task_id, out_labels.device))
-        if lut is None:
-            lut = out_labels.new_tensor([self.class_names.index(name) for name in self.tasks[task_id]["class_names"]])
-            luts[(task_id, out_labels.device)] = lut
+        lut = self._label_lut(task_id, out_labels.device)
         new_labels = lut[out_labels] if len(out_labels) > 0 else torch.zeros_like(out_labels) - 1
         return out_bboxes, out_scores, new_labels
+
+    def _label_lut(self, task_id, device):
+        luts = self.__dict__.setdefault("_label_luts", {})
+        lut = luts.get((task_id, device))
+        if lut is None:
+            lut = torch.tensor([self.class_names.index(name) for name in self.tasks[task_id]["class_names"]], dtype=torch.long,
+                               device=device)
+            luts[(task_id, device)] = lut
+        return lut
+
+    def _box_tail_fused(self, task_id, cfg, box_type, cls_logits, iou_logits, reg_preds, cluster_xyz):
+        """Inference on the GPU: everything between the head's outputs and the host-side result as four C-ABI calls (K24 decode,
+        K24 class ranks, K20 capped multi-class NMS, K24 selection) and ONE read-back, instead of ~95 ATen launches and three host
+        round trips.  Returns None when the configuration is outside what that path takes (the generic path below runs)."""
+        max_num = cfg.get("max_num", 0)
+        nms_pre = cfg.get("nms_pre", -1)
+        n, c = cls_logits.shape
+        if not (switches.BOX_TAIL_FUSED and cls_logits.is_cuda and cls_logits.dtype == torch.float32 and reg_preds.dtype == torch.float32
+                and cluster_xyz.dtype == torch.float32 and iou_logits is None and not torch.is_grad_enabled()
+                and box_type is LiDARInstance3DBoxes and getattr(self, "vis_dir", None) is None
+                and isinstance(max_num, int) and max_num > 0 and c * max_num <= hip_ops.nms_select_capacity()
+                and not (nms_pre > 0 and n > nms_pre) and type(self.bbox_coder) is BasePointBBoxCoder):
+            return None
+        boxes, boxes_nms, scores_t = hip_ops.decode_cluster_boxes(cls_logits, reg_preds, cluster_xyz, self.bbox_coder.EPS)
+        order, rank, count = hip_ops.class_rank_desc(scores_t, cfg.get("score_thr", 0))
+        keep, num, incomplete = hip_ops.nms_bev_multiclass(boxes_nms, rank, count, cfg["nms_thr"],
+                                                           rotated=bool(cfg.get("use_rotate_nms", False)), max_keep=max_num, windowed=True)
+        buf = hip_ops.nms_select(boxes, scores_t, order, keep, num, max_num, max_num, self._label_lut(task_id, cls_logits.device),
+                                 incomplete)
+        d = boxes.size(1)
+        host = buf.cpu()  # the frame's one read-back for the box tail: rows + (rows written, boxes kept, incomplete)
+        meta = host[max_num * (d + 2):].view(torch.int32)
+        if int(meta[2]) != 0:  # a class ran out of its mask window before max_num keeps (never seen): the generic path repeats it in full
+            return None
+        k = int(meta[0])
+        rows = buf[:max_num * (d + 2)].view(max_num, d + 2)[:k]
+        out_bboxes = LiDARInstance3DBoxes._wrap(rows[:, :d], d)
+        out_bboxes._host_rows = host[:max_num * (d + 2)].view(max_num, d + 2)[:k]
+        return out_bboxes, rows[:, d], rows[:, d + 1].long()
 
     def _append_debug_columns(self, bboxes, preds_2d):
         return bboxes

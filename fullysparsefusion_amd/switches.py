@@ -23,6 +23,7 @@ TRAIN_BN = _on("FSF_TRAIN_BN")                      # training-mode BatchNorm (+
 SYNCBN_FUSED = _on("FSF_SYNCBN_FUSED")              # naiveSyncBN1d across ranks as one autograd node
 UNET_LATERAL_STREAM = _on("FSF_UNET_LATERAL_STREAM")  # the fine lateral blocks on a side stream
 UNET_LATERAL_LEVELS = _int("FSF_UNET_LATERAL_LEVELS", 3)
+BOX_TAIL_FUSED = _on("FSF_BOX_TAIL_FUSED")            # inference: decode -> class ranks -> NMS -> selection as four C-ABI calls and one read-back
 UNET_PLAN_STREAM = _on("FSF_UNET_PLAN_STREAM")        # inference: each level's rulebooks built one level ahead on a side stream
 HEAD_SLICED = _on("FSF_HEAD_SLICED")                # the head's attribute branches as one sliced K22 launch per layer
 SEG_HEAD_STACK = _on("FSF_SEG_HEAD_STACK")          # the segmentation head's two output Linears as one launch

@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 4
+#define FSF_ABI_VERSION 5
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -619,6 +619,40 @@ int64_t fsf_nms_bev_multiclass_capped_workspace_bytes(int64_t n, int32_t num_cla
 int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_classes, const int32_t* rank, const int32_t* count,
                                   float thresh, int32_t rotated, int64_t max_keep, int64_t* keep, int64_t* num_keep,
                                   int32_t* incomplete, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K24  the box tail of a cluster head around K20 (round 3)
+ * Replaces, for one sample and one task of FrustumClusterHead._get_bboxes_single
+ *   (projects/mmdet3d_plugin/models/dense_heads/frustum_cluster_head.py:595-698) and what it calls:
+ *   - `cls_logits.sigmoid()`, BasePointBBoxCoder.decode (projects/mmdet3d_plugin/core/bbox/coders/base_point_bbox_coder.py:58-82:
+ *     xyz = reg[:, :3] + centre, dims = exp(reg[:, 3:6]) - eps, yaw = atan2(reg[:, 6], reg[:, 7]), velocity appended for code size 10),
+ *     LiDARInstance3DBoxes(...).bev and xywhr2xyxyr [UNVENDORED mmdet3d.core.bbox]          -> fsf_decode_cluster_boxes
+ *       cls_logits f32 [n, C], reg_preds f32 [n, code] (code 8 | 10), cluster_xyz f32 [n, 3], all contiguous ->
+ *       boxes f32 [n, code - 1], boxes_nms f32 [n, 5] = (x1, y1, x2, y2, yaw), scores_t f32 [C, n] (class-major sigmoid scores);
+ *   - box3d_multiclass_nms [UNVENDORED mmdet3d.core.post_processing]: the per-class `scores > score_thr` mask and score sort
+ *                                                                                           -> fsf_class_rank_desc
+ *       order i32 [C, n] = class c's boxes by descending score (ties: ascending index; boxes at or under the threshold last, in
+ *       index order), rank i32 [C, n] = position of box i in that order or -1 under the threshold, count i32 [C] — rank / count
+ *       are fsf_nms_bev_multiclass[_capped]'s inputs;
+ *   - its concatenation of the classes' kept boxes, the `scores.sort(descending=True)[:max_num]` cut, the label table of
+ *     frustum_cluster_head.py:680-690 and bbox3d2result's packing                             -> fsf_nms_select
+ *       keep / num_keep as K20 returned them (keep_stride = row stride of keep), max_keep = the cap K20 ran with
+ *       (num_classes * max_keep <= fsf_nms_select_capacity(), else FSF_ERR_UNSUPPORTED) ->
+ *       out f32 [max_num, box_dim + 2] rows (box | score | label as float, label = label_lut[c] or c), class-major and
+ *       score-descending within a class when at most max_num boxes were kept, otherwise the max_num best by descending
+ *       score (ties: class-major order); meta i32 [4] = (rows written, boxes kept over all classes, *incomplete or 0, 0).
+ * Nothing here synchronises; the caller reads `out` and `meta` back with one copy.
+ */
+int fsf_decode_cluster_boxes(const float* cls_logits, const float* reg_preds, const float* cluster_xyz, int64_t n,
+                             int32_t num_classes, int32_t code_size, float eps, float* boxes, float* boxes_nms, float* scores_t,
+                             void* stream);
+int64_t fsf_class_rank_desc_workspace_bytes(int64_t n, int32_t num_classes);
+int fsf_class_rank_desc(const float* scores_t, int64_t n, int32_t num_classes, float score_thr, int32_t* order, int32_t* rank,
+                        int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t fsf_nms_select_capacity(void);
+int fsf_nms_select(const float* boxes, int32_t box_dim, const float* scores_t, const int32_t* order, const int64_t* keep,
+                   int64_t keep_stride, const int64_t* num_keep, int64_t n, int32_t num_classes, int64_t max_keep, int32_t max_num,
+                   const int64_t* label_lut, const int32_t* incomplete, float* out, int32_t* meta, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K18  in-group rank (TorchEx ingroup_indices [UNVENDORED]); sst_ops.py:239-259.

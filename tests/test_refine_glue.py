@@ -79,7 +79,7 @@ def test_get_bboxes_single_around_the_nms_call(g, monkeypatch):
     head = types.SimpleNamespace(as_rpn=False, training=False, test_cfg=cfg, tasks=[dict(class_names=["bus", "car", "pedestrian"])],
                                  box_code_size=10, bbox_coder=BasePointBBoxCoder(code_size=10), vis_dir=None, class_names=classes,
                                  EMPTY_BOX_DIM=9)
-    for name in ("_box_type", "_append_debug_columns", "_strip_debug_columns"):
+    for name in ("_box_type", "_append_debug_columns", "_strip_debug_columns", "_box_tail_fused", "_label_lut"):
         setattr(head, name, types.MethodType(getattr(cluster_heads.FrustumClusterHead, name), head))
     boxes, scores, labels = cluster_heads.FrustumClusterHead._get_bboxes_single(
         head, 0, t(g["gb_cls"]), None, t(g["gb_reg"]), torch.zeros(200, 9), t(g["gb_xyz"]), dict(box_type_3d=LiDARInstance3DBoxes))
