@@ -29,8 +29,8 @@ python tools/profiling/planes_layers.py > $out/spconv_layers_k9b_vs_k9d.txt 2>/d
   done
 } > $out/pmc_stalls_k9d.txt
 {
-  echo "# K9c (FSF_PLANES_PIPE=0) vs K9d (default) vs K9e (FSF_PLANES_WIDE_MIN_ROWS=30000), same box, tools/profiling/planes_one.py"
-  for e in "FSF_PLANES_PIPE=0" "FSF_PLANES_PIPE=1" "FSF_PLANES_WIDE_MIN_ROWS=30000"; do echo "[$e]"; env $e python tools/profiling/planes_one.py 0 1 2 4 10 12 22 23 24 2>/dev/null | tr "|" "\n"; done
+  echo "# K9c (FSF_PLANES_PIPE=0) vs K9d (default) vs K9e (FSF_PLANES_WIDE_MIN_ROWS=30000) vs K9f (FSF_PLANES_TRI_MIN_ROWS=1), same box, tools/profiling/planes_one.py"
+  for e in "FSF_PLANES_PIPE=0" "FSF_PLANES_PIPE=1" "FSF_PLANES_WIDE_MIN_ROWS=30000" "FSF_PLANES_TRI_MIN_ROWS=1"; do echo "[$e]"; env $e python tools/profiling/planes_one.py 0 1 2 4 10 12 22 23 24 2>/dev/null | tr "|" "\n"; done
 } > $out/spconv_k9c_k9d_k9e.txt
 bash tools/profiling/pipe_ablate.sh > /dev/null 2>&1
 cp gpurun_out/pipe_ablate.txt $out/spconv_k9d_ablations.txt
@@ -42,4 +42,15 @@ bash tools/profiling/lna_ablate.sh > /dev/null 2>&1
 cp gpurun_out/lna_ablate.txt $out/k22_ablations.txt
 { for p in 0 1; do echo "[FSF_K22_F16=$p]"; FSF_K22_F16=$p python tools/profiling/lna_bench.py 2>/dev/null | sed "s/F.linear .*//"; done; } > $out/k22_vs_k22b.txt
 python tools/profiling/aten_sites.py 90 2>/dev/null > $out/aten_sites.txt
+python tools/profiling/plan_stream_trace.py 2>/dev/null > $out/unet_plan_stream_trace.txt
+python tools/profiling/plan_stream_ab.py 2>/dev/null >> $out/unet_plan_stream_trace.txt
+python tools/profiling/tail_times.py 2>/dev/null > $out/box_tail_times.txt
+FSF_BOX_TAIL_FUSED=0 python tools/profiling/tail_times.py 2>/dev/null | sed "s/^/[FSF_BOX_TAIL_FUSED=0] /" >> $out/box_tail_times.txt
+python tools/profiling/stage_times.py 2>/dev/null > $out/stage_times.txt
+rm -rf gpurun_out/prof_tl
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_tl -o fsf -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-describe --no-trained-like > /dev/null 2>&1
+python tools/profiling/frame_timeline.py gpurun_out/prof_tl/fsf_results.db 7 > $out/frame_timeline.txt
+python tools/profiling/dispatch_list.py gpurun_out/prof_tl/fsf_results.db 7 seg_reduce_kernel seg_fixup_long sir_input_kernel linear_norm_act_kernel > $out/dispatches_in_situ.txt
+rm -rf gpurun_out/prof_tl
+bash tools/profiling/ab_bench.sh "FSF_UNET_PLAN_STREAM=0 FSF_BOX_TAIL_FUSED=0" "FSF_UNET_PLAN_STREAM=1 FSF_BOX_TAIL_FUSED=0" "FSF_UNET_PLAN_STREAM=1 FSF_BOX_TAIL_FUSED=1" > $out/ab_plan_stream_box_tail.txt 2>/dev/null
 tail -c 700 $out/bench.json; echo; tail -c 300 $out/bench_train.json; echo; tail -c 300 $out/bench_train_bs2.json; echo; tail -c 300 $out/bench_av2.json
