@@ -63,16 +63,17 @@ __global__ void __launch_bounds__(256)
 }
 
 constexpr int BT_SEL_THREADS = 1024;
-constexpr int BT_SEL_CAP = 8192;   // kept boxes over all classes the selection can take (LDS: 64 KB of keys)
+constexpr int BT_SEL_CAP = 16384;  // kept boxes over all classes the selection can take (dynamic LDS: 8 B of key per box, 128 KB at most)
 constexpr int BT_MAX_CLASSES = 32;
 
 // one workgroup: class-major list of the kept boxes -> (if more than max_num) sorted by descending score, ties in class-major order
 __global__ void __launch_bounds__(BT_SEL_THREADS)
     bt_select_kernel(const float* __restrict__ boxes, const float* __restrict__ scores_t, const int32_t* __restrict__ order,
                      const int64_t* __restrict__ keep, int64_t keep_stride, const int64_t* __restrict__ num, int C, int64_t n, int D,
-                     int max_num, const int64_t* __restrict__ lut, const int32_t* __restrict__ incomplete, float* __restrict__ out,
-                     int32_t* __restrict__ meta) {
-  __shared__ uint64_t keys[BT_SEL_CAP];
+                     int max_num, int cap, const int64_t* __restrict__ lut, const int32_t* __restrict__ incomplete,
+                     float* __restrict__ out, int32_t* __restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) char bt_smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(bt_smem);  // [next power of two >= num_classes * max_keep]
   __shared__ int offs[BT_MAX_CLASSES + 1];
   const int tid = threadIdx.x;
   if (tid == 0) {
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(BT_SEL_THREADS)
       offs[c] = acc;
       int64_t k = num[c];
       k = k < 0 ? 0 : (k > n ? n : k);
-      acc += (int)(k > BT_SEL_CAP - acc ? BT_SEL_CAP - acc : k);  // (never clipped: the host checks C * max_keep <= BT_SEL_CAP)
+      acc += (int)(k > cap - acc ? cap - acc : k);  // (never clipped when num[c] <= max_keep, as K20 guarantees: cap >= C * max_keep)
     }
     offs[C] = acc;
   }
@@ -211,8 +212,12 @@ extern "C" int fsf_nms_select(const float* boxes, int32_t box_dim, const float* 
   // every class contributes at most max_keep boxes: the list must fit the selection's LDS
   if (num_classes > BT_MAX_CLASSES || max_keep < 1 || max_keep * (int64_t)num_classes > BT_SEL_CAP || n >= ((int64_t)1 << 31))
     return FSF_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(bt_select_kernel, dim3(1), dim3(BT_SEL_THREADS), 0, stream, boxes, scores_t, order, keep, keep_stride, num_keep,
-                     (int)num_classes, n, (int)box_dim, (int)max_num, label_lut, incomplete, out, meta);
+  int64_t cap = 1;
+  while (cap < max_keep * (int64_t)num_classes) cap <<= 1;
+  static std::atomic<uint64_t> attr_done{0};
+  FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)bt_select_kernel, BT_SEL_CAP * 8, attr_done));
+  hipLaunchKernelGGL(bt_select_kernel, dim3(1), dim3(BT_SEL_THREADS), (size_t)cap * 8, stream, boxes, scores_t, order, keep, keep_stride, num_keep,
+                     (int)num_classes, n, (int)box_dim, (int)max_num, (int)cap, label_lut, incomplete, out, meta);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

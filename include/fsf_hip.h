@@ -637,7 +637,7 @@ int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_cla
  *   - its concatenation of the classes' kept boxes, the `scores.sort(descending=True)[:max_num]` cut, the label table of
  *     frustum_cluster_head.py:680-690 and bbox3d2result's packing                             -> fsf_nms_select
  *       keep / num_keep as K20 returned them (keep_stride = row stride of keep), max_keep = the cap K20 ran with
- *       (num_classes * max_keep <= fsf_nms_select_capacity(), else FSF_ERR_UNSUPPORTED) ->
+ *       (num_classes * max_keep <= fsf_nms_select_capacity() = 16 384, else FSF_ERR_UNSUPPORTED) ->
  *       out f32 [max_num, box_dim + 2] rows (box | score | label as float, label = label_lut[c] or c), class-major and
  *       score-descending within a class when at most max_num boxes were kept, otherwise the max_num best by descending
  *       score (ties: class-major order); meta i32 [4] = (rows written, boxes kept over all classes, *incomplete or 0, 0).

@@ -70,7 +70,7 @@ def fake_head(cfg, classes, code):
 
 
 @pytest.mark.parametrize("n,c,code,max_num,spread,must_fuse", [
-    (300, 3, 10, 500, 200.0, True), (10397, 10, 10, 500, 60.0, True), (6000, 10, 8, 300, 30.0, True), (50, 10, 10, 500, 5.0, True),
+    (300, 3, 10, 500, 200.0, True), (10397, 10, 10, 500, 60.0, True), (9000, 26, 8, 500, 120.0, True), (6000, 10, 8, 300, 30.0, True), (50, 10, 10, 500, 5.0, True),
     (4000, 2, 10, 500, 25.0, False)])  # (the last: 2 000 boxes of a class piled on 25 m — a class may exhaust its mask window: full repeat)
 def test_get_bboxes_single_fused_equals_the_generic_path(device, monkeypatch, n, c, code, max_num, spread, must_fuse):
     """The whole tail, fused (default) against generic (FSF_BOX_TAIL_FUSED=0): the same boxes, scores and labels in the same order —
@@ -135,4 +135,4 @@ def test_nms_select_reports_counts_and_the_incomplete_flag(device):
     np.testing.assert_array_equal(rows[:, d].numpy(), want)                                   # class-major, descending within a class
     np.testing.assert_array_equal(rows[:, d + 1].numpy(), np.repeat(np.arange(c), num.cpu().numpy()).astype(np.float32))
     with pytest.raises(RuntimeError):
-        hip_ops.nms_select(boxes, st, order, keep, num, 8192, 500)  # 3 x 8192 boxes do not fit the selection
+        hip_ops.nms_select(boxes, st, order, keep, num, 8192, 500)  # 3 x 8192 boxes do not fit the selection's 16 384
