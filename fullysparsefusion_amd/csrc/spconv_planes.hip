@@ -975,14 +975,20 @@ __global__ void __launch_bounds__(256, SP_PIPE_WPS) spconv_fwd_pipe_kernel(SpArg
 // into them directly; the epilogue multiplies the last unit back out.  (Exact as long as no intermediate leaves the fp32
 // range: the rows of one 27-neighbourhood may differ by up to ~2^80 in magnitude.)
 // Ring: three chunk slots of 16 KB (slot index carried at run time), two workgroups per CU.
-template <int TPW>
+// Round 3, second form (K9g = RG 6): 96-row blocks.  Eight cells do not fit three waves per SIMD (K9e: 216 registers, and measured
+// 12-30 % slower at two); SIX do if a wave keeps the X fragments of only half its cells at a time: per iteration it multiplies cells
+// 0..RG/2-1, refilling each cell's fragment registers with cell + RG/2 of the SAME chunk behind its MFMAs, then multiplies those,
+// refilling with the first half of the next chunk.  16 KB of weight fragments + 12 KB of rows per 96 rows and chunk (K9d: 16 + 8 per
+// 64), 36 MFMAs per wave between two barriers instead of 24, a 3 x 12 KB ring + the 10 KB table = 51 KB: three workgroups per CU.
+// A wave gathers 4 RG rows (24: one and a half cells), eight rows per instruction.
+template <int TPW, int RG>
 struct SpWideSmem {
-  static constexpr int RG = 8, R = 128;
+  static constexpr int R = 16 * RG;
   static constexpr size_t nbr_bytes = (size_t)R * SP_KVOL_MAX * 4;
   static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
   static constexpr size_t xring_bytes = (size_t)3 * RG * 2048;  // [slot][cell][row][piece ^ swizzle(row)] x 16 B
   static constexpr size_t sring_off = xring_off + xring_bytes;
-  static constexpr size_t sring_bytes = (size_t)2 * RG * 16 * 4;  // [step parity][cell][row]
+  static constexpr size_t sring_bytes = (size_t)2 * R * 4;  // [step parity][row of the block]
   static constexpr size_t meta_off = sring_off + sring_bytes;
   static constexpr size_t meta_bytes = 32 * 4 + 16 + (size_t)SP_KVOL_MAX * RG;
   static constexpr size_t vec_off = (meta_off + meta_bytes + 15) / 16 * 16;
@@ -992,11 +998,12 @@ struct SpWideSmem {
   static constexpr size_t bytes = rowmax_off + rowmax_bytes;
 };
 
-template <int TPW, int NKC>
-__global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
-  using S = SpWideSmem<TPW>;
-  constexpr int RG = 8, R = 128, CPW = 2;
+template <int TPW, int NKC, int RG>
+__global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_wide_kernel(SpArgs a) {
+  using S = SpWideSmem<TPW, RG>;
+  constexpr int R = 16 * RG, RPW = R / 4, NLD = RPW / 8, HB = RG / 2;  // rows per wave, gather instructions per wave and chunk, cells per half
   static_assert(NKC == 2 || NKC == 4, "sources of 64 or 128 channels");
+  static_assert(RG == 6 || RG == 8, "96- or 128-row blocks");
   extern __shared__ __attribute__((aligned(16))) char sp_smem[];
   int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
   uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
@@ -1013,7 +1020,7 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const int slice = blockIdx.y;
 
-  // ---- prologue (as K9c, eight cells)
+  // ---- prologue (as K9c, RG cells)
   {
     const int64_t base = row0 * kvol, lim = a.m_out * kvol;
     for (int idx = tid; idx < R * kvol; idx += 256) nbr_s[idx] = (base + idx < lim) ? a.nbr[base + idx] : -1;
@@ -1070,52 +1077,43 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
     for (int t = 0; t < TPW; ++t) acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  // ---- this wave's share of the gather: cells 2 wave and 2 wave + 1, line-coalesced (see K9d): per cell and chunk two loads
-  uint4 g_v[CPW][2];
-  uint32_t g_off[CPW][2];
+  // ---- this wave's share of the gather: rows RPW wave .. RPW wave + RPW - 1 of the block, line-coalesced (see K9d): lane l takes piece
+  // l % 8 of row 8 h + l / 8 in its h-th load, so a load's eight rows are one half of one cell
+  uint4 g_v[NLD];
+  uint32_t g_off[NLD];
   float g_sc = 1.0f;
 #pragma unroll
-  for (int u = 0; u < CPW; ++u)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      g_v[u][h] = make_uint4(0, 0, 0, 0);
-      g_off[u][h] = 0;
-    }
+  for (int h = 0; h < NLD; ++h) {
+    g_v[h] = make_uint4(0, 0, 0, 0);
+    g_off[h] = 0;
+  }
   const int grow = lane >> 3, gpiece = lane & 7;
   auto gather_row = [&](const SpStep& st) {  // first chunk of a step: which rows, their scale
-    const int32_t* col = nbr_s + (16 * CPW * wave) * kvol + st.k;
+    const int32_t* col = nbr_s + (RPW * wave) * kvol + st.k;
     const int zero = (int)a.m_in;  // (no neighbour: the all-zero row m_in, scale 1)
 #pragma unroll
-    for (int u = 0; u < CPW; ++u)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int i = col[(16 * u + 8 * h + grow) * kvol];
-        i = i >= 0 ? i : zero;
-        g_off[u][h] = (uint32_t)i * rowbytes + (uint32_t)(gpiece * 16);
-      }
-    int is = col[(16 * (q & 1) + j) * kvol];  // lanes of q = 0 / 1 fetch the scales of the first / second cell's rows
+    for (int h = 0; h < NLD; ++h) {
+      int i = col[(8 * h + grow) * kvol];
+      i = i >= 0 ? i : zero;
+      g_off[h] = (uint32_t)i * rowbytes + (uint32_t)(gpiece * 16);
+    }
+    int is = col[(lane < RPW ? lane : 0) * kvol];  // lane l < RPW fetches the scale of the wave's l-th row
     is = is >= 0 ? is : zero;
     g_sc = (st.src ? a.sx[1] : a.sx[0])[is];
   };
   auto gather_chunk = [&](const SpStep& st, int kc) {
     const char* p = (st.src ? a.x[1] : a.x[0]) + (uint32_t)(kc * 128);
 #pragma unroll
-    for (int u = 0; u < CPW; ++u)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) g_v[u][h] = *reinterpret_cast<const uint4*>(p + g_off[u][h]);
+    for (int h = 0; h < NLD; ++h) g_v[h] = *reinterpret_cast<const uint4*>(p + g_off[h]);
   };
-  const int wr0 = grow * 8 + (gpiece ^ ((grow >> 1) & 7)), wr1 = (8 + grow) * 8 + (gpiece ^ (((8 + grow) >> 1) & 7));
   auto stage_to_lds = [&](const SpStep& st, int kc, int slot, int parity) {
 #pragma unroll
-    for (int u = 0; u < CPW; ++u) {
-      const int cc = CPW * wave + u;
-      if ((st.mask >> cc) & 1u) {
-        uint4* dst = xring + (slot * RG + cc) * 128;
-        dst[wr0] = g_v[u][0];
-        dst[wr1] = g_v[u][1];
-      }
+    for (int h = 0; h < NLD; ++h) {
+      const int r8 = RPW * wave + 8 * h;          // first row of this load's eight (a multiple of 8: one half of cell r8 / 16)
+      const int cc = r8 >> 4, rr = (r8 & 8) + grow;  // cell, row within the cell
+      if ((st.mask >> cc) & 1u) xring[(slot * RG + cc) * 128 + rr * 8 + (gpiece ^ ((rr >> 1) & 7))] = g_v[h];
     }
-    if (kc == 0 && q < 2) sring[(parity * RG + CPW * wave + q) * 16 + j] = g_sc;  // (dead cells too: never read)
+    if (kc == 0 && lane < RPW) sring[parity * R + RPW * wave + lane] = g_sc;  // (dead cells too: never read)
   };
   auto load_w = [&](const SpStep& st, int kc, uint4 (&wf)[TPW][2]) {
     const int c = (st.src ? NKC : 0) + kc;
@@ -1147,17 +1145,17 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
     for (int t = 0; t < TPW; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, acc[g][t], 0, 0, 0);
   };
 
-  // ---- pipeline state
+  // ---- pipeline state: two weight sets, the X fragments of HALF the cells
   uint4 wA[TPW][2], wB[TPW][2];
-  uint4 xh[RG], xl[RG];
+  uint4 xh[HB], xl[HB];
 #pragma unroll
-  for (int g = 0; g < RG; ++g) xh[g] = xl[g] = make_uint4(0, 0, 0, 0);
+  for (int g = 0; g < HB; ++g) xh[g] = xl[g] = make_uint4(0, 0, 0, 0);
 
   SpStep r0 = entry(0, 0);
   SpStep r1 = advance(r0);
   SpStep r2 = advance(r1);
 
-  // ---- fill: X(0), X(1) -> LDS slots 0, 1; X(2) -> staging registers; W(0) -> set A; then the fragments of chunk 0
+  // ---- fill: X(0), X(1) -> LDS slots 0, 1; X(2) -> staging registers; W(0) -> set A; then the fragments of chunk 0's first half
   gather_row(r0);
   gather_chunk(r0, 0);
   load_w(r0, 0, wA);
@@ -1172,7 +1170,7 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
   }
   __syncthreads();
 #pragma unroll
-  for (int g = 0; g < RG; ++g)
+  for (int g = 0; g < HB; ++g)
     if ((r0.mask >> g) & 1u) read_cell(0, g, xh[g], xl[g]);
 
   int slot = 0;    // LDS slot of the chunk being multiplied (chunk counter modulo 3)
@@ -1188,7 +1186,7 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
     constexpr int kc1 = (KC + 1) % NKC, kc2 = (KC + 2) % NKC, kc3 = (KC + 3) % NKC;
     const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
     __syncthreads();
-    // staging of the chunks ahead
+    // staging of the chunks ahead (slot2 was last read — chunk KC - 1's second half — before the previous barrier)
     stage_to_lds(st2, kc2, slot2, (parity + d2) & 1);
     if (kc3 == 0) gather_row(st3);
     gather_chunk(st3, kc3);
@@ -1199,7 +1197,7 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
 #pragma unroll
       for (int g = 0; g < RG; ++g) {
         if ((st.mask >> g) & 1u) {
-          const float v = sring[(parity * RG + g) * 16 + j];
+          const float v = sring[parity * R + 16 * g + j];
           const float f = __fmul_rn(cinv[g], __uint_as_float(0x7F000000u - __float_as_uint(v)));  // old unit / new unit = cinv_old * (1 / v)
           cinv[g] = v;
 #pragma unroll
@@ -1209,10 +1207,16 @@ __global__ void __launch_bounds__(256, 2) spconv_fwd_wide_kernel(SpArgs a) {
         }
       }
     }
-    // multiply chunk KC; each cell's fragment registers take chunk KC + 1 as soon as its MFMAs are issued
+    // first half of chunk KC; a cell's fragment registers take the chunk's second half as soon as its MFMAs are issued
 #pragma unroll
-    for (int g = 0; g < RG; ++g) {
+    for (int g = 0; g < HB; ++g) {
       if ((st.mask >> g) & 1u) mma_cell(g, xh[g], xl[g], (KC % 2 == 0) ? wA : wB);
+      if ((st.mask >> (g + HB)) & 1u) read_cell(slot, g + HB, xh[g], xl[g]);
+    }
+    // second half; then the first half of chunk KC + 1
+#pragma unroll
+    for (int g = 0; g < HB; ++g) {
+      if ((st.mask >> (g + HB)) & 1u) mma_cell(g + HB, xh[g], xl[g], (KC % 2 == 0) ? wA : wB);
       if ((st1.mask >> g) & 1u) read_cell(slot1, g, xh[g], xl[g]);
     }
     slot = slot1;
@@ -1650,14 +1654,17 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
   // turns it on from that many output rows x channel slices
   static const int64_t wide_min_rows = getenv("FSF_PLANES_WIDE_MIN_ROWS") ? atoll(getenv("FSF_PLANES_WIDE_MIN_ROWS")) : ((int64_t)1 << 40);
   const bool wide = pipe_on && !big && nkc_fix > 0 && m_out * nslice >= wide_min_rows;
-#define FSF_SPW(TPW_, NKC_)                                                                                              \
-  do {                                                                                                                  \
-    using S = SpWideSmem<TPW_>;                                                                                         \
-    static std::atomic<uint64_t> attr_done{0};                                                                          \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_wide_kernel<TPW_, NKC_>, (int)S::bytes, attr_done));    \
-    const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                           \
-    hipLaunchKernelGGL((spconv_fwd_wide_kernel<TPW_, NKC_>), grid, dim3(256), S::bytes, stream, a);                     \
+#define FSF_SPW(TPW_, NKC_, RG_)                                                                                              \
+  do {                                                                                                                       \
+    using S = SpWideSmem<TPW_, RG_>;                                                                                         \
+    static std::atomic<uint64_t> attr_done{0};                                                                               \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_wide_kernel<TPW_, NKC_, RG_>, (int)S::bytes, attr_done));    \
+    const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                                \
+    hipLaunchKernelGGL((spconv_fwd_wide_kernel<TPW_, NKC_, RG_>), grid, dim3(256), S::bytes, stream, a);                     \
   } while (0)
+  // K9g (96-row blocks, three workgroups per CU) from FSF_PLANES_R96_MIN_ROWS output rows x channel slices
+  static const int64_t r96_min_rows = getenv("FSF_PLANES_R96_MIN_ROWS") ? atoll(getenv("FSF_PLANES_R96_MIN_ROWS")) : ((int64_t)1 << 40);
+  const bool r96 = pipe_on && !big && !wide && nkc_fix > 0 && m_out * nslice >= r96_min_rows;
   // K9f (192-row workgroups sharing the weight fragments) from FSF_PLANES_TRI_MIN_ROWS output rows
   static const int64_t tri_min_rows = getenv("FSF_PLANES_TRI_MIN_ROWS") ? atoll(getenv("FSF_PLANES_TRI_MIN_ROWS")) : ((int64_t)1 << 40);
   const bool tri = pipe_on && !big && !wide && nkc_fix > 0 && m_out >= tri_min_rows;
@@ -1669,12 +1676,15 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
     const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                           \
     hipLaunchKernelGGL((spconv_fwd_tri_kernel<TPW_, NKC_>), grid, dim3(768), S::bytes, stream, a);                      \
   } while (0)
-  if (tri && nkc_fix == 4 && tpw == 2) FSF_SPT(2, 4);
+  if (r96 && nkc_fix == 4 && tpw == 2) FSF_SPW(2, 4, 6);
+  else if (r96 && nkc_fix == 2 && tpw == 2) FSF_SPW(2, 2, 6);
+  else if (r96 && nkc_fix == 2 && tpw == 1) FSF_SPW(1, 2, 6);
+  else if (tri && nkc_fix == 4 && tpw == 2) FSF_SPT(2, 4);
   else if (tri && nkc_fix == 2 && tpw == 2) FSF_SPT(2, 2);
   else if (tri && nkc_fix == 2 && tpw == 1) FSF_SPT(1, 2);
-  else if (wide && nkc_fix == 4 && tpw == 2) FSF_SPW(2, 4);
-  else if (wide && nkc_fix == 2 && tpw == 2) FSF_SPW(2, 2);
-  else if (wide && nkc_fix == 2 && tpw == 1) FSF_SPW(1, 2);
+  else if (wide && nkc_fix == 4 && tpw == 2) FSF_SPW(2, 4, 8);
+  else if (wide && nkc_fix == 2 && tpw == 2) FSF_SPW(2, 2, 8);
+  else if (wide && nkc_fix == 2 && tpw == 1) FSF_SPW(1, 2, 8);
   else if (pipe_on && !big && nkc_fix == 4 && tpw == 2) FSF_SPP(2, 4);   // K9d: the chunk-granular pipeline
   else if (pipe_on && !big && nkc_fix == 2 && tpw == 2) FSF_SPP(2, 2);
   else if (pipe_on && !big && nkc_fix == 2 && tpw == 1) FSF_SPP(1, 2);

@@ -3,6 +3,8 @@ the parity tests of the default kernels are re-run in a child process with the v
 
   * K9e (`spconv_fwd_wide_kernel`: 128-row blocks, accumulators kept in the unit of the row being multiplied) —
     FSF_PLANES_WIDE_MIN_ROWS=1;
+  * K9g (the same kernel template on 96-row blocks, half the cells' fragments in registers at a time: three workgroups per CU) —
+    FSF_PLANES_R96_MIN_ROWS=1;
   * K9f (`spconv_fwd_tri_kernel`: 192-row workgroups of twelve waves sharing the weight fragments through LDS) —
     FSF_PLANES_TRI_MIN_ROWS=1;
   * K9c as the only plane kernel (K9d off) — FSF_PLANES_PIPE=0;
@@ -28,8 +30,8 @@ def run_child(env_extra, select):
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
 
 
-@pytest.mark.parametrize("env", [dict(FSF_PLANES_WIDE_MIN_ROWS="1"), dict(FSF_PLANES_PIPE="0"), dict(FSF_PLANES_TRI_MIN_ROWS="1")],
-                         ids=["K9e", "K9c", "K9f"])
+@pytest.mark.parametrize("env", [dict(FSF_PLANES_WIDE_MIN_ROWS="1"), dict(FSF_PLANES_PIPE="0"), dict(FSF_PLANES_TRI_MIN_ROWS="1"),
+                                 dict(FSF_PLANES_R96_MIN_ROWS="1")], ids=["K9e", "K9c", "K9f", "K9g"])
 def test_plane_kernel_variants(device, env):
     run_child(env, "spconv_forward_planes")
 

@@ -29,8 +29,8 @@ python tools/profiling/planes_layers.py > $out/spconv_layers_k9b_vs_k9d.txt 2>/d
   done
 } > $out/pmc_stalls_k9d.txt
 {
-  echo "# K9c (FSF_PLANES_PIPE=0) vs K9d (default) vs K9e (FSF_PLANES_WIDE_MIN_ROWS=30000) vs K9f (FSF_PLANES_TRI_MIN_ROWS=1), same box, tools/profiling/planes_one.py"
-  for e in "FSF_PLANES_PIPE=0" "FSF_PLANES_PIPE=1" "FSF_PLANES_WIDE_MIN_ROWS=30000" "FSF_PLANES_TRI_MIN_ROWS=1"; do echo "[$e]"; env $e python tools/profiling/planes_one.py 0 1 2 4 10 12 22 23 24 2>/dev/null | tr "|" "\n"; done
+  echo "# K9c (FSF_PLANES_PIPE=0) vs K9d (default) vs K9e (FSF_PLANES_WIDE_MIN_ROWS=30000) vs K9f (FSF_PLANES_TRI_MIN_ROWS=1) vs K9g (FSF_PLANES_R96_MIN_ROWS=1), same box, tools/profiling/planes_one.py"
+  for e in "FSF_PLANES_PIPE=0" "FSF_PLANES_PIPE=1" "FSF_PLANES_WIDE_MIN_ROWS=30000" "FSF_PLANES_TRI_MIN_ROWS=1" "FSF_PLANES_R96_MIN_ROWS=1"; do echo "[$e]"; env $e python tools/profiling/planes_one.py 0 1 2 4 10 12 22 23 24 2>/dev/null | tr "|" "\n"; done
 } > $out/spconv_k9c_k9d_k9e.txt
 bash tools/profiling/pipe_ablate.sh > /dev/null 2>&1
 cp gpurun_out/pipe_ablate.txt $out/spconv_k9d_ablations.txt
