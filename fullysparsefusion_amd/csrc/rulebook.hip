@@ -146,6 +146,43 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// The same pass with a thread per INPUT voxel (round 3): a voxel walks its kvol offsets itself — most fail the stride test at once (a
+// stride-2 3 x 3 x 3 convolution admits at most 8 of 27) — and parks the sites it was first to propose in an LDS list of the
+// workgroup (at most `per_in` per thread); one device atomic and one coalesced copy per workgroup.  m * kvol threads, two barriers per
+// 524 k of them, took 90 us on the 92 k-voxel level; the order of `list` differs, the sorted result does not.
+__global__ void __launch_bounds__(256)
+    rb_propose_rows_kernel(const int32_t* __restrict__ indices, int64_t m, ConvGeom g, uint64_t* set_keys, uint64_t set_mask,
+                           uint64_t* __restrict__ list, uint32_t* __restrict__ list_count) {
+  extern __shared__ __attribute__((aligned(16))) char rbp_smem[];
+  uint64_t* s_keys = reinterpret_cast<uint64_t*>(rbp_smem);  // [256 * per_in]
+  __shared__ uint32_t s_cnt, s_base;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) {
+    const int4 c = *reinterpret_cast<const int4*>(indices + i * 4);
+    for (int kzi = 0; kzi < g.kz; ++kzi) {
+      const int nz = c.y + g.pz - kzi * g.dz;
+      if (nz < 0 || nz % g.sz || nz / g.sz >= g.OZ) continue;
+      for (int kyi = 0; kyi < g.ky; ++kyi) {
+        const int ny = c.z + g.py - kyi * g.dy;
+        if (ny < 0 || ny % g.sy || ny / g.sy >= g.OY) continue;
+        for (int kxi = 0; kxi < g.kx; ++kxi) {
+          const int nx = c.w + g.px - kxi * g.dx;
+          if (nx < 0 || nx % g.sx || nx / g.sx >= g.OX) continue;
+          const uint64_t key = lin_out(g, c.x, nz / g.sz, ny / g.sy, nx / g.sx);
+          if (hash_insert_set(set_keys, set_mask, key)) s_keys[atomicAdd(&s_cnt, 1u)] = key;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n_new = s_cnt;
+  if (threadIdx.x == 0 && n_new) s_base = atomicAdd(list_count, n_new);
+  __syncthreads();
+  for (uint32_t t = threadIdx.x; t < n_new; t += blockDim.x) list[s_base + t] = s_keys[t];
+}
+
 __global__ void __launch_bounds__(256) rb_iota_kernel(uint32_t* v, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     v[i] = (uint32_t)i;
@@ -395,8 +432,13 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
   FSF_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint32_t), stream));
   hipLaunchKernelGGL(rb_insert_inputs_kernel, dim3(fsf_stream_grid(m, 256)), dim3(256), 0, stream, indices, m, g, in_keys,
                      in_vals, (uint64_t)(in_cap - 1));
-  hipLaunchKernelGGL(rb_propose_kernel, dim3(fsf_stream_grid(cand, 256)), dim3(256), 0, stream, indices, m, g, set_keys,
-                     (uint64_t)(set_cap - 1), list_a, count_dev);
+  static const bool propose_by_pair = getenv("FSF_RB_PROPOSE_PAIRS") != nullptr;  // (A/B switch, latched: the round-1 kernel)
+  if (propose_by_pair || per_in > 32 || (m + 255) / 256 > 0x7FFFFFFF)
+    hipLaunchKernelGGL(rb_propose_kernel, dim3(fsf_stream_grid(cand, 256)), dim3(256), 0, stream, indices, m, g, set_keys,
+                       (uint64_t)(set_cap - 1), list_a, count_dev);
+  else
+    hipLaunchKernelGGL(rb_propose_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), (size_t)256 * per_in * 8, stream, indices, m,
+                       g, set_keys, (uint64_t)(set_cap - 1), list_a, count_dev);
   uint32_t count_h = 0;
   FSF_HIP_TRY(hipMemcpyAsync(&count_h, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   FSF_HIP_TRY(hipStreamSynchronize(stream));
