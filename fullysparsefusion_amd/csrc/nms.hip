@@ -457,8 +457,9 @@ static int64_t nms_bins_bytes(int64_t n) {
   return fsf_align_up((int64_t)(2 * NMS_GRID * NMS_GRID + 1) * 4, 256) + 4 * fsf_align_up(n * 4, 256) + 256;
 }
 
-// pair bits of all boxes into a.mask / a.rowsum (rowsum must be zero on entry)
-static int nms_launch_mask(const NmsArgs& a, FsfArena& arena, hipStream_t stream) {
+// pair bits of all boxes into a.mask / a.rowsum (rowsum must be zero on entry); `prezeroed`: the caller has cleared a.mask and everything
+// this function takes from the arena (one memset over the lot instead of three here)
+static int nms_launch_mask(const NmsArgs& a, FsfArena& arena, hipStream_t stream, bool prezeroed = false) {
   if (a.n < NMS_BIN_MIN) {
     // words below the diagonal are never written by the mask kernel and never read by the scan / build (w starts at i / 64)
     hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)a.words, (unsigned)a.words), dim3(64), 0, stream, a);
@@ -474,9 +475,11 @@ static int nms_launch_mask(const NmsArgs& a, FsfArena& arena, hipStream_t stream
   b.big_list = arena.take<int32_t>(a.n);
   b.nbig = arena.take<int32_t>(1);
   if (!arena.ok()) return FSF_ERR_WORKSPACE;
-  FSF_HIP_TRY(hipMemsetAsync(a.mask, 0, (size_t)a.n * a.words * 8, stream));
-  FSF_HIP_TRY(hipMemsetAsync(b.cell_cnt, 0, sizeof(int32_t) * NMS_GRID * NMS_GRID, stream));
-  FSF_HIP_TRY(hipMemsetAsync(b.nbig, 0, sizeof(int32_t), stream));
+  if (!prezeroed) {
+    FSF_HIP_TRY(hipMemsetAsync(a.mask, 0, (size_t)a.n * a.words * 8, stream));
+    FSF_HIP_TRY(hipMemsetAsync(b.cell_cnt, 0, sizeof(int32_t) * NMS_GRID * NMS_GRID, stream));
+    FSF_HIP_TRY(hipMemsetAsync(b.nbig, 0, sizeof(int32_t), stream));
+  }
   const unsigned g = (unsigned)fsf_stream_grid(a.n, 256);
   hipLaunchKernelGGL(nms_bin_count_kernel, dim3(g), dim3(256), 0, stream, a, b);
   hipLaunchKernelGGL(nms_bin_scan_kernel, dim3(1), dim3(1024), 0, stream, b);
@@ -587,12 +590,13 @@ extern "C" int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int3
   uint64_t* mask = arena.take<uint64_t>((int64_t)num_classes * rows * cwords);
   uint64_t* rowsum = arena.take<uint64_t>((int64_t)num_classes * rows * csum);
   if (!arena.ok()) return FSF_ERR_WORKSPACE;
-  // the build kernel walks mask0 through rowsum0, so the lower-triangle words the mask kernel skips are never read
-  FSF_HIP_TRY(hipMemsetAsync(rowsum0, 0, (size_t)n * sum_words * 8, stream));
-  FSF_HIP_TRY(hipMemsetAsync(mask, 0, (size_t)num_classes * rows * cwords * 8, stream));
-  FSF_HIP_TRY(hipMemsetAsync(rowsum, 0, (size_t)num_classes * rows * csum * 8, stream));
+  // ONE clear for everything that must start at zero: the four arrays above (the build kernel walks mask0 through rowsum0, so the
+  // lower-triangle words the mask kernel skips are never read) and, right behind them in the arena, the cell counters / lists
+  // nms_launch_mask takes (six memsets before)
+  const int64_t clear_bytes = std::min<int64_t>(arena.used + nms_bins_bytes(n), workspace_bytes);
+  FSF_HIP_TRY(hipMemsetAsync(mask0, 0, (size_t)clear_bytes, stream));
   NmsArgs a0{boxes, n, thresh, (int)rotated, mask0, rowsum0, (int)words, (int)sum_words, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr};
-  const int rc = nms_launch_mask(a0, arena, stream);
+  const int rc = nms_launch_mask(a0, arena, stream, true);
   if (rc != FSF_OK) return rc;
   NmsBuildArgs b{mask0, rowsum0, rank, mask, rowsum, n, (int)words, (int)sum_words, rows, (int)cwords, (int)csum};
   hipLaunchKernelGGL(nms_build_kernel, dim3((unsigned)fsf_stream_grid(n * sum_words, 256), (unsigned)num_classes), dim3(256), 0,
