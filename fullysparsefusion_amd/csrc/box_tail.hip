@@ -17,12 +17,14 @@ __device__ __forceinline__ uint32_t bt_desc_key(float s) {
 }
 
 __global__ void __launch_bounds__(256)
-    bt_decode_kernel(const float* __restrict__ cls, const float* __restrict__ reg, const float* __restrict__ xyz, int64_t n, int C,
-                     int code, float eps, float* __restrict__ boxes, float* __restrict__ boxes_nms, float* __restrict__ scores_t) {
+    bt_decode_kernel(const float* __restrict__ cls, int64_t cls_stride, const float* __restrict__ reg, int64_t reg_stride,
+                     const float* __restrict__ xyz, int64_t xyz_stride, int64_t n, int C, int code, float eps, float* __restrict__ boxes,
+                     float* __restrict__ boxes_nms, float* __restrict__ scores_t) {
   const int D = code - 1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const float* r = reg + i * code;
-    const float x = __fadd_rn(r[0], xyz[i * 3 + 0]), y = __fadd_rn(r[1], xyz[i * 3 + 1]), z = __fadd_rn(r[2], xyz[i * 3 + 2]);
+    const float* r = reg + i * reg_stride;
+    const float* p = xyz + i * xyz_stride;
+    const float x = __fadd_rn(r[0], p[0]), y = __fadd_rn(r[1], p[1]), z = __fadd_rn(r[2], p[2]);
     const float dx = __fsub_rn(expf(r[3]), eps), dy = __fsub_rn(expf(r[4]), eps), dz = __fsub_rn(expf(r[5]), eps);
     const float yaw = atan2f(r[6], r[7]);
     float* b = boxes + i * D;
@@ -32,7 +34,7 @@ __global__ void __launch_bounds__(256)
     float* q = boxes_nms + i * 5;
     q[0] = __fsub_rn(x, hw); q[1] = __fsub_rn(y, hh); q[2] = __fadd_rn(x, hw); q[3] = __fadd_rn(y, hh); q[4] = yaw;
     for (int c = 0; c < C; ++c)
-      scores_t[(int64_t)c * n + i] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-cls[i * C + c])));
+      scores_t[(int64_t)c * n + i] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-cls[i * cls_stride + c])));
   }
 }
 
@@ -153,16 +155,17 @@ static int bt_class_bits(int32_t c) {
   return b;
 }
 
-extern "C" int fsf_decode_cluster_boxes(const float* cls_logits, const float* reg_preds, const float* cluster_xyz, int64_t n,
-                                        int32_t num_classes, int32_t code_size, float eps, float* boxes, float* boxes_nms,
-                                        float* scores_t, void* stream_) {
+extern "C" int fsf_decode_cluster_boxes(const float* cls_logits, int64_t cls_stride, const float* reg_preds, int64_t reg_stride,
+                                        const float* cluster_xyz, int64_t xyz_stride, int64_t n, int32_t num_classes, int32_t code_size,
+                                        float eps, float* boxes, float* boxes_nms, float* scores_t, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || num_classes < 1 || (n > 0 && (!cls_logits || !reg_preds || !cluster_xyz || !boxes || !boxes_nms || !scores_t)))
     return FSF_ERR_INVALID_ARG;
+  if (cls_stride < num_classes || reg_stride < code_size || xyz_stride < 3) return FSF_ERR_INVALID_ARG;
   if (code_size != 8 && code_size != 10) return FSF_ERR_UNSUPPORTED;
   if (n == 0) return FSF_OK;
-  hipLaunchKernelGGL(bt_decode_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, cls_logits, reg_preds, cluster_xyz, n,
-                     (int)num_classes, (int)code_size, eps, boxes, boxes_nms, scores_t);
+  hipLaunchKernelGGL(bt_decode_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, cls_logits, cls_stride, reg_preds,
+                     reg_stride, cluster_xyz, xyz_stride, n, (int)num_classes, (int)code_size, eps, boxes, boxes_nms, scores_t);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -92,7 +92,7 @@ _ARGTYPES = {
     "fsf_nms_bev_multiclass": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_nms_bev_multiclass_capped": [_P, c_i64, c_i32, _P, _P, c_f32, c_i32, c_i64, _P, _P, _P, _P, c_i64, _P],
     "fsf_nms_bev_multiclass_capped_workspace_bytes": [c_i64, c_i32, c_i64],
-    "fsf_decode_cluster_boxes": [_P, _P, _P, c_i64, c_i32, c_i32, c_f32, _P, _P, _P, _P],
+    "fsf_decode_cluster_boxes": [_P, c_i64, _P, c_i64, _P, c_i64, c_i64, c_i32, c_i32, c_f32, _P, _P, _P, _P],
     "fsf_class_rank_desc_workspace_bytes": [c_i64, c_i32],
     "fsf_class_rank_desc": [_P, c_i64, c_i32, c_f32, _P, _P, _P, _P, c_i64, _P],
     "fsf_nms_select_capacity": [],
@@ -997,13 +997,14 @@ def decode_cluster_boxes(cls_logits: torch.Tensor, reg_preds: torch.Tensor, clus
     assert cls_logits.dtype == reg_preds.dtype == cluster_xyz.dtype == torch.float32
     n, c, code = cls_logits.size(0), cls_logits.size(1), reg_preds.size(1)
     assert reg_preds.size(0) == n and cluster_xyz.shape == (n, 3)
-    cls_logits, reg_preds, cluster_xyz = cls_logits.contiguous(), reg_preds.contiguous(), cluster_xyz.contiguous()
+    cls_logits, reg_preds, cluster_xyz = (t if t.stride(1) == 1 else t.contiguous() for t in (cls_logits, reg_preds, cluster_xyz))
     dev = cls_logits.device
     boxes = torch.empty((n, code - 1), dtype=torch.float32, device=dev)
     boxes_nms = torch.empty((n, 5), dtype=torch.float32, device=dev)
     scores_t = torch.empty((c, n), dtype=torch.float32, device=dev)
-    check(_L().fsf_decode_cluster_boxes(ptr(cls_logits), ptr(reg_preds), ptr(cluster_xyz), n, c, code, float(eps), ptr(boxes),
-                                        ptr(boxes_nms), ptr(scores_t), stream_ptr()), "fsf_decode_cluster_boxes")
+    check(_L().fsf_decode_cluster_boxes(c_p(cls_logits.data_ptr()), cls_logits.stride(0), c_p(reg_preds.data_ptr()),
+                                        reg_preds.stride(0), c_p(cluster_xyz.data_ptr()), cluster_xyz.stride(0), n, c, code,
+                                        float(eps), ptr(boxes), ptr(boxes_nms), ptr(scores_t), stream_ptr()), "fsf_decode_cluster_boxes")
     return boxes, boxes_nms, scores_t
 
 

@@ -627,7 +627,8 @@ int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_cla
  *   - `cls_logits.sigmoid()`, BasePointBBoxCoder.decode (projects/mmdet3d_plugin/core/bbox/coders/base_point_bbox_coder.py:58-82:
  *     xyz = reg[:, :3] + centre, dims = exp(reg[:, 3:6]) - eps, yaw = atan2(reg[:, 6], reg[:, 7]), velocity appended for code size 10),
  *     LiDARInstance3DBoxes(...).bev and xywhr2xyxyr [UNVENDORED mmdet3d.core.bbox]          -> fsf_decode_cluster_boxes
- *       cls_logits f32 [n, C], reg_preds f32 [n, code] (code 8 | 10), cluster_xyz f32 [n, 3], all contiguous ->
+ *       cls_logits f32 [n, C], reg_preds f32 [n, code] (code 8 | 10), cluster_xyz f32 [n, 3], each with its row stride in floats
+ *       (the heads hand over column slices of wider outputs) ->
  *       boxes f32 [n, code - 1], boxes_nms f32 [n, 5] = (x1, y1, x2, y2, yaw), scores_t f32 [C, n] (class-major sigmoid scores);
  *   - box3d_multiclass_nms [UNVENDORED mmdet3d.core.post_processing]: the per-class `scores > score_thr` mask and score sort
  *                                                                                           -> fsf_class_rank_desc
@@ -643,9 +644,9 @@ int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int32_t num_cla
  *       score (ties: class-major order); meta i32 [4] = (rows written, boxes kept over all classes, *incomplete or 0, 0).
  * Nothing here synchronises; the caller reads `out` and `meta` back with one copy.
  */
-int fsf_decode_cluster_boxes(const float* cls_logits, const float* reg_preds, const float* cluster_xyz, int64_t n,
-                             int32_t num_classes, int32_t code_size, float eps, float* boxes, float* boxes_nms, float* scores_t,
-                             void* stream);
+int fsf_decode_cluster_boxes(const float* cls_logits, int64_t cls_stride, const float* reg_preds, int64_t reg_stride,
+                             const float* cluster_xyz, int64_t xyz_stride, int64_t n, int32_t num_classes, int32_t code_size, float eps,
+                             float* boxes, float* boxes_nms, float* scores_t, void* stream);
 int64_t fsf_class_rank_desc_workspace_bytes(int64_t n, int32_t num_classes);
 int fsf_class_rank_desc(const float* scores_t, int64_t n, int32_t num_classes, float score_thr, int32_t* order, int32_t* rank,
                         int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);

@@ -348,7 +348,7 @@ def test_fused_syncbn_relu_equals_upstream_formulation_world2_gloo():
 
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher re-launches itself under torch.distributed.run on 127.0.0.1: here (no HIP
-    device) both ranks must come up with RANK / WORLD_SIZE set and stop at the device check — not at an assertion about the
+    device) the ranks must come up with RANK / WORLD_SIZE set and stop at the device check — not at an assertion about the
     environment, and not hang."""
     import subprocess
     import sys
@@ -361,5 +361,6 @@ def test_bench_launches_its_own_ranks():
                        capture_output=True, text=True, timeout=240, env=env, cwd=root)
     out = r.stdout + r.stderr
     assert r.returncode != 0
-    assert out.count("needs a HIP device") >= 2, out[-2000:]
+    # (the launcher stops the other rank as soon as one has failed: the second message may not make it out)
+    assert out.count("needs a HIP device") >= 1 and "local_rank" in out, out[-2000:]
     assert "WORLD_SIZE=" not in out  # (the mismatch message of a rank that was not launched per GPU)
