@@ -118,8 +118,11 @@ class FrameDataParallel(torch.nn.Module):
             for p, v in zip(b.params, b.views):
                 if p.grad is None:
                     p.grad = v
-                elif p.grad.data_ptr() != v.data_ptr():  # a gradient tensor the caller put there: keep its values
-                    v.copy_(p.grad)
+                elif p.grad.data_ptr() != v.data_ptr():
+                    # a gradient tensor that is not the bucket view (the caller's, or autograd's after a backward that ran
+                    # un-armed): its values carry over into the bucket — except under zero_grad(), which clears them
+                    if not zero:
+                        v.copy_(p.grad)
                     p.grad = v
         self._armed = True
 

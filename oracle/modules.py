@@ -210,6 +210,34 @@ def segmentor_extract_feat(seg, points_list, grad=False, dtype=torch.float32):
 
 
 # --------------------------------------------------------------------------------------------------- FSF
+def point_image_feat(fsf, obj_id, mask_anno, encode_mlp, img_hw, dtype=torch.float32):
+    """FSF.img_cross_attn (FSF.py:694-728), one sample, on the gathered ids `obj_id` [n, cams, classes]: the camera with the
+    largest id sum (:716-718, first maximum), that camera's id row, `get_all_cls_preds_2d` (:506-535: anno row id - 1, id 0
+    -> zeros with category = the number of id planes), `encode_2d_feats` (:537-552) and the MLP.  nuScenes keeps the score
+    column only (:472-473, `cam_select_score`); Argoverse 2 (`is_argo`) encodes box / W H, score and the one-hot category of
+    every id plane (:459-470)."""
+    obj_id = np.asarray(obj_id)
+    anno = torch.as_tensor(np.asarray(mask_anno), dtype=torch.float32)
+    if not fsf.is_argo and not fsf.encode_label_only:
+        _, score = oproj.cam_select_score(obj_id, anno.numpy())
+        return apply_module(encode_mlp, torch.from_numpy(score).to(dtype))
+    cam = obj_id.sum(-1).argmax(-1)
+    ids = torch.from_numpy(obj_id[np.arange(obj_id.shape[0]), cam, :])          # [n, planes]
+    valid = ids > 0
+    preds = anno[(ids - 1).clamp(min=0)] * valid.unsqueeze(-1)                  # [n, planes, 9]
+    preds[..., 5] = torch.where(valid, preds[..., 5], torch.full((), float(ids.shape[-1])))
+    preds = preds.reshape(-1, preds.shape[-1])
+    onehot = F.one_hot(preds[:, 5].long(), fsf.num_classes + 1).float()
+    if fsf.encode_label_only:
+        enc = onehot
+    else:
+        bbox = preds[:, :4].clone()
+        bbox[:, 0::2] /= img_hw[1]
+        bbox[:, 1::2] /= img_hw[0]
+        enc = torch.cat([bbox, preds[:, 4:5], onehot], -1)
+    return apply_module(encode_mlp, enc.to(dtype))
+
+
 def fsf_stage1(fsf, points8, mask_data, mask_anno, lidar2img, grad=False, dtype=torch.float32):
     """FSF.simple_test step 1 (FSF.py:1123-1130): segmentor features + image branch + seg head, one sample."""
     points = [points8[:, :-3]]
@@ -217,8 +245,7 @@ def fsf_stage1(fsf, points8, mask_data, mask_anno, lidar2img, grad=False, dtype=
     ex = segmentor_extract_feat(fsf.segmentor, points, grad=grad, dtype=dtype)
     assert bool(ex["mask"].all())
     obj_id, _ = oproj.points_in_mask(infos.numpy(), mask_data.numpy(), lidar2img.numpy())
-    ids, score = oproj.cam_select_score(obj_id, mask_anno.numpy())
-    img_feat = apply_module(fsf.segmentor_updated_mlp, torch.from_numpy(score).to(dtype))
+    img_feat = point_image_feat(fsf, obj_id, mask_anno, fsf.segmentor_updated_mlp, mask_data.shape[-2:], dtype)
     pts_feats = ex["neck"] + img_feat
     head = fsf.segmentor.segmentation_head
     h = apply_module(head.pre_seg_conv, pts_feats)
@@ -423,9 +450,9 @@ def cluster_head_forward(head, feats):
 
 
 def coder_decode(reg_preds, base_points, eps=1e-6):
-    """BasePointBBoxCoder.decode (core/bbox/coders/base_point_bbox_coder.py:59-82), code_size 10; pinned bit-exact by
-    tests/golden/refine_glue.npz."""
-    velo = reg_preds[:, -2:]
+    """BasePointBBoxCoder.decode (core/bbox/coders/base_point_bbox_coder.py:59-82), code_size 10 (nuScenes: velocity rides
+    along) or 8 (Argoverse 2); pinned bit-exact by tests/golden/refine_glue.npz."""
+    velo = reg_preds[:, 8:]
     r = reg_preds[:, :8]
     dims = r[:, 3:6].exp() - eps
     xyz = r[:, :3] + base_points
@@ -453,12 +480,11 @@ def decode_stage_bboxes(obj_centers, bz_coors, reg_preds):
     return torch.cat([bz_coors.unsqueeze(-1).to(obj_centers.dtype), coder_decode(reg_preds[0], obj_centers)], -1)
 
 
-def query_feat_refine(fsf, i_stage, seg_points, seg_feats, obj_id, mask_anno, rois, pool):
+def query_feat_refine(fsf, i_stage, seg_points, seg_feats, obj_id, mask_anno, rois, pool, img_hw=(900, 1600)):
     """FSF.query_feat_refine (FSF.py:1000-1044) on a given pooling result `pool` = (point idx, roi idx, feats [k,13]):
     per-point image feature of the pooled points (img_cross_attn :694-728 with ext_pts_inds), then FullySparseBboxHead."""
     inds, roi_inds, info = pool
-    ids, score = oproj.cam_select_score(obj_id.numpy()[inds.numpy()], mask_anno.numpy())
-    img = apply_module(fsf.refine_img_mlp[i_stage], torch.from_numpy(score))
+    img = point_image_feat(fsf, obj_id.numpy()[inds.numpy()], mask_anno, fsf.refine_img_mlp[i_stage], img_hw)
     feats = torch.cat([seg_feats[inds], img], -1)
     pts_info = dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1], is_in_margin=info[:, -1])
     return refine_head_forward(fsf.refine_sir_layers[i_stage], seg_points[inds], feats, pts_info, roi_inds, rois)[0]
@@ -515,3 +541,37 @@ def get_bboxes_single(cfg, cls_logits, reg_preds, cluster_xyz, delta=1e-4, near_
         if reach.shape[0]:
             margin = float(reach[:, 1].min())
     return rows, scs, labs, boxes, margin
+
+
+# ------------------------------------------------------------------------------ the whole frame, un-restarted
+def simple_test(fsf, points8, mask_data, mask_anno, lidar2img, i_stage=0):
+    """FSF.simple_test (FSF.py:1114-1178) for one sample, every stage fed by the ORACLE's own previous stage (no restart
+    from device intermediates): segmentor + image fusion + segmentation head (:1123-1130), camera queries (:607-650) and
+    LiDAR queries (:569-600) with their heads, combine_frustum_and_fsd (:657-692), one refinement stage (:1046-1083:
+    decode_stage_bboxes, RoI point pooling, refine SIR, query update, refined head) and get_bboxes
+    (frustum_cluster_head.py:587-698).  Returns the final (boxes, scores, labels) and the intermediates an end-to-end
+    agreement test reports on (tests/test_e2e_agreement_gpu.py)."""
+    from . import refine as orefine
+
+    img_hw = tuple(mask_data.shape[-2:])
+    s1 = fsf_stage1(fsf, points8, mask_data, mask_anno, lidar2img)
+    s2 = fsf_stage2(fsf, s1, mask_anno, img_hw)
+    s3 = fsf_stage3(fsf, s1)
+    f_res = cluster_head_forward(fsf.frustum_obj_head, s2["obj_feat"])
+    l_res = cluster_head_forward(fsf.bbox_head, s3["cluster_feats"])
+    centers, coors, result, feats, p2d = combine_frustum_and_fsd(
+        fsf, s2["obj_centers"], s2["obj_coors"], f_res, s2["obj_feat"], s2["preds_2d"],
+        s3["cluster_xyz"], s3["cluster_inds"], l_res, s3["cluster_feats"])
+    rois = decode_stage_bboxes(centers, coors[:, 0], result["reg_preds"])
+    ext = fsf.roi_extractor
+    wp, wr, wf = orefine.dynamic_point_pool(rois[:, 1:8].numpy(), s1["seg_points"][:, :3].numpy(), ext.extra_wlh,
+                                            ext.max_inbox_point, ext.max_all_pts, stop_at_cap=True)
+    pool = (torch.from_numpy(wp), torch.from_numpy(wr), torch.from_numpy(wf))
+    lidar_img = query_feat_refine(fsf, i_stage, s1["seg_points"], s1["seg_feats"], s1["obj_id"], mask_anno, rois, pool,
+                                  img_hw)
+    res, query = refined_query(fsf, i_stage, lidar_img, feats, rois[:, 1:4])
+    cfg = fsf.frustum_refined_head[i_stage].test_cfg
+    rows, scs, labs, boxes, margin = get_bboxes_single(cfg, res["cls_logits"][0], res["reg_preds"][0], rois[:, 1:4])
+    return dict(boxes=boxes[rows], scores=scs, labels=labs, rows=rows, margin=margin, s1=s1, s2=s2, s3=s3,
+                query_coors=coors, query_feats=feats, rois=rois, refined_query=query, cls_logits=res["cls_logits"][0],
+                reg_preds=res["reg_preds"][0], all_boxes=boxes)

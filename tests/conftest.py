@@ -60,9 +60,11 @@ def build_test_fsf():
     return model
 
 
-def build_av2_fsf():
+def build_av2_fsf(perturb_image_branch=False):
     """The Argoverse-2 detector (configs/fsf_av2.py = the model part of the reference's FSF_AV2_config.py) behind
-    tests/golden/av2_segmentor_150k.npz: fixed seed, BN running statistics away from (0, 1)."""
+    tests/golden/av2_segmentor_150k.npz: fixed seed, BN running statistics away from (0, 1).  `perturb_image_branch`
+    un-zeroes the image branch's last Linear (FSF.py:142-143) from its own generator — the segmentor, which the golden's
+    parameter checksum covers, is untouched."""
     import torch
 
     from fullysparsefusion_amd import mmdet3d_plugin
@@ -75,6 +77,10 @@ def build_av2_fsf():
         if isinstance(m, torch.nn.BatchNorm1d):
             m.running_mean.normal_(0, 0.1)
             m.running_var.uniform_(0.5, 1.5)
+    if perturb_image_branch:
+        g = torch.Generator().manual_seed(5)
+        w = model.segmentor_updated_mlp[-1].weight
+        w.data.copy_(torch.randn(w.shape, generator=g) * 0.05)
     return model
 
 

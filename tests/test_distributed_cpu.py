@@ -346,6 +346,112 @@ def test_fused_syncbn_relu_equals_upstream_formulation_world2_gloo():
             assert np.allclose(a, b, rtol=1e-10, atol=1e-12), rank
 
 
+def test_zero_grad_clears_a_gradient_tensor_that_is_not_the_bucket_view():
+    """after `optimizer.zero_grad(set_to_none=True)` and a backward that ran un-armed, `param.grad` is a tensor of
+    autograd's own; `dp.zero_grad()` must drop its values (re-point at the zeroed bucket), while a forward without
+    zero_grad() carries them over."""
+    from fullysparsefusion_amd.data_parallel import FrameDataParallel
+
+    net = torch.nn.Linear(3, 2)
+    dp = FrameDataParallel(net)
+    for p in net.parameters():
+        p.grad = torch.ones_like(p)
+    dp.zero_grad()
+    for p in net.parameters():
+        assert p.grad.data_ptr() == dp._view[p].data_ptr() and float(p.grad.abs().sum()) == 0.0
+    for p in net.parameters():
+        p.grad = torch.full_like(p, 2.0)
+    dp._arm(zero=False)  # what forward() does
+    for p in net.parameters():
+        assert p.grad.data_ptr() == dp._view[p].data_ptr() and bool((p.grad == 2.0).all())
+
+
+# ----------------------------------------------- world size 8 (north_star: the 8 GPUs of one node), gloo on CPU
+def _dp8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullysparsefusion_amd.data_parallel import FrameDataParallel
+        from fullysparsefusion_amd.mmdet3d_plugin.registry import build_norm_layer
+
+        torch.manual_seed(100 + rank)  # different init per rank: the wrapper must broadcast rank 0's
+        bn = build_norm_layer(dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), 16)[1]
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), bn, torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                                  torch.nn.Linear(16, 3))
+        branch = torch.nn.Linear(6, 3)  # only ranks 0, 3, 6 use it: a data-dependent graph (an empty class group elsewhere)
+        model = torch.nn.ModuleDict(dict(net=net, branch=branch)).train()
+        dp = FrameDataParallel(model, bucket_mb=0.001)
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        torch.manual_seed(7)
+        x = torch.randn(world, 5, 6)[rank]
+
+        def loss():
+            y = dp.module["net"](x)  # SyncBN all-reduces on the default group while the buckets reduce on the wrapper's own
+            if rank % 3 == 0:
+                y = y + dp.module["branch"](x)
+            return (y ** 2).sum()
+
+        out = []
+        for it in range(3):
+            if it == 1:
+                opt.zero_grad(set_to_none=True)  # the standard loop's way of clearing
+            else:
+                dp.zero_grad()
+            if it == 2:  # gradient accumulation: a local backward first, the next one reduces the sum
+                with dp.no_sync():
+                    dp.backward(loss())
+            dp.backward(loss())
+            out.append({n: p.grad.numpy().copy() for n, p in model.named_parameters()})
+        q.put((rank, len(dp.buckets), {n: p.detach().numpy().copy() for n, p in model.named_parameters()}, out,
+               bn.running_mean.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@_retry_rendezvous
+def test_frame_data_parallel_and_syncbn_world8_gloo():
+    """VERDICT r3 next-1(d): the gradient all-reduce and the SyncBN collectives at the world size north_star names (8 ranks;
+    world 2 hides ordering bugs: with two ranks every pairwise exchange is the whole collective).  Every rank must end with
+    bit-identical buckets equal to the single-process gradient of the mean loss over the concatenated batch — with a branch
+    only ranks 0 / 3 / 6 take, `optimizer.zero_grad()` in between and one gradient-accumulation step under `no_sync()`."""
+    import numpy as np
+
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][1] >= 3
+    for r in range(1, world):
+        for n in got[0][2]:
+            assert np.array_equal(got[0][2][n], got[r][2][n]), (r, n)  # broadcast at construction
+        assert np.array_equal(got[0][4], got[r][4])                   # running statistics agree
+    # single-process reference: plain BatchNorm over the concatenated rows (equal row counts per rank), mean of the rank losses
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.BatchNorm1d(16, eps=1e-3, momentum=0.01), torch.nn.ReLU(),
+                              torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 3))
+    branch = torch.nn.Linear(6, 3)
+    model = torch.nn.ModuleDict(dict(net=net, branch=branch)).double().train()
+    model.load_state_dict({n: torch.from_numpy(v).double() for n, v in got[0][2].items()}, strict=False)
+    torch.manual_seed(7)
+    x = torch.randn(world, 5, 6).double()
+    y = model["net"](x.reshape(-1, 6)).reshape(world, 5, 3)
+    loss = sum(((y[r] + (model["branch"](x[r]) if r % 3 == 0 else 0)) ** 2).sum() for r in range(world)) / world
+    loss.backward()
+    want = {n: p.grad.numpy() for n, p in model.named_parameters()}
+    for it, factor in enumerate([1.0, 1.0, 2.0]):  # iteration 2 accumulated the same backward twice
+        for n in want:
+            for r in range(world):
+                assert np.array_equal(got[0][3][it][n], got[r][3][it][n]), (it, n, r)
+            assert np.allclose(got[0][3][it][n], factor * want[n], rtol=2e-4, atol=2e-5), (it, n)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without a launcher re-launches itself under torch.distributed.run on 127.0.0.1: here (no HIP
     device) the ranks must come up with RANK / WORLD_SIZE set and stop at the device check — not at an assertion about the

@@ -107,13 +107,16 @@ def test_hot_path_10sweep_vs_oracle(fsf_pair, frame10, device):
     oracle's stage-1 output so that every integer decision (fg thresholds, duplicated points, voxel keys, cluster voxels,
     connected components of 8e4 centres) sees identical inputs and must match bit-exactly."""
     model, cpu = fsf_pair
-    f = frame10
+    _hot_path_vs_oracle(model, cpu, frame10, device, min_clusters=1000, min_lidar_points=200000, min_camera_queries=100)
+
+
+def _hot_path_vs_oracle(model, cpu, f, device, min_clusters, min_lidar_points, min_camera_queries):
     pts8, mask, anno, L = (torch.from_numpy(f[k]) for k in ("points", "mask_data", "mask_anno", "lidar2img"))
     metas = [dict(lidar2img=f["lidar2img"])]
     with torch.no_grad():
         out = model.forward_hot_path([pts8.to(device)], metas, mask.to(device)[None], anno.to(device)[None])
         s1 = omod.fsf_stage1(cpu, pts8, mask, anno, L)
-        s2 = omod.fsf_stage2(cpu, s1, anno, (900, 1600))
+        s2 = omod.fsf_stage2(cpu, s1, anno, tuple(mask.shape[-2:]))
         s3 = omod.fsf_stage3(cpu, s1)
     seg = out["seg"]
     close(seg["seg_feats"], s1["seg_feats"])
@@ -176,7 +179,8 @@ def test_hot_path_10sweep_vs_oracle(fsf_pair, frame10, device):
         _, want_feats, want_coors = omod.sir_forward(cpu.backbone, gp, gfe, gco, gfc)
     np.testing.assert_array_equal(l_inds.cpu().numpy(), want_coors.numpy())
     close(l_feats, want_feats)
-    assert s3["cluster_inds"].shape[0] > 1000 and gp.shape[0] > 200000 and s2["obj_coors"].shape[0] > 100
+    assert s3["cluster_inds"].shape[0] > min_clusters and gp.shape[0] > min_lidar_points
+    assert s2["obj_coors"].shape[0] > min_camera_queries
 
 
 # ------------------------------------------------------- every sparse-conv launch of the 10-sweep U-Net, in situ
@@ -330,11 +334,18 @@ def test_final_boxes_vs_oracle_chain(fsf_pair, which, request, device, monkeypat
     runs the whole forward; the oracle chain restarts from the GPU's query features (the SIR stages upstream are
     ill-conditioned, see test_fsf_hot_path_vs_oracle) and at each discontinuity (RoI membership of a point, an NMS decision)
     takes the GPU's inputs to that decision, so that a difference there is the kernel's, not an upstream rounding."""
-    from oracle import refine as orefine
-
     model, cpu = fsf_pair
     frame = request.getfixturevalue(which)
+    sizes = _final_boxes_vs_oracle_chain(model, cpu, frame, device, monkeypatch)
+    if which == "frame10":  # the sizes the docs quote
+        assert sizes["rois"] > 8000 and sizes["pooled"] == model.roi_extractor.max_all_pts and sizes["queries"] > 8000
+
+
+def _final_boxes_vs_oracle_chain(model, cpu, frame, device, monkeypatch):
+    from oracle import refine as orefine
+
     pts, metas, mask, anno = to_dev(frame, device)
+    img_hw = tuple(mask.shape[-2:])
     cap = {}
 
     def tap(obj, name, key):
@@ -392,7 +403,7 @@ def test_final_boxes_vs_oracle_chain(fsf_pair, which, request, device, monkeypat
         g_info13 = torch.cat([c(xyz_in)[c(g_inds)], c(g_info["local_xyz"]), c(g_info["boundary_offset"]),
                               c(g_info["is_in_margin"])[:, None]], 1)
         lidar_img = omod.query_feat_refine(cpu, 0, seg["seg_points"], seg["seg_feats"], obj_id, c(anno[0]),
-                                           torch.from_numpy(rois_g), (c(g_inds), c(g_roi_inds), g_info13))
+                                           torch.from_numpy(rois_g), (c(g_inds), c(g_roi_inds), g_info13), img_hw)
         o_res, o_query = omod.refined_query(cpu, 0, lidar_img, c(g_feats), torch.from_numpy(rois_g[:, 1:4]))
         (q_in,), _, g_res = cap["head"]
         close(q_in, o_query)
@@ -415,8 +426,7 @@ def test_final_boxes_vs_oracle_chain(fsf_pair, which, request, device, monkeypat
         d = np.abs(c(gb.tensor).numpy()[:, None, :7] - dec[None, :, :7]).max(-1)
         assert float(d.min(1).max()) < 1e-5
     assert rows.numel() > 0 and len(g_inds) > 100
-    if which == "frame10":  # the sizes the docs quote
-        assert rois_g.shape[0] > 8000 and len(g_inds) == ext.max_all_pts and b_cls[0].shape[0] > 8000
+    return dict(rois=rois_g.shape[0], pooled=len(g_inds), queries=b_cls[0].shape[0], classes=b_cls[0].shape[1], margin=margin)
 
 
 # ------------------------------------------------------------------ Argoverse-2 segmentor at 150 k points (config 5)
@@ -459,6 +469,39 @@ def test_av2_segmentor_at_150k_points_vs_oracle(device):
     assert int(inv.long().sum()) == int(g["inv_sum"])
     for name, t, rows in [("voxel_feats", vf, vrow), ("unet", unet, vrow), ("neck", neck, prow)]:
         close(t[rows], torch.from_numpy(g[name + "_rows"]), 1e-4, scale=float(g[name + "_scale"]))
+
+
+@pytest.fixture(scope="module")
+def av2_pair(device):
+    model = build_av2_fsf(perturb_image_branch=True)
+    cpu = copy.deepcopy(model)
+    return model.to(device), cpu
+
+
+@pytest.fixture(scope="module")
+def frame_av2():
+    from fullysparsefusion_amd import synthetic
+
+    return synthetic.make_frame_av2(seed=0)
+
+
+def test_av2_query_stages_at_150k_points_vs_oracle(av2_pair, frame_av2, device):
+    """BASELINE config 5 beyond the segmentor (VERDICT r3 "missing" 3): the `is_argo` image branch (one i32 id plane per
+    camera, box + score + one-hot encoding, FSF.py:459-470), camera queries (`frustum_forward`) and LiDAR queries
+    (`fsd_forward`: 26 classes in six groups) of configs/fsf_av2.py on the 150 k-point +-200 m frame `bench.py --dataset av2`
+    times, against the oracle exactly as the 10-sweep nuScenes frame is (`_hot_path_vs_oracle`)."""
+    model, cpu = av2_pair
+    assert frame_av2["points"].shape[0] >= 149000 and frame_av2["mask_data"].shape == (7, 1, 1550, 2048)
+    _hot_path_vs_oracle(model, cpu, frame_av2, device, min_clusters=1000, min_lidar_points=20000, min_camera_queries=100)
+
+
+def test_av2_final_boxes_at_150k_points_vs_oracle_chain(av2_pair, frame_av2, device, monkeypatch):
+    """... and the rest of `FSF.simple_test` at that size: heads, combine, decode of the stage boxes (8-d code), RoI pooling,
+    the refine SIR with the `is_argo` per-point image feature, query update, refined head and the 26-class box tail (K24:
+    26 x 500 = 13 000 candidate slots of `fsf_nms_select`'s 16 384) against the oracle chain."""
+    model, cpu = av2_pair
+    sizes = _final_boxes_vs_oracle_chain(model, cpu, frame_av2, device, monkeypatch)
+    assert sizes["classes"] == 26 and sizes["queries"] > 2000 and sizes["pooled"] > 10000, sizes
 
 
 # ------------------------------------------------------------- neighbour-mask row order inside the U-Net

@@ -93,6 +93,45 @@ def test_voxelization_module(plugin, device):
         hard(torch.from_numpy(pts).to(device))
 
 
+def test_voxel_downsample_vs_the_reference_expression(fsf_pair, device):
+    """VoteSegmentor.voxel_downsample (single_stage_fsd.py:263-273): per sample `torch.div(points[:, :3] - range[:3], size,
+    rounding_mode='floor').long()` keys (x, y, z order), then `scatter_v2(points, coors, 'avg', return_inv=False)` = rows in
+    torch.unique's lexicographic key order, every column averaged.  The reference expression is evaluated here by CPU torch
+    (keys bit-exact incl. points ON cell boundaries +-1 ulp, means 1e-5); FSF.forward_hot_path calls it when
+    `voxel_downsampling_size` is set (FSF.py:1120-1121)."""
+    model, _ = fsf_pair
+    seg = model.segmentor
+    rng = np.random.default_rng(21)
+    size = (0.5, 0.25, 1.0)
+    lo = np.array(seg.point_cloud_range[:3], dtype=np.float32)
+    pts_list = []
+    for n in (40000, 1, 777):
+        xyz = rng.uniform([-50, -50, -4.9], [50, 50, 2.9], (n, 3)).astype(np.float32)
+        k = min(n, 2000)  # a block of points exactly on cell boundaries and one ulp either side
+        cell = rng.integers(1, 150, (k, 3)).astype(np.float32)
+        edge = (lo[None] + cell * np.array(size, dtype=np.float32)[None]).astype(np.float32)
+        edge = np.nextafter(edge, np.where(rng.random((k, 3)) < 0.5, -np.inf, np.inf).astype(np.float32)) if n > 1 else edge
+        xyz[:k] = np.where(rng.random((k, 3)) < 0.7, edge, xyz[:k])
+        pts_list.append(np.concatenate([xyz, rng.random((n, 5)).astype(np.float32)], 1))
+    old = seg.voxel_downsampling_size
+    seg.voxel_downsampling_size = size
+    try:
+        with torch.no_grad():
+            got = seg.voxel_downsample([torch.from_numpy(p).to(device) for p in pts_list])
+    finally:
+        seg.voxel_downsampling_size = old
+    assert len(got) == len(pts_list)
+    for p, g in zip(pts_list, got):
+        pt = torch.from_numpy(p)
+        coors = torch.div(pt[:, :3] - torch.tensor(seg.point_cloud_range)[None, :3], torch.tensor(size)[None, :],
+                          rounding_mode="floor").long()
+        new_coors, inv = torch.unique(coors, return_inverse=True, dim=0)
+        want = torch.zeros((new_coors.shape[0], pt.shape[1]), dtype=torch.float64).index_add_(0, inv, pt.double())
+        want = want / torch.bincount(inv, minlength=new_coors.shape[0]).double()[:, None]
+        assert g.shape == want.shape, (g.shape, want.shape)   # same number of cells <=> identical keys (the rows are in key order)
+        np.testing.assert_allclose(g.cpu().double().numpy(), want.numpy(), rtol=0, atol=1e-5 * 51.2)
+
+
 def test_get_inner_win_inds_contract(plugin, device):
     g = torch.randint(0, 50, (5000,), device=device)
     r = plugin.ops.get_inner_win_inds(g).cpu()
