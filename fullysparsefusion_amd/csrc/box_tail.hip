@@ -203,6 +203,7 @@ extern "C" int fsf_class_rank_desc(const float* scores_t, int64_t n, int32_t num
 }
 
 extern "C" int64_t fsf_nms_select_capacity(void) { return BT_SEL_CAP; }
+extern "C" int32_t fsf_box_tail_max_classes(void) { return BT_MAX_CLASSES; }
 
 extern "C" int fsf_nms_select(const float* boxes, int32_t box_dim, const float* scores_t, const int32_t* order, const int64_t* keep,
                               int64_t keep_stride, const int64_t* num_keep, int64_t n, int32_t num_classes, int64_t max_keep,

@@ -51,7 +51,6 @@ struct LnaArgs {
   // output channels per blockIdx.y slice (128 unless "sliced": independent layers side by side, one per slice), the width a
   // LayerNorm spans (c, or the slice width), and the column offset between the inputs of consecutive slices
   int slice_w, norm_w; int64_t x_slice_off;
-  const float* w_hdr;  // K22b: the prepared weight's header ([0] = inverse layer scale); unused by the bf16 kernel
 };
 
 __device__ __forceinline__ float lna_row_sum(float v) {
@@ -357,238 +356,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_ac
   }
 }
 
-
-// =====================================================================================================================
-// K22b (round 3): the same fused layer from f16 planes — 3 MFMAs per fp32-equivalent product instead of 6 — with the x rows
-// taken in by LINE-COALESCED loads.
-//
-// What the ablations of the kernel above say (profiles/r3_k22_ablations.txt, 510 k x 256 -> 128, 268 us): with every x load
-// hitting cache-resident rows, no weight DMA, no stores and no MFMAs 139 us remain — and 82 us of vector-memory issue time is
-// exactly what its x loads cost: lane (row, g) reads 32 contiguous bytes of ITS row, so consecutive lanes sit on different rows
-// and an instruction's 64 lanes are 64 separate 16-byte requests (10.4 B/clk per CU whatever the cache says,
-// tools/profiling/gather_pattern_probe.hip); eight consecutive lanes on one 128-byte line move 24 B/clk.  The MFMAs are
-// another 60 us on top (not hidden), the HBM stream itself only 36.
-// Here:  * a wave loads the 32-column chunk of its 32 rows as four row-major instructions (lane l: quad l % 8 of row l / 8 [+ 8 h]),
-//          the eight lanes of a row agree on the chunk's power-of-two scale (absmax into [2^13, 2^14), as the K9 planes), split
-//          their four values into f16 hi + lo ONCE and park them in a wave-private 4 KB LDS tile, swizzled like K9d's so that
-//          the operand reads (lane (row j, g): 8 k values hi, 8 lo) are conflict-free — no barrier is involved, the tile
-//          belongs to the wave;
-//        * the weights are two f16 planes with one power-of-two scale per layer (16 KB per chunk instead of 24 KB of bf16
-//          hi | mid | lo), k groups permuted by sp-style sigma to match the tile; x w = hi hi + hi lo + lo hi;
-//        * a (row, chunk) has its own scale, so the accumulators are kept in the unit of the chunk being multiplied: before a
-//          chunk's first MFMA they are multiplied by (old unit / new unit) — exact, powers of two — and the MFMAs accumulate
-//          into them; the epilogue multiplies the last unit (and the weight's) back out.  Error: 2^-22 relative per product
-//          term at the chunk's scale — the tests hold it to the fp32 GEMM's own error against float64.
-constexpr int LNB_XT_U4 = 32 * 8;  // uint4 per wave-private x tile: 32 rows x 8 pieces of 16 B
-
-__device__ __forceinline__ int lnb_kgroup(int q) { return (0x9C >> (2 * q)) & 3; }  // sigma = (0, 3, 1, 2), see spconv_planes.hip
-
-__device__ __forceinline__ void lnb_pick_scale(float amax, float& s, float& inv) {
-  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
-  e = amax > 0.0f ? (e < -113 ? -113 : e) : 13;
-  s = __uint_as_float((unsigned)(13 - e + 127) << 23);
-  inv = __uint_as_float((unsigned)(e - 13 + 127) << 23);
-}
-
-typedef _Float16 lnb_f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 lnb_f16x4 __attribute__((ext_vector_type(4)));
-
-__global__ void __launch_bounds__(256) lnb_weight_absmax_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ hdr) {
-  __shared__ float wave_max[4];
-  float amax = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) amax = fmaxf(amax, fabsf(w[i]));
-  amax = fsf_wave_max(amax);
-  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = amax;
-  __syncthreads();
-  if (threadIdx.x == 0) atomicMax(hdr + 2, __float_as_uint(fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]))));
-}
-
-// weight [c, k] fp32 -> header (256 B: [0] inverse scale, [1] scale, [2] max |w| bits) + fragment-ordered f16 planes
-// [slice][chunk][tile][hi | lo][64 lanes] x 16 B; lane (col, q) holds the 8 k values of k group sigma(q) of its column
-__global__ void __launch_bounds__(256)
-    lnb_prepare_kernel(const float* __restrict__ w, int k, int c, int T, int nkc, int nslice, int slice_w, float* hdr, uint4* planes) {
-  float sc, inv;
-  lnb_pick_scale(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[2]), sc, inv);
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    hdr[0] = inv;
-    hdr[1] = sc;
-  }
-  const int64_t total = (int64_t)nslice * nkc * T * 64;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int lane = (int)(idx & 63);
-    const int t = (int)((idx >> 6) % T);
-    const int kc = (int)(((idx >> 6) / T) % nkc);
-    const int slice = (int)((idx >> 6) / ((int64_t)T * nkc));
-    const int lc = 16 * t + (lane & 15), col = slice_w * slice + lc, k0 = kc * LNA_KC + 8 * lnb_kgroup(lane >> 4);
-    lnb_f16x8 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float v = (lc < slice_w && col < c && k0 + e < k) ? w[(int64_t)col * k + k0 + e] : 0.0f;
-      const float xs = __fmul_rn(v, sc);
-      hi[e] = (_Float16)xs;
-      lo[e] = (_Float16)__fsub_rn(xs, (float)hi[e]);
-    }
-    uint4* dst = planes + (((int64_t)slice * nkc + kc) * T + t) * 2 * 64 + lane;
-    dst[0] = __builtin_bit_cast(uint4, hi);
-    dst[64] = __builtin_bit_cast(uint4, lo);
-  }
-}
-
-template <int T>  // 16-channel tiles (c <= 16 T)
-__global__ void __launch_bounds__(LNA_NW * 64, LNA_WPS) linear_norm_act_f16_kernel(LnaArgs a) {
-  constexpr int CHUNK_U4 = T * 2 * 64;  // uint4 per weight chunk
-  extern __shared__ __attribute__((aligned(16))) char lna_smem[];
-  uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);                       // [2][CHUNK_U4]
-  uint4* xtile = wbuf + 2 * CHUNK_U4;                                      // [LNA_NW][LNB_XT_U4]
-  float* xscale = reinterpret_cast<float*>(xtile + LNA_NW * LNB_XT_U4);    // [LNA_NW][32]
-  float* vec = xscale + LNA_NW * 32;                                       // 384 floats of per-channel vectors
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rowl = lane & 15, grp = lane >> 4;
-  const int nkc = (a.k + LNA_KC - 1) / LNA_KC;
-  const int64_t nblk = (a.n + LNA_ROWS - 1) / LNA_ROWS;
-  const int ch_base = a.slice_w * (int)blockIdx.y;
-  const uint4* planes = a.planes + (int64_t)blockIdx.y * nkc * CHUNK_U4;
-  const float w_inv = a.w_hdr[0];
-  uint4* my_tile = xtile + wave * LNB_XT_U4;
-  float* my_scale = xscale + wave * 32;
-
-  auto stage_w = [&](int kc, int buf) {
-    const float* src = reinterpret_cast<const float*>(planes + (int64_t)kc * CHUNK_U4);
-    float* dst = reinterpret_cast<float*>(wbuf + buf * CHUNK_U4);
-    for (int u = wave * 64; u < CHUNK_U4; u += LNA_NW * 64)
-      __builtin_amdgcn_global_load_lds(src + 4 * (u + lane), dst + 4 * u, 16, 0, 0);
-  };
-
-  // ---- x: line-coalesced loads.  Load h (0..3) of a chunk: lane l takes quad u = l % 8 (4 floats) of row 8 h + l / 8 of the wave's 32 rows
-  const int lrow = lane >> 3, lquad = lane & 7;
-  const float* xrow[4];
-  auto set_rows = [&](int64_t blk) {
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      int64_t r = blk * LNA_ROWS + (int64_t)wave * 32 + 8 * h + lrow;
-      if (r >= a.n) r = a.n - 1;  // rows past n repeat the last one (finite, never stored)
-      xrow[h] = a.x + r * a.x_stride + (int64_t)blockIdx.y * a.x_slice_off;
-    }
-  };
-  const int last_quad = (int)a.x_stride - 4 - (int)((int64_t)blockIdx.y * a.x_slice_off);
-  auto load_x = [&](int kc, float4 (&v)[4]) {
-    const int kq = kc * LNA_KC + 4 * lquad;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) v[h] = *reinterpret_cast<const float4*>(xrow[h] + min(kq, last_quad));
-  };
-  // split a loaded chunk into the wave's tile: piece 2 g (hi) / 2 g + 1 (lo) of k group g = u / 2, this lane's half u % 2 of it
-  auto park_x = [&](int kc, float4 (&v)[4]) {
-    const int kq = kc * LNA_KC + 4 * lquad;
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      float e[4] = {v[h].x, v[h].y, v[h].z, v[h].w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (kq + i >= a.k) e[i] = 0.0f;  // (columns >= k: what follows the row in memory may be NaN)
-      float amax = fmaxf(fmaxf(fabsf(e[0]), fabsf(e[1])), fmaxf(fabsf(e[2]), fabsf(e[3])));
-      amax = fmaxf(amax, __shfl_xor(amax, 1));
-      amax = fmaxf(amax, __shfl_xor(amax, 2));
-      amax = fmaxf(amax, __shfl_xor(amax, 4));
-      float sc, inv;
-      lnb_pick_scale(amax, sc, inv);
-      lnb_f16x4 hi, lo;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float xs = __fmul_rn(e[i], sc);
-        hi[i] = (_Float16)xs;
-        lo[i] = (_Float16)__fsub_rn(xs, (float)hi[i]);
-      }
-      const int r = 8 * h + lrow, sw = (r >> 1) & 7, g2 = 2 * (lquad >> 1);
-      char* base = reinterpret_cast<char*>(my_tile + r * 8) + (lquad & 1) * 8;
-      *reinterpret_cast<uint2*>(base + ((g2 ^ sw) << 4)) = __builtin_bit_cast(uint2, hi);
-      *reinterpret_cast<uint2*>(base + (((g2 + 1) ^ sw) << 4)) = __builtin_bit_cast(uint2, lo);
-      if (lquad == 0) my_scale[r] = inv;
-    }
-  };
-  const int rd_sw = (rowl >> 1) & 7;
-  const int rd_hi = rowl * 8 + ((2 * lnb_kgroup(grp)) ^ rd_sw), rd_lo = rowl * 8 + ((2 * lnb_kgroup(grp) + 1) ^ rd_sw);
-
-  lna_stage_vectors(a, ch_base, vec);
-  float4 xc[4];
-  int buf = 0;
-  if ((int64_t)blockIdx.x < nblk) {
-    set_rows(blockIdx.x);
-    load_x(0, xc);
-    stage_w(0, 0);
-  }
-  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    const int64_t row0 = blk * LNA_ROWS + (int64_t)wave * (LNA_RG * 16);
-    lna_f32x4 acc[LNA_RG][T];
-    float cinv[LNA_RG];
-#pragma unroll
-    for (int rg = 0; rg < LNA_RG; ++rg) {
-      cinv[rg] = 1.0f;
-#pragma unroll
-      for (int t = 0; t < T; ++t) acc[rg][t] = lna_f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    for (int kc = 0; kc < nkc; ++kc, buf ^= 1) {
-      // the chunk that arrived while the previous one was multiplied goes into the wave's tile (its previous contents were read into
-      // registers before that chunk's MFMAs: the LDS queue of a wave is in order)
-      park_x(kc, xc);
-      // this chunk's weights (DMA issued one iteration ago) have landed; the raw barrier carries no fence
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // + every wave is done reading buffer buf^1
-      asm volatile("" ::: "memory");
-      if (kc + 1 < nkc) {
-        stage_w(kc + 1, buf ^ 1);
-        load_x(kc + 1, xc);
-      } else if (blk + gridDim.x < nblk) {  // first chunk of the next row block
-        stage_w(0, buf ^ 1);
-        set_rows(blk + gridDim.x);
-        load_x(0, xc);
-      }
-      // operand fragments of this chunk and the unit change of the accumulators
-      lnb_f16x8 xh[LNA_RG], xl[LNA_RG];
-#pragma unroll
-      for (int rg = 0; rg < LNA_RG; ++rg) {
-        xh[rg] = __builtin_bit_cast(lnb_f16x8, my_tile[16 * rg * 8 + rd_hi]);
-        xl[rg] = __builtin_bit_cast(lnb_f16x8, my_tile[16 * rg * 8 + rd_lo]);
-        const float v = my_scale[16 * rg + rowl];
-        const float f = __fmul_rn(cinv[rg], __uint_as_float(0x7F000000u - __float_as_uint(v)));  // old unit / new unit (exact)
-        cinv[rg] = v;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[rg][t][r] = __fmul_rn(acc[rg][t][r], f);
-      }
-      const uint4* wc = wbuf + buf * CHUNK_U4;
-#pragma unroll
-      for (int t = 0; t < T; t += 2) {
-        lnb_f16x8 wfr[2][2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const uint4* wf = wc + ((t + tt) * 2) * 64 + lane;
-          wfr[tt][0] = __builtin_bit_cast(lnb_f16x8, wf[0]);
-          wfr[tt][1] = __builtin_bit_cast(lnb_f16x8, wf[64]);
-        }
-        // small terms first; two channel tiles x LNA_RG row groups: consecutive MFMAs never hit the same accumulator
-#pragma unroll
-        for (int term = 0; term < 3; ++term)
-#pragma unroll
-          for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int rg = 0; rg < LNA_RG; ++rg)
-              acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfr[tt][term == 0 ? 1 : 0], term == 1 ? xl[rg] : xh[rg],
-                                                                       acc[rg][t + tt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int rg = 0; rg < LNA_RG; ++rg) {  // back into true units
-      const float sc = __fmul_rn(cinv[rg], w_inv);
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[rg][t][r] = __fmul_rn(acc[rg][t][r], sc);
-    }
-    lna_epilogue<T>(a, acc, row0, ch_base, rowl, grp, vec);
-  }
-}
-
 }  // namespace fsf
 
 using namespace fsf;
@@ -601,33 +368,9 @@ static int lna_tiles(int c) {
 
 static int lna_slices(int c) { return (c + 127) / 128; }
 
-// K22b (f16 planes, coalesced x) only with FSF_K22_F16=1 (A/B, latched at the first call: the prepared weight's format follows it).
-// Measured round 3 (same box, tools/profiling/lna_bench.py, profiles/r3_pmc_k22_vs_k22b.txt): 278 vs 281 us on 510 k x 256 -> 128 and
-// within +-4 % on every other shape — half the MFMAs and line-coalesced x loads buy nothing, because neither was what the kernel
-// waits for: both variants issue ~70 M VALU instructions per launch (the split / the park + unit change: ~0.5 per input element),
-// keep the SIMDs' VALU busy half the time and their waves parked on the per-chunk waitcnt + barrier 41-44 % of theirs.
-static bool lnb_on() {
-  static const bool on = getenv("FSF_K22_F16") && atoi(getenv("FSF_K22_F16")) != 0;
-  return on;
-}
-constexpr int64_t LNB_HDR_BYTES = 256;
-
-static int lnb_prepare(const float* weight, int k, int c, int T, int nkc, int nslice, int slice_w, void* planes, hipStream_t stream) {
-  FSF_HIP_TRY(hipMemsetAsync(planes, 0, LNB_HDR_BYTES, stream));
-  const int64_t n = (int64_t)c * k;
-  hipLaunchKernelGGL(lnb_weight_absmax_kernel, dim3((unsigned)std::min<int64_t>(256, (n + 1023) / 1024)), dim3(256), 0, stream, weight, n,
-                     (unsigned*)planes);
-  const int64_t total = (int64_t)nslice * nkc * T * 64;
-  hipLaunchKernelGGL(lnb_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, k, c, T, nkc, nslice, slice_w,
-                     (float*)planes, (uint4*)((char*)planes + LNB_HDR_BYTES));
-  FSF_LAUNCH_CHECK();
-  return FSF_OK;
-}
-
 extern "C" int64_t fsf_linear_prepared_weight_bytes(int32_t k, int32_t c) {
   if (k < 1 || c < 1) return 0;
   const int64_t nkc = (k + LNA_KC - 1) / LNA_KC;
-  if (lnb_on()) return LNB_HDR_BYTES + lna_slices(c) * nkc * lna_tiles(c) * 2 * 64 * 16;
   return lna_slices(c) * nkc * lna_tiles(c) * 3 * 64 * 16;
 }
 
@@ -635,7 +378,6 @@ extern "C" int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t
   hipStream_t stream = (hipStream_t)stream_;
   if (!weight || !planes || k < 1 || c < 1) return FSF_ERR_INVALID_ARG;
   const int T = lna_tiles(c), nkc = (k + LNA_KC - 1) / LNA_KC, nslice = lna_slices(c);
-  if (lnb_on()) return lnb_prepare(weight, (int)k, (int)c, T, nkc, nslice, 128, planes, stream);
   const int64_t total = (int64_t)nslice * nkc * T * 64;
   hipLaunchKernelGGL(lna_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k, (int)c, T, nkc,
                      nslice, 128, (uint4*)planes);
@@ -648,7 +390,6 @@ extern "C" int fsf_linear_prepare_weight(const float* weight, int32_t k, int32_t
 extern "C" int64_t fsf_linear_prepared_weight_sliced_bytes(int32_t k, int32_t nslice, int32_t slice_c) {
   if (k < 1 || nslice < 1 || slice_c < 1 || slice_c > 128) return 0;
   const int64_t nkc = (k + LNA_KC - 1) / LNA_KC;
-  if (lnb_on()) return LNB_HDR_BYTES + (int64_t)nslice * nkc * lna_tiles(slice_c) * 2 * 64 * 16;
   return (int64_t)nslice * nkc * lna_tiles(slice_c) * 3 * 64 * 16;
 }
 
@@ -657,7 +398,6 @@ extern "C" int fsf_linear_prepare_weight_sliced(const float* weight, int32_t k, 
   hipStream_t stream = (hipStream_t)stream_;
   if (!weight || !planes || k < 1 || nslice < 1 || slice_c < 1 || slice_c > 128) return FSF_ERR_INVALID_ARG;
   const int T = lna_tiles(slice_c), nkc = (k + LNA_KC - 1) / LNA_KC;
-  if (lnb_on()) return lnb_prepare(weight, (int)k, (int)(nslice * slice_c), T, nkc, (int)nslice, (int)slice_c, planes, stream);
   const int64_t total = (int64_t)nslice * nkc * T * 64;
   hipLaunchKernelGGL(lna_prepare_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k,
                      (int)(nslice * slice_c), T, nkc, (int)nslice, (int)slice_c, (uint4*)planes);
@@ -667,35 +407,10 @@ extern "C" int fsf_linear_prepare_weight_sliced(const float* weight, int32_t k, 
 
 static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream) {
   LnaArgs a = a_in;
-  if (lnb_on()) {  // K22b: header in front of the fragment planes
-    a.w_hdr = reinterpret_cast<const float*>(a_in.planes);
-    a.planes = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(a_in.planes) + LNB_HDR_BYTES);
-    const int T = lna_tiles(a.slice_w < a.c ? a.slice_w : a.c);
-    const int64_t nblk = (a.n + LNA_ROWS - 1) / LNA_ROWS;
-    int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;
-    if (gx > nblk) gx = nblk;
-    const dim3 grid((unsigned)gx, (unsigned)nslice);
-#define FSF_LNB(T_)                                                                                                         \
-    do {                                                                                                                   \
-      constexpr size_t smem = (size_t)2 * T_ * 2 * 64 * 16 + (size_t)LNA_NW * LNB_XT_U4 * 16 + LNA_NW * 32 * 4 + 384 * 4;   \
-      static std::atomic<uint64_t> attr_done{0};                                                                           \
-      FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_f16_kernel<T_>, (int)smem, attr_done));             \
-      hipLaunchKernelGGL((linear_norm_act_f16_kernel<T_>), grid, dim3(LNA_NW * 64), smem, stream, a);                      \
-    } while (0)
-    if (T == 2) FSF_LNB(2);
-    else if (T == 4) FSF_LNB(4);
-    else FSF_LNB(8);
-#undef FSF_LNB
-    FSF_LAUNCH_CHECK();
-    return FSF_OK;
-  }
-  // FSF_K22_WIDE_MIN_ROWS (A/B, latched): from how many rows the 12-wave workgroups run; 0 = never (the default)
-  static const int64_t wide_min_rows = getenv("FSF_K22_WIDE_MIN_ROWS") ? atoll(getenv("FSF_K22_WIDE_MIN_ROWS")) : 0;
   const int T = lna_tiles(a.slice_w < a.c ? a.slice_w : a.c);
-  const bool wide = T == 8 && wide_min_rows > 0 && a.n * nslice >= wide_min_rows;
-  const int rows = (wide ? 12 : LNA_NW) * LNA_RG * 16;
+  const int rows = LNA_NW * LNA_RG * 16;
   const int64_t nblk = (a.n + rows - 1) / rows;
-  int64_t gx = ((wide ? 256 : 256 * LNA_WPS) + nslice - 1) / nslice;  // 12 waves per CU in total either way
+  int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;
   if (gx > nblk) gx = nblk;
   const dim3 grid((unsigned)gx, (unsigned)nslice);
 #define FSF_LNA(T_, NW_)                                                                                                \
@@ -705,8 +420,7 @@ static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream) {
     FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_, NW_>, (int)smem, attr_done));          \
     hipLaunchKernelGGL((linear_norm_act_kernel<T_, NW_>), grid, dim3(NW_ * 64), smem, stream, a);                      \
   } while (0)
-  if (wide) FSF_LNA(8, 12);
-  else if (T == 2) FSF_LNA(2, 4);
+  if (T == 2) FSF_LNA(2, 4);
   else if (T == 4) FSF_LNA(4, 4);
   else FSF_LNA(8, 4);
 #undef FSF_LNA

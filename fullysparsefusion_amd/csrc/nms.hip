@@ -596,8 +596,12 @@ extern "C" int fsf_nms_bev_multiclass_capped(const float* boxes, int64_t n, int3
   const int64_t clear_bytes = std::min<int64_t>(arena.used + nms_bins_bytes(n), workspace_bytes);
   FSF_HIP_TRY(hipMemsetAsync(mask0, 0, (size_t)clear_bytes, stream));
   NmsArgs a0{boxes, n, thresh, (int)rotated, mask0, rowsum0, (int)words, (int)sum_words, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, nullptr};
+  const int64_t used_before = arena.used;
   const int rc = nms_launch_mask(a0, arena, stream, true);
   if (rc != FSF_OK) return rc;
+  // the single clear above covers what nms_launch_mask took only if it took it right behind the four arrays and no more
+  // than nms_bins_bytes(n): a layout change there must fail here, not read uncleared counters
+  if (arena.used - used_before > nms_bins_bytes(n) || arena.used > clear_bytes) return FSF_ERR_WORKSPACE;
   NmsBuildArgs b{mask0, rowsum0, rank, mask, rowsum, n, (int)words, (int)sum_words, rows, (int)cwords, (int)csum};
   hipLaunchKernelGGL(nms_build_kernel, dim3((unsigned)fsf_stream_grid(n * sum_words, 256), (unsigned)num_classes), dim3(256), 0,
                      stream, b);

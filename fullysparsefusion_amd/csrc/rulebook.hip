@@ -433,12 +433,14 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
   hipLaunchKernelGGL(rb_insert_inputs_kernel, dim3(fsf_stream_grid(m, 256)), dim3(256), 0, stream, indices, m, g, in_keys,
                      in_vals, (uint64_t)(in_cap - 1));
   static const bool propose_by_pair = getenv("FSF_RB_PROPOSE_PAIRS") != nullptr;  // (A/B switch, latched: the round-1 kernel)
-  if (propose_by_pair || per_in > 32 || (m + 255) / 256 > 0x7FFFFFFF)
+  // (the per-workgroup list of the rows kernel is 256 * per_in * 8 bytes of dynamic LDS + 8 static: 64 KB without an attribute)
+  if (propose_by_pair || 256 * per_in * 8 + 8 > 64 * 1024 || (m + 255) / 256 > 0x7FFFFFFF)
     hipLaunchKernelGGL(rb_propose_kernel, dim3(fsf_stream_grid(cand, 256)), dim3(256), 0, stream, indices, m, g, set_keys,
                        (uint64_t)(set_cap - 1), list_a, count_dev);
   else
     hipLaunchKernelGGL(rb_propose_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), (size_t)256 * per_in * 8, stream, indices, m,
                        g, set_keys, (uint64_t)(set_cap - 1), list_a, count_dev);
+  FSF_LAUNCH_CHECK();
   uint32_t count_h = 0;
   FSF_HIP_TRY(hipMemcpyAsync(&count_h, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   FSF_HIP_TRY(hipStreamSynchronize(stream));

@@ -959,606 +959,6 @@ __global__ void __launch_bounds__(256, SP_PIPE_WPS) spconv_fwd_pipe_kernel(SpArg
 }
 
 
-// =====================================================================================================================
-// K9e: K9d's pipeline on 128-row blocks, accumulating straight into the output tile.
-//
-// What bounds K9c / K9d (profiles/r3_vmem_return_probe.txt, r3_spconv_k9d_ablations.txt): a CU takes in vector-memory data at
-// ~25 B/clk however the request looks and wherever it hits (1 KB contiguous per instruction, L1-resident or not: 24-25 B/clk/CU;
-// K9c's row-per-lane gather 10.4) — a tenth of what LDS delivers.  A 64-row block pays 16 KB of weight fragments per chunk next to
-// 8 KB of gathered rows, and three such workgroups per CU fetch the SAME fragments three times: 4 GB through the vector memory path
-// for the 101 k-row 128 -> 128 layer = the kernel's duration at that rate.  The lever is bytes taken in per row: here a workgroup
-// owns 128 rows (eight 16-row cells) x 128 output channels, a wave all eight cells of its 32 channels, so a chunk's 16 KB of
-// fragments serve twice the rows (375 -> 250 bytes per row and chunk).
-// The 16 accumulator tiles of a wave leave no room for K9d's per-step product registers D, and they are not needed: the row
-// scales are powers of two, so a lane keeps each cell's accumulators in the unit of the row it is currently multiplying —
-// before a step's first MFMA the cell's accumulators are multiplied by (old unit / new unit), exactly, and the MFMAs accumulate
-// into them directly; the epilogue multiplies the last unit back out.  (Exact as long as no intermediate leaves the fp32
-// range: the rows of one 27-neighbourhood may differ by up to ~2^80 in magnitude.)
-// Ring: three chunk slots of 16 KB (slot index carried at run time), two workgroups per CU.
-// Round 3, second form (K9g = RG 6): 96-row blocks.  Eight cells do not fit three waves per SIMD (K9e: 216 registers, and measured
-// 12-30 % slower at two); SIX do if a wave keeps the X fragments of only half its cells at a time: per iteration it multiplies cells
-// 0..RG/2-1, refilling each cell's fragment registers with cell + RG/2 of the SAME chunk behind its MFMAs, then multiplies those,
-// refilling with the first half of the next chunk.  16 KB of weight fragments + 12 KB of rows per 96 rows and chunk (K9d: 16 + 8 per
-// 64), 36 MFMAs per wave between two barriers instead of 24, a 3 x 12 KB ring + the 10 KB table = 51 KB: three workgroups per CU.
-// A wave gathers 4 RG rows (24: one and a half cells), eight rows per instruction.
-template <int TPW, int RG>
-struct SpWideSmem {
-  static constexpr int R = 16 * RG;
-  static constexpr size_t nbr_bytes = (size_t)R * SP_KVOL_MAX * 4;
-  static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
-  static constexpr size_t xring_bytes = (size_t)3 * RG * 2048;  // [slot][cell][row][piece ^ swizzle(row)] x 16 B
-  static constexpr size_t sring_off = xring_off + xring_bytes;
-  static constexpr size_t sring_bytes = (size_t)2 * R * 4;  // [step parity][row of the block]
-  static constexpr size_t meta_off = sring_off + sring_bytes;
-  static constexpr size_t meta_bytes = 32 * 4 + 16 + (size_t)SP_KVOL_MAX * RG;
-  static constexpr size_t vec_off = (meta_off + meta_bytes + 15) / 16 * 16;
-  static constexpr size_t vec_bytes = (size_t)2 * 64 * TPW * 4;
-  static constexpr size_t rowmax_off = vec_off + vec_bytes;
-  static constexpr size_t rowmax_bytes = (size_t)4 * R * 4;
-  static constexpr size_t bytes = rowmax_off + rowmax_bytes;
-};
-
-template <int TPW, int NKC, int RG>
-__global__ void __launch_bounds__(256, RG == 8 ? 2 : 3) spconv_fwd_wide_kernel(SpArgs a) {
-  using S = SpWideSmem<TPW, RG>;
-  constexpr int R = 16 * RG, RPW = R / 4, NLD = RPW / 8, HB = RG / 2;  // rows per wave, gather instructions per wave and chunk, cells per half
-  static_assert(NKC == 2 || NKC == 4, "sources of 64 or 128 channels");
-  static_assert(RG == 6 || RG == 8, "96- or 128-row blocks");
-  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
-  int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
-  uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
-  float* sring = reinterpret_cast<float*>(sp_smem + S::sring_off);
-  int* sched = reinterpret_cast<int*>(sp_smem + S::meta_off);
-  int* nk_s = reinterpret_cast<int*>(sp_smem + S::meta_off + 128);
-  unsigned char* flags = reinterpret_cast<unsigned char*>(sp_smem + S::meta_off + 144);
-  float* vec = reinterpret_cast<float*>(sp_smem + S::vec_off);
-  float* rowmax = reinterpret_cast<float*>(sp_smem + S::rowmax_off);
-
-  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kvol = a.kvol;
-  const int64_t row0 = (int64_t)blockIdx.x * R;
-  const int slice = blockIdx.y;
-
-  // ---- prologue (as K9c, RG cells)
-  {
-    const int64_t base = row0 * kvol, lim = a.m_out * kvol;
-    for (int idx = tid; idx < R * kvol; idx += 256) nbr_s[idx] = (base + idx < lim) ? a.nbr[base + idx] : -1;
-    if (tid < 2 * 64 * TPW) {
-      const int which = tid / (64 * TPW), ch = slice * 64 * TPW + tid % (64 * TPW);
-      const float* src = which == 0 ? a.scale : a.shift;
-      vec[tid] = (src && ch < a.cout) ? src[ch] : (which == 0 ? 1.0f : 0.0f);
-    }
-  }
-  __syncthreads();
-  if (tid < kvol * RG) {
-    const int k = tid / RG, g = tid - k * RG;
-    bool any = false;
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) any |= nbr_s[(16 * g + jj) * kvol + k] >= 0;
-    flags[tid] = any ? 1 : 0;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    unsigned mask = 0;
-    if (lane < kvol) {
-#pragma unroll
-      for (int g = 0; g < RG; ++g) mask |= (unsigned)flags[lane * RG + g] << g;
-    }
-    const unsigned long long live = __ballot(mask != 0);
-    if (lane < 32) sched[lane] = 0;
-    if (mask != 0) sched[__popcll(live & ((1ull << lane) - 1ull))] = lane | (int)(mask << 8);
-    if (lane == 0) *nk_s = __popcll(live);
-  }
-  __syncthreads();
-  const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
-  const int nsrc = a.c[1] > 0 ? 2 : 1;
-  const int nchunks = NKC * nsrc;
-  const int nsteps = nk * nsrc;
-  const uint32_t rowbytes = (uint32_t)NKC * 128u;
-
-  auto entry = [&](int kidx, int src) -> SpStep {
-    const int e = kidx < nk ? __builtin_amdgcn_readfirstlane(sched[kidx]) : 0;
-    return SpStep{kidx, src, e & 255, (unsigned)e >> 8};
-  };
-  auto advance = [&](const SpStep& p) -> SpStep {
-    if (p.src + 1 < nsrc) return SpStep{p.kidx, p.src + 1, p.k, p.mask};
-    return entry(p.kidx + 1, 0);
-  };
-
-  // acc[g][t]: the output tile of cell g in the unit 1 / cinv[g] (x the weight scale); cinv[g] = inverse scale of the row this lane is
-  // multiplying in cell g
-  sp_f32x4 acc[RG][TPW];
-  float cinv[RG];
-#pragma unroll
-  for (int g = 0; g < RG; ++g) {
-    cinv[g] = 1.0f;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  // ---- this wave's share of the gather: rows RPW wave .. RPW wave + RPW - 1 of the block, line-coalesced (see K9d): lane l takes piece
-  // l % 8 of row 8 h + l / 8 in its h-th load, so a load's eight rows are one half of one cell
-  uint4 g_v[NLD];
-  uint32_t g_off[NLD];
-  float g_sc = 1.0f;
-#pragma unroll
-  for (int h = 0; h < NLD; ++h) {
-    g_v[h] = make_uint4(0, 0, 0, 0);
-    g_off[h] = 0;
-  }
-  const int grow = lane >> 3, gpiece = lane & 7;
-  auto gather_row = [&](const SpStep& st) {  // first chunk of a step: which rows, their scale
-    const int32_t* col = nbr_s + (RPW * wave) * kvol + st.k;
-    const int zero = (int)a.m_in;  // (no neighbour: the all-zero row m_in, scale 1)
-#pragma unroll
-    for (int h = 0; h < NLD; ++h) {
-      int i = col[(8 * h + grow) * kvol];
-      i = i >= 0 ? i : zero;
-      g_off[h] = (uint32_t)i * rowbytes + (uint32_t)(gpiece * 16);
-    }
-    int is = col[(lane < RPW ? lane : 0) * kvol];  // lane l < RPW fetches the scale of the wave's l-th row
-    is = is >= 0 ? is : zero;
-    g_sc = (st.src ? a.sx[1] : a.sx[0])[is];
-  };
-  auto gather_chunk = [&](const SpStep& st, int kc) {
-    const char* p = (st.src ? a.x[1] : a.x[0]) + (uint32_t)(kc * 128);
-#pragma unroll
-    for (int h = 0; h < NLD; ++h) g_v[h] = *reinterpret_cast<const uint4*>(p + g_off[h]);
-  };
-  auto stage_to_lds = [&](const SpStep& st, int kc, int slot, int parity) {
-#pragma unroll
-    for (int h = 0; h < NLD; ++h) {
-      const int r8 = RPW * wave + 8 * h;          // first row of this load's eight (a multiple of 8: one half of cell r8 / 16)
-      const int cc = r8 >> 4, rr = (r8 & 8) + grow;  // cell, row within the cell
-      if ((st.mask >> cc) & 1u) xring[(slot * RG + cc) * 128 + rr * 8 + (gpiece ^ ((rr >> 1) & 7))] = g_v[h];
-    }
-    if (kc == 0 && lane < RPW) sring[parity * R + RPW * wave + lane] = g_sc;  // (dead cells too: never read)
-  };
-  auto load_w = [&](const SpStep& st, int kc, uint4 (&wf)[TPW][2]) {
-    const int c = (st.src ? NKC : 0) + kc;
-    const uint4* p = reinterpret_cast<const uint4*>(a.w) + ((((int64_t)slice * kvol + st.k) * nchunks + c) * 4 + wave) * (TPW * 2 * 64) + lane;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) wf[t][pl] = p[(t * 2 + pl) * 64];
-  };
-  const int rd_hi = j * 8 + ((2 * sp_kgroup(q)) ^ ((j >> 1) & 7)), rd_lo = j * 8 + ((2 * sp_kgroup(q) + 1) ^ ((j >> 1) & 7));
-  auto read_cell = [&](int slot, int g, uint4& xh, uint4& xl) {
-    const uint4* xs = xring + (slot * RG + g) * 128;
-    xh = xs[rd_hi];
-    xl = xs[rd_lo];
-  };
-  auto mma_cell = [&](int g, const uint4& xh, const uint4& xl, uint4 (&wk)[TPW][2]) {
-    const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh), bl = __builtin_bit_cast(sp_f16x8, xl);
-    sp_f16x8 wh[TPW], wl[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      wh[t] = __builtin_bit_cast(sp_f16x8, wk[t][0]);
-      wl[t] = __builtin_bit_cast(sp_f16x8, wk[t][1]);
-    }
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[t], bh, acc[g][t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bl, acc[g][t], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[t], bh, acc[g][t], 0, 0, 0);
-  };
-
-  // ---- pipeline state: two weight sets, the X fragments of HALF the cells
-  uint4 wA[TPW][2], wB[TPW][2];
-  uint4 xh[HB], xl[HB];
-#pragma unroll
-  for (int g = 0; g < HB; ++g) xh[g] = xl[g] = make_uint4(0, 0, 0, 0);
-
-  SpStep r0 = entry(0, 0);
-  SpStep r1 = advance(r0);
-  SpStep r2 = advance(r1);
-
-  // ---- fill: X(0), X(1) -> LDS slots 0, 1; X(2) -> staging registers; W(0) -> set A; then the fragments of chunk 0's first half
-  gather_row(r0);
-  gather_chunk(r0, 0);
-  load_w(r0, 0, wA);
-  stage_to_lds(r0, 0, 0, 0);
-  gather_chunk(r0, 1);  // (NKC >= 2: chunk 1 belongs to the same step)
-  stage_to_lds(r0, 1, 1, 0);
-  if constexpr (NKC > 2) {
-    gather_chunk(r0, 2);
-  } else {
-    gather_row(r1);
-    gather_chunk(r1, 0);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int g = 0; g < HB; ++g)
-    if ((r0.mask >> g) & 1u) read_cell(0, g, xh[g], xl[g]);
-
-  int slot = 0;    // LDS slot of the chunk being multiplied (chunk counter modulo 3)
-  int parity = 0;  // parity of the step being multiplied (which half of sring)
-  auto iteration = [&](auto kc_tag) {
-    constexpr int KC = decltype(kc_tag)::value;
-    constexpr int d1 = (KC + 1) / NKC, d2 = (KC + 2) / NKC, d3 = (KC + 3) / NKC;
-    static_assert(d3 <= 2, "three step records suffice");
-    const SpStep st = r0;
-    const SpStep st1 = d1 == 0 ? r0 : r1;
-    const SpStep st2 = d2 == 0 ? r0 : r1;
-    const SpStep st3 = d3 == 0 ? r0 : (d3 == 1 ? r1 : r2);
-    constexpr int kc1 = (KC + 1) % NKC, kc2 = (KC + 2) % NKC, kc3 = (KC + 3) % NKC;
-    const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
-    __syncthreads();
-    // staging of the chunks ahead (slot2 was last read — chunk KC - 1's second half — before the previous barrier)
-    stage_to_lds(st2, kc2, slot2, (parity + d2) & 1);
-    if (kc3 == 0) gather_row(st3);
-    gather_chunk(st3, kc3);
-    // next chunk's weights into the set the previous iteration multiplied from
-    if (KC % 2 == 0) load_w(st1, kc1, wB);
-    else load_w(st1, kc1, wA);
-    if (KC == 0) {  // a new step: every live cell's accumulators into the unit of the row this lane multiplies now (exact: powers of two)
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        if ((st.mask >> g) & 1u) {
-          const float v = sring[parity * R + 16 * g + j];
-          const float f = __fmul_rn(cinv[g], __uint_as_float(0x7F000000u - __float_as_uint(v)));  // old unit / new unit = cinv_old * (1 / v)
-          cinv[g] = v;
-#pragma unroll
-          for (int t = 0; t < TPW; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmul_rn(acc[g][t][r], f);
-        }
-      }
-    }
-    // first half of chunk KC; a cell's fragment registers take the chunk's second half as soon as its MFMAs are issued
-#pragma unroll
-    for (int g = 0; g < HB; ++g) {
-      if ((st.mask >> g) & 1u) mma_cell(g, xh[g], xl[g], (KC % 2 == 0) ? wA : wB);
-      if ((st.mask >> (g + HB)) & 1u) read_cell(slot, g + HB, xh[g], xl[g]);
-    }
-    // second half; then the first half of chunk KC + 1
-#pragma unroll
-    for (int g = 0; g < HB; ++g) {
-      if ((st.mask >> (g + HB)) & 1u) mma_cell(g + HB, xh[g], xl[g], (KC % 2 == 0) ? wA : wB);
-      if ((st1.mask >> g) & 1u) read_cell(slot1, g, xh[g], xl[g]);
-    }
-    slot = slot1;
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
-  for (int s = 0; s < nsteps; ++s) {
-    iteration(I0{});
-    iteration(I1{});
-    if constexpr (NKC == 4) {
-      iteration(I2{});
-      iteration(I3{});
-    }
-    r0 = r1;
-    r1 = r2;
-    r2 = advance(r2);
-    parity ^= 1;
-  }
-  // the accumulators back into true units (x the weight's inverse scale)
-  const float w_inv = a.w_hdr[0];
-#pragma unroll
-  for (int g = 0; g < RG; ++g) {
-    const float sc = __fmul_rn(cinv[g], w_inv);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmul_rn(acc[g][t][r], sc);
-  }
-  __syncthreads();  // (the ring's last reads precede the epilogue's use of `rowmax`; the gathers still in flight are dropped)
-  sp_epilogue<RG, TPW>(a, acc, vec, rowmax, row0, slice, wave, tid);
-}
-
-// =====================================================================================================================
-// K9f: K9d's pipeline with the weight fragments SHARED by three 64-row blocks (round 3).
-//
-// K9d's three workgroups per CU fetch the same 16 KB of weight fragments per chunk three times, next to 8 KB of gathered rows
-// each: 72 KB through a vector-memory path that takes in ~25 B/clk per CU (profiles/r3_vmem_return_probe.txt), and the kernel's
-// duration is that intake plus the rest (profiles/r3_spconv_k9d_ablations.txt).  Here ONE workgroup of twelve waves owns 192 rows:
-// wave (rb, cs) is K9d's wave cs of row block rb — same cells, same accumulators, same X ring (one per row block) — but a
-// chunk's weight fragments enter the CU once: the waves of one row block (rotating with the chunk index) load them to staging
-// registers (chunk i+3 during iteration i), write them to a two-slot LDS ring the iteration after, and every wave refills its
-// single fragment register set from the ring behind the MFMAs that used it (the t = 0 tiles of all cells first, then t = 1, so
-// a half set is free while the other multiplies).  40 KB per chunk instead of 72 KB.
-// The price: the step sequence is the union of the three row blocks' live offsets (a row block idles through steps none of its
-// cells needs), one barrier spans twelve waves, and the workgroup has a CU to itself (157 KB of LDS).
-// Twelve waves of 168 registers leave no room for K9d's per-step product tiles D next to the weight staging registers: the
-// accumulators are kept in the unit of the row being multiplied, as in K9e (exact power-of-two rescaling at every step).
-template <int TPW>
-struct SpTriSmem {
-  static constexpr int NRB = 3, R = 64 * NRB, NCELL = 4 * NRB;
-  static constexpr size_t nbr_bytes = (size_t)R * SP_KVOL_MAX * 4;
-  static constexpr size_t xring_off = (nbr_bytes + 255) / 256 * 256;
-  static constexpr size_t xring_bytes = (size_t)4 * NCELL * 2048;  // [slot][row block][cell][row][piece ^ swizzle(row)] x 16 B
-  static constexpr size_t wring_off = xring_off + xring_bytes;
-  static constexpr size_t wring_bytes = (size_t)2 * 4 * TPW * 2 * 1024;  // [chunk parity][wave's slice][tile][hi | lo][lane] x 16 B
-  static constexpr size_t sring_off = wring_off + wring_bytes;
-  static constexpr size_t sring_bytes = (size_t)2 * NCELL * 16 * 4;  // [step parity][cell][row]
-  static constexpr size_t meta_off = sring_off + sring_bytes;
-  static constexpr size_t meta_bytes = 32 * 4 + 16 + (size_t)SP_KVOL_MAX * NCELL;
-  static constexpr size_t vec_off = (meta_off + meta_bytes + 15) / 16 * 16;
-  static constexpr size_t vec_bytes = (size_t)2 * 64 * TPW * 4;
-  static constexpr size_t rowmax_off = vec_off + vec_bytes;
-  static constexpr size_t rowmax_bytes = (size_t)4 * R * 4;
-  static constexpr size_t bytes = rowmax_off + rowmax_bytes;
-};
-
-template <int TPW, int NKC>
-__global__ void __launch_bounds__(768, 1) spconv_fwd_tri_kernel(SpArgs a) {
-  using S = SpTriSmem<TPW>;
-  constexpr int RG = 4, R = S::R, NCELL = S::NCELL, NT = 768;
-  static_assert(NKC == 2 || NKC == 4, "sources of 64 or 128 channels");
-  extern __shared__ __attribute__((aligned(16))) char sp_smem[];
-  int32_t* nbr_s = reinterpret_cast<int32_t*>(sp_smem);
-  uint4* xring = reinterpret_cast<uint4*>(sp_smem + S::xring_off);
-  uint4* wring = reinterpret_cast<uint4*>(sp_smem + S::wring_off);
-  float* sring = reinterpret_cast<float*>(sp_smem + S::sring_off);
-  int* sched = reinterpret_cast<int*>(sp_smem + S::meta_off);
-  int* nk_s = reinterpret_cast<int*>(sp_smem + S::meta_off + 128);
-  unsigned char* flags = reinterpret_cast<unsigned char*>(sp_smem + S::meta_off + 144);
-  float* vec = reinterpret_cast<float*>(sp_smem + S::vec_off);
-  float* rowmax = reinterpret_cast<float*>(sp_smem + S::rowmax_off);
-
-  const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rb = wave >> 2, cs = wave & 3;  // row block, 16*TPW-channel share of the slice
-  const int kvol = a.kvol;
-  const int64_t row0 = (int64_t)blockIdx.x * R;
-  const int slice = blockIdx.y;
-
-  // ---- prologue: the 192 rows of the neighbour table, the epilogue's vectors, the union schedule with a 12-cell mask per offset
-  {
-    const int64_t base = row0 * kvol, lim = a.m_out * kvol;
-    for (int idx = tid; idx < R * kvol; idx += NT) nbr_s[idx] = (base + idx < lim) ? a.nbr[base + idx] : -1;
-    if (tid < 2 * 64 * TPW) {
-      const int which = tid / (64 * TPW), ch = slice * 64 * TPW + tid % (64 * TPW);
-      const float* src = which == 0 ? a.scale : a.shift;
-      vec[tid] = (src && ch < a.cout) ? src[ch] : (which == 0 ? 1.0f : 0.0f);
-    }
-  }
-  __syncthreads();
-  if (tid < kvol * NCELL) {
-    const int k = tid / NCELL, g = tid - k * NCELL;
-    bool any = false;
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) any |= nbr_s[(16 * g + jj) * kvol + k] >= 0;
-    flags[tid] = any ? 1 : 0;
-  }
-  __syncthreads();
-  if (wave == 0) {
-    unsigned mask = 0;
-    if (lane < kvol) {
-#pragma unroll
-      for (int g = 0; g < NCELL; ++g) mask |= (unsigned)flags[lane * NCELL + g] << g;
-    }
-    const unsigned long long live = __ballot(mask != 0);
-    if (lane < 32) sched[lane] = 0;
-    if (mask != 0) sched[__popcll(live & ((1ull << lane) - 1ull))] = lane | (int)(mask << 8);
-    if (lane == 0) *nk_s = __popcll(live);
-  }
-  __syncthreads();
-  const int nk = __builtin_amdgcn_readfirstlane(*nk_s);
-  const int nsrc = a.c[1] > 0 ? 2 : 1;
-  const int nchunks = NKC * nsrc;
-  const int nsteps = nk * nsrc;
-  const float w_inv = a.w_hdr[0];
-  const uint32_t rowbytes = (uint32_t)NKC * 128u;
-
-  auto entry = [&](int kidx, int src) -> SpStep {  // (the mask of a step record is this wave's row block's four cells)
-    const int e = kidx < nk ? __builtin_amdgcn_readfirstlane(sched[kidx]) : 0;
-    return SpStep{kidx, src, e & 255, ((unsigned)e >> (8 + 4 * rb)) & 15u};
-  };
-  auto advance = [&](const SpStep& p) -> SpStep {
-    if (p.src + 1 < nsrc) return SpStep{p.kidx, p.src + 1, p.k, p.mask};
-    return entry(p.kidx + 1, 0);
-  };
-
-  // acc[g][t]: the output tile of cell g in the unit 1 / cinv[g] (x the weight scale), cinv[g] = inverse scale of the row this lane
-  // multiplies in cell g at the moment (K9e's scheme)
-  sp_f32x4 acc[RG][TPW];
-  float cinv[RG];
-#pragma unroll
-  for (int g = 0; g < RG; ++g) {
-    cinv[g] = 1.0f;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) acc[g][t] = sp_f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  // ---- the gather of cell cs of row block rb: K9d's (two line-coalesced loads per chunk, swizzled row-major LDS tile)
-  uint4 g_a = make_uint4(0, 0, 0, 0), g_b = make_uint4(0, 0, 0, 0);
-  float g_sc = 1.0f;
-  uint32_t g_off0 = 0, g_off1 = 0;
-  const int grow = lane >> 3, gpiece = lane & 7;
-  const int cell = rb * RG + cs;
-  auto gather_row = [&](const SpStep& st, uint32_t& off0, uint32_t& off1, float& sc) {
-    const int32_t* col = nbr_s + (16 * cell) * kvol + st.k;
-    int i0 = col[grow * kvol], i1 = col[(8 + grow) * kvol], is = col[j * kvol];
-    const int zero = (int)a.m_in;
-    i0 = i0 >= 0 ? i0 : zero;
-    i1 = i1 >= 0 ? i1 : zero;
-    is = is >= 0 ? is : zero;
-    off0 = (uint32_t)i0 * rowbytes + (uint32_t)(gpiece * 16);
-    off1 = (uint32_t)i1 * rowbytes + (uint32_t)(gpiece * 16);
-    sc = (st.src ? a.sx[1] : a.sx[0])[is];
-  };
-  auto gather_chunk = [&](const SpStep& st, int kc, uint32_t off0, uint32_t off1, uint4& va, uint4& vb) {
-#ifdef PT_SKIP_DEAD
-    if (!((st.mask >> cs) & 1u)) return;
-#endif
-    const char* p = (st.src ? a.x[1] : a.x[0]) + (uint32_t)(kc * 128);
-    va = *reinterpret_cast<const uint4*>(p + off0);
-    vb = *reinterpret_cast<const uint4*>(p + off1);
-  };
-  const int wr_a = grow * 8 + (gpiece ^ ((grow >> 1) & 7)), wr_b = (8 + grow) * 8 + (gpiece ^ (((8 + grow) >> 1) & 7));
-  auto stage_to_lds = [&](const SpStep& st, int kc, int slot, int parity, const uint4& va, const uint4& vb, float sc) {
-    if ((st.mask >> cs) & 1u) {
-      uint4* dst = xring + (slot * NCELL + cell) * 128;
-      dst[wr_a] = va;
-      dst[wr_b] = vb;
-      if (kc == 0 && q == 0) sring[(parity * NCELL + cell) * 16 + j] = sc;
-    }
-  };
-  const int rd_hi = j * 8 + ((2 * sp_kgroup(q)) ^ ((j >> 1) & 7)), rd_lo = j * 8 + ((2 * sp_kgroup(q) + 1) ^ ((j >> 1) & 7));
-  auto read_cell = [&](int slot, int g, uint4& xh, uint4& xl) {
-    const uint4* xs = xring + (slot * NCELL + rb * RG + g) * 128;
-    xh = xs[rd_hi];
-    xl = xs[rd_lo];
-  };
-  // ---- weights: global -> registers (the duty waves) -> LDS ring -> every wave's fragment registers
-  auto load_w = [&](const SpStep& st, int kc, uint4 (&wf)[TPW][2]) {
-    const int c = (st.src ? NKC : 0) + kc;
-    const uint4* p = reinterpret_cast<const uint4*>(a.w) + ((((int64_t)slice * kvol + st.k) * nchunks + c) * 4 + cs) * (TPW * 2 * 64) + lane;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) wf[t][pl] = p[(t * 2 + pl) * 64];
-  };
-  auto w_to_lds = [&](int wslot, const uint4 (&wf)[TPW][2]) {
-    uint4* dst = wring + (wslot * 4 + cs) * (TPW * 2 * 64) + lane;
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) dst[(t * 2 + pl) * 64] = wf[t][pl];
-  };
-  auto w_from_lds = [&](int wslot, int t, uint4 (&wf)[TPW][2]) {
-    const uint4* src = wring + (wslot * 4 + cs) * (TPW * 2 * 64) + lane;
-    wf[t][0] = src[(t * 2) * 64];
-    wf[t][1] = src[(t * 2 + 1) * 64];
-  };
-  auto mma_tile = [&](int g, int t, const uint4& xh, const uint4& xl, const uint4 (&wk)[TPW][2]) {
-    const sp_f16x8 bh = __builtin_bit_cast(sp_f16x8, xh), bl = __builtin_bit_cast(sp_f16x8, xl);
-    const sp_f16x8 wh = __builtin_bit_cast(sp_f16x8, wk[t][0]), wl = __builtin_bit_cast(sp_f16x8, wk[t][1]);
-    acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, acc[g][t], 0, 0, 0);
-    acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, acc[g][t], 0, 0, 0);
-    acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, acc[g][t], 0, 0, 0);
-  };
-
-  uint4 wK[TPW][2], wS[TPW][2];
-  uint4 xh[RG], xl[RG];
-#pragma unroll
-  for (int g = 0; g < RG; ++g) xh[g] = xl[g] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-  for (int t = 0; t < TPW; ++t) wS[t][0] = wS[t][1] = make_uint4(0, 0, 0, 0);
-
-  SpStep r0 = entry(0, 0);
-  SpStep r1 = advance(r0);
-  SpStep r2 = advance(r1);
-
-  // ---- fill: X(0), X(1) -> slots 0, 1; X(2) -> staging; W(0) -> registers; W(1) -> ring slot 1 (row block 1); W(2) -> row block 2's staging
-  {
-    uint4 a0 = make_uint4(0, 0, 0, 0), b0 = a0, a1 = a0, b1 = a0;
-    gather_row(r0, g_off0, g_off1, g_sc);
-    gather_chunk(r0, 0, g_off0, g_off1, a0, b0);
-    gather_chunk(r0, 1, g_off0, g_off1, a1, b1);
-    const float sc0 = g_sc;
-    if constexpr (NKC > 2) {
-      gather_chunk(r0, 2, g_off0, g_off1, g_a, g_b);
-    } else {
-      gather_row(r1, g_off0, g_off1, g_sc);
-      gather_chunk(r1, 0, g_off0, g_off1, g_a, g_b);
-    }
-    load_w(r0, 0, wK);
-    if (rb == 1) {
-      load_w(r0, 1, wS);
-      w_to_lds(1, wS);
-    }
-    if (rb == 2) {
-      if constexpr (NKC > 2) load_w(r0, 2, wS);
-      else load_w(r1, 0, wS);
-    }
-    stage_to_lds(r0, 0, 0, 0, a0, b0, sc0);
-    stage_to_lds(r0, 1, 1, 0, a1, b1, sc0);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int g = 0; g < RG; ++g)
-    if ((r0.mask >> g) & 1u) read_cell(0, g, xh[g], xl[g]);
-
-  int ph = 0;  // chunk counter modulo 3: row block (c % 3) carries chunk c's weights into the CU
-  const int ph_store = rb == 2 ? 0 : rb + 1;
-  auto iteration = [&](auto kc_tag, auto odd_tag) {
-    constexpr int KC = decltype(kc_tag)::value;
-    constexpr int ODD = decltype(odd_tag)::value;
-    constexpr int I = (NKC == 4) ? KC : (2 * ODD + KC);
-    constexpr int d1 = (KC + 1) / NKC, d2 = (KC + 2) / NKC, d3 = (KC + 3) / NKC;
-    static_assert(d3 <= 2, "three step records suffice");
-    const SpStep st = r0;
-    const SpStep st1 = d1 == 0 ? r0 : r1;
-    const SpStep st2 = d2 == 0 ? r0 : r1;
-    const SpStep st3 = d3 == 0 ? r0 : (d3 == 1 ? r1 : r2);
-    constexpr int kc1 = (KC + 1) % NKC, kc2 = (KC + 2) % NKC, kc3 = (KC + 3) % NKC;
-    (void)kc1;
-    __syncthreads();
-    stage_to_lds(st2, kc2, (I + 2) % 4, (ODD + d2) & 1, g_a, g_b, g_sc);
-    if (kc3 == 0) gather_row(st3, g_off0, g_off1, g_sc);
-    gather_chunk(st3, kc3, g_off0, g_off1, g_a, g_b);
-    if (ph == ph_store) w_to_lds(I % 2, wS);     // chunk i + 2, fetched by this wave during iteration i - 1
-    if (ph == rb) load_w(st3, kc3, wS);          // chunk i + 3
-    ph = ph == 2 ? 0 : ph + 1;
-    if (KC == 0) {  // a new step: every live cell's accumulators into the unit of the row this lane multiplies now (exact: powers of two)
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        if ((st.mask >> g) & 1u) {
-          const float v = sring[(ODD * NCELL + rb * RG + g) * 16 + j];
-          const float f = __fmul_rn(cinv[g], __uint_as_float(0x7F000000u - __float_as_uint(v)));  // old unit / new unit
-          cinv[g] = v;
-#pragma unroll
-          for (int t = 0; t < TPW; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmul_rn(acc[g][t][r], f);
-        }
-      }
-    }
-    // multiply chunk KC tile-major; a tile's weight registers and (after the last tile) a cell's X registers take chunk KC + 1
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-#pragma unroll
-      for (int g = 0; g < RG; ++g) {
-        if ((st.mask >> g) & 1u) mma_tile(g, t, xh[g], xl[g], wK);
-        if (t == TPW - 1 && ((st1.mask >> g) & 1u)) read_cell((I + 1) % 4, g, xh[g], xl[g]);
-      }
-      w_from_lds((I + 1) % 2, t, wK);
-    }
-  };
-  auto next_step = [&]() {
-    r0 = r1;
-    r1 = r2;
-    r2 = advance(r2);
-  };
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  using I3 = std::integral_constant<int, 3>;
-  auto whole_step = [&](auto odd_tag) {
-    iteration(I0{}, odd_tag);
-    iteration(I1{}, odd_tag);
-    if constexpr (NKC == 4) {
-      iteration(I2{}, odd_tag);
-      iteration(I3{}, odd_tag);
-    }
-  };
-  int s = 0;
-  for (; s + 1 < nsteps; s += 2) {
-    whole_step(I0{});
-    next_step();
-    whole_step(I1{});
-    next_step();
-  }
-  if (s < nsteps) whole_step(I0{});
-#pragma unroll
-  for (int g = 0; g < RG; ++g) {  // the accumulators back into true units (x the weight's inverse scale)
-    const float sc = __fmul_rn(cinv[g], w_inv);
-#pragma unroll
-    for (int t = 0; t < TPW; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[g][t][r] = __fmul_rn(acc[g][t][r], sc);
-  }
-  __syncthreads();
-  sp_epilogue<RG, TPW>(a, acc, vec, rowmax + rb * 4 * 64, row0 + 64 * rb, slice, cs, tid & 255);
-}
-
 }  // namespace fsf
 
 using namespace fsf;
@@ -1625,8 +1025,6 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
   a.scale = scale; a.shift = shift; a.residual = residual;
   a.out = out; a.out_planes = (uint4*)out_planes; a.out_scales = out_scales;
   const int tpw = sp_tpw(cout), nslice = sp_nslice(cout);
-  static const int64_t rg8_min_rows = getenv("FSF_PLANES_RG8_MIN_ROWS") ? atoll(getenv("FSF_PLANES_RG8_MIN_ROWS")) : ((int64_t)1 << 40);  // 64-row blocks (3 workgroups per CU) win at every size measured
-  const bool big = m_out >= rg8_min_rows;
   if ((m_in + 1) * (int64_t)(ca > cb ? ca : cb) * 4 >= (int64_t)1 << 32) return FSF_ERR_UNSUPPORTED;  // 32-bit gather offsets
 #define FSF_SP(RG_, TPW_, NKC_)                                                                                             \
   do {                                                                                                                     \
@@ -1649,47 +1047,9 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
     const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                           \
     hipLaunchKernelGGL((spconv_fwd_pipe_kernel<TPW_, NKC_>), grid, dim3(256), S::bytes, stream, a);                     \
   } while (0)
-  // K9e (128-row blocks: half the weight bytes per row) is OFF by default: measured 12-30 % slower than K9d on every layer of the
-  // frame — two waves per SIMD cover the pipeline's latencies worse than three; FSF_PLANES_WIDE_MIN_ROWS=<rows>
-  // turns it on from that many output rows x channel slices
-  static const int64_t wide_min_rows = getenv("FSF_PLANES_WIDE_MIN_ROWS") ? atoll(getenv("FSF_PLANES_WIDE_MIN_ROWS")) : ((int64_t)1 << 40);
-  const bool wide = pipe_on && !big && nkc_fix > 0 && m_out * nslice >= wide_min_rows;
-#define FSF_SPW(TPW_, NKC_, RG_)                                                                                              \
-  do {                                                                                                                       \
-    using S = SpWideSmem<TPW_, RG_>;                                                                                         \
-    static std::atomic<uint64_t> attr_done{0};                                                                               \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_wide_kernel<TPW_, NKC_, RG_>, (int)S::bytes, attr_done));    \
-    const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                                \
-    hipLaunchKernelGGL((spconv_fwd_wide_kernel<TPW_, NKC_, RG_>), grid, dim3(256), S::bytes, stream, a);                     \
-  } while (0)
-  // K9g (96-row blocks, three workgroups per CU) from FSF_PLANES_R96_MIN_ROWS output rows x channel slices
-  static const int64_t r96_min_rows = getenv("FSF_PLANES_R96_MIN_ROWS") ? atoll(getenv("FSF_PLANES_R96_MIN_ROWS")) : ((int64_t)1 << 40);
-  const bool r96 = pipe_on && !big && !wide && nkc_fix > 0 && m_out * nslice >= r96_min_rows;
-  // K9f (192-row workgroups sharing the weight fragments) from FSF_PLANES_TRI_MIN_ROWS output rows
-  static const int64_t tri_min_rows = getenv("FSF_PLANES_TRI_MIN_ROWS") ? atoll(getenv("FSF_PLANES_TRI_MIN_ROWS")) : ((int64_t)1 << 40);
-  const bool tri = pipe_on && !big && !wide && nkc_fix > 0 && m_out >= tri_min_rows;
-#define FSF_SPT(TPW_, NKC_)                                                                                              \
-  do {                                                                                                                  \
-    using S = SpTriSmem<TPW_>;                                                                                          \
-    static std::atomic<uint64_t> attr_done{0};                                                                          \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_tri_kernel<TPW_, NKC_>, (int)S::bytes, attr_done));     \
-    const dim3 grid((unsigned)((m_out + S::R - 1) / S::R), (unsigned)nslice);                                           \
-    hipLaunchKernelGGL((spconv_fwd_tri_kernel<TPW_, NKC_>), grid, dim3(768), S::bytes, stream, a);                      \
-  } while (0)
-  if (r96 && nkc_fix == 4 && tpw == 2) FSF_SPW(2, 4, 6);
-  else if (r96 && nkc_fix == 2 && tpw == 2) FSF_SPW(2, 2, 6);
-  else if (r96 && nkc_fix == 2 && tpw == 1) FSF_SPW(1, 2, 6);
-  else if (tri && nkc_fix == 4 && tpw == 2) FSF_SPT(2, 4);
-  else if (tri && nkc_fix == 2 && tpw == 2) FSF_SPT(2, 2);
-  else if (tri && nkc_fix == 2 && tpw == 1) FSF_SPT(1, 2);
-  else if (wide && nkc_fix == 4 && tpw == 2) FSF_SPW(2, 4, 8);
-  else if (wide && nkc_fix == 2 && tpw == 2) FSF_SPW(2, 2, 8);
-  else if (wide && nkc_fix == 2 && tpw == 1) FSF_SPW(1, 2, 8);
-  else if (pipe_on && !big && nkc_fix == 4 && tpw == 2) FSF_SPP(2, 4);   // K9d: the chunk-granular pipeline
-  else if (pipe_on && !big && nkc_fix == 2 && tpw == 2) FSF_SPP(2, 2);
-  else if (pipe_on && !big && nkc_fix == 2 && tpw == 1) FSF_SPP(1, 2);
-  else if (big && tpw == 2) FSF_SP(8, 2, 0);
-  else if (big) FSF_SP(8, 1, 0);
+  if (pipe_on && nkc_fix == 4 && tpw == 2) FSF_SPP(2, 4);   // K9d: the chunk-granular pipeline
+  else if (pipe_on && nkc_fix == 2 && tpw == 2) FSF_SPP(2, 2);
+  else if (pipe_on && nkc_fix == 2 && tpw == 1) FSF_SPP(1, 2);
   else if (tpw == 2 && nkc_fix == 4) FSF_SP(4, 2, 4);
   else if (tpw == 2 && nkc_fix == 2) FSF_SP(4, 2, 2);
   else if (tpw == 1 && nkc_fix == 2) FSF_SP(4, 1, 2);
@@ -1697,8 +1057,6 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
   else FSF_SP(4, 1, 0);
 #undef FSF_SP
 #undef FSF_SPP
-#undef FSF_SPW
-#undef FSF_SPT
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

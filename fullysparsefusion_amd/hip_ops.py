@@ -96,6 +96,7 @@ _ARGTYPES = {
     "fsf_class_rank_desc_workspace_bytes": [c_i64, c_i32],
     "fsf_class_rank_desc": [_P, c_i64, c_i32, c_f32, _P, _P, _P, _P, c_i64, _P],
     "fsf_nms_select_capacity": [],
+    "fsf_box_tail_max_classes": [],
     "fsf_nms_select": [_P, c_i32, _P, _P, _P, c_i64, _P, c_i64, c_i32, c_i64, c_i32, _P, _P, _P, _P, _P],
     "fsf_connected_components_grouped": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
@@ -1028,6 +1029,10 @@ def class_rank_desc(scores_t: torch.Tensor, score_thr: float):
 
 def nms_select_capacity() -> int:
     return int(_L().fsf_nms_select_capacity())
+
+
+def box_tail_max_classes() -> int:
+    return int(_L().fsf_box_tail_max_classes())
 
 
 def nms_select(boxes: torch.Tensor, scores_t: torch.Tensor, order: torch.Tensor, keep: torch.Tensor, num_keep: torch.Tensor,

@@ -199,8 +199,11 @@ def box3d_multiclass_nms(mlvl_bboxes, mlvl_bboxes_for_nms, mlvl_scores, score_th
 def bbox3d2result(bboxes, scores, labels, attrs=None):
     """mmdet3d.core.bbox3d2result: results on the host, the form the dataset evaluators take."""
     t = getattr(bboxes, "tensor", None)
-    host = getattr(bboxes, "_host_rows", None)  # (boxes | score | label) rows already on the host (the fused box tail's one read-back)
-    if host is not None and t is not None and host.size(0) == len(t) == scores.numel() == labels.numel() and attrs is None:
+    hr = getattr(bboxes, "_host_rows", None)  # (boxes | score | label) rows already on the host (the fused box tail's one read-back)
+    if (hr is not None and t is not None and attrs is None and hr[1] is t and t._version == hr[2] and hr[3] is scores
+            and scores._version == hr[4] and hr[5] is labels and labels._version == hr[6]):
+        # ... and still what the device tensors hold: the very tensors the box tail returned, un-edited since
+        host = hr[0]
         c = t.size(1)
         return dict(boxes_3d=type(bboxes)._wrap(host[:, :c].contiguous(), c, getattr(bboxes, "with_yaw", True)),
                     scores_3d=host[:, c].contiguous(), labels_3d=host[:, c + 1].to(labels.dtype))

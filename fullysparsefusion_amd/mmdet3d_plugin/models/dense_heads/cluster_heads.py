@@ -329,6 +329,7 @@ class SparseClusterHeadV2(SparseClusterHead):
                 and cluster_xyz.dtype == torch.float32 and iou_logits is None and not torch.is_grad_enabled()
                 and box_type is LiDARInstance3DBoxes and getattr(self, "vis_dir", None) is None
                 and isinstance(max_num, int) and max_num > 0 and c * max_num <= hip_ops.nms_select_capacity()
+                and c <= hip_ops.box_tail_max_classes()
                 and not (nms_pre > 0 and n > nms_pre) and type(self.bbox_coder) is BasePointBBoxCoder):
             return None
         boxes, boxes_nms, scores_t = hip_ops.decode_cluster_boxes(cls_logits, reg_preds, cluster_xyz, self.bbox_coder.EPS)
@@ -344,9 +345,13 @@ class SparseClusterHeadV2(SparseClusterHead):
             return None
         k = int(meta[0])
         rows = buf[:max_num * (d + 2)].view(max_num, d + 2)[:k]
-        out_bboxes = LiDARInstance3DBoxes._wrap(rows[:, :d], d)
-        out_bboxes._host_rows = host[:max_num * (d + 2)].view(max_num, d + 2)[:k]
-        return out_bboxes, rows[:, d], rows[:, d + 1].long()
+        # (views of `buf`: row stride d + 2 — consumers index / reshape them; `.view()` needs `.contiguous()` first)
+        out_bboxes, out_scores, out_labels = LiDARInstance3DBoxes._wrap(rows[:, :d], d), rows[:, d], rows[:, d + 1].long()
+        # the same rows already on the host, for bbox3d2result — valid only while nobody has edited the device tensors since
+        # (rescale / flip / score re-weighting between get_bboxes and bbox3d2result): identity + version counters travel along
+        out_bboxes._host_rows = (host[:max_num * (d + 2)].view(max_num, d + 2)[:k], out_bboxes.tensor, out_bboxes.tensor._version,
+                                 out_scores, out_scores._version, out_labels, out_labels._version)
+        return out_bboxes, out_scores, out_labels
 
     def _append_debug_columns(self, bboxes, preds_2d):
         return bboxes

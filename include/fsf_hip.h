@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 5
+#define FSF_ABI_VERSION 6
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -651,6 +651,9 @@ int64_t fsf_class_rank_desc_workspace_bytes(int64_t n, int32_t num_classes);
 int fsf_class_rank_desc(const float* scores_t, int64_t n, int32_t num_classes, float score_thr, int32_t* order, int32_t* rank,
                         int32_t* count, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t fsf_nms_select_capacity(void);
+/* the most classes fsf_class_rank_desc / fsf_nms_select take (32: beyond it they return FSF_ERR_UNSUPPORTED and the caller keeps
+ * the per-class path of box3d_multiclass_nms) */
+int32_t fsf_box_tail_max_classes(void);
 int fsf_nms_select(const float* boxes, int32_t box_dim, const float* scores_t, const int32_t* order, const int64_t* keep,
                    int64_t keep_stride, const int64_t* num_keep, int64_t n, int32_t num_classes, int64_t max_keep, int32_t max_num,
                    const int64_t* label_lut, const int32_t* incomplete, float* out, int32_t* meta, void* stream);
