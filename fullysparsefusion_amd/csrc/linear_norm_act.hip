@@ -442,7 +442,7 @@ extern "C" int fsf_linear_norm_act_sliced(const float* x, int64_t n, int32_t k, 
   if (x_stride < (int64_t)(nslice - 1) * x_slice_offset + k || out_stride < (int64_t)nslice * slice_c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n,
-            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset, nullptr};
+            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset};
   return lna_launch(a, nslice, stream);
 }
 
@@ -475,6 +475,6 @@ extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k,
   if (x_stride < k || out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
-            row_add, row_add_index, row_add_stride, 128, (int)c, 0, nullptr};
+            row_add, row_add_index, row_add_stride, 128, (int)c, 0};
   return lna_launch(a, lna_slices(c), stream);
 }
