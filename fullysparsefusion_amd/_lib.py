@@ -10,7 +10,9 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfsf_hip.so")
+# FSF_LIB_PATH: another BUILD of the same library (same ABI version, checked below) — same-box A/B of two source states by
+# tools/profiling/ab_bench.sh; never set in product runs
+LIB_PATH = os.environ.get("FSF_LIB_PATH") or os.path.join(_HERE, "libfsf_hip.so")
 
 _lib = None
 _lock = threading.Lock()

@@ -51,7 +51,19 @@ struct LnaArgs {
   // output channels per blockIdx.y slice (128 unless "sliced": independent layers side by side, one per slice), the width a
   // LayerNorm spans (c, or the slice width), and the column offset between the inputs of consecutive slices
   int slice_w, norm_w; int64_t x_slice_off;
+  // fused segmented max (K22s): rows arrive SORTED by segment (seg_ids nondecreasing, segment s = rows [seg_offsets[s],
+  // seg_offsets[s + 1])); seg_out[s, ch] = max over the segment's rows of the activated output.  seg_out must hold -inf on
+  // entry (segments that straddle two workgroups' row ranges are combined with atomic max).  `out` may then be null.
+  const int64_t* seg_ids; const int32_t* seg_offsets; float* seg_out; int64_t seg_out_stride;
 };
+
+// max of two floats into memory, any signs, by integer atomics on the IEEE bit patterns (target initialised to -inf): a value
+// >= 0 orders like a signed int above every negative pattern, a value < 0 orders inversely as an unsigned int below every
+// non-negative pattern's... (min over unsigned: non-negative patterns are the smallest, so a stored non-negative survives).
+__device__ __forceinline__ void lna_atomic_max(float* p, float v) {
+  if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(p), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned*>(p), __float_as_uint(v));
+}
 
 __device__ __forceinline__ float lna_row_sum(float v) {
   v += __shfl_xor(v, 16);
@@ -74,22 +86,37 @@ __device__ __forceinline__ void lna_split8(const float (&v)[8], lna_u32x4& hi, l
   }
 }
 
+typedef float lna_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ lna_f32x2 lna_pk_fma(lna_f32x2 a, lna_f32x2 b, lna_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ lna_f32x2 lna_pk(float v) { return lna_f32x2{v, v}; }
+
 // GELU with erf by Abramowitz & Stegun 7.1.26, branch-free (|error| <= 1.5e-7 absolute — float epsilon; the same form as
-// K21's, see sir_input.hip)
-__device__ __forceinline__ float lna_gelu(float y) {
-  const float u = fabsf(y) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float pe = p * t * __builtin_amdgcn_exp2f(u * u * -1.4426950408889634f);
-  return 0.5f * y * (y < 0.0f ? pe : 2.0f - pe);
+// K21's, see sir_input.hip), on TWO values per lane: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the rate of
+// their scalar forms, so everything but the two transcendentals (v_rcp, v_exp: quarter rate, unpacked) costs half the
+// instructions per value — the kernel is bound by VALU issue, not by the matrix pipe.
+// 0.5 y (1 + sign(y) (1 - pe)) = 0.5 ((y + |y|) - |y| pe): no compare / select.
+__device__ __forceinline__ lna_f32x2 lna_gelu2(lna_f32x2 y) {
+  lna_f32x2 ay;
+  ay.x = fabsf(y.x); ay.y = fabsf(y.y);
+  const lna_f32x2 u = ay * lna_pk(0.70710678118654752440f);
+  const lna_f32x2 d = lna_pk_fma(lna_pk(0.3275911f), u, lna_pk(1.0f));
+  lna_f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+  lna_f32x2 p = lna_pk_fma(lna_pk(1.061405429f), t, lna_pk(-1.453152027f));
+  p = lna_pk_fma(p, t, lna_pk(1.421413741f));
+  p = lna_pk_fma(p, t, lna_pk(-0.284496736f));
+  p = lna_pk_fma(p, t, lna_pk(0.254829592f));
+  const lna_f32x2 e = u * u * lna_pk(-1.4426950408889634f);
+  lna_f32x2 ex;
+  ex.x = __builtin_amdgcn_exp2f(e.x); ex.y = __builtin_amdgcn_exp2f(e.y);
+  const lna_f32x2 pe = p * t * ex;
+  return ((y + ay) - ay * pe) * lna_pk(0.5f);
 }
 
-__device__ __forceinline__ float lna_act(float y, int act) {
-  if (act == 1) return fmaxf(y, 0.0f);
-  if (act == 2) return lna_gelu(y);
+__device__ __forceinline__ lna_f32x2 lna_act2(lna_f32x2 y, int act) {
+  if (act == 1) return lna_f32x2{fmaxf(y.x, 0.0f), fmaxf(y.y, 0.0f)};
+  if (act == 2) return lna_gelu2(y);
   return y;
 }
 
@@ -129,10 +156,14 @@ __device__ __forceinline__ void lna_stage_vectors(const LnaArgs& a, int ch_base,
 // `vec` = this slice's bias | gamma | beta, 128 floats each, staged in LDS once per workgroup: as ordinary global loads in
 // here every one of them was followed by the `vmcnt(0)` hipcc emits at the first use of a load beside an LDS-DMA — 24-48
 // serialized L2 round trips per row block (and a drain of the next block's prefetch each time).
-template <int T>
+template <int T, bool KEEP = false>  // KEEP: the activated values replace the accumulators (the segmented max reads them)
 __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[LNA_RG][T], int64_t row0, int ch_base, int rowl,
                                              int grp, const float* vec) {
   const float inv_c = 1.0f / (float)a.norm_w;
+  // the arithmetic below runs on pairs (v_pk_*_f32): the same IEEE operations per value as the scalar form, half the instructions
+  auto lo = [](const lna_f32x4& v) { return lna_f32x2{v[0], v[1]}; };
+  auto hi = [](const lna_f32x4& v) { return lna_f32x2{v[2], v[3]}; };
+  auto put = [](lna_f32x4& v, lna_f32x2 l, lna_f32x2 h) { v[0] = l.x; v[1] = l.y; v[2] = h.x; v[3] = h.y; };
 #pragma unroll
   for (int rg = 0; rg < LNA_RG; ++rg) {
     const int64_t row = row0 + 16 * rg + rowl;
@@ -141,7 +172,7 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const float4 b = *reinterpret_cast<const float4*>(vec + 16 * t + 4 * grp);  // (0 beyond c)
-        acc[rg][t][0] += b.x; acc[rg][t][1] += b.y; acc[rg][t][2] += b.z; acc[rg][t][3] += b.w;
+        put(acc[rg][t], lo(acc[rg][t]) + lna_f32x2{b.x, b.y}, hi(acc[rg][t]) + lna_f32x2{b.z, b.w});
       }
     }
     if (a.row_add) {  // all loads of the row first, then the adds: one wait instead of one per tile
@@ -158,50 +189,161 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
         }
 #pragma unroll
         for (int t = 0; t < TB; ++t) {
-          if (16 * (t0 + t) + 4 * grp < a.slice_w && ch_base + 16 * (t0 + t) + 4 * grp < a.c) {
-            acc[rg][t0 + t][0] += b[t].x; acc[rg][t0 + t][1] += b[t].y; acc[rg][t0 + t][2] += b[t].z; acc[rg][t0 + t][3] += b[t].w;
-          }
+          if (16 * (t0 + t) + 4 * grp < a.slice_w && ch_base + 16 * (t0 + t) + 4 * grp < a.c)
+            put(acc[rg][t0 + t], lo(acc[rg][t0 + t]) + lna_f32x2{b[t].x, b[t].y}, hi(acc[rg][t0 + t]) + lna_f32x2{b[t].z, b[t].w});
         }
       }
     }
     if (a.norm == 1) {  // LayerNorm over the c channels (channels >= c are exactly 0: zero weights, no bias)
-      float s = 0.0f;
+      lna_f32x2 s2 = lna_pk(0.0f);
 #pragma unroll
-      for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t) s2 = (s2 + lo(acc[rg][t])) + hi(acc[rg][t]);
+      mean = lna_row_sum(s2.x + s2.y) * inv_c;
+      const lna_f32x2 m2 = lna_pk(mean);
+      lna_f32x2 q2 = lna_pk(0.0f);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += acc[rg][t][r];
-      mean = lna_row_sum(s) * inv_c;
-      float q = 0.0f;
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = (16 * t + 4 * grp + r < a.slice_w && ch_base + 16 * t + 4 * grp + r < a.c) ? acc[rg][t][r] - mean : 0.0f;
-          q += d * d;
-        }
-      rstd = rsqrtf(lna_row_sum(q) * inv_c + a.eps);
+      for (int t = 0; t < T; ++t) {
+        const bool live = 16 * t + 4 * grp < a.slice_w && ch_base + 16 * t + 4 * grp < a.c;  // (widths are multiples of 4)
+        const lna_f32x2 dl = live ? lo(acc[rg][t]) - m2 : lna_pk(0.0f), dh = live ? hi(acc[rg][t]) - m2 : lna_pk(0.0f);
+        q2 = lna_pk_fma(dl, dl, q2);
+        q2 = lna_pk_fma(dh, dh, q2);
+      }
+      rstd = rsqrtf(lna_row_sum(q2.x + q2.y) * inv_c + a.eps);
     }
-    if (row < a.n) {
+    if (row < a.n || KEEP) {
       float* orow = a.out + row * a.out_stride;
+      const lna_f32x2 m2 = lna_pk(mean), r2 = lna_pk(rstd);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         const int ch0 = ch_base + 16 * t + 4 * grp;
         if (16 * t + 4 * grp < a.slice_w && ch0 < a.c) {
           const float4 g = *reinterpret_cast<const float4*>(vec + 128 + 16 * t + 4 * grp);  // (1 / 0 without a norm)
           const float4 b = *reinterpret_cast<const float4*>(vec + 256 + 16 * t + 4 * grp);
-          float4 y;
-          y.x = lna_act((acc[rg][t][0] - mean) * rstd * g.x + b.x, a.act);
-          y.y = lna_act((acc[rg][t][1] - mean) * rstd * g.y + b.y, a.act);
-          y.z = lna_act((acc[rg][t][2] - mean) * rstd * g.z + b.z, a.act);
-          y.w = lna_act((acc[rg][t][3] - mean) * rstd * g.w + b.w, a.act);
+          const lna_f32x2 yl = lna_act2((lo(acc[rg][t]) - m2) * r2 * lna_f32x2{g.x, g.y} + lna_f32x2{b.x, b.y}, a.act);
+          const lna_f32x2 yh = lna_act2((hi(acc[rg][t]) - m2) * r2 * lna_f32x2{g.z, g.w} + lna_f32x2{b.z, b.w}, a.act);
+          const float4 y = make_float4(yl.x, yl.y, yh.x, yh.y);
+          if (KEEP) put(acc[rg][t], yl, yh);
 #ifndef FSF_ABL_LNA_NO_STORE
-          *reinterpret_cast<float4*>(orow + ch0) = y;
+          if (!KEEP || (a.out && row < a.n)) *reinterpret_cast<float4*>(orow + ch0) = y;
 #else
           if (y.x == 123.456f) *reinterpret_cast<float4*>(orow + ch0) = y;
 #endif
         }
       }
     }
+  }
+}
+
+
+// ---- K22s: segmented max of the activated tile, rows sorted by segment ------------------------------------------------
+// Per 16-row group a segmented max-scan along the rows (16 lanes of a DPP row per channel quad), then per run:
+//   closed (the segment starts and ends inside the group)  -> its last lane stores the maximum,
+//   open at the head and / or the tail                      -> one of the group's two LDS slots (in the weight buffer the last
+//                                                              chunk just left free), merged in row order by 128 threads with
+//                                                              the maximum carried from the previous blocks of this workgroup.
+// A workgroup walks a CONTIGUOUS range of row blocks, so only the segments that straddle a range boundary (<= 2 per workgroup)
+// end in an atomic max; every other segment is stored once.  max is exact: the result does not depend on any order.
+constexpr int LNA_DPP_ROW_SHR = 0x110, LNA_DPP_ROW_SHL = 0x100;
+
+template <int CTRL>
+__device__ __forceinline__ float lna_dpp(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int lna_dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+
+struct LnaSegSmem {      // persistent part (behind the per-channel vectors)
+  float carry_val[128];
+  int carry_sid[2];
+  int slot_sid[16];
+};
+
+template <int T>
+__device__ __forceinline__ void lna_segmax(const LnaArgs& a, lna_f32x4 (&y)[LNA_RG][T], int64_t blk_row0, int wave, int rowl, int grp,
+                                           float* slots, LnaSegSmem* sm, int parity, int64_t wg_row_begin, int64_t wg_row_end,
+                                           bool last_block) {
+  const int lane = threadIdx.x & 63;
+  // all waves are done with the weight buffer the slots overlay
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS reads of the last chunk have returned
+  __builtin_amdgcn_s_barrier();
+  if (lane < 4) sm->slot_sid[4 * wave + lane] = -1;
+#pragma unroll
+  for (int rg = 0; rg < LNA_RG; ++rg) {
+    const int g = 2 * wave + rg;
+    const int64_t grow0 = blk_row0 + 16 * g;
+    const int64_t r = grow0 + rowl;
+    const int sid = (int)a.seg_ids[r < a.n ? r : a.n - 1];  // (rows past n repeat row n - 1 in every respect: the max is unchanged)
+    const int up1 = lna_dpp_i<LNA_DPP_ROW_SHR + 1>(-1, sid), up2 = lna_dpp_i<LNA_DPP_ROW_SHR + 2>(-1, sid);
+    const int up4 = lna_dpp_i<LNA_DPP_ROW_SHR + 4>(-1, sid), up8 = lna_dpp_i<LNA_DPP_ROW_SHR + 8>(-1, sid);
+    const int dn1 = lna_dpp_i<LNA_DPP_ROW_SHL + 1>(-1, sid);
+    const bool s1 = up1 == sid, s2 = up2 == sid, s4 = up4 == sid, s8 = up8 == sid;  // (ids are >= 0: -1 = no such lane)
+    const bool one_seg = __builtin_amdgcn_readfirstlane(sid) == __builtin_amdgcn_readlane(sid, 15);  // sorted: first == last
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = y[rg][t][e];
+        if (one_seg) {  // (wave-uniform) the whole group is one run: plain prefix maxima, no selects
+          v = fmaxf(v, lna_dpp<LNA_DPP_ROW_SHR + 1>(v, v));
+          v = fmaxf(v, lna_dpp<LNA_DPP_ROW_SHR + 2>(v, v));
+          v = fmaxf(v, lna_dpp<LNA_DPP_ROW_SHR + 4>(v, v));
+          v = fmaxf(v, lna_dpp<LNA_DPP_ROW_SHR + 8>(v, v));
+        } else {
+          float o = lna_dpp<LNA_DPP_ROW_SHR + 1>(v, v); v = s1 ? fmaxf(v, o) : v;
+          o = lna_dpp<LNA_DPP_ROW_SHR + 2>(v, v); v = s2 ? fmaxf(v, o) : v;
+          o = lna_dpp<LNA_DPP_ROW_SHR + 4>(v, v); v = s4 ? fmaxf(v, o) : v;
+          o = lna_dpp<LNA_DPP_ROW_SHR + 8>(v, v); v = s8 ? fmaxf(v, o) : v;
+        }
+        y[rg][t][e] = v;
+      }
+    const bool run_end = rowl == 15 || dn1 != sid;
+    if (run_end) {
+      const int s_begin = a.seg_offsets[sid], s_end = a.seg_offsets[sid + 1];
+      const bool head_open = s_begin < grow0, tail_open = s_end > grow0 + 16;
+      if (!head_open && !tail_open) {
+        float* dst = a.seg_out + (int64_t)sid * a.seg_out_stride;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          if (16 * t + 4 * grp < a.c)
+            *reinterpret_cast<float4*>(dst + 16 * t + 4 * grp) = make_float4(y[rg][t][0], y[rg][t][1], y[rg][t][2], y[rg][t][3]);
+      } else {
+        const int slot = 2 * g + (head_open ? 0 : 1);
+        if (grp == 0) sm->slot_sid[slot] = sid;
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+          *reinterpret_cast<float4*>(slots + slot * 128 + 16 * t + 4 * grp) = make_float4(y[rg][t][0], y[rg][t][1], y[rg][t][2], y[rg][t][3]);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int ch = threadIdx.x;
+    int cs = sm->carry_sid[parity];
+    float cv = sm->carry_val[ch];
+    auto flush = [&](int sid, float v) {
+      if (ch >= a.c) return;
+      const int64_t s_begin = a.seg_offsets[sid], s_end = a.seg_offsets[sid + 1];
+      float* p = a.seg_out + (int64_t)sid * a.seg_out_stride + ch;
+      if (s_begin >= wg_row_begin && s_end <= wg_row_end) *p = v;
+      else lna_atomic_max(p, v);
+    };
+    for (int s = 0; s < 16; ++s) {
+      const int ss = sm->slot_sid[s];
+      if (ss < 0) continue;
+      const float v = slots[s * 128 + ch];
+      if (ss == cs) cv = fmaxf(cv, v);
+      else {
+        if (cs >= 0) flush(cs, cv);
+        cs = ss;
+        cv = v;
+      }
+    }
+    if (cs >= 0 && (last_block || (int64_t)a.seg_offsets[cs + 1] <= blk_row0 + 16 * LNA_NW * LNA_RG)) {
+      flush(cs, cv);
+      cs = -1;
+    }
+    sm->carry_val[ch] = cv;
+    if (ch == 0) sm->carry_sid[parity ^ 1] = cs;
   }
 }
 

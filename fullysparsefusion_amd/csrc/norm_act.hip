@@ -32,7 +32,28 @@ __device__ __forceinline__ void gelu_terms(float y, float& pe, float& e) {
 __device__ __forceinline__ float gelu_erf(float y) {
   float pe, e;
   gelu_terms(y, pe, e);
-  return 0.5f * y * (y < 0.0f ? pe : 2.0f - pe);
+  return ((y + fabsf(y)) - fabsf(y) * pe) * 0.5f;  // = 0.5 y (y < 0 ? pe : 2 - pe) without the compare / select (K21 / K22: same form)
+}
+
+typedef float na_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ na_f32x2 na_pk(float v) { return na_f32x2{v, v}; }
+// two values per lane on v_pk_*_f32 (full rate on gfx950: half the instructions per value outside v_rcp / v_exp)
+__device__ __forceinline__ na_f32x2 gelu_erf2(na_f32x2 y) {
+  na_f32x2 ay;
+  ay.x = fabsf(y.x); ay.y = fabsf(y.y);
+  const na_f32x2 u = ay * na_pk(0.70710678118654752440f);
+  const na_f32x2 d = __builtin_elementwise_fma(na_pk(0.3275911f), u, na_pk(1.0f));
+  na_f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+  na_f32x2 p = __builtin_elementwise_fma(na_pk(1.061405429f), t, na_pk(-1.453152027f));
+  p = __builtin_elementwise_fma(p, t, na_pk(1.421413741f));
+  p = __builtin_elementwise_fma(p, t, na_pk(-0.284496736f));
+  p = __builtin_elementwise_fma(p, t, na_pk(0.254829592f));
+  const na_f32x2 e = u * u * na_pk(-1.4426950408889634f);
+  na_f32x2 ex;
+  ex.x = __builtin_amdgcn_exp2f(e.x); ex.y = __builtin_amdgcn_exp2f(e.y);
+  const na_f32x2 pe = p * t * ex;
+  return ((y + ay) - ay * pe) * na_pk(0.5f);
 }
 
 template <int TEAM, int ACT, int NORM, int PL = NA_MAX_PER_LANE>  // PL channels per lane (16 for the 1024-wide query MLPs)
@@ -168,20 +189,21 @@ __global__ void __launch_bounds__(256)
         for (int k = 0; k < PLV; ++k) {
           const int ch4 = tl + k * TEAM;
           if (ch4 < c4) {
-            float y[4] = {v[u][k].x, v[u][k].y, v[u][k].z, v[u][k].w};
-            const float gg[4] = {g[k].x, g[k].y, g[k].z, g[k].w}, bb[4] = {b[k].x, b[k].y, b[k].z, b[k].w};
+            na_f32x2 y[2] = {na_f32x2{v[u][k].x, v[u][k].y}, na_f32x2{v[u][k].z, v[u][k].w}};
+            const na_f32x2 gg[2] = {na_f32x2{g[k].x, g[k].y}, na_f32x2{g[k].z, g[k].w}};
+            const na_f32x2 bb[2] = {na_f32x2{b[k].x, b[k].y}, na_f32x2{b[k].z, b[k].w}};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 2; ++e) {  // (pairs: the same IEEE operations per value as the scalar form)
               if (NORM == NORM_LN) {
-                y[e] = (y[e] - mean) * rstd;
+                y[e] = (y[e] - na_pk(mean)) * na_pk(rstd);
                 if (gamma) y[e] = y[e] * gg[e] + bb[e];
               } else {
                 y[e] = y[e] * gg[e] + bb[e];
               }
-              if (ACT == ACT_RELU) y[e] = fmaxf(y[e], 0.0f);
-              if (ACT == ACT_GELU) y[e] = gelu_erf(y[e]);
+              if (ACT == ACT_RELU) y[e] = na_f32x2{fmaxf(y[e].x, 0.0f), fmaxf(y[e].y, 0.0f)};
+              if (ACT == ACT_GELU) y[e] = gelu_erf2(y[e]);
             }
-            reinterpret_cast<float4*>(out + (row0 + u) * out_stride)[ch4] = make_float4(y[0], y[1], y[2], y[3]);
+            reinterpret_cast<float4*>(out + (row0 + u) * out_stride)[ch4] = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
           }
         }
       }

@@ -49,7 +49,7 @@ __device__ __forceinline__ float si_gelu(float y) {
   p = fmaf(p, t, 0.254829592f);
   const float e = __builtin_amdgcn_exp2f(u * u * -1.4426950408889634f);
   const float pe = p * t * e;
-  return 0.5f * y * (y < 0.0f ? pe : 2.0f - pe);
+  return ((y + fabsf(y)) - fabsf(y) * pe) * 0.5f;  // = 0.5 y (y < 0 ? pe : 2 - pe) without the compare / select
 }
 
 __device__ __forceinline__ float si_act(float y, int act) {
@@ -59,6 +59,37 @@ __device__ __forceinline__ float si_act(float y, int act) {
 }
 
 typedef float si_f32x4 __attribute__((ext_vector_type(4)));
+typedef float si_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ si_f32x2 si_pk(float v) { return si_f32x2{v, v}; }
+__device__ __forceinline__ si_f32x2 si_pk_fma(si_f32x2 a, si_f32x2 b, si_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// The same GELU on TWO values per lane (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue at the rate of their scalar forms: everything
+// but v_rcp / v_exp costs half the instructions per value — this kernel is bound by instruction issue);
+// 0.5 y (1 + sign(y) (1 - pe)) = 0.5 ((y + |y|) - |y| pe): no compare / select.  The same form as K22's (linear_norm_act.hip).
+__device__ __forceinline__ si_f32x2 si_gelu2(si_f32x2 y) {
+  si_f32x2 ay;
+  ay.x = fabsf(y.x); ay.y = fabsf(y.y);
+  const si_f32x2 u = ay * si_pk(0.70710678118654752440f);
+  const si_f32x2 d = si_pk_fma(si_pk(0.3275911f), u, si_pk(1.0f));
+  si_f32x2 t;
+  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+  si_f32x2 p = si_pk_fma(si_pk(1.061405429f), t, si_pk(-1.453152027f));
+  p = si_pk_fma(p, t, si_pk(1.421413741f));
+  p = si_pk_fma(p, t, si_pk(-0.284496736f));
+  p = si_pk_fma(p, t, si_pk(0.254829592f));
+  const si_f32x2 e = u * u * si_pk(-1.4426950408889634f);
+  si_f32x2 ex;
+  ex.x = __builtin_amdgcn_exp2f(e.x); ex.y = __builtin_amdgcn_exp2f(e.y);
+  const si_f32x2 pe = p * t * ex;
+  return ((y + ay) - ay * pe) * si_pk(0.5f);
+}
+
+__device__ __forceinline__ si_f32x2 si_act2(si_f32x2 y, int act) {
+  if (act == 1) return si_f32x2{fmaxf(y.x, 0.0f), fmaxf(y.y, 0.0f)};
+  if (act == 2) return si_gelu2(y);
+  return y;
+}
 
 // sum over the 4 lanes that share a point row (lane = row + 16 * group)
 __device__ __forceinline__ float si_row_sum(float v) {
@@ -235,8 +266,12 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
       }
       const float rstd = rsqrtf(si_row_sum(q) * inv_h1 + a.eps);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        h1v[r] = 4 * grp + r < a.h1 ? si_act((acc1[r] - mean) * rstd * g1r[r] + b1r[r], ACT) : 0.0f;
+      for (int r = 0; r < 4; r += 2) {
+        const si_f32x2 y = si_act2((si_f32x2{acc1[r], acc1[r + 1]} - si_pk(mean)) * si_pk(rstd) * si_f32x2{g1r[r], g1r[r + 1]} +
+                                   si_f32x2{b1r[r], b1r[r + 1]}, ACT);
+        h1v[r] = 4 * grp + r < a.h1 ? y.x : 0.0f;
+        h1v[r + 1] = 4 * grp + r + 1 < a.h1 ? y.y : 0.0f;
+      }
     }
     // ---- layer 2: two 16-channel tiles, K = h1
     si_f32x4 acc2[2];
@@ -266,8 +301,12 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          h2v[t2][r] = 16 * t2 + 4 * grp + r < a.h2 ? si_act((acc2[t2][r] - mean) * rstd * g2r[t2][r] + b2r[t2][r], ACT) : 0.0f;
+        for (int r = 0; r < 4; r += 2) {
+          const si_f32x2 y = si_act2((si_f32x2{acc2[t2][r], acc2[t2][r + 1]} - si_pk(mean)) * si_pk(rstd) *
+                                     si_f32x2{g2r[t2][r], g2r[t2][r + 1]} + si_f32x2{b2r[t2][r], b2r[t2][r + 1]}, ACT);
+          h2v[t2][r] = 16 * t2 + 4 * grp + r < a.h2 ? y.x : 0.0f;
+          h2v[t2][r + 1] = 16 * t2 + 4 * grp + r + 1 < a.h2 ? y.y : 0.0f;
+        }
     }
     // ---- layer 3: NT3 tiles, K = h2 walked in (t2, r) order = the order the lanes hold h2v
     si_f32x4 acc3[NT3];
@@ -287,31 +326,30 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
       // of living in 2 x 4 NT3 scalar registers for the whole kernel)
       int lim = a.c - 4 * grp;
       asm volatile("" : "+v"(lim));
-      float s = 0.0f;
+      si_f32x2 s2 = si_pk(0.0f);
+#pragma unroll
+      for (int t3 = 0; t3 < NT3; ++t3) s2 = (s2 + si_f32x2{acc3[t3][0], acc3[t3][1]}) + si_f32x2{acc3[t3][2], acc3[t3][3]};
+      const float mean = si_row_sum(s2.x + s2.y) * inv_c;
+      si_f32x2 q2 = si_pk(0.0f);
 #pragma unroll
       for (int t3 = 0; t3 < NT3; ++t3)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s += acc3[t3][r];
-      const float mean = si_row_sum(s) * inv_c;
-      float q = 0.0f;
-#pragma unroll
-      for (int t3 = 0; t3 < NT3; ++t3)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = 16 * t3 + r < lim ? acc3[t3][r] - mean : 0.0f;
-          q += d * d;
+        for (int r = 0; r < 4; r += 2) {
+          si_f32x2 d = si_f32x2{acc3[t3][r], acc3[t3][r + 1]} - si_pk(mean);
+          d.x = 16 * t3 + r < lim ? d.x : 0.0f;
+          d.y = 16 * t3 + r + 1 < lim ? d.y : 0.0f;
+          q2 = si_pk_fma(d, d, q2);
         }
-      const float rstd = rsqrtf(si_row_sum(q) * inv_c + a.eps);
+      const float rstd = rsqrtf(si_row_sum(q2.x + q2.y) * inv_c + a.eps);
 #pragma unroll
       for (int t3 = 0; t3 < NT3; ++t3) {
         const int ch0 = 16 * t3 + 4 * grp;
         const float4 gv = *reinterpret_cast<const float4*>(g3s + ch0), bv = *reinterpret_cast<const float4*>(b3s + ch0);
-        float4 y;
-        y.x = si_act((acc3[t3][0] - mean) * rstd * gv.x + bv.x, ACT);
-        y.y = si_act((acc3[t3][1] - mean) * rstd * gv.y + bv.y, ACT);
-        y.z = si_act((acc3[t3][2] - mean) * rstd * gv.z + bv.z, ACT);
-        y.w = si_act((acc3[t3][3] - mean) * rstd * gv.w + bv.w, ACT);
-        *reinterpret_cast<float4*>(tile + rowl * TS + ch0) = y;  // (channels >= c: affine 0 -> act(0) = 0, never read)
+        const si_f32x2 yl = si_act2((si_f32x2{acc3[t3][0], acc3[t3][1]} - si_pk(mean)) * si_pk(rstd) * si_f32x2{gv.x, gv.y} +
+                                    si_f32x2{bv.x, bv.y}, ACT);
+        const si_f32x2 yh = si_act2((si_f32x2{acc3[t3][2], acc3[t3][3]} - si_pk(mean)) * si_pk(rstd) * si_f32x2{gv.z, gv.w} +
+                                    si_f32x2{bv.z, bv.w}, ACT);
+        *reinterpret_cast<float4*>(tile + rowl * TS + ch0) = make_float4(yl.x, yl.y, yh.x, yh.y);  // (channels >= c: affine 0 -> act(0) = 0, never read)
       }
     }
     // ---- product with the concatenated sources, lane = channel (the tile is private to this wave: its LDS writes are

@@ -147,10 +147,15 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
     assert gb.shape[0] == ob.shape[0] > 0
     assert good.sum() >= E2E_MIN_MATCHED_FRACTION * n, report
     assert report["unmatched_gpu"] <= E2E_MAX_UNMATCHED and report["unmatched_oracle"] <= E2E_MAX_UNMATCHED, report
-    assert cam["p999"] <= E2E_MAX_SIR_DEV_P999 and lid["p999"] <= E2E_MAX_SIR_DEV_P999, report
+    assert report["camera_queries"]["keys_identical"] and report["lidar_queries"]["keys_identical"], report
+    assert cam["p999"] <= E2E_MAX_CAMERA_SIR_DEV_P999 and lid["p999"] <= E2E_MAX_LIDAR_SIR_DEV_P999, report
 
 
-# thresholds: measured first (round 4, MI355X), then frozen — see DESIGN.md section 3
-E2E_MIN_MATCHED_FRACTION = 0.5
-E2E_MAX_UNMATCHED = 250
-E2E_MAX_SIR_DEV_P999 = 1.0
+# Thresholds: measured first (round 4, MI355X, gpurun_out/e2e_agreement_*.json -> DESIGN.md section 3), then frozen with margin.
+# Measured: 500 / 500 boxes matched on all three frames, worst matched IoU 0.99957, worst |dscore| 2.1e-5; query keys identical;
+# SIR group features 99.9th percentile 5.6e-3 (camera stack: rel_mlp's LayerNorms amplify the 1e-5 m centroid rounding) and
+# 3.4e-4 (LiDAR stack) of the feature scale.
+E2E_MIN_MATCHED_FRACTION = 0.99      # of the 500 returned boxes, matched at BEV IoU >= 0.99 with |dscore| <= 1e-3
+E2E_MAX_UNMATCHED = 5
+E2E_MAX_CAMERA_SIR_DEV_P999 = 2e-2
+E2E_MAX_LIDAR_SIR_DEV_P999 = 2e-3

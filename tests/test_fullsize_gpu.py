@@ -113,6 +113,11 @@ def test_hot_path_10sweep_vs_oracle(fsf_pair, frame10, device):
 def _hot_path_vs_oracle(model, cpu, f, device, min_clusters, min_lidar_points, min_camera_queries):
     pts8, mask, anno, L = (torch.from_numpy(f[k]) for k in ("points", "mask_data", "mask_anno", "lidar2img"))
     metas = [dict(lidar2img=f["lidar2img"])]
+    # centroids are fp32 (weighted) means over up to 1e5 points whose summation order differs (deterministic chunks here,
+    # sequential index_add in the oracle, atomics upstream): 2e-5 of the coordinate range (1e-3 m on nuScenes' 51.2 m, 4e-3 m on
+    # Argoverse 2's 204.8 m) — the oracle's own fp32 sum drifts by as much
+    tol_m = 2e-5 * float(pts8[:, :2].abs().max())
+    tol_m = max(tol_m, 1e-3)
     with torch.no_grad():
         out = model.forward_hot_path([pts8.to(device)], metas, mask.to(device)[None], anno.to(device)[None])
         s1 = omod.fsf_stage1(cpu, pts8, mask, anno, L)
@@ -158,10 +163,10 @@ def _hot_path_vs_oracle(model, cpu, f, device, min_clusters, min_lidar_points, m
     np.testing.assert_array_equal(f_preds.cpu().numpy(), s2["preds_2d"].numpy())
     # group centres: fp32 weighted means over up to 1e5 points per group whose summation order differs (deterministic
     # chunks here, sequential index_add in the oracle, atomics upstream): a few ulp of the 50 m coordinate range
-    assert float((f_centers.cpu() - s2["obj_centers"]).abs().max()) < 1e-3  # (2e-5 of the range; the oracle's own fp32 sum drifts)
+    assert float((f_centers.cpu() - s2["obj_centers"]).abs().max()) < tol_m
     # the camera-query SIR sees exactly the oracle's grouping (keys, duplicated points, order) ...
     np.testing.assert_array_equal(fcap["in"][2].cpu().numpy(), s2["sir_coors"].numpy())
-    assert float((fcap["in"][3].cpu() - s2["f_cluster"]).abs().max()) < 1e-3
+    assert float((fcap["in"][3].cpu() - s2["f_cluster"]).abs().max()) < tol_m
     # ... and, like the LiDAR-query SIR below, is ill-conditioned in f_cluster ~ 0 (three LayerNorm(eps=1e-3) of rel_mlp
     # amplify a 1e-5 m centroid difference ~30x each): features are compared on the IDENTICAL inputs the GPU pipeline fed it
     fp_, ffe, fco, ffc = [t.cpu() for t in fcap["in"]]
@@ -173,7 +178,7 @@ def _hot_path_vs_oracle(model, cpu, f, device, min_clusters, min_lidar_points, m
     close(f_feats[:, want_f.shape[1]:], s2["obj_feat"][:, want_f.shape[1]:])  # the 2-D prediction embedding
     np.testing.assert_array_equal(l_inds.cpu().numpy(), s3["cluster_inds"].numpy())
     np.testing.assert_array_equal(cap["in"][2].cpu().long().numpy(), s3["pts_cluster_inds"].long().numpy())
-    assert float((l_xyz.cpu() - s3["cluster_xyz"]).abs().max()) < 1e-3
+    assert float((l_xyz.cpu() - s3["cluster_xyz"]).abs().max()) < tol_m
     gp, gfe, gco, gfc = [t.cpu() for t in cap["in"]]
     with torch.no_grad():
         _, want_feats, want_coors = omod.sir_forward(cpu.backbone, gp, gfe, gco, gfc)
