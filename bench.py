@@ -526,6 +526,17 @@ def _acc_linear(a, k, out):
     return ("linear_norm_act", n * 4.0 * (kk + c) + (n * (8.0 + 4.0 * c) if grouped else 0.0), 2.0 * n * kk * c)
 
 
+def _acc_linear_segmax(a, k, out):
+    """K22s: the rows of K22 (x in; rows out unless `want_rows=False`) + the segmented max it fuses (8 B of segment id per row,
+    4 c B per segment written) — SURVEY 8(d)'s per-unit figures of the two kernels it replaces, minus the re-read of the rows."""
+    x, c, seg_offsets = a[0], int(a[2]), a[4]
+    n, kk = x.shape
+    m = seg_offsets.numel() - 1
+    grouped = k.get("row_add") is not None
+    rows_out = 4.0 * c if k.get("want_rows", True) else 0.0
+    return ("linear_norm_act_segmax", n * (4.0 * kk + rows_out + 8.0) + m * 4.0 * c + (n * 4.0 * c if grouped else 0.0), 2.0 * n * kk * c)
+
+
 def _acc_linear_sliced(a, k, out):
     x, kk, nslice, slice_c = a[0], int(a[1]), int(a[4]), int(a[5])
     n = x.size(0)
@@ -568,6 +579,7 @@ def instrumented_pass(model, pool, steps, hot_path_only):
     q.wrap(hip_ops, "sir_input", _acc_sir_input)
     q.wrap(hip_ops, "linear_norm_act", _acc_linear)
     q.wrap(hip_ops, "linear_norm_act_sliced", _acc_linear_sliced)
+    q.wrap(hip_ops, "linear_norm_act_segmax", _acc_linear_segmax)
     if hasattr(hip_ops, "project_score"):
         q.wrap(hip_ops, "project_score", _acc_project_score)
     try:
@@ -614,7 +626,7 @@ def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic_of):
         hbm[k] = dict(calls_per_step=v["calls"], ms_per_step=round(v["ms"], 3),
                       algorithmic_mb_per_step=round(v["bytes"] / 1e6, 1), gb_per_s=round(gbs, 1),
                       frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4))
-        if k == "linear_norm_act":
+        if k in ("linear_norm_act", "linear_norm_act_segmax"):
             hbm[k]["tflops_fp32_equivalent"] = round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)
         hbm_floor_ms += v["bytes"] / (HBM_PEAK_GBS * 1e6)
     conv_floor_ms = sum(v["flops"] / steps / (SPCONV_KERNELS[k][1] * 1e9) for k, v in conv.items())

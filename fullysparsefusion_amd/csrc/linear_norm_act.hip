@@ -352,14 +352,16 @@ __device__ __forceinline__ void lna_segmax(const LnaArgs& a, lna_f32x4 (&y)[LNA_
 // once per 384 rows.  Measured (round 3, same box): no faster in isolation (510 k x 256 -> 128: 277 vs 279 us; k = 128 .. 180: 5-15 %
 // SLOWER — a barrier over twelve waves per chunk) and 7 % slower in the frame (a 768-thread workgroup shuts the other stream's kernels
 // out of its CU) — so the weight stream is not what this kernel waits for.  Kept behind FSF_K22_WIDE_MIN_ROWS=<rows> (default: never).
-template <int T, int NW>  // 16-channel tiles (c <= 16 T)
+template <int T, int NW, bool SEG = false>  // 16-channel tiles (c <= 16 T); SEG: + segmented max of the output (rows sorted by segment)
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_act_kernel(LnaArgs a) {
   constexpr int LNA_NW = NW;
   constexpr int LNA_ROWS = NW * LNA_RG * 16;
   constexpr int CHUNK_U4 = T * 3 * 64;  // uint4 per weight chunk
+  static_assert(!SEG || (NW == 4 && CHUNK_U4 * 16 >= 16 * 128 * 4), "the segmented max parks 16 x 128 floats in a weight buffer");
   extern __shared__ __attribute__((aligned(16))) char lna_smem[];
-  uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4], then 384 floats of per-channel vectors
+  uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4], then 384 floats of per-channel vectors (, then LnaSegSmem)
   float* vec = reinterpret_cast<float*>(wbuf + 2 * CHUNK_U4);
+  LnaSegSmem* segsm = reinterpret_cast<LnaSegSmem*>(vec + 384);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rowl = lane & 15, grp = lane >> 4;
   const int nkc = (a.k + LNA_KC - 1) / LNA_KC;
@@ -410,15 +412,26 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_ac
       v[rg][4] = q.x; v[rg][5] = q.y; v[rg][6] = q.z; v[rg][7] = q.w;
     }
   };
+  // row blocks of this workgroup: strided over the grid, or (SEG) one contiguous range, so that a segment's rows meet in one
+  // workgroup wherever they can
+  const int64_t blk_first = SEG ? nblk * (int64_t)blockIdx.x / gridDim.x : (int64_t)blockIdx.x;
+  const int64_t seg_blk_end = SEG ? nblk * ((int64_t)blockIdx.x + 1) / gridDim.x : 0;
+#define LNA_BLK_END (SEG ? seg_blk_end : nblk)
+#define LNA_BLK_STEP (SEG ? 1 : gridDim.x)
+  if constexpr (SEG) {
+    if (threadIdx.x < 128) segsm->carry_val[threadIdx.x] = -INFINITY;
+    if (threadIdx.x < 2) segsm->carry_sid[threadIdx.x] = -1;
+  }
   lna_stage_vectors(a, ch_base, vec);
   float xc[LNA_RG][8];
   int buf = 0;
-  if ((int64_t)blockIdx.x < nblk) {
-    set_rows(blockIdx.x);
+  int seg_parity = 0;
+  if (blk_first < LNA_BLK_END) {
+    set_rows(blk_first);
     load_x(0, xc);
     stage_w(0, 0);
   }
-  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  for (int64_t blk = blk_first; blk < LNA_BLK_END; blk += LNA_BLK_STEP) {
     const int64_t row0 = blk * LNA_ROWS + (int64_t)wave * (LNA_RG * 16);
     lna_f32x4 acc[LNA_RG][T];
 #pragma unroll
@@ -457,9 +470,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_ac
         load_x(kc + 1, xc);
       }
 #ifndef FSF_ABL_LNA_NO_XBLK
-      else if (blk + gridDim.x < nblk) {  // first chunk of the next row block
+      else if (blk + LNA_BLK_STEP < LNA_BLK_END) {  // first chunk of the next row block
         stage_w(0, buf ^ 1);
-        set_rows(blk + gridDim.x);
+        set_rows(blk + LNA_BLK_STEP);
         load_x(0, xc);
       }
 #endif
@@ -494,8 +507,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_ac
             }
       }
     }
-    lna_epilogue<T>(a, acc, row0, ch_base, rowl, grp, vec);
+    lna_epilogue<T, SEG>(a, acc, row0, ch_base, rowl, grp, vec);
+    if constexpr (SEG) {  // (`buf` was flipped by the loop: the chunk loop's last buffer, free now, is buf ^ 1)
+      lna_segmax<T>(a, acc, blk * LNA_ROWS, wave, rowl, grp, reinterpret_cast<float*>(wbuf + (buf ^ 1) * CHUNK_U4), segsm, seg_parity,
+                    blk_first * LNA_ROWS, min(seg_blk_end * LNA_ROWS, a.n), blk + 1 == seg_blk_end);
+      seg_parity ^= 1;
+    }
   }
+#undef LNA_BLK_END
+#undef LNA_BLK_STEP
 }
 
 }  // namespace fsf
@@ -555,16 +575,20 @@ static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream) {
   int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;
   if (gx > nblk) gx = nblk;
   const dim3 grid((unsigned)gx, (unsigned)nslice);
-#define FSF_LNA(T_, NW_)                                                                                                \
+#define FSF_LNA(T_, NW_, SEG_)                                                                                          \
   do {                                                                                                                 \
-    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4;                                                    \
+    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4 + (SEG_ ? sizeof(LnaSegSmem) : 0);                   \
     static std::atomic<uint64_t> attr_done{0};                                                                         \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_, NW_>, (int)smem, attr_done));          \
-    hipLaunchKernelGGL((linear_norm_act_kernel<T_, NW_>), grid, dim3(NW_ * 64), smem, stream, a);                      \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_, NW_, SEG_>, (int)smem, attr_done));    \
+    hipLaunchKernelGGL((linear_norm_act_kernel<T_, NW_, SEG_>), grid, dim3(NW_ * 64), smem, stream, a);                \
   } while (0)
-  if (T == 2) FSF_LNA(2, 4);
-  else if (T == 4) FSF_LNA(4, 4);
-  else FSF_LNA(8, 4);
+  if (a.seg_out) {
+    if (T == 4) FSF_LNA(4, 4, true);
+    else if (T == 8) FSF_LNA(8, 4, true);
+    else return FSF_ERR_UNSUPPORTED;
+  } else if (T == 2) FSF_LNA(2, 4, false);
+  else if (T == 4) FSF_LNA(4, 4, false);
+  else FSF_LNA(8, 4, false);
 #undef FSF_LNA
   FSF_LAUNCH_CHECK();
   return FSF_OK;
@@ -584,7 +608,7 @@ extern "C" int fsf_linear_norm_act_sliced(const float* x, int64_t n, int32_t k, 
   if (x_stride < (int64_t)(nslice - 1) * x_slice_offset + k || out_stride < (int64_t)nslice * slice_c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n,
-            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset};
+            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset, nullptr, nullptr, nullptr, 0};
   return lna_launch(a, nslice, stream);
 }
 
@@ -617,6 +641,29 @@ extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k,
   if (x_stride < k || out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
-            row_add, row_add_index, row_add_stride, 128, (int)c, 0};
+            row_add, row_add_index, row_add_stride, 128, (int)c, 0, nullptr, nullptr, nullptr, 0};
   return lna_launch(a, lna_slices(c), stream);
+}
+
+extern "C" int fsf_linear_norm_act_segmax(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
+                                          const float* bias, const float* row_add, const int64_t* row_add_index,
+                                          int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta, float eps,
+                                          int32_t act, const int64_t* seg_ids, const int32_t* seg_offsets, int64_t num_segments,
+                                          float* seg_out, int64_t seg_out_stride, float* out, int64_t out_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if ((row_add == nullptr) != (row_add_index == nullptr)) return FSF_ERR_INVALID_ARG;
+  if (row_add && ((row_add_stride % 4) != 0 || row_add_stride < c || ((uintptr_t)row_add % 16) != 0)) return FSF_ERR_UNSUPPORTED;
+  if (n < 0 || k < 1 || c < 1 || !planes || norm < 0 || norm > 2 || act < 0 || act > 2 || (norm != 0 && (!gamma || !beta)) ||
+      num_segments < 0 || (n > 0 && (!x || !seg_ids || !seg_offsets || !seg_out || num_segments < 1)))
+    return FSF_ERR_INVALID_ARG;
+  // one 128-channel slice at most (the LayerNorm case of K22), more than 32 channels (the slots overlay a >= 12 KB weight buffer)
+  if (c > 128 || c <= 32 || (c % 4) != 0 || (x_stride % 4) != 0 || ((uintptr_t)x % 16) != 0 || (seg_out_stride % 4) != 0 ||
+      seg_out_stride < c || ((uintptr_t)seg_out % 16) != 0 || (out && ((out_stride % 4) != 0 || ((uintptr_t)out % 16) != 0)) ||
+      n >= ((int64_t)1 << 31))
+    return FSF_ERR_UNSUPPORTED;
+  if (x_stride < k || (out && out_stride < c)) return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
+            row_add, row_add_index, row_add_stride, 128, (int)c, 0, seg_ids, seg_offsets, seg_out, seg_out_stride};
+  return lna_launch(a, 1, stream);
 }

@@ -5,7 +5,8 @@ return triple; the single `torch.unique` of the stack (:68) is the HIP packed-ke
 import torch
 import torch.nn as nn
 
-from ...ops.sst_ops import unique_with_plan
+from .... import hip_ops, switches
+from ...ops.sst_ops import GatheredRows, plan_of, unique_with_plan
 from ...registry import BACKBONES, build_voxel_encoder
 
 
@@ -41,8 +42,44 @@ class SIR(nn.Module):
                 dropout=dropout,
             )))
         self.block_list = nn.ModuleList(blocks)
+        # Does the caller read the per-point features this stack returns first?  FSF / SingleStageFSD only consume the group
+        # features (FSF.py:436-447, single_stage_fsd.py:468-474) and say so; then the sorted path neither writes the last layer's
+        # rows nor un-sorts them, and the first return value is None.
+        self.point_feats_needed = True
+
+    def _forward_sorted(self, points, features, coors, f_cluster):
+        """Inference: the whole stack on rows SORTED by group (one permutation in, through the indices K21 reads its sources by):
+        a group's rows are then one contiguous run, and every `Linear -> LN -> GELU -> scatter_v2(max)` pair of sir.py:65-85 /
+        SIRLayer is ONE kernel (K22s) — the [n, 128] activations are read back by nothing but the next layer, the twelve
+        segmented-max launches and their gathers through `order` are gone, and the [g, 768] group features are written in place."""
+        new_coors, unq_inv, _ = unique_with_plan(coors)
+        m = new_coors.size(0)
+        plan = plan_of(unq_inv, m)
+        order = plan.order.long()
+        seg_ids = unq_inv.index_select(0, order)
+        pts_s, fcl_s = hip_ops.gather_rows(points, order), hip_ops.gather_rows(f_cluster, order)
+        feats = (GatheredRows(features.sources, features.index.index_select(0, order)) if isinstance(features, GatheredRows)
+                 else GatheredRows([features], order))
+        widths = [b.group_width() for b in self.block_list]
+        groups = torch.full((m, sum(widths)), float("-inf"), dtype=torch.float32, device=points.device)
+        col, rows = 0, None
+        for i, block in enumerate(self.block_list):
+            want = i < self.num_blocks - 1 or self.point_feats_needed
+            rows = block.forward_sorted(pts_s, feats, fcl_s, seg_ids, plan.seg_offsets, groups[:, col:col + widths[i]], want)
+            feats = rows
+            col += widths[i]
+        out_feats = None
+        if self.point_feats_needed:
+            out_feats = torch.empty_like(rows)
+            out_feats.index_copy_(0, order, rows)
+        return out_feats, groups, new_coors
 
     def forward(self, points, features, coors, f_cluster=None):
+        if (switches.SIR_SORTED and self.unique_once and f_cluster is not None and not torch.is_grad_enabled() and points.is_cuda
+                and points.dtype == torch.float32 and points.size(0) > 0 and f_cluster.dtype == torch.float32
+                and (isinstance(features, GatheredRows) or (features.dtype == torch.float32 and features.stride(1) == 1))
+                and all(getattr(b, "sorted_supported", lambda: False)() for b in self.block_list)):
+            return self._forward_sorted(points, features, coors, f_cluster)
         if self.unique_once:
             new_coors, unq_inv, _ = unique_with_plan(coors)
         else:

@@ -65,6 +65,8 @@ class FSF(SingleStageFSD):
         self.use_fsd, self.use_frustum = use_fsd, use_frustum
         self.frustum_obj_head = build_head(frustum_obj_head)
         self.frustum_sir = build_head(frustum_sir)
+        if hasattr(self.frustum_sir, "point_feats_needed"):
+            self.frustum_sir.point_feats_needed = False  # frustum_pooling reads the group features only (FSF.py:436-447)
         self.combine_frustum_feat_mlp = build_mlp(self.lidar_img_input_dim, [self.embed_dims], self.norm_cfg, act=self.act)
         self.encode_2d_mlp_cfg = encode_2d_mlp_cfg
         self.encode_2d_mlp = build_mlp(encode_2d_mlp_cfg["in_channel"], encode_2d_mlp_cfg["mlp_channel"],

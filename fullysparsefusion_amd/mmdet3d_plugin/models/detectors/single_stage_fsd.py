@@ -162,6 +162,8 @@ class SingleStageFSD(nn.Module):
         self.cluster_assigner.num_classes = self.num_classes
         self.print_info = {}
         self.as_rpn = bbox_head.get("as_rpn", False)
+        if hasattr(self.backbone, "point_feats_needed"):
+            self.backbone.point_feats_needed = bool(self.as_rpn)  # extract_feat only hands the per-point features on for an RPN
         self.runtime_info = dict() if self.cfg.get("disable_pretrain", False) else None
 
     def extract_feat(self, points, pts_feats, pts_cluster_inds, img_metas, center_preds):

@@ -9,9 +9,9 @@ in ascending (roi, point) order — i.e. sorted by the RoI index the SIR layers 
 import torch
 import torch.nn as nn
 
-from .... import hip_ops
+from .... import hip_ops, switches
 from ...ops.dynamic_point_pool_op import dynamic_point_pool
-from ...ops.sst_ops import unique_with_plan
+from ...ops.sst_ops import plan_of, unique_with_plan
 from ...registry import HEADS, ROI_EXTRACTORS, build_voxel_encoder
 
 
@@ -47,6 +47,7 @@ class DynamicPointROIExtractor(nn.Module):
             assert torch.isclose(info[:, 7] + info[:, 10], roi_per_pts[:, 3], atol=1e-4).all()
             assert torch.isclose(info[:, 8] + info[:, 11], roi_per_pts[:, 5], atol=1e-4).all()
         ext_pts_info = dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1], is_in_margin=info[:, -1])
+        roi_inds._fsf_sorted = True  # K17's rows come in ascending (roi, point) order: FullySparseBboxHead's groups are contiguous runs
         return inds, roi_inds, ext_pts_info
 
 
@@ -91,6 +92,23 @@ class FullySparseBboxHead(nn.Module):
         out_feats = pts_features
         f_cluster = torch.cat([pts_info["local_xyz"], pts_info["boundary_offset"], pts_info["is_in_margin"][:, None], rel_xyz],
                               dim=-1)
+        if (switches.SIR_SORTED and unq_inv is not None and getattr(roi_inds, "_fsf_sorted", False) and self.use_middle_cluster_feature
+                and not torch.is_grad_enabled() and pts_xyz.is_cuda and pts_xyz.dtype == torch.float32
+                and pts_features.dtype == torch.float32 and pts_features.stride(1) == 1
+                and all(getattr(b, "sorted_supported", lambda: False)() for b in self.block_list)):
+            # the pooled rows are sorted by RoI already: every Linear -> LN -> GELU -> max pair of the three blocks is one K22s launch,
+            # the [rois, 768] group features are written in place (see SIR._forward_sorted)
+            m = new_coors.size(0)
+            plan = plan_of(unq_inv, m)
+            widths = [b.group_width() for b in self.block_list]
+            groups = torch.full((m, sum(widths)), float("-inf"), dtype=torch.float32, device=pts_xyz.device)
+            col = 0
+            for i, block in enumerate(self.block_list):
+                out_feats = block.forward_sorted(pts_xyz, out_feats, f_cluster, unq_inv, plan.seg_offsets, groups[:, col:col + widths[i]],
+                                                 i < self.num_blocks - 1, extra=f_cluster if self.geo_input else None, extra_div=10.0)
+                col += widths[i]
+            out_coors = new_coors.squeeze(1)
+            return self.align_roi_feature_and_rois(groups, out_coors, len(rois)), self.get_nonempty_roi_mask(out_coors, len(rois))
         cluster_feat_list = []
         for i, block in enumerate(self.block_list):
             # in_feats = cat([pts_xyz, out_feats(, f_cluster / 10)], 1) (:127-132), folded into the block's input kernel

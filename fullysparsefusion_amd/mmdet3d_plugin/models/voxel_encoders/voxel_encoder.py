@@ -15,7 +15,8 @@ import torch.nn as nn
 
 from .... import hip_ops
 from ...ops.sst_ops import (build_mlp, fused_norm_act, gather_by_inverse, get_activation_layer, linear_norm_act,
-                            GatheredRows, GroupedConcat, point_group_concat, point_linear, scatter_v2, unique_with_plan)
+                            GatheredRows, GroupedConcat, point_group_concat, point_linear, scatter_v2, sorted_stack_forward,
+                            sorted_stack_supported, unique_with_plan)
 from ...registry import VOXEL_ENCODERS, build_norm_layer
 
 
@@ -217,6 +218,34 @@ class SIRLayer(nn.Module):
             features = hip_ops.sir_input(points, feats, f_cluster, self.xyz_normalizer, (*layers, eps), act, self.rel_dist_scaler,
                                          extra=extra, extra_div=extra_div)
         return self._run_vfe(features, coors, **kwargs)
+
+    # ---- inference on rows SORTED by group (SIR.forward / FullySparseBboxHead permute once per stack) -------------------
+    def sorted_supported(self):
+        """K21 takes the position MLP and K22s (Linear + norm + act + segmented max in one pass) every layer of the stack."""
+        single_with_shortcut = (len(self.vfe_layers) == 1 and self.with_shortcut
+                                and self.vfe_layers[0].linear.out_features == self.in_channels)
+        return (not self.training and self._fused_input_layers() is not None and not single_with_shortcut
+                and sorted_stack_supported(self.vfe_layers, self.mode))
+
+    def group_width(self):
+        return sum(v.linear.out_features for v in self.vfe_layers)
+
+    def forward_sorted(self, points, feats, f_cluster, seg_ids, seg_offsets, group_out, want_rows, extra=None, extra_div=1.0,
+                       rows_index=None):
+        """One block on rows sorted by group.  `points` / `f_cluster` / `extra` are in sorted order already; `feats` is either a
+        tensor in sorted order or — with `rows_index` (sorted row -> source row) or as GatheredRows — read through an index by K21.
+        group_out f32 [m, group_width()] (holding -inf) receives the block's group features; returns the point rows (sorted),
+        or None unless `want_rows`."""
+        layers, eps, act = self._fused_input_layers()
+        if isinstance(feats, GatheredRows):
+            sources, index = feats.sources, feats.index
+        elif rows_index is not None:
+            sources, index = [feats], rows_index
+        else:
+            sources, index = feats, None
+        features = hip_ops.sir_input(points, sources, f_cluster, self.xyz_normalizer, (*layers, eps), act, self.rel_dist_scaler,
+                                     extra=extra, extra_div=extra_div, feats_index=index)
+        return sorted_stack_forward(self.vfe_layers, features, seg_ids, seg_offsets, group_out, want_rows)
 
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None, return_both=False,
                 unq_inv_once=None, new_coors_once=None):

@@ -215,6 +215,81 @@ def _grouped_linear_norm_act(linear, norm, act, gc):
                                    eps=eps, act=act_code, row_add=table, row_add_index=inv.contiguous())
 
 
+def _k22_norm_act(norm, act, out_features):
+    """(norm kind, gamma, beta, eps, act code) of a [norm, act] pair K22's epilogue covers, else None."""
+    act_code = "relu" if isinstance(act, nn.ReLU) else (
+        "gelu" if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none" else None)
+    if act_code is None:
+        return None
+    if isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1 and norm.elementwise_affine and out_features <= 128:
+        return "ln", norm.weight, norm.bias, norm.eps, act_code
+    if isinstance(norm, nn.BatchNorm1d) and not norm.training and norm.track_running_stats:
+        from .spconv import _bn_affine
+
+        gamma, beta = _bn_affine(norm)
+        return "affine", gamma, beta, 0.0, act_code
+    return None
+
+
+def sorted_stack_supported(vfe_layers, mode):
+    """Can the `DynamicVFELayer`s of a SIRLayer run as K22s launches (Linear + norm + act + segmented max in one pass over rows
+    sorted by segment)?  Every layer: plain nn.Linear into 36..128 channels (a multiple of 4), LayerNorm / eval BatchNorm, ReLU /
+    exact GELU, no dropout; the reduction is a max; every layer after the first takes `cat(point, group[inv])` of the previous."""
+    if mode != "max" or len(vfe_layers) == 0:
+        return False
+    prev = None
+    for i, vfe in enumerate(vfe_layers):
+        lin = vfe.linear
+        c = lin.out_features
+        if (type(lin) is not nn.Linear and not isinstance(lin, nn.Linear)) or vfe.dropout is not None or c % 4 or not 32 < c <= 128:
+            return False
+        if _k22_norm_act(vfe.norm, vfe.act, c) is None:
+            return False
+        if i > 0 and (lin.in_features != 2 * prev or prev % 4):
+            return False
+        prev = c
+    return True
+
+
+def sorted_stack_forward(vfe_layers, x, seg_ids, seg_offsets, group_out, want_last_rows):
+    """The layer stack of one SIRLayer on rows SORTED by group: per layer ONE K22s launch (`fsf_linear_norm_act_segmax`) computes
+    point_feats = act(norm(linear(.))) and the group maxima; from the second layer on the input `cat([point, group[inv]], 1)` is
+    taken as `point W_left^T + (group W_right^T)[seg_ids]` (the right half once per group, added per row in the epilogue).
+    `group_out` f32 [m, sum of the layers' widths] (pre-filled with -inf) receives the layers' group features side by side —
+    the `cat` of SIRLayer's return value is never formed.  Returns the last layer's point rows (None unless `want_last_rows`)."""
+    col = 0
+    point = x
+    for i, vfe in enumerate(vfe_layers):
+        lin = vfe.linear
+        c = lin.out_features
+        kind, gamma, beta, eps, act_code = _k22_norm_act(vfe.norm, vfe.act, c)
+        last = i == len(vfe_layers) - 1
+        seg_out = group_out[:, col:col + c]
+        if i == 0:
+            point = hip_ops.linear_norm_act_segmax(point, _prepared_planes(lin), c, seg_ids, seg_offsets, seg_out, bias=lin.bias,
+                                                   norm=kind, gamma=gamma, beta=beta, eps=eps, act=act_code,
+                                                   want_rows=(not last) or want_last_rows)
+        else:
+            c_left = point.size(1)
+            key = (lin.weight.data_ptr(), lin.weight._version, lin.weight.device, c_left)
+            cache = lin.__dict__.get("_fsf_planes_grouped")
+            if cache is None or cache[0] != key:
+                w = lin.weight.detach()
+                w_right = w[:, c_left:].contiguous()
+                cache = (key, hip_ops.linear_prepare_weight(w[:, :c_left].contiguous()), w_right, hip_ops.linear_prepare_weight(w_right))
+                lin.__dict__["_fsf_planes_grouped"] = cache
+            g = group_out[:, col - c_left:col]  # the previous layer's group maxima (a column slice: rows 16-byte aligned)
+            if g.size(0) >= _SMALL_N_MIN and hip_ops.linear_norm_act_supported(g, c):
+                table = hip_ops.linear_norm_act(g, cache[3], c)
+            else:
+                table = F.linear(g, cache[2])
+            point = hip_ops.linear_norm_act_segmax(point, cache[1], c, seg_ids, seg_offsets, seg_out, bias=lin.bias, norm=kind,
+                                                   gamma=gamma, beta=beta, eps=eps, act=act_code, row_add=table,
+                                                   row_add_index=seg_ids, want_rows=(not last) or want_last_rows)
+        col += c
+    return point
+
+
 _TRAIN_GROUPED = os.environ.get("FSF_TRAIN_GROUPED", "1") != "0"  # (A/B switch)
 
 

@@ -27,6 +27,7 @@ BOX_TAIL_FUSED = _on("FSF_BOX_TAIL_FUSED")            # inference: decode -> cla
 UNET_PLAN_STREAM = _on("FSF_UNET_PLAN_STREAM")        # inference: each level's rulebooks built one level ahead on a side stream
 HEAD_SLICED = _on("FSF_HEAD_SLICED")                # the head's attribute branches as one sliced K22 launch per layer
 SEG_HEAD_STACK = _on("FSF_SEG_HEAD_STACK")          # the segmentation head's two output Linears as one launch
+SIR_SORTED = _on("FSF_SIR_SORTED")                  # inference: SIR stacks on rows sorted by group, segmented max fused into K22 (K22s)
 SIR_GATHER = _on("FSF_SIR_GATHER")                  # first SIR layer reads the point features in place through an index
 FUSED_VOTE = _on("FSF_FUSED_VOTE")                  # vote centres + cluster-voxel keys in one kernel
 CLUSTER_ONE_UNIQUE = _on("FSF_CLUSTER_ONE_UNIQUE")  # a single unique in the cluster assignment

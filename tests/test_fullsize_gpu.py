@@ -303,9 +303,14 @@ def test_sir_stack_at_half_a_million_points_with_a_long_segment(fsf_pair, device
     ids[300000:330000] = 4242     # and a 3e4-row one
     coors = torch.from_numpy(np.stack([np.zeros(n), np.zeros(n), ids], 1).astype(np.int64))
     f_cluster = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32))
-    with torch.no_grad():
-        pf, cf, oc = model.frustum_sir(points.to(device), feats.to(device), coors.to(device), f_cluster.to(device))
-        opf, ocf, ooc = omod.sir_forward(cpu.frustum_sir, points, feats, coors, f_cluster)
+    sir = model.frustum_sir
+    sir.point_feats_needed = True  # (the detector itself does not read them)
+    try:
+        with torch.no_grad():
+            pf, cf, oc = sir(points.to(device), feats.to(device), coors.to(device), f_cluster.to(device))
+            opf, ocf, ooc = omod.sir_forward(cpu.frustum_sir, points, feats, coors, f_cluster)
+    finally:
+        sir.point_feats_needed = False
     np.testing.assert_array_equal(oc.cpu().numpy(), ooc.numpy())
     close(pf, opf)
     close(cf, ocf)

@@ -1662,3 +1662,52 @@ def test_nms_bev_binned_pairs_equal_all_pairs(ops, device, n):
             alive[i + 1:] &= ~hit[i, i + 1:]
     np.testing.assert_array_equal(keep, np.asarray(want))
     assert np.array_equal(keep, ops.nms_bev(b, thresh, False).cpu().numpy())
+
+
+@pytest.mark.parametrize("n,m,k,c,norm,act,grouped,long_seg", [
+    (300000, 9000, 180, 128, "ln", "gelu", False, 120000), (300000, 9000, 128, 128, "ln", "gelu", True, 120000),
+    (100000, 250, 136, 128, "ln", "gelu", False, 30000), (70001, 70001, 64, 64, "affine", "relu", True, 0),
+    (50000, 3000, 128, 36, "ln", "gelu", False, 0), (129, 5, 128, 128, "ln", "gelu", True, 0), (17, 17, 40, 128, "ln", "relu", False, 0),
+    (1, 1, 128, 128, "ln", "gelu", False, 0), (200000, 1, 128, 128, "ln", "gelu", True, 0)])
+def test_linear_norm_act_segmax_equals_the_two_pass_form(ops, device, n, m, k, c, norm, act, grouped, long_seg):
+    """K22s (`fsf_linear_norm_act_segmax`): rows sorted by segment -> the rows of fsf_linear_norm_act[_grouped] bit for bit, and the
+    segment maxima of fsf_segment_reduce(mode max) over them bit for bit (max is exact, whatever the combination order: closed runs
+    inside a 16-row group, the LDS slots of a 128-row block, the carry across a workgroup's blocks, the atomic max across
+    workgroups); segment lengths from 1 to > 1e5 rows (a segment that spans many workgroups), one segment only, n = 1; output into a
+    column slice of a wider buffer; `want_rows=False` writes no rows."""
+    torch.manual_seed(n + m + k)
+    if m == n:
+        ids = torch.arange(n, device=device)
+    else:
+        ids = torch.randint(0, m, (n,), device=device)
+        if long_seg:
+            ids[:long_seg] = min(17, m - 1)
+        ids[:m] = torch.maximum(ids[:m], torch.zeros_like(ids[:m]))
+        ids = torch.cat([torch.arange(m, device=device), ids])[:n] if n >= m else ids  # every id occurs (unique -> no empty segment)
+    ids = torch.sort(ids)[0]
+    uniq, inv = torch.unique(ids, return_inverse=True)
+    m_eff = uniq.numel()
+    plan = ops.segment_plan_from_inverse(inv, m_eff)
+    assert torch.equal(plan.order.long(), torch.arange(n, device=device))  # sorted input: the plan's order is the identity
+    x = torch.randn(n, k, device=device) * torch.exp(torch.randn(n, 1, device=device))
+    w = torch.randn(c, k, device=device) / k ** 0.5
+    gam, bet = torch.rand(c, device=device) + 0.5, torch.randn(c, device=device) * 0.1
+    planes = ops.linear_prepare_weight(w)
+    kw = dict(norm=norm, gamma=gam, beta=bet, eps=1e-3, act=act)
+    if grouped:
+        table = torch.randn(m_eff, c, device=device)
+        kw.update(row_add=table, row_add_index=inv)
+    rows = ops.linear_norm_act(x, planes, c, **kw)
+    want = ops.segment_reduce(rows, plan, "max")
+    wide = torch.full((m_eff, 2 * c + 4), float("-inf"), device=device)
+    seg_out = wide[:, c:2 * c]
+    got_rows = ops.linear_norm_act_segmax(x, planes, c, inv, plan.seg_offsets, seg_out, **kw)
+    assert torch.equal(got_rows, rows)
+    assert torch.equal(seg_out, want)
+    assert bool(torch.isinf(wide[:, :c]).all()) and bool(torch.isinf(wide[:, 2 * c:]).all())  # nothing written beside the slice
+    seg2 = torch.full((m_eff, c), float("-inf"), device=device)
+    assert ops.linear_norm_act_segmax(x, planes, c, inv, plan.seg_offsets, seg2, want_rows=False, **kw) is None
+    assert torch.equal(seg2, want)
+    # an independent yardstick for the maxima (torch's scatter-reduce over the same rows)
+    ref = torch.full((m_eff, c), float("-inf"), device=device).scatter_reduce(0, inv[:, None].expand(n, c), rows, "amax", include_self=True)
+    assert torch.equal(want, ref)

@@ -448,13 +448,31 @@ def test_sir_vs_oracle(fsf_pair, device):
     ids[:7000] = 3  # one giant group, like a truck's frustum
     coors = torch.from_numpy(np.stack([np.zeros(n), np.zeros(n), ids], 1).astype(np.int64))
     f_cluster = torch.from_numpy(rng.standard_normal((n, 3)).astype(np.float32))
+    from fullysparsefusion_amd import switches
+
+    sir = model.frustum_sir
+    assert sir.point_feats_needed is False  # the detector only reads the group features (FSF.py:436-447)
     with torch.no_grad():
-        pf, cf, oc = model.frustum_sir(points.to(device), feats.to(device), coors.to(device), f_cluster.to(device))
+        none_pf, cf_fast, _ = sir(points.to(device), feats.to(device), coors.to(device), f_cluster.to(device))
+        sir.point_feats_needed = True
+        try:
+            pf, cf, oc = sir(points.to(device), feats.to(device), coors.to(device), f_cluster.to(device))
+            switches.SIR_SORTED = False  # the segment-plan path (rows in input order, separate segmented-max launches)
+            try:
+                pf_plan, cf_plan, oc_plan = sir(points.to(device), feats.to(device), coors.to(device), f_cluster.to(device))
+            finally:
+                switches.SIR_SORTED = True
+        finally:
+            sir.point_feats_needed = False
         opf, ocf, ooc = omod.sir_forward(cpu.frustum_sir, points, feats, coors, f_cluster)
     np.testing.assert_array_equal(oc.cpu().numpy(), ooc.numpy())
     assert cf.shape == (ooc.shape[0], 768)
     close(pf, opf)
     close(cf, ocf)
+    # rows sorted by group + K22s (the default) == rows in input order + fsf_segment_reduce: every row's arithmetic is the same and
+    # max is exact, so the two paths agree bit for bit
+    assert none_pf is None and torch.equal(cf_fast, cf) and torch.equal(cf, cf_plan) and torch.equal(pf, pf_plan)
+    assert torch.equal(oc, oc_plan)
 
 
 def test_fsf_hot_path_vs_oracle(fsf_pair, frame1, device):

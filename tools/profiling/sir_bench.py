@@ -1,7 +1,7 @@
 """K21 (sir_input), K22 (fused Linear + LN + GELU, plain and grouped) and the segmented max at the LiDAR-query SIR stack's shapes
 (510 k points, 10 k groups) — one line per kernel; run once per library build (FSF_LIB_PATH=...) for a same-box A/B."""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+sys.path.insert(0, os.path.abspath(os.environ.get('FSF_ROOT') or os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')))
 from fullysparsefusion_amd import hip_ops as ops
 dev = torch.device('cuda:0')
 def t(f, it=20):
@@ -33,6 +33,15 @@ ids = torch.randint(0, g, (n,), device=dev)
 ids[:120000] = 17
 plan = ops.segment_plan_from_inverse(ids, g)
 out.append(f"segment max [n,128] (random order, one 120 k segment): {t(lambda: ops.segment_reduce(x, plan, 'max')):7.1f} us")
+if hasattr(ops, "linear_norm_act_segmax"):
+    sid = torch.sort(ids)[0]
+    u, sinv = torch.unique(sid, return_inverse=True)
+    splan = ops.segment_plan_from_inverse(sinv, u.numel())
+    so = torch.full((u.numel(), 128), float("-inf"), device=dev)
+    tb = torch.randn(u.numel(), 128, device=dev)
+    out.append(f"K22s grouped k=128->128 + segmax (sorted rows): {t(lambda: ops.linear_norm_act_segmax(x, planes, 128, sinv, splan.seg_offsets, so, norm='ln', gamma=gam, beta=bet, eps=1e-3, act='gelu', row_add=tb, row_add_index=sinv)):7.1f} us")
+    out.append(f"K22s (no rows written): {t(lambda: ops.linear_norm_act_segmax(x, planes, 128, sinv, splan.seg_offsets, so, norm='ln', gamma=gam, beta=bet, eps=1e-3, act='gelu', row_add=tb, row_add_index=sinv, want_rows=False)):7.1f} us")
+    out.append(f"segment max on sorted rows (plan path): {t(lambda: ops.segment_reduce(x, splan, 'max')):7.1f} us")
 xn = torch.randn(n, 1024, device=dev)[:20000]
 gam2 = torch.rand(1024, device=dev); bet2 = torch.randn(1024, device=dev)
 out.append(f"norm_act 20000 x 1024 ln gelu: {t(lambda: ops.norm_act(xn, gam2, bet2, 1e-3, 'ln', 'gelu')):7.1f} us")
