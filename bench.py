@@ -529,9 +529,9 @@ def _acc_linear(a, k, out):
 def _acc_linear_segmax(a, k, out):
     """K22s: the rows of K22 (x in; rows out unless `want_rows=False`) + the segmented max it fuses (8 B of segment id per row,
     4 c B per segment written) — SURVEY 8(d)'s per-unit figures of the two kernels it replaces, minus the re-read of the rows."""
-    x, c, seg_offsets = a[0], int(a[2]), a[4]
+    x, c, seg_out = a[0], int(a[2]), a[4]
     n, kk = x.shape
-    m = seg_offsets.numel() - 1
+    m = seg_out.size(0)
     grouped = k.get("row_add") is not None
     rows_out = 4.0 * c if k.get("want_rows", True) else 0.0
     return ("linear_norm_act_segmax", n * (4.0 * kk + rows_out + 8.0) + m * 4.0 * c + (n * 4.0 * c if grouped else 0.0), 2.0 * n * kk * c)

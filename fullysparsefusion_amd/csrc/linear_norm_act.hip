@@ -51,10 +51,10 @@ struct LnaArgs {
   // output channels per blockIdx.y slice (128 unless "sliced": independent layers side by side, one per slice), the width a
   // LayerNorm spans (c, or the slice width), and the column offset between the inputs of consecutive slices
   int slice_w, norm_w; int64_t x_slice_off;
-  // fused segmented max (K22s): rows arrive SORTED by segment (seg_ids nondecreasing, segment s = rows [seg_offsets[s],
-  // seg_offsets[s + 1])); seg_out[s, ch] = max over the segment's rows of the activated output.  seg_out must hold -inf on
-  // entry (segments that straddle two workgroups' row ranges are combined with atomic max).  `out` may then be null.
-  const int64_t* seg_ids; const int32_t* seg_offsets; float* seg_out; int64_t seg_out_stride;
+  // fused segmented max (K22s): rows arrive SORTED by segment (seg_ids nondecreasing); seg_out[s, ch] = max over the rows of
+  // segment s of the activated output.  seg_out must hold -inf on entry (a segment that reaches beyond one 128-row block is
+  // combined with atomic max).  `out` may then be null.
+  const int64_t* seg_ids; float* seg_out; int64_t seg_out_stride;
 };
 
 // max of two floats into memory, any signs, by integer atomics on the IEEE bit patterns (target initialised to -inf): a value
@@ -142,6 +142,137 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- K22s: segmented max of the activated tile, rows sorted by segment ------------------------------------------------
+// Per 16-row group a segmented max-scan along the rows (16 lanes of a DPP row per channel quad), then per run:
+//   closed (the segment starts and ends inside the group)  -> its last lane stores the maximum,
+//   open at the head and / or the tail                      -> one of the group's two LDS slots (in the weight buffer the last
+//                                                              chunk just left free), merged in row order by 128 threads.
+// Only a segment that reaches beyond its 128-row block (<= 2 per block) ends in an atomic max; every other segment is stored
+// once.  max is exact: the result does not depend on any order.  (A contiguous range of blocks per workgroup with the open
+// maximum carried from block to block — atomics only at the range ends — was built first and measured 10 % slower for the
+// whole kernel: 768 workgroups each streaming its own region lose to 768 workgroups sweeping one window.)
+// The scan runs inside the epilogue's tile loop (four values at a time, right after they are activated): nothing but the
+// per-group flags below outlives a tile.
+constexpr int LNA_DPP_ROW_SHR = 0x110, LNA_DPP_ROW_SHL = 0x100;
+
+template <int CTRL>
+__device__ __forceinline__ float lna_dpp(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int lna_dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+
+constexpr int LNA_SLOT_HEAD_OPEN = 1 << 29, LNA_SLOT_TAIL_OPEN = 1 << 30, LNA_SLOT_SID = (1 << 29) - 1;  // (-1 = empty slot)
+
+struct LnaSegSmem {      // persistent part (behind the per-channel vectors)
+  int slot_sid[16];      // segment | LNA_SLOT_HEAD_OPEN | LNA_SLOT_TAIL_OPEN, or -1
+};
+
+struct LnaSegCtx {       // per lane, for ONE 16-row group of its wave (built right before the group's tiles: half the live masks)
+  bool one_seg;          // (wave-uniform) the whole group is one run
+  bool s1, s2, s4, s8;   // the row 1 / 2 / 4 / 8 above belongs to the same segment
+  bool write, to_slot;   // this lane ends a run of a group that holds rows < n; the run is open (its maxima go to an LDS slot)
+  int dst;               // float offset of the run's row in seg_out (a closed run) or in the slots — 32 bits: a 64-bit pointer per
+                         // lane was spilled and re-read from scratch for every tile
+};
+
+struct LnaSegBlock {     // what the epilogue needs to build the groups' contexts
+  int sid[LNA_RG];       // segment of this lane's row in either group (requested at the top of the block: no exposed latency here)
+  int sid_before, sid_after;  // (wave-uniform) segment of the row above the wave's 32 rows / below them, -1 where there is none
+  int64_t blk_row0;
+  int wave;
+  float* slots;
+  LnaSegSmem* sm;
+};
+
+__device__ __forceinline__ float4 lna_seg_scan(const LnaSegCtx& sc, float4 y) {
+  float v[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float x = v[e];
+    if (sc.one_seg) {  // (wave-uniform) plain prefix maxima, no selects
+      x = fmaxf(x, lna_dpp<LNA_DPP_ROW_SHR + 1>(x, x));
+      x = fmaxf(x, lna_dpp<LNA_DPP_ROW_SHR + 2>(x, x));
+      x = fmaxf(x, lna_dpp<LNA_DPP_ROW_SHR + 4>(x, x));
+      x = fmaxf(x, lna_dpp<LNA_DPP_ROW_SHR + 8>(x, x));
+    } else {
+      float o = lna_dpp<LNA_DPP_ROW_SHR + 1>(x, x); x = sc.s1 ? fmaxf(x, o) : x;
+      o = lna_dpp<LNA_DPP_ROW_SHR + 2>(x, x); x = sc.s2 ? fmaxf(x, o) : x;
+      o = lna_dpp<LNA_DPP_ROW_SHR + 4>(x, x); x = sc.s4 ? fmaxf(x, o) : x;
+      o = lna_dpp<LNA_DPP_ROW_SHR + 8>(x, x); x = sc.s8 ? fmaxf(x, o) : x;
+    }
+    v[e] = x;
+  }
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// one group's segment ids -> scan flags, run ends and their destinations; called after the barrier that frees the slot buffer
+__device__ __forceinline__ LnaSegCtx lna_seg_prepare(const LnaArgs& a, const LnaSegBlock& sb, int rg, int rowl, int grp) {
+  LnaSegCtx sc;
+  const int g = 2 * sb.wave + rg;
+  const int64_t grow0 = sb.blk_row0 + 16 * g;
+  const int sid = sb.sid[rg];  // (rows past n repeat row n - 1 in every respect: the maxima are unchanged)
+  const int up1 = lna_dpp_i<LNA_DPP_ROW_SHR + 1>(-1, sid), up2 = lna_dpp_i<LNA_DPP_ROW_SHR + 2>(-1, sid);
+  const int up4 = lna_dpp_i<LNA_DPP_ROW_SHR + 4>(-1, sid), up8 = lna_dpp_i<LNA_DPP_ROW_SHR + 8>(-1, sid);
+  const int dn1 = lna_dpp_i<LNA_DPP_ROW_SHL + 1>(-1, sid);
+  sc.s1 = up1 == sid; sc.s2 = up2 == sid; sc.s4 = up4 == sid; sc.s8 = up8 == sid;  // (ids >= 0: -1 = no such lane)
+  sc.one_seg = __builtin_amdgcn_readfirstlane(sid) == __builtin_amdgcn_readlane(sid, 15);  // sorted: first == last
+  sc.write = sc.to_slot = false;
+  sc.dst = 0;
+  if (grow0 < a.n && (rowl == 15 || dn1 != sid)) {  // (a group past the last row forms no run: its slots stay empty)
+    sc.write = true;
+    // a run is open at the head iff it is the group's first run and the row above the group belongs to the same segment (ids are
+    // sorted), open at the tail iff it is the last run and the row below does: no look-up of the segment's bounds
+    const int first = __builtin_amdgcn_readfirstlane(sid), last = __builtin_amdgcn_readlane(sid, 15);
+    const int above = rg == 0 ? sb.sid_before : __builtin_amdgcn_readlane(sb.sid[0], 15);
+    const int below = rg == LNA_RG - 1 ? sb.sid_after : __builtin_amdgcn_readfirstlane(sb.sid[LNA_RG - 1]);
+    const bool head_open = sid == first && above == first, tail_open = sid == last && below == last;
+    if (!head_open && !tail_open) {
+      sc.dst = sid * (int)a.seg_out_stride;
+    } else {
+      const int slot = 2 * g + (head_open ? 0 : 1);
+      if (grp == 0) sb.sm->slot_sid[slot] = sid | (head_open ? LNA_SLOT_HEAD_OPEN : 0) | (tail_open ? LNA_SLOT_TAIL_OPEN : 0);
+      sc.to_slot = true;
+      sc.dst = slot * 128;
+    }
+  }
+  return sc;
+}
+
+// after every wave has parked its open runs: merge them in row order (128 threads, one per channel).  A segment whose parts all
+// lie in this 128-row block (its first slot is closed at the head, its last at the tail) is stored plainly; one that reaches into
+// a neighbouring block — some other workgroup's — is combined by atomic max: at most two per block, fire-and-forget.
+__device__ __forceinline__ void lna_seg_merge(const LnaArgs& a, const float* slots, const LnaSegSmem* sm) {
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int ch = threadIdx.x;
+    int cs = -1;  // segment | LNA_SLOT_HEAD_OPEN (it began above this block)
+    float cv = -INFINITY;
+    auto flush = [&](int tag, float v, bool complete) {
+      if (ch >= a.c) return;
+      float* p = a.seg_out + (int64_t)(tag & LNA_SLOT_SID) * a.seg_out_stride + ch;
+      if (complete && !(tag & LNA_SLOT_HEAD_OPEN)) *p = v;
+      else lna_atomic_max(p, v);
+    };
+    for (int s = 0; s < 16; ++s) {
+      const int ss = sm->slot_sid[s];
+      if (ss < 0) continue;
+      const float v = slots[s * 128 + ch];
+      if (cs >= 0 && (ss & LNA_SLOT_SID) == (cs & LNA_SLOT_SID)) cv = fmaxf(cv, v);
+      else {  // (an open segment always continues in the next occupied slot; kept general)
+        if (cs >= 0) flush(cs, cv, false);
+        cs = ss & (LNA_SLOT_SID | LNA_SLOT_HEAD_OPEN);
+        cv = v;
+      }
+      if (!(ss & LNA_SLOT_TAIL_OPEN)) {  // the segment ends in this group
+        flush(cs, cv, true);
+        cs = -1;
+      }
+    }
+    if (cs >= 0) flush(cs, cv, false);  // continues below this block
+  }
+}
+
 // epilogue of one row block: lane (row, g) holds channels ch_base + 16 t + 4 g + r of its row
 // bias | gamma | beta of the 128-channel slice at ch_base -> LDS (defaults 0 | 1 | 0 where absent or beyond c)
 __device__ __forceinline__ void lna_stage_vectors(const LnaArgs& a, int ch_base, float* vec) {
@@ -156,9 +287,11 @@ __device__ __forceinline__ void lna_stage_vectors(const LnaArgs& a, int ch_base,
 // `vec` = this slice's bias | gamma | beta, 128 floats each, staged in LDS once per workgroup: as ordinary global loads in
 // here every one of them was followed by the `vmcnt(0)` hipcc emits at the first use of a load beside an LDS-DMA — 24-48
 // serialized L2 round trips per row block (and a drain of the next block's prefetch each time).
-template <int T, bool KEEP = false>  // KEEP: the activated values replace the accumulators (the segmented max reads them)
+template <int T, bool SEG = false, int NORM_CT = -1, int ACT_CT = -1>  // SEG: the activated values also go through the segmented
+// max-scan; NORM_CT / ACT_CT >= 0: norm and activation fixed at compile time (the K22s variants: their epilogue is already twice
+// the code, and the run-time switches of the plain kernel would double it again)
 __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[LNA_RG][T], int64_t row0, int ch_base, int rowl,
-                                             int grp, const float* vec) {
+                                             int grp, const float* vec, const LnaSegBlock* sb = nullptr) {
   const float inv_c = 1.0f / (float)a.norm_w;
   // the arithmetic below runs on pairs (v_pk_*_f32): the same IEEE operations per value as the scalar form, half the instructions
   auto lo = [](const lna_f32x4& v) { return lna_f32x2{v[0], v[1]}; };
@@ -168,6 +301,14 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
   for (int rg = 0; rg < LNA_RG; ++rg) {
     const int64_t row = row0 + 16 * rg + rowl;
     float mean = 0.0f, rstd = 1.0f;
+    LnaSegCtx sc;
+    int g4 = 4 * grp;  // this lane's channel offset inside a tile
+    if constexpr (SEG) {
+      sc = lna_seg_prepare(a, *sb, rg, rowl, grp);
+      // (opaque: with the scan's live state on top, the compiler otherwise hoists the 64-bit per-lane store offsets of all tiles out
+      // of the block loop, spills them, and re-reads one from scratch in front of every tile's stores)
+      asm volatile("" : "+v"(g4));
+    }
     if (a.bias) {
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -194,7 +335,7 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
         }
       }
     }
-    if (a.norm == 1) {  // LayerNorm over the c channels (channels >= c are exactly 0: zero weights, no bias)
+    if ((NORM_CT >= 0 ? NORM_CT : a.norm) == 1) {  // LayerNorm over the c channels (channels >= c are exactly 0: zero weights, no bias)
       lna_f32x2 s2 = lna_pk(0.0f);
 #pragma unroll
       for (int t = 0; t < T; ++t) s2 = (s2 + lo(acc[rg][t])) + hi(acc[rg][t]);
@@ -210,149 +351,44 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
       }
       rstd = rsqrtf(lna_row_sum(q2.x + q2.y) * inv_c + a.eps);
     }
-    if (row < a.n || KEEP) {
+    if (row < a.n || SEG) {
       float* orow = a.out + row * a.out_stride;
       const lna_f32x2 m2 = lna_pk(mean), r2 = lna_pk(rstd);
 #pragma unroll
       for (int t = 0; t < T; ++t) {
-        const int ch0 = ch_base + 16 * t + 4 * grp;
-        if (16 * t + 4 * grp < a.slice_w && ch0 < a.c) {
+        const int ch0 = ch_base + 16 * t + g4;
+        if (16 * t + 4 * grp < a.slice_w && ch_base + 16 * t + 4 * grp < a.c) {
           const float4 g = *reinterpret_cast<const float4*>(vec + 128 + 16 * t + 4 * grp);  // (1 / 0 without a norm)
           const float4 b = *reinterpret_cast<const float4*>(vec + 256 + 16 * t + 4 * grp);
-          const lna_f32x2 yl = lna_act2((lo(acc[rg][t]) - m2) * r2 * lna_f32x2{g.x, g.y} + lna_f32x2{b.x, b.y}, a.act);
-          const lna_f32x2 yh = lna_act2((hi(acc[rg][t]) - m2) * r2 * lna_f32x2{g.z, g.w} + lna_f32x2{b.z, b.w}, a.act);
+          const lna_f32x2 yl = lna_act2((lo(acc[rg][t]) - m2) * r2 * lna_f32x2{g.x, g.y} + lna_f32x2{b.x, b.y}, ACT_CT >= 0 ? ACT_CT : a.act);
+          const lna_f32x2 yh = lna_act2((hi(acc[rg][t]) - m2) * r2 * lna_f32x2{g.z, g.w} + lna_f32x2{b.z, b.w}, ACT_CT >= 0 ? ACT_CT : a.act);
           const float4 y = make_float4(yl.x, yl.y, yh.x, yh.y);
-          if (KEEP) put(acc[rg][t], yl, yh);
 #ifndef FSF_ABL_LNA_NO_STORE
-          if (!KEEP || (a.out && row < a.n)) *reinterpret_cast<float4*>(orow + ch0) = y;
+          if (!SEG || (a.out && row < a.n)) *reinterpret_cast<float4*>(orow + ch0) = y;
 #else
           if (y.x == 123.456f) *reinterpret_cast<float4*>(orow + ch0) = y;
 #endif
+          if constexpr (SEG) {
+            const float4 mx = lna_seg_scan(sc, y);  // (a group past the last row scans copies of row n - 1 and writes nothing)
+            if (sc.write) {
+              if (sc.to_slot) *reinterpret_cast<float4*>(sb->slots + (sc.dst + 16 * t + g4)) = mx;
+              else *reinterpret_cast<float4*>(a.seg_out + (sc.dst + 16 * t + g4)) = mx;
+            }
+          }
         }
       }
     }
   }
 }
 
-
-// ---- K22s: segmented max of the activated tile, rows sorted by segment ------------------------------------------------
-// Per 16-row group a segmented max-scan along the rows (16 lanes of a DPP row per channel quad), then per run:
-//   closed (the segment starts and ends inside the group)  -> its last lane stores the maximum,
-//   open at the head and / or the tail                      -> one of the group's two LDS slots (in the weight buffer the last
-//                                                              chunk just left free), merged in row order by 128 threads with
-//                                                              the maximum carried from the previous blocks of this workgroup.
-// A workgroup walks a CONTIGUOUS range of row blocks, so only the segments that straddle a range boundary (<= 2 per workgroup)
-// end in an atomic max; every other segment is stored once.  max is exact: the result does not depend on any order.
-constexpr int LNA_DPP_ROW_SHR = 0x110, LNA_DPP_ROW_SHL = 0x100;
-
-template <int CTRL>
-__device__ __forceinline__ float lna_dpp(float old, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, 0xf, false));
-}
-template <int CTRL>
-__device__ __forceinline__ int lna_dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
-
-struct LnaSegSmem {      // persistent part (behind the per-channel vectors)
-  float carry_val[128];
-  int carry_sid[2];
-  int slot_sid[16];
-};
-
-template <int T>
-__device__ __forceinline__ void lna_segmax(const LnaArgs& a, lna_f32x4 (&y)[LNA_RG][T], int64_t blk_row0, int wave, int rowl, int grp,
-                                           float* slots, LnaSegSmem* sm, int parity, int64_t wg_row_begin, int64_t wg_row_end,
-                                           bool last_block) {
-  const int lane = threadIdx.x & 63;
-  // all waves are done with the weight buffer the slots overlay
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS reads of the last chunk have returned
-  __builtin_amdgcn_s_barrier();
-  if (lane < 4) sm->slot_sid[4 * wave + lane] = -1;
-#pragma unroll
-  for (int rg = 0; rg < LNA_RG; ++rg) {
-    const int g = 2 * wave + rg;
-    const int64_t grow0 = blk_row0 + 16 * g;
-    const int64_t r = grow0 + rowl;
-    const int sid = (int)a.seg_ids[r < a.n ? r : a.n - 1];  // (rows past n repeat row n - 1 in every respect: the max is unchanged)
-    const int up1 = lna_dpp_i<LNA_DPP_ROW_SHR + 1>(-1, sid), up2 = lna_dpp_i<LNA_DPP_ROW_SHR + 2>(-1, sid);
-    const int up4 = lna_dpp_i<LNA_DPP_ROW_SHR + 4>(-1, sid), up8 = lna_dpp_i<LNA_DPP_ROW_SHR + 8>(-1, sid);
-    const int dn1 = lna_dpp_i<LNA_DPP_ROW_SHL + 1>(-1, sid);
-    const bool s1 = up1 == sid, s2 = up2 == sid, s4 = up4 == sid, s8 = up8 == sid;  // (ids are >= 0: -1 = no such lane)
-    const bool one_seg = __builtin_amdgcn_readfirstlane(sid) == __builtin_amdgcn_readlane(sid, 15);  // sorted: first == last
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float v = y[rg][t][e];
-        if (one_seg) {  // (wave-uniform) the whole group is one run: plain prefix maxima, no selects
-          v = fmaxf(v, lna_dpp<LNA_DPP_ROW_SHR + 1>(v, v));
-          v = fmaxf(v, lna_dpp<LNA_DPP_ROW_SHR + 2>(v, v));
-          v = fmaxf(v, lna_dpp<LNA_DPP_ROW_SHR + 4>(v, v));
-          v = fmaxf(v, lna_dpp<LNA_DPP_ROW_SHR + 8>(v, v));
-        } else {
-          float o = lna_dpp<LNA_DPP_ROW_SHR + 1>(v, v); v = s1 ? fmaxf(v, o) : v;
-          o = lna_dpp<LNA_DPP_ROW_SHR + 2>(v, v); v = s2 ? fmaxf(v, o) : v;
-          o = lna_dpp<LNA_DPP_ROW_SHR + 4>(v, v); v = s4 ? fmaxf(v, o) : v;
-          o = lna_dpp<LNA_DPP_ROW_SHR + 8>(v, v); v = s8 ? fmaxf(v, o) : v;
-        }
-        y[rg][t][e] = v;
-      }
-    const bool run_end = rowl == 15 || dn1 != sid;
-    if (run_end) {
-      const int s_begin = a.seg_offsets[sid], s_end = a.seg_offsets[sid + 1];
-      const bool head_open = s_begin < grow0, tail_open = s_end > grow0 + 16;
-      if (!head_open && !tail_open) {
-        float* dst = a.seg_out + (int64_t)sid * a.seg_out_stride;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-          if (16 * t + 4 * grp < a.c)
-            *reinterpret_cast<float4*>(dst + 16 * t + 4 * grp) = make_float4(y[rg][t][0], y[rg][t][1], y[rg][t][2], y[rg][t][3]);
-      } else {
-        const int slot = 2 * g + (head_open ? 0 : 1);
-        if (grp == 0) sm->slot_sid[slot] = sid;
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-          *reinterpret_cast<float4*>(slots + slot * 128 + 16 * t + 4 * grp) = make_float4(y[rg][t][0], y[rg][t][1], y[rg][t][2], y[rg][t][3]);
-      }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < 128) {
-    const int ch = threadIdx.x;
-    int cs = sm->carry_sid[parity];
-    float cv = sm->carry_val[ch];
-    auto flush = [&](int sid, float v) {
-      if (ch >= a.c) return;
-      const int64_t s_begin = a.seg_offsets[sid], s_end = a.seg_offsets[sid + 1];
-      float* p = a.seg_out + (int64_t)sid * a.seg_out_stride + ch;
-      if (s_begin >= wg_row_begin && s_end <= wg_row_end) *p = v;
-      else lna_atomic_max(p, v);
-    };
-    for (int s = 0; s < 16; ++s) {
-      const int ss = sm->slot_sid[s];
-      if (ss < 0) continue;
-      const float v = slots[s * 128 + ch];
-      if (ss == cs) cv = fmaxf(cv, v);
-      else {
-        if (cs >= 0) flush(cs, cv);
-        cs = ss;
-        cv = v;
-      }
-    }
-    if (cs >= 0 && (last_block || (int64_t)a.seg_offsets[cs + 1] <= blk_row0 + 16 * LNA_NW * LNA_RG)) {
-      flush(cs, cv);
-      cs = -1;
-    }
-    sm->carry_val[ch] = cv;
-    if (ch == 0) sm->carry_sid[parity ^ 1] = cs;
-  }
-}
 
 // NW waves per workgroup.  A weight chunk enters the CU once per WORKGROUP and chunk (LDS-DMA), so three 4-wave workgroups per CU
 // take the same 24 KB in three times per 128 rows each; ONE 12-wave workgroup per CU (same 12 waves, same registers) takes it in
 // once per 384 rows.  Measured (round 3, same box): no faster in isolation (510 k x 256 -> 128: 277 vs 279 us; k = 128 .. 180: 5-15 %
 // SLOWER — a barrier over twelve waves per chunk) and 7 % slower in the frame (a 768-thread workgroup shuts the other stream's kernels
 // out of its CU) — so the weight stream is not what this kernel waits for.  Kept behind FSF_K22_WIDE_MIN_ROWS=<rows> (default: never).
-template <int T, int NW, bool SEG = false>  // 16-channel tiles (c <= 16 T); SEG: + segmented max of the output (rows sorted by segment)
+template <int T, int NW, bool SEG = false, int NORM_CT = -1, int ACT_CT = -1>  // 16-channel tiles (c <= 16 T); SEG: + segmented max of the
+// output (rows sorted by segment), norm / act fixed at compile time
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_act_kernel(LnaArgs a) {
   constexpr int LNA_NW = NW;
   constexpr int LNA_ROWS = NW * LNA_RG * 16;
@@ -414,18 +450,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_ac
   };
   // row blocks of this workgroup: strided over the grid, or (SEG) one contiguous range, so that a segment's rows meet in one
   // workgroup wherever they can
-  const int64_t blk_first = SEG ? nblk * (int64_t)blockIdx.x / gridDim.x : (int64_t)blockIdx.x;
-  const int64_t seg_blk_end = SEG ? nblk * ((int64_t)blockIdx.x + 1) / gridDim.x : 0;
-#define LNA_BLK_END (SEG ? seg_blk_end : nblk)
-#define LNA_BLK_STEP (SEG ? 1 : gridDim.x)
-  if constexpr (SEG) {
-    if (threadIdx.x < 128) segsm->carry_val[threadIdx.x] = -INFINITY;
-    if (threadIdx.x < 2) segsm->carry_sid[threadIdx.x] = -1;
-  }
+  const int64_t blk_first = blockIdx.x;
+#define LNA_BLK_END nblk
+#define LNA_BLK_STEP gridDim.x
   lna_stage_vectors(a, ch_base, vec);
   float xc[LNA_RG][8];
   int buf = 0;
-  int seg_parity = 0;
   if (blk_first < LNA_BLK_END) {
     set_rows(blk_first);
     load_x(0, xc);
@@ -433,6 +463,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_ac
   }
   for (int64_t blk = blk_first; blk < LNA_BLK_END; blk += LNA_BLK_STEP) {
     const int64_t row0 = blk * LNA_ROWS + (int64_t)wave * (LNA_RG * 16);
+    LnaSegBlock sb;
+    if constexpr (SEG) {  // the rows' segment ids (and those of the rows just above / below the wave's 32) arrive under the chunk loop
+#pragma unroll
+      for (int rg = 0; rg < LNA_RG; ++rg) {
+        const int64_t r = row0 + 16 * rg + rowl;
+        sb.sid[rg] = (int)a.seg_ids[r < a.n ? r : a.n - 1];
+      }
+      sb.sid_before = row0 > 0 ? (int)a.seg_ids[row0 - 1 < a.n ? row0 - 1 : a.n - 1] : -1;
+      sb.sid_after = row0 + 16 * LNA_RG < a.n ? (int)a.seg_ids[row0 + 16 * LNA_RG] : -1;
+    }
     lna_f32x4 acc[LNA_RG][T];
 #pragma unroll
     for (int rg = 0; rg < LNA_RG; ++rg)
@@ -507,11 +547,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_ac
             }
       }
     }
-    lna_epilogue<T, SEG>(a, acc, row0, ch_base, rowl, grp, vec);
     if constexpr (SEG) {  // (`buf` was flipped by the loop: the chunk loop's last buffer, free now, is buf ^ 1)
-      lna_segmax<T>(a, acc, blk * LNA_ROWS, wave, rowl, grp, reinterpret_cast<float*>(wbuf + (buf ^ 1) * CHUNK_U4), segsm, seg_parity,
-                    blk_first * LNA_ROWS, min(seg_blk_end * LNA_ROWS, a.n), blk + 1 == seg_blk_end);
-      seg_parity ^= 1;
+      float* slots = reinterpret_cast<float*>(wbuf + (buf ^ 1) * CHUNK_U4);
+      sb.blk_row0 = blk * LNA_ROWS; sb.wave = wave; sb.slots = slots; sb.sm = segsm;
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS reads of the last chunk have returned ...
+      __builtin_amdgcn_s_barrier();        // ... and so have every other wave's: the slots may overlay that buffer
+      if (lane < 4) segsm->slot_sid[4 * wave + lane] = -1;
+      lna_epilogue<T, true, NORM_CT, ACT_CT>(a, acc, row0, ch_base, rowl, grp, vec, &sb);
+      lna_seg_merge(a, slots, segsm);
+    } else {
+      lna_epilogue<T, false>(a, acc, row0, ch_base, rowl, grp, vec);
     }
   }
 #undef LNA_BLK_END
@@ -575,20 +620,23 @@ static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream) {
   int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;
   if (gx > nblk) gx = nblk;
   const dim3 grid((unsigned)gx, (unsigned)nslice);
-#define FSF_LNA(T_, NW_, SEG_)                                                                                          \
-  do {                                                                                                                 \
-    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4 + (SEG_ ? sizeof(LnaSegSmem) : 0);                   \
-    static std::atomic<uint64_t> attr_done{0};                                                                         \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_, NW_, SEG_>, (int)smem, attr_done));    \
-    hipLaunchKernelGGL((linear_norm_act_kernel<T_, NW_, SEG_>), grid, dim3(NW_ * 64), smem, stream, a);                \
+#define FSF_LNA(T_, NW_, SEG_, NORM_, ACT_)                                                                                          \
+  do {                                                                                                                              \
+    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4 + (SEG_ ? sizeof(LnaSegSmem) : 0);                                \
+    static std::atomic<uint64_t> attr_done{0};                                                                                      \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_, NW_, SEG_, NORM_, ACT_>, (int)smem, attr_done));    \
+    hipLaunchKernelGGL((linear_norm_act_kernel<T_, NW_, SEG_, NORM_, ACT_>), grid, dim3(NW_ * 64), smem, stream, a);                \
   } while (0)
-  if (a.seg_out) {
-    if (T == 4) FSF_LNA(4, 4, true);
-    else if (T == 8) FSF_LNA(8, 4, true);
+  if (a.seg_out) {  // K22s: LayerNorm + GELU / ReLU (the SIR layers), 36 .. 128 channels
+    if (a.norm != 1 || (a.act != 1 && a.act != 2)) return FSF_ERR_UNSUPPORTED;
+    if (T == 4 && a.act == 2) FSF_LNA(4, 4, true, 1, 2);
+    else if (T == 4) FSF_LNA(4, 4, true, 1, 1);
+    else if (T == 8 && a.act == 2) FSF_LNA(8, 4, true, 1, 2);
+    else if (T == 8) FSF_LNA(8, 4, true, 1, 1);
     else return FSF_ERR_UNSUPPORTED;
-  } else if (T == 2) FSF_LNA(2, 4, false);
-  else if (T == 4) FSF_LNA(4, 4, false);
-  else FSF_LNA(8, 4, false);
+  } else if (T == 2) FSF_LNA(2, 4, false, -1, -1);
+  else if (T == 4) FSF_LNA(4, 4, false, -1, -1);
+  else FSF_LNA(8, 4, false, -1, -1);
 #undef FSF_LNA
   FSF_LAUNCH_CHECK();
   return FSF_OK;
@@ -608,7 +656,7 @@ extern "C" int fsf_linear_norm_act_sliced(const float* x, int64_t n, int32_t k, 
   if (x_stride < (int64_t)(nslice - 1) * x_slice_offset + k || out_stride < (int64_t)nslice * slice_c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n,
-            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset, nullptr, nullptr, nullptr, 0};
+            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset, nullptr, nullptr, 0};
   return lna_launch(a, nslice, stream);
 }
 
@@ -641,29 +689,30 @@ extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k,
   if (x_stride < k || out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
-            row_add, row_add_index, row_add_stride, 128, (int)c, 0, nullptr, nullptr, nullptr, 0};
+            row_add, row_add_index, row_add_stride, 128, (int)c, 0, nullptr, nullptr, 0};
   return lna_launch(a, lna_slices(c), stream);
 }
 
 extern "C" int fsf_linear_norm_act_segmax(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
                                           const float* bias, const float* row_add, const int64_t* row_add_index,
                                           int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta, float eps,
-                                          int32_t act, const int64_t* seg_ids, const int32_t* seg_offsets, int64_t num_segments,
+                                          int32_t act, const int64_t* seg_ids, int64_t num_segments,
                                           float* seg_out, int64_t seg_out_stride, float* out, int64_t out_stride, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if ((row_add == nullptr) != (row_add_index == nullptr)) return FSF_ERR_INVALID_ARG;
   if (row_add && ((row_add_stride % 4) != 0 || row_add_stride < c || ((uintptr_t)row_add % 16) != 0)) return FSF_ERR_UNSUPPORTED;
   if (n < 0 || k < 1 || c < 1 || !planes || norm < 0 || norm > 2 || act < 0 || act > 2 || (norm != 0 && (!gamma || !beta)) ||
-      num_segments < 0 || (n > 0 && (!x || !seg_ids || !seg_offsets || !seg_out || num_segments < 1)))
+      num_segments < 0 || (n > 0 && (!x || !seg_ids || !seg_out || num_segments < 1)))
     return FSF_ERR_INVALID_ARG;
-  // one 128-channel slice at most (the LayerNorm case of K22), more than 32 channels (the slots overlay a >= 12 KB weight buffer)
-  if (c > 128 || c <= 32 || (c % 4) != 0 || (x_stride % 4) != 0 || ((uintptr_t)x % 16) != 0 || (seg_out_stride % 4) != 0 ||
+  // LayerNorm + ReLU / GELU (what SIRLayer puts in front of its max), one 128-channel slice at most, more than 32 channels (the
+  // slots overlay a >= 12 KB weight buffer)
+  if (norm != 1 || act == 0 || c > 128 || c <= 32 || (c % 4) != 0 || (x_stride % 4) != 0 || ((uintptr_t)x % 16) != 0 || (seg_out_stride % 4) != 0 ||
       seg_out_stride < c || ((uintptr_t)seg_out % 16) != 0 || (out && ((out_stride % 4) != 0 || ((uintptr_t)out % 16) != 0)) ||
-      n >= ((int64_t)1 << 31))
+      n >= ((int64_t)1 << 31) || num_segments >= LNA_SLOT_HEAD_OPEN || num_segments * seg_out_stride >= ((int64_t)1 << 31))
     return FSF_ERR_UNSUPPORTED;
   if (x_stride < k || (out && out_stride < c)) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
-            row_add, row_add_index, row_add_stride, 128, (int)c, 0, seg_ids, seg_offsets, seg_out, seg_out_stride};
+            row_add, row_add_index, row_add_stride, 128, (int)c, 0, seg_ids, seg_out, seg_out_stride};
   return lna_launch(a, 1, stream);
 }

@@ -95,7 +95,7 @@ _ARGTYPES = {
     "fsf_decode_cluster_boxes": [_P, c_i64, _P, c_i64, _P, c_i64, c_i64, c_i32, c_i32, c_f32, _P, _P, _P, _P],
     "fsf_class_rank_desc_workspace_bytes": [c_i64, c_i32],
     "fsf_class_rank_desc": [_P, c_i64, c_i32, c_f32, _P, _P, _P, _P, c_i64, _P],
-    "fsf_linear_norm_act_segmax": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, c_i64,
+    "fsf_linear_norm_act_segmax": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, _P, _P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, c_i64,
                                    _P, c_i64, _P, c_i64, _P],
     "fsf_nms_select_capacity": [],
     "fsf_box_tail_max_classes": [],
@@ -875,19 +875,18 @@ def linear_norm_act(x: torch.Tensor, planes: torch.Tensor, out_features: int, bi
     return out
 
 
-def linear_norm_act_segmax(x: torch.Tensor, planes: torch.Tensor, out_features: int, seg_ids: torch.Tensor, seg_offsets: torch.Tensor,
-                           seg_out: torch.Tensor, bias=None, norm: str = "none", gamma=None, beta=None, eps: float = 0.0,
-                           act: str = "none", row_add=None, row_add_index=None, want_rows=True):
-    """fsf_linear_norm_act_segmax (K22s): y = act(norm(x @ W^T + bias [+ row_add[row_add_index]])) for rows SORTED by segment
-    (seg_ids i64 [n] nondecreasing, seg_offsets i32 [m + 1]) and, in the same pass, seg_out[s] = max over the rows of segment s of
-    y — `seg_out` f32 [m, c] (a column slice of a wider buffer qualifies) must hold -inf on entry.  Returns y f32 [n, c], or None with
+def linear_norm_act_segmax(x: torch.Tensor, planes: torch.Tensor, out_features: int, seg_ids: torch.Tensor, seg_out: torch.Tensor,
+                           bias=None, norm: str = "ln", gamma=None, beta=None, eps: float = 0.0, act: str = "gelu", row_add=None,
+                           row_add_index=None, want_rows=True):
+    """fsf_linear_norm_act_segmax (K22s): y = act(LayerNorm(x @ W^T + bias [+ row_add[row_add_index]])) for rows SORTED by segment
+    (seg_ids i64 [n] nondecreasing, values < m) and, in the same pass, seg_out[s] = max over the rows of segment s of y — `seg_out`
+    f32 [m, c] (a column slice of a wider buffer qualifies) must hold -inf on entry.  Returns y f32 [n, c], or None with
     `want_rows=False` (the rows are then never written)."""
-    require_cuda(x, planes, bias, gamma, beta, row_add, row_add_index, seg_ids, seg_offsets, seg_out)
+    require_cuda(x, planes, bias, gamma, beta, row_add, row_add_index, seg_ids, seg_out)
     n, k = x.shape
     c = int(out_features)
-    m = seg_offsets.numel() - 1
-    assert seg_ids.dtype == torch.int64 and seg_ids.shape == (n,) and seg_ids.is_contiguous()
-    assert seg_offsets.dtype == torch.int32 and seg_offsets.is_contiguous() and m >= (1 if n else 0)
+    m = seg_out.size(0)
+    assert seg_ids.dtype == torch.int64 and seg_ids.shape == (n,) and seg_ids.is_contiguous() and m >= (1 if n else 0)
     assert seg_out.dtype == torch.float32 and seg_out.shape == (m, c) and seg_out.stride(1) == 1
     out = torch.empty((n, c), dtype=torch.float32, device=x.device) if want_rows else None
     xs = x.stride(0) if n > 1 else (k + 3) // 4 * 4
@@ -897,7 +896,7 @@ def linear_norm_act_segmax(x: torch.Tensor, planes: torch.Tensor, out_features: 
                 and row_add_index.dtype == torch.int64 and row_add_index.shape == (n,) and row_add_index.is_contiguous())
     check(_L().fsf_linear_norm_act_segmax(c_p(x.data_ptr()) if n else c_p(None), n, k, xs, ptr(planes), c, ptr(bias), ptr(row_add),
                                           ptr(row_add_index), row_add.stride(0) if row_add is not None else 0, norm_code, ptr(gamma),
-                                          ptr(beta), float(eps), act_code, ptr(seg_ids), ptr(seg_offsets), m,
+                                          ptr(beta), float(eps), act_code, ptr(seg_ids), m,
                                           c_p(seg_out.data_ptr()) if m else c_p(None), seg_out.stride(0) if m > 1 else (c + 3) // 4 * 4,
                                           ptr(out), c, stream_ptr()), "fsf_linear_norm_act_segmax")
     return out

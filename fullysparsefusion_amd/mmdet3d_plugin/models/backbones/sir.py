@@ -65,7 +65,7 @@ class SIR(nn.Module):
         col, rows = 0, None
         for i, block in enumerate(self.block_list):
             want = i < self.num_blocks - 1 or self.point_feats_needed
-            rows = block.forward_sorted(pts_s, feats, fcl_s, seg_ids, plan.seg_offsets, groups[:, col:col + widths[i]], want)
+            rows = block.forward_sorted(pts_s, feats, fcl_s, seg_ids, groups[:, col:col + widths[i]], want)
             feats = rows
             col += widths[i]
         out_feats = None

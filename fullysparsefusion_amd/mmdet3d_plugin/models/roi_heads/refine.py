@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .... import hip_ops, switches
 from ...ops.dynamic_point_pool_op import dynamic_point_pool
-from ...ops.sst_ops import plan_of, unique_with_plan
+from ...ops.sst_ops import unique_with_plan
 from ...registry import HEADS, ROI_EXTRACTORS, build_voxel_encoder
 
 
@@ -99,12 +99,11 @@ class FullySparseBboxHead(nn.Module):
             # the pooled rows are sorted by RoI already: every Linear -> LN -> GELU -> max pair of the three blocks is one K22s launch,
             # the [rois, 768] group features are written in place (see SIR._forward_sorted)
             m = new_coors.size(0)
-            plan = plan_of(unq_inv, m)
             widths = [b.group_width() for b in self.block_list]
             groups = torch.full((m, sum(widths)), float("-inf"), dtype=torch.float32, device=pts_xyz.device)
             col = 0
             for i, block in enumerate(self.block_list):
-                out_feats = block.forward_sorted(pts_xyz, out_feats, f_cluster, unq_inv, plan.seg_offsets, groups[:, col:col + widths[i]],
+                out_feats = block.forward_sorted(pts_xyz, out_feats, f_cluster, unq_inv, groups[:, col:col + widths[i]],
                                                  i < self.num_blocks - 1, extra=f_cluster if self.geo_input else None, extra_div=10.0)
                 col += widths[i]
             out_coors = new_coors.squeeze(1)

@@ -230,7 +230,7 @@ class SIRLayer(nn.Module):
     def group_width(self):
         return sum(v.linear.out_features for v in self.vfe_layers)
 
-    def forward_sorted(self, points, feats, f_cluster, seg_ids, seg_offsets, group_out, want_rows, extra=None, extra_div=1.0,
+    def forward_sorted(self, points, feats, f_cluster, seg_ids, group_out, want_rows, extra=None, extra_div=1.0,
                        rows_index=None):
         """One block on rows sorted by group.  `points` / `f_cluster` / `extra` are in sorted order already; `feats` is either a
         tensor in sorted order or — with `rows_index` (sorted row -> source row) or as GatheredRows — read through an index by K21.
@@ -245,7 +245,7 @@ class SIRLayer(nn.Module):
             sources, index = feats, None
         features = hip_ops.sir_input(points, sources, f_cluster, self.xyz_normalizer, (*layers, eps), act, self.rel_dist_scaler,
                                      extra=extra, extra_div=extra_div, feats_index=index)
-        return sorted_stack_forward(self.vfe_layers, features, seg_ids, seg_offsets, group_out, want_rows)
+        return sorted_stack_forward(self.vfe_layers, features, seg_ids, group_out, want_rows)
 
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None, return_both=False,
                 unq_inv_once=None, new_coors_once=None):

@@ -243,7 +243,8 @@ def sorted_stack_supported(vfe_layers, mode):
         c = lin.out_features
         if (type(lin) is not nn.Linear and not isinstance(lin, nn.Linear)) or vfe.dropout is not None or c % 4 or not 32 < c <= 128:
             return False
-        if _k22_norm_act(vfe.norm, vfe.act, c) is None:
+        na = _k22_norm_act(vfe.norm, vfe.act, c)
+        if na is None or na[0] != "ln":  # (K22s is built for LayerNorm + ReLU / GELU: what SIRLayer uses)
             return False
         if i > 0 and (lin.in_features != 2 * prev or prev % 4):
             return False
@@ -251,7 +252,7 @@ def sorted_stack_supported(vfe_layers, mode):
     return True
 
 
-def sorted_stack_forward(vfe_layers, x, seg_ids, seg_offsets, group_out, want_last_rows):
+def sorted_stack_forward(vfe_layers, x, seg_ids, group_out, want_last_rows):
     """The layer stack of one SIRLayer on rows SORTED by group: per layer ONE K22s launch (`fsf_linear_norm_act_segmax`) computes
     point_feats = act(norm(linear(.))) and the group maxima; from the second layer on the input `cat([point, group[inv]], 1)` is
     taken as `point W_left^T + (group W_right^T)[seg_ids]` (the right half once per group, added per row in the epilogue).
@@ -266,7 +267,7 @@ def sorted_stack_forward(vfe_layers, x, seg_ids, seg_offsets, group_out, want_la
         last = i == len(vfe_layers) - 1
         seg_out = group_out[:, col:col + c]
         if i == 0:
-            point = hip_ops.linear_norm_act_segmax(point, _prepared_planes(lin), c, seg_ids, seg_offsets, seg_out, bias=lin.bias,
+            point = hip_ops.linear_norm_act_segmax(point, _prepared_planes(lin), c, seg_ids, seg_out, bias=lin.bias,
                                                    norm=kind, gamma=gamma, beta=beta, eps=eps, act=act_code,
                                                    want_rows=(not last) or want_last_rows)
         else:
@@ -283,7 +284,7 @@ def sorted_stack_forward(vfe_layers, x, seg_ids, seg_offsets, group_out, want_la
                 table = hip_ops.linear_norm_act(g, cache[3], c)
             else:
                 table = F.linear(g, cache[2])
-            point = hip_ops.linear_norm_act_segmax(point, cache[1], c, seg_ids, seg_offsets, seg_out, bias=lin.bias, norm=kind,
+            point = hip_ops.linear_norm_act_segmax(point, cache[1], c, seg_ids, seg_out, bias=lin.bias, norm=kind,
                                                    gamma=gamma, beta=beta, eps=eps, act=act_code, row_add=table,
                                                    row_add_index=seg_ids, want_rows=(not last) or want_last_rows)
         col += c

@@ -285,17 +285,19 @@ int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_
                                 int64_t out_stride, void* stream);
 /* K22s: the same layer PLUS the segmented max that follows it in DynamicVFELayer / SIRLayer [UNVENDORED] —
  * `scatter_v2(point_feats, coors, mode='max')` (ops/sst_ops.py:150-177 over torch_scatter.scatter_max) — in one pass, for rows
- * that arrive SORTED by segment: seg_ids i64 [n] nondecreasing (the inverse of the rows' keys, in row order), seg_offsets i32
- * [num_segments + 1] (CSR: segment s = rows [seg_offsets[s], seg_offsets[s + 1])).  seg_out f32 [num_segments, seg_out_stride >=
- * c] receives max over each segment's rows of the activated output and MUST hold -inf on entry (a workgroup owns a contiguous
- * row range; only a segment that straddles two ranges is combined by atomic max — max is exact, the result is bit-identical to
- * fsf_segment_reduce(mode max) on `out`).  out f32 [n, c] or NULL (the rows are then never written: the last layer of a stack
- * whose point features nobody reads).  32 < c <= 128.  row_add / row_add_index as fsf_linear_norm_act_grouped, or both NULL. */
+ * that arrive SORTED by segment: seg_ids i64 [n] nondecreasing, values in [0, num_segments) (the inverse of the rows' keys, in row
+ * order).  seg_out f32 [num_segments, seg_out_stride >= c] receives max over each segment's rows of the activated output and MUST
+ * hold -inf on entry: per 16-row group a segmented max-scan across lanes, a 128-row block's open runs merged through LDS, and only
+ * a segment that reaches beyond its block is combined by atomic max — max is exact, so the result is bit-identical to
+ * fsf_segment_reduce(mode max) over `out`.  out f32 [n, c] or NULL (the rows are then never written: the last layer of a stack
+ * whose point features nobody reads).  norm 1 (LayerNorm), act 1 | 2, 32 < c <= 128, num_segments < 2^29,
+ * num_segments * seg_out_stride < 2^31; else FSF_ERR_UNSUPPORTED (the caller runs the two kernels).  row_add / row_add_index as
+ * fsf_linear_norm_act_grouped, or both NULL. */
 int fsf_linear_norm_act_segmax(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
                                const float* bias, const float* row_add, const int64_t* row_add_index, int64_t row_add_stride,
                                int32_t norm, const float* gamma, const float* beta, float eps, int32_t act,
-                               const int64_t* seg_ids, const int32_t* seg_offsets, int64_t num_segments, float* seg_out,
-                               int64_t seg_out_stride, float* out, int64_t out_stride, void* stream);
+                               const int64_t* seg_ids, int64_t num_segments, float* seg_out, int64_t seg_out_stride, float* out,
+                               int64_t out_stride, void* stream);
 /* "Sliced": nslice INDEPENDENT layers of slice_c (<= 128, % 4 == 0) output channels each in ONE launch — the per-attribute
  * MLPs of FSDSeparateHead (projects/mmdet3d_plugin/models/dense_heads/sparse_cluster_head_v2.py:18-50: center / dim / rot /
  * vel / score branches, every one `build_mlp(in, [hidden] * num_layer + [out_dim])` on the SAME query features) side by side:

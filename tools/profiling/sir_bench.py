@@ -39,8 +39,8 @@ if hasattr(ops, "linear_norm_act_segmax"):
     splan = ops.segment_plan_from_inverse(sinv, u.numel())
     so = torch.full((u.numel(), 128), float("-inf"), device=dev)
     tb = torch.randn(u.numel(), 128, device=dev)
-    out.append(f"K22s grouped k=128->128 + segmax (sorted rows): {t(lambda: ops.linear_norm_act_segmax(x, planes, 128, sinv, splan.seg_offsets, so, norm='ln', gamma=gam, beta=bet, eps=1e-3, act='gelu', row_add=tb, row_add_index=sinv)):7.1f} us")
-    out.append(f"K22s (no rows written): {t(lambda: ops.linear_norm_act_segmax(x, planes, 128, sinv, splan.seg_offsets, so, norm='ln', gamma=gam, beta=bet, eps=1e-3, act='gelu', row_add=tb, row_add_index=sinv, want_rows=False)):7.1f} us")
+    out.append(f"K22s grouped k=128->128 + segmax (sorted rows): {t(lambda: ops.linear_norm_act_segmax(x, planes, 128, sinv, so, norm='ln', gamma=gam, beta=bet, eps=1e-3, act='gelu', row_add=tb, row_add_index=sinv)):7.1f} us")
+    out.append(f"K22s (no rows written): {t(lambda: ops.linear_norm_act_segmax(x, planes, 128, sinv, so, norm='ln', gamma=gam, beta=bet, eps=1e-3, act='gelu', row_add=tb, row_add_index=sinv, want_rows=False)):7.1f} us")
     out.append(f"segment max on sorted rows (plan path): {t(lambda: ops.segment_reduce(x, splan, 'max')):7.1f} us")
 xn = torch.randn(n, 1024, device=dev)[:20000]
 gam2 = torch.rand(1024, device=dev); bet2 = torch.randn(1024, device=dev)
