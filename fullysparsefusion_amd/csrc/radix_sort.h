@@ -21,8 +21,9 @@ int64_t radix_sort_scratch_bytes(int64_t n);
 
 // Sorts n pairs by the low `key_bits` bits of the key.  keys_a/vals_a hold the input and are clobbered;
 // keys_b/vals_b are the alternate buffers.  On return *keys_out/*vals_out point at whichever buffer holds
-// the sorted result.  `hist` = u32[RS_BINS * (radix_num_tiles(n) + 1)].
+// the sorted result.  `hist` = u32[RS_BINS * (radix_num_tiles(n) + 1)]; `hist_zeroed`: the caller has cleared ALL of it on `stream`
+// already (one memset over several scratch arrays instead of one per helper).
 int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t* hist,
-                     int64_t n, int key_bits, uint64_t** keys_out, uint32_t** vals_out, hipStream_t stream);
+                     int64_t n, int key_bits, uint64_t** keys_out, uint32_t** vals_out, hipStream_t stream, bool hist_zeroed = false);
 
 }  // namespace fsf

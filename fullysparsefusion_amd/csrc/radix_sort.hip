@@ -246,7 +246,7 @@ int64_t radix_sort_scratch_bytes(int64_t n) {
 }
 
 int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, uint32_t* hist,
-                     int64_t n, int key_bits, uint64_t** keys_out, uint32_t** vals_out, hipStream_t stream) {
+                     int64_t n, int key_bits, uint64_t** keys_out, uint32_t** vals_out, hipStream_t stream, bool hist_zeroed) {
   uint64_t* kin = keys_a;
   uint32_t* vin = vals_a;
   uint64_t* kout = keys_b;
@@ -259,7 +259,7 @@ int radix_sort_pairs(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint3
     uint32_t* ticket = ghist + (int64_t)passes_all * RS_BINS;
     uint32_t* status = ticket + RS_BINS;
     const size_t zero_bytes = ((size_t)passes_all * RS_BINS + RS_BINS + (size_t)passes_all * tiles * RS_BINS) * 4;
-    if (hipMemsetAsync(hist, 0, zero_bytes, stream) != hipSuccess) return FSF_ERR_HIP;
+    if (!hist_zeroed && hipMemsetAsync(hist, 0, zero_bytes, stream) != hipSuccess) return FSF_ERR_HIP;
     hipLaunchKernelGGL(rs_hist_all_kernel, dim3((unsigned)tiles), dim3(RS_THREADS), 0, stream, kin, n, passes_all, ghist);
     for (int p = 0; p < passes_all; ++p) {
       hipLaunchKernelGGL(rs_onesweep_kernel, dim3((unsigned)tiles), dim3(RS_THREADS), 0, stream, kin, vin, kout, vout, n, p * 8,

@@ -163,11 +163,11 @@ __global__ void __launch_bounds__(SC_THREADS)
 // three-launch form (32-bit sums) runs.
 template <class In, class Out>
 static inline int exclusive_scan_u32(In in, Out out, int64_t n, uint32_t* tile_sums, uint32_t* total_u32,
-                                     int64_t* total_i64, hipStream_t stream, int64_t max_item = 1) {
+                                     int64_t* total_i64, hipStream_t stream, int64_t max_item = 1, bool tile_sums_zeroed = false) {
   if (max_item < 1) max_item = 1;
   if (n < (int64_t)SC_VALUE_MASK / max_item) {
     const int64_t tiles = scan_grid_tiles(n);
-    if (hipMemsetAsync(tile_sums, 0, (size_t)(tiles + 1) * 4, stream) != hipSuccess) return FSF_ERR_HIP;
+    if (!tile_sums_zeroed && hipMemsetAsync(tile_sums, 0, (size_t)(tiles + 1) * 4, stream) != hipSuccess) return FSF_ERR_HIP;
     hipLaunchKernelGGL((scan_lookback_kernel<In, Out>), dim3((unsigned)tiles), dim3(SC_THREADS), 0, stream, in, out, n, tile_sums,
                        tile_sums + tiles, tiles, total_u32, total_i64);
     FSF_LAUNCH_CHECK();

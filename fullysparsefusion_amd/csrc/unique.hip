@@ -134,9 +134,14 @@ struct HeadOut {
   }
 };
 
+// `ret` (optional): [0] = m, [1] = the key-range error flag — what the host reads back, in ONE 16-byte copy
 __global__ void uq_finish_kernel(const int64_t* __restrict__ m_dev, int64_t n, int32_t* __restrict__ seg_offsets,
-                                 int64_t* __restrict__ cnt) {
+                                 int64_t* __restrict__ cnt, const int32_t* __restrict__ err_flag = nullptr, int64_t* __restrict__ ret = nullptr) {
   const int64_t m = *m_dev;
+  if (ret && blockIdx.x == 0 && threadIdx.x == 0) {
+    ret[0] = m;
+    ret[1] = *err_flag;
+  }
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < m; s += (int64_t)gridDim.x * blockDim.x) {
     const int32_t lo = seg_offsets[s];
     const int32_t hi = (s + 1 < m) ? seg_offsets[s + 1] : (int32_t)n;
@@ -233,10 +238,14 @@ extern "C" int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const
   uint64_t* keys_b = ar.take<uint64_t>(n);
   uint32_t* vals_a = ar.take<uint32_t>(n);
   uint32_t* vals_b = ar.take<uint32_t>(n);
+  // [hist | tile_sums | err_flag (+ the read-back pair)] are consecutive: ONE memset clears what the sort, the scan and the packing
+  // kernel each used to clear for themselves
   uint32_t* hist = ar.take<uint32_t>((radix_num_tiles(n) + 1) * RS_BINS);
   uint32_t* tile_sums = ar.take<uint32_t>(scan_num_tiles(n));
-  ColRange* range_dev = ar.take<ColRange>(1);
   int32_t* err_flag = ar.take<int32_t>(1);
+  int64_t* ret_dev = ar.take<int64_t>(2);
+  const size_t zero_bytes = (size_t)((char*)ret_dev - (char*)hist);
+  ColRange* range_dev = ar.take<ColRange>(1);
   if (!ar.ok()) return FSF_ERR_WORKSPACE;
 
   const int grid = fsf_stream_grid(n, 256);
@@ -284,7 +293,7 @@ extern "C" int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const
     spec.mask[j] = bits[j] >= 64 ? ~0ull : ((1ull << bits[j]) - 1ull);
     sh += bits[j];
   }
-  FSF_HIP_TRY(hipMemsetAsync(err_flag, 0, sizeof(int32_t), stream));
+  FSF_HIP_TRY(hipMemsetAsync(hist, 0, zero_bytes, stream));
   switch (k) {
     case 1: hipLaunchKernelGGL((uq_pack_kernel<1>), dim3(grid), dim3(256), 0, stream, coors, n, spec, keys_a, vals_a, err_flag); break;
     case 2: hipLaunchKernelGGL((uq_pack_kernel<2>), dim3(grid), dim3(256), 0, stream, coors, n, spec, keys_a, vals_a, err_flag); break;
@@ -293,20 +302,20 @@ extern "C" int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const
   }
   uint64_t* keys_s;
   uint32_t* vals_s;
-  int rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, n, total_bits, &keys_s, &vals_s, stream);
+  int rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, n, total_bits, &keys_s, &vals_s, stream, true);
   if (rc != FSF_OK) return rc;
   HeadIn hin{keys_s};
   HeadOut hout{keys_s, vals_s, spec, new_coors, inv, order, seg_offsets};
-  rc = exclusive_scan_u32(hin, hout, n, tile_sums, nullptr, m_dev, stream);
+  rc = exclusive_scan_u32(hin, hout, n, tile_sums, nullptr, m_dev, stream, 1, true);
   if (rc != FSF_OK) return rc;
-  hipLaunchKernelGGL(uq_finish_kernel, dim3(grid), dim3(256), 0, stream, m_dev, n, seg_offsets, cnt);
+  hipLaunchKernelGGL(uq_finish_kernel, dim3(grid), dim3(256), 0, stream, m_dev, n, seg_offsets, cnt, err_flag, m_host ? ret_dev : nullptr);
   FSF_LAUNCH_CHECK();
   if (m_host) {
-    int32_t err_h = 0;
-    FSF_HIP_TRY(hipMemcpyAsync(m_host, m_dev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FSF_HIP_TRY(hipMemcpyAsync(&err_h, err_flag, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+    int64_t ret_h[2] = {0, 0};
+    FSF_HIP_TRY(hipMemcpyAsync(ret_h, ret_dev, sizeof(ret_h), hipMemcpyDeviceToHost, stream));  // (count + error flag in one copy)
     FSF_HIP_TRY(hipStreamSynchronize(stream));
-    if (err_h) return FSF_ERR_KEY_RANGE;
+    *m_host = ret_h[0];
+    if (ret_h[1]) return FSF_ERR_KEY_RANGE;
   }
   return FSF_OK;
 }
