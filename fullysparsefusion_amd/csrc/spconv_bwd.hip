@@ -216,6 +216,175 @@ __global__ void __launch_bounds__(256, 2) spconv_bwd_weight_kernel(SpconvBwdArgs
   }
 }
 
+// =====================================================================================================================
+// K10p (round 4): the same weight gradient on the bf16 matrix cores from an EXACT three-way split of both operands.
+//
+// The kernel above sits on v_mfma_f32_16x16x4_f32 — 1/16 of the 16-bit rate — at 0.5 of that pipe's peak.  Here, as in K22 / K9b:
+// x = hi + mid + lo with each piece the next 8 significant bits (truncation: exact, three bf16 cover the 24-bit significand), a * b =
+// the six leading cross products on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (dropped terms < 2^-23 of the product): fp32
+// accuracy at 2.7x the fp32 pipe's ceiling.
+// The reduction index of these GEMMs is the PAIR, and both operands arrive pair-major (a gathered feature row = one k index), while
+// the 16-bit MFMA wants 8 consecutive k of one channel in a lane's register.  So a stage of 32 pairs takes a detour through registers:
+//   * thread (channel quad cq = tid % 32, pair quad pq = tid / 32) loads a 4 pair x 4 channel micro-tile of either operand — for a
+//     fixed pair the 32 lanes of a half-wave read one whole 512-byte row: line-coalesced;
+//   * it splits the 16 values, and for each of its 4 channels packs the 4 pairs' hi (mid, lo) pieces into 8 bytes = 4 CONSECUTIVE k
+//     of that channel, written to a channel-major LDS image [plane][row(channel)][32 k] of 64-byte rows.  Bank arithmetic decides the
+//     rest: the bank period (256 B) is four rows, and at step c every thread writes a channel = c mod 4 — with rows in channel order
+//     all 64 lanes of a write would share a quarter of the banks (8-way conflicts; measured: the first version of this kernel spent
+//     as long in its LDS writes as in its MFMAs).  So channel ch lives in row (ch & 3) * 32 + (ch >> 2), a wave's lanes are
+//     (channel quad cq & 7, pair quad pq) — 8 consecutive quads still cover a whole 128-byte line of a gathered row — and the
+//     16-byte unit of a row is XOR-ed with ch & 3: a write instruction then touches every bank exactly twice (the minimum for
+//     512 bytes) and a fragment read — lane (m, kg) takes unit kg of channel 16 t + m — every bank once;
+//   * each wave owns a 64 x 64 corner of the 128 x 128 tile of grad_W[k]: its four A tiles' fragments (3 planes) stay in registers
+//     for the stage, the B tiles' stream through; 96 MFMAs per wave and stage.
+// One LDS image (48 KB: two workgroups per CU) and the NEXT stage's micro-tiles in flight in registers during the MFMAs; two barriers
+// per stage (image free -> written -> read).  Partial tiles and the fold kernel are the fp32 kernel's.
+typedef __bf16 bw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned bw_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int BWS_ROW = 64;                       // bytes per channel row of a plane: 32 k x bf16
+constexpr int BWS_PLANE = 128 * BWS_ROW;          // one plane of one operand
+constexpr int BWS_OPER = 3 * BWS_PLANE;           // hi | mid | lo
+constexpr int BWS_SMEM = 2 * BWS_OPER;            // A | B: 48 KB
+
+// 4 values (the same channel of 4 consecutive pairs) -> three 8-byte groups of bf16 (element e in the low / high half of dword e / 2)
+__device__ __forceinline__ void bws_split4(const float (&v)[4], bw_u32x2& hi, bw_u32x2& mid, bw_u32x2& lo) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    const float ah = __uint_as_float(__float_as_uint(a) & 0xffff0000u), bh = __uint_as_float(__float_as_uint(b) & 0xffff0000u);
+    const float ar = __fsub_rn(a, ah), br = __fsub_rn(b, bh);
+    const float am = __uint_as_float(__float_as_uint(ar) & 0xffff0000u), bm = __uint_as_float(__float_as_uint(br) & 0xffff0000u);
+    const float al = __fsub_rn(ar, am), bl = __fsub_rn(br, bm);
+    hi[j] = __builtin_amdgcn_perm(__float_as_uint(bh), __float_as_uint(ah), 0x07060302u);
+    mid[j] = __builtin_amdgcn_perm(__float_as_uint(bm), __float_as_uint(am), 0x07060302u);
+    lo[j] = __builtin_amdgcn_perm(__float_as_uint(bl), __float_as_uint(al), 0x07060302u);
+  }
+}
+
+__global__ void __launch_bounds__(256, 2) spconv_bwd_weight_split_kernel(SpconvBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char bws_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int k = blockIdx.y;
+  const int split = blockIdx.x;
+  const int a0 = (blockIdx.z / a.tiles_b) * 128;
+  const int b0 = (blockIdx.z % a.tiles_b) * 128;
+  const int n = a.num ? a.num[k] : (int)a.cap;
+  const int p_begin = split * a.range;
+  if (p_begin >= n) return;
+  const int p_end = min(n, p_begin + a.range);
+  const int nstages = (p_end - p_begin + BW_RT - 1) / BW_RT;
+  const bool ident = a.pairs == nullptr;
+  const int32_t* pin = ident ? nullptr : a.pairs + (int64_t)k * 2 * a.cap;
+  const int32_t* pout = ident ? nullptr : pin + a.cap;
+
+  // ---- loader role: micro-tile (pairs 4 pq .. 4 pq + 3) x (channels 4 cq .. 4 cq + 3) of both operands
+  const int cq = 8 * wave + (lane & 7), pq = lane >> 3;
+  int ca = a0 + 4 * cq;
+  ca = ca + 4 <= a.cin ? ca : a.cin - 4;   // (channels past cin / cout only feed accumulators that are never written out)
+  int cb = b0 + 4 * cq;
+  cb = cb + 4 <= a.cout ? cb : a.cout - 4;
+  // LDS byte offset of this thread's 8-byte group for channel 4 cq + c: row c * 32 + cq, unit (pq >> 1) ^ c, half pq & 1
+  const int wr_row = cq * BWS_ROW + (pq & 1) * 8, wr_unit = pq >> 1;
+
+  int32_t ia[4], ib[4];
+  f32x4 xa[4], xb[4];
+  auto load_indices = [&](int stage) {
+    const int p0 = p_begin + stage * BW_RT + 4 * pq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = min(p0 + r, p_end - 1);  // (clamped address; rows past the end are zeroed after the load)
+      ia[r] = ident ? p : pin[p];
+      ib[r] = ident ? p : pout[p];
+    }
+  };
+  auto load_stage = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xa[r] = *reinterpret_cast<const f32x4*>(a.feat + (int64_t)ia[r] * a.cin + ca);
+      xb[r] = *reinterpret_cast<const f32x4*>(a.gout + (int64_t)ib[r] * a.cout + cb);
+    }
+  };
+  auto write_stage = [&](int stage) {
+    const int p0 = p_begin + stage * BW_RT + 4 * pq;
+#pragma unroll
+    for (int oper = 0; oper < 2; ++oper) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        char* base = bws_smem + oper * BWS_OPER + wr_row + (c * 32) * BWS_ROW + ((wr_unit ^ c) * 16);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = p0 + r < p_end ? (oper == 0 ? xa[r][c] : xb[r][c]) : 0.0f;
+        bw_u32x2 hi, mid, lo;
+        bws_split4(v, hi, mid, lo);
+        *reinterpret_cast<bw_u32x2*>(base) = hi;
+        *reinterpret_cast<bw_u32x2*>(base + BWS_PLANE) = mid;
+        *reinterpret_cast<bw_u32x2*>(base + 2 * BWS_PLANE) = lo;
+      }
+    }
+  };
+
+  // ---- MFMA role: wave (wa, wb) owns channels [64 wa, +64) x [64 wb, +64) of the tile
+  const int wa = wave >> 1, wb = wave & 1;
+  const int m = lane & 15, kg = lane >> 4;
+  // channel 64 w + 16 t + m lives in row (m & 3) * 32 + 16 w + 4 t + (m >> 2), its unit kg at kg ^ (m & 3)
+  const int rd_off = ((m & 3) * 32 + (m >> 2)) * BWS_ROW + ((kg ^ (m & 3)) * 16);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_indices(0);
+  load_stage();
+  if (nstages > 1) load_indices(1);
+  for (int s = 0; s < nstages; ++s) {
+    if (s > 0) __syncthreads();  // every wave is done reading the image of stage s - 1
+    write_stage(s);              // (waits for this stage's micro-tiles)
+    __syncthreads();
+    if (s + 1 < nstages) {       // the next stage's rows travel under this stage's MFMAs
+      load_stage();
+      if (s + 2 < nstages) load_indices(s + 2);
+    }
+    const char* As = bws_smem + (16 * wa) * BWS_ROW + rd_off;
+    const char* Bs = bws_smem + BWS_OPER + (16 * wb) * BWS_ROW + rd_off;
+    bw_bf16x8 af[4][3];
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        af[ta][pl] = *reinterpret_cast<const bw_bf16x8*>(As + (4 * ta) * BWS_ROW + pl * BWS_PLANE);
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      bw_bf16x8 bf[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bf[pl] = *reinterpret_cast<const bw_bf16x8*>(Bs + (4 * tb) * BWS_ROW + pl * BWS_PLANE);
+      // (plane of A, plane of B) of the six leading cross terms, small ones first
+      constexpr int TERM_A[6] = {2, 0, 1, 1, 0, 0};
+      constexpr int TERM_B[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ta][TERM_A[term]], bf[TERM_B[term]], acc[ta][tb], 0, 0, 0);
+    }
+  }
+
+  // D of tile (ta, tb): lane (n = lane % 16, g = lane / 16) holds rows ci = 16 ta + 4 g + r, column co = 16 tb + n
+  float* dst = a.nsplit > 1 ? a.part + ((int64_t)k * a.nsplit + split) * a.cin * a.cout : a.gw + (int64_t)k * a.cin * a.cout;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      const int co = b0 + 64 * wb + 16 * tb + m;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = a0 + 64 * wa + 16 * ta + 4 * kg + r;
+        if (ci < a.cin && co < a.cout) dst[(int64_t)ci * a.cout + co] = acc[ta][tb][r];
+      }
+    }
+}
+
 // grad_W[k] = sum of the live partial slices (or zero when the offset has no pairs), in a fixed order: a workgroup owns 16
 // float4 elements x 16 slices; slice s adds partials s, s + 16, ... on four independent chains, then the 16 slice sums are
 // added in slice order.  (One thread per element walking up to ~1000 partials serially was a 100-250 us latency chain.)
@@ -312,7 +481,13 @@ extern "C" int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32
     FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_bwd_weight_kernel<TA_, TB_>, (int)smem_bytes, attr_done));                                                                                                                    \
     hipLaunchKernelGGL((spconv_bwd_weight_kernel<TA_, TB_>), grid, dim3(256), smem_bytes, stream, a);                    \
   } while (0)
-  if (cap > 0) {
+  // (A/B switch, latched: FSF_BWD_SPLIT=0 keeps the fp32-pipe kernel for the 128 x 128 tiles as well)
+  static const bool split_on = !(getenv("FSF_BWD_SPLIT") && atoi(getenv("FSF_BWD_SPLIT")) == 0);
+  if (cap > 0 && split_on && ta == 128 && tb == 128) {
+    static std::atomic<uint64_t> attr_done{0};
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_bwd_weight_split_kernel, BWS_SMEM, attr_done));
+    hipLaunchKernelGGL(spconv_bwd_weight_split_kernel, grid, dim3(256), BWS_SMEM, stream, a);
+  } else if (cap > 0) {
     if (ta == 64 && tb == 64) FSF_BWD_LAUNCH(64, 64);
     else if (ta == 64) FSF_BWD_LAUNCH(64, 128);
     else if (tb == 64) FSF_BWD_LAUNCH(128, 64);
