@@ -869,6 +869,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
+            **({"commit": os.environ["FSF_COMMIT"]} if os.environ.get("FSF_COMMIT") else {}),
             "dtype": "f32",
             "data": "synthetic",
             "config": {

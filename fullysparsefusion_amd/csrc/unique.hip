@@ -206,6 +206,76 @@ struct IgIn {
   __device__ uint32_t operator()(int64_t i) const { return (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u; }
 };
 
+
+// ---- K25: which cluster voxels (and which (group, point) pairs) survive ClusterAssigner's density filter ------------------------
+// ClusterAssigner.forward_single_class (single_stage_fsd.py:951-956) per class group: a voxel key with fewer than `min_points` pairs
+// is dropped — unless NONE of the group's keys is dense enough, then the group keeps everything.  With all groups in one key list
+// (group = key[0] / batch size, keys sorted by it) that is: flag per key, OR per group, two stable compactions (keys, pairs) and the
+// pair -> surviving-voxel map.  Upstream does it with boolean masks and a second torch.unique on the survivors (two host syncs per
+// group); the plugin had ~22 small ATen launches and two nonzero() syncs here.
+__global__ void __launch_bounds__(256)
+    ks_group_valid_kernel(const int64_t* __restrict__ new_keys, int key_cols, const int64_t* __restrict__ cnt, int64_t m, int64_t bsz,
+                          int64_t min_points, int ng, int* __restrict__ has_valid) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    if (cnt[i] >= min_points) {
+      const int64_t g = new_keys[i * key_cols] / bsz;
+      if (g >= 0 && g < ng) atomicOr(has_valid + g, 1);  // (idempotent: the result does not depend on the order)
+    }
+  }
+}
+
+struct KsKeyIn {
+  const int64_t* new_keys; int key_cols; const int64_t* cnt; int64_t bsz, min_points; int ng; const int* has_valid;
+  __device__ uint32_t operator()(int64_t i) const {
+    const int64_t g = new_keys[i * key_cols] / bsz;
+    const bool group_has = g >= 0 && g < ng && has_valid[g] != 0;
+    return (cnt[i] >= min_points || !group_has) ? 1u : 0u;
+  }
+};
+struct KsKeyOut {
+  int64_t* k_idx; int32_t* kpos; int32_t* k_group; const int64_t* new_keys; int key_cols; int64_t bsz;
+  __device__ void operator()(int64_t i, uint32_t excl, uint32_t keep) const {
+    kpos[i] = keep ? (int32_t)excl : -1;
+    if (keep) {
+      k_idx[excl] = i;
+      if (k_group) k_group[excl] = (int32_t)(new_keys[i * key_cols] / bsz);
+    }
+  }
+};
+
+// cluster id of every surviving pair: the connected-component label of its voxel, renumbered from 0 inside its class group
+// (labels are numbered by first member over ALL voxels and the voxels are group-sorted: a group's labels start at its first voxel's)
+__global__ void __launch_bounds__(256)
+    ks_group_base_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ vox_group, int64_t m, int ng, int32_t* __restrict__ base) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
+    const int g = vox_group[i];
+    if ((i == 0 || vox_group[i - 1] != g) && g >= 0 && g < ng) base[g] = labels[i];
+  }
+}
+__global__ void __launch_bounds__(256)
+    ks_point_ids_kernel(const int32_t* __restrict__ labels, const int32_t* __restrict__ vox_group, const int32_t* __restrict__ base,
+                        const int64_t* __restrict__ vox_inv, const int64_t* __restrict__ g_ids, const int64_t* __restrict__ b_pts, int64_t nv,
+                        int64_t* __restrict__ out) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < nv; j += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = vox_inv[j];
+    out[3 * j] = g_ids[j];
+    out[3 * j + 1] = b_pts[j];
+    out[3 * j + 2] = (int64_t)(labels[v] - base[vox_group[v]]);
+  }
+}
+struct KsPairIn {
+  const int64_t* inv; const int32_t* kpos;
+  __device__ uint32_t operator()(int64_t i) const { return kpos[inv[i]] >= 0 ? 1u : 0u; }
+};
+struct KsPairOut {
+  const int64_t* inv; const int32_t* kpos; int64_t* v_idx; int64_t* vox_inv;
+  __device__ void operator()(int64_t i, uint32_t excl, uint32_t keep) const {
+    if (keep) {
+      v_idx[excl] = i;
+      vox_inv[excl] = (int64_t)kpos[inv[i]];
+    }
+  }
+};
 }  // namespace fsf
 
 using namespace fsf;
@@ -428,6 +498,64 @@ extern "C" int fsf_ingroup_rank(const int64_t* group_inds, int64_t n, int64_t* o
   rc = exclusive_scan_u32(iin, iout, n, tile_sums, nullptr, nullptr, stream);
   if (rc != FSF_OK) return rc;
   hipLaunchKernelGGL(ig_final_kernel, dim3(grid), dim3(256), 0, stream, vals_s, seg_of, seg_start, n, out_inds);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int64_t fsf_cluster_key_survival_workspace_bytes(int64_t m, int64_t n) {
+  return fsf_align_up((m > 0 ? m : 1) * 4, 256) + fsf_align_up(scan_num_tiles(m) * 4, 256) + fsf_align_up(scan_num_tiles(n) * 4, 256) + 6 * 256;
+}
+
+extern "C" int fsf_cluster_key_survival(const int64_t* new_keys, int32_t key_cols, const int64_t* cnt, int64_t m, const int64_t* inv,
+                                        int64_t n, int64_t batch_size, int64_t min_points, int32_t num_groups, int64_t* k_idx,
+                                        int32_t* k_group, int64_t* v_idx, int64_t* vox_inv, int64_t* counts_host, void* workspace,
+                                        int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || n < 0 || key_cols < 1 || batch_size < 1 || num_groups < 1 || num_groups > 64 || !counts_host ||
+      (m > 0 && (!new_keys || !cnt || !k_idx)) || (n > 0 && (!inv || !v_idx || !vox_inv)))
+    return FSF_ERR_INVALID_ARG;
+  if (m >= ((int64_t)1 << 31) || n >= ((int64_t)1 << 31)) return FSF_ERR_UNSUPPORTED;
+  if (workspace_bytes < fsf_cluster_key_survival_workspace_bytes(m, n) || !workspace) return FSF_ERR_WORKSPACE;
+  counts_host[0] = counts_host[1] = 0;
+  if (m == 0 || n == 0) return FSF_OK;
+  FsfArena ar(workspace, workspace_bytes);
+  int32_t* kpos = ar.take<int32_t>(m);
+  // [has_valid | tile sums of the two scans] are consecutive: one memset
+  int* has_valid = ar.take<int>(64);
+  uint32_t* tiles_k = ar.take<uint32_t>(scan_num_tiles(m));
+  uint32_t* tiles_p = ar.take<uint32_t>(scan_num_tiles(n));
+  int64_t* totals = ar.take<int64_t>(2);
+  const size_t zero_bytes = (size_t)((char*)totals - (char*)has_valid);
+  if (!ar.ok()) return FSF_ERR_WORKSPACE;
+  FSF_HIP_TRY(hipMemsetAsync(has_valid, 0, zero_bytes, stream));
+  hipLaunchKernelGGL(ks_group_valid_kernel, dim3(fsf_stream_grid(m, 256)), dim3(256), 0, stream, new_keys, (int)key_cols, cnt, m,
+                     batch_size, min_points, (int)num_groups, has_valid);
+  int rc = exclusive_scan_u32(KsKeyIn{new_keys, (int)key_cols, cnt, batch_size, min_points, (int)num_groups, has_valid},
+                              KsKeyOut{k_idx, kpos, k_group, new_keys, (int)key_cols, batch_size}, m, tiles_k, nullptr, totals, stream, 1, true);
+  if (rc != FSF_OK) return rc;
+  rc = exclusive_scan_u32(KsPairIn{inv, kpos}, KsPairOut{inv, kpos, v_idx, vox_inv}, n, tiles_p, nullptr, totals + 1, stream, 1, true);
+  if (rc != FSF_OK) return rc;
+  int64_t ret_h[2] = {0, 0};
+  FSF_HIP_TRY(hipMemcpyAsync(ret_h, totals, sizeof(ret_h), hipMemcpyDeviceToHost, stream));  // (both counts in one copy)
+  FSF_HIP_TRY(hipStreamSynchronize(stream));
+  counts_host[0] = ret_h[0];
+  counts_host[1] = ret_h[1];
+  return FSF_OK;
+}
+
+extern "C" int fsf_cluster_point_ids(const int32_t* labels, const int32_t* vox_group, int64_t m, const int64_t* vox_inv,
+                                     const int64_t* g_ids, const int64_t* b_pts, int64_t nv, int32_t num_groups, int64_t* out,
+                                     void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || nv < 0 || num_groups < 1 || num_groups > 64 || (nv > 0 && (!labels || !vox_group || !vox_inv || !g_ids || !b_pts || !out || m < 1)))
+    return FSF_ERR_INVALID_ARG;
+  if (workspace_bytes < 256 || !workspace) return FSF_ERR_WORKSPACE;
+  if (nv == 0) return FSF_OK;
+  int32_t* base = (int32_t*)workspace;
+  FSF_HIP_TRY(hipMemsetAsync(base, 0, 64 * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(ks_group_base_kernel, dim3(fsf_stream_grid(m, 256)), dim3(256), 0, stream, labels, vox_group, m, (int)num_groups, base);
+  hipLaunchKernelGGL(ks_point_ids_kernel, dim3(fsf_stream_grid(nv, 256)), dim3(256), 0, stream, labels, vox_group, base, vox_inv, g_ids, b_pts,
+                     nv, out);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -101,6 +101,9 @@ _ARGTYPES = {
     "fsf_box_tail_max_classes": [],
     "fsf_nms_select": [_P, c_i32, _P, _P, _P, c_i64, _P, c_i64, c_i32, c_i64, c_i32, _P, _P, _P, _P, _P],
     "fsf_connected_components_grouped": [_P, c_i64, c_i32, _P, _P, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_cluster_key_survival_workspace_bytes": [c_i64, c_i64],
+    "fsf_cluster_key_survival": [_P, c_i32, _P, c_i64, _P, c_i64, c_i64, c_i64, c_i32, _P, _P, _P, _P, _P, _P, c_i64, _P],
+    "fsf_cluster_point_ids": [_P, _P, c_i64, _P, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_ingroup_rank_workspace_bytes": [c_i64],
     "fsf_ingroup_rank": [_P, c_i64, _P, _P, c_i64, _P],
     "fsf_order_by_neighbor_mask_workspace_bytes": [c_i64],
@@ -1054,6 +1057,48 @@ def class_rank_desc(scores_t: torch.Tensor, score_thr: float):
     check(h.fsf_class_rank_desc(ptr(scores_t), n, c, float(score_thr), ptr(order), ptr(rank), ptr(count), ptr(ws), ws.numel(),
                                 stream_ptr()), "fsf_class_rank_desc")
     return order, rank, count
+
+
+def cluster_key_survival(new_keys: torch.Tensor, cnt: torch.Tensor, inv: torch.Tensor, batch_size: int, min_points: int, num_groups: int):
+    """fsf_cluster_key_survival (K25): ClusterAssigner's density filter for all class groups at once.  new_keys i64 [m, k] (ascending, column 0 =
+    group * batch_size + sample), cnt i64 [m], inv i64 [n] -> (k_idx i64 [mk], k_group i32 [mk], v_idx i64 [nv], vox_inv i64 [nv]): surviving
+    keys and their class groups, surviving pairs (both ascending) and each surviving pair's position among the surviving keys.  One host sync."""
+    require_cuda(new_keys, cnt, inv)
+    assert new_keys.dtype == torch.int64 and new_keys.dim() == 2 and new_keys.is_contiguous()
+    assert cnt.dtype == torch.int64 and inv.dtype == torch.int64
+    cnt, inv = cnt.contiguous(), inv.contiguous()
+    m, n = new_keys.size(0), inv.numel()
+    assert cnt.numel() == m
+    dev = new_keys.device
+    k_idx = torch.empty((max(m, 1),), dtype=torch.int64, device=dev)
+    k_group = torch.empty((max(m, 1),), dtype=torch.int32, device=dev)
+    v_idx = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    vox_inv = torch.empty((max(n, 1),), dtype=torch.int64, device=dev)
+    counts = (ctypes.c_int64 * 2)(0, 0)
+    h = _L()
+    ws = _lib.workspace(h.fsf_cluster_key_survival_workspace_bytes(m, n), dev)
+    check(h.fsf_cluster_key_survival(ptr(new_keys), new_keys.size(1), ptr(cnt), m, ptr(inv), n, int(batch_size), int(min_points),
+                                     int(num_groups), ptr(k_idx), ptr(k_group), ptr(v_idx), ptr(vox_inv), ctypes.cast(counts, c_p), ptr(ws),
+                                     ws.numel(), stream_ptr()), "fsf_cluster_key_survival")
+    mk, nv = int(counts[0]), int(counts[1])
+    return k_idx[:mk], k_group[:mk], v_idx[:nv], vox_inv[:nv]
+
+
+def cluster_point_ids(labels: torch.Tensor, vox_group: torch.Tensor, vox_inv: torch.Tensor, g_ids: torch.Tensor, b_pts: torch.Tensor,
+                      num_groups: int):
+    """fsf_cluster_point_ids: (group, sample, cluster id within the group) i64 [nv, 3] of every surviving pair from the grouped
+    connected-component labels i32 [m] of the (group-sorted) cluster voxels."""
+    require_cuda(labels, vox_group, vox_inv, g_ids, b_pts)
+    assert labels.dtype == torch.int32 and vox_group.dtype == torch.int32 and labels.numel() == vox_group.numel()
+    assert vox_inv.dtype == torch.int64 and g_ids.dtype == torch.int64 and b_pts.dtype == torch.int64
+    labels, vox_group, vox_inv, g_ids, b_pts = (t.contiguous() for t in (labels, vox_group, vox_inv, g_ids, b_pts))
+    nv = vox_inv.numel()
+    assert g_ids.numel() == nv and b_pts.numel() == nv
+    out = torch.empty((nv, 3), dtype=torch.int64, device=labels.device)
+    ws = _lib.workspace(256, labels.device)
+    check(_L().fsf_cluster_point_ids(ptr(labels), ptr(vox_group), labels.numel(), ptr(vox_inv), ptr(g_ids), ptr(b_pts), nv, int(num_groups),
+                                     ptr(out), ptr(ws), ws.numel(), stream_ptr()), "fsf_cluster_point_ids")
+    return out
 
 
 def nms_select_capacity() -> int:

@@ -277,20 +277,26 @@ class SingleStageFSD(nn.Module):
             # Whether a pair survives is a property of its voxel key (dense enough, or its whole group has no dense voxel, :953-954),
             # so the voxels of the surviving pairs are a SUBSET of the unique just taken: their keys, the pair -> voxel map and the
             # voxel means (same rows in the same order per voxel) follow from it — upstream runs a second unique on the survivors.
-            key_ok = cnt >= ca.min_points
-            key_group = torch.div(new_keys[:, 0], bsz, rounding_mode="floor")           # ascending: keys sort by (group, batch) first
-            kcs = torch.cat([key_ok.new_zeros(1, dtype=torch.int64), key_ok.to(torch.int64).cumsum(0)])
-            kb = torch.searchsorted(key_group, torch.arange(ng + 1, device=dev))
-            has_valid = (kcs[kb[1:]] - kcs[kb[:-1]]) > 0
-            key_keep = key_ok | ~has_valid.index_select(0, key_group)
-            valid = key_keep.index_select(0, inv)
-            v_idx = valid.nonzero(as_tuple=False).squeeze(1)
-            k_idx = key_keep.nonzero(as_tuple=False).squeeze(1)
-            remap = key_keep.to(torch.int64).cumsum(0) - 1
+            if new_keys.is_cuda and ng <= 64 and switches.KEY_SURVIVAL:
+                # one C-ABI call and one read-back (K25) instead of ~22 small launches and two nonzero() round trips
+                k_idx, vox_group_i32, v_idx, vox_inv = hip_ops.cluster_key_survival(new_keys, cnt, inv, bsz, ca.min_points, ng)
+            else:
+                vox_group_i32 = None
+                key_ok = cnt >= ca.min_points
+                key_group = torch.div(new_keys[:, 0], bsz, rounding_mode="floor")           # ascending: keys sort by (group, batch) first
+                kcs = torch.cat([key_ok.new_zeros(1, dtype=torch.int64), key_ok.to(torch.int64).cumsum(0)])
+                kb = torch.searchsorted(key_group, torch.arange(ng + 1, device=dev))
+                has_valid = (kcs[kb[1:]] - kcs[kb[:-1]]) > 0
+                key_keep = key_ok | ~has_valid.index_select(0, key_group)
+                valid = key_keep.index_select(0, inv)
+                v_idx = valid.nonzero(as_tuple=False).squeeze(1)
+                k_idx = key_keep.nonzero(as_tuple=False).squeeze(1)
+                remap = key_keep.to(torch.int64).cumsum(0) - 1
+                vox_inv = remap.index_select(0, inv.index_select(0, v_idx))
             all_means, _, _ = scatter_v2(centers, keys, mode="avg", return_inv=True, unq_inv=inv, new_coors=new_keys,
                                          short_segments=True)
-            vox_centers, vox_keys = all_means.index_select(0, k_idx), new_keys.index_select(0, k_idx)
-            vox_inv = remap.index_select(0, inv.index_select(0, v_idx))
+            vox_centers = all_means.index_select(0, k_idx)
+            vox_keys = new_keys.index_select(0, k_idx) if vox_group_i32 is None else None  # (only the generic tail below reads them)
             g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
             centers = centers.index_select(0, v_idx)
         else:
@@ -306,15 +312,20 @@ class SingleStageFSD(nn.Module):
             centers = centers.index_select(0, v_idx)
             vox_centers, vox_keys, vox_inv = scatter_v2(centers, keys.index_select(0, v_idx), mode="avg", return_inv=True,
                                                         short_segments=True)
-        vox_group = torch.div(vox_keys[:, 0], bsz, rounding_mode="floor")
         dist = const("connected_dist", lambda: torch.tensor([ca._per_class(ca.connected_dist, n) for n in ca.class_names[:ng]],
                                                             dtype=torch.float32))
         # test-time clustering ignores the sample index inside a group (:69-82); components never span groups
-        labels = hip_ops.connected_components_grouped(vox_centers, vox_group, dist).long()
-        first = torch.searchsorted(vox_group, torch.arange(ng, device=dev))            # voxels are group-sorted
-        base = labels[first.clamp(max=labels.numel() - 1)]                              # a group's labels start at its first voxel's
-        cluster = (labels - base.index_select(0, vox_group)).index_select(0, vox_inv)
-        pts_cluster_inds = torch.stack([g_ids, b_pts, cluster], 1)
+        if switches.CLUSTER_ONE_UNIQUE and vox_group_i32 is not None:
+            labels = hip_ops.connected_components_grouped(vox_centers, vox_group_i32, dist)
+            # (a group's labels start at its first voxel's: renumbered from 0 per group and mapped to the pairs in two launches)
+            pts_cluster_inds = hip_ops.cluster_point_ids(labels, vox_group_i32, vox_inv, g_ids, b_pts, ng)
+        else:
+            vox_group = torch.div(vox_keys[:, 0], bsz, rounding_mode="floor")
+            labels = hip_ops.connected_components_grouped(vox_centers, vox_group, dist).long()
+            first = torch.searchsorted(vox_group, torch.arange(ng, device=dev))            # voxels are group-sorted
+            base = labels[first.clamp(max=labels.numel() - 1)]                              # a group's labels start at its first voxel's
+            cluster = (labels - base.index_select(0, vox_group)).index_select(0, vox_inv)
+            pts_cluster_inds = torch.stack([g_ids, b_pts, cluster], 1)
         def take(t):  # rows p_ids of t (ATen's index_select is slow on narrow float rows: 118 us for [510 k, 4])
             if t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1:
                 return hip_ops.gather_rows(t, p_ids)

@@ -31,6 +31,7 @@ SIR_SORTED = _on("FSF_SIR_SORTED")                  # inference: SIR stacks on r
 SIR_GATHER = _on("FSF_SIR_GATHER")                  # first SIR layer reads the point features in place through an index
 FUSED_VOTE = _on("FSF_FUSED_VOTE")                  # vote centres + cluster-voxel keys in one kernel
 CLUSTER_ONE_UNIQUE = _on("FSF_CLUSTER_ONE_UNIQUE")  # a single unique in the cluster assignment
+KEY_SURVIVAL = _on("FSF_KEY_SURVIVAL")              # ... and its density filter as one C-ABI call / one read-back (K25)
 VFE_DECORATE = _on("FSF_VFE_DECORATE")              # the VFE input decoration in one kernel
 UNET_MASK_ORDER = _on("FSF_UNET_MASK_ORDER")          # inference: the U-Net's fine levels in neighbour-mask row order
 UNET_MASK_ORDER_LEVELS = _int("FSF_UNET_MASK_ORDER_LEVELS", 2)  # how many levels from the finest (1 = the input level only)

@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 7
+#define FSF_ABI_VERSION 9
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -681,6 +681,34 @@ int fsf_nms_select(const float* boxes, int32_t box_dim, const float* scores_t, c
 int64_t fsf_ingroup_rank_workspace_bytes(int64_t n);
 int fsf_ingroup_rank(const int64_t* group_inds, int64_t n, int64_t* out_inds, void* workspace,
                      int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K25  ClusterAssigner's density filter over ALL class groups at once
+ * Replaces: in ClusterAssigner.forward_single_class (projects/mmdet3d_plugin/models/detectors/single_stage_fsd.py:951-956,
+ *   called per class group from :903-935) the `filter_almost_empty(coors, min_points)` mask (`:31-35`: torch.unique + counts +
+ *   `cnt[inv] >= min_points`), the `if not valid_mask.any(): valid_mask = ~valid_mask` rule and the boolean compactions of the
+ *   points and their voxel keys behind it (two host round trips per group).  With the groups as the leading key column
+ *   (key[0] = group * batch_size + sample) and ONE fsf_unique_rows over all (group, point) pairs:
+ *   new_keys i64 [m, key_cols] (ascending, as fsf_unique_rows returns them), cnt i64 [m], inv i64 [n] (pair -> key) ->
+ *   a key survives iff cnt >= min_points, or no key of its group does;
+ *   k_idx i64 [<= m] = surviving keys in ascending order, v_idx i64 [<= n] = surviving pairs in ascending order,
+ *   vox_inv i64 [<= n] = position of pair v_idx[j]'s key in k_idx (the inverse a second unique over the survivors would return);
+ *   k_group i32 [<= m] (optional) = class group of every surviving key (what the grouped connected components take);
+ *   counts_host[0] = surviving keys, counts_host[1] = surviving pairs (one 16-byte read-back, one stream sync).
+ *   Stable compactions by single-pass look-back scans: deterministic.  num_groups <= 64.
+ * fsf_cluster_point_ids: the tail of the same function (`:971-977`) for all groups at once — the component labels of the cluster
+ *   voxels (fsf_connected_components_grouped: numbered by first member over all voxels; the voxels are group-sorted) renumbered
+ *   from 0 inside each group and mapped back to the surviving pairs: out i64 [nv, 3] = (group, sample, cluster id), the rows
+ *   `combine_classes` concatenates (`:892-901`).  workspace >= 256 bytes.
+ */
+int64_t fsf_cluster_key_survival_workspace_bytes(int64_t m, int64_t n);
+int fsf_cluster_key_survival(const int64_t* new_keys, int32_t key_cols, const int64_t* cnt, int64_t m, const int64_t* inv, int64_t n,
+                             int64_t batch_size, int64_t min_points, int32_t num_groups, int64_t* k_idx, int32_t* k_group,
+                             int64_t* v_idx, int64_t* vox_inv, int64_t* counts_host, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+int fsf_cluster_point_ids(const int32_t* labels, const int32_t* vox_group, int64_t m, const int64_t* vox_inv, const int64_t* g_ids,
+                          const int64_t* b_pts, int64_t nv, int32_t num_groups, int64_t* out, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,7 +82,7 @@ def test_stage1_10sweep_vs_committed_oracle_fixture(fsf_pair, frame10, device):
         vf, vc, inv = seg.voxel_encoder(p_dev, coors, return_inv=True)
         unet = seg.backbone(dict(voxel_feats=vf, voxel_coors=vc, batch_size=1))[0]["voxel_feats"]
         out = model.forward_hot_path(pts, metas, mask, anno)["seg"]
-        obj_id = model.points_in_mask(pts[0][:, 5:8].contiguous(), mask[0], metas[0]["lidar2img"])
+        obj_id = model.points_in_mask(pts[0][:, -3:].contiguous(), mask[0], metas[0]["lidar2img"])
     prow, vrow = torch.from_numpy(g["point_rows"]).to(device), torch.from_numpy(g["voxel_rows"]).to(device)
     # integer outputs: whole-tensor checksums + sampled rows, exact
     assert vc.shape[0] == int(g["num_voxels"])
@@ -409,7 +409,7 @@ def _final_boxes_vs_oracle_chain(model, cpu, frame, device, monkeypatch):
         n_pool_exact = _compare_pool((c(g_inds).numpy(), c(g_roi_inds).numpy(), g13), (wp, wr, wf), near)
         assert n_pool_exact >= min(len(wp), 1000), (n_pool_exact, len(wp))
         # refine SIR on the GPU's pooling result, query update, refined head
-        obj_id = c(model.points_in_mask(pts[0][:, 5:8].contiguous(), mask[0], metas[0]["lidar2img"]))
+        obj_id = c(model.points_in_mask(pts[0][:, -3:].contiguous(), mask[0], metas[0]["lidar2img"]))
         g_info13 = torch.cat([c(xyz_in)[c(g_inds)], c(g_info["local_xyz"]), c(g_info["boundary_offset"]),
                               c(g_info["is_in_margin"])[:, None]], 1)
         lidar_img = omod.query_feat_refine(cpu, 0, seg["seg_points"], seg["seg_feats"], obj_id, c(anno[0]),

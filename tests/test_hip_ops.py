@@ -1711,3 +1711,43 @@ def test_linear_norm_act_segmax_equals_the_two_pass_form(ops, device, n, m, k, c
     # an independent yardstick for the maxima (torch's scatter-reduce over the same rows)
     ref = torch.full((m_eff, c), float("-inf"), device=device).scatter_reduce(0, inv[:, None].expand(n, c), rows, "amax", include_self=True)
     assert torch.equal(want, ref)
+
+
+@pytest.mark.parametrize("n,m_target,ng,bsz,minp,empty_group", [(200000, 30000, 6, 1, 2, None), (50000, 49000, 6, 2, 2, 3), (1000, 10, 3, 1, 5, 1),
+                                                               (5, 5, 6, 1, 2, None), (300000, 2000, 6, 1, 2, None)])
+def test_cluster_key_survival_equals_the_torch_expression(ops, device, n, m_target, ng, bsz, minp, empty_group):
+    """K25 against the plugin's own ATen chain (itself exact against the oracle's per-group loop in the full-size tests): surviving keys /
+    pairs in ascending order and the pair -> surviving-key map; a group none of whose keys is dense enough keeps all of them
+    (single_stage_fsd.py:953-954)."""
+    torch.manual_seed(n + m_target)
+    g = torch.randint(0, ng * bsz, (n,), device=device)
+    vox = torch.randint(0, max(1, m_target // (ng * bsz)), (n, 1), device=device)
+    keys = torch.cat([g[:, None], vox, vox % 7, vox % 3], 1)
+    if empty_group is not None:  # every key of this group is a singleton: none reaches min_points -> the whole group survives
+        sel = (g // bsz) == empty_group
+        keys[sel, 1] = torch.arange(int(sel.sum()), device=device) + 10 ** 6
+    new_keys, plan = ops.unique_rows(keys)
+    inv, cnt = plan.inv, plan.cnt
+    k_idx, k_group, v_idx, vox_inv = ops.cluster_key_survival(new_keys, cnt, inv, bsz, minp, ng)
+    key_ok = cnt >= minp
+    key_group = torch.div(new_keys[:, 0], bsz, rounding_mode="floor")
+    has_valid = torch.zeros(ng, dtype=torch.bool, device=device)
+    has_valid[key_group[key_ok]] = True
+    key_keep = key_ok | ~has_valid[key_group]
+    want_k = key_keep.nonzero().squeeze(1)
+    want_v = key_keep[inv].nonzero().squeeze(1)
+    remap = key_keep.long().cumsum(0) - 1
+    assert torch.equal(k_idx, want_k) and torch.equal(v_idx, want_v) and torch.equal(vox_inv, remap[inv[want_v]])
+    assert torch.equal(k_group.long(), key_group[want_k])
+    # fsf_cluster_point_ids: labels numbered over all voxels -> from 0 inside each group, mapped to the surviving pairs
+    labels = torch.cumsum(torch.randint(0, 2, (want_k.numel(),), device=device), 0).int()  # nondecreasing, like first-member numbering
+    gp = (torch.arange(want_v.numel(), device=device) % ng).long()
+    bp = (torch.arange(want_v.numel(), device=device) % bsz).long()
+    got = ops.cluster_point_ids(labels, k_group, vox_inv, gp, bp, ng)
+    vg = key_group[want_k]
+    first = torch.searchsorted(vg, torch.arange(ng, device=device))
+    base = labels.long()[first.clamp(max=max(labels.numel() - 1, 0))]
+    want = torch.stack([gp, bp, (labels.long() - base[vg])[vox_inv]], 1)
+    assert torch.equal(got, want)
+    if empty_group is not None:
+        assert bool(key_keep[key_group == empty_group].all()) and int((key_group == empty_group).sum()) > 0
