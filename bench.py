@@ -128,7 +128,7 @@ def count_launch_sources(model, inp, hot_path_only=False):
     """How many things one frame asks the device / the host for, counted in ONE extra untimed frame: C-ABI calls
     of libfsf_hip (each 1-12 kernel launches), ATen ops that do device work (non-view ops seen by a TorchDispatchMode, ~1 launch each)
     and host synchronisations the Python side can see (`.item()` / `bool()` / `int()` of a device tensor, `nonzero`, boolean-mask
-    indexing, `torch.cuda.synchronize`, and the C-ABI calls that read a count back: fsf_unique_rows, fsf_rulebook_strided).  The exact
+    indexing, `torch.cuda.synchronize`, and the C-ABI calls that read a count back: fsf_unique_rows, fsf_rulebook_strided, fsf_cluster_key_survival).  The exact
     kernel-launch count needs a trace: `kernel_launches_per_frame_rocprof` is read from the newest committed
     profiles/*_kernel_stats_full_forward.txt."""
     import collections
@@ -154,7 +154,7 @@ def count_launch_sources(model, inp, hot_path_only=False):
             return func(*args, **(kwargs or {}))
 
     orig_check, orig_sync = _lib.check, torch.cuda.synchronize
-    sync_calls = {"fsf_unique_rows", "fsf_rulebook_strided"}
+    sync_calls = {"fsf_unique_rows", "fsf_rulebook_strided", "fsf_cluster_key_survival"}
 
     def check(status, what):
         counts["cabi"] += 1

@@ -34,7 +34,7 @@ class Spy(TorchDispatchMode):
 
 orig = _lib.check
 def check(status, what):
-    if what in ("fsf_unique_rows", "fsf_rulebook_strided"):
+    if what in ("fsf_unique_rows", "fsf_rulebook_strided", "fsf_cluster_key_survival"):
         site("C-ABI read-back " + what)
     return orig(status, what)
 _lib.check = hip_ops.check = check
