@@ -393,7 +393,10 @@ def _acc_bwd_weight(a, k, out):
     feat, grad_out, num = a[0], a[1], a[3]   # hip_ops.spconv_backward_weight(feat, grad_out, pairs, num)
     pairs = float(num.sum())
     cin, cout = feat.size(1), grad_out.size(1)
-    return "spconv_bwd_weight", pairs * (cin + cout) * 4 + 8 * pairs + num.numel() * cin * cout * 4, 2.0 * pairs * cin * cout
+    # (the library runs 128 x 128 tiles on K10p — bf16 MFMA x 6 — and 64-wide ones on K10 — fp32 MFMA —: csrc/spconv_bwd.hip::bwd_plan)
+    split = cin > 64 and cout > 64 and os.environ.get("FSF_BWD_SPLIT", "1") != "0"
+    return ("spconv_bwd_weight_bf16x6" if split else "spconv_bwd_weight"), pairs * (cin + cout) * 4 + 8 * pairs + num.numel() * cin * cout * 4, \
+        2.0 * pairs * cin * cout
 
 
 def train_extras(train_step, pool, steps, world, dist, device):
@@ -421,16 +424,22 @@ def train_extras(train_step, pool, steps, world, dist, device):
         p.restore()
     t = p.table()
     kern = {}
-    peaks = {"spconv_bwd_weight": MFMA_F32_PEAK_TFLOPS, "spconv_planes": MFMA_16BIT_PEAK_TFLOPS / 3, "spconv_split": MFMA_16BIT_PEAK_TFLOPS / 6,
-             "spconv_fp32": MFMA_F32_PEAK_TFLOPS}
+    peaks = {"spconv_bwd_weight": MFMA_F32_PEAK_TFLOPS, "spconv_bwd_weight_bf16x6": MFMA_16BIT_PEAK_TFLOPS / 6,
+             "spconv_planes": MFMA_16BIT_PEAK_TFLOPS / 3, "spconv_split": MFMA_16BIT_PEAK_TFLOPS / 6, "spconv_fp32": MFMA_F32_PEAK_TFLOPS}
     for key, d in t.items():
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         kern[key] = dict(launches_per_step=round(d["calls"] / n, 1), ms_per_step=round(d["ms"] / n, 3), tflops_fp32_equivalent=round(tf, 2),
                          pipe_peak_tflops_fp32_equivalent=round(peaks[key], 1), frac_of_pipe_peak=round(tf / peaks[key], 4),
                          algorithmic_gflop_per_step=round(d["flops"] / n / 1e9, 1))
-    k10 = kern.get("spconv_bwd_weight", dict(tflops_fp32_equivalent=0.0, frac_of_pipe_peak=0.0))
-    roof = dict(bound="mfma", kernel="fsf::spconv_bwd_weight_kernel (K10: weight gradient over the spconv-v1 pair lists, fp32 matrix pipe)",
-                achieved=k10["tflops_fp32_equivalent"], peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=k10["frac_of_pipe_peak"], traffic=None,
+    dom_key = "spconv_bwd_weight_bf16x6" if kern.get("spconv_bwd_weight_bf16x6", {}).get("ms_per_step", 0.0) >= \
+        kern.get("spconv_bwd_weight", {}).get("ms_per_step", 0.0) and "spconv_bwd_weight_bf16x6" in kern else "spconv_bwd_weight"
+    k10 = kern.get(dom_key, dict(tflops_fp32_equivalent=0.0, frac_of_pipe_peak=0.0))
+    title = ("fsf::spconv_bwd_weight_split_kernel (K10p: weight gradient over the spconv-v1 pair lists, exact 3-way bf16 split of both operands, "
+             "v_mfma_f32_16x16x32_bf16 x 6 per fp32-equivalent product)" if dom_key.endswith("bf16x6") else
+             "fsf::spconv_bwd_weight_kernel (K10: weight gradient over the spconv-v1 pair lists, fp32 matrix pipe)")
+    roof = dict(bound="mfma", kernel=title,
+                achieved=k10["tflops_fp32_equivalent"], peak=round(peaks[dom_key], 1), unit="TFLOP/s", frac=k10["frac_of_pipe_peak"], traffic=None,
+                ms_per_step_in_kernel=k10.get("ms_per_step"), launches_per_step=k10.get("launches_per_step"),
                 kernels=kern, note="HIP events in situ on the launching stream over %d instrumented training steps; forward / data-gradient "
                                    "launches (K9c/K9d, K9b, fp32 kernel) of the same steps listed beside the dominant kernel" % n)
     # --- the collective: exposed vs isolated
