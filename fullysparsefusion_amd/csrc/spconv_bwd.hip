@@ -39,33 +39,7 @@ struct SpconvBwdArgs {
   int nsplit;             // pair-range splits per offset
   int range;              // pairs per split (multiple of BW_RT)
   int tiles_b;            // cout tiles
-  // K10p by OUTPUT-ROW range (the pair lists ascend in output row): split s of offset k is the pairs whose output row lies in
-  // [s * rows_per_range, (s + 1) * rows_per_range) = [bounds[k * (nsplit + 1) + s], bounds[.. + s + 1]); 0 = by pair index
-  const int32_t* bounds;
-  int rows_per_range, tiles;
 };
-
-// bounds[k][r] = first pair of offset k whose output row is >= r * rows_per_range (lower bound in the ascending list)
-__global__ void __launch_bounds__(256) bws_bounds_kernel(SpconvBwdArgs a, int32_t* __restrict__ bounds) {
-  const int per_k = a.nsplit + 1;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.kvol * per_k) return;
-  const int k = t / per_k, r = t - k * per_k;
-  const int n = a.num ? a.num[k] : (int)a.cap;
-  const int64_t target = (int64_t)r * a.rows_per_range;
-  int lo = 0, hi = n;
-  if (a.pairs) {
-    const int32_t* pout = a.pairs + ((int64_t)k * 2 + 1) * a.cap;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if ((int64_t)pout[mid] < target) lo = mid + 1;
-      else hi = mid;
-    }
-  } else {  // identity pairing: pair p = row p
-    lo = target < n ? (int)target : n;
-  }
-  bounds[t] = r == a.nsplit ? n : lo;
-}
 
 template <int TA, int TB>
 struct BwdSmem {
@@ -288,43 +262,18 @@ __device__ __forceinline__ void bws_split4(const float (&v)[4], bw_u32x2& hi, bw
   }
 }
 
-// RANGES: the work is cut by output-row range and dealt so that the kvol x tiles workgroups of one range run back to back ON ONE XCD
-// (workgroup ids go round-robin over the eight XCDs: id % 8 is the XCD, id / 8 walks (range of that XCD, offset, tile) with the tile
-// fastest): a gathered row is needed by ~15 offsets and every channel tile, and this way those re-reads meet in one 4 MB L2 instead
-// of going to the Infinity Cache.
-template <bool RANGES>
 __global__ void __launch_bounds__(256, 2) spconv_bwd_weight_split_kernel(SpconvBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char bws_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int k, split, tile, p_begin, p_end;
-  if constexpr (RANGES) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    tile = j % a.tiles;
-    k = (j / a.tiles) % a.kvol;
-    split = (j / (a.tiles * a.kvol)) * 8 + xcd;
-    if (split >= a.nsplit) return;
-    p_begin = a.bounds[k * (a.nsplit + 1) + split];
-    p_end = a.bounds[k * (a.nsplit + 1) + split + 1];
-  } else {
-    k = blockIdx.y;
-    split = blockIdx.x;
-    tile = blockIdx.z;
-    const int n = a.num ? a.num[k] : (int)a.cap;
-    p_begin = split * a.range;
-    if (p_begin >= n) return;
-    p_end = min(n, p_begin + a.range);
-  }
-  const int a0 = (tile / a.tiles_b) * 128;
-  const int b0 = (tile % a.tiles_b) * 128;
+  const int k = blockIdx.y;
+  const int split = blockIdx.x;
+  const int a0 = (blockIdx.z / a.tiles_b) * 128;
+  const int b0 = (blockIdx.z % a.tiles_b) * 128;
+  const int n = a.num ? a.num[k] : (int)a.cap;
+  const int p_begin = split * a.range;
+  if (p_begin >= n) return;
+  const int p_end = min(n, p_begin + a.range);
   const int nstages = (p_end - p_begin + BW_RT - 1) / BW_RT;
-  if (RANGES && nstages == 0) {  // a row range without pairs at this offset: its partial tile is zero (the fold reads every range)
-    float* dst = a.nsplit > 1 ? a.part + ((int64_t)k * a.nsplit + split) * a.cin * a.cout : a.gw + (int64_t)k * a.cin * a.cout;
-    for (int e = tid; e < 128 * 128; e += 256) {
-      const int ci = a0 + (e >> 7), co = b0 + (e & 127);
-      if (ci < a.cin && co < a.cout) dst[(int64_t)ci * a.cout + co] = 0.0f;
-    }
-    return;
-  }
   const bool ident = a.pairs == nullptr;
   const int32_t* pin = ident ? nullptr : a.pairs + (int64_t)k * 2 * a.cap;
   const int32_t* pout = ident ? nullptr : pin + a.cap;
@@ -450,7 +399,7 @@ __global__ void __launch_bounds__(256) spconv_bwd_fold_kernel(SpconvBwdArgs a) {
     const int k = ok ? (int)(t / per_k) : 0;
     const int64_t e = t - (int64_t)k * per_k;
     const int n = a.num ? a.num[k] : (int)a.cap;
-    const int live = ok ? (a.rows_per_range > 0 ? a.nsplit : (n + a.range - 1) / a.range) : 0;
+    const int live = ok ? (n + a.range - 1) / a.range : 0;
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.nsplit > 1) {
       f32x4 acc[4] = {zero, zero, zero, zero};
@@ -504,14 +453,13 @@ using namespace fsf;
 extern "C" int64_t fsf_spconv_backward_weight_workspace_bytes(int64_t cap, int32_t cin, int32_t cout, int32_t kvol) {
   int ta, tb, nsplit, range;
   bwd_plan(cap, cin, cout, kvol, &ta, &tb, &nsplit, &range);
-  // (+ the row-range bounds table of the sorted entry point)
-  return (nsplit > 1 ? fsf_align_up((int64_t)kvol * nsplit * cin * cout * 4, 256) + 256 : 256) +
-         fsf_align_up((int64_t)kvol * (nsplit + 1) * 4, 256);
+  return nsplit > 1 ? fsf_align_up((int64_t)kvol * nsplit * cin * cout * 4, 256) + 256 : 256;
 }
 
-static int bwd_weight_impl(const float* feat, int64_t m_in, int32_t cin, const float* grad_out, int64_t m_out, int32_t cout,
-                           const int32_t* indice_pairs, const int32_t* indice_num, int64_t cap, int32_t kvol, float* grad_weight,
-                           void* workspace, int64_t workspace_bytes, void* stream_, bool sorted_by_out) {
+extern "C" int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32_t cin, const float* grad_out, int64_t m_out,
+                                          int32_t cout, const int32_t* indice_pairs, const int32_t* indice_num, int64_t cap,
+                                          int32_t kvol, float* grad_weight, void* workspace, int64_t workspace_bytes,
+                                          void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const bool identity = indice_pairs == nullptr && indice_num == nullptr;  // dense layer: pair p = (row p, row p), kvol 1
   if (m_in < 0 || m_out < 0 || cin < 1 || cout < 1 || kvol < 1 || cap < 0 || !grad_weight ||
@@ -524,7 +472,7 @@ static int bwd_weight_impl(const float* feat, int64_t m_in, int32_t cin, const f
   if (workspace_bytes < fsf_spconv_backward_weight_workspace_bytes(cap, cin, cout, kvol) || (nsplit > 1 && !workspace))
     return FSF_ERR_WORKSPACE;
   SpconvBwdArgs a{feat, grad_out, indice_pairs, indice_num, grad_weight, (float*)workspace, cap,
-                  (int)cin, (int)cout, (int)kvol, nsplit, range, fsf_cdiv(cout, tb), nullptr, 0, fsf_cdiv(cin, ta) * fsf_cdiv(cout, tb)};
+                  (int)cin, (int)cout, (int)kvol, nsplit, range, fsf_cdiv(cout, tb)};
   const dim3 grid((unsigned)nsplit, (unsigned)kvol, (unsigned)(fsf_cdiv(cin, ta) * fsf_cdiv(cout, tb)));
 #define FSF_BWD_LAUNCH(TA_, TB_)                                                                                         \
   do {                                                                                                                   \
@@ -535,23 +483,10 @@ static int bwd_weight_impl(const float* feat, int64_t m_in, int32_t cin, const f
   } while (0)
   // (A/B switch, latched: FSF_BWD_SPLIT=0 keeps the fp32-pipe kernel for the 128 x 128 tiles as well)
   static const bool split_on = !(getenv("FSF_BWD_SPLIT") && atoi(getenv("FSF_BWD_SPLIT")) == 0);
-  // (A/B switch, latched: FSF_BWD_RANGES=0 keeps the cut by pair index for sorted pair lists as well)
-  static const bool ranges_on = !(getenv("FSF_BWD_RANGES") && atoi(getenv("FSF_BWD_RANGES")) == 0);
-  if (cap > 0 && split_on && ta == 128 && tb == 128 && sorted_by_out && ranges_on && kvol >= 8 && nsplit > 1 && m_out > 0) {
-    // K10p by output-row range: the same number of splits, cut where the output row crosses a multiple of rows_per_range
-    a.rows_per_range = (int)fsf_align_up(fsf_cdiv(m_out, nsplit), 16);
-    a.nsplit = fsf_cdiv(m_out, a.rows_per_range);
-    int32_t* bounds = (int32_t*)((char*)workspace + fsf_align_up((int64_t)kvol * nsplit * cin * cout * 4, 256) + 256);
-    a.bounds = bounds;
-    hipLaunchKernelGGL(bws_bounds_kernel, dim3(fsf_cdiv((int64_t)kvol * (a.nsplit + 1), 256)), dim3(256), 0, stream, a, bounds);
+  if (cap > 0 && split_on && ta == 128 && tb == 128) {
     static std::atomic<uint64_t> attr_done{0};
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_bwd_weight_split_kernel<true>, BWS_SMEM, attr_done));
-    const unsigned wgs = 8u * (unsigned)fsf_cdiv(a.nsplit, 8) * (unsigned)kvol * (unsigned)a.tiles;
-    hipLaunchKernelGGL(spconv_bwd_weight_split_kernel<true>, dim3(wgs), dim3(256), BWS_SMEM, stream, a);
-  } else if (cap > 0 && split_on && ta == 128 && tb == 128) {
-    static std::atomic<uint64_t> attr_done{0};
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_bwd_weight_split_kernel<false>, BWS_SMEM, attr_done));
-    hipLaunchKernelGGL(spconv_bwd_weight_split_kernel<false>, grid, dim3(256), BWS_SMEM, stream, a);
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_bwd_weight_split_kernel, BWS_SMEM, attr_done));
+    hipLaunchKernelGGL(spconv_bwd_weight_split_kernel, grid, dim3(256), BWS_SMEM, stream, a);
   } else if (cap > 0) {
     if (ta == 64 && tb == 64) FSF_BWD_LAUNCH(64, 64);
     else if (ta == 64) FSF_BWD_LAUNCH(64, 128);
@@ -562,20 +497,4 @@ static int bwd_weight_impl(const float* feat, int64_t m_in, int32_t cin, const f
   hipLaunchKernelGGL(spconv_bwd_fold_kernel, dim3(fsf_stream_grid((int64_t)kvol * cin * cout / 4 * 16, 256)), dim3(256), 0, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
-}
-
-extern "C" int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32_t cin, const float* grad_out, int64_t m_out,
-                                          int32_t cout, const int32_t* indice_pairs, const int32_t* indice_num, int64_t cap,
-                                          int32_t kvol, float* grad_weight, void* workspace, int64_t workspace_bytes,
-                                          void* stream_) {
-  return bwd_weight_impl(feat, m_in, cin, grad_out, m_out, cout, indice_pairs, indice_num, cap, kvol, grad_weight, workspace,
-                         workspace_bytes, stream_, false);
-}
-
-extern "C" int fsf_spconv_backward_weight_sorted(const float* feat, int64_t m_in, int32_t cin, const float* grad_out, int64_t m_out,
-                                                 int32_t cout, const int32_t* indice_pairs, const int32_t* indice_num, int64_t cap,
-                                                 int32_t kvol, float* grad_weight, void* workspace, int64_t workspace_bytes,
-                                                 void* stream_) {
-  return bwd_weight_impl(feat, m_in, cin, grad_out, m_out, cout, indice_pairs, indice_num, cap, kvol, grad_weight, workspace,
-                         workspace_bytes, stream_, true);
 }

@@ -215,11 +215,13 @@ struct IgIn {
 // group); the plugin had ~22 small ATen launches and two nonzero() syncs here.
 __global__ void __launch_bounds__(256)
     ks_group_valid_kernel(const int64_t* __restrict__ new_keys, int key_cols, const int64_t* __restrict__ cnt, int64_t m, int64_t bsz,
-                          int64_t min_points, int ng, int* __restrict__ has_valid) {
+                          int64_t min_points, int ng, volatile int* has_valid) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (int64_t)gridDim.x * blockDim.x) {
     if (cnt[i] >= min_points) {
       const int64_t g = new_keys[i * key_cols] / bsz;
-      if (g >= 0 && g < ng) atomicOr(has_valid + g, 1);  // (idempotent: the result does not depend on the order)
+      // a plain store of 1 (idempotent, so the race is benign): a wave's lanes mostly share g and their stores merge into one
+      // write, where one atomicOr per dense key serialised ~100k same-address atomics on one L2 channel (0.95 ms per 10-sweep frame)
+      if (g >= 0 && g < ng && has_valid[g] == 0) has_valid[g] = 1;
     }
   }
 }

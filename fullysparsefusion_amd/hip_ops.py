@@ -49,7 +49,6 @@ _ARGTYPES = {
     "fsf_spconv_forward": [_P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
     "fsf_spconv_backward_weight_workspace_bytes": [c_i64, c_i32, c_i32, c_i32],
     "fsf_spconv_backward_weight": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
-    "fsf_spconv_backward_weight_sorted": [_P, c_i64, c_i32, _P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_connected_components_workspace_bytes": [c_i64],
     "fsf_connected_components": [_P, c_i64, c_i32, _P, c_f32, _P, _P, _P, c_i64, _P],
     "fsf_column_stats_workspace_bytes": [c_i32],
@@ -750,11 +749,9 @@ def linear_backward_weight(x: torch.Tensor, grad_out: torch.Tensor):
     return gw[0]
 
 
-def spconv_backward_weight(feat: torch.Tensor, grad_out: torch.Tensor, pairs: torch.Tensor, num: torch.Tensor, sorted_pairs: bool = False):
-    """fsf_spconv_backward_weight[_sorted]: feat f32 [m_in,cin], grad_out f32 [m_out,cout], (pairs, num) from
-    rulebook_to_pairs -> grad_weight f32 [kvol,cin,cout].  `sorted_pairs`: every offset's list ascends in output row (what
-    rulebook_to_pairs produces) — the library may then cut the work by output-row range (L2 reuse); pass False for lists of any other
-    order."""
+def spconv_backward_weight(feat: torch.Tensor, grad_out: torch.Tensor, pairs: torch.Tensor, num: torch.Tensor):
+    """fsf_spconv_backward_weight: feat f32 [m_in,cin], grad_out f32 [m_out,cout], (pairs, num) from
+    rulebook_to_pairs -> grad_weight f32 [kvol,cin,cout]."""
     require_cuda(feat, grad_out, pairs, num)
     feat = feat.contiguous()
     grad_out = grad_out.contiguous()
@@ -767,9 +764,8 @@ def spconv_backward_weight(feat: torch.Tensor, grad_out: torch.Tensor, pairs: to
     gw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=feat.device)
     h = _L()
     ws = _lib.workspace(h.fsf_spconv_backward_weight_workspace_bytes(cap, cin, cout, kvol), feat.device)
-    fn = h.fsf_spconv_backward_weight_sorted if sorted_pairs else h.fsf_spconv_backward_weight
-    check(fn(ptr(feat), m_in, cin, ptr(grad_out), m_out, cout, ptr(pairs), ptr(num), cap, kvol,
-             ptr(gw), ptr(ws), ws.numel(), stream_ptr()), "fsf_spconv_backward_weight")
+    check(h.fsf_spconv_backward_weight(ptr(feat), m_in, cin, ptr(grad_out), m_out, cout, ptr(pairs), ptr(num), cap, kvol,
+                                       ptr(gw), ptr(ws), ws.numel(), stream_ptr()), "fsf_spconv_backward_weight")
     return gw
 
 

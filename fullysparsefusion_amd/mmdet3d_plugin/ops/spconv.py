@@ -136,7 +136,7 @@ class _SparseConvFn(torch.autograd.Function):
                 g_feat = hip_ops.spconv_forward(grad, w, table_t)
         if ctx.needs_input_grad[1]:
             pairs, num = rb.pairs(inverse)
-            g_w = hip_ops.spconv_backward_weight(feat, grad, pairs, num, sorted_pairs=True).reshape(weight.shape)  # (rulebook_to_pairs: ascending output row)
+            g_w = hip_ops.spconv_backward_weight(feat, grad, pairs, num).reshape(weight.shape)
         return g_feat, g_w, None, None, None, None
 
 

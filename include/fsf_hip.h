@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 10
+#define FSF_ABI_VERSION 9
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -520,14 +520,6 @@ int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32_t cin, con
                                int32_t cout, const int32_t* indice_pairs, const int32_t* indice_num, int64_t cap,
                                int32_t kvol, float* grad_weight, void* workspace, int64_t workspace_bytes,
                                void* stream);
-/* The same for pair lists whose every offset ascends in OUTPUT ROW (what fsf_rulebook_to_pairs produces; the identity pairing of a
- * dense layer trivially does): the 128 x 128 tiles are then cut by output-row range instead of by pair index, and the kvol x tiles
- * workgroups of one range run back to back on one XCD, so that the ~15 re-reads of a gathered row (one per offset it takes part in,
- * times the channel tiles) meet in that XCD's L2.  Same results as the unsorted entry point up to the fp32 summation order of the
- * partial tiles (fixed: deterministic).  A list that is not sorted gives wrong gradients here — use fsf_spconv_backward_weight. */
-int fsf_spconv_backward_weight_sorted(const float* feat, int64_t m_in, int32_t cin, const float* grad_out, int64_t m_out,
-                                      int32_t cout, const int32_t* indice_pairs, const int32_t* indice_num, int64_t cap, int32_t kvol,
-                                      float* grad_weight, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K19  connected components of the graph "xy-distance < dist" (same batch index), labels contiguous 0..K-1
