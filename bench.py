@@ -149,17 +149,22 @@ def count_launch_sources(model, inp, hot_path_only=False):
             name = str(func).replace("aten.", "").split(".")[0]
             if name not in view:
                 counts["aten"] += 1
-            if name in ("_local_scalar_dense", "nonzero", "masked_select"):
-                counts["sync"] += 1
+            a0 = args[0] if args else None
+            if name in ("nonzero", "masked_select") or (name == "_local_scalar_dense" and torch.is_tensor(a0) and a0.is_cuda):
+                counts["sync"] += 1  # (an .item() on a HOST tensor — the box tail reads its one read-back that way — waits for nothing)
+            elif name in ("_to_copy", "copy_"):  # a device -> host copy waits for the stream
+                src = args[1] if name == "copy_" else a0
+                dst = a0.device if name == "copy_" else (kwargs or {}).get("device", None)
+                if torch.is_tensor(src) and src.is_cuda and dst is not None and torch.device(dst).type == "cpu":
+                    counts["sync"] += 1
             return func(*args, **(kwargs or {}))
 
     orig_check, orig_sync = _lib.check, torch.cuda.synchronize
-    sync_calls = {"fsf_unique_rows", "fsf_rulebook_strided", "fsf_cluster_key_survival"}
+    HOST_WAITS = 2  # FSF_OPT_HOST_WAITS: the library's own count of its stream waits (every count / flag read-back)
+    waits0 = int(_lib.lib().fsf_get_option(HOST_WAITS))
 
     def check(status, what):
         counts["cabi"] += 1
-        if what in sync_calls:
-            counts["sync"] += 1
         return orig_check(status, what)
 
     def sync(*a, **k):
@@ -180,6 +185,7 @@ def count_launch_sources(model, inp, hot_path_only=False):
             model.test_cfg.pop("concurrent_query_branches", None)
         else:
             model.test_cfg["concurrent_query_branches"] = was
+    counts["sync"] += int(_lib.lib().fsf_get_option(HOST_WAITS)) - waits0
     orig_sync()
     traced = None
     pdir = os.path.join(ROOT, "profiles")

@@ -72,6 +72,7 @@ def lib():
                     "fsf_planes_bytes", "fsf_planes_scale_count", "fsf_spconv_planes_weight_bytes", "fsf_assemble_sweeps_workspace_bytes",
                     "fsf_get_option", "fsf_order_by_neighbor_mask_workspace_bytes",
                     "fsf_class_rank_desc_workspace_bytes", "fsf_nms_select_capacity", "fsf_cluster_key_survival_workspace_bytes",
+                    "fsf_overlap_plan_workspace_bytes",
                 ):
                     getattr(h, name).restype = c_i64
                 _lib = h
@@ -81,7 +82,9 @@ def lib():
 def check(status, what):
     if status != 0:
         msg = lib().fsf_status_string(int(status)).decode()
-        raise FsfHipError(f"{what} failed: {msg} (status {status})")
+        err = FsfHipError(f"{what} failed: {msg} (status {status})")
+        err.status = int(status)
+        raise err
 
 
 def require_cuda(*tensors):

@@ -134,7 +134,7 @@ extern "C" int fsf_assemble_sweeps(const float* raw, int64_t n_rows, int32_t loa
   if (rc != FSF_OK) return rc;
   if (count_host) {
     FSF_HIP_TRY(hipMemcpyAsync(count_host, tot, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FSF_HIP_TRY(hipStreamSynchronize(stream));
+    FSF_STREAM_WAIT(stream);
   }
   return FSF_OK;
 }

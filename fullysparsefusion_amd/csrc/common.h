@@ -15,6 +15,17 @@
     if (_e != hipSuccess) return FSF_ERR_HIP;  \
   } while (0)
 
+// Every place the library makes the HOST wait for the stream goes through this: the count is what bench.py / sync_sites.py report
+// (fsf_get_option(FSF_OPT_HOST_WAITS)).
+namespace fsf {
+extern std::atomic<int64_t> g_host_waits;
+}
+#define FSF_STREAM_WAIT(stream)                                        \
+  do {                                                                 \
+    fsf::g_host_waits.fetch_add(1, std::memory_order_relaxed);         \
+    FSF_HIP_TRY(hipStreamSynchronize(stream));                         \
+  } while (0)
+
 #define FSF_LAUNCH_CHECK()                               \
   do {                                                   \
     if (hipPeekAtLastError() != hipSuccess) return FSF_ERR_HIP; \

@@ -523,7 +523,7 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
   }
   if (num_keep_host) {
     FSF_HIP_TRY(hipMemcpyAsync(num_keep_host, ndev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FSF_HIP_TRY(hipStreamSynchronize(stream));
+    FSF_STREAM_WAIT(stream);
   }
   return FSF_OK;
 }

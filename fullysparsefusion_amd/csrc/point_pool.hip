@@ -548,7 +548,7 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
       FSF_LAUNCH_CHECK();
       if (count_host) {
         FSF_HIP_TRY(hipMemcpyAsync(count_host, cdev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-        FSF_HIP_TRY(hipStreamSynchronize(stream));
+        FSF_STREAM_WAIT(stream);
       }
       return FSF_OK;
     }
@@ -573,7 +573,7 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
   }
   if (count_host) {
     FSF_HIP_TRY(hipMemcpyAsync(count_host, cdev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FSF_HIP_TRY(hipStreamSynchronize(stream));
+    FSF_STREAM_WAIT(stream);
   }
   return FSF_OK;
 }

@@ -3,6 +3,8 @@
 // type (no float copy).  Every fp32 operation is an explicit round-to-nearest op in the order the
 // reference's elementwise PyTorch ops apply them (FSF.py:169-200), so pixel indices are bit-exact.
 #include "common.h"
+#include "radix_sort.h"
+#include "scan.h"
 
 namespace fsf {
 
@@ -163,9 +165,34 @@ struct ProjScoreArgs {
   float* score;
   int64_t* ids;
   unsigned char* fg;
+  unsigned char* count;
+  int32_t* max_id;
   int64_t n;
   int stride, ncam, ncls, H, W, num_anno, anno_dim, score_col;
 };
+
+
+// One camera of FSF.prj_points_2d (FSF.py:169-200) + the nearest-pixel rule of grid_sample(mode='nearest', align_corners=False,
+// padding_mode='zeros') that points_in_mask (:202-226) applies: true and *pix = row * W + column if the point lands inside the image.
+__device__ __forceinline__ bool proj_pixel(const float* m, float x, float y, float z, float fw, float fh, int W, int64_t* pix) {
+  float px = proj_row(m, x, y, z), py = proj_row(m + 4, x, y, z), pz = proj_row(m + 8, x, y, z);
+  const bool depth_valid = pz > 1e-3f;
+  pz = fminf(fmaxf(pz, 1e-5f), 1e5f);
+  px = __fdiv_rn(__fdiv_rn(px, pz), fw);
+  py = __fdiv_rn(__fdiv_rn(py, pz), fh);
+  float gx = __fmul_rn(__fsub_rn(px, 0.5f), 2.0f), gy = __fmul_rn(__fsub_rn(py, 0.5f), 2.0f);
+  const bool valid = depth_valid && gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f;
+  if (!valid) {
+    gx = -2.0f;
+    gy = -2.0f;
+  }
+  const float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), __fdiv_rn(fw, 2.0f)), 0.5f);
+  const float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), __fdiv_rn(fh, 2.0f)), 0.5f);
+  const float rx = rintf(ix), ry = rintf(iy);
+  const bool inb = valid && rx >= 0.0f && rx < fw && ry >= 0.0f && ry < fh;
+  *pix = inb ? (int64_t)ry * W + (int64_t)rx : 0;
+  return inb;
+}
 
 template <typename MaskT>
 __global__ void __launch_bounds__(256) project_score_kernel(ProjScoreArgs a) {
@@ -183,30 +210,19 @@ __global__ void __launch_bounds__(256) project_score_kernel(ProjScoreArgs a) {
     for (int k = 0; k < PS_MAX_CLS; ++k) best[k] = 0;
     int64_t best_sum = INT64_MIN;
     bool any = false;
+    int positive = 0, top = 0;  // cells with an id > 0 over ALL cameras, and the largest id (obj_id_tensor.max(-1), FSF.py:263)
     for (int cam = 0; cam < a.ncam; ++cam) {
-      const float* m = s_mat + cam * 12;
-      float px = proj_row(m, x, y, z), py = proj_row(m + 4, x, y, z), pz = proj_row(m + 8, x, y, z);
-      const bool depth_valid = pz > 1e-3f;
-      pz = fminf(fmaxf(pz, 1e-5f), 1e5f);
-      px = __fdiv_rn(__fdiv_rn(px, pz), fw);
-      py = __fdiv_rn(__fdiv_rn(py, pz), fh);
-      float gx = __fmul_rn(__fsub_rn(px, 0.5f), 2.0f), gy = __fmul_rn(__fsub_rn(py, 0.5f), 2.0f);
-      const bool valid = depth_valid && gx > -1.0f && gx < 1.0f && gy > -1.0f && gy < 1.0f;
-      if (!valid) {
-        gx = -2.0f;
-        gy = -2.0f;
-      }
-      const float ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.0f), __fdiv_rn(fw, 2.0f)), 0.5f);
-      const float iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.0f), __fdiv_rn(fh, 2.0f)), 0.5f);
-      const float rx = rintf(ix), ry = rintf(iy);
-      const bool inb = valid && rx >= 0.0f && rx < fw && ry >= 0.0f && ry < fh;
+      int64_t pix;
+      const bool inb = proj_pixel(s_mat + cam * 12, x, y, z, fw, fh, a.W, &pix);
       int cur[PS_MAX_CLS];
       int64_t sum = 0;
-      const MaskT* mc = mask + (int64_t)cam * a.ncls * plane + (inb ? (int64_t)ry * a.W + (int64_t)rx : 0);
+      const MaskT* mc = mask + (int64_t)cam * a.ncls * plane + (inb ? pix : 0);
 #pragma unroll
       for (int k = 0; k < PS_MAX_CLS; ++k) {
         cur[k] = (inb && k < a.ncls) ? (int)mc[(int64_t)k * plane] : 0;
         sum += cur[k];
+        positive += cur[k] > 0 ? 1 : 0;
+        top = cur[k] > top ? cur[k] : top;
       }
       any |= sum > 0;
       if (sum > best_sum) {  // strict: the first maximum wins, like torch.max(dim)[1]
@@ -224,6 +240,8 @@ __global__ void __launch_bounds__(256) project_score_kernel(ProjScoreArgs a) {
       }
     }
     if (a.fg) a.fg[i] = any ? 1 : 0;
+    if (a.count) a.count[i] = (unsigned char)(positive > 255 ? 255 : positive);
+    if (a.max_id) a.max_id[i] = top;
   }
 }
 }  // namespace fsf
@@ -231,7 +249,7 @@ __global__ void __launch_bounds__(256) project_score_kernel(ProjScoreArgs a) {
 extern "C" int fsf_project_score(const float* xyz, int64_t n, int32_t xyz_stride, const float* lidar2img, int32_t ncam,
                                  const void* mask, int32_t elem_bytes, int32_t ncls, int32_t img_h, int32_t img_w,
                                  const float* mask_anno, int32_t num_anno, int32_t anno_dim, int32_t score_col, float* out_score,
-                                 int64_t* out_ids, uint8_t* out_fg, void* stream_) {
+                                 int64_t* out_ids, uint8_t* out_fg, uint8_t* out_count, int32_t* out_max_id, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || xyz_stride < 3 || ncam < 1 || ncam > 64 || ncls < 1 || img_h < 1 || img_w < 1 || !lidar2img || !mask ||
       (elem_bytes != 1 && elem_bytes != 4) || num_anno < 0 || anno_dim < 1 || score_col < 0 || score_col >= anno_dim ||
@@ -239,7 +257,7 @@ extern "C" int fsf_project_score(const float* xyz, int64_t n, int32_t xyz_stride
     return FSF_ERR_INVALID_ARG;
   if (ncls > fsf::PS_MAX_CLS) return FSF_ERR_UNSUPPORTED;
   if (n == 0) return FSF_OK;
-  fsf::ProjScoreArgs a{xyz, lidar2img, mask, mask_anno, out_score, out_ids, out_fg, n, (int)xyz_stride, (int)ncam, (int)ncls,
+  fsf::ProjScoreArgs a{xyz, lidar2img, mask, mask_anno, out_score, out_ids, out_fg, out_count, out_max_id, n, (int)xyz_stride, (int)ncam, (int)ncls,
                        (int)img_h, (int)img_w, (int)num_anno, (int)anno_dim, (int)score_col};
   const int grid = fsf_stream_grid(n, 256);
   const size_t shmem = (size_t)ncam * 12 * sizeof(float);
@@ -418,6 +436,243 @@ extern "C" int fsf_row_topk_desc(const int64_t* x, int64_t n, int32_t w, int32_t
   int64_t g = (n + 15) / 16;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(fsf::row_topk_kernel, dim3((unsigned)g), dim3(256), 0, stream, x, n, (int)w, (int)k, out);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// K26: the row list of the camera-query branch in two calls and ONE read-back.
+// FSF.frustum_pooling (FSF.py:388-437) keeps the points inside any mask (extract_fg_pts :299-308), then double_overlap_pts
+// (:260-297) appends, for k = 2, 3, ... and within k for j = 1 .. k - 1, one more row per point that lies inside k masks, carrying the
+// j-th largest of its ids (row 0 of topk went to the point's own row), and get_sir_coors (:373-376) makes the (batch, 0, id) keys.
+// Upstream: a boolean-mask compaction of five tensors per k (a host sync each).  The plugin's ATen form of it: nonzero, the ids of the
+// foreground points as an [F, ncam * ncls] int64 tensor, ~45 small launches and three host syncs.  Here:
+//   fsf_overlap_plan:  from K13-K16's per-point cell count: scan of the foreground flag (-> the ascending foreground list), ONE 8-bit
+//                      stable radix pass over (k if k >= 2 else 0) (-> the points of each k in ascending order), a 256-thread kernel that
+//                      turns the sorted keys into per-k starts / counts / row bases; reads back (F, M, T);
+//   fsf_overlap_rows:  row r < F: point fg[r], id = its largest id; the rows of a point with k cells, rank q among the points of its k:
+//                      F + base[k] + (j - 1) * count[k] + q, id = its j-th largest (the mask cells are re-read: 1-byte L2 hits).
+namespace fsf {
+
+struct OvIn {
+  const uint8_t* fg;
+  const uint8_t* count;
+  uint64_t* keys;
+  uint32_t* vals;
+  __device__ uint32_t operator()(int64_t i) const {
+    const bool f = fg[i] != 0;
+    const uint32_t k = count[i];
+    keys[i] = (f && k >= 2u) ? (uint64_t)k : 0ull;  // (idempotent side effect: the 3-launch scan calls this twice)
+    vals[i] = (uint32_t)i;
+    return f ? 1u : 0u;
+  }
+};
+struct OvOut {
+  uint32_t* fg_idx;
+  __device__ void operator()(int64_t i, uint32_t excl, uint32_t v) const {
+    if (v) fg_idx[excl] = (uint32_t)i;
+  }
+};
+
+// table: int32 [3][256] = start / count / base per k; ret: int64 [4] = F (already there), M, T, saturated-count flag
+__global__ void __launch_bounds__(256) ov_plan_kernel(const uint64_t* __restrict__ keys, int64_t n, int32_t* __restrict__ table, int64_t* __restrict__ ret) {
+  __shared__ int64_t s_start[257];
+  __shared__ int64_t s_rows[256];
+  const int k = threadIdx.x;
+  int64_t lo = 0, hi = n;  // first position with key >= k
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < (uint64_t)k) lo = mid + 1; else hi = mid;
+  }
+  s_start[k] = lo;
+  if (k == 0) s_start[256] = n;
+  __syncthreads();
+  const int64_t cnt = k >= 2 ? s_start[k + 1] - s_start[k] : 0;
+  s_rows[k] = cnt * (k - 1);
+  __syncthreads();
+  int64_t base = 0;
+  for (int q = 2; q < k; ++q) base += s_rows[q];
+  table[k] = (int32_t)s_start[k];
+  table[256 + k] = (int32_t)cnt;
+  table[512 + k] = (int32_t)base;
+  if (k == 255) {
+    ret[1] = n - s_start[2];
+    ret[2] = base + s_rows[255];
+    ret[3] = cnt > 0 ? 1 : 0;  // a count of 255 may be a saturated one: the caller must not trust the plan
+  }
+}
+
+struct OvRowsArgs {
+  const float* xyz;
+  const float* lidar2img;
+  const void* mask;
+  const int32_t* max_id;
+  const int64_t* batch_idx;  // or NULL: batch 0
+  const uint32_t* fg_idx;
+  const uint64_t* keys;
+  const uint32_t* vals;
+  const int32_t* table;
+  int64_t* src_pt;
+  int64_t* sir_coors;
+  int64_t n, F, M;
+  int stride, ncam, ncls, H, W;
+};
+
+__global__ void __launch_bounds__(256) ov_own_rows_kernel(OvRowsArgs a) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.F; r += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = a.fg_idx[r];
+    a.src_pt[r] = i;
+    a.sir_coors[r * 3 + 0] = a.batch_idx ? a.batch_idx[i] : 0;
+    a.sir_coors[r * 3 + 1] = 0;
+    a.sir_coors[r * 3 + 2] = a.max_id[i];
+  }
+}
+
+template <typename MaskT>
+__global__ void __launch_bounds__(256) ov_extra_rows_kernel(OvRowsArgs a) {
+  extern __shared__ float s_mat[];
+  for (int t = threadIdx.x; t < a.ncam * 12; t += blockDim.x) s_mat[t] = a.lidar2img[(t / 12) * 16 + t % 12];
+  __syncthreads();
+  const MaskT* mask = reinterpret_cast<const MaskT*>(a.mask);
+  const float fw = (float)a.W, fh = (float)a.H;
+  const int64_t plane = (int64_t)a.H * a.W;
+  const int64_t first = a.n - a.M;  // the sorted list holds the points with k < 2 (key 0) in front
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < a.M; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = first + t;
+    const int64_t i = a.vals[s];
+    const int k = (int)a.keys[s];
+    const int64_t per_j = a.table[256 + k];
+    const int64_t row0 = a.F + a.table[512 + k] + (s - a.table[k]);
+    const int64_t b = a.batch_idx ? a.batch_idx[i] : 0;
+    const float* p = a.xyz + i * a.stride;
+    const float x = p[0], y = p[1], z = p[2];
+    int64_t prev = INT64_MAX;
+    int emitted = 0;
+    while (emitted < k) {
+      // the largest id below `prev` and how many cells hold it (topk keeps duplicates as separate entries)
+      int64_t cur = 0;
+      int same = 0;
+      for (int cam = 0; cam < a.ncam; ++cam) {
+        int64_t pix;
+        if (!proj_pixel(s_mat + cam * 12, x, y, z, fw, fh, a.W, &pix)) continue;
+        const MaskT* mc = mask + (int64_t)cam * a.ncls * plane + pix;
+        for (int c = 0; c < a.ncls; ++c) {
+          const int64_t v = (int64_t)mc[(int64_t)c * plane];
+          if (v <= 0 || v >= prev) continue;
+          if (v > cur) {
+            cur = v;
+            same = 1;
+          } else if (v == cur) {
+            ++same;
+          }
+        }
+      }
+      if (same == 0) break;  // (cannot happen when `k` is this point's cell count)
+      for (int e = 0; e < same; ++e) {
+        const int j = emitted + e;
+        if (j >= 1 && j < k) {
+          const int64_t r = row0 + (int64_t)(j - 1) * per_j;
+          a.src_pt[r] = i;
+          a.sir_coors[r * 3 + 0] = b;
+          a.sir_coors[r * 3 + 1] = 0;
+          a.sir_coors[r * 3 + 2] = cur;
+        }
+      }
+      emitted += same;
+      prev = cur;
+    }
+  }
+}
+
+struct OvLayout {
+  uint32_t* fg_idx;
+  uint64_t *keys_a, *keys_b;
+  uint32_t *vals_a, *vals_b;
+  uint32_t* hist;
+  uint32_t* tile_sums;
+  int64_t* ret;
+  int32_t* table;
+  size_t zero_bytes;
+  bool ok;
+};
+static OvLayout ov_layout(void* ws, int64_t ws_bytes, int64_t n) {
+  FsfArena ar(ws, ws_bytes);
+  OvLayout l;
+  l.fg_idx = ar.take<uint32_t>(n);
+  l.keys_a = ar.take<uint64_t>(n);
+  l.keys_b = ar.take<uint64_t>(n);
+  l.vals_a = ar.take<uint32_t>(n);
+  l.vals_b = ar.take<uint32_t>(n);
+  l.hist = ar.take<uint32_t>((radix_num_tiles(n) + 1) * RS_BINS);  // [hist | tile_sums | ret] are consecutive: one memset
+  l.tile_sums = ar.take<uint32_t>(scan_num_tiles(n));
+  l.ret = ar.take<int64_t>(4);
+  l.table = ar.take<int32_t>(3 * 256);
+  l.zero_bytes = (size_t)((char*)l.table - (char*)l.hist);
+  l.ok = ar.ok();
+  return l;
+}
+}  // namespace fsf
+
+extern "C" int64_t fsf_overlap_plan_workspace_bytes(int64_t n) {
+  const int64_t m = n > 0 ? n : 1;
+  return fsf_align_up(m * 4, 256) * 3 + fsf_align_up(m * 8, 256) * 2 + fsf_align_up((radix_num_tiles(n) + 1) * RS_BINS * 4, 256) +
+         fsf_align_up(scan_num_tiles(n) * 4, 256) + 256 + fsf_align_up(3 * 256 * 4, 256);
+}
+
+extern "C" int fsf_overlap_plan(const uint8_t* fg, const uint8_t* count, int64_t n, int32_t max_cells, int64_t* counts_host, void* workspace,
+                                int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || !counts_host || (n > 0 && (!fg || !count))) return FSF_ERR_INVALID_ARG;
+  if (max_cells < 1 || max_cells > 254 || n >= ((int64_t)1 << 31)) return FSF_ERR_UNSUPPORTED;  // (a u8 count must not saturate)
+  counts_host[0] = counts_host[1] = counts_host[2] = 0;
+  if (n == 0) return FSF_OK;
+  if (!workspace || workspace_bytes < fsf_overlap_plan_workspace_bytes(n)) return FSF_ERR_WORKSPACE;
+  const OvLayout l = ov_layout(workspace, workspace_bytes, n);
+  if (!l.ok) return FSF_ERR_WORKSPACE;
+  FSF_HIP_TRY(hipMemsetAsync(l.hist, 0, l.zero_bytes, stream));
+  int rc = exclusive_scan_u32(OvIn{fg, count, l.keys_a, l.vals_a}, OvOut{l.fg_idx}, n, l.tile_sums, nullptr, l.ret, stream, 1, true);
+  if (rc != FSF_OK) return rc;
+  uint64_t* keys_s;
+  uint32_t* vals_s;
+  rc = radix_sort_pairs(l.keys_a, l.vals_a, l.keys_b, l.vals_b, l.hist, n, 8, &keys_s, &vals_s, stream, true);
+  if (rc != FSF_OK) return rc;
+  if (keys_s != l.keys_b || vals_s != l.vals_b) return FSF_ERR_UNSUPPORTED;  // (one pass: fsf_overlap_rows reads the alternate buffers)
+  hipLaunchKernelGGL(ov_plan_kernel, dim3(1), dim3(256), 0, stream, keys_s, n, l.table, l.ret);
+  FSF_LAUNCH_CHECK();
+  int64_t ret_h[4] = {0, 0, 0, 0};
+  FSF_HIP_TRY(hipMemcpyAsync(ret_h, l.ret, sizeof(ret_h), hipMemcpyDeviceToHost, stream));
+  FSF_STREAM_WAIT(stream);
+  if (ret_h[3]) return FSF_ERR_UNSUPPORTED;
+  counts_host[0] = ret_h[0];
+  counts_host[1] = ret_h[1];
+  counts_host[2] = ret_h[2];
+  return FSF_OK;
+}
+
+extern "C" int fsf_overlap_rows(const float* xyz, int64_t n, int32_t xyz_stride, const float* lidar2img, int32_t ncam, const void* mask,
+                                int32_t elem_bytes, int32_t ncls, int32_t img_h, int32_t img_w, const int32_t* max_id,
+                                const int64_t* batch_idx, const void* workspace, int64_t workspace_bytes, int64_t num_fg, int64_t num_multi,
+                                int64_t num_extra, int64_t* src_pt, int64_t* sir_coors, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || xyz_stride < 3 || ncam < 1 || ncam > 64 || ncls < 1 || img_h < 1 || img_w < 1 || !lidar2img || !mask ||
+      (elem_bytes != 1 && elem_bytes != 4) || num_fg < 0 || num_multi < 0 || num_extra < 0 || num_fg > n || num_multi > num_fg ||
+      (num_fg > 0 && (!xyz || !max_id || !src_pt || !sir_coors)))
+    return FSF_ERR_INVALID_ARG;
+  if (num_fg == 0) return FSF_OK;
+  if (!workspace || workspace_bytes < fsf_overlap_plan_workspace_bytes(n)) return FSF_ERR_WORKSPACE;
+  const OvLayout l = ov_layout(const_cast<void*>(workspace), workspace_bytes, n);
+  if (!l.ok) return FSF_ERR_WORKSPACE;
+  (void)num_extra;
+  OvRowsArgs a{xyz, lidar2img, mask, max_id, batch_idx, l.fg_idx, l.keys_b, l.vals_b, l.table, src_pt, sir_coors, n, num_fg, num_multi,
+               (int)xyz_stride, (int)ncam, (int)ncls, (int)img_h, (int)img_w};
+  hipLaunchKernelGGL(ov_own_rows_kernel, dim3(fsf_stream_grid(num_fg, 256)), dim3(256), 0, stream, a);
+  if (num_multi > 0) {
+    const size_t shmem = (size_t)ncam * 12 * sizeof(float);
+    if (elem_bytes == 1)
+      hipLaunchKernelGGL((ov_extra_rows_kernel<uint8_t>), dim3(fsf_stream_grid(num_multi, 256)), dim3(256), shmem, stream, a);
+    else
+      hipLaunchKernelGGL((ov_extra_rows_kernel<int32_t>), dim3(fsf_stream_grid(num_multi, 256)), dim3(256), shmem, stream, a);
+  }
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

@@ -443,14 +443,14 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
   FSF_LAUNCH_CHECK();
   uint32_t count_h = 0;
   FSF_HIP_TRY(hipMemcpyAsync(&count_h, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  FSF_HIP_TRY(hipStreamSynchronize(stream));
+  FSF_STREAM_WAIT(stream);
   const int64_t m_out = (int64_t)count_h;
   *m_out_host = m_out;
   if (m_out > cap_out) return FSF_ERR_CAPACITY;
   if (m_out_dev) {
     int64_t tmp = m_out;
     FSF_HIP_TRY(hipMemcpyAsync(m_out_dev, &tmp, sizeof(int64_t), hipMemcpyHostToDevice, stream));
-    FSF_HIP_TRY(hipStreamSynchronize(stream));
+    FSF_STREAM_WAIT(stream);
   }
   if (m_out == 0) return FSF_OK;
   // ascending linear (b,z,y,x) order of the output sites

@@ -23,6 +23,7 @@ std::atomic<int64_t> g_opt_pool_brute{[] {
   const char* e = getenv("FSF_POOL_BRUTE");  // read once, when the library is loaded
   return (int64_t)(e ? atoll(e) : 0);
 }()};
+std::atomic<int64_t> g_host_waits{0};
 }  // namespace fsf
 
 extern "C" int fsf_set_option(int32_t option, int64_t value) {
@@ -35,5 +36,6 @@ extern "C" int fsf_set_option(int32_t option, int64_t value) {
 
 extern "C" int64_t fsf_get_option(int32_t option) {
   if (option == FSF_OPT_POOL_BRUTE) return fsf::g_opt_pool_brute.load(std::memory_order_relaxed);
+  if (option == FSF_OPT_HOST_WAITS) return fsf::g_host_waits.load(std::memory_order_relaxed);
   return -1;
 }

@@ -11,7 +11,9 @@ from typing import Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import c_f32, c_i32, c_i64, c_p, check, f32_array, i32_array, i64_array, ptr, require_cuda, stream_ptr
+from ._lib import FsfHipError, c_f32, c_i32, c_i64, c_p, check, f32_array, i32_array, i64_array, ptr, require_cuda, stream_ptr
+
+ERR_KEY_RANGE = -3  # FSF_ERR_KEY_RANGE (include/fsf_hip.h)
 
 _P = c_p
 _ARGTYPES = {
@@ -37,7 +39,10 @@ _ARGTYPES = {
     "fsf_voxel2point_strided": [_P, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, _P, _P, c_f32, _P, c_i64, _P, _P],
     "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
-    "fsf_project_score": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P, _P],
+    "fsf_project_score": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P, _P, _P, _P],
+    "fsf_overlap_plan_workspace_bytes": [c_i64],
+    "fsf_overlap_plan": [_P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
+    "fsf_overlap_rows": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P, c_i64, c_i64, c_i64, c_i64, _P, _P, _P],
     "fsf_project_gather_bilinear": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_rulebook_workspace_bytes": [c_i64, c_i32],
     "fsf_rulebook_subm": [_P, c_i64, c_i32, _P, _P, _P, _P, _P, c_i64, _P],
@@ -441,9 +446,10 @@ PROJECT_SCORE_MAX_CLS = 16
 
 
 def project_score(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.Tensor, mask_anno: torch.Tensor, score_col=4,
-                  return_ids=False, return_fg=True):
+                  return_ids=False, return_fg=True, return_overlap=False):
     """fsf_project_score for ONE sample: xyz f32 [n,>=3], mask u8|i32 [ncam,ncls,H,W], mask_anno f32 [A,D] ->
-    score f32 [n,ncls] (+ ids i64 [n,ncls] of the selected camera) (+ fg bool [n]: inside any mask)."""
+    score f32 [n,ncls] (+ ids i64 [n,ncls] of the selected camera) (+ fg bool [n]: inside any mask)
+    (+ with return_overlap: (fg u8 [n], count u8 [n], max_id i32 [n]) — what overlap_plan / overlap_rows take)."""
     require_cuda(xyz, lidar2img, mask, mask_anno)
     assert xyz.dtype == torch.float32 and lidar2img.dtype == torch.float32 and mask.dtype in (torch.uint8, torch.int32)
     xyz, lidar2img, mask = xyz.contiguous(), lidar2img.contiguous(), mask.contiguous()
@@ -452,16 +458,51 @@ def project_score(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.Tensor
     ncam, ncls, H, W = mask.shape
     score = torch.empty((n, ncls), dtype=torch.float32, device=xyz.device)
     ids = torch.empty((n, ncls), dtype=torch.int64, device=xyz.device) if return_ids else None
-    fg = torch.empty((n,), dtype=torch.uint8, device=xyz.device) if return_fg else None
+    fg = torch.empty((n,), dtype=torch.uint8, device=xyz.device) if return_fg or return_overlap else None
+    count = torch.empty((n,), dtype=torch.uint8, device=xyz.device) if return_overlap else None
+    max_id = torch.empty((n,), dtype=torch.int32, device=xyz.device) if return_overlap else None
     check(_L().fsf_project_score(ptr(xyz), n, xyz.size(1), ptr(lidar2img), ncam, ptr(mask), mask.element_size(), ncls, H, W,
                                  ptr(mask_anno), mask_anno.size(0), mask_anno.size(1), int(score_col), ptr(score), ptr(ids),
-                                 ptr(fg), stream_ptr()), "fsf_project_score")
+                                 ptr(fg), ptr(count), ptr(max_id), stream_ptr()), "fsf_project_score")
     out = (score,)
     if return_ids:
         out += (ids,)
     if return_fg:
         out += (fg.bool(),)
+    if return_overlap:
+        out += ((fg, count, max_id),)
     return out if len(out) > 1 else score
+
+
+def overlap_plan(fg: torch.Tensor, count: torch.Tensor, max_cells: int):
+    """fsf_overlap_plan: fg u8 [n], count u8 [n] -> (F, M, T, workspace): foreground points, points inside >= 2 masks, appended rows;
+    the workspace goes to overlap_rows unchanged.  One host wait."""
+    require_cuda(fg, count)
+    assert fg.dtype == torch.uint8 and count.dtype == torch.uint8 and fg.is_contiguous() and count.is_contiguous()
+    n = fg.size(0)
+    # (its own buffer, not the per-stream scratch: the index lists must survive until overlap_rows)
+    ws = torch.empty((max(int(_L().fsf_overlap_plan_workspace_bytes(n)), 256),), dtype=torch.uint8, device=fg.device)
+    counts = (ctypes.c_int64 * 3)()
+    check(_L().fsf_overlap_plan(ptr(fg), ptr(count), n, int(max_cells), ctypes.cast(counts, c_p), ptr(ws), ws.numel(), stream_ptr()), "fsf_overlap_plan")
+    return int(counts[0]), int(counts[1]), int(counts[2]), ws
+
+
+def overlap_rows(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.Tensor, max_id: torch.Tensor, batch_idx, ws, num_fg, num_multi,
+                 num_extra):
+    """fsf_overlap_rows -> (src_pt i64 [F + T], sir_coors i64 [F + T, 3]) in the order extract_fg_pts + double_overlap_pts produce."""
+    require_cuda(xyz, lidar2img, mask, max_id)
+    assert xyz.dtype == torch.float32 and lidar2img.dtype == torch.float32 and mask.dtype in (torch.uint8, torch.int32)
+    assert max_id.dtype == torch.int32 and (batch_idx is None or (batch_idx.dtype == torch.int64 and batch_idx.is_contiguous()))
+    xyz, lidar2img, mask = xyz.contiguous(), lidar2img.contiguous(), mask.contiguous()
+    n = xyz.size(0)
+    ncam, ncls, H, W = mask.shape
+    rows = int(num_fg) + int(num_extra)
+    src_pt = torch.empty((rows,), dtype=torch.int64, device=xyz.device)
+    sir_coors = torch.empty((rows, 3), dtype=torch.int64, device=xyz.device)
+    check(_L().fsf_overlap_rows(ptr(xyz), n, xyz.size(1), ptr(lidar2img), ncam, ptr(mask), mask.element_size(), ncls, H, W, ptr(max_id),
+                                ptr(batch_idx), ptr(ws), ws.numel(), int(num_fg), int(num_multi), int(num_extra), ptr(src_pt),
+                                ptr(sir_coors), stream_ptr()), "fsf_overlap_rows")
+    return src_pt, sir_coors
 
 
 def project_gather_bilinear(xyz: torch.Tensor, lidar2img: torch.Tensor, feat: torch.Tensor, img_hw, channels_last=False,

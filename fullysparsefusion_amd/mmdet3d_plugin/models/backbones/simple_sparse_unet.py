@@ -282,4 +282,7 @@ class SimpleSparseUNet(nn.Module):
         out = x.features
         if inv_perm is not None:
             out = out.index_select(0, inv_perm)  # back to the caller's voxel order
+        # every decoder stage ends in a ReLU (asserted in __init__): no row can equal the neck's negative padding value, which spares
+        # Voxel2PointScatterNeck its `pts_mask.all()` reduction and the host wait on its result
+        out._fsf_nonnegative = True
         return [{"voxel_feats": out}]

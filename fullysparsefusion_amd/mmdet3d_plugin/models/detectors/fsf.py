@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import hip_ops
-from ...ops.sst_ops import GatheredRows, build_mlp, clear_unique_cache, gather_by_inverse, scatter_v2
+from ...ops.sst_ops import with_key_bounds, GatheredRows, build_mlp, clear_unique_cache, gather_by_inverse, scatter_v2
 from ...core.bbox import bbox3d2result
 from ...registry import BBOX_CODERS, DETECTORS, build_head, build_roi_extractor
 from .single_stage_fsd import SingleStageFSD
@@ -200,9 +200,25 @@ class FSF(SingleStageFSD):
         return sir_coors, obj_id_tensor
 
     def frustum_pooling(self, pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights, img_metas=None,
-                        cluster_center=None, fg_idx=None):
+                        cluster_center=None, fg_idx=None, rows=None):
+        """`rows` = (src_pt, sir_coors) of K26 (hip_ops.overlap_rows): the selection / duplication below already done as an index
+        list; `rows=None` with `obj_id_tensor=None`: no point lies inside a mask."""
         lazy_src = None
-        if fg_idx is not None:  # `obj_id_tensor` already holds the rows of the foreground points `fg_idx` (ascending)
+        fused = obj_id_tensor is None
+        if fused:
+            sir_coors_fused = None
+            if rows is None:
+                obj_id_tensor = bz_coor.new_zeros((0,))
+                pts_feat, bz_coor, points, point_fg_weights = pts_feat[:0], bz_coor[:0], points[:0], point_fg_weights[:0]
+            else:
+                src_pt, sir_coors_fused = rows
+                obj_id_tensor = sir_coors_fused[:, 2]
+                if pts_feat.dtype == torch.float32 and pts_feat.stride(1) == 1 and switches.SIR_GATHER:
+                    lazy_src, pts_feat = pts_feat, src_pt.unsqueeze(1)  # (the row index in place of the 131-wide rows, as below)
+                else:
+                    pts_feat = pts_feat.index_select(0, src_pt)
+                points, point_fg_weights = points.index_select(0, src_pt), point_fg_weights.index_select(0, src_pt)
+        elif fg_idx is not None:  # `obj_id_tensor` already holds the rows of the foreground points `fg_idx` (ascending)
             if (pts_feat.is_cuda and pts_feat.dtype == torch.float32 and pts_feat.stride(1) == 1 and not torch.is_grad_enabled()
                     and switches.SIR_GATHER):
                 # the 131-wide point features are not gathered here: their row INDEX travels through the selection / duplication
@@ -227,9 +243,12 @@ class FSF(SingleStageFSD):
             points_delta = points.new_zeros(fake_num, 3)
             cluster_center = points.new_zeros(fake_num, 3)
         else:
-            pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights = self.double_overlap_pts(
-                pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights)
-            sir_coors, obj_id_tensor = self.get_sir_coors(bz_coor, obj_id_tensor, point_fg_weights)
+            if fused:
+                sir_coors = sir_coors_fused
+            else:
+                pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights = self.double_overlap_pts(
+                    pts_feat, bz_coor, points, obj_id_tensor, point_fg_weights)
+                sir_coors, obj_id_tensor = self.get_sir_coors(bz_coor, obj_id_tensor, point_fg_weights)
             if cluster_center is None:
                 points_delta, cluster_center, _ = self.get_cluster_delta_weighted(points, sir_coors,
                                                                                   point_fg_weights.unsqueeze(-1))
@@ -305,9 +324,10 @@ class FSF(SingleStageFSD):
             # :716-719, :506-535, :472-473): the [n, cams, classes] int64 tensor is never written.  The "inside any mask"
             # flag it also emits lets frustum_forward gather ids for the foreground points only.
             lidar2img = torch.as_tensor(img_metas[0]["lidar2img"], dtype=torch.float32, device=points_info_flat.device)
-            score, fg = hip_ops.project_score(points_info_flat[:, :3], lidar2img, mask_data[0], mask_anno[0], score_col=4)
+            score, fg, overlap = hip_ops.project_score(points_info_flat[:, :3], lidar2img, mask_data[0], mask_anno[0], score_col=4,
+                                                       return_overlap=True)
             if ext_pts_inds is None:
-                self._fg_cache = (points_info_flat, mask_data, fg)
+                self._fg_cache = (points_info_flat, mask_data, fg, overlap, lidar2img)
             return encode_mlp(score)
         obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
         _, num_cams, num_classes = obj_id_tensor.shape
@@ -355,12 +375,29 @@ class FSF(SingleStageFSD):
         fgc = getattr(self, "_fg_cache", None)
         if (fgc is not None and batch_size == 1 and fgc[0].data_ptr() == points_info_flat.data_ptr()
                 and fgc[0].shape == points_info_flat.shape and fgc[1] is mask_data and fgc[0]._version == points_info_flat._version):
-            # img_cross_attn already knows which points lie inside a mask: gather the ids of THOSE points only
-            fg_idx = fgc[2].nonzero(as_tuple=False).squeeze(1)
-            lidar2img = torch.as_tensor(img_metas[0]["lidar2img"], dtype=torch.float32, device=points.device)
-            obj_fg = self.points_in_mask(points_info_flat.index_select(0, fg_idx)[:, :3].contiguous(), mask_data[0], lidar2img)
-            lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, obj_fg,
-                                                                      point_fg_weights, img_metas, cluster_center, fg_idx=fg_idx)
+            ncells = mask_data.shape[1] * mask_data.shape[2]
+            if switches.OVERLAP_ROWS and ncells <= 254 and not torch.is_grad_enabled():
+                # K26: the rows extract_fg_pts + double_overlap_pts + get_sir_coors produce, from the cell count / largest id
+                # img_cross_attn's kernel already emitted: two C-ABI calls, one read-back (was: nonzero, a second projection of the
+                # foreground points into an [F, cams * classes] int64 tensor, ~45 ATen launches, three host syncs)
+                fg_u8, count_u8, max_id = fgc[3]
+                num_fg, num_multi, num_extra, ws = hip_ops.overlap_plan(fg_u8, count_u8, ncells)
+                rows = None
+                if num_fg > 0:
+                    rows = hip_ops.overlap_rows(points_info_flat[:, :3], fgc[4], mask_data[0], max_id, None, ws, num_fg, num_multi,
+                                                num_extra)
+                    # (sample, 0, instance id): ids index mask_anno's rows; a u8 plane cannot hold more than 255 either way
+                    top = mask_anno.shape[1] if mask_data.dtype != torch.uint8 else 255
+                    with_key_bounds(rows[1], [0, 0, 0], [0, 0, max(int(top), 1)])
+                lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, None,
+                                                                          point_fg_weights, img_metas, cluster_center, rows=rows)
+            else:
+                # img_cross_attn already knows which points lie inside a mask: gather the ids of THOSE points only
+                fg_idx = fgc[2].nonzero(as_tuple=False).squeeze(1)
+                lidar2img = torch.as_tensor(img_metas[0]["lidar2img"], dtype=torch.float32, device=points.device)
+                obj_fg = self.points_in_mask(points_info_flat.index_select(0, fg_idx)[:, :3].contiguous(), mask_data[0], lidar2img)
+                lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, obj_fg,
+                                                                          point_fg_weights, img_metas, cluster_center, fg_idx=fg_idx)
         else:
             obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
             lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, obj_id_tensor,

@@ -9,11 +9,14 @@ to the HIP library.  Training-only branches (targets, losses, SSG/Hybrid assigne
 from .... import switches
 import os
 
+import math
+
 import torch
 from torch import nn
 
 from .... import hip_ops
-from ...ops.sst_ops import GatheredRows, gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, unique_with_plan
+from ...ops.sst_ops import (GatheredRows, gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, unique_with_plan,
+                            with_key_bounds)
 from ...ops.voxel import Voxelization
 from ...registry import (DETECTORS, SEGMENTORS, build_backbone, build_detector, build_head, build_middle_encoder,
                          build_neck, build_voxel_encoder)
@@ -272,6 +275,10 @@ class SingleStageFSD(nn.Module):
             vox = torch.div(centers - rmin[None, :], vsize.index_select(0, g_ids), rounding_mode="floor").long()
             b_pts = batch_idx.index_select(0, p_ids).long()
             keys = torch.cat([(g_ids * bsz + b_pts)[:, None], vox], dim=1)
+        # (group * batch + sample, voxel of the voted centre): the centres are points of the range moved by a regressed offset, so the
+        # cells get the range's extent plus half of it either side; a vote beyond that sends the unique through its range pass
+        cells = [max(int(math.ceil((ca.point_cloud_range[3 + a] - ca.point_cloud_range[a]) / row[a])) for row in vs_rows) for a in range(3)]
+        with_key_bounds(keys, [0] + [-(c // 2) - 8 for c in cells], [ng * bsz - 1] + [c + c // 2 + 8 for c in cells])
         new_keys, inv, cnt = unique_with_plan(keys)
         if switches.CLUSTER_ONE_UNIQUE:
             # Whether a pair survives is a property of its voxel key (dense enough, or its whole group has no dense voxel, :953-954),
@@ -319,6 +326,8 @@ class SingleStageFSD(nn.Module):
             labels = hip_ops.connected_components_grouped(vox_centers, vox_group_i32, dist)
             # (a group's labels start at its first voxel's: renumbered from 0 per group and mapped to the pairs in two launches)
             pts_cluster_inds = hip_ops.cluster_point_ids(labels, vox_group_i32, vox_inv, g_ids, b_pts, ng)
+            # (group, sample, cluster id within the group): a cluster holds at least one of the kept voxels
+            with_key_bounds(pts_cluster_inds, [0, 0, 0], [ng - 1, bsz - 1, max(int(labels.numel()) - 1, 0)])
         else:
             vox_group = torch.div(vox_keys[:, 0], bsz, rounding_mode="floor")
             labels = hip_ops.connected_components_grouped(vox_centers, vox_group, dist).long()
@@ -352,6 +361,11 @@ class SingleStageFSD(nn.Module):
         points = data_dict["seg_points"]
         coors = hip_ops.voxelize_divfloor(points, self.cfg["pre_voxelization_size"],
                                           self.cluster_assigner.point_cloud_range[:3], order="zyx", batch_idx=batch_idx)
+        bsz = getattr(self, "_batch_size_hint", None)
+        if bsz is not None:  # (batch, z, y, x) cells of the cluster assigner's range, a few cells of slack either side
+            rng, vs = self.cluster_assigner.point_cloud_range, self.cfg["pre_voxelization_size"]
+            cells = [int(math.ceil((rng[3 + a] - rng[a]) / vs[a])) for a in (2, 1, 0)]
+            with_key_bounds(coors, [0, -8, -8, -8], [bsz - 1] + [c + 8 for c in cells])
         new_coors, unq_inv, _ = unique_with_plan(coors)
         # (upstream: one scatter_v2(.., mode='avg') per float field over the shared unique; here the fields go through one launch)
         names = [name for name, data in data_dict.items() if data.dtype in (torch.float, torch.float16)]

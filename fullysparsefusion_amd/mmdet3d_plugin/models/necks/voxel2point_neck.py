@@ -28,7 +28,8 @@ class Voxel2PointScatterNeck(nn.Module):
                 vs = torch.tensor(self.voxel_size, dtype=out.dtype, device=out.device).reshape(1, 3)
                 assert (out[pts_mask][:, -3:].abs() < vs / 2 + 1e-3).all(), \
                     "Holds in training. However, in test, this is not always True because of lack of point range clip"
-            if not self.training and bool(pts_mask.all()):  # no padded voxel row (the usual case): nothing to compact
+            # no padded voxel row (the usual case; known without looking when the features are >= 0 and the padding value is not)
+            if not self.training and ((voxel_padding < 0 and getattr(voxel_feats, "_fsf_nonnegative", False)) or bool(pts_mask.all())):
                 pts_mask.fsf_all_true = True  # (the detector asks the same question: spare it the second round trip)
                 return out, pts_mask
             return out[pts_mask], pts_mask

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .... import hip_ops, switches
 from ...ops.dynamic_point_pool_op import dynamic_point_pool
-from ...ops.sst_ops import unique_with_plan
+from ...ops.sst_ops import unique_with_plan, with_key_bounds
 from ...registry import HEADS, ROI_EXTRACTORS, build_voxel_encoder
 
 
@@ -85,6 +85,7 @@ class FullySparseBboxHead(nn.Module):
         rois = rois[:, 1:]
         rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds]
         coors = roi_inds.unsqueeze(1)  # the segment machinery takes key ROWS; upstream groups on the 1-D index
+        with_key_bounds(coors, [0], [max(rois.size(0) - 1, 0)])
         if self.unique_once:  # torch.unique(roi_inds, return_inverse=True) upstream (:114-115), with the segment plan
             new_coors, unq_inv, _ = unique_with_plan(coors)
         else:

@@ -68,6 +68,17 @@ def _unique_entries():
     return e
 
 
+_BOUNDS_ATTR = "_fsf_key_bounds"
+
+
+def with_key_bounds(keys, col_min, col_max):
+    """Attach per-column bounds the producer of `keys` knows from its configuration (grid sizes, class / batch / row counts) so that
+    `unique_with_plan` packs the sort key from them instead of running the range kernel and WAITING for its result (two launches and
+    one host round trip per unique).  Violations are detected on the device and fall back to the range pass."""
+    setattr(keys, _BOUNDS_ATTR, ([int(v) for v in col_min], [int(v) for v in col_max]))
+    return keys
+
+
 def unique_with_plan(coors, col_min=None, col_max=None):
     """torch.unique(coors, return_inverse=True, return_counts=True, dim=0) + the sort-once segment plan.
     The plan rides on the returned inverse tensor so that the `unq_inv=`/`new_coors=` path of scatter_v2
@@ -78,12 +89,24 @@ def unique_with_plan(coors, col_min=None, col_max=None):
     get_cluster_delta_weighted, then the frustum SIR on `sir_coors`): the result of the last calls is kept, keyed on the tensor
     OBJECT and its version counter (the tensor is held, so its storage cannot be recycled under the key), at inference only."""
     cache_ok = _UNIQUE_CACHE_SIZE > 0 and coors.is_cuda and not torch.is_grad_enabled()
+    hinted = False
+    if col_min is None and switches.UNIQUE_BOUNDS:
+        b = getattr(coors, _BOUNDS_ATTR, None)
+        if b is not None:
+            (col_min, col_max), hinted = b, True
     key = (None if col_min is None else tuple(col_min), None if col_max is None else tuple(col_max))
     if cache_ok:  # (per thread: the two query branches run on two host threads and streams)
         for t, ver, k, res in reversed(_unique_entries()):
             if t is coors and ver == coors._version and k == key:
                 return res
-    new_coors, plan = hip_ops.unique_rows(coors, col_min=col_min, col_max=col_max)
+    try:
+        new_coors, plan = hip_ops.unique_rows(coors, col_min=col_min, col_max=col_max)
+    except hip_ops.FsfHipError as e:
+        # bounds a producer ATTACHED to its keys (with_key_bounds) are a promise about typical data, not a contract: a key outside
+        # them (or bounds too wide for a 64-bit packed key) sends this call through the data-dependent range pass instead
+        if not hinted or getattr(e, "status", 0) != hip_ops.ERR_KEY_RANGE:
+            raise
+        new_coors, plan = hip_ops.unique_rows(coors)
     inv = plan.inv.detach()  # a second tensor object on the same storage: tensor -> plan -> tensor would be a cycle
     setattr(inv, _PLAN_ATTR, plan)
     res = (new_coors, inv, plan.cnt)

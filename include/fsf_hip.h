@@ -31,15 +31,18 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 9
+#define FSF_ABI_VERSION 10
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
  * fast paths.  Stored atomically inside the library: entry points read them instead of the environment, so a call never
  * touches getenv (the library is driven from several host threads).  Returns FSF_ERR_INVALID_ARG for an unknown option.
  *   FSF_OPT_POOL_BRUTE (1): fsf_dynamic_point_pool through the P x R brute-force passes instead of the cell-binned path
- *                           (initial value: the environment variable FSF_POOL_BRUTE at load time, else 0). */
+ *                           (initial value: the environment variable FSF_POOL_BRUTE at load time, else 0).
+ *   FSF_OPT_HOST_WAITS (2), read-only: how many times the library has made the calling host thread wait for a stream since it was
+ *                           loaded (every count / flag read-back of every entry point) — what bench.py reports as host waits. */
 #define FSF_OPT_POOL_BRUTE 1
+#define FSF_OPT_HOST_WAITS 2
 int fsf_set_option(int32_t option, int64_t value);
 int64_t fsf_get_option(int32_t option);
 
@@ -354,10 +357,31 @@ int fsf_project_gather_mask(const float* xyz, int64_t n, int32_t xyz_stride, con
  * fsf_project_gather_mask followed by fsf_cam_select_score).  ncls <= 16.
  *   out_score f32 [n, ncls]; out_ids i64 [n, ncls] or NULL (ids of the selected camera);
  *   out_fg u8 [n] or NULL: 1 if the point is inside any mask of any camera (obj_id.sum((-2,-1)) > 0, FSF.py:299-308)
+ *   out_count u8 [n] or NULL: (camera, class) cells with an id > 0 (`(obj_id_tensor > 0).sum(-1)`, FSF.py:262), saturated at 255
+ *   out_max_id i32 [n] or NULL: the largest id over all cells (`obj_id_tensor.max(-1)[0]`, FSF.py:263)
  */
 int fsf_project_score(const float* xyz, int64_t n, int32_t xyz_stride, const float* lidar2img, int32_t ncam, const void* mask,
                       int32_t elem_bytes, int32_t ncls, int32_t img_h, int32_t img_w, const float* mask_anno, int32_t num_anno,
-                      int32_t anno_dim, int32_t score_col, float* out_score, int64_t* out_ids, uint8_t* out_fg, void* stream);
+                      int32_t anno_dim, int32_t score_col, float* out_score, int64_t* out_ids, uint8_t* out_fg, uint8_t* out_count,
+                      int32_t* out_max_id, void* stream);
+
+/* K26  the camera-query branch's row list: extract_fg_pts (FSF.py:299-308) + double_overlap_pts (:260-297) + get_sir_coors (:373-376)
+ * for ONE sample, from fsf_project_score's per-point outputs, in two calls and one 32-byte read-back.
+ *   fsf_overlap_plan: fg u8 [n], count u8 [n] (max_cells = ncam * ncls <= 254, else FSF_ERR_UNSUPPORTED: the count must not saturate)
+ *     -> counts_host i64 [3] = (F foreground points, M of them inside >= 2 masks, T appended rows = sum (k - 1)); the index lists stay in
+ *     `workspace` (fsf_overlap_plan_workspace_bytes(n)), which the caller hands UNCHANGED to
+ *   fsf_overlap_rows: -> src_pt i64 [F + T] (the point a row is a copy of), sir_coors i64 [F + T, 3] = (batch_idx[pt] or 0, 0, id).
+ *     Rows 0 .. F-1: the foreground points ascending, id = the point's largest id.  Then, exactly in the order the reference's loop over
+ *     `overlap_num = 2, 3, ...` appends them (k ascending; within k, j = 1 .. k-1; within (k, j) the points ascending): the row of point p
+ *     with k cells carries its j-th largest id (0-based; `topk(k)[0][:, j]`, duplicates kept).  xyz / lidar2img / mask as fsf_project_score.
+ */
+int64_t fsf_overlap_plan_workspace_bytes(int64_t n);
+int fsf_overlap_plan(const uint8_t* fg, const uint8_t* count, int64_t n, int32_t max_cells, int64_t* counts_host, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+int fsf_overlap_rows(const float* xyz, int64_t n, int32_t xyz_stride, const float* lidar2img, int32_t ncam, const void* mask,
+                     int32_t elem_bytes, int32_t ncls, int32_t img_h, int32_t img_w, const int32_t* max_id, const int64_t* batch_idx,
+                     const void* workspace, int64_t workspace_bytes, int64_t num_fg, int64_t num_multi, int64_t num_extra,
+                     int64_t* src_pt, int64_t* sir_coors, void* stream);
 
 /* K13b  LiDAR -> camera projection + per-point BILINEAR image-feature gather (BASELINE.json north_star; the reference only
  * gathers instance ids, FSF.py:216-225 — this is the feature-map counterpart of the same call site: prj_points_2d

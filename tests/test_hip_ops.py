@@ -365,6 +365,74 @@ def test_project_gather_av2_shape_vs_oracle(ops, device):
     np.testing.assert_array_equal(ffg.cpu().numpy(), want.sum((-2, -1)) > 0)
 
 
+def overlap_rows_reference(obj):
+    """extract_fg_pts + double_overlap_pts + get_sir_coors of the reference (FSF.py:299-308, :260-297, :373-376) on an [n, cells]
+    id tensor, as index lists: (src_pt, id) per output row."""
+    fg_idx = (obj.sum(-1) > 0).nonzero().squeeze(1)
+    rows = obj[fg_idx]
+    k = (rows > 0).sum(-1)
+    src, ids = [fg_idx], [rows.max(-1)[0]]
+    for kk in range(2, int(k.max()) + 1 if k.numel() else 0):
+        sel = k == kk
+        if int(sel.sum()) == 0:
+            continue
+        top = rows[sel].topk(kk, dim=-1)[0]
+        for j in range(1, kk):
+            src.append(fg_idx[sel])
+            ids.append(top[:, j])
+    return torch.cat(src), torch.cat(ids)
+
+
+@pytest.mark.parametrize("case", ["frame_like", "dense_overlaps", "no_foreground", "int32_masks"])
+def test_overlap_rows_equal_the_reference_loop(ops, device, case):
+    """K26 (fsf_overlap_plan + fsf_overlap_rows, fed by fsf_project_score's count / largest id) against the reference's
+    extract_fg_pts + double_overlap_pts + get_sir_coors on the [n, cams, classes] tensor of fsf_project_gather_mask: the same rows in
+    the same order.  Cases: a frame-like mask set; every pixel of every camera inside several class planes (k of 8 and more, duplicate ids
+    in one point's cells); no point inside any mask; int32 id planes."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from fullysparsefusion_amd.synthetic import make_lidar2img, make_mask_data
+
+    rng = np.random.default_rng(11)
+    n, ncam, ncls, H, W = 60000, 6, 10, 450, 800
+    pts = cloud(n, seed=5)[:, :3].copy()
+    L = make_lidar2img(ncam, fx=630.0, cx=400.0, cy=225.0)
+    if case == "frame_like":
+        mask, _ = make_mask_data(rng, ncam, ncls, H, W, 120)
+    elif case == "int32_masks":
+        mask, _ = make_mask_data(rng, ncam, ncls, H, W, 400, dtype=np.int32)
+    elif case == "no_foreground":
+        mask = np.zeros((ncam, ncls, H, W), dtype=np.uint8)
+    else:
+        mask = np.zeros((ncam, ncls, H, W), dtype=np.uint8)
+        for c in range(ncam):
+            for k in range(ncls):
+                if rng.random() < 0.9:  # a plane of 64 x 64 tiles with ids from a SMALL set: duplicates inside a point's cells
+                    tiles = rng.integers(0, 6, size=((H + 63) // 64, (W + 63) // 64)).astype(np.uint8)
+                    mask[c, k] = np.kron(tiles, np.ones((64, 64), dtype=np.uint8))[:H, :W]
+    anno = np.zeros((int(mask.max()) + 1, 9), dtype=np.float32)
+    t = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+    obj = ops.project_gather_mask(t(pts), t(L), t(mask)).reshape(n, -1)
+    _, fg_bool, (fg, count, max_id) = ops.project_score(t(pts), t(L), t(mask), t(anno), return_overlap=True)
+    assert torch.equal(fg_bool, obj.sum(-1) > 0) and torch.equal(count.long(), (obj > 0).sum(-1))
+    assert torch.equal(max_id.long(), obj.max(-1)[0])
+    num_fg, num_multi, num_extra, ws = ops.overlap_plan(fg, count, ncam * ncls)
+    want_src, want_id = overlap_rows_reference(obj)
+    k = (obj > 0).sum(-1)
+    assert num_fg == int((obj.sum(-1) > 0).sum()) and num_multi == int((k >= 2).sum()) and num_extra == int((k - 1).clamp(min=0).sum())
+    if case == "no_foreground":
+        assert num_fg == 0
+        return
+    assert num_multi > 0
+    if case == "dense_overlaps":
+        assert int(k.max()) >= 8 and bool(((obj.sort(-1)[0][:, 1:] == obj.sort(-1)[0][:, :-1]) & (obj.sort(-1)[0][:, 1:] > 0)).any())
+    batch = torch.full((n,), 3, dtype=torch.int64, device=device)
+    for b in (None, batch):
+        src, coors = ops.overlap_rows(t(pts), t(L), t(mask), max_id, b, ws, num_fg, num_multi, num_extra)
+        assert torch.equal(src, want_src)
+        assert torch.equal(coors[:, 2], want_id) and bool((coors[:, 1] == 0).all()) and bool((coors[:, 0] == (0 if b is None else 3)).all())
+
+
 # ----------------------------------------------------------------------------------------- rulebooks
 def sparse_sites(rng, batch, shape, m):
     cells = batch * shape[0] * shape[1] * shape[2]

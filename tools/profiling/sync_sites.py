@@ -23,8 +23,9 @@ def site(tag):
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func).replace("aten.", "").split(".")[0]
-        if name in ("_local_scalar_dense", "nonzero", "masked_select"):
-            site(name)
+        a0 = args[0] if args else None
+        if name in ("nonzero", "masked_select") or (name == "_local_scalar_dense" and torch.is_tensor(a0) and a0.is_cuda):
+            site(name)  # (.item() on a host tensor waits for nothing)
         elif name in ("_to_copy", "copy_"):
             src = args[1] if name == "copy_" else args[0]
             dst_dev = (args[0].device if name == "copy_" else (kwargs or {}).get("device", None))
@@ -32,10 +33,14 @@ class Spy(TorchDispatchMode):
                 site("d2h copy")
         return func(*args, **(kwargs or {}))
 
+# the library counts its own stream waits (FSF_OPT_HOST_WAITS = 2): the difference across a C-ABI call is what that call waited
 orig = _lib.check
+state = dict(last=int(_lib.lib().fsf_get_option(2)))
 def check(status, what):
-    if what in ("fsf_unique_rows", "fsf_rulebook_strided", "fsf_cluster_key_survival"):
+    now = int(_lib.lib().fsf_get_option(2))
+    for _ in range(now - state["last"]):
         site("C-ABI read-back " + what)
+    state["last"] = now
     return orig(status, what)
 _lib.check = hip_ops.check = check
 with Spy():
