@@ -479,7 +479,7 @@ using namespace fsf;
 extern "C" int64_t fsf_dynamic_point_pool_workspace_bytes(int64_t n_pts, int64_t n_rois) {
   const int64_t pt_tiles = n_pts > 0 ? (n_pts + PP_TILE - 1) / PP_TILE : 1;
   const int64_t r = n_rois > 0 ? n_rois : 1;
-  return fsf_align_up(pt_tiles * r * 4, 256) + 3 * fsf_align_up(r * 4, 256) + fsf_align_up(scan_num_tiles(r) * 4, 256) + 768 +
+  return fsf_align_up(pt_tiles * r * 4, 256) + 3 * fsf_align_up(r * 4, 256) + 2 * fsf_align_up(scan_num_tiles(r) * 4, 256) + 768 +
          radix_sort_scratch_bytes(n_pts) + 2 * fsf_align_up((int64_t)PB_NCELL * 4, 256) +
          fsf_align_up((n_pts > 0 ? n_pts : 1) * 16, 256);  // (+ the binned path's sort, cell tables and sorted points)
 }
@@ -523,25 +523,26 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
       uint64_t* keys_b = arena.take<uint64_t>(n_pts);
       uint32_t* vals_a = arena.take<uint32_t>(n_pts);
       uint32_t* vals_b = arena.take<uint32_t>(n_pts);
+      // [sort histograms | cell_start | cell_end | the scan's tile words] are consecutive: ONE memset instead of four
       uint32_t* hist = arena.take<uint32_t>((radix_num_tiles(n_pts) + 1) * RS_BINS);
       uint32_t* cell_start = arena.take<uint32_t>(PB_NCELL);
       uint32_t* cell_end = arena.take<uint32_t>(PB_NCELL);
+      uint32_t* tile_sums_b = arena.take<uint32_t>(scan_num_tiles(r1));
       float4* sorted = arena.take<float4>(n_pts);
       if (!arena.ok()) return FSF_ERR_WORKSPACE;
+      FSF_HIP_TRY(hipMemsetAsync(hist, 0, (size_t)((char*)sorted - (char*)hist), stream));
       hipLaunchKernelGGL(pb_keys_kernel, dim3((unsigned)fsf_stream_grid(n_pts, 256)), dim3(256), 0, stream, pts, n_pts, (int)pts_stride,
                          keys_a, vals_a);
       uint64_t* keys = nullptr;
       uint32_t* order = nullptr;
-      int rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, n_pts, 2 * PB_BITS, &keys, &order, stream);
+      int rc = radix_sort_pairs(keys_a, vals_a, keys_b, vals_b, hist, n_pts, 2 * PB_BITS, &keys, &order, stream, true);
       if (rc != FSF_OK) return rc;
-      FSF_HIP_TRY(hipMemsetAsync(cell_start, 0, (size_t)PB_NCELL * 4, stream));
-      FSF_HIP_TRY(hipMemsetAsync(cell_end, 0, (size_t)PB_NCELL * 4, stream));
       hipLaunchKernelGGL(pb_cells_kernel, dim3((unsigned)fsf_stream_grid(n_pts, 256)), dim3(256), 0, stream, keys, order, n_pts, pts,
                          (int)pts_stride, pts_batch, cell_start, cell_end, sorted);
       PoolBinArgs b{a, order, sorted, cell_start, cell_end, hits_full};
       const unsigned wg = (unsigned)((n_rois + 3) / 4);
       hipLaunchKernelGGL(pb_count_kernel, dim3(wg), dim3(256), 0, stream, b);
-      rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums, total, nullptr, stream, (int64_t)max_inbox_point);
+      rc = exclusive_scan_u32(PoolScanIn{roi_total}, PoolScanOut{roi_off}, n_rois, tile_sums_b, total, nullptr, stream, (int64_t)max_inbox_point, true);
       if (rc != FSF_OK) return rc;
       hipLaunchKernelGGL(pb_fill_kernel, dim3(wg), dim3(256), 0, stream, b);
       hipLaunchKernelGGL(pool_count_kernel, dim3(1), dim3(1), 0, stream, total, max_all_pts, cdev);

@@ -64,7 +64,9 @@ __device__ __forceinline__ int32_t hash_lookup(const uint64_t* __restrict__ keys
   }
 }
 
-__global__ void __launch_bounds__(256) hash_fill_empty_kernel(uint64_t* keys, int64_t cap) {
+// (`zero_word`: a counter the same call needs cleared — one launch instead of a fill and a memset)
+__global__ void __launch_bounds__(256) hash_fill_empty_kernel(uint64_t* keys, int64_t cap, uint32_t* zero_word = nullptr) {
+  if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x)
     keys[i] = HASH_EMPTY;
 }
@@ -415,9 +417,10 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
   const int pz_ = g.sz / gcd(g.sz, g.dz), py_ = g.sy / gcd(g.sy, g.dy), px_ = g.sx / gcd(g.sx, g.dx);
   const int64_t per_in = (int64_t)((g.kz + pz_ - 1) / pz_) * ((g.ky + py_ - 1) / py_) * ((g.kx + px_ - 1) / px_);
   const int64_t set_cap = (int64_t)pow2_at_least((uint64_t)(m * per_in) * 2);
-  uint64_t* in_keys = ar.take<uint64_t>(in_cap);
+  // (the two key tables back to back — capacities are powers of two >= 2, so both stay 256-byte aligned: ONE fill launch)
+  uint64_t* in_keys = ar.take<uint64_t>(in_cap + set_cap);
+  uint64_t* set_keys = in_keys + in_cap;
   int32_t* in_vals = ar.take<int32_t>(in_cap);
-  uint64_t* set_keys = ar.take<uint64_t>(set_cap);
   int32_t* set_vals = ar.take<int32_t>(set_cap);
   uint64_t* list_a = ar.take<uint64_t>(cand);
   uint64_t* list_b = ar.take<uint64_t>(cand);
@@ -427,9 +430,8 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
   uint32_t* count_dev = ar.take<uint32_t>(1);
   if (!ar.ok()) return FSF_ERR_WORKSPACE;
 
-  hipLaunchKernelGGL(hash_fill_empty_kernel, dim3(fsf_stream_grid(in_cap, 256)), dim3(256), 0, stream, in_keys, in_cap);
-  hipLaunchKernelGGL(hash_fill_empty_kernel, dim3(fsf_stream_grid(set_cap, 256)), dim3(256), 0, stream, set_keys, set_cap);
-  FSF_HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(uint32_t), stream));
+  hipLaunchKernelGGL(hash_fill_empty_kernel, dim3(fsf_stream_grid(in_cap + set_cap, 256)), dim3(256), 0, stream, in_keys,
+                     in_cap + set_cap, count_dev);
   hipLaunchKernelGGL(rb_insert_inputs_kernel, dim3(fsf_stream_grid(m, 256)), dim3(256), 0, stream, indices, m, g, in_keys,
                      in_vals, (uint64_t)(in_cap - 1));
   static const bool propose_by_pair = getenv("FSF_RB_PROPOSE_PAIRS") != nullptr;  // (A/B switch, latched: the round-1 kernel)

@@ -36,10 +36,12 @@ class DynamicPointROIExtractor(nn.Module):
             inds, roi_inds, info = hip_ops.dynamic_point_pool(
                 rois, pts_xyz.float(), self.extra_wlh, self.max_inbox_point, self.max_all_pts,
                 roi_batch_col=0, box_col=1, pts_batch=batch_inds)
-            if inds.numel() == 0:  # upstream fakes one (-1, -1, zeros) row so that downstream shapes stay non-empty
+            real = inds.numel() > 0
+            if not real:  # upstream fakes one (-1, -1, zeros) row so that downstream shapes stay non-empty
                 inds = inds.new_full((1,), -1)
                 roi_inds = roi_inds.new_full((1,), -1)
                 info = info.new_zeros((1, 13))
+            roi_inds._fsf_real_rows = real  # (known on the host: every roi index is then >= 0)
         if self.debug and inds[0] >= 0:
             roi_per_pts = rois[:, -7:][roi_inds]
             assert torch.isclose(pts_xyz[inds], info[:, :3]).all()
@@ -84,6 +86,28 @@ class FullySparseBboxHead(nn.Module):
         assert pts_features.size(0) > 0
         rois = rois[:, 1:]
         rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds]
+        sorted_ok = (switches.SIR_SORTED and self.unique_once and getattr(roi_inds, "_fsf_sorted", False)
+                     and self.use_middle_cluster_feature and not torch.is_grad_enabled() and pts_xyz.is_cuda
+                     and pts_xyz.dtype == torch.float32 and pts_features.dtype == torch.float32 and pts_features.stride(1) == 1
+                     and all(getattr(b, "sorted_supported", lambda: False)() for b in self.block_list))
+        if sorted_ok and switches.REFINE_DIRECT and getattr(roi_inds, "_fsf_real_rows", False) and roi_inds.dtype == torch.int64:
+            # The pooled rows are sorted by RoI and every index is a real RoI: the RoI index IS the segment id and the
+            # [rois, 768] result IS the group table — no unique (12 launches, a host wait), no scatter of the groups to their RoI
+            # rows (11 ATen launches).  A RoI without points keeps the -inf the table starts with: that is the non-empty mask,
+            # and its row becomes the zeros upstream returns (align_roi_feature_and_rois, :153-165).
+            num_rois = len(rois)
+            f_cluster = torch.cat([pts_info["local_xyz"], pts_info["boundary_offset"], pts_info["is_in_margin"][:, None], rel_xyz],
+                                  dim=-1)
+            widths = [b.group_width() for b in self.block_list]
+            groups = torch.full((num_rois, sum(widths)), float("-inf"), dtype=torch.float32, device=pts_xyz.device)
+            seg_ids = roi_inds.contiguous()
+            out_feats, col = pts_features, 0
+            for i, block in enumerate(self.block_list):
+                out_feats = block.forward_sorted(pts_xyz, out_feats, f_cluster, seg_ids, groups[:, col:col + widths[i]],
+                                                 i < self.num_blocks - 1, extra=f_cluster if self.geo_input else None, extra_div=10.0)
+                col += widths[i]
+            nonempty = groups[:, 0] > float("-inf")
+            return torch.where(nonempty[:, None], groups, groups.new_zeros(())), nonempty
         coors = roi_inds.unsqueeze(1)  # the segment machinery takes key ROWS; upstream groups on the 1-D index
         with_key_bounds(coors, [0], [max(rois.size(0) - 1, 0)])
         if self.unique_once:  # torch.unique(roi_inds, return_inverse=True) upstream (:114-115), with the segment plan
@@ -93,10 +117,7 @@ class FullySparseBboxHead(nn.Module):
         out_feats = pts_features
         f_cluster = torch.cat([pts_info["local_xyz"], pts_info["boundary_offset"], pts_info["is_in_margin"][:, None], rel_xyz],
                               dim=-1)
-        if (switches.SIR_SORTED and unq_inv is not None and getattr(roi_inds, "_fsf_sorted", False) and self.use_middle_cluster_feature
-                and not torch.is_grad_enabled() and pts_xyz.is_cuda and pts_xyz.dtype == torch.float32
-                and pts_features.dtype == torch.float32 and pts_features.stride(1) == 1
-                and all(getattr(b, "sorted_supported", lambda: False)() for b in self.block_list)):
+        if sorted_ok and unq_inv is not None:
             # the pooled rows are sorted by RoI already: every Linear -> LN -> GELU -> max pair of the three blocks is one K22s launch,
             # the [rois, 768] group features are written in place (see SIR._forward_sorted)
             m = new_coors.size(0)

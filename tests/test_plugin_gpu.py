@@ -629,6 +629,15 @@ def test_refine_head_vs_oracle(plugin, device):
         np.testing.assert_array_equal(roi_inds.cpu().numpy(), wr)
     with torch.no_grad():
         out, mask = head(d_pts[inds], torch.from_numpy(feats).to(device)[inds], info, roi_inds, d_rois)
+        # the groups indexed by RoI directly (default) and through a unique + scatter: the same rows, bit for bit
+        from fullysparsefusion_amd import switches
+        assert switches.REFINE_DIRECT and getattr(roi_inds, "_fsf_real_rows", False)
+        switches.REFINE_DIRECT = False
+        try:
+            out_u, mask_u = head(d_pts[inds], torch.from_numpy(feats).to(device)[inds], info, roi_inds, d_rois)
+        finally:
+            switches.REFINE_DIRECT = True
+        assert torch.equal(out, out_u) and torch.equal(mask, mask_u)
     c = lambda x: x.cpu()  # noqa: E731
     want, wmask = omod.refine_head_forward(cpu, c(d_pts[inds]), torch.from_numpy(feats)[c(inds)],
                                            {k: c(v) for k, v in info.items()}, c(roi_inds), torch.from_numpy(rois))
