@@ -133,8 +133,7 @@ extern "C" int fsf_assemble_sweeps(const float* raw, int64_t n_rows, int32_t loa
   int rc = exclusive_scan_u32(AsIn{a_dev}, AsOut{a_dev}, n_rows, tile_sums, nullptr, tot, stream);
   if (rc != FSF_OK) return rc;
   if (count_host) {
-    FSF_HIP_TRY(hipMemcpyAsync(count_host, tot, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FSF_STREAM_WAIT(stream);
+    FSF_READ_BACK(count_host, tot, sizeof(int64_t), stream);
   }
   return FSF_OK;
 }

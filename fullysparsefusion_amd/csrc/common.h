@@ -26,6 +26,16 @@ extern std::atomic<int64_t> g_host_waits;
     FSF_HIP_TRY(hipStreamSynchronize(stream));                         \
   } while (0)
 
+// A few words the device just produced -> the host, through the calling thread's pinned mailbox (readback.hip); counts as a host wait.
+namespace fsf {
+int fsf_read_back(void* host_dst, const void* dev_src, size_t bytes, hipStream_t stream);
+}
+#define FSF_READ_BACK(host_dst, dev_src, bytes, stream)                              \
+  do {                                                                               \
+    const int _rb = fsf::fsf_read_back((host_dst), (dev_src), (bytes), (stream));    \
+    if (_rb != FSF_OK) return _rb;                                                   \
+  } while (0)
+
 #define FSF_LAUNCH_CHECK()                               \
   do {                                                   \
     if (hipPeekAtLastError() != hipSuccess) return FSF_ERR_HIP; \

@@ -522,8 +522,7 @@ extern "C" int fsf_nms_bev(const float* boxes, int64_t n, float thresh, int32_t 
     FSF_LAUNCH_CHECK();
   }
   if (num_keep_host) {
-    FSF_HIP_TRY(hipMemcpyAsync(num_keep_host, ndev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FSF_STREAM_WAIT(stream);
+    FSF_READ_BACK(num_keep_host, ndev, sizeof(int64_t), stream);
   }
   return FSF_OK;
 }

@@ -548,8 +548,7 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
       hipLaunchKernelGGL(pool_count_kernel, dim3(1), dim3(1), 0, stream, total, max_all_pts, cdev);
       FSF_LAUNCH_CHECK();
       if (count_host) {
-        FSF_HIP_TRY(hipMemcpyAsync(count_host, cdev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-        FSF_STREAM_WAIT(stream);
+        FSF_READ_BACK(count_host, cdev, sizeof(int64_t), stream);
       }
       return FSF_OK;
     }
@@ -573,8 +572,7 @@ extern "C" int fsf_dynamic_point_pool(const float* rois, int64_t n_rois, int32_t
     FSF_LAUNCH_CHECK();
   }
   if (count_host) {
-    FSF_HIP_TRY(hipMemcpyAsync(count_host, cdev, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
-    FSF_STREAM_WAIT(stream);
+    FSF_READ_BACK(count_host, cdev, sizeof(int64_t), stream);
   }
   return FSF_OK;
 }

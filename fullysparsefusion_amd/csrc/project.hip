@@ -640,8 +640,7 @@ extern "C" int fsf_overlap_plan(const uint8_t* fg, const uint8_t* count, int64_t
   hipLaunchKernelGGL(ov_plan_kernel, dim3(1), dim3(256), 0, stream, keys_s, n, l.table, l.ret);
   FSF_LAUNCH_CHECK();
   int64_t ret_h[4] = {0, 0, 0, 0};
-  FSF_HIP_TRY(hipMemcpyAsync(ret_h, l.ret, sizeof(ret_h), hipMemcpyDeviceToHost, stream));
-  FSF_STREAM_WAIT(stream);
+  FSF_READ_BACK(ret_h, l.ret, sizeof(ret_h), stream);
   if (ret_h[3]) return FSF_ERR_UNSUPPORTED;
   counts_host[0] = ret_h[0];
   counts_host[1] = ret_h[1];

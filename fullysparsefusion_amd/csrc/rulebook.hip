@@ -444,8 +444,7 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
                        g, set_keys, (uint64_t)(set_cap - 1), list_a, count_dev);
   FSF_LAUNCH_CHECK();
   uint32_t count_h = 0;
-  FSF_HIP_TRY(hipMemcpyAsync(&count_h, count_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  FSF_STREAM_WAIT(stream);
+  FSF_READ_BACK(&count_h, count_dev, sizeof(uint32_t), stream);
   const int64_t m_out = (int64_t)count_h;
   *m_out_host = m_out;
   if (m_out > cap_out) return FSF_ERR_CAPACITY;

@@ -338,8 +338,7 @@ extern "C" int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const
       case 3: hipLaunchKernelGGL((uq_range_kernel<3>), dim3(rgrid), dim3(256), 0, stream, coors, n, range_dev); break;
       default: hipLaunchKernelGGL((uq_range_kernel<4>), dim3(rgrid), dim3(256), 0, stream, coors, n, range_dev); break;
     }
-    FSF_HIP_TRY(hipMemcpyAsync(&range, range_dev, sizeof(ColRange), hipMemcpyDeviceToHost, stream));
-    FSF_STREAM_WAIT(stream);
+    FSF_READ_BACK(&range, range_dev, sizeof(ColRange), stream);
   }
   PackSpec spec;
   spec.k = k;
@@ -384,8 +383,7 @@ extern "C" int fsf_unique_rows(const int64_t* coors, int64_t n, int32_t k, const
   FSF_LAUNCH_CHECK();
   if (m_host) {
     int64_t ret_h[2] = {0, 0};
-    FSF_HIP_TRY(hipMemcpyAsync(ret_h, ret_dev, sizeof(ret_h), hipMemcpyDeviceToHost, stream));  // (count + error flag in one copy)
-    FSF_STREAM_WAIT(stream);
+    FSF_READ_BACK(ret_h, ret_dev, sizeof(ret_h), stream);  // (count + error flag in one copy)
     *m_host = ret_h[0];
     if (ret_h[1]) return FSF_ERR_KEY_RANGE;
   }
@@ -476,8 +474,7 @@ extern "C" int fsf_ingroup_rank(const int64_t* group_inds, int64_t n, int64_t* o
   ColRange range;
   hipLaunchKernelGGL(uq_range_init_kernel, dim3(1), dim3(64), 0, stream, range_dev);
   hipLaunchKernelGGL((uq_range_kernel<1>), dim3(grid > 512 ? 512 : grid), dim3(256), 0, stream, group_inds, n, range_dev);
-  FSF_HIP_TRY(hipMemcpyAsync(&range, range_dev, sizeof(ColRange), hipMemcpyDeviceToHost, stream));
-  FSF_STREAM_WAIT(stream);
+  FSF_READ_BACK(&range, range_dev, sizeof(ColRange), stream);
   PackSpec spec;
   for (int j = 0; j < 4; ++j) {
     spec.mn[j] = 0; spec.mx[j] = 0; spec.shift[j] = 0; spec.mask[j] = 0;
@@ -538,8 +535,7 @@ extern "C" int fsf_cluster_key_survival(const int64_t* new_keys, int32_t key_col
   rc = exclusive_scan_u32(KsPairIn{inv, kpos}, KsPairOut{inv, kpos, v_idx, vox_inv}, n, tiles_p, nullptr, totals + 1, stream, 1, true);
   if (rc != FSF_OK) return rc;
   int64_t ret_h[2] = {0, 0};
-  FSF_HIP_TRY(hipMemcpyAsync(ret_h, totals, sizeof(ret_h), hipMemcpyDeviceToHost, stream));  // (both counts in one copy)
-  FSF_STREAM_WAIT(stream);
+  FSF_READ_BACK(ret_h, totals, sizeof(ret_h), stream);  // (both counts in one copy)
   counts_host[0] = ret_h[0];
   counts_host[1] = ret_h[1];
   return FSF_OK;

@@ -1,7 +1,10 @@
-mkdir -p gpurun_out/j5
-timeout 900 python -m pytest tests/test_hip_ops.py -m gpu -x -q -k "rulebook or point_pool or pool" 2>&1 | tail -5 > gpurun_out/j5/tests_a.txt
-timeout 1800 python -m pytest tests/test_plugin_gpu.py tests/test_e2e_agreement_gpu.py tests/test_fullsize_gpu.py -m gpu -x -q 2>&1 | tail -15 > gpurun_out/j5/tests_b.txt
-bash tools/profiling/ab_bench.sh "FSF_REFINE_DIRECT=0" "FSF_REFINE_DIRECT=1" > gpurun_out/j5/ab.txt 2>&1
-python tools/profiling/sync_sites.py > gpurun_out/j5/sync.txt 2>&1
-python tools/profiling/stage_times.py > gpurun_out/j5/stages.txt 2>&1
-cat gpurun_out/j5/tests_a.txt gpurun_out/j5/tests_b.txt gpurun_out/j5/ab.txt gpurun_out/j5/sync.txt gpurun_out/j5/stages.txt
+mkdir -p gpurun_out/j8
+for rep in 1 2 3 4; do
+  for e in "FSF_READBACK_MAILBOX=0" "FSF_READBACK_MAILBOX=1"; do
+    v=$(env $e python bench.py --no-cpu-baseline --no-roofline --no-describe --no-trained-like --no-train-block --steps 40 --warmup 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    echo "rep $rep 10-sweep [$e]  $v"
+    v=$(env $e python bench.py --sweeps 1 --no-cpu-baseline --no-roofline --no-describe --no-trained-like --no-train-block --steps 60 --warmup 10 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
+    echo "rep $rep 1-sweep  [$e]  $v"
+  done
+done > gpurun_out/j8/ab.txt 2>&1
+cat gpurun_out/j8/ab.txt
