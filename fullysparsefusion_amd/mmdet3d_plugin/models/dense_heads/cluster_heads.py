@@ -54,7 +54,9 @@ class FSDSeparateHead(nn.Module):
         depth = len(mlps[0])
         if any(len(m) != depth for m in mlps) or depth < 2:
             return None
-        params = [p for m in mlps for p in m.parameters()]
+        params = self.__dict__.get("_fsf_param_list")  # (the Parameter objects: walking the module tree per frame and head costs ~50 us)
+        if params is None:
+            params = self.__dict__["_fsf_param_list"] = [p for m in mlps for p in m.parameters()]
         key = tuple((p.data_ptr(), p._version) for p in params)
         cache = self.__dict__.get("_fsf_sliced")
         if cache is not None and cache[0] == key:
