@@ -38,4 +38,10 @@ cp gpurun_out/r4_pmc_traffic.json $out/pmc_traffic.json
 { hdr; python tools/profiling/train_ops.py 60 2>/dev/null; } > $out/train_step_ops.txt
 { hdr; bash tools/profiling/ab_bench.sh "FSF_SIR_SORTED=0" "FSF_SIR_SORTED=1" 2>/dev/null; } > $out/ab_sir_sorted.txt
 { hdr; for v in 0 1 0 1; do FSF_BWD_SPLIT=$v python bench.py --train --no-roofline --steps 8 --warmup 3 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('FSF_BWD_SPLIT=$v', d['value'], 'frames/s', d['ms_per_step'], 'ms')"; done; } > $out/ab_train_k10p.txt
+{ hdr; echo "# the launch / host-wait work of the round's second half, all off vs all on (default), interleaved, 10-sweep and single-sweep frame"
+  OFF="FSF_OVERLAP_ROWS=0 FSF_UNIQUE_BOUNDS=0 FSF_REFINE_DIRECT=0 FSF_READBACK_MAILBOX=0"
+  for rep in 1 2 3; do for e in "$OFF" "FSF_OVERLAP_ROWS=1"; do for sw in 10 1; do
+    v=$(env $e python bench.py --sweeps $sw --no-cpu-baseline --no-roofline --no-describe --no-trained-like --no-train-block --steps 40 --warmup 8 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], 'frames/s', d['ms_per_step'], 'ms', d['launches']['host_syncs_per_frame'], 'host waits')")
+    echo "rep $rep  ${sw}-sweep  [$( [ "$e" = "$OFF" ] && echo K26/bounds/direct-refine/mailbox OFF || echo default )]  $v"
+  done; done; done; } > $out/ab_launch_tail.txt
 tail -c 600 $out/bench_final.json; echo; tail -c 300 $out/bench_train.json; echo; head -5 $out/kernel_stats_full_forward.txt
