@@ -72,7 +72,7 @@ def lib():
                     "fsf_planes_bytes", "fsf_planes_scale_count", "fsf_spconv_planes_weight_bytes", "fsf_assemble_sweeps_workspace_bytes",
                     "fsf_get_option", "fsf_order_by_neighbor_mask_workspace_bytes",
                     "fsf_class_rank_desc_workspace_bytes", "fsf_nms_select_capacity", "fsf_cluster_key_survival_workspace_bytes",
-                    "fsf_overlap_plan_workspace_bytes",
+                    "fsf_overlap_plan_workspace_bytes", "fsf_group_pairs_workspace_bytes",
                 ):
                     getattr(h, name).restype = c_i64
                 _lib = h

@@ -278,6 +278,42 @@ struct KsPairOut {
     }
   }
 };
+
+// ---- K27: the (group, point) pairs of SingleStageFSD's grouped sampling -----------------------------------------------------------
+// `fg = grouped_score > thresh[None, :]; fg[0] |= ~fg.any(0); gp = fg.t().nonzero()` (single_stage_fsd.py:826-838 for one sample: every
+// class group keeps the points whose summed class scores pass the group's threshold, a group nobody passes keeps point 0) as: one pass
+// that ORs the groups somebody passes into a word, one scan over the (group, point) grid in group-major order that writes the pairs.
+// Replaces a compare, an any-reduction, three boolean elementwise ops, a transposing copy and ATen's nonzero (~12 launches and its
+// blocking count read-back).
+__global__ void __launch_bounds__(256)
+    gp_any_kernel(const float* __restrict__ score, int64_t n, int ng, int64_t stride, const float* __restrict__ thresh, uint32_t* __restrict__ any_mask) {
+  uint32_t mine = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    for (int g = 0; g < ng; ++g)
+      if (score[i * stride + g] > thresh[g]) mine |= 1u << g;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine |= (uint32_t)__shfl_xor((int)mine, o);
+  if ((threadIdx.x & 63) == 0 && mine) atomicOr(any_mask, mine);
+}
+struct GpIn {
+  const float* score; int64_t n; int64_t stride; const float* thresh; const uint32_t* any_mask; int keep_one;
+  __device__ uint32_t operator()(int64_t t) const {
+    const int g = (int)(t / n);
+    const int64_t i = t - (int64_t)g * n;
+    if (score[i * stride + g] > thresh[g]) return 1u;
+    return (keep_one && i == 0 && !((*any_mask >> g) & 1u)) ? 1u : 0u;
+  }
+};
+struct GpOut {
+  int64_t n; int64_t* g_ids; int64_t* p_ids;
+  __device__ void operator()(int64_t t, uint32_t excl, uint32_t keep) const {
+    if (keep) {
+      const int64_t g = t / n;
+      g_ids[excl] = g;
+      p_ids[excl] = t - g * n;
+    }
+  }
+};
 }  // namespace fsf
 
 using namespace fsf;
@@ -555,5 +591,36 @@ extern "C" int fsf_cluster_point_ids(const int32_t* labels, const int32_t* vox_g
   hipLaunchKernelGGL(ks_point_ids_kernel, dim3(fsf_stream_grid(nv, 256)), dim3(256), 0, stream, labels, vox_group, base, vox_inv, g_ids, b_pts,
                      nv, out);
   FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int64_t fsf_group_pairs_workspace_bytes(int64_t n, int32_t ng) {
+  return fsf_align_up(scan_num_tiles((n > 0 ? n : 1) * (ng > 0 ? ng : 1)) * 4, 256) + 2 * 256;
+}
+
+extern "C" int fsf_group_pairs(const float* score, int64_t n, int32_t ng, int64_t score_stride, const float* thresh, int32_t keep_one,
+                               int64_t* g_ids, int64_t* p_ids, int64_t capacity, int64_t* count_host, void* workspace, int64_t workspace_bytes,
+                               void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || ng < 1 || !thresh || !count_host || score_stride < ng || (n > 0 && (!score || !g_ids || !p_ids))) return FSF_ERR_INVALID_ARG;
+  if (ng > 32 || n * (int64_t)ng >= ((int64_t)1 << 30)) return FSF_ERR_UNSUPPORTED;
+  if (capacity < n * ng) return FSF_ERR_CAPACITY;  // (the caller allocates the upper bound: the count is only known afterwards)
+  *count_host = 0;
+  if (n == 0) return FSF_OK;
+  if (!workspace || workspace_bytes < fsf_group_pairs_workspace_bytes(n, ng)) return FSF_ERR_WORKSPACE;
+  FsfArena ar(workspace, workspace_bytes);
+  uint32_t* any_mask = ar.take<uint32_t>(1);  // [any_mask | the scan's tile words]: one memset
+  uint32_t* tiles = ar.take<uint32_t>(scan_num_tiles(n * ng));
+  int64_t* total = ar.take<int64_t>(1);
+  if (!ar.ok()) return FSF_ERR_WORKSPACE;
+  FSF_HIP_TRY(hipMemsetAsync(any_mask, 0, (size_t)((char*)total - (char*)any_mask), stream));
+  if (keep_one)
+    hipLaunchKernelGGL(gp_any_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, score, n, (int)ng, score_stride, thresh, any_mask);
+  const int rc = exclusive_scan_u32(GpIn{score, n, score_stride, thresh, any_mask, (int)keep_one}, GpOut{n, g_ids, p_ids}, n * ng, tiles, nullptr,
+                                    total, stream, 1, true);
+  if (rc != FSF_OK) return rc;
+  int64_t total_h = 0;
+  FSF_READ_BACK(&total_h, total, sizeof(int64_t), stream);
+  *count_host = total_h;
   return FSF_OK;
 }

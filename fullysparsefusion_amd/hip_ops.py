@@ -40,6 +40,8 @@ _ARGTYPES = {
     "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_project_score": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P, _P, _P, _P],
+    "fsf_group_pairs_workspace_bytes": [c_i64, c_i32],
+    "fsf_group_pairs": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, _P, c_i64, _P, _P, c_i64, _P],
     "fsf_overlap_plan_workspace_bytes": [c_i64],
     "fsf_overlap_plan": [_P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_overlap_rows": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P, c_i64, c_i64, c_i64, c_i64, _P, _P, _P],
@@ -472,6 +474,25 @@ def project_score(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.Tensor
     if return_overlap:
         out += ((fg, count, max_id),)
     return out if len(out) > 1 else score
+
+
+def group_pairs(score: torch.Tensor, thresh: torch.Tensor, keep_one=True):
+    """fsf_group_pairs: score f32 [n, ng], thresh f32 [ng] -> (g_ids i64 [P], p_ids i64 [P]) = ((score > thresh) with point 0 kept
+    for a group nobody passes).t().nonzero() columns; one host wait."""
+    require_cuda(score, thresh)
+    assert score.dtype == torch.float32 and thresh.dtype == torch.float32 and score.dim() == 2 and score.stride(1) == 1
+    n, ng = score.shape
+    assert thresh.shape == (ng,) and thresh.is_contiguous()
+    cap = max(n * ng, 1)
+    buf = torch.empty((2, cap), dtype=torch.int64, device=score.device)
+    h = _L()
+    ws = _lib.workspace(h.fsf_group_pairs_workspace_bytes(n, ng), score.device)
+    count = c_i64(0)
+    check(h.fsf_group_pairs(c_p(score.data_ptr()) if n else c_p(None), n, ng, score.stride(0) if n > 1 else ng, ptr(thresh),
+                            int(bool(keep_one)), ptr(buf[0]), ptr(buf[1]), cap, ctypes.cast(ctypes.pointer(count), c_p), ptr(ws),
+                            ws.numel(), stream_ptr()), "fsf_group_pairs")
+    k = int(count.value)
+    return buf[0, :k], buf[1, :k]
 
 
 def overlap_plan(fg: torch.Tensor, count: torch.Tensor, max_cells: int):

@@ -241,16 +241,21 @@ class SingleStageFSD(nn.Module):
         else:
             # the reference's sums (same columns, same order as its boolean column mask; an index list does not sync the host)
             grouped_score = torch.stack([scores[:, cols].sum(1) for cols in group_cols], dim=1)
-        fg = grouped_score > const(("score_thresh", tuple(cfg["score_thresh"])),
-                                   lambda: torch.tensor(cfg["score_thresh"], dtype=grouped_score.dtype))[None, :]
-        if bsz == 1:
-            fg[0] |= ~fg.any(0)  # "at least one point per sample" (:832-834)
+        thresh = const(("score_thresh", tuple(cfg["score_thresh"])), lambda: torch.tensor(cfg["score_thresh"], dtype=grouped_score.dtype))
+        if (bsz == 1 and switches.GROUP_PAIRS and grouped_score.is_cuda and grouped_score.dtype == torch.float32 and ng <= 32
+                and grouped_score.stride(1) == 1):
+            # K27: threshold, "at least one point per group" (:832-834) and the group-major pair list in one C-ABI call
+            g_ids, p_ids = hip_ops.group_pairs(grouped_score, thresh, keep_one=True)
         else:
-            for gi in range(ng):
-                if len(torch.unique(batch_idx[fg[:, gi]])) < bsz:
-                    fg[self.get_sample_beg_position(batch_idx, fg[:, gi]), gi] = True
-        gp = fg.t().nonzero(as_tuple=False)                      # (group, point), group-major
-        g_ids, p_ids = gp[:, 0], gp[:, 1]
+            fg = grouped_score > thresh[None, :]
+            if bsz == 1:
+                fg[0] |= ~fg.any(0)  # "at least one point per sample" (:832-834)
+            else:
+                for gi in range(ng):
+                    if len(torch.unique(batch_idx[fg[:, gi]])) < bsz:
+                        fg[self.get_sample_beg_position(batch_idx, fg[:, gi]), gi] = True
+            gp = fg.t().nonzero(as_tuple=False)                      # (group, point), group-major
+            g_ids, p_ids = gp[:, 0], gp[:, 1]
         # vote centre (the offsets of the group's classes weighted by "is the group's arg-max class", ties split evenly) and the
         # cluster-voxel key (torch.div(.., 'floor') with the group's voxel size, :948-950; group folded into the batch column)
         vs_rows = [ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]]

@@ -31,6 +31,7 @@ SIR_SORTED = _on("FSF_SIR_SORTED")                  # inference: SIR stacks on r
 SIR_GATHER = _on("FSF_SIR_GATHER")                  # first SIR layer reads the point features in place through an index
 FUSED_VOTE = _on("FSF_FUSED_VOTE")                  # vote centres + cluster-voxel keys in one kernel
 CLUSTER_ONE_UNIQUE = _on("FSF_CLUSTER_ONE_UNIQUE")  # a single unique in the cluster assignment
+GROUP_PAIRS = _on("FSF_GROUP_PAIRS")                # inference, one sample: the (group, point) pairs of the grouped sampling as one C-ABI call (K27)
 REFINE_DIRECT = _on("FSF_REFINE_DIRECT")            # inference: the refine head's groups indexed by RoI directly (no unique, no scatter)
 UNIQUE_BOUNDS = _on("FSF_UNIQUE_BOUNDS")            # uniques pack their sort key from bounds the key's producer attached (no range pass / host wait)
 OVERLAP_ROWS = _on("FSF_OVERLAP_ROWS")              # inference: the camera-query row list (foreground + overlap duplicates) as two C-ABI calls (K26)

@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 10
+#define FSF_ABI_VERSION 11
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -733,6 +733,15 @@ int fsf_cluster_key_survival(const int64_t* new_keys, int32_t key_cols, const in
 int fsf_cluster_point_ids(const int32_t* labels, const int32_t* vox_group, int64_t m, const int64_t* vox_inv, const int64_t* g_ids,
                           const int64_t* b_pts, int64_t nv, int32_t num_groups, int64_t* out, void* workspace,
                           int64_t workspace_bytes, void* stream);
+
+/* K27  the (group, point) pairs of SingleStageFSD's grouped sampling for ONE sample (single_stage_fsd.py:826-838):
+ *   fg = score > thresh[None, :];  keep_one: fg[0] |= ~fg.any(0) (a group nobody passes keeps point 0);  (g_ids, p_ids) = fg.t().nonzero()
+ *   score f32 [n, ng] (row stride score_stride floats, ng <= 32), thresh f32 [ng] -> g_ids, p_ids i64 [capacity >= n * ng], the first
+ *   *count_host entries valid, group-major, points ascending inside a group.  One read-back. */
+int64_t fsf_group_pairs_workspace_bytes(int64_t n, int32_t ng);
+int fsf_group_pairs(const float* score, int64_t n, int32_t ng, int64_t score_stride, const float* thresh, int32_t keep_one,
+                    int64_t* g_ids, int64_t* p_ids, int64_t capacity, int64_t* count_host, void* workspace, int64_t workspace_bytes,
+                    void* stream);
 
 #ifdef __cplusplus
 }

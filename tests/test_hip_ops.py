@@ -365,6 +365,30 @@ def test_project_gather_av2_shape_vs_oracle(ops, device):
     np.testing.assert_array_equal(ffg.cpu().numpy(), want.sum((-2, -1)) > 0)
 
 
+@pytest.mark.parametrize("n,ng,empty_group,with_nan", [(250003, 6, 4, False), (3000, 6, None, True), (1, 3, 1, False), (70001, 32, 31, False)])
+def test_group_pairs_equal_the_torch_expression(ops, device, n, ng, empty_group, with_nan):
+    """K27 against `fg = score > thresh; fg[0] |= ~fg.any(0); fg.t().nonzero()` (single_stage_fsd.py:826-838): the same pairs in the same
+    order; a group nobody passes (keeps point 0), NaN scores (never pass), one point, 32 groups, a row-strided score matrix."""
+    torch.manual_seed(n + ng)
+    buf = torch.rand((n, ng + 3), device=device)
+    score = buf[:, :ng]
+    thresh = torch.rand(ng, device=device) * 0.5 + 0.45
+    if empty_group is not None:
+        score[:, empty_group] = 0.0
+    if with_nan:
+        score[::7, 1] = float("nan")
+    fg = score > thresh[None, :]
+    fg[0] |= ~fg.any(0)
+    want = fg.t().nonzero(as_tuple=False)
+    g_ids, p_ids = ops.group_pairs(score, thresh, keep_one=True)
+    assert torch.equal(g_ids, want[:, 0]) and torch.equal(p_ids, want[:, 1])
+    if empty_group is not None:
+        assert int((g_ids == empty_group).sum()) == 1 and int(p_ids[g_ids == empty_group][0]) == 0
+    g2, p2 = ops.group_pairs(score, thresh, keep_one=False)
+    want2 = (score > thresh[None, :]).t().nonzero(as_tuple=False)
+    assert torch.equal(g2, want2[:, 0]) and torch.equal(p2, want2[:, 1])
+
+
 def overlap_rows_reference(obj):
     """extract_fg_pts + double_overlap_pts + get_sir_coors of the reference (FSF.py:299-308, :260-297, :373-376) on an [n, cells]
     id tensor, as index lists: (src_pt, id) per output row."""
