@@ -1,4 +1,4 @@
-"""The one kernel variant that is kept behind an environment switch stays parity-green: K9c as the only plane kernel
+"""The variants kept behind an environment switch stay parity-green: the read-back route without the pinned mailbox, and K9c as the only plane kernel
 (`FSF_PLANES_PIPE=0`; by default it only runs the source widths K9d's compile-time chunk loops do not cover).  The library
 latches `getenv` switches at its first call, so the variant runs in a FRESH interpreter that executes the existing GPU tests
 of the plane kernels.
@@ -16,9 +16,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_child(env_extra, select):
+def run_child(env_extra, select, file="test_hip_ops.py"):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_hip_ops.py"), "-m", "gpu", "-x", "-q", "-k", select,
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", file), "-m", "gpu", "-x", "-q", "-k", select,
                         "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     tail = (r.stdout + r.stderr)[-2500:]
     assert r.returncode == 0, tail
@@ -27,3 +27,9 @@ def run_child(env_extra, select):
 
 def test_k9c_as_the_only_plane_kernel(device):
     run_child(dict(FSF_PLANES_PIPE="0"), "spconv_forward_planes")
+
+
+def test_read_backs_through_copy_and_synchronize(device):
+    """`FSF_READBACK_MAILBOX=0`: every count / flag read-back of the library as hipMemcpyAsync + hipStreamSynchronize instead of the
+    pinned mailbox (csrc/readback.hip) — the entry points that read something back stay green on that route."""
+    run_child(dict(FSF_READBACK_MAILBOX="0"), "unique or key_survival or overlap_rows or group_pairs or rulebook_strided or point_pool or ingroup")

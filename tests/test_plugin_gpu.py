@@ -54,6 +54,29 @@ def test_scatter_v2_reference_golden(plugin, device, case):
         np.testing.assert_allclose(out[0].cpu().numpy(), g["new_feat"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("hint", ["exact", "wide", "too_narrow", "too_wide_for_64_bits"])
+def test_unique_with_attached_key_bounds_equals_torch_unique(plugin, device, hint):
+    """`with_key_bounds` is a hint: with bounds that hold the unique packs its sort key from them (no range pass, no host wait for it);
+    a key outside them, or bounds whose bit widths exceed 64, send the call through the data-dependent range pass — same result."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops.sst_ops import clear_unique_cache, with_key_bounds
+
+    torch.manual_seed(3)
+    coors = torch.stack([torch.randint(0, 2, (50000,)), torch.randint(-5, 40, (50000,)), torch.randint(0, 700, (50000,)),
+                         torch.randint(0, 700, (50000,))], 1).to(device)
+    want = torch.unique(coors, return_inverse=True, return_counts=True, dim=0)
+    lo, hi = {"exact": ([0, -5, 0, 0], [1, 39, 699, 699]), "wide": ([0, -100, -100, -100], [7, 1000, 5000, 5000]),
+              "too_narrow": ([0, 0, 0, 0], [1, 39, 699, 699]),
+              "too_wide_for_64_bits": ([0, -2 ** 40, -2 ** 40, -2 ** 40], [1, 2 ** 40, 2 ** 40, 2 ** 40])}[hint]
+    clear_unique_cache()
+    got = plugin.ops.unique_with_plan(with_key_bounds(coors.clone(), lo, hi))
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    # explicit bounds (the argument form) stay a contract: a key outside them is an error, not a silent fallback
+    if hint == "too_narrow":
+        with pytest.raises(Exception, match="row key|bounds|KEY_RANGE|status -3"):
+            plugin.ops.unique_with_plan(coors.clone(), lo, hi)
+
+
 def test_scatter_v2_precomputed_inverse_and_autograd(plugin, device):
     g = golden_cases(load_golden("scatter_v2.npz"))["k4_max"]
     feat = torch.from_numpy(g["feat"]).to(device).requires_grad_(True)
