@@ -36,6 +36,9 @@ constexpr int LNA_RG = 2;         // 16-row groups per wave and iteration
 #ifndef LNA_WPS
 #define LNA_WPS 3                 // waves per SIMD the register budget is set for (workgroups per CU)
 #endif
+#ifndef LNA_SEG_WPS
+#define LNA_SEG_WPS 3             // ... of the K22s variants (2 = no spills at 256 registers, a third fewer waves: measured, see DESIGN)
+#endif
 constexpr int LNA_ROWS = LNA_NW * LNA_RG * 16;  // rows per workgroup iteration (4-wave workgroups)
 
 struct LnaArgs {
@@ -389,7 +392,7 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
 // out of its CU) — so the weight stream is not what this kernel waits for.  Kept behind FSF_K22_WIDE_MIN_ROWS=<rows> (default: never).
 template <int T, int NW, bool SEG = false, int NORM_CT = -1, int ACT_CT = -1>  // 16-channel tiles (c <= 16 T); SEG: + segmented max of the
 // output (rows sorted by segment), norm / act fixed at compile time
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? LNA_WPS : 3) linear_norm_act_kernel(LnaArgs a) {
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WPS) : 3) linear_norm_act_kernel(LnaArgs a) {
   constexpr int LNA_NW = NW;
   constexpr int LNA_ROWS = NW * LNA_RG * 16;
   constexpr int CHUNK_U4 = T * 3 * 64;  // uint4 per weight chunk
@@ -617,7 +620,7 @@ static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream) {
   const int T = lna_tiles(a.slice_w < a.c ? a.slice_w : a.c);
   const int rows = LNA_NW * LNA_RG * 16;
   const int64_t nblk = (a.n + rows - 1) / rows;
-  int64_t gx = (256 * LNA_WPS + nslice - 1) / nslice;
+  int64_t gx = (256 * (a.seg_out ? LNA_SEG_WPS : LNA_WPS) + nslice - 1) / nslice;
   if (gx > nblk) gx = nblk;
   const dim3 grid((unsigned)gx, (unsigned)nslice);
 #define FSF_LNA(T_, NW_, SEG_, NORM_, ACT_)                                                                                          \
