@@ -285,22 +285,34 @@ struct KsPairOut {
 // that ORs the groups somebody passes into a word, one scan over the (group, point) grid in group-major order that writes the pairs.
 // Replaces a compare, an any-reduction, three boolean elementwise ops, a transposing copy and ATen's nonzero (~12 launches and its
 // blocking count read-back).
+// `groups.use`: `score` holds CLASS scores and group g's score is the sum of its one or two member columns (lo, hi) — what
+// `scores @ member.t()` / `scores[:, cols].sum(1)` give for such groups, bit for bit (one add of two floats has one result)
+struct GpGroups {
+  int use;
+  unsigned char lo[32], hi[32];  // hi == 255: one member
+};
+__device__ __forceinline__ float gp_score(const float* row, int g, const GpGroups& groups) {
+  if (!groups.use) return row[g];
+  const float a = row[groups.lo[g]];
+  return groups.hi[g] == 255 ? a : __fadd_rn(a, row[groups.hi[g]]);
+}
 __global__ void __launch_bounds__(256)
-    gp_any_kernel(const float* __restrict__ score, int64_t n, int ng, int64_t stride, const float* __restrict__ thresh, uint32_t* __restrict__ any_mask) {
+    gp_any_kernel(const float* __restrict__ score, int64_t n, int ng, int64_t stride, const float* __restrict__ thresh, GpGroups groups,
+                  uint32_t* __restrict__ any_mask) {
   uint32_t mine = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     for (int g = 0; g < ng; ++g)
-      if (score[i * stride + g] > thresh[g]) mine |= 1u << g;
+      if (gp_score(score + i * stride, g, groups) > thresh[g]) mine |= 1u << g;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mine |= (uint32_t)__shfl_xor((int)mine, o);
   if ((threadIdx.x & 63) == 0 && mine) atomicOr(any_mask, mine);
 }
 struct GpIn {
-  const float* score; int64_t n; int64_t stride; const float* thresh; const uint32_t* any_mask; int keep_one;
+  const float* score; int64_t n; int64_t stride; const float* thresh; const uint32_t* any_mask; int keep_one; GpGroups groups;
   __device__ uint32_t operator()(int64_t t) const {
     const int g = (int)(t / n);
     const int64_t i = t - (int64_t)g * n;
-    if (score[i * stride + g] > thresh[g]) return 1u;
+    if (gp_score(score + i * stride, g, groups) > thresh[g]) return 1u;
     return (keep_one && i == 0 && !((*any_mask >> g) & 1u)) ? 1u : 0u;
   }
 };
@@ -599,11 +611,25 @@ extern "C" int64_t fsf_group_pairs_workspace_bytes(int64_t n, int32_t ng) {
 }
 
 extern "C" int fsf_group_pairs(const float* score, int64_t n, int32_t ng, int64_t score_stride, const float* thresh, int32_t keep_one,
-                               int64_t* g_ids, int64_t* p_ids, int64_t capacity, int64_t* count_host, void* workspace, int64_t workspace_bytes,
-                               void* stream_) {
+                               const uint32_t* group_class_masks, int32_t num_classes, int64_t* g_ids, int64_t* p_ids, int64_t capacity,
+                               int64_t* count_host, void* workspace, int64_t workspace_bytes, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (n < 0 || ng < 1 || !thresh || !count_host || score_stride < ng || (n > 0 && (!score || !g_ids || !p_ids))) return FSF_ERR_INVALID_ARG;
+  const int cols = group_class_masks ? num_classes : ng;
+  if (n < 0 || ng < 1 || !thresh || !count_host || score_stride < cols || (n > 0 && (!score || !g_ids || !p_ids))) return FSF_ERR_INVALID_ARG;
   if (ng > 32 || n * (int64_t)ng >= ((int64_t)1 << 30)) return FSF_ERR_UNSUPPORTED;
+  GpGroups groups;
+  groups.use = group_class_masks ? 1 : 0;
+  for (int g = 0; g < 32; ++g) groups.lo[g] = 0, groups.hi[g] = 255;
+  if (group_class_masks) {  // (a HOST array: one or two member classes per group, else the caller sums the columns itself)
+    if (num_classes < 1 || num_classes > 32) return FSF_ERR_UNSUPPORTED;
+    for (int g = 0; g < ng; ++g) {
+      const uint32_t m = group_class_masks[g];
+      const int members = __builtin_popcount(m);
+      if (members < 1 || members > 2 || (num_classes < 32 && (m >> num_classes))) return FSF_ERR_UNSUPPORTED;
+      groups.lo[g] = (unsigned char)__builtin_ctz(m);
+      if (members == 2) groups.hi[g] = (unsigned char)(31 - __builtin_clz(m));
+    }
+  }
   if (capacity < n * ng) return FSF_ERR_CAPACITY;  // (the caller allocates the upper bound: the count is only known afterwards)
   *count_host = 0;
   if (n == 0) return FSF_OK;
@@ -615,8 +641,9 @@ extern "C" int fsf_group_pairs(const float* score, int64_t n, int32_t ng, int64_
   if (!ar.ok()) return FSF_ERR_WORKSPACE;
   FSF_HIP_TRY(hipMemsetAsync(any_mask, 0, (size_t)((char*)total - (char*)any_mask), stream));
   if (keep_one)
-    hipLaunchKernelGGL(gp_any_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, score, n, (int)ng, score_stride, thresh, any_mask);
-  const int rc = exclusive_scan_u32(GpIn{score, n, score_stride, thresh, any_mask, (int)keep_one}, GpOut{n, g_ids, p_ids}, n * ng, tiles, nullptr,
+    hipLaunchKernelGGL(gp_any_kernel, dim3(fsf_stream_grid(n, 256)), dim3(256), 0, stream, score, n, (int)ng, score_stride, thresh, groups,
+                       any_mask);
+  const int rc = exclusive_scan_u32(GpIn{score, n, score_stride, thresh, any_mask, (int)keep_one, groups}, GpOut{n, g_ids, p_ids}, n * ng, tiles, nullptr,
                                     total, stream, 1, true);
   if (rc != FSF_OK) return rc;
   int64_t total_h = 0;

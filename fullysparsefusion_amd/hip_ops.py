@@ -41,7 +41,7 @@ _ARGTYPES = {
     "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_project_score": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P, _P, _P, _P],
     "fsf_group_pairs_workspace_bytes": [c_i64, c_i32],
-    "fsf_group_pairs": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, _P, c_i64, _P, _P, c_i64, _P],
+    "fsf_group_pairs": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_i64, _P, _P, c_i64, _P],
     "fsf_overlap_plan_workspace_bytes": [c_i64],
     "fsf_overlap_plan": [_P, _P, c_i64, c_i32, _P, _P, c_i64, _P],
     "fsf_overlap_rows": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P, c_i64, c_i64, c_i64, c_i64, _P, _P, _P],
@@ -82,6 +82,7 @@ _ARGTYPES = {
     "fsf_spconv_forward_planes": [_P, _P, c_i32, _P, _P, c_i32, c_i64, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, _P,
                                   _P],
     "fsf_channel_group_sum_add": [_P, c_i64, c_i32, c_i32, _P, _P, _P],
+    "fsf_channel_group_sum_add2": [_P, c_i32, _P, c_i32, c_i64, c_i32, _P, _P, _P],
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
     "fsf_linear_norm_act": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
@@ -405,6 +406,21 @@ def channel_group_sum_add(feat: torch.Tensor, cout: int, add: Optional[torch.Ten
     return out
 
 
+def channel_group_sum_add2(feat_a: torch.Tensor, feat_b: torch.Tensor, cout: int, add: Optional[torch.Tensor] = None):
+    """fsf_channel_group_sum_add2: channel_group_sum_add over cat([feat_a, feat_b], 1) without forming it."""
+    require_cuda(feat_a, feat_b, add)
+    feat_a, feat_b = feat_a.contiguous(), feat_b.contiguous()
+    n = feat_a.size(0)
+    assert feat_b.size(0) == n and feat_a.dtype == torch.float32 and feat_b.dtype == torch.float32
+    if add is not None:
+        add = add.contiguous()
+        assert add.shape == (n, cout)
+    out = torch.empty((n, cout), dtype=torch.float32, device=feat_a.device)
+    check(_L().fsf_channel_group_sum_add2(ptr(feat_a), feat_a.size(1), ptr(feat_b), feat_b.size(1), n, int(cout), ptr(add), ptr(out),
+                                          stream_ptr()), "fsf_channel_group_sum_add2")
+    return out
+
+
 def voxel2point(points, coors_bzyx, voxel_feats, inv, voxel_size, range_min, padding=-1.0):
     """fsf_voxel2point: fused gather + local-xyz decoration + padding mask (Voxel2PointScatterNeck)."""
     require_cuda(points, coors_bzyx, voxel_feats, inv)
@@ -476,21 +492,30 @@ def project_score(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.Tensor
     return out if len(out) > 1 else score
 
 
-def group_pairs(score: torch.Tensor, thresh: torch.Tensor, keep_one=True):
+def group_pairs(score: torch.Tensor, thresh: torch.Tensor, keep_one=True, group_cols=None):
     """fsf_group_pairs: score f32 [n, ng], thresh f32 [ng] -> (g_ids i64 [P], p_ids i64 [P]) = ((score > thresh) with point 0 kept
-    for a group nobody passes).t().nonzero() columns; one host wait."""
+    for a group nobody passes).t().nonzero() columns; one host wait.  With `group_cols` (per group the list of its one or two class
+    columns) `score` is the class score matrix [n, classes] and the group scores are formed inside."""
     require_cuda(score, thresh)
     assert score.dtype == torch.float32 and thresh.dtype == torch.float32 and score.dim() == 2 and score.stride(1) == 1
-    n, ng = score.shape
-    assert thresh.shape == (ng,) and thresh.is_contiguous()
+    n, cols = score.shape
+    ng = thresh.numel()
+    masks = None
+    if group_cols is not None:
+        assert len(group_cols) == ng and all(1 <= len(c) <= 2 and max(c) < cols for c in group_cols)
+        masks = (ctypes.c_uint32 * ng)(*[sum(1 << int(c) for c in cs) for cs in group_cols])
+    else:
+        assert cols == ng
+    assert thresh.is_contiguous()
     cap = max(n * ng, 1)
     buf = torch.empty((2, cap), dtype=torch.int64, device=score.device)
     h = _L()
     ws = _lib.workspace(h.fsf_group_pairs_workspace_bytes(n, ng), score.device)
     count = c_i64(0)
-    check(h.fsf_group_pairs(c_p(score.data_ptr()) if n else c_p(None), n, ng, score.stride(0) if n > 1 else ng, ptr(thresh),
-                            int(bool(keep_one)), ptr(buf[0]), ptr(buf[1]), cap, ctypes.cast(ctypes.pointer(count), c_p), ptr(ws),
-                            ws.numel(), stream_ptr()), "fsf_group_pairs")
+    check(h.fsf_group_pairs(c_p(score.data_ptr()) if n else c_p(None), n, ng, score.stride(0) if n > 1 else cols, ptr(thresh),
+                            int(bool(keep_one)), ctypes.cast(masks, c_p) if masks is not None else c_p(None), cols, ptr(buf[0]),
+                            ptr(buf[1]), cap, ctypes.cast(ctypes.pointer(count), c_p), ptr(ws), ws.numel(), stream_ptr()),
+          "fsf_group_pairs")
     k = int(count.value)
     return buf[0, :k], buf[1, :k]
 

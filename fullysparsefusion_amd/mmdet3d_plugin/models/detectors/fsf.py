@@ -25,7 +25,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import hip_ops
-from ...ops.sst_ops import with_key_bounds, GatheredRows, build_mlp, clear_unique_cache, gather_by_inverse, scatter_v2
+from ...ops.sst_ops import (GatheredRows, build_mlp, clear_unique_cache, gather_by_inverse, point_linear_add, scatter_v2,
+                            with_key_bounds)
 from ...core.bbox import bbox3d2result
 from ...registry import BBOX_CODERS, DETECTORS, build_head, build_roi_extractor
 from .single_stage_fsd import SingleStageFSD
@@ -312,7 +313,7 @@ class FSF(SingleStageFSD):
         return flat
 
     # ----------------------------------------------------------------------------------- stages
-    def img_cross_attn(self, point_infos, batch_idx, mask_anno, mask_data, img_metas, encode_mlp, ext_pts_inds=None):
+    def img_cross_attn(self, point_infos, batch_idx, mask_anno, mask_data, img_metas, encode_mlp, ext_pts_inds=None, add_to=None):
         batch_size = mask_anno.shape[0]
         points_info_flat = self.combine_by_batch(point_infos, batch_idx, batch_size)
         if ext_pts_inds is not None:
@@ -328,6 +329,16 @@ class FSF(SingleStageFSD):
                                                        return_overlap=True)
             if ext_pts_inds is None:
                 self._fg_cache = (points_info_flat, mask_data, fg, overlap, lidar2img)
+            if add_to is not None and isinstance(encode_mlp, nn.Sequential) and isinstance(encode_mlp[-1], nn.Linear):
+                # `add_to + encode_mlp(score)` with the MLP's last (131-wide) Linear and the sum as one launch (point_linear_add)
+                h = score
+                for layer in list(encode_mlp)[:-1]:
+                    h = layer(h)
+                fused = point_linear_add(encode_mlp[-1], h, add_to)
+                if fused is not None:
+                    fused._fsf_sum_done = True
+                    return fused
+                return encode_mlp[-1](h)
             return encode_mlp(score)
         obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
         _, num_cams, num_classes = obj_id_tensor.shape
@@ -350,8 +361,11 @@ class FSF(SingleStageFSD):
             point_infos_valid = None
         batch_idx = pts_coors[:, 0]
         pts_updated_feats = self.img_cross_attn(point_infos, batch_idx, mask_anno, mask_data, img_metas,
-                                                encode_mlp=self.segmentor_updated_mlp)
-        if (pts_lidar_feats.is_cuda and pts_lidar_feats.dim() == 2 and pts_lidar_feats.size(1) % 4 != 0
+                                                encode_mlp=self.segmentor_updated_mlp,
+                                                add_to=pts_lidar_feats if switches.FUSION_ADD_FUSED else None)
+        if getattr(pts_updated_feats, "_fsf_sum_done", False):
+            pts_feats = pts_updated_feats  # (the sum already: the update MLP's last Linear added the LiDAR features in its epilogue)
+        elif (pts_lidar_feats.is_cuda and pts_lidar_feats.dim() == 2 and pts_lidar_feats.size(1) % 4 != 0
                 and not (torch.is_grad_enabled() and (pts_lidar_feats.requires_grad or pts_updated_feats.requires_grad))):
             # the sum lands in rows padded to a multiple of 4 floats: the 131-column result is then a legal operand of the fused
             # Linear kernel (the segmentation head's first layer otherwise falls back to the library GEMM + a norm pass)

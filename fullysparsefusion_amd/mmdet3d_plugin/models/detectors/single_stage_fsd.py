@@ -234,19 +234,21 @@ class SingleStageFSD(nn.Module):
 
         member = const(("member", ng, nc), _member)
         scores = seg_logits.softmax(1)[:, :-1]
-        if max(len(cols) for cols in group_cols) <= 2:
-            # every group has one or two classes (the nuScenes grouping): a 0/1 membership matmul adds the same one or two
-            # scores plus exact zeros — bit-identical to the reference's per-group column sums, one launch instead of 18
-            grouped_score = scores @ member.t().to(scores.dtype)
+        thresh = const(("score_thresh", tuple(cfg["score_thresh"])), lambda: torch.tensor(cfg["score_thresh"], dtype=scores.dtype))
+        small_groups = max(len(cols) for cols in group_cols) <= 2
+        if (bsz == 1 and switches.GROUP_PAIRS and scores.is_cuda and scores.dtype == torch.float32 and ng <= 32 and nc <= 32
+                and small_groups and scores.stride(1) == 1):
+            # K27: the group scores (every group has one or two classes — the nuScenes grouping: their sum has one value whatever
+            # adds it), the threshold, "at least one point per group" (:832-834) and the group-major pair list in one C-ABI call
+            g_ids, p_ids = hip_ops.group_pairs(scores, thresh, keep_one=True, group_cols=group_cols)
         else:
-            # the reference's sums (same columns, same order as its boolean column mask; an index list does not sync the host)
-            grouped_score = torch.stack([scores[:, cols].sum(1) for cols in group_cols], dim=1)
-        thresh = const(("score_thresh", tuple(cfg["score_thresh"])), lambda: torch.tensor(cfg["score_thresh"], dtype=grouped_score.dtype))
-        if (bsz == 1 and switches.GROUP_PAIRS and grouped_score.is_cuda and grouped_score.dtype == torch.float32 and ng <= 32
-                and grouped_score.stride(1) == 1):
-            # K27: threshold, "at least one point per group" (:832-834) and the group-major pair list in one C-ABI call
-            g_ids, p_ids = hip_ops.group_pairs(grouped_score, thresh, keep_one=True)
-        else:
+            if small_groups:
+                # a 0/1 membership matmul adds the same one or two scores plus exact zeros — bit-identical to the reference's
+                # per-group column sums, one launch instead of 18
+                grouped_score = scores @ member.t().to(scores.dtype)
+            else:
+                # the reference's sums (same columns, same order as its boolean column mask; an index list does not sync the host)
+                grouped_score = torch.stack([scores[:, cols].sum(1) for cols in group_cols], dim=1)
             fg = grouped_score > thresh[None, :]
             if bsz == 1:
                 fg[0] |= ~fg.any(0)  # "at least one point per sample" (:832-834)

@@ -687,6 +687,51 @@ def point_linear(linear, x):
     return F.linear(x, linear.weight, linear.bias)
 
 
+_IDENTITY_ROWS = {}
+
+
+def _identity_rows(n, device):
+    """arange(n) i64 on `device` (grow-only, per device and stream owner thread): the row index of `point_linear_add`'s addend."""
+    key = (device, threading.get_ident())
+    t = _IDENTITY_ROWS.get(key)
+    if t is None or t.numel() < n:
+        t = _IDENTITY_ROWS[key] = torch.arange(max(n, 1 << 16), dtype=torch.int64, device=device)
+    return t[:n]
+
+
+def point_linear_add(linear, x, addend):
+    """`linear(x) + addend` for a per-point nn.Linear whose width is NOT a multiple of 4 (the 131-wide image feature update of
+    FSF.segmentor_feat_inhance_test, FSF.py:789-792) in ONE K22 launch: the weight padded with zero rows to the next multiple of 4,
+    the addend — rows of a buffer padded the same way, as the neck emits them — added in the kernel's epilogue, the result a
+    `[:, :c]` view of a padded buffer (a legal K22 operand for the next layer).  Returns None when the shapes are not covered
+    (the caller then runs the library GEMM and the add)."""
+    c = linear.out_features
+    cpad = (c + 3) // 4 * 4
+    n = x.size(0)
+    if (torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad or addend.requires_grad)) or n < 1024:
+        return None
+    if not (x.is_cuda and x.dim() == 2 and addend.dim() == 2 and addend.shape == (n, c) and addend.dtype == torch.float32
+            and addend.stride(1) == 1 and addend.stride(0) == cpad and addend.data_ptr() % 16 == 0
+            and hip_ops.linear_norm_act_supported(x, cpad)):
+        return None
+    key = (linear.weight.data_ptr(), linear.weight._version, None if linear.bias is None else (linear.bias.data_ptr(), linear.bias._version),
+           linear.weight.device)
+    cache = linear.__dict__.get("_fsf_planes_padded")
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            w = linear.weight.new_zeros((cpad, linear.in_features))
+            w[:c] = linear.weight
+            b = linear.weight.new_zeros((cpad,))
+            if linear.bias is not None:
+                b[:c] = linear.bias
+            cache = (key, hip_ops.linear_prepare_weight(w), b)
+        linear.__dict__["_fsf_planes_padded"] = cache
+    rows = torch.as_strided(addend, (n, cpad), (cpad, 1))  # the padded buffer behind the view (its last columns are never used)
+    out = torch.empty((n, cpad), dtype=torch.float32, device=x.device)
+    hip_ops.linear_norm_act(x, cache[1], cpad, bias=cache[2], out=out, row_add=rows, row_add_index=_identity_rows(n, x.device))
+    return out[:, :c]
+
+
 class PointLinear(nn.Linear):
     """nn.Linear (same parameters, same state-dict keys) whose training-time weight gradient takes the K10 route."""
 

@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 11
+#define FSF_ABI_VERSION 12
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -192,6 +192,10 @@ int fsf_gather_rows_add(const float* src, int64_t src_stride, int64_t m, int32_t
  *   cout % 4 == 0. */
 int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t cin, int32_t cout, const float* add, float* out,
                               void* stream);
+/* ... over `cat([feat_a, feat_b], 1)` without the concatenation (the decoder's `cat((x_bottom.features, x_lateral.features), 1)` has no
+ * other fp32 reader once the merge convolution takes its two inputs as plane sources): ca + cb = 2 * cout, ca and cb multiples of 8. */
+int fsf_channel_group_sum_add2(const float* feat_a, int32_t ca, const float* feat_b, int32_t cb, int64_t n, int32_t cout, const float* add,
+                               float* out, void* stream);
 
 /* Fused a7: Voxel2PointScatterNeck.forward (voxel2point_neck.py:27-70) without the boolean compaction:
  *   out[i, 0:c]   = voxel_feats[inv[i], :]
@@ -737,11 +741,14 @@ int fsf_cluster_point_ids(const int32_t* labels, const int32_t* vox_group, int64
 /* K27  the (group, point) pairs of SingleStageFSD's grouped sampling for ONE sample (single_stage_fsd.py:826-838):
  *   fg = score > thresh[None, :];  keep_one: fg[0] |= ~fg.any(0) (a group nobody passes keeps point 0);  (g_ids, p_ids) = fg.t().nonzero()
  *   score f32 [n, ng] (row stride score_stride floats, ng <= 32), thresh f32 [ng] -> g_ids, p_ids i64 [capacity >= n * ng], the first
- *   *count_host entries valid, group-major, points ascending inside a group.  One read-back. */
+ *   *count_host entries valid, group-major, points ascending inside a group.  One read-back.
+ *   group_class_masks (HOST u32 [ng], or NULL): `score` is then the CLASS score matrix f32 [n, num_classes] and group g's score the sum
+ *   of its member columns (bit c of mask g) — `gather_group_by_names` (:868-872) folded in; one or two members per group (one add has one
+ *   result whatever the order: identical to the reference's column sums), else FSF_ERR_UNSUPPORTED. */
 int64_t fsf_group_pairs_workspace_bytes(int64_t n, int32_t ng);
 int fsf_group_pairs(const float* score, int64_t n, int32_t ng, int64_t score_stride, const float* thresh, int32_t keep_one,
-                    int64_t* g_ids, int64_t* p_ids, int64_t capacity, int64_t* count_host, void* workspace, int64_t workspace_bytes,
-                    void* stream);
+                    const uint32_t* group_class_masks, int32_t num_classes, int64_t* g_ids, int64_t* p_ids, int64_t capacity,
+                    int64_t* count_host, void* workspace, int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

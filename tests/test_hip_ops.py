@@ -387,6 +387,21 @@ def test_group_pairs_equal_the_torch_expression(ops, device, n, ng, empty_group,
     g2, p2 = ops.group_pairs(score, thresh, keep_one=False)
     want2 = (score > thresh[None, :]).t().nonzero(as_tuple=False)
     assert torch.equal(g2, want2[:, 0]) and torch.equal(p2, want2[:, 1])
+    if ng <= 16:  # class scores in, one or two member classes per group (gather_group_by_names folded in): the reference's column sums
+        nc = 2 * ng - 1
+        cls = torch.softmax(torch.randn(n, nc + 1, device=device) * 3.0, 1)[:, :-1]  # (a row-strided view, as in the detector)
+        cols = [[2 * g, 2 * g + 1] if g < ng - 1 else [2 * g] for g in range(ng)]
+        member = torch.zeros((ng, nc), device=device)
+        for g, c in enumerate(cols):
+            member[g, c] = 1.0
+        grouped = torch.stack([cls[:, c].sum(1) for c in cols], dim=1)
+        assert torch.equal(grouped, cls @ member.t())
+        th = torch.full((ng,), 0.3, device=device)
+        fg3 = grouped > th[None, :]
+        fg3[0] |= ~fg3.any(0)
+        want3 = fg3.t().nonzero(as_tuple=False)
+        g3, p3 = ops.group_pairs(cls, th, keep_one=True, group_cols=cols)
+        assert torch.equal(g3, want3[:, 0]) and torch.equal(p3, want3[:, 1])
 
 
 def overlap_rows_reference(obj):

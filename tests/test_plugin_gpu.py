@@ -77,6 +77,28 @@ def test_unique_with_attached_key_bounds_equals_torch_unique(plugin, device, hin
             plugin.ops.unique_with_plan(coors.clone(), lo, hi)
 
 
+def test_point_linear_add_equals_linear_plus_addend(plugin, device):
+    """`point_linear_add` (the 131-wide image-feature update + the LiDAR features in one K22 launch, FSF.py:789-792) against float64;
+    the addend is a [:, :131] view of a 132-wide buffer whose last column holds NaN (never read into a result)."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops.sst_ops import PointLinear, point_linear_add
+
+    torch.manual_seed(2)
+    n, k, c = 30011, 128, 131
+    lin = PointLinear(k, c, bias=True).to(device)
+    x = torch.randn(n, k, device=device)
+    buf = torch.full((n, 132), float("nan"), device=device)
+    buf[:, :c] = torch.randn(n, c, device=device)
+    addend = buf[:, :c]
+    with torch.no_grad():
+        out = point_linear_add(lin, x, addend)
+        assert out is not None and out.shape == (n, c) and out.stride(0) == 132
+        want = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double()) + addend.double()
+        ref32 = torch.nn.functional.linear(x, lin.weight, lin.bias) + addend
+    err, err32 = float((out.double() - want).abs().max()), float((ref32.double() - want).abs().max())
+    assert err <= max(2.0 * err32, 2e-6 * float(want.abs().max())), (err, err32)
+    assert point_linear_add(lin, x, buf[:, :c].contiguous()) is None  # (an addend without the padded rows: the caller's generic path)
+
+
 def test_scatter_v2_precomputed_inverse_and_autograd(plugin, device):
     g = golden_cases(load_golden("scatter_v2.npz"))["k4_max"]
     feat = torch.from_numpy(g["feat"]).to(device).requires_grad_(True)

@@ -1,27 +1,30 @@
-"""RoI / pooled-point statistics of the bench frame's refine stage (what the pooling kernels see).  (GPU box)"""
+"""RoI pooling (K17) in the benchmark frame: how many rows each RoI keeps and the launch's time.  usage: pool_stats.py [sweeps]  (GPU box)"""
 import os, sys, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench
 from fullysparsefusion_amd import hip_ops
-dev = torch.device('cuda:0')
+dev = torch.device("cuda:0")
 model = bench.build_model(dev)
-frame, inp = bench.make_inputs(10, 0, dev)
+_, inp = bench.make_inputs(int(sys.argv[1]) if len(sys.argv) > 1 else 10, 0, dev)
+for _ in range(2): bench.step(model, inp)
 calls = []
 orig = hip_ops.dynamic_point_pool
 def spy(*a, **k):
-    calls.append((a, k)); return orig(*a, **k)
+    out = orig(*a, **k); calls.append((a, k, out)); return out
 hip_ops.dynamic_point_pool = spy
 bench.step(model, inp)
 hip_ops.dynamic_point_pool = orig
-for a, k in calls:
+for a, k, out in calls:
     rois, pts = a[0], a[1]
-    box = rois[:, k.get('box_col', 0):][:, :7]
-    print("rois", tuple(rois.shape), "pts", tuple(pts.shape), "args", a[2:], {kk: v for kk, v in k.items() if kk != 'pts_batch'})
-    for name, col in (("w", 3), ("l", 4), ("h", 5)):
-        v = box[:, col]
-        print(f"  {name}: min {v.min():.2f} median {v.median():.2f} p90 {v.quantile(0.9):.2f} max {v.max():.2f}")
-    gp, gr, gf = orig(rois, pts, a[2], 10 ** 6, 10 ** 8, **{kk: v for kk, v in k.items()})
-    cnt = torch.bincount(gr, minlength=rois.size(0)).float()
-    print(f"  uncapped hits per RoI: median {cnt.median():.0f} mean {cnt.mean():.0f} p90 {cnt.quantile(0.9):.0f} max {cnt.max():.0f}; first RoIs: {cnt[:12].tolist()}")
-    c512 = cnt.clamp(max=a[3]).cumsum(0)
-    print(f"  RoIs until max_all={a[4] if len(a) > 4 else k.get('max_all_pts')}: {(c512 < (a[4] if len(a) > 4 else 50000)).sum().item()}")
+    roi_idx = out[1]
+    cnt = torch.bincount(roi_idx.clamp(min=0), minlength=rois.size(0))
+    q = torch.quantile(cnt.float(), torch.tensor([0.5, 0.9, 0.99, 1.0], device=dev)).tolist()
+    print(f"rois {rois.size(0)} points {pts.size(0)} rows {roi_idx.numel()} max_inbox {a[3]}: rows per RoI median {q[0]:.0f} p90 {q[1]:.0f} p99 {q[2]:.0f} max {q[3]:.0f}; "
+          f"RoIs at the cap {int((cnt >= a[3]).sum())}, empty {int((cnt == 0).sum())}")
+    def t(f, it=10):
+        for _ in range(3): f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(it): f()
+        e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it * 1e3
+    print(f"  whole call {t(lambda: orig(*a, **k)):.0f} us")
