@@ -82,7 +82,6 @@ _ARGTYPES = {
     "fsf_spconv_forward_planes": [_P, _P, c_i32, _P, _P, c_i32, c_i64, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, _P,
                                   _P],
     "fsf_channel_group_sum_add": [_P, c_i64, c_i32, c_i32, _P, _P, _P],
-    "fsf_channel_group_sum_add2": [_P, c_i32, _P, c_i32, c_i64, c_i32, _P, _P, _P],
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
     "fsf_linear_norm_act": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
@@ -403,21 +402,6 @@ def channel_group_sum_add(feat: torch.Tensor, cout: int, add: Optional[torch.Ten
         assert add.shape == (n, cout)
     out = torch.empty((n, cout), dtype=torch.float32, device=feat.device)
     check(_L().fsf_channel_group_sum_add(ptr(feat), n, cin, cout, ptr(add), ptr(out), stream_ptr()), "fsf_channel_group_sum_add")
-    return out
-
-
-def channel_group_sum_add2(feat_a: torch.Tensor, feat_b: torch.Tensor, cout: int, add: Optional[torch.Tensor] = None):
-    """fsf_channel_group_sum_add2: channel_group_sum_add over cat([feat_a, feat_b], 1) without forming it."""
-    require_cuda(feat_a, feat_b, add)
-    feat_a, feat_b = feat_a.contiguous(), feat_b.contiguous()
-    n = feat_a.size(0)
-    assert feat_b.size(0) == n and feat_a.dtype == torch.float32 and feat_b.dtype == torch.float32
-    if add is not None:
-        add = add.contiguous()
-        assert add.shape == (n, cout)
-    out = torch.empty((n, cout), dtype=torch.float32, device=feat_a.device)
-    check(_L().fsf_channel_group_sum_add2(ptr(feat_a), feat_a.size(1), ptr(feat_b), feat_b.size(1), n, int(cout), ptr(add), ptr(out),
-                                          stream_ptr()), "fsf_channel_group_sum_add2")
     return out
 
 

@@ -108,29 +108,12 @@ class SimpleSparseUNet(nn.Module):
     def decoder_layer_forward(self, x_lateral, x_bottom, lateral_layer, merge_layer, upsample_layer, lateral_out=None):
         x = lateral_out if lateral_out is not None else lateral_layer(x_lateral)
         lat_planes, bot_planes = x.plane_sources, x_bottom.plane_sources
-        fb, fl = x_bottom.features, x.features
-        two_sources = (lat_planes is not None and len(lat_planes) == 1 and fb.size(1) <= 128 and fb.size(1) % 32 == 0)
-        if two_sources and (bot_planes is None or len(bot_planes) != 1):
-            bot_planes = [hip_ops.to_planes(fb)]
-        conv = merge_layer[0] if isinstance(merge_layer, SparseSequential) and len(merge_layer) > 0 else None
-        if (two_sources and switches.UNET_NO_CONCAT and isinstance(conv, SparseConvolution) and fb.is_cuda and fb.dtype == torch.float32
-                and not torch.is_grad_enabled() and fb.size(1) % 8 == 0 and fl.size(1) % 8 == 0 and fb.size(0) > 0):
-            # Nobody needs the fp32 concatenation: the merge convolution reads its two halves as plane sources (the lateral block's
-            # own plane-form output and a conversion of the bottom-up features) and the channel reduction reads them in place.
-            lazy = x._like(fb.new_empty((fb.size(0), 0)))
-            lazy.plane_sources = [bot_planes[0], lat_planes[0]]
-            if conv._use_planes_kernel(lazy, fb.size(0)):
-                x_merge = merge_layer(lazy)
-                cout = x_merge.features.shape[1]
-                if fb.size(1) + fl.size(1) == 2 * cout:
-                    return upsample_layer(x._like(hip_ops.channel_group_sum_add2(fb, fl, cout, add=x_merge.features)))
-                x = x._like(torch.cat((fb, fl), dim=1))
-                x = self.reduce_channel(x, cout)
-                return upsample_layer(x._like(x_merge.features + x.features))
-        x = x._like(torch.cat((fb, fl), dim=1))
-        if two_sources:
-            # the merge layer reads the concatenation as two plane sources (the fp32 concat above is still what the channel
-            # reduction reads)
+        x = x._like(torch.cat((x_bottom.features, x.features), dim=1))
+        if lat_planes is not None and len(lat_planes) == 1 and x_bottom.features.size(1) <= 128 and x_bottom.features.size(1) % 32 == 0:
+            # the merge layer reads the concatenation as two plane sources: the lateral block's own plane-form output and
+            # a conversion of the bottom-up features (the fp32 concat above is still what the channel reduction reads)
+            if bot_planes is None or len(bot_planes) != 1:
+                bot_planes = [hip_ops.to_planes(x_bottom.features)]
             x.plane_sources = [bot_planes[0], lat_planes[0]]
         x_merge = merge_layer(x)
         cout, f = x_merge.features.shape[1], x.features

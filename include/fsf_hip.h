@@ -192,10 +192,7 @@ int fsf_gather_rows_add(const float* src, int64_t src_stride, int64_t m, int32_t
  *   cout % 4 == 0. */
 int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t cin, int32_t cout, const float* add, float* out,
                               void* stream);
-/* ... over `cat([feat_a, feat_b], 1)` without the concatenation (the decoder's `cat((x_bottom.features, x_lateral.features), 1)` has no
- * other fp32 reader once the merge convolution takes its two inputs as plane sources): ca + cb = 2 * cout, ca and cb multiples of 8. */
-int fsf_channel_group_sum_add2(const float* feat_a, int32_t ca, const float* feat_b, int32_t cb, int64_t n, int32_t cout, const float* add,
-                               float* out, void* stream);
+
 
 /* Fused a7: Voxel2PointScatterNeck.forward (voxel2point_neck.py:27-70) without the boolean compaction:
  *   out[i, 0:c]   = voxel_feats[inv[i], :]
