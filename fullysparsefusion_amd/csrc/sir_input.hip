@@ -465,3 +465,107 @@ extern "C" int fsf_sir_input_gather(const float* points, int64_t points_stride, 
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }
+
+// ----------------------------------------------------------------------------------------------------------------
+// K28 (training): y = cat([points[:, :3] / normalizer, points[:, 3:], feats, extra / extra_div], 1) * h  and its adjoint.
+// SIRLayer.forward (sir_layer [UNVENDORED]) in training mode: the position MLP h = rel_mlp(f_cluster / scaler) stays
+// in autograd (three thin layers), but around it ATen wrote the concatenation twice (SIR.forward's cat, then the copy with the
+// normalised xyz), the product, and in the backward two more products, a zero-filled slice-gradient and its accumulation:
+// ~1.8 GB written per 491 k-row block.  Here the forward writes y only and the backward writes grad_h and grad_feats
+// (, grad_extra) only; x is re-formed from its sources in both.  The same IEEE operations per element as the ATen chain
+// (division, not multiplication by a reciprocal): bit-identical results.
+namespace fsf {
+struct CatMulArgs {
+  const float* points; int64_t points_stride; int p_cols;
+  const float* feats; int64_t feats_stride; int f_cols;
+  const float* extra; int64_t extra_stride; int e_cols; float extra_div;
+  float norm[3];
+  const float* h;       // [n, c] contiguous
+  const float* g;       // backward: grad of y [n, c] contiguous
+  float* out;           // forward: y [n, c];  backward: grad_h [n, c]
+  float* g_feats;       // backward (optional): [n, f_cols] contiguous
+  float* g_extra;       // backward (optional): [n, e_cols] contiguous
+  int64_t n; int c;
+};
+
+__device__ __forceinline__ float cm_x(const CatMulArgs& a, int64_t i, int col) {
+  if (col < a.p_cols) {
+    const float v = a.points[i * a.points_stride + col];
+    return col < 3 ? __fdiv_rn(v, a.norm[col]) : v;
+  }
+  col -= a.p_cols;
+  if (col < a.f_cols) return a.feats[i * a.feats_stride + col];
+  col -= a.f_cols;
+  return __fdiv_rn(a.extra[i * a.extra_stride + col], a.extra_div);
+}
+
+__global__ void __launch_bounds__(256) cat_mul_kernel(CatMulArgs a) {
+  const int64_t total = a.n * a.c;
+  const bool small = total <= 0x7fffffff;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = small ? (int64_t)((uint32_t)t / (uint32_t)a.c) : t / a.c;
+    const int col = (int)(t - i * a.c);
+    a.out[t] = __fmul_rn(cm_x(a, i, col), a.h[t]);
+  }
+}
+
+__global__ void __launch_bounds__(256) cat_mul_bwd_kernel(CatMulArgs a) {
+  const int64_t total = a.n * a.c;
+  const bool small = total <= 0x7fffffff;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = small ? (int64_t)((uint32_t)t / (uint32_t)a.c) : t / a.c;
+    const int col = (int)(t - i * a.c);
+    const float g = a.g[t];
+    a.out[t] = __fmul_rn(g, cm_x(a, i, col));  // d/dh
+    const int fc = col - a.p_cols;
+    if (fc >= 0) {
+      const float gx = __fmul_rn(g, a.h[t]);   // d/dx
+      if (fc < a.f_cols) {
+        if (a.g_feats) a.g_feats[i * a.f_cols + fc] = gx;
+      } else if (a.g_extra) {
+        a.g_extra[i * a.e_cols + (fc - a.f_cols)] = __fdiv_rn(gx, a.extra_div);
+      }
+    }
+  }
+}
+}  // namespace fsf
+
+static int cat_mul_check(const float* points, int64_t points_stride, int32_t p_cols, const float* xyz_normalizer, const float* feats,
+                         int64_t feats_stride, int32_t f_cols, const float* extra, int64_t extra_stride, int32_t e_cols, const float* h,
+                         int64_t n) {
+  if (n < 0 || p_cols < 3 || f_cols < 0 || e_cols < 0 || !xyz_normalizer || points_stride < p_cols || (f_cols > 0 && feats_stride < f_cols) ||
+      (e_cols > 0 && extra_stride < e_cols) || (n > 0 && (!points || !h || (f_cols > 0 && !feats) || (e_cols > 0 && !extra))))
+    return FSF_ERR_INVALID_ARG;
+  return FSF_OK;
+}
+
+extern "C" int fsf_concat_mul(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3], const float* feats,
+                              int64_t feats_stride, int32_t f_cols, const float* extra, int64_t extra_stride, int32_t e_cols,
+                              float extra_div, const float* h, int64_t n, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = cat_mul_check(points, points_stride, p_cols, xyz_normalizer, feats, feats_stride, f_cols, extra, extra_stride, e_cols, h, n);
+  if (rc != FSF_OK || (n > 0 && !out)) return rc != FSF_OK ? rc : FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  fsf::CatMulArgs a{points, points_stride, (int)p_cols, feats, feats_stride, (int)f_cols, extra, extra_stride, (int)e_cols, extra_div,
+                    {xyz_normalizer[0], xyz_normalizer[1], xyz_normalizer[2]}, h, nullptr, out, nullptr, nullptr, n,
+                    (int)(p_cols + f_cols + e_cols)};
+  hipLaunchKernelGGL(fsf::cat_mul_kernel, dim3(fsf_stream_grid(n * a.c, 256)), dim3(256), 0, stream, a);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_concat_mul_backward(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3],
+                                       const float* feats, int64_t feats_stride, int32_t f_cols, const float* extra, int64_t extra_stride,
+                                       int32_t e_cols, float extra_div, const float* h, const float* grad_out, int64_t n, float* grad_h,
+                                       float* grad_feats, float* grad_extra, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int rc = cat_mul_check(points, points_stride, p_cols, xyz_normalizer, feats, feats_stride, f_cols, extra, extra_stride, e_cols, h, n);
+  if (rc != FSF_OK || (n > 0 && (!grad_out || !grad_h))) return rc != FSF_OK ? rc : FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  fsf::CatMulArgs a{points, points_stride, (int)p_cols, feats, feats_stride, (int)f_cols, extra, extra_stride, (int)e_cols, extra_div,
+                    {xyz_normalizer[0], xyz_normalizer[1], xyz_normalizer[2]}, h, grad_out, grad_h, grad_feats, grad_extra, n,
+                    (int)(p_cols + f_cols + e_cols)};
+  hipLaunchKernelGGL(fsf::cat_mul_bwd_kernel, dim3(fsf_stream_grid(n * a.c, 256)), dim3(256), 0, stream, a);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}

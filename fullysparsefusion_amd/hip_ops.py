@@ -40,6 +40,8 @@ _ARGTYPES = {
     "fsf_project_gather_mask": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_cam_select_score": [_P, c_i64, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P],
     "fsf_project_score": [_P, c_i64, c_i32, _P, c_i32, _P, c_i32, c_i32, c_i32, c_i32, _P, c_i32, c_i32, c_i32, _P, _P, _P, _P, _P, _P],
+    "fsf_concat_mul": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, _P, _P],
+    "fsf_concat_mul_backward": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, _P, c_i64, _P, _P, _P, _P],
     "fsf_group_pairs_workspace_bytes": [c_i64, c_i32],
     "fsf_group_pairs": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_i64, _P, _P, c_i64, _P],
     "fsf_overlap_plan_workspace_bytes": [c_i64],
@@ -474,6 +476,43 @@ def project_score(xyz: torch.Tensor, lidar2img: torch.Tensor, mask: torch.Tensor
     if return_overlap:
         out += ((fg, count, max_id),)
     return out if len(out) > 1 else score
+
+
+def _concat_mul_args(points, feats, extra, xyz_normalizer, extra_div):
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.stride(1) == 1 and points.size(1) >= 3
+    n = points.size(0)
+    for t in (feats, extra):
+        assert t is None or (t.dtype == torch.float32 and t.dim() == 2 and t.size(0) == n and t.stride(1) == 1)
+    def rows(t):
+        return (c_p(t.data_ptr()) if t is not None and t.numel() else c_p(None), (t.stride(0) if n > 1 else t.size(1)) if t is not None else 0,
+                t.size(1) if t is not None else 0)
+    return (c_p(points.data_ptr()) if n else c_p(None), points.stride(0) if n > 1 else points.size(1), points.size(1),
+            f32_array(xyz_normalizer), *rows(feats), *rows(extra), float(extra_div))
+
+
+def concat_mul(points, feats, extra, h, xyz_normalizer, extra_div=1.0):
+    """fsf_concat_mul (K28): cat([points[:, :3] / normalizer, points[:, 3:], feats, extra / extra_div], 1) * h -> f32 [n, c]."""
+    require_cuda(points, feats, extra, h)
+    n = points.size(0)
+    c = points.size(1) + (feats.size(1) if feats is not None else 0) + (extra.size(1) if extra is not None else 0)
+    assert h.shape == (n, c) and h.dtype == torch.float32 and h.is_contiguous()
+    out = torch.empty((n, c), dtype=torch.float32, device=points.device)
+    check(_L().fsf_concat_mul(*_concat_mul_args(points, feats, extra, xyz_normalizer, extra_div), ptr(h), n, ptr(out), stream_ptr()),
+          "fsf_concat_mul")
+    return out
+
+
+def concat_mul_backward(points, feats, extra, h, grad_out, xyz_normalizer, extra_div=1.0, want_feats=True, want_extra=False):
+    """fsf_concat_mul_backward -> (grad_h [n, c], grad_feats [n, cf] | None, grad_extra [n, ce] | None)."""
+    require_cuda(points, feats, extra, h, grad_out)
+    n, c = h.shape
+    assert grad_out.shape == (n, c) and grad_out.dtype == torch.float32 and grad_out.is_contiguous() and h.is_contiguous()
+    g_h = torch.empty((n, c), dtype=torch.float32, device=h.device)
+    g_f = torch.empty((n, feats.size(1)), dtype=torch.float32, device=h.device) if (want_feats and feats is not None) else None
+    g_e = torch.empty((n, extra.size(1)), dtype=torch.float32, device=h.device) if (want_extra and extra is not None) else None
+    check(_L().fsf_concat_mul_backward(*_concat_mul_args(points, feats, extra, xyz_normalizer, extra_div), ptr(h), ptr(grad_out), n,
+                                       ptr(g_h), ptr(g_f), ptr(g_e), stream_ptr()), "fsf_concat_mul_backward")
+    return g_h, g_f, g_e
 
 
 def group_pairs(score: torch.Tensor, thresh: torch.Tensor, keep_one=True, group_cols=None):

@@ -144,6 +144,27 @@ class DynamicScatterVFE(nn.Module):
         return voxel_feats, voxel_coors
 
 
+class _SirProductFn(torch.autograd.Function):
+    """y = cat([points[:, :3] / normalizer, points[:, 3:], feats, extra / extra_div], 1) * h with the adjoints of feats, extra and h
+    (hip_ops.concat_mul / concat_mul_backward, K28); nothing but the inputs is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, points, feats, extra, h, normalizer, extra_div):
+        points, feats, h = points.contiguous(), feats.contiguous(), h.contiguous()
+        extra = extra.contiguous() if extra is not None else None
+        ctx.save_for_backward(points, feats, extra, h)
+        ctx.normalizer, ctx.extra_div = normalizer, extra_div
+        return hip_ops.concat_mul(points, feats, extra, h, normalizer, extra_div)
+
+    @staticmethod
+    def backward(ctx, grad):
+        points, feats, extra, h = ctx.saved_tensors
+        g_h, g_f, g_e = hip_ops.concat_mul_backward(points, feats, extra, h, grad.contiguous(), ctx.normalizer, ctx.extra_div,
+                                                    want_feats=ctx.needs_input_grad[1],
+                                                    want_extra=extra is not None and ctx.needs_input_grad[2])
+        return None, g_f, g_e, g_h if ctx.needs_input_grad[3] else None, None, None
+
+
 @VOXEL_ENCODERS.register_module()
 class SIRLayer(nn.Module):
     def __init__(self, in_channels=4, feat_channels=[], with_distance=False, with_cluster_center=False,
@@ -208,6 +229,15 @@ class SIRLayer(nn.Module):
         if gathered and (fused is None or len(feats.sources) > 3):
             feats, gathered = feats.materialize(), False
         if fused is None:
+            if (needs_grad and switches.TRAIN_SIR_PRODUCT and self._with_rel_mlp and not gathered and torch.is_tensor(feats)
+                    and feats.is_cuda and feats.dtype == torch.float32 and points.dtype == torch.float32 and feats.dim() == 2
+                    and not points.requires_grad and points.size(1) >= 3 and feats.size(0) > 0
+                    and (extra is None or extra.dtype == torch.float32)):
+                # training: the position MLP stays in autograd; the two concatenations and the product around it are one kernel
+                # each way (K28), bit-identical to the ATen chain of `forward`
+                h = self.rel_mlp(f_cluster / self.rel_dist_scaler)
+                features = _SirProductFn.apply(points, feats, extra, h, tuple(float(v) for v in self.xyz_normalizer), float(extra_div))
+                return self._run_vfe(features, coors, **kwargs)
             parts = [points, feats] + ([extra / extra_div] if extra is not None else [])
             return self.forward(torch.cat(parts, 1), coors, f_cluster, **kwargs)
         layers, eps, act = fused

@@ -31,6 +31,7 @@ SIR_SORTED = _on("FSF_SIR_SORTED")                  # inference: SIR stacks on r
 SIR_GATHER = _on("FSF_SIR_GATHER")                  # first SIR layer reads the point features in place through an index
 FUSED_VOTE = _on("FSF_FUSED_VOTE")                  # vote centres + cluster-voxel keys in one kernel
 CLUSTER_ONE_UNIQUE = _on("FSF_CLUSTER_ONE_UNIQUE")  # a single unique in the cluster assignment
+TRAIN_SIR_PRODUCT = _on("FSF_TRAIN_SIR_PRODUCT")    # training: SIRLayer's concatenations + product with the position MLP as one kernel each way (K28)
 FUSION_ADD_FUSED = _on("FSF_FUSION_ADD_FUSED")      # inference: LiDAR + image point features summed in the epilogue of the update MLP's last Linear
 GROUP_PAIRS = _on("FSF_GROUP_PAIRS")                # inference, one sample: the (group, point) pairs of the grouped sampling as one C-ABI call (K27)
 REFINE_DIRECT = _on("FSF_REFINE_DIRECT")            # inference: the refine head's groups indexed by RoI directly (no unique, no scatter)

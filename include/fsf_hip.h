@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 12
+#define FSF_ABI_VERSION 13
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -603,6 +603,20 @@ int fsf_sir_input_gather(const float* points, int64_t points_stride, int32_t p_c
                          const float* g1, const float* b1, int32_t h1, const float* w2, const float* g2, const float* b2, int32_t h2,
                          const float* w3, const float* g3, const float* b3, float eps, int32_t act, int64_t n, float* out,
                          int64_t out_stride, void* stream);
+
+/* K28 (training)  y = cat([points[:, :3] / xyz_normalizer, points[:, 3:], feats, extra / extra_div], 1) * h  — the input side of
+ * SIRLayer.forward [UNVENDORED; SURVEY App. C] around the position MLP's output h f32 [n, c] (contiguous), c = p_cols + f_cols + e_cols —
+ * and its adjoint: grad_h = grad_out * x (x re-formed from the sources), grad_feats = (grad_out * h)[:, p_cols : p_cols + f_cols],
+ * grad_extra = (grad_out * h)[:, p_cols + f_cols :] / extra_div (either may be NULL; contiguous).  points are not differentiated.
+ * The same IEEE operations per element as the ATen chain they replace (two cats, a product; two products, a zero-filled slice
+ * gradient and its accumulation): bit-identical. */
+int fsf_concat_mul(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3], const float* feats,
+                   int64_t feats_stride, int32_t f_cols, const float* extra, int64_t extra_stride, int32_t e_cols, float extra_div,
+                   const float* h, int64_t n, float* out, void* stream);
+int fsf_concat_mul_backward(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3], const float* feats,
+                            int64_t feats_stride, int32_t f_cols, const float* extra, int64_t extra_stride, int32_t e_cols,
+                            float extra_div, const float* h, const float* grad_out, int64_t n, float* grad_h, float* grad_feats,
+                            float* grad_extra, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K17  dynamic point pooling: (point, RoI) memberships of the enlarged rotated boxes + box-frame geometry

@@ -99,6 +99,38 @@ def test_point_linear_add_equals_linear_plus_addend(plugin, device):
     assert point_linear_add(lin, x, buf[:, :c].contiguous()) is None  # (an addend without the padded rows: the caller's generic path)
 
 
+@pytest.mark.parametrize("n,cp,cf,ce", [(50021, 3, 130, 0), (20000, 5, 175, 0), (7001, 3, 128, 13), (1, 3, 4, 2)])
+def test_sir_product_training_function_equals_the_aten_chain(plugin, device, n, cp, cf, ce):
+    """K28 (`_SirProductFn`: SIRLayer's two concatenations + the product with the position MLP's output, one kernel each way) against
+    the ATen chain of SIRLayer.forward (true divisions) — values and the gradients of feats / extra / h bit for bit."""
+    from fullysparsefusion_amd.mmdet3d_plugin.models.voxel_encoders.voxel_encoder import _SirProductFn
+
+    torch.manual_seed(n)
+    norm, div = (20.0, 20.0, 4.0), 10.0
+    points = torch.randn(n, cp, device=device) * 30
+    feats = torch.randn(n, cf, device=device, requires_grad=True)
+    extra = torch.randn(n, ce, device=device, requires_grad=True) if ce else None
+    c = cp + cf + ce
+    h = torch.randn(n, c, device=device, requires_grad=True)
+    go = torch.randn(n, c, device=device)
+
+    def aten(points, feats, extra, h):
+        # (a DEVICE-tensor divisor: ATen's CUDA kernel turns `t / python_scalar` into a multiplication by the rounded reciprocal, which is
+        # not the division the reference computes on the CPU — K28, like K21, divides)
+        x = torch.cat([points, feats] + ([extra / torch.tensor(div, device=device)] if extra is not None else []), 1)
+        x = torch.cat([x[:, :3] / torch.tensor(norm, device=device)[None, :], x[:, 3:]], dim=1)
+        return x * h
+
+    leaves = [feats, h] + ([extra] if ce else [])
+    want = aten(points, feats, extra, h)
+    want_g = torch.autograd.grad(want, leaves, go)
+    got = _SirProductFn.apply(points, feats, extra, h, norm, div)
+    got_g = torch.autograd.grad(got, leaves, go)
+    assert torch.equal(got, want)
+    for a, b in zip(got_g, want_g):
+        assert torch.equal(a, b)
+
+
 def test_scatter_v2_precomputed_inverse_and_autograd(plugin, device):
     g = golden_cases(load_golden("scatter_v2.npz"))["k4_max"]
     feat = torch.from_numpy(g["feat"]).to(device).requires_grad_(True)
