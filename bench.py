@@ -498,6 +498,13 @@ def _acc_seg_reduce(a, k, out):
     return "seg_reduce", 4.0 * c * n + 8.0 * n + 4.0 * c * plan.m, 0.0       # 4C B/row + 8 B/row + 4C B/segment
 
 
+def _acc_seg_reduce_short(a, k, out):
+    feats, plan = a[0], a[1]
+    n = feats[0].size(0)
+    c = sum(int(f.size(1)) for f in feats)
+    return "seg_reduce", 4.0 * c * n + 8.0 * n + 4.0 * c * plan.m, 0.0      # (the short-segment form: same bytes, up to 8 tensors per launch)
+
+
 def _acc_gather_rows(a, k, out):
     src, idx = a[0], a[1]
     return "gather_rows", idx.numel() * (8.0 + 8.0 * src.size(1)), 0.0         # 8 B index + 4C read + 4C written per row
@@ -592,6 +599,7 @@ def instrumented_pass(model, pool, steps, hot_path_only):
     conv = p.table()
     q = _Probe("capture")
     q.wrap(hip_ops, "segment_reduce", _acc_seg_reduce)
+    q.wrap(hip_ops, "segment_reduce_short", _acc_seg_reduce_short)
     q.wrap(hip_ops, "gather_rows", _acc_gather_rows)
     q.wrap(hip_ops, "voxel2point", _acc_voxel2point)
     q.wrap(hip_ops, "project_gather_mask", _acc_project)
