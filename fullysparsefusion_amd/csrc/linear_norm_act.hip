@@ -27,6 +27,8 @@
 namespace fsf {
 
 typedef __bf16 lna_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lna_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lna_f16x4 __attribute__((ext_vector_type(4)));
 typedef float lna_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lna_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -58,13 +60,19 @@ struct LnaArgs {
   // segment s of the activated output.  seg_out must hold -inf on entry (a segment that reaches beyond one 128-row block is
   // combined with atomic max).  `out` may then be null.
   const int64_t* seg_ids; float* seg_out; int64_t seg_out_stride;
+  // K22h (XP): `x` is the input in PLANE form — [row][k / 8][2][8] f16 hi | lo of x * s_row (rows_to_planes_kernel below; the layout
+  // of fsf_to_planes with ONE power-of-two scale per row) —, x_inv_scale[row] = 1 / s_row, `planes` = f16 hi | lo fragments of
+  // W * s_w behind a 256-byte header whose first float is 1 / s_w.  The product runs as three v_mfma_f32_16x16x32_f16 per
+  // fp32-equivalent one (hi hi + hi lo + lo hi, as K9d), no split in the main loop.
+  const float* x_inv_scale;
 };
 
 // max of two floats into memory, any signs, by integer atomics on the IEEE bit patterns (target initialised to -inf): a value
 // >= 0 orders like a signed int above every negative pattern, a value < 0 orders inversely as an unsigned int below every
 // non-negative pattern's... (min over unsigned: non-negative patterns are the smallest, so a stored non-negative survives).
 __device__ __forceinline__ void lna_atomic_max(float* p, float v) {
-  if (v >= 0.0f) atomicMax(reinterpret_cast<int*>(p), __float_as_int(v));
+  // (the branch is on the SIGN BIT: -0.0f compares >= 0 but its pattern is INT_MIN, which a signed max never stores)
+  if (__float_as_int(v) >= 0) atomicMax(reinterpret_cast<int*>(p), __float_as_int(v));
   else atomicMin(reinterpret_cast<unsigned*>(p), __float_as_uint(v));
 }
 
@@ -142,6 +150,155 @@ __global__ void __launch_bounds__(256)
     dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
     dst[64] = make_uint4(mid[0], mid[1], mid[2], mid[3]);
     dst[128] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
+// ---- K22h: both operands as f16 hi | lo planes --------------------------------------------------------------------------
+// power of two s with s * amax in [2^13, 2^14) and inv = 1 / s (exact; the scheme of K9c / K9d, csrc/spconv_planes.hip):
+// hi = rn_f16(x s), lo = rn_f16(x s - hi): |x s - hi - lo| <= max(2^-22 |x s|, 2^-25), no f16 range hazard for any finite input
+__device__ __forceinline__ void lna_pick_scale(float amax, float& s, float& inv) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  e = amax > 0.0f ? (e < -113 ? -113 : e) : 13;
+  s = __uint_as_float((unsigned)(13 - e + 127) << 23);
+  inv = __uint_as_float((unsigned)(e - 13 + 127) << 23);
+}
+
+__device__ __forceinline__ void lna_split8_f16(const float (&v)[8], float s, lna_u32x4& hi, lna_u32x4& lo) {
+  lna_f16x8 h, l;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float xs = __fmul_rn(v[e], s);
+    h[e] = (_Float16)xs;
+    l[e] = (_Float16)__fsub_rn(xs, (float)h[e]);
+  }
+  hi = __builtin_bit_cast(lna_u32x4, h);
+  lo = __builtin_bit_cast(lna_u32x4, l);
+}
+
+// max |w| over the layer -> hdr[2] (bit pattern; cleared by the caller), one atomic per workgroup
+__global__ void __launch_bounds__(256) lna_weight_absmax_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ hdr) {
+  __shared__ float wave_max[4];
+  float amax = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) amax = fmaxf(amax, fabsf(w[i]));
+  amax = fsf_wave_max(amax);
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(hdr + 2, __float_as_uint(fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]))));
+}
+
+// weight [c, k] fp32 -> header (inverse scale, scale, max |w| bits) + fragment-ordered f16 hi | lo planes of W * s_w
+__global__ void __launch_bounds__(256)
+    lna_prepare_f16_kernel(const float* __restrict__ w, int k, int c, int T, int nkc, int nslice, int slice_w, float* __restrict__ hdr,
+                           uint4* __restrict__ planes) {
+  float s_w, inv_w;
+  lna_pick_scale(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[2]), s_w, inv_w);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = inv_w; hdr[1] = s_w; }
+  const int64_t total = (int64_t)nslice * nkc * T * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    const int t = (int)((idx >> 6) % T);
+    const int kc = (int)(((idx >> 6) / T) % nkc);
+    const int slice = (int)((idx >> 6) / ((int64_t)T * nkc));
+    const int lc = 16 * t + (lane & 15), col = slice_w * slice + lc, k0 = kc * LNA_KC + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (lc < slice_w && col < c && k0 + e < k) ? w[(int64_t)col * k + k0 + e] : 0.0f;
+    lna_u32x4 hi, lo;
+    lna_split8_f16(v, s_w, hi, lo);
+    uint4* dst = planes + (((int64_t)slice * nkc + kc) * T + t) * 2 * 64 + lane;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
+// fp32 rows [n, c] (optionally through LayerNorm + ReLU / GELU first: the norm pass that follows a Linear wider than 128 channels)
+// -> row planes [n][c / 8][2][8] f16 + one inverse scale per row (+ the fp32 rows themselves when `out` is given).  One wave per row;
+// lane l owns the 8-channel blocks l, l + 64, ... (BL of them: c <= 512 BL).
+template <int BL, int NORM, int ACT>
+__global__ void __launch_bounds__(256)
+    rows_to_planes_kernel(const float* __restrict__ x, int64_t n, int c, int64_t x_stride, const float* __restrict__ gamma,
+                          const float* __restrict__ beta, float eps, uint4* __restrict__ planes, float* __restrict__ inv_scales,
+                          float* __restrict__ out, int64_t out_stride) {
+  const int lane = threadIdx.x & 63;
+  const int nb = c >> 3;
+  const float inv_c = 1.0f / (float)c;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += (int64_t)gridDim.x * 4) {
+    float v[BL][8];
+#pragma unroll
+    for (int b = 0; b < BL; ++b) {
+      const int blk = lane + 64 * b;
+      if (blk < nb) {
+        const float4 p = *reinterpret_cast<const float4*>(x + row * x_stride + 8 * blk);
+        const float4 q = *reinterpret_cast<const float4*>(x + row * x_stride + 8 * blk + 4);
+        v[b][0] = p.x; v[b][1] = p.y; v[b][2] = p.z; v[b][3] = p.w; v[b][4] = q.x; v[b][5] = q.y; v[b][6] = q.z; v[b][7] = q.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[b][e] = 0.0f;
+      }
+    }
+    if (NORM == 1) {
+      float s = 0.0f;
+#pragma unroll
+      for (int b = 0; b < BL; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[b][e];
+      const float mean = fsf_wave_sum(s) * inv_c;
+      float q = 0.0f;
+#pragma unroll
+      for (int b = 0; b < BL; ++b)
+        if (lane + 64 * b < nb) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = v[b][e] - mean; q = fmaf(d, d, q); }
+        }
+      const float rstd = rsqrtf(fsf_wave_sum(q) * inv_c + eps);
+#pragma unroll
+      for (int b = 0; b < BL; ++b) {
+        const int blk = lane + 64 * b;
+        if (blk < nb) {
+          const float4 g0 = *reinterpret_cast<const float4*>(gamma + 8 * blk), g1 = *reinterpret_cast<const float4*>(gamma + 8 * blk + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(beta + 8 * blk), b1 = *reinterpret_cast<const float4*>(beta + 8 * blk + 4);
+          const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            lna_f32x2 y = (lna_f32x2{v[b][e], v[b][e + 1]} - lna_pk(mean)) * lna_pk(rstd) * lna_f32x2{gg[e], gg[e + 1]} + lna_f32x2{bb[e], bb[e + 1]};
+            y = lna_act2(y, ACT);
+            v[b][e] = y.x; v[b][e + 1] = y.y;
+          }
+        }
+      }
+    } else if (ACT != 0) {
+#pragma unroll
+      for (int b = 0; b < BL; ++b)
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const lna_f32x2 y = lna_act2(lna_f32x2{v[b][e], v[b][e + 1]}, ACT);
+          v[b][e] = y.x; v[b][e + 1] = y.y;
+        }
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int b = 0; b < BL; ++b)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[b][e]));
+    amax = fsf_wave_max(amax);
+    float s_row, inv_row;
+    lna_pick_scale(amax, s_row, inv_row);
+    if (lane == 0) inv_scales[row] = inv_row;
+#pragma unroll
+    for (int b = 0; b < BL; ++b) {
+      const int blk = lane + 64 * b;
+      if (blk < nb) {
+        lna_u32x4 hi, lo;
+        lna_split8_f16(v[b], s_row, hi, lo);
+        uint4* dst = planes + (row * nb + blk) * 2;
+        dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        dst[1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        if (out) {
+          *reinterpret_cast<float4*>(out + row * out_stride + 8 * blk) = make_float4(v[b][0], v[b][1], v[b][2], v[b][3]);
+          *reinterpret_cast<float4*>(out + row * out_stride + 8 * blk + 4) = make_float4(v[b][4], v[b][5], v[b][6], v[b][7]);
+        }
+      }
+    }
   }
 }
 
@@ -390,12 +547,13 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
 // once per 384 rows.  Measured (round 3, same box): no faster in isolation (510 k x 256 -> 128: 277 vs 279 us; k = 128 .. 180: 5-15 %
 // SLOWER — a barrier over twelve waves per chunk) and 7 % slower in the frame (a 768-thread workgroup shuts the other stream's kernels
 // out of its CU) — so the weight stream is not what this kernel waits for.  Kept behind FSF_K22_WIDE_MIN_ROWS=<rows> (default: never).
-template <int T, int NW, bool SEG = false, int NORM_CT = -1, int ACT_CT = -1>  // 16-channel tiles (c <= 16 T); SEG: + segmented max of the
-// output (rows sorted by segment), norm / act fixed at compile time
+template <int T, int NW, bool SEG = false, int NORM_CT = -1, int ACT_CT = -1, bool XP = false>  // 16-channel tiles (c <= 16 T); SEG: +
+// segmented max of the output (rows sorted by segment), norm / act fixed at compile time; XP: x and W arrive as f16 hi | lo planes (K22h)
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WPS) : 3) linear_norm_act_kernel(LnaArgs a) {
   constexpr int LNA_NW = NW;
   constexpr int LNA_ROWS = NW * LNA_RG * 16;
-  constexpr int CHUNK_U4 = T * 3 * 64;  // uint4 per weight chunk
+  constexpr int NPL = XP ? 2 : 3;             // weight planes per tile
+  constexpr int CHUNK_U4 = T * NPL * 64;      // uint4 per weight chunk
   static_assert(!SEG || (NW == 4 && CHUNK_U4 * 16 >= 16 * 128 * 4), "the segmented max parks 16 x 128 floats in a weight buffer");
   extern __shared__ __attribute__((aligned(16))) char lna_smem[];
   uint4* wbuf = reinterpret_cast<uint4*>(lna_smem);  // [2][CHUNK_U4], then 384 floats of per-channel vectors (, then LnaSegSmem)
@@ -407,8 +565,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
   const int64_t nblk = (a.n + LNA_ROWS - 1) / LNA_ROWS;
   // more than 128 output channels: gridDim.y slices of 128, each an independent [rows, 128] product (no LayerNorm then:
   // its statistics span the slices; the caller runs fsf_norm_act on the result)
-  const int ch_base = a.slice_w * (int)blockIdx.y;
-  const uint4* planes = a.planes + (int64_t)blockIdx.y * nkc * CHUNK_U4;
+  // XP launches come as a 1-D grid laid out so that the workgroups that share a row block (one per 128-channel slice) have the same
+  // id modulo 8, i.e. land on the same XCD and meet their x rows in its L2: id = xcd + 8 (slice + nslice j), row-block lane 8 j + xcd
+  int slice_id = (int)blockIdx.y;
+  int64_t blk_first_ = blockIdx.x, blk_step_ = gridDim.x;
+  if constexpr (XP) {
+    const int nslice = (a.c + a.slice_w - 1) / a.slice_w;
+    const int wg = (int)blockIdx.x, q = wg >> 3;
+    slice_id = q % nslice;
+    blk_first_ = (int64_t)(q / nslice) * 8 + (wg & 7);
+    blk_step_ = gridDim.x / nslice;
+  }
+  const int ch_base = a.slice_w * slice_id;
+  const uint4* planes = a.planes + (XP ? 16 : 0) + (int64_t)slice_id * nkc * CHUNK_U4;  // (XP: behind the 256-byte header)
 
   // weight chunk kc -> LDS buffer by LDS-DMA: fragment order in HBM == fragment order in LDS, 1 KB per wave instruction
   auto stage_w = [&](int kc, int buf) {
@@ -433,17 +602,25 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
 #ifdef FSF_ABL_LNA_X_HOT  // ablation: every x load hits one of 4096 cache-resident rows
       r &= 4095;
 #endif
-      xrow[rg] = a.x + r * a.x_stride + (int64_t)blockIdx.y * a.x_slice_off;
+      if constexpr (XP) xrow[rg] = a.x + r * (int64_t)a.k;  // (plane rows: k / 8 blocks x 2 planes x 16 B = 4 k bytes, like fp32 rows)
+      else xrow[rg] = a.x + r * a.x_stride + (int64_t)slice_id * a.x_slice_off;
     }
   };
   // raw x of one chunk: [row group][8 floats]; the NEXT chunk is requested while this one is split and multiplied.
   // Always exactly two 16-byte loads per row group: offsets past the row are clamped into it (x_stride is a multiple
   // of 4 and >= k, so a quad that holds any column < k is never clamped) and the columns >= k are zeroed afterwards
   // (what follows the row in memory may be NaN).
-  const int last_quad = (int)a.x_stride - 4 - (int)((int64_t)blockIdx.y * a.x_slice_off);  // (relative to this slice's first column)
+  const int last_quad = XP ? 0 : (int)a.x_stride - 4 - (int)((int64_t)slice_id * a.x_slice_off);  // (relative to this slice's first column)
   auto load_x = [&](int kc, float (&v)[LNA_RG][8]) {
 #pragma unroll
     for (int rg = 0; rg < LNA_RG; ++rg) {
+      if constexpr (XP) {  // k block 4 kc + grp of the row: hi plane | lo plane, 32 contiguous bytes (k is a multiple of 32 here)
+        const float4* pb = reinterpret_cast<const float4*>(xrow[rg]) + 2 * (4 * kc + grp);
+        const float4 p = pb[0], q = pb[1];
+        v[rg][0] = p.x; v[rg][1] = p.y; v[rg][2] = p.z; v[rg][3] = p.w;
+        v[rg][4] = q.x; v[rg][5] = q.y; v[rg][6] = q.z; v[rg][7] = q.w;
+        continue;
+      }
       const int kq = kc * LNA_KC + 8 * grp;  // this lane's 8 k values
       const float4 p = *reinterpret_cast<const float4*>(xrow[rg] + min(kq, last_quad));
       const float4 q = *reinterpret_cast<const float4*>(xrow[rg] + min(kq + 4, last_quad));
@@ -453,9 +630,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
   };
   // row blocks of this workgroup: strided over the grid, or (SEG) one contiguous range, so that a segment's rows meet in one
   // workgroup wherever they can
-  const int64_t blk_first = blockIdx.x;
+  const int64_t blk_first = blk_first_;
 #define LNA_BLK_END nblk
-#define LNA_BLK_STEP gridDim.x
+#define LNA_BLK_STEP blk_step_
   lna_stage_vectors(a, ch_base, vec);
   float xc[LNA_RG][8];
   int buf = 0;
@@ -481,8 +658,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
     for (int rg = 0; rg < LNA_RG; ++rg)
 #pragma unroll
       for (int t = 0; t < T; ++t) acc[rg][t] = lna_f32x4{0.f, 0.f, 0.f, 0.f};
+    float xinv[LNA_RG];
+    if constexpr (XP) {  // the rows' inverse scales (requested here, used after the chunk loop)
+#pragma unroll
+      for (int rg = 0; rg < LNA_RG; ++rg) {
+        const int64_t r = row0 + 16 * rg + rowl;
+        xinv[rg] = a.x_inv_scale[r < a.n ? r : a.n - 1];
+      }
+    }
 #ifdef FSF_ABL_LNA_NO_XBLK  // ablation: every row block starts with an exposed load (the kernel before the cross-block pipeline)
-    if (blk != (int64_t)blockIdx.x) {
+    if (blk != blk_first) {
       set_rows(blk);
       load_x(0, xc);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -494,6 +679,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
     for (int kc = 0; kc < nkc; ++kc, buf ^= 1) {
       // split the chunk that arrived while the previous one was multiplied; its registers then take the next prefetch
       lna_u32x4 xh[LNA_RG], xm[LNA_RG], xl[LNA_RG];
+      if constexpr (XP) {  // the planes ARE the operands: nothing to split
+#pragma unroll
+        for (int rg = 0; rg < LNA_RG; ++rg) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xh[rg][e] = __float_as_uint(xc[rg][e]); xl[rg][e] = __float_as_uint(xc[rg][4 + e]); }
+          xm[rg] = xh[rg];
+        }
+      } else
       if ((kc + 1) * LNA_KC > a.k) {  // (uniform: the last chunk of a k that is not a multiple of 32)
 #pragma unroll
         for (int rg = 0; rg < LNA_RG; ++rg)
@@ -501,8 +694,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
           for (int e = 0; e < 8; ++e)
             if (kc * LNA_KC + 8 * grp + e >= a.k) xc[rg][e] = 0.0f;
       }
+      if constexpr (!XP) {
 #pragma unroll
-      for (int rg = 0; rg < LNA_RG; ++rg) lna_split8(xc[rg], xh[rg], xm[rg], xl[rg]);
+        for (int rg = 0; rg < LNA_RG; ++rg) lna_split8(xc[rg], xh[rg], xm[rg], xl[rg]);
+      }
       // this chunk's weights (DMA issued one iteration ago, before that iteration's MFMAs) have landed; the raw barrier
       // carries no fence, so nothing else is drained with them
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -522,6 +717,31 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
       const uint4* wc = wbuf + buf * CHUNK_U4;
       // Two channel tiles x LNA_RG row groups = 4 independent accumulators per product term: consecutive MFMAs never hit
       // the same accumulator
+      if constexpr (XP) {
+#pragma unroll
+        for (int t = 0; t < T; t += 2) {
+          lna_f16x8 wfr[2][2];
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const uint4* wf = wc + ((t + tt) * 2) * 64 + lane;
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wfr[tt][pl] = __builtin_bit_cast(lna_f16x8, wf[64 * pl]);
+          }
+          // (weight plane, x plane): lo hi, hi lo, hi hi — small terms first
+          constexpr int TERM_W[3] = {1, 0, 0};
+          constexpr int TERM_X[3] = {0, 1, 0};
+#pragma unroll
+          for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+              for (int rg = 0; rg < LNA_RG; ++rg) {
+                const lna_u32x4 xb = TERM_X[term] == 0 ? xh[rg] : xl[rg];
+                acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfr[tt][TERM_W[term]], __builtin_bit_cast(lna_f16x8, xb),
+                                                                         acc[rg][t + tt], 0, 0, 0);
+              }
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < T; t += 2) {
         lna_bf16x8 wfr[2][3];
@@ -548,6 +768,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
               acc[rg][t + tt][term & 3] += __uint_as_float(xb[term & 3] ^ __builtin_bit_cast(lna_u32x4, wfr[tt][TERM_W[term]])[term & 3]);
 #endif
             }
+      }
+      }
+    }
+    if constexpr (XP) {  // back to the unscaled product: both scales are powers of two (exact)
+      const float w_inv = *reinterpret_cast<const float*>(a.planes);
+#pragma unroll
+      for (int rg = 0; rg < LNA_RG; ++rg) {
+        const float sc = xinv[rg] * w_inv;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[rg][t] = acc[rg][t] * sc;
       }
     }
     if constexpr (SEG) {  // (`buf` was flipped by the loop: the chunk loop's last buffer, free now, is buf ^ 1)
@@ -615,13 +845,23 @@ extern "C" int fsf_linear_prepare_weight_sliced(const float* weight, int32_t k, 
   return FSF_OK;
 }
 
-static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream) {
+static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream, bool xp = false) {
   LnaArgs a = a_in;
   const int T = lna_tiles(a.slice_w < a.c ? a.slice_w : a.c);
   const int rows = LNA_NW * LNA_RG * 16;
   const int64_t nblk = (a.n + rows - 1) / rows;
   int64_t gx = (256 * (a.seg_out ? LNA_SEG_WPS : LNA_WPS) + nslice - 1) / nslice;
   if (gx > nblk) gx = nblk;
+  if (xp) {  // K22h: 1-D grid, `gx` row-block lanes (a multiple of 8: one XCD per lane) x nslice workgroups each
+    if (T != 8 || a.seg_out) return FSF_ERR_UNSUPPORTED;
+    gx = (gx + 7) / 8 * 8;
+    constexpr size_t smem = (size_t)2 * 8 * 2 * 64 * 16 + 384 * 4;
+    static std::atomic<uint64_t> attr_done{0};
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<8, 4, false, -1, -1, true>, (int)smem, attr_done));
+    hipLaunchKernelGGL((linear_norm_act_kernel<8, 4, false, -1, -1, true>), dim3((unsigned)(gx * nslice)), dim3(256), smem, stream, a);
+    FSF_LAUNCH_CHECK();
+    return FSF_OK;
+  }
   const dim3 grid((unsigned)gx, (unsigned)nslice);
 #define FSF_LNA(T_, NW_, SEG_, NORM_, ACT_)                                                                                          \
   do {                                                                                                                              \
@@ -659,7 +899,7 @@ extern "C" int fsf_linear_norm_act_sliced(const float* x, int64_t n, int32_t k, 
   if (x_stride < (int64_t)(nslice - 1) * x_slice_offset + k || out_stride < (int64_t)nslice * slice_c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n,
-            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset, nullptr, nullptr, 0};
+            (int)(nslice * slice_c), nullptr, nullptr, 0, (int)slice_c, (int)slice_c, x_slice_offset, nullptr, nullptr, 0, nullptr};
   return lna_launch(a, nslice, stream);
 }
 
@@ -692,7 +932,7 @@ extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k,
   if (x_stride < k || out_stride < c) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
-            row_add, row_add_index, row_add_stride, 128, (int)c, 0, nullptr, nullptr, 0};
+            row_add, row_add_index, row_add_stride, 128, (int)c, 0, nullptr, nullptr, 0, nullptr};
   return lna_launch(a, lna_slices(c), stream);
 }
 
@@ -716,6 +956,83 @@ extern "C" int fsf_linear_norm_act_segmax(const float* x, int64_t n, int32_t k, 
   if (x_stride < k || (out && out_stride < c)) return FSF_ERR_INVALID_ARG;
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
-            row_add, row_add_index, row_add_stride, 128, (int)c, 0, seg_ids, seg_out, seg_out_stride};
+            row_add, row_add_index, row_add_stride, 128, (int)c, 0, seg_ids, seg_out, seg_out_stride, nullptr};
   return lna_launch(a, 1, stream);
+}
+
+// ---- K22h entry points ---------------------------------------------------------------------------------------------------
+extern "C" int64_t fsf_linear_prepared_weight_f16_bytes(int32_t k, int32_t c, int32_t slice_c) {
+  if (k < 1 || c < 1 || slice_c < 1 || slice_c > 128) return 0;
+  const int64_t nkc = (k + LNA_KC - 1) / LNA_KC, nslice = (c + slice_c - 1) / slice_c;
+  return 256 + nslice * nkc * lna_tiles(slice_c) * 2 * 64 * 16;
+}
+
+extern "C" int fsf_linear_prepare_weight_f16(const float* weight, int32_t k, int32_t c, int32_t slice_c, void* planes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!weight || !planes || k < 1 || c < 1 || slice_c < 1 || slice_c > 128) return FSF_ERR_INVALID_ARG;
+  if (((uintptr_t)planes % 16) != 0) return FSF_ERR_UNSUPPORTED;
+  const int T = lna_tiles(slice_c), nkc = (k + LNA_KC - 1) / LNA_KC, nslice = (c + slice_c - 1) / slice_c;
+  FSF_HIP_TRY(hipMemsetAsync(planes, 0, 256, stream));
+  const int64_t nw = (int64_t)c * k;
+  hipLaunchKernelGGL(lna_weight_absmax_kernel, dim3(fsf_stream_grid(nw, 256)), dim3(256), 0, stream, weight, nw, (unsigned*)planes);
+  FSF_LAUNCH_CHECK();
+  const int64_t total = (int64_t)nslice * nkc * T * 64;
+  hipLaunchKernelGGL(lna_prepare_f16_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k, (int)c, T, nkc,
+                     nslice, (int)slice_c, (float*)planes, (uint4*)planes + 16);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int64_t fsf_row_planes_bytes(int64_t n, int32_t c) { return (n < 0 || c < 8 || (c % 8) != 0) ? 0 : n * (int64_t)c * 4; }
+
+extern "C" int fsf_rows_to_planes(const float* x, int64_t n, int32_t c, int64_t x_stride, int32_t norm, const float* gamma,
+                                  const float* beta, float eps, int32_t act, void* planes, float* inv_scales, float* out,
+                                  int64_t out_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || c < 8 || norm < 0 || norm > 1 || act < 0 || act > 2 || (norm == 1 && (!gamma || !beta)) ||
+      (n > 0 && (!x || !planes || !inv_scales)))
+    return FSF_ERR_INVALID_ARG;
+  if ((c % 8) != 0 || c > 2048 || (x_stride % 4) != 0 || x_stride < c || ((uintptr_t)x % 16) != 0 || ((uintptr_t)planes % 16) != 0 ||
+      (out && ((out_stride % 4) != 0 || out_stride < c || ((uintptr_t)out % 16) != 0)) ||
+      (norm == 1 && (((uintptr_t)gamma % 16) != 0 || ((uintptr_t)beta % 16) != 0)))
+    return FSF_ERR_UNSUPPORTED;
+  if (n == 0) return FSF_OK;
+  const int bl = (c / 8 + 63) / 64;  // 8-channel blocks per lane
+  int64_t g = (n + 3) / 4;
+  if (g > 16384) g = 16384;
+#define FSF_R2P(BL_, N_, A_)                                                                                                     \
+  hipLaunchKernelGGL((rows_to_planes_kernel<BL_, N_, A_>), dim3((unsigned)g), dim3(256), 0, stream, x, n, (int)c, x_stride, gamma, \
+                     beta, eps, (uint4*)planes, inv_scales, out, out_stride)
+#define FSF_R2P_ACT(BL_, N_)                      \
+  do {                                            \
+    if (act == 0) FSF_R2P(BL_, N_, 0);            \
+    else if (act == 1) FSF_R2P(BL_, N_, 1);       \
+    else FSF_R2P(BL_, N_, 2);                     \
+  } while (0)
+  if (bl <= 1) { if (norm) FSF_R2P_ACT(1, 1); else FSF_R2P_ACT(1, 0); }
+  else if (bl <= 2) { if (norm) FSF_R2P_ACT(2, 1); else FSF_R2P_ACT(2, 0); }
+  else { if (norm) FSF_R2P_ACT(4, 1); else FSF_R2P_ACT(4, 0); }
+#undef FSF_R2P_ACT
+#undef FSF_R2P
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_linear_planes_norm_act(const void* x_planes, const float* x_inv_scales, int64_t n, int32_t k, const void* w_planes,
+                                          int32_t c, int32_t slice_c, const float* bias, int32_t norm, const float* gamma,
+                                          const float* beta, float eps, int32_t act, float* out, int64_t out_stride, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || k < 1 || c < 1 || slice_c < 1 || !w_planes || norm < 0 || norm > 2 || act < 0 || act > 2 ||
+      (norm != 0 && (!gamma || !beta)) || (n > 0 && (!x_planes || !x_inv_scales || !out)))
+    return FSF_ERR_INVALID_ARG;
+  // whole 32-k chunks; 128-channel tiles (slice_c in 68..128 so that the launched variant is the 8-tile one); a LayerNorm spans ONE slice
+  if ((k % 32) != 0 || slice_c > 128 || slice_c <= 64 || (slice_c % 4) != 0 || (c % 4) != 0 || (out_stride % 4) != 0 ||
+      ((uintptr_t)x_planes % 16) != 0 || ((uintptr_t)w_planes % 16) != 0 || ((uintptr_t)out % 16) != 0)
+    return FSF_ERR_UNSUPPORTED;
+  if (out_stride < c) return FSF_ERR_INVALID_ARG;
+  if (n == 0) return FSF_OK;
+  const int nslice = (c + slice_c - 1) / slice_c;
+  LnaArgs a{(const float*)x_planes, (int64_t)k, (int)k, (const uint4*)w_planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n,
+            (int)c, nullptr, nullptr, 0, (int)slice_c, (int)slice_c, 0, nullptr, nullptr, 0, x_inv_scales};
+  return lna_launch(a, nslice, stream, true);
 }

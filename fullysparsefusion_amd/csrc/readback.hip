@@ -6,8 +6,14 @@
 // host thread spins on the sequence number (acquire): 10.3 us per iteration in the same probe.  One mailbox per (host thread, device):
 // the two query branches run on two host threads.  A stream that goes idle without the post (a failed launch) ends the spin with
 // FSF_ERR_HIP; FSF_READBACK_MAILBOX=0 (A/B switch, latched) or more than 120 bytes take the copy + synchronize route.
+// Mailboxes outlive their threads: a thread that exits hands its mailboxes (with their sequence counters) to a process-wide free list
+// and the next new thread takes them from there, so a host that starts a worker thread per frame pins one mailbox per CONCURRENT
+// thread and device, not one per frame (no HIP call runs in a thread-exit destructor: the list is handed back, never freed).
 #include <stdlib.h>
 #include <string.h>
+
+#include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -26,7 +32,26 @@ struct MailboxSlot {
   bool failed;
 };
 constexpr int RB_MAX_DEVICES = 16;
-static thread_local MailboxSlot t_slots[RB_MAX_DEVICES];
+
+struct MailboxPool {
+  std::mutex mu;
+  std::vector<MailboxSlot> idle[RB_MAX_DEVICES];
+};
+static MailboxPool& rb_pool() {
+  static MailboxPool* p = new MailboxPool;  // (never destroyed: thread-exit destructors may run after static destruction began)
+  return *p;
+}
+
+struct ThreadSlots {
+  MailboxSlot s[RB_MAX_DEVICES] = {};
+  ~ThreadSlots() {
+    MailboxPool& p = rb_pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    for (int d = 0; d < RB_MAX_DEVICES; ++d)
+      if (s[d].host) p.idle[d].push_back(s[d]);
+  }
+};
+static thread_local ThreadSlots t_slots;
 
 __global__ void __launch_bounds__(64) rb_post_kernel(Mailbox* mb, uint64_t seq, const uint32_t* __restrict__ src, int words) {
   if ((int)threadIdx.x < words) mb->v[threadIdx.x] = src[threadIdx.x];
@@ -45,7 +70,15 @@ int fsf_read_back(void* host_dst, const void* dev_src, size_t bytes, hipStream_t
   MailboxSlot* s = nullptr;
   if (rb_mailbox_enabled() && bytes > 0 && bytes <= sizeof(((Mailbox*)0)->v) && (bytes % 4) == 0 && ((uintptr_t)dev_src % 4) == 0 &&
       hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < RB_MAX_DEVICES) {
-    s = &t_slots[dev];
+    s = &t_slots.s[dev];
+    if (!s->host && !s->failed) {
+      MailboxPool& p = rb_pool();
+      std::lock_guard<std::mutex> g(p.mu);
+      if (!p.idle[dev].empty()) {  // a mailbox an exited thread left behind (its sequence counter continues)
+        *s = p.idle[dev].back();
+        p.idle[dev].pop_back();
+      }
+    }
     if (!s->host && !s->failed) {
       void* h = nullptr;
       void* d = nullptr;

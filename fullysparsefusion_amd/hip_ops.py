@@ -120,6 +120,11 @@ _ARGTYPES = {
     "fsf_remap_indices": [_P, c_i64, _P, _P, _P],
     "fsf_set_option": [c_i32, c_i64],
     "fsf_get_option": [c_i32],
+    "fsf_row_planes_bytes": [c_i64, c_i32],
+    "fsf_rows_to_planes": [_P, c_i64, c_i32, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, c_i64, _P],
+    "fsf_linear_prepared_weight_f16_bytes": [c_i32, c_i32, c_i32],
+    "fsf_linear_prepare_weight_f16": [_P, c_i32, c_i32, c_i32, _P, _P],
+    "fsf_linear_planes_norm_act": [_P, _P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
 }
 _configured = False
 
@@ -540,6 +545,8 @@ def group_pairs(score: torch.Tensor, thresh: torch.Tensor, keep_one=True, group_
                             ptr(buf[1]), cap, ctypes.cast(ctypes.pointer(count), c_p), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_group_pairs")
     k = int(count.value)
+    if 2 * k < cap:  # the upper-bound buffer would stay alive behind two short views (~56 MB at 5e5 points x 7 groups): copy them out
+        return buf[0, :k].clone(), buf[1, :k].clone()
     return buf[0, :k], buf[1, :k]
 
 
@@ -1046,6 +1053,69 @@ def linear_norm_act_sliced(x: torch.Tensor, k: int, x_slice_offset: int, planes:
                                           int(nslice), int(slice_c), ptr(bias), norm_code, ptr(gamma), ptr(beta), float(eps),
                                           act_code, c_p(out.data_ptr()) if n else c_p(None), os_, stream_ptr()),
           "fsf_linear_norm_act_sliced")
+    return out
+
+
+class RowPlanes:
+    """A matrix f32 [n, c] as K22h's operand: `data` u8 [n * c * 4] = [n][c / 8][2][8] f16 hi | lo of the row-scaled values,
+    `inv_scales` f32 [n] (fsf_rows_to_planes)."""
+
+    __slots__ = ("data", "inv_scales", "n", "c")
+
+    def __init__(self, data, inv_scales, n, c):
+        self.data, self.inv_scales, self.n, self.c = data, inv_scales, int(n), int(c)
+
+
+def rows_to_planes_supported(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) % 8 == 0 and 8 <= x.size(1) <= 2048
+            and x.stride(1) == 1 and (x.size(0) <= 1 or x.stride(0) % 4 == 0) and x.data_ptr() % 16 == 0)
+
+
+def rows_to_planes(x: torch.Tensor, norm: str = "none", gamma=None, beta=None, eps: float = 0.0, act: str = "none", want_rows=False):
+    """fsf_rows_to_planes: act(LayerNorm(x)) (or x itself) -> RowPlanes (+ the fp32 rows with `want_rows`)."""
+    require_cuda(x, gamma, beta)
+    assert rows_to_planes_supported(x)
+    n, c = x.shape
+    h = _L()
+    data = torch.empty(max(int(h.fsf_row_planes_bytes(n, c)), 16), dtype=torch.uint8, device=x.device)
+    inv = torch.empty((max(n, 1),), dtype=torch.float32, device=x.device)
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device) if want_rows else None
+    xs = x.stride(0) if n > 1 else c
+    check(h.fsf_rows_to_planes(c_p(x.data_ptr()) if n else c_p(None), n, c, xs, {"none": 0, "ln": 1}[norm], ptr(gamma), ptr(beta),
+                               float(eps), {"none": 0, "relu": 1, "gelu": 2}[act], ptr(data), ptr(inv), ptr(out), c, stream_ptr()),
+          "fsf_rows_to_planes")
+    rp = RowPlanes(data, inv, n, c)
+    return (rp, out) if want_rows else rp
+
+
+def linear_prepare_weight_f16(weight: torch.Tensor, slice_c: int = 128):
+    """fsf_linear_prepare_weight_f16: Linear weight f32 [c, k] -> header + f16 hi | lo fragment planes (K22h)."""
+    require_cuda(weight)
+    weight = weight.detach().contiguous()
+    c, k = weight.shape
+    h = _L()
+    planes = torch.empty(h.fsf_linear_prepared_weight_f16_bytes(k, c, slice_c), dtype=torch.uint8, device=weight.device)
+    check(h.fsf_linear_prepare_weight_f16(ptr(weight), k, c, int(slice_c), ptr(planes), stream_ptr()), "fsf_linear_prepare_weight_f16")
+    return planes
+
+
+def linear_planes_supported(k: int, c: int, slice_c: int = 128) -> bool:
+    return k % 32 == 0 and c % 4 == 0 and 64 < slice_c <= 128 and slice_c % 4 == 0
+
+
+def linear_planes_norm_act(xp: RowPlanes, wplanes: torch.Tensor, out_features: int, slice_c: int = 128, bias=None, norm: str = "none",
+                           gamma=None, beta=None, eps: float = 0.0, act: str = "none", out=None):
+    """fsf_linear_planes_norm_act (K22h): act(norm(x W^T + bias)) -> f32 [n, c] from x in plane form and f16-prepared weights."""
+    require_cuda(xp.data, wplanes, bias, gamma, beta, out)
+    n, k, c = xp.n, xp.c, int(out_features)
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=xp.data.device)
+    assert out.shape == (n, c) and out.dtype == torch.float32 and out.stride(1) == 1
+    os_ = out.stride(0) if n > 1 else (c + 3) // 4 * 4
+    check(_L().fsf_linear_planes_norm_act(ptr(xp.data), ptr(xp.inv_scales), n, k, ptr(wplanes), c, int(slice_c), ptr(bias),
+                                          {"none": 0, "ln": 1, "affine": 2}[norm], ptr(gamma), ptr(beta), float(eps),
+                                          {"none": 0, "relu": 1, "gelu": 2}[act], c_p(out.data_ptr()) if n else c_p(None), os_,
+                                          stream_ptr()), "fsf_linear_planes_norm_act")
     return out
 
 

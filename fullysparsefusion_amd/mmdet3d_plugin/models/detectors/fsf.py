@@ -32,6 +32,19 @@ from ...registry import BBOX_CODERS, DETECTORS, build_head, build_roi_extractor
 from .single_stage_fsd import SingleStageFSD
 
 
+_CAMERA_WORKER = None
+
+
+def _camera_worker():
+    """The process's camera-query worker: a single persistent host thread (frames of one process run one after the other)."""
+    global _CAMERA_WORKER
+    if _CAMERA_WORKER is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _CAMERA_WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="fsf-camera-queries")
+    return _CAMERA_WORKER
+
+
 @DETECTORS.register_module()
 class FSF(SingleStageFSD):
     def __init__(self, backbone, segmentor, voxel_layer=None, voxel_encoder=None, middle_encoder=None, neck=None,
@@ -468,8 +481,6 @@ class FSF(SingleStageFSD):
         on_gpu = torch.cuda.is_available() and next(self.parameters()).is_cuda
         if self.training or not on_gpu or not (self.test_cfg or {}).get("concurrent_query_branches", True):
             return camera_branch(), lidar_branch()
-        import threading
-
         main = torch.cuda.current_stream()
         if getattr(self, "_side_stream", None) is None:
             self._side_stream = torch.cuda.Stream()
@@ -484,13 +495,16 @@ class FSF(SingleStageFSD):
                     box["out"] = camera_branch()
             except BaseException as e:  # re-raised on the calling thread
                 box["err"] = e
+            finally:
+                clear_unique_cache()  # (thread-local, and this thread lives on: nothing of the frame may stay behind in it)
 
-        th = threading.Thread(target=worker, name="fsf-camera-queries")
-        th.start()
+        # ONE worker thread for the life of the process (not one per frame): its thread-local state — the read-back mailbox in mapped
+        # pinned memory (csrc/readback.hip), torch's per-thread stream and grad mode, the per-thread workspaces — is set up once
+        fut = _camera_worker().submit(worker)
         try:
             lidar_out = lidar_branch()
         finally:
-            th.join()
+            fut.result()
         if "err" in box:
             raise box["err"]
         main.wait_stream(side)
@@ -633,5 +647,56 @@ class FSF(SingleStageFSD):
             raise NotImplementedError("test-time augmentation is outside the hot path")
         return self.simple_test(points[0], img_metas[0], mask_data[0], mask_anno[0], **kwargs)
 
-    def forward_train(self, *args, **kwargs):
-        raise NotImplementedError("training path (targets, assigners, losses) is outside this round's hot path")
+    def multi_stage_refine_graph(self, obj_centers, obj_coors, obj_result, points, point_infos, pts_feat, batch_idx, mask_data,
+                                 mask_anno, img_metas, res_query_feat):
+        """`multi_stage_refine_train` (:905-959) without the per-stage `frustum_refined_head[i].loss(...)`: every stage's RoIs are
+        the boxes decoded from the previous stage's regression output (`decode_stage_bboxes`, no assigner in between — upstream has
+        none either), points pooled per RoI, the stage's refine SIR layers, `lidar_img_mlp` / `position_encoder` / `out_proj`, the
+        refined head.  Returns [(obj_centers, obj_result, query_feat)] per stage."""
+        stages = []
+        for i_stage in range(self.num_extra_stages):
+            obj_centers, obj_result, res_query_feat = self.each_stage_refine(
+                i_stage, obj_centers, obj_coors, obj_result, points, point_infos, pts_feat, batch_idx, mask_data, mask_anno,
+                img_metas, res_query_feat)
+            stages.append((obj_centers, obj_result, res_query_feat))
+        return stages
+
+    def forward_train_graph(self, points, img_metas, mask_data, mask_anno):
+        """The differentiable graph of `forward_train` (:806-903) — segmentor + image fusion + segmentation head, camera queries
+        WITH `frustum_obj_head`, LiDAR queries WITH `bbox_head`, `combine_frustum_and_fsd` (both `combine_*_mlp`), and
+        `multi_stage_refine_train` (:905-959: RoI point pooling, `refine_sir_layers`, `lidar_img_mlp`, `position_encoder`,
+        `out_proj`, `frustum_refined_head`) — up to the tensors the losses would consume.  Target assignment and the losses themselves
+        (`*.loss(...)`: host-side label bookkeeping) are out of scope; the caller supplies a scalar of these
+        outputs (bench.py::dummy_loss: their sum, SURVEY §8(d) config 3)."""
+        self._gather_cache = None
+        self._fg_cache = None
+        if self.voxel_downsampling_size is not None:
+            points = self.segmentor.voxel_downsample(points)
+        points, point_infos = self.split_points_last_3dim(points)
+        seg_out_tuple = self.segmentor.simple_test(points, img_metas, extract_feat_only=True, rescale=False)
+        seg_out_dict = self.segmentor_feat_inhance_test(seg_out_tuple, point_infos, mask_anno, mask_data, img_metas)
+        f_feats, f_centers, f_coors, f_result, f_preds_2d = self.frustum_forward(seg_out_dict, mask_anno, mask_data, point_infos,
+                                                                                  img_metas, cluster_center=None)
+        l_feats, l_centers, l_coors, l_result = self.fsd_forward(seg_out_dict, img_metas)
+        out = dict(seg=seg_out_dict, frustum_obj_feats=f_feats, frustum_obj_centers=f_centers, frustum_obj_coors=f_coors,
+                   frustum_preds_2d=f_preds_2d, frustum_obj_result=f_result, fsd_obj_feats=l_feats, fsd_obj_centers=l_centers,
+                   fsd_obj_coors=l_coors, fsd_obj_result=l_result, stage_results=[])
+        obj_centers, obj_coors, obj_result, obj_feats, preds_2d = self.combine_frustum_and_fsd(
+            f_centers, f_coors, f_result, f_feats, f_preds_2d, l_centers, l_coors, l_result, l_feats)
+        out.update(obj_centers=obj_centers, obj_coors=obj_coors, obj_feats=obj_feats, preds_2d=preds_2d)
+        if self.num_extra_stages > 0:
+            stages = self.multi_stage_refine_graph(obj_centers, obj_coors, obj_result, seg_out_dict["seg_points"], point_infos,
+                                                   seg_out_dict["seg_feats"], seg_out_dict["batch_idx"], mask_data, mask_anno,
+                                                   img_metas, obj_feats)
+            out["stage_results"] = [s[1] for s in stages]
+            out["stage_centers"] = [s[0] for s in stages]
+        self._gather_cache = None
+        clear_unique_cache()
+        return out
+
+    def forward_train(self, points, img_metas, *args, mask_data=None, mask_anno=None, **kwargs):
+        """`forward_train` (:806-903): the graph is `forward_train_graph`; the `.loss(...)` calls that close it upstream (label
+        assignment on the host, focal / L1 losses) are outside the built path and the heads' `loss` says so."""
+        out = self.forward_train_graph(points, img_metas, mask_data, mask_anno)
+        self.frustum_obj_head.loss(out["frustum_obj_result"]["cls_logits"], out["frustum_obj_result"]["reg_preds"])  # raises
+        return out

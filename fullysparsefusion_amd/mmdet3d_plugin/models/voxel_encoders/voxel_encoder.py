@@ -232,12 +232,19 @@ class SIRLayer(nn.Module):
             if (needs_grad and switches.TRAIN_SIR_PRODUCT and self._with_rel_mlp and not gathered and torch.is_tensor(feats)
                     and feats.is_cuda and feats.dtype == torch.float32 and points.dtype == torch.float32 and feats.dim() == 2
                     and not points.requires_grad and points.size(1) >= 3 and feats.size(0) > 0
-                    and (extra is None or extra.dtype == torch.float32)):
+                    and (extra is None or extra.dtype == torch.float32) and not torch.is_autocast_enabled()):
                 # training: the position MLP stays in autograd; the two concatenations and the product around it are one kernel
                 # each way (K28), bit-identical to the ATen chain of `forward`
                 h = self.rel_mlp(f_cluster / self.rel_dist_scaler)
-                features = _SirProductFn.apply(points, feats, extra, h, tuple(float(v) for v in self.xyz_normalizer), float(extra_div))
-                return self._run_vfe(features, coors, **kwargs)
+                if h.dtype == torch.float32:  # (anything else — a mixed-precision wrapper around the MLP — takes the ATen chain below)
+                    features = _SirProductFn.apply(points, feats, extra, h, tuple(float(v) for v in self.xyz_normalizer),
+                                                   float(extra_div))
+                    return self._run_vfe(features, coors, **kwargs)
+                parts = [points, feats] + ([extra / extra_div] if extra is not None else [])
+                x = torch.cat(parts, 1)
+                nrm = torch.tensor(self.xyz_normalizer, device=x.device, dtype=x.dtype)
+                x = torch.cat([x[:, :3] / nrm[None, :], x[:, 3:]], dim=1) * h
+                return self._run_vfe(x, coors, **kwargs)
             parts = [points, feats] + ([extra / extra_div] if extra is not None else [])
             return self.forward(torch.cat(parts, 1), coors, f_cluster, **kwargs)
         layers, eps, act = fused
@@ -252,9 +259,12 @@ class SIRLayer(nn.Module):
     # ---- inference on rows SORTED by group (SIR.forward / FullySparseBboxHead permute once per stack) -------------------
     def sorted_supported(self):
         """K21 takes the position MLP and K22s (Linear + norm + act + segmented max in one pass) every layer of the stack."""
-        single_with_shortcut = (len(self.vfe_layers) == 1 and self.with_shortcut
-                                and self.vfe_layers[0].linear.out_features == self.in_channels)
-        return (not self.training and self._fused_input_layers() is not None and not single_with_shortcut
+        # `_run_vfe` adds the residual on the LAST layer whenever its output is as wide as its input — `in_channels` for a one-layer
+        # block, the `cat(point, group[inv])` of the previous layer (2 x prev) otherwise, e.g. feat_channels=[64, 128]; K22s has no
+        # residual, so such a block stays on the unsorted path
+        last = self.vfe_layers[-1].linear
+        last_with_shortcut = self.with_shortcut and last.out_features == last.in_features
+        return (not self.training and self._fused_input_layers() is not None and not last_with_shortcut
                 and sorted_stack_supported(self.vfe_layers, self.mode))
 
     def group_width(self):

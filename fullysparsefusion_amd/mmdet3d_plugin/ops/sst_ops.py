@@ -106,6 +106,11 @@ def unique_with_plan(coors, col_min=None, col_max=None):
         # them (or bounds too wide for a 64-bit packed key) sends this call through the data-dependent range pass instead
         if not hinted or getattr(e, "status", 0) != hip_ops.ERR_KEY_RANGE:
             raise
+        try:  # the promise did not hold for THIS tensor: later uniques on it go straight to the range pass
+            delattr(coors, _BOUNDS_ATTR)
+        except AttributeError:
+            pass
+        key = (None, None)
         new_coors, plan = hip_ops.unique_rows(coors)
     inv = plan.inv.detach()  # a second tensor object on the same storage: tensor -> plan -> tensor would be a cycle
     setattr(inv, _PLAN_ATTR, plan)
@@ -626,11 +631,83 @@ def _train_k22(x, out_features):
             and hip_ops.linear_norm_act_supported(x, out_features))
 
 
-def linear_norm_act(linear, norm, act, x, out=None):
+
+# ---- K22h: the wide Linears of the query / refine heads on f16 x 3 planes ------------------------------------------------
+def _rows_of(x):
+    return x.n if isinstance(x, hip_ops.RowPlanes) else x.size(0)
+
+
+def wide_linear_supported(linear, x):
+    """Does `linear(x)` take K22h (fsf_linear_planes_norm_act)?  Inference, >= K22H_MIN_ROWS rows, whole 32-wide k chunks, at least 256
+    channels either side (the `shared_mlp_dims=[1024, 1024]` / `embed_dims=1024` layers: bound by K22's six matrix passes)."""
+    if not (switches.K22H and isinstance(linear, nn.Linear) and linear.in_features % 32 == 0 and linear.in_features >= 256
+            and linear.out_features >= 256 and linear.out_features % 4 == 0 and linear.weight.is_cuda
+            and linear.weight.dtype == torch.float32):
+        return False
+    if torch.is_grad_enabled() and linear.weight.requires_grad:
+        return False
+    if isinstance(x, hip_ops.RowPlanes):
+        return x.c == linear.in_features
+    return (torch.is_tensor(x) and x.dim() == 2 and x.size(0) >= switches.K22H_MIN_ROWS and x.size(1) == linear.in_features
+            and not (torch.is_grad_enabled() and x.requires_grad) and hip_ops.rows_to_planes_supported(x))
+
+
+def as_row_planes(x):
+    """x (f32 rows or RowPlanes) -> RowPlanes; the conversion of a tensor is kept on it (two consumers of the LiDAR query features)."""
+    if isinstance(x, hip_ops.RowPlanes):
+        return x
+    c = x.__dict__.get("_fsf_row_planes") if hasattr(x, "__dict__") else None
+    if c is not None and c[1] == x._version and c[2] == x.data_ptr():
+        return c[0]
+    rp = hip_ops.rows_to_planes(x)
+    try:
+        x._fsf_row_planes = (rp, x._version, x.data_ptr())
+    except AttributeError:
+        pass
+    return rp
+
+
+def _prepared_planes_f16(linear, slice_c=128):
+    key = (linear.weight.data_ptr(), linear.weight._version, linear.weight.device, slice_c)
+    cache = linear.__dict__.get("_fsf_planes_f16")
+    if cache is None or cache[0] != key:
+        cache = (key, hip_ops.linear_prepare_weight_f16(linear.weight, slice_c))
+        linear.__dict__["_fsf_planes_f16"] = cache
+    return cache[1]
+
+
+def _wide_linear_norm_act(linear, norm, act, x, out=None, planes_out=False):
+    """act(norm(linear(x))) on K22h; returns f32 rows, or RowPlanes with `planes_out` (the next wide layer's operand: the LayerNorm
+    + activation pass writes the planes instead of fp32 rows).  None when the norm / activation pair is not covered."""
+    act_code = "relu" if isinstance(act, nn.ReLU) else (
+        "gelu" if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none" else None)
+    ln = isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1 and norm.elementwise_affine
+    if act_code is None or not ln:
+        return None
+    c = linear.out_features
+    y = hip_ops.linear_planes_norm_act(as_row_planes(x), _prepared_planes_f16(linear), c, 128, bias=linear.bias)
+    if planes_out and out is None and hip_ops.rows_to_planes_supported(y):
+        return hip_ops.rows_to_planes(y, "ln", norm.weight, norm.bias, norm.eps, act_code)
+    return hip_ops.norm_act(y, norm.weight, norm.bias, norm.eps, "ln", act_code, out=out)
+
+
+def materialize_rows(x):
+    """RowPlanes reached a consumer that wants fp32 rows (never on the built paths: producers only emit planes for a wide consumer)."""
+    if isinstance(x, hip_ops.RowPlanes):
+        raise hip_ops.FsfHipError("RowPlanes handed to a layer that is not a wide Linear")
+    return x
+
+
+def linear_norm_act(linear, norm, act, x, out=None, planes_out=False):
     """`act(norm(linear(x)))` for the [Linear, norm, act] blocks applied to every point / cluster row.  At inference, for
     up to 128 output channels with LayerNorm or eval-mode BatchNorm1d and ReLU / exact GELU, this is ONE HIP kernel
     (fsf_linear_norm_act, K22: the product from an exact 3-way bf16 split on the bf16 matrix cores — fp32-accurate — with
     the norm and the activation as its epilogue); otherwise the GEMM runs on the library and `fused_norm_act` follows."""
+    if wide_linear_supported(linear, x):
+        y = _wide_linear_norm_act(linear, norm, act, x, out=out, planes_out=planes_out)
+        if y is not None:
+            return y
+    x = materialize_rows(x)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad)
     act_code = "relu" if isinstance(act, nn.ReLU) else (
         "gelu" if isinstance(act, nn.GELU) and getattr(act, "approximate", "none") == "none" else None)
@@ -676,6 +753,9 @@ def _prepared_planes(linear):
 def point_linear(linear, x):
     """`linear(x)` for a per-point nn.Linear; training on the GPU routes the weight gradient through K10, inference on
     >= 1024 rows runs the product on K22 (no norm, no activation: 10 641 x 1024 -> 1024 158 us vs 225 us on the library)."""
+    if wide_linear_supported(linear, x):  # (K22h: 10 641 x 1024 -> 1024 on f16 x 3 planes)
+        return hip_ops.linear_planes_norm_act(as_row_planes(x), _prepared_planes_f16(linear), linear.out_features, 128, bias=linear.bias)
+    x = materialize_rows(x)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad)
     if (needs_grad and linear.weight.requires_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
             and x.size(0) >= 16384):
@@ -743,12 +823,42 @@ class MLPBlock(nn.Sequential):
     """[Linear, norm, act(, Dropout)] with the same child names ('0', '1', '2'[, '3']) as the reference's
     nn.Sequential, so state-dict keys are unchanged; forward fuses norm + act."""
 
-    def forward(self, x):
+    def forward(self, x, planes_out=False):
         mods = list(self._modules.values())
-        x = linear_norm_act(mods[0], mods[1], mods[2], x)
+        x = linear_norm_act(mods[0], mods[1], mods[2], x, planes_out=planes_out and len(mods) == 3)
         for m in mods[3:]:
             x = m(x)
         return x
+
+
+class MLPSequential(nn.Sequential):
+    """The nn.Sequential `build_mlp` returns (same child names, same state-dict keys).  Inference: a block whose consumer is a wide
+    Linear (K22h) hands its output over in plane form — written by its own LayerNorm + activation pass instead of fp32 rows;
+    `planes_out=True` asks the same of the LAST block (a caller whose next step is a wide layer: the cluster heads' branches)."""
+
+    def forward(self, x, planes_out=False):
+        mods = list(self._modules.values())
+        for i, m in enumerate(mods):
+            if isinstance(m, MLPBlock):
+                if i + 1 < len(mods):
+                    nxt = mods[i + 1]
+                    lin = nxt[0] if isinstance(nxt, MLPBlock) else nxt
+                    want = (isinstance(lin, nn.Linear) and wide_linear_supported(m[0], x) and m[0].out_features == lin.in_features
+                            and _wide_consumer(lin, _rows_of(x)))
+                else:
+                    want = planes_out
+                x = m(x, planes_out=want)
+            else:
+                x = m(x)
+        return x
+
+
+def _wide_consumer(linear, n_rows):
+    """Would `linear` take a RowPlanes input of `n_rows` rows (wide_linear_supported without an input tensor)?"""
+    return (switches.K22H and isinstance(linear, nn.Linear) and linear.in_features % 32 == 0 and linear.in_features >= 256
+            and linear.out_features >= 256 and linear.out_features % 4 == 0 and n_rows >= switches.K22H_MIN_ROWS
+            and linear.weight.is_cuda and linear.weight.dtype == torch.float32
+            and not (torch.is_grad_enabled() and linear.weight.requires_grad))
 
 
 def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act="relu", bias=False, dropout=0):
@@ -765,4 +875,4 @@ def build_mlp(in_channel, hidden_dims, norm_cfg, is_head=False, act="relu", bias
                 block.append(nn.Dropout(dropout))
             layers.append(MLPBlock(*block))
         last = c
-    return nn.Sequential(*layers)
+    return MLPSequential(*layers)

@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 13
+#define FSF_ABI_VERSION 14
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -314,6 +314,32 @@ int fsf_linear_prepare_weight_sliced(const float* weight, int32_t k, int32_t nsl
 int fsf_linear_norm_act_sliced(const float* x, int64_t n, int32_t k, int64_t x_stride, int64_t x_slice_offset, const void* planes,
                                int32_t nslice, int32_t slice_c, const float* bias, int32_t norm, const float* gamma,
                                const float* beta, float eps, int32_t act, float* out, int64_t out_stride, void* stream);
+
+/* K22h: the same per-row Linear for the WIDE layers of the query / refine heads — `shared_mlp_dims=[1024, 1024]`, `embed_dims=1024`
+ * (projects/configs/nuScenes/FSF_nuScenes_config.py: `mlp_cfg`, the cluster heads; FSF.py:120-164 builds them with build_mlp,
+ * ops/sst_ops.py:808-833) and the first layer of FSDSeparateHead's branches (sparse_cluster_head_v2.py:18-50) — with BOTH operands
+ * pre-split into f16 hi | lo planes, K9d's arithmetic (fsf_to_planes / fsf_spconv_forward_planes): x s_row = hi + lo with
+ * |x s_row - hi - lo| <= max(2^-22 |x s_row|, 2^-25), s_row the power of two that puts the row's largest magnitude in
+ * [2^13, 2^14), one power-of-two scale per layer for the weights; x w = hi hi + hi lo + lo hi: THREE v_mfma_f32_16x16x32_f16 per
+ * fp32-equivalent product (K22 issues six bf16 ones), fp32 accumulation, nothing split inside the main loop.
+ * fsf_rows_to_planes: x f32 [n, c] (row stride x_stride; c % 8 == 0, c <= 2048), optionally through LayerNorm(gamma, beta, eps)
+ *   (norm 1) and ReLU / GELU(erf) (act 1 / 2) first — the norm pass that follows a Linear wider than 128 channels — ->
+ *   planes [n][c / 8][2][8] f16 (fsf_row_planes_bytes) + inv_scales f32 [n] (1 / s_row) (+ the fp32 rows in `out` unless NULL).
+ * fsf_linear_prepare_weight_f16: weight f32 [c, k] -> 256-byte header (1 / s_w, s_w, max |w|) + fragment-ordered planes; slice_c =
+ *   output channels per 128-wide tile group: 128 for a plain layer, the per-branch width (65 .. 128) for independent layers stacked
+ *   along c (weight rows [s * slice_c, (s + 1) * slice_c) = layer s).
+ * fsf_linear_planes_norm_act: out f32 [n, c] = act(norm(x W^T + bias)); k % 32 == 0; a LayerNorm (norm 1) spans ONE slice of
+ *   slice_c channels (stacked layers) — a plain layer wider than 128 channels takes norm 0 and the caller runs
+ *   fsf_rows_to_planes(norm 1, ...) / fsf_norm_act on the result.  Workgroups of one row block (one per slice) share an XCD.
+ *   Deterministic; FSF_ERR_UNSUPPORTED for shapes outside the above (the caller runs fsf_linear_norm_act). */
+int64_t fsf_row_planes_bytes(int64_t n, int32_t c);
+int fsf_rows_to_planes(const float* x, int64_t n, int32_t c, int64_t x_stride, int32_t norm, const float* gamma, const float* beta,
+                       float eps, int32_t act, void* planes, float* inv_scales, float* out, int64_t out_stride, void* stream);
+int64_t fsf_linear_prepared_weight_f16_bytes(int32_t k, int32_t c, int32_t slice_c);
+int fsf_linear_prepare_weight_f16(const float* weight, int32_t k, int32_t c, int32_t slice_c, void* planes, void* stream);
+int fsf_linear_planes_norm_act(const void* x_planes, const float* x_inv_scales, int64_t n, int32_t k, const void* w_planes, int32_t c,
+                               int32_t slice_c, const float* bias, int32_t norm, const float* gamma, const float* beta, float eps,
+                               int32_t act, float* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K0  multi-sweep point-cloud assembly on the device (input side of the path)

@@ -289,14 +289,14 @@ def fsf_stage2(fsf, s1, mask_anno, img_hw):
     f_cluster = pts[:, :3] - center[inv]
     _, cluster_feats, out_coors = sir_forward(fsf.frustum_sir, pts, feat, sir_coors, f_cluster)
     ids_k = out_coors[:, 2]
-    preds = torch.zeros((out_coors.size(0), 9))
+    preds = torch.zeros((out_coors.size(0), 9), dtype=feat.dtype)  # (float64 when the chain runs in float64: test arbitration)
     valid = ids_k > 0
-    preds[valid] = mask_anno[ids_k[valid] - 1]
+    preds[valid] = mask_anno[ids_k[valid] - 1].to(feat.dtype)
     preds[~valid, 5] = fsf.num_classes
     bbox = preds[:, :4].clone()
     bbox[:, 0::2] /= img_hw[1]
     bbox[:, 1::2] /= img_hw[0]
-    enc = torch.cat([bbox, preds[:, 4:5], F.one_hot(preds[:, 5].long(), fsf.num_classes + 1).float()], -1)
+    enc = torch.cat([bbox, preds[:, 4:5], F.one_hot(preds[:, 5].long(), fsf.num_classes + 1).to(feat.dtype)], -1)
     img_feat = apply_module(fsf.encode_2d_mlp, enc)
     return dict(obj_feat=torch.cat([cluster_feats, img_feat], -1), obj_coors=out_coors, obj_centers=center,
                 sir_coors=sir_coors, f_cluster=f_cluster, preds_2d=preds)

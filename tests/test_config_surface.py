@@ -135,3 +135,20 @@ def test_grouped_concat_host_logic_cpu():
     assert sst_ops._grouped_linear_norm_act(torch.nn.Linear(2 * c, c), torch.nn.LayerNorm(c), torch.nn.GELU(), gc) is None
     with pytest.raises(FsfHipError):
         gc.materialize()  # gathers through the HIP library: loud failure on a CPU tensor, never a silent fallback
+
+
+def test_sorted_sir_path_refuses_a_last_layer_with_a_residual():
+    """`SIRLayer._run_vfe` adds `vfe(features) + features` on the LAST layer whenever its output is as wide as its (concatenated) input —
+    feat_channels=[64, 128]: cat(point 64, group 64) = 128 -> 128.  The sorted K22s path has no residual, so `sorted_supported()` must
+    send such a block through the unsorted path; the FSF configs' blocks ([128, 128]: 256 -> 128) stay on K22s."""
+    from fullysparsefusion_amd.mmdet3d_plugin.models.voxel_encoders.voxel_encoder import SIRLayer
+
+    kw = dict(in_channels=36, rel_mlp_hidden_dims=[16, 32], norm_cfg=dict(type="LN", eps=1e-3), mode="max", act="gelu")
+    residual = SIRLayer(feat_channels=[64, 128], with_shortcut=True, **kw).eval()
+    assert residual.vfe_layers[-1].linear.in_features == residual.vfe_layers[-1].linear.out_features == 128
+    assert not residual.sorted_supported()
+    assert SIRLayer(feat_channels=[64, 128], with_shortcut=False, **kw).eval().sorted_supported()
+    assert SIRLayer(feat_channels=[128, 128], with_shortcut=True, **kw).eval().sorted_supported()
+    one = SIRLayer(in_channels=64, feat_channels=[64], with_shortcut=True, rel_mlp_hidden_dims=[16, 32],
+                   norm_cfg=dict(type="LN", eps=1e-3), mode="max", act="gelu").eval()
+    assert not one.sorted_supported()

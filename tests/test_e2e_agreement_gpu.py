@@ -10,6 +10,13 @@ BEV IoU (float64 polygon oracle), matched at IoU >= 0.99 with |dscore| <= 1e-3, 
 score difference; identity of the integer query structure (camera-query keys, LiDAR cluster keys); 99.9th-percentile and
 maximum deviation of the two SIR stacks' group features on the common keys, relative to the feature scale.
 
+Arbitration (round 5): the camera stack's SIR group features are the one quantity whose GPU / oracle distance is far above the
+per-kernel bounds (LayerNorm(eps=1e-3) rows of the position MLP on `f_cluster ~ 0` amplify the centroid's fp32 rounding).
+The oracle chain therefore runs a SECOND time in float64 — same integer structure: the voxel keys and the projected mask ids
+depend on the fp32 input points only — through the segmentor, the fusion, the segmentation head and the camera stack, and the
+test asserts that the GPU features are no farther from that float64 chain than a small multiple of the fp32 ORACLE's own
+distance to it: the deviation is fp32 conditioning of the reference arithmetic, not a property of the HIP kernels.
+
 The thresholds asserted below were read off the measurement on MI355X ("end-to-end agreement") and
 then frozen.
 """
@@ -115,6 +122,11 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
     with torch.no_grad():
         res = model.simple_test([pts8.to(device)], [dict(lidar2img=L.to(device))], mask.to(device)[None], anno.to(device)[None])
         o = omod.simple_test(cpu, pts8, mask, anno, L)
+        # the float64 yardstick: stage 1 (segmentor + fusion + segmentation head) and the camera stack in float64 from the same input
+        cpu64 = copy.deepcopy(cpu).double()
+        s1_64 = omod.fsf_stage1(cpu64, pts8, mask, anno, L, dtype=torch.float64)
+        s2_64 = omod.fsf_stage2(cpu64, s1_64, anno, tuple(mask.shape[-2:]))
+        del cpu64
     monkeypatch.undo()
     gb, gs, gl = (res[0][k] for k in ("boxes_3d", "scores_3d", "labels_3d"))
     gb = gb.tensor.cpu().numpy()
@@ -126,6 +138,10 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
     f_centers, f_coors, _, f_feats, _, l_centers, l_coors, _, l_feats = cap["combine_in"]
     cam = _feature_deviation(c(f_feats)[:, :768], c(f_coors), o["s2"]["obj_feat"][:, :768].numpy(), o["s2"]["obj_coors"].numpy())
     lid = _feature_deviation(c(l_feats), c(l_coors), o["s3"]["cluster_feats"].numpy(), o["s3"]["cluster_inds"].numpy())
+    assert np.array_equal(s2_64["obj_coors"].numpy(), o["s2"]["obj_coors"].numpy()), "the float64 chain changed the camera-query keys"
+    cam_gpu64 = _feature_deviation(c(f_feats)[:, :768], c(f_coors), s2_64["obj_feat"][:, :768].numpy(), s2_64["obj_coors"].numpy())
+    cam_o32_64 = _feature_deviation(o["s2"]["obj_feat"][:, :768].numpy(), o["s2"]["obj_coors"].numpy(),
+                                    s2_64["obj_feat"][:, :768].numpy(), s2_64["obj_coors"].numpy())
     report = dict(
         frame=which, points=int(pts8.shape[0]), gpu_boxes=int(gb.shape[0]), oracle_boxes=int(ob.shape[0]),
         matched=int(len(pairs)), matched_iou99_dscore1e3=int(good.sum()),
@@ -133,7 +149,8 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
         min_matched_iou=float(iou.min()) if len(iou) else None, max_dscore=float(ds.max()) if len(ds) else None,
         median_one_minus_iou=float(np.median(1 - iou)) if len(iou) else None,
         camera_queries=dict(gpu=int(f_coors.shape[0]), oracle=int(o["s2"]["obj_coors"].shape[0]),
-                            keys_identical=bool(np.array_equal(c(f_coors), o["s2"]["obj_coors"].numpy())), sir_feature_dev=cam),
+                            keys_identical=bool(np.array_equal(c(f_coors), o["s2"]["obj_coors"].numpy())), sir_feature_dev=cam,
+                            sir_feature_dev_gpu_vs_float64=cam_gpu64, sir_feature_dev_oracle32_vs_float64=cam_o32_64),
         lidar_queries=dict(gpu=int(l_coors.shape[0]), oracle=int(o["s3"]["cluster_inds"].shape[0]),
                            keys_identical=bool(np.array_equal(c(l_coors), o["s3"]["cluster_inds"].numpy())), sir_feature_dev=lid),
         oracle_nms_margin=float(o["margin"]))
@@ -149,6 +166,11 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
     assert report["unmatched_gpu"] <= E2E_MAX_UNMATCHED and report["unmatched_oracle"] <= E2E_MAX_UNMATCHED, report
     assert report["camera_queries"]["keys_identical"] and report["lidar_queries"]["keys_identical"], report
     assert cam["p999"] <= E2E_MAX_CAMERA_SIR_DEV_P999 and lid["p999"] <= E2E_MAX_LIDAR_SIR_DEV_P999, report
+    # arbitration against the float64 chain: the device is no farther from it than the fp32 oracle is (x 3, with a floor at the
+    # per-kernel bound) — at the 99.9th percentile, at the median and at the maximum
+    for q in ("median", "p999", "max"):
+        assert cam_gpu64[q] <= E2E_F64_RATIO * cam_o32_64[q] + E2E_F64_FLOOR, (q, cam_gpu64, cam_o32_64)
+    assert cam_gpu64["p999"] <= E2E_MAX_CAMERA_SIR_DEV_VS_F64_P999, report
 
 
 # Thresholds: measured first (round 4, MI355X, gpurun_out/e2e_agreement_*.json -> DESIGN.md section 3), then frozen with margin.
@@ -157,5 +179,13 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
 # 3.4e-4 (LiDAR stack) of the feature scale.
 E2E_MIN_MATCHED_FRACTION = 0.99      # of the 500 returned boxes, matched at BEV IoU >= 0.99 with |dscore| <= 1e-3
 E2E_MAX_UNMATCHED = 5
-E2E_MAX_CAMERA_SIR_DEV_P999 = 2e-2
+E2E_MAX_CAMERA_SIR_DEV_P999 = 2e-2   # vs the fp32 ORACLE chain — whose own distance to the float64 chain is 5.7e-3 (10 sweeps), 3.5e-3 (AV2):
+#                                      this bound limits the oracle's conditioning, the next three limit the device
+# Round 5, measured on MI355X (profiles/r5_e2e_agreement_*.json): camera-stack SIR group features, 99.9th percentile of the row
+# maximum relative to the feature scale — device vs the float64 chain 1.8e-4 / 9.0e-5 / 5.5e-5 (1 sweep / 10 sweeps / AV2), the fp32
+# oracle vs the float64 chain 1.8e-4 / 5.7e-3 / 3.5e-3: the device is as close to float64 as the fp32 oracle on the small frame and
+# 60 x closer on the large ones (its centroids and LayerNorm statistics are accumulated in blocked / pairwise order).
+E2E_F64_RATIO = 3.0                  # |gpu - float64 chain| <= ratio x |fp32 oracle - float64 chain| + floor
+E2E_F64_FLOOR = 1e-5
+E2E_MAX_CAMERA_SIR_DEV_VS_F64_P999 = 5e-4   # (40 x tighter than the bound against the fp32 oracle)
 E2E_MAX_LIDAR_SIR_DEV_P999 = 2e-3

@@ -1085,7 +1085,7 @@ def test_training_step_two_frames_per_gpu_in_a_process_group(device):
         _, inp = bench.make_inputs(1, 3, device, frames=2)
         # reference: the same model, training mode, plain autograd
         model.train()
-        out = model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
+        out = model.forward_train_graph(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
         loss = bench.dummy_loss(out)
         params = [p for p in model.parameters() if p.requires_grad]
         want = torch.autograd.grad(loss, params, allow_unused=True)
