@@ -497,17 +497,49 @@ def train_extras(train_step, pool, steps, world, dist, device):
         torch.cuda.synchronize()
         iso = (time.perf_counter() - t0) / 3 * 1e3
         dp.zero_grad()
-    vals = torch.tensor([t_sync, t_local, iso], dtype=torch.float64, device=device)
+    # --- naiveSyncBN1d's statistics collectives (C3): 2 x (number of synced norms) latency-bound [2C] all-reduces per step, on the
+    # critical path of both passes.  Counted from the module's own log; exposed = the step with them skipped on every rank alike
+    # (statistics per rank: a timing experiment) against the full step; isolated = the same message sizes back to back.
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import norm as norm_mod
+
+    sync_sizes, t_nobn, bn_iso = [], t_sync, 0.0
+    if dist is not None and world > 1:
+        norm_mod.SYNC_LOG = log = []
+        train_step(pool[0])
+        torch.cuda.synchronize()
+        norm_mod.SYNC_LOG = None
+        sync_sizes = [numel for _, numel in log]
+        norm_mod.SYNC_COLLECTIVES = False
+        try:
+            t_nobn = timed(k, True)
+        finally:
+            norm_mod.SYNC_COLLECTIVES = True
+        msgs = [torch.zeros(numel, dtype=torch.float32, device=device) for numel in sync_sizes]
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for m in msgs:
+                dist.all_reduce(m)
+        torch.cuda.synchronize()
+        bn_iso = (time.perf_counter() - t0) / 3 * 1e3
+    vals = torch.tensor([t_sync, t_local, iso, t_nobn, bn_iso], dtype=torch.float64, device=device)
     if dist is not None:
         dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-    t_sync, t_local, iso = [float(v) for v in vals]
+    t_sync, t_local, iso, t_nobn, bn_iso = [float(v) for v in vals]
     exposed = max(0.0, t_sync - t_local)
     nbytes = sum(b.flat.numel() for b in dp.buckets) * 4
     allreduce = dict(world_size=world, gradient_bytes=nbytes, buckets=len(dp.buckets), step_ms=round(t_sync, 3), step_ms_no_sync=round(t_local, 3),
                      exposed_ms=round(exposed, 3), isolated_ms=round(iso, 3),
                      overlap_fraction=(round(1.0 - min(1.0, exposed / iso), 3) if iso > 0 else None),
                      bus_gb_per_s_isolated=(round(2.0 * (world - 1) / world * nbytes / (iso * 1e-3) / 1e9, 1) if iso > 0 else None),
-                     note="max over ranks; world size 1 issues no collective (exposed = run-to-run noise)")
+                     note="max over ranks; world size 1 issues no collective (exposed = run-to-run noise)",
+                     syncbn=dict(collectives_per_step=len(sync_sizes), floats_per_step=int(sum(sync_sizes)),
+                                 step_ms_without_them=round(t_nobn, 3), exposed_ms=round(max(0.0, t_sync - t_nobn), 3),
+                                 isolated_ms=round(bn_iso, 3),
+                                 note="naiveSyncBN1d [2C] statistics all-reduces (forward + backward of every synced norm): exposed = "
+                                      "full step - the step with these collectives skipped on every rank; isolated = the same messages "
+                                      "back to back; 0 at world size 1"))
     return roof, allreduce
 
 

@@ -40,6 +40,15 @@ class FSDSeparateHead(nn.Module):
             return fused
         return {attr_name: getattr(self, attr_name)(x) for attr_name in self.attrs}
 
+    def accepts_planes(self, n_rows):
+        """Will `forward` take the query features in plane form (RowPlanes) for `n_rows` rows?  (Its first layer then runs on K22h.)"""
+        if not (switches.HEAD_SLICED and switches.K22H) or self.training or n_rows < switches.K22H_MIN_ROWS or len(self.attrs) <= 1:
+            return False
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return False
+        plan = self._sliced_plan()
+        return plan is not None and "first_f16" in plan
+
     # ---- inference on the GPU: the attribute branches are independent MLPs of one shape on the same input, so layer i of
     # all of them is ONE K22 launch (fsf_linear_norm_act_sliced) instead of one per attribute — per query head 15 launches
     # (10 fused blocks + 5 library GEMMs for the 2..10-wide outputs) become 3, and a 10 k-row x 1024 -> 128 layer, which
@@ -104,23 +113,39 @@ class FSDSeparateHead(nn.Module):
                         b[i * pad:i * pad + l.out_features] = l.bias
                 plan = dict(names=names, layers=layers, out_k=kin, out_planes=hip_ops.linear_prepare_weight_sliced(w, len(names), pad),
                             out_bias=b, out_dims=[l.out_features for l in last])
+                # the branches' FIRST layer on K22h (f16 x 3 planes; all branches read the same >= 256-wide query features)
+                first = [m[0][0] for m in mlps]
+                k0, h0 = first[0].in_features, first[0].out_features
+                if switches.K22H and k0 % 32 == 0 and k0 >= 256 and 64 < h0 <= 128 and h0 % 4 == 0:
+                    plan["first_f16"] = hip_ops.linear_prepare_weight_f16(torch.cat([l.weight for l in first], 0), h0)
         self.__dict__["_fsf_sliced"] = (key, plan)
         return plan
 
     def _forward_sliced(self, x):
         if not switches.HEAD_SLICED:
             return None
-        if (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))) or self.training:
+        from ...ops.sst_ops import as_row_planes
+
+        is_planes = isinstance(x, hip_ops.RowPlanes)
+        if self.training or (torch.is_grad_enabled() and ((not is_planes and x.requires_grad) or any(p.requires_grad for p in self.parameters()))):
             return None
-        if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(0) >= 1 and x.stride(1) == 1
-                and (x.size(0) == 1 or x.stride(0) % 4 == 0) and x.data_ptr() % 16 == 0 and len(self.attrs) > 1):
+        if not is_planes and not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(0) >= 1 and x.stride(1) == 1
+                                  and (x.size(0) == 1 or x.stride(0) % 4 == 0) and x.data_ptr() % 16 == 0 and len(self.attrs) > 1):
             return None
         plan = self._sliced_plan()
-        if plan is None or plan["layers"][0]["k"] != x.size(1):
+        k_in, n_rows = (x.c, x.n) if is_planes else (x.size(1), x.size(0))
+        if plan is None or plan["layers"][0]["k"] != k_in:
             return None
         ns = len(plan["names"])
         h_prev = 0
-        for lay in plan["layers"]:
+        for li, lay in enumerate(plan["layers"]):
+            if li == 0 and "first_f16" in plan and (is_planes or (n_rows >= switches.K22H_MIN_ROWS and hip_ops.rows_to_planes_supported(x))):
+                x = hip_ops.linear_planes_norm_act(as_row_planes(x), plan["first_f16"], ns * lay["h"], lay["h"], bias=lay["bias"], norm="ln",
+                                                   gamma=lay["gamma"], beta=lay["beta"], eps=lay["eps"], act=lay["act"])
+                h_prev = lay["h"]
+                continue
+            if isinstance(x, hip_ops.RowPlanes):
+                return None
             x = hip_ops.linear_norm_act_sliced(x, lay["k"], h_prev, lay["planes"], ns, lay["h"], bias=lay["bias"], norm="ln",
                                                gamma=lay["gamma"], beta=lay["beta"], eps=lay["eps"], act=lay["act"])
             h_prev = lay["h"]
@@ -221,7 +246,11 @@ class SparseClusterHeadV2(SparseClusterHead):
 
     def forward(self, feats, pts_xyz=None, pts_inds=None):
         if self.shared_mlp is not None:
-            feats = self.shared_mlp(feats)
+            # (the shared MLP's output only feeds the task heads' branches: in plane form when every one of them takes it)
+            as_planes = (torch.is_tensor(feats) and feats.dim() == 2 and feats.is_cuda
+                         and all(getattr(h, "accepts_planes", lambda n: False)(feats.size(0)) for h in self.task_heads)
+                         and self.task_heads[0]._sliced_plan()["layers"][0]["k"] == self.shared_mlp[-1][0].out_features)
+            feats = self.shared_mlp(feats, planes_out=True) if as_planes else self.shared_mlp(feats)
         cls_logit_list, reg_pred_list, iou_logits_list = [], [], []
         for h in self.task_heads:
             ret = h(feats)

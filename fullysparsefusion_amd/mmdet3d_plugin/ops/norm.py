@@ -16,6 +16,22 @@ import torch.nn as nn
 
 from ..registry import NORM_LAYERS
 
+# Instrumentation of the statistics collectives (C3): `SYNC_LOG` — a list the tests / bench.py install to record every collective
+# this module issues, in issue order, as (direction, numel) — and `SYNC_COLLECTIVES` — bench.py's A/B switch: False skips the
+# all-reduces on EVERY rank alike (the statistics are then per rank: a timing experiment, never a training mode), which is how
+# the exposed time of the 2 x 38 latency-bound [2C] messages per step is measured.
+SYNC_LOG = None
+SYNC_COLLECTIVES = True
+
+
+def _all_reduce_stats(t, direction, group=None):
+    if SYNC_LOG is not None:
+        SYNC_LOG.append((direction, int(t.numel())))
+    if SYNC_COLLECTIVES:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        t.mul_(dist.get_world_size(group))
+
 
 class _SyncStats(torch.autograd.Function):
     """all-reduce(mean) of a packed [2C] statistics vector; backward all-reduces the gradient the same way."""
@@ -23,13 +39,13 @@ class _SyncStats(torch.autograd.Function):
     @staticmethod
     def forward(ctx, packed):
         out = packed.clone()
-        dist.all_reduce(out, op=dist.ReduceOp.SUM)
+        _all_reduce_stats(out, "fwd")
         return out / dist.get_world_size()
 
     @staticmethod
     def backward(ctx, grad):
         g = grad.clone()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        _all_reduce_stats(g, "bwd")
         return g / dist.get_world_size()
 
 
@@ -63,7 +79,7 @@ class _SyncBatchNormAct(torch.autograd.Function):
         world = dist.get_world_size(group)
         mean_l, var_l = _column_stats(x)
         packed = torch.cat([mean_l, var_l + mean_l * mean_l])
-        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce_stats(packed, "fwd", group)
         packed /= world
         mean, meansqr = packed[:c], packed[c:]
         var = meansqr - mean * mean
@@ -103,7 +119,7 @@ class _SyncBatchNormAct(torch.autograd.Function):
         w, s = weight.detach(), invstd
         dl_ds = w * dg / s
         g_stats = torch.cat([-w * s * db + dl_ds * s ** 3 * mean, -0.5 * dl_ds * s ** 3])
-        dist.all_reduce(g_stats, op=dist.ReduceOp.SUM, group=ctx.group)
+        _all_reduce_stats(g_stats, "bwd", ctx.group)
         g_stats /= ctx.world
         c0 = (w * s * db - w * s * s * mean * dg + g_stats[:c]) / n
         c1 = (w * s * s * dg + 2.0 * g_stats[c:]) / n

@@ -470,3 +470,83 @@ def test_bench_launches_its_own_ranks():
     # (the launcher stops the other rank as soon as one has failed: the second message may not make it out)
     assert out.count("needs a HIP device") >= 1 and "local_rank" in out, out[-2000:]
     assert "WORLD_SIZE=" not in out  # (the mismatch message of a rank that was not launched per GPU)
+
+
+# --------------------------------- the SyncBN collective sequence does not depend on which class groups a rank's frame holds
+def _syncbn_sequence_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fullysparsefusion_amd.data_parallel import FrameDataParallel
+        from fullysparsefusion_amd.mmdet3d_plugin.ops import norm as norm_mod
+        from fullysparsefusion_amd.mmdet3d_plugin.registry import build_norm_layer
+
+        torch.manual_seed(5)
+        sbn = lambda c: build_norm_layer(dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), c)[1]  # noqa: E731
+        # the FSF layout: synced BatchNorm only in the always-executed trunk (VFE / U-Net: "segmentor."), LayerNorm in the per-group
+        # query branches (SIR layers, heads) — a rank whose frame has no points of a class group skips that group's branch
+        trunk = torch.nn.Sequential(torch.nn.Linear(6, 8), sbn(8), torch.nn.ReLU(), torch.nn.Linear(8, 12), sbn(12), torch.nn.ReLU())
+        groups = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(12, 12), torch.nn.LayerNorm(12), torch.nn.GELU(),
+                                                          torch.nn.Linear(12, 3)) for _ in range(3)])
+        model = torch.nn.ModuleDict(dict(trunk=trunk, groups=groups)).train()
+        dp = FrameDataParallel(model, bucket_mb=0.0002)
+        x = torch.randn(world, 10, 6, generator=torch.Generator().manual_seed(9))[rank]
+        present = [[True, True, True], [True, False, True]][rank]   # rank 1's frame holds no point of class group 1
+        norm_mod.SYNC_LOG = log = []
+        seqs, grads = [], []
+        for it in range(2):
+            log.clear()
+            dp.zero_grad()
+            h = dp.module["trunk"](x)
+            y = sum(dp.module["groups"][g](h).sum() for g in range(3) if present[g])
+            dp.backward(y)
+            seqs.append(list(log))
+            grads.append({n: p.grad.numpy().copy() for n, p in model.named_parameters()})
+        norm_mod.SYNC_LOG = None
+        q.put((rank, seqs, grads))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+@_retry_rendezvous
+def test_syncbn_collective_sequence_is_the_same_on_a_rank_that_skips_a_class_group_world2_gloo():
+    """a rank whose frame skips a class group must still issue the identical sequence of statistics collectives
+    (RCCL pairs them by issue order).  They all sit in the trunk every rank runs; the skipped branch only changes WHEN its gradient
+    bucket is reduced, on the buckets' own communicator.  Recorded sequence equal on both ranks; gradients agree."""
+    import numpy as np
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_syncbn_sequence_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=100) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for it in range(2):
+        assert got[0][1][it] == got[1][1][it] == [("fwd", 16), ("fwd", 24), ("bwd", 24), ("bwd", 16)], got[0][1][it]
+        for n in got[0][2][it]:
+            assert np.array_equal(got[0][2][it][n], got[1][2][it][n]), (it, n)
+    assert np.abs(got[1][2][0]["groups.1.0.weight"]).max() > 0  # rank 0's gradient of the group rank 1 skipped reached rank 1
+
+
+def test_synced_batch_norms_of_the_fsf_configs_sit_only_in_the_always_executed_trunk():
+    """What the sequence argument above rests on, for the REAL models: every naiveSyncBN1d of the nuScenes and Argoverse-2 detectors is
+    a submodule of `segmentor.` (voxel encoder, sparse U-Net) — executed once per step on every rank whatever the frame holds; the
+    per-class-group / per-query modules (SIR stacks, heads, refine stage) carry LayerNorm only."""
+    from fullysparsefusion_amd import mmdet3d_plugin
+    from fullysparsefusion_amd.compat import Config
+    from fullysparsefusion_amd.mmdet3d_plugin.ops.norm import NaiveSyncBatchNorm1d
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cfg_name in ("fsf_nuscenes.py", "fsf_av2.py"):
+        model = mmdet3d_plugin.build_model(Config.fromfile(os.path.join(root, "configs", cfg_name)).model)
+        names = [n for n, m in model.named_modules() if isinstance(m, NaiveSyncBatchNorm1d)]
+        assert len(names) >= 30, (cfg_name, len(names))
+        outside = [n for n in names if not n.startswith("segmentor.")]
+        assert not outside, outside[:5]
+        conditional = [n for n, m in model.named_modules() if isinstance(m, torch.nn.BatchNorm1d) and not n.startswith("segmentor.")]
+        assert not conditional, conditional[:5]

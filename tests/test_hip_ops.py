@@ -1885,3 +1885,125 @@ def test_spconv_backward_weight_on_strided_and_inverse_tables_equals_float64(ops
         want = feat[tb[sel, k]].double().t() @ gout[sel].double()
         scale = max(1.0, float(want.abs().max()))
         assert float((got[k].double() - want).abs().max()) <= 1e-5 * scale, (kind, k)
+
+
+# ------------------------------------------------------------------------------------------------ K22h (f16 x 3 planes)
+def _decode_row_planes(rp):
+    """RowPlanes -> float64 [n, c]: (hi + lo) / s_row."""
+    n, c = rp.n, rp.c
+    raw = rp.data[:n * c * 4].view(torch.float16).view(n, c // 8, 2, 8).double()
+    return (raw[:, :, 0, :] + raw[:, :, 1, :]).reshape(n, c) * rp.inv_scales[:n, None].double()
+
+
+@pytest.mark.parametrize("n,c,norm,act", [(1000, 1024, "none", "none"), (2049, 768, "ln", "gelu"), (37, 128, "ln", "relu"),
+                                          (1, 8, "none", "gelu"), (513, 2048, "ln", "gelu"), (300, 896, "none", "none")])
+def test_rows_to_planes_split_and_norm(ops, device, n, c, norm, act):
+    """fsf_rows_to_planes: hi + lo reproduces x s_row to 2^-22 of every element that matters at the row's scale (rows spanning 12
+    orders of magnitude, an all-zero row), the fp32 rows it can emit equal act(LayerNorm(x)) within fp32 rounding, strided input."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(n + c)
+    buf = torch.randn(n, c + 8, device=device) * torch.exp(torch.randn(n, 1, device=device) * 4.0)
+    x = buf[:, :c]
+    if n > 2:
+        x[1] = 0.0
+    g, b = torch.rand(c, device=device) + 0.5, torch.randn(c, device=device) * 0.1
+    rp, rows = ops.rows_to_planes(x, norm, g if norm == "ln" else None, b if norm == "ln" else None, 1e-3, act, want_rows=True)
+    y = x.double()
+    if norm == "ln":
+        y = F.layer_norm(y, (c,), g.double(), b.double(), 1e-3)
+    y = F.gelu(y) if act == "gelu" else F.relu(y) if act == "relu" else y
+    scale = y.abs().amax(1, keepdim=True).clamp_min(1e-30)
+    assert float(((rows.double() - y).abs() / scale).max()) <= 4e-6
+    dec = _decode_row_planes(rp)
+    err = (dec - rows.double()).abs()
+    # |x s - hi - lo| <= max(2^-22 |x s|, 2^-25): relative to the element, or 2^-38 of the row maximum (which sits at 2^13 .. 2^14)
+    bound = torch.maximum(rows.double().abs() * 2.0 ** -21.9, rows.double().abs().amax(1, keepdim=True) * 2.0 ** -37.9)
+    assert bool((err <= bound).all()), float((err / bound.clamp_min(1e-300)).max())
+    rp2 = ops.rows_to_planes(x, norm, g if norm == "ln" else None, b if norm == "ln" else None, 1e-3, act)
+    assert torch.equal(rp2.data, rp.data) and torch.equal(rp2.inv_scales, rp.inv_scales)
+
+
+@pytest.mark.parametrize("n,k,c,slice_c,norm,act,bias", [
+    (10641, 1024, 1024, 128, "none", "none", True),    # shared_mlp / out_proj of the query heads at the frame's query count
+    (10397, 768, 1024, 128, "none", "none", False),   # combine_fsd_feat_mlp / bbox_head.shared_mlp[0]
+    (3000, 896, 1024, 128, "none", "none", True),
+    (10641, 1024, 640, 128, "ln", "gelu", True),      # first layer of FSDSeparateHead's five branches
+    (1500, 256, 256, 128, "none", "gelu", True),
+    (129, 512, 272, 68, "ln", "relu", False),         # four stacked 68-wide layers, a partial row block
+    (1, 32, 128, 128, "affine", "none", True),
+])
+def test_linear_planes_f16x3_vs_float64(ops, device, n, k, c, slice_c, norm, act, bias):
+    """K22h: act(norm(x W^T + b)) with both operands as f16 hi | lo planes (three MFMA passes) against float64: <= 1e-5 of the output
+    scale (what the sparse-conv plane kernels are held to), no farther from float64 than a few fp32 GEMM errors on well-scaled data,
+    rows of very different magnitude in one launch, deterministic."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(n + k + c)
+    x = torch.randn(n, k, device=device) * torch.exp(torch.randn(n, 1, device=device) * 2.0)
+    w = torch.randn(c, k, device=device) / k ** 0.5
+    w[::7] *= 1e-3  # output channels with weights far below the layer's maximum
+    b = torch.randn(c, device=device) if bias else None
+    g, be = torch.rand(c, device=device) + 0.5, torch.randn(c, device=device) * 0.1
+    assert ops.linear_planes_supported(k, c, slice_c)
+    wp = ops.linear_prepare_weight_f16(w, slice_c)
+    xp = ops.rows_to_planes(x)
+    kw = dict(bias=b, norm=norm, gamma=g if norm != "none" else None, beta=be if norm != "none" else None, eps=1e-3, act=act)
+    out = ops.linear_planes_norm_act(xp, wp, c, slice_c, **kw)
+
+    def tail(y):
+        if norm == "ln":
+            parts = [F.layer_norm(y[:, s:s + slice_c], (min(slice_c, c - s),), g[s:s + slice_c].to(y.dtype), be[s:s + slice_c].to(y.dtype), 1e-3)
+                     for s in range(0, c, slice_c)]
+            y = torch.cat(parts, 1)
+        elif norm == "affine":
+            y = y * g.to(y.dtype) + be.to(y.dtype)
+        return F.gelu(y) if act == "gelu" else F.relu(y) if act == "relu" else y
+
+    pre = F.linear(x.double(), w.double(), b.double() if bias else None)
+    want = tail(pre)
+    # per ROW: rows differ by orders of magnitude, each is judged at its own output scale
+    row_scale = (pre.abs().amax(1, keepdim=True) if norm != "ln" else want.abs().amax(1, keepdim=True)).clamp_min(1e-30)
+    err = float(((out.double() - want).abs() / row_scale).max())
+    ref32 = tail(F.linear(x, w, b))
+    err32 = float(((ref32.double() - want).abs() / row_scale).max())
+    assert err <= 1e-5, (err, err32)
+    assert err <= max(8.0 * err32, 2e-6), (err, err32)
+    assert torch.equal(out, ops.linear_planes_norm_act(xp, wp, c, slice_c, **kw))
+
+
+def test_wide_mlp_chain_on_planes_equals_the_k22_path(ops, device, monkeypatch):
+    """`build_mlp(768, [1024, 1024])` + a five-branch FSDSeparateHead at the frame's query count: the K22h route (planes handed from
+    layer to layer, the LayerNorm + GELU pass writing planes) against float64 and against the K22 route (FSF_K22H=0)."""
+    import torch.nn.functional as F
+
+    from fullysparsefusion_amd import switches
+    from fullysparsefusion_amd.mmdet3d_plugin.models.dense_heads.cluster_heads import FSDSeparateHead
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import sst_ops
+
+    torch.manual_seed(5)
+    mlp = sst_ops.build_mlp(768, [1024, 1024], dict(type="LN", eps=1e-3), act="gelu").to(device).eval()
+    head = FSDSeparateHead(1024, dict(center=(3, 2, 128), dim=(3, 2, 128), rot=(2, 2, 128), vel=(2, 2, 128), score=(10, 2, 128)),
+                           norm_cfg=dict(type="LN"), act="gelu").to(device).eval()
+    x = torch.randn(10397, 768, device=device).clamp_min(0) * 3  # (max-pooled GELU features are non-negative)
+    with torch.no_grad():
+        assert switches.K22H and head.accepts_planes(x.size(0))
+        mid = mlp(x, planes_out=True)
+        assert isinstance(mid, sst_ops.hip_ops.RowPlanes) and mid.c == 1024
+        got = head(mid)
+        got_rows = mlp(x)                       # the same chain ending in fp32 rows
+        monkeypatch.setattr(switches, "K22H", False)
+        head.__dict__.pop("_fsf_sliced", None)
+        ref_rows = mlp(x)
+        ref = head(ref_rows)
+        # float64
+        y = x.double()
+        for blk in mlp:
+            y = F.gelu(F.layer_norm(F.linear(y, blk[0].weight.double()), (1024,), blk[1].weight.double(), blk[1].bias.double(), blk[1].eps))
+    scale = float(y.abs().max())
+    assert float((got_rows.double() - y).abs().max()) <= 1e-5 * scale
+    assert float((ref_rows.double() - y).abs().max()) <= 1e-5 * scale
+    for name in head.attrs:
+        a, b = got[name].double(), ref[name].double()
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), name
