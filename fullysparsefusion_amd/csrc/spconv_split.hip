@@ -16,6 +16,8 @@
 //     32 rows has);
 //   * six leading cross terms of the exact split, fp32 accumulation: fp32 accuracy (see linear_norm_act.hip).
 // Deterministic: fixed (offset, cin) order, no atomics.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace fsf {
@@ -44,6 +46,9 @@ struct ScsArgs {
   float* partial;  // [ksplit][m_out][cout] raw sums when the (offset, cin chunk) sequence is split over gridDim.z
   int64_t m_in, m_out;
   int cin, cout, kvol, relu, ksplit;
+  // xcd_lanes > 0: a 1-D grid of 8 * xcd_lanes * ceil(nslice * ksplit / 8) workgroups in which the xcd_lanes workgroups that stream
+  // the SAME weight chunks (one (slice, k range), different row blocks) are congruent modulo 8, i.e. share an XCD and its L2
+  int xcd_lanes, nslice;
 };
 
 __device__ __forceinline__ void scs_split8(const float (&v)[8], scs_u32x4& hi, scs_u32x4& mid, scs_u32x4& lo) {
@@ -96,17 +101,29 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
   const int nchunks = a.kvol * nkc;
   // a small layer (too few 128-row workgroups to fill the chip) splits the chunk sequence over gridDim.z; the slices are
   // folded in order by scs_fold_kernel
-  const int ci_begin = (int)((int64_t)nchunks * blockIdx.z / a.ksplit), ci_end = (int)((int64_t)nchunks * (blockIdx.z + 1) / a.ksplit);
+  // (slice, k range, first row block, row-block step) of this workgroup.  The deep U-Net levels have a dozen row blocks and 42 MB of
+  // split weights per layer: every row block streams all of them, and with the row block on blockIdx.x the twelve workgroups that
+  // read the same chunks were dealt to eight different XCDs — each L2 pulled the whole weight set through the fabric (630 MB per
+  // launch measured against 184 MB algorithmic).  In the XCD-aware layout they sit on ONE XCD and meet in its L2.
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, bz = (int)blockIdx.z, bstep = (int)gridDim.x;
+  if (a.xcd_lanes > 0) {
+    const int wg = (int)blockIdx.x, j = wg >> 3;
+    const int group = (j / a.xcd_lanes) * 8 + (wg & 7);
+    if (group >= a.nslice * a.ksplit) return;  // (uniform: the last round of groups may be partial)
+    bx = j % a.xcd_lanes; bstep = a.xcd_lanes;
+    by = group % a.nslice; bz = group / a.nslice;
+  }
+  const int ci_begin = (int)((int64_t)nchunks * bz / a.ksplit), ci_end = (int)((int64_t)nchunks * (bz + 1) / a.ksplit);
   const int64_t nblk = (a.m_out + SCS_ROWS - 1) / SCS_ROWS;
-  const int ch_base = 128 * (int)blockIdx.y;
-  const uint4* planes = a.planes + (int64_t)blockIdx.y * nchunks * CHUNK_U4;
+  const int ch_base = 128 * by;
+  const uint4* planes = a.planes + (int64_t)by * nchunks * CHUNK_U4;
   const int last_quad = a.cin - 4;
   // The epilogue's per-channel vectors go through LDS, and its residual row is loaded before the first store: as plain
   // global loads inside the tile loop each one sat behind the previous tile's store (the pointers may alias) — ~48
   // serialized round trips at the end of every workgroup's chain.
   {
     const int t = threadIdx.x;  // 256 threads: scale[128] | shift[128]
-    const int ch = 128 * (int)blockIdx.y + (t & 127);
+    const int ch = 128 * by + (t & 127);
     const float* src = t < 128 ? a.scale : a.shift;
     vec[t] = (src && ch < a.cout) ? src[ch] : (t < 128 ? 1.0f : 0.0f);
   }
@@ -119,7 +136,7 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
       __builtin_amdgcn_global_load_lds(src + 4 * (u + lane), dst + 4 * u, 16, 0, 0);
   };
 
-  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  for (int64_t blk = bx; blk < nblk; blk += bstep) {
     const int64_t row0 = blk * SCS_ROWS + (int64_t)wave * (SCS_RG * 16);
     scs_f32x4 acc[SCS_RG][T];
 #pragma unroll
@@ -240,7 +257,7 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
           for (int t = 0; t < T; ++t) {
             const int ch0 = ch_base + 16 * t + 4 * grp;
             if (ch0 < a.cout)
-              *reinterpret_cast<float4*>(a.partial + ((int64_t)blockIdx.z * a.m_out + row) * a.cout + ch0) =
+              *reinterpret_cast<float4*>(a.partial + ((int64_t)bz * a.m_out + row) * a.cout + ch0) =
                   make_float4(acc[rg][t][0], acc[rg][t][1], acc[rg][t][2], acc[rg][t][3]);
           }
           continue;
@@ -366,12 +383,18 @@ extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t
   const int ksplit = scs_ksplit(m_out, cin, cout, kvol);
   if (ksplit > 1 && (!workspace || workspace_bytes < fsf_spconv_split_workspace_bytes(m_out, cin, cout, kvol))) return FSF_ERR_WORKSPACE;
   ScsArgs a{feat, (const uint4*)planes, nbr, scale, shift, residual, out, (float*)workspace, m_in, m_out,
-            (int)cin, (int)cout, (int)kvol, (int)relu, ksplit};
+            (int)cin, (int)cout, (int)kvol, (int)relu, ksplit, 0, 0};
   const int64_t nblk = (m_out + SCS_ROWS - 1) / SCS_ROWS;
   const int nslice = scs_slices(cout);
   int64_t gx = (256 * SCS_WPS + nslice * ksplit - 1) / (nslice * ksplit);
   if (gx > nblk) gx = nblk;
-  const dim3 grid((unsigned)gx, (unsigned)nslice, (unsigned)ksplit);
+  dim3 grid((unsigned)gx, (unsigned)nslice, (unsigned)ksplit);
+  static const int xcd_on = getenv("FSF_SCS_XCD") ? atoi(getenv("FSF_SCS_XCD")) : 1;  // (A/B switch, latched)
+  if (xcd_on && gx > 1 && nslice * ksplit >= 8) {  // several row blocks stream the same chunks and there are groups for every XCD
+    a.xcd_lanes = (int)gx;
+    a.nslice = nslice;
+    grid = dim3((unsigned)(8 * gx * ((nslice * ksplit + 7) / 8)), 1, 1);
+  }
 #define FSF_SCS(T_)                                                                                                     \
   do {                                                                                                                 \
     constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 1024;                                                       \

@@ -594,6 +594,10 @@ class _PointLinearFn(torch.autograd.Function):
         half of a Linear over cat([point, group[inv]], 1); its adjoint is the segmented sum of grad over the plan."""
         ctx.save_for_backward(x, weight)
         ctx.has_bias, ctx.plan = bias is not None, plan
+        if _train_wide(x, weight.size(1), weight.size(0)):  # the heads' wide layers: K22h (both operands as f16 hi | lo planes, 3 passes)
+            y = hip_ops.linear_planes_norm_act(hip_ops.rows_to_planes(x), hip_ops.linear_prepare_weight_f16(weight), weight.size(0), 128,
+                                               bias=bias)
+            return hip_ops.gather_rows_add(row_add, plan.inv, y) if row_add is not None else y
         if _train_k22(x, weight.size(0)):  # the product on K22 (split-bf16 matrix cores, fp32-accurate; no norm, no activation)
             return hip_ops.linear_norm_act(x, hip_ops.linear_prepare_weight(weight), weight.size(0), bias=bias,
                                            row_add=row_add, row_add_index=plan.inv if row_add is not None else None)
@@ -606,7 +610,10 @@ class _PointLinearFn(torch.autograd.Function):
         grad = grad.contiguous()
         g_x = None
         if ctx.needs_input_grad[0]:
-            if _train_k22(grad, weight.size(1)):
+            if _train_wide(grad, weight.size(0), weight.size(1)):
+                g_x = hip_ops.linear_planes_norm_act(hip_ops.rows_to_planes(grad), hip_ops.linear_prepare_weight_f16(weight.t().contiguous()),
+                                                     weight.size(1), 128)
+            elif _train_k22(grad, weight.size(1)):
                 g_x = hip_ops.linear_norm_act(grad, hip_ops.linear_prepare_weight(weight.t()), weight.size(1))
             else:
                 g_x = grad @ weight
@@ -624,6 +631,14 @@ class _PointLinearFn(torch.autograd.Function):
 
 
 _TRAIN_K22 = os.environ.get("FSF_TRAIN_K22", "1") != "0"  # (A/B switch)
+_TRAIN_WIDE_MIN_ROWS = int(os.environ.get("FSF_TRAIN_WIDE_MIN_ROWS", "4096"))  # (A/B switch: 1 << 40 restores the library GEMMs)
+
+
+def _train_wide(x, k, c):
+    """Training: a [>= 4096 rows, k] x [k, c] product of the query / refine heads (k, c >= 256: `shared_mlp_dims`, `embed_dims`) on K22h —
+    the library's fp32 GEMMs run these at ~100 TFLOP/s, 36 of them per step."""
+    return (switches.K22H and x.dim() == 2 and x.size(0) >= _TRAIN_WIDE_MIN_ROWS and k % 32 == 0 and k >= 256 and c >= 256 and c % 4 == 0
+            and x.size(1) == k and hip_ops.rows_to_planes_supported(x))
 
 
 def _train_k22(x, out_features):
@@ -758,7 +773,7 @@ def point_linear(linear, x):
     x = materialize_rows(x)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or linear.weight.requires_grad)
     if (needs_grad and linear.weight.requires_grad and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
-            and x.size(0) >= 16384):
+            and (x.size(0) >= 16384 or _train_wide(x, linear.in_features, linear.out_features))):
         return _PointLinearFn.apply(x, linear.weight, linear.bias)
     if (not needs_grad and x.dim() == 2 and linear.out_features % 4 == 0
             and (x.size(0) >= 1024 or (x.size(0) >= _SMALL_N_MIN and linear.in_features <= 256))

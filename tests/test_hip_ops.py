@@ -558,7 +558,8 @@ def test_spconv_forward_subm_vs_oracle(ops, device, cin, cout):
 
 
 @pytest.mark.parametrize("m,cin,cout", [(3000, 16, 16), (3000, 64, 64), (3000, 64, 128), (40000, 128, 128), (20000, 256, 128),
-                                        (3000, 128, 256), (1500, 48, 32)])
+                                        (3000, 128, 256), (1500, 48, 32),
+                                        (1517, 512, 512)])  # the deepest U-Net level: 12 row blocks x 4 slices x 16 k ranges, XCD-aware grid
 def test_spconv_forward_split_vs_oracle_and_fp32_kernel(ops, device, m, cin, cout):
     """K9b (row-stationary, exact bf16 split on the bf16 matrix cores) against the CPU oracle at small sizes and against the
     fp32-pipe kernel at large ones, with the fused epilogue; error vs float64 on sampled rows no larger than fp32's."""
@@ -1255,7 +1256,10 @@ def test_sir_input_vs_torch_composition(ops, device, p, cf, ce, r, act):
                                                  (513, 128, 128, "none", "none", True), (1, 64, 32, "ln", "gelu", False),
                                                  (40000, 128, 64, "affine", "gelu", True),
                                                  (10641, 1024, 1024, "none", "none", True), (5000, 768, 1024, "affine", "relu", False),
-                                                 (3001, 128, 132, "none", "none", True)])
+                                                 (3001, 128, 132, "none", "none", True),
+                                                 # >= 65 536 rows (sizes the weight-resident experiment K22r, profiles/r5_k22r_*, was checked at)
+                                                 (100003, 131, 128, "affine", "relu", False), (80000, 180, 128, "ln", "gelu", True),
+                                                 (65536, 64, 64, "ln", "relu", False)])
 def test_linear_norm_act_split_bf16_is_fp32_accurate(ops, device, n, k, c, norm, act, bias):
     """K22: Linear -> LayerNorm / affine -> act with the product formed from the exact 3-way bf16 split (six cross terms).
     Against float64: the error must be of the size of an fp32 GEMM's own error (compared with torch's fp32 F.linear on the
