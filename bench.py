@@ -622,6 +622,18 @@ def _acc_linear_sliced(a, k, out):
     return ("linear_norm_act", n * 4.0 * (reads + nslice * slice_c), 2.0 * n * kk * nslice * slice_c)
 
 
+def _acc_linear_planes(a, k, out):
+    """K22h: x planes in (4 K B/row + 4 B scale), f32 rows out — the K22 family's bytes and fp32-equivalent flops."""
+    xp, c = a[0], int(a[2])
+    return ("linear_norm_act", xp.n * (4.0 * xp.c + 4.0 + 4.0 * c), 2.0 * xp.n * xp.c * c)
+
+
+def _acc_rows_to_planes(a, k, out):
+    x = a[0]
+    n, c = x.shape
+    return "rows_to_planes", n * (8.0 * c + 4.0 + (4.0 * c if k.get("want_rows") else 0.0)), 0.0  # 4C read, 4C planes (+ 4C rows) written
+
+
 def instrumented_pass(model, pool, steps, hot_path_only):
     """Two passes over the same frames: the sparse-conv forward kernels with HIP events in situ (`steps` frames); the
     scatter / gather / segmented-reduce / projection / fused-linear kernels captured on ONE frame and replayed in isolation.
@@ -659,6 +671,8 @@ def instrumented_pass(model, pool, steps, hot_path_only):
     q.wrap(hip_ops, "linear_norm_act", _acc_linear)
     q.wrap(hip_ops, "linear_norm_act_sliced", _acc_linear_sliced)
     q.wrap(hip_ops, "linear_norm_act_segmax", _acc_linear_segmax)
+    q.wrap(hip_ops, "linear_planes_norm_act", _acc_linear_planes)
+    q.wrap(hip_ops, "rows_to_planes", _acc_rows_to_planes)
     if hasattr(hip_ops, "project_score"):
         q.wrap(hip_ops, "project_score", _acc_project_score)
     try:
@@ -756,6 +770,7 @@ HBM_KERNELS = {
     "sir_input": ("sir_input_kernel",),
     "linear_norm_act": ("linear_norm_act_kernel",),
     "gather_rows": ("gather_rows_kernel",),
+    "rows_to_planes": ("rows_to_planes_kernel",),
     "voxel2point": ("voxel2point_kernel",),
     "project_gather": ("project_gather_kernel",),
     "project_score": ("project_score_kernel",),
