@@ -73,7 +73,7 @@ def lib():
                     "fsf_get_option", "fsf_order_by_neighbor_mask_workspace_bytes",
                     "fsf_class_rank_desc_workspace_bytes", "fsf_nms_select_capacity", "fsf_cluster_key_survival_workspace_bytes",
                     "fsf_overlap_plan_workspace_bytes", "fsf_group_pairs_workspace_bytes",
-                    "fsf_row_planes_bytes", "fsf_linear_prepared_weight_f16_bytes",
+                    "fsf_row_planes_bytes", "fsf_linear_prepared_weight_f16_bytes", "fsf_spconv_split_weight_f16_bytes",
                 ):
                     getattr(h, name).restype = c_i64
                 _lib = h

@@ -23,6 +23,7 @@
 namespace fsf {
 
 typedef __bf16 scs_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 scs_f16x8 __attribute__((ext_vector_type(8)));
 typedef float scs_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned scs_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -49,6 +50,12 @@ struct ScsArgs {
   // xcd_lanes > 0: a 1-D grid of 8 * xcd_lanes * ceil(nslice * ksplit / 8) workgroups in which the xcd_lanes workgroups that stream
   // the SAME weight chunks (one (slice, k range), different row blocks) are congruent modulo 8, i.e. share an XCD and its L2
   int xcd_lanes, nslice;
+  // K9b-XP: `feat` holds the input rows in PLANE form ([row][cin / 8][2][8] f16 hi | lo of x * s_row, fsf_rows_to_planes: the same
+  // 4 cin bytes per row, so every address of the fp32 form stands) with x_inv_scale[row] = 1 / s_row, `planes` = f16 hi | lo weight
+  // fragments behind a 256-byte header (1 / s_w first); three v_mfma_f32_16x16x32_f16 per fp32-equivalent product.  A lane's rows
+  // change scale from offset to offset: the accumulators are kept in the UNIT of the row being multiplied (K9e's scheme) — before an
+  // offset's first MFMA they are multiplied by old unit / new unit, a power of two (exact) — and brought back once at the end.
+  const float* x_inv_scale;
 };
 
 __device__ __forceinline__ void scs_split8(const float (&v)[8], scs_u32x4& hi, scs_u32x4& mid, scs_u32x4& lo) {
@@ -89,9 +96,58 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <int T>
+// ---- K9b-XP weights: one power-of-two scale per layer (s * max |w| in [2^13, 2^14)), hi = rn_f16(w s), lo = rn_f16(w s - hi)
+__device__ __forceinline__ void scs_pick_scale(float amax, float& s, float& inv) {
+  int e = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127;
+  e = amax > 0.0f ? (e < -113 ? -113 : e) : 13;
+  s = __uint_as_float((unsigned)(13 - e + 127) << 23);
+  inv = __uint_as_float((unsigned)(e - 13 + 127) << 23);
+}
+
+__global__ void __launch_bounds__(256) scs_weight_absmax_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ hdr) {
+  __shared__ float wave_max[4];
+  float amax = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) amax = fmaxf(amax, fabsf(w[i]));
+  amax = fsf_wave_max(amax);
+  if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(hdr + 2, __float_as_uint(fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3]))));
+}
+
+__global__ void __launch_bounds__(256)
+    scs_prepare_f16_kernel(const float* __restrict__ w, int kvol, int cin, int cout, int T, int nkc, int nslice, float* __restrict__ hdr,
+                           uint4* __restrict__ planes) {
+  float s_w, inv_w;
+  scs_pick_scale(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[2]), s_w, inv_w);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = inv_w; hdr[1] = s_w; }
+  const int64_t total = (int64_t)nslice * kvol * nkc * T * 64;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(idx & 63);
+    int64_t r = idx >> 6;
+    const int t = (int)(r % T); r /= T;
+    const int kc = (int)(r % nkc); r /= nkc;
+    const int k = (int)(r % kvol);
+    const int slice = (int)(r / kvol);
+    const int col = 128 * slice + 16 * t + (lane & 15), c0 = kc * SCS_KC + 8 * (lane >> 4);
+    scs_f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (col < cout && c0 + e < cin) ? w[((int64_t)k * cin + c0 + e) * cout + col] : 0.0f;
+      const float xs = __fmul_rn(v, s_w);
+      h[e] = (_Float16)xs;
+      l[e] = (_Float16)__fsub_rn(xs, (float)h[e]);
+    }
+    const scs_u32x4 hi = __builtin_bit_cast(scs_u32x4, h), lo = __builtin_bit_cast(scs_u32x4, l);
+    uint4* dst = planes + ((((int64_t)slice * kvol + k) * nkc + kc) * T + t) * 2 * 64 + lane;
+    dst[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    dst[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
+template <int T, bool XP = false>
 __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(ScsArgs a) {
-  constexpr int CHUNK_U4 = T * 3 * 64;
+  constexpr int NPL = XP ? 2 : 3;
+  constexpr int CHUNK_U4 = T * NPL * 64;
   extern __shared__ __attribute__((aligned(16))) char scs_smem[];
   uint4* wbuf = reinterpret_cast<uint4*>(scs_smem);  // [2][CHUNK_U4], then scale | shift of this 128-channel slice
   float* vec = reinterpret_cast<float*>(wbuf + 2 * CHUNK_U4);
@@ -116,7 +172,7 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
   const int ci_begin = (int)((int64_t)nchunks * bz / a.ksplit), ci_end = (int)((int64_t)nchunks * (bz + 1) / a.ksplit);
   const int64_t nblk = (a.m_out + SCS_ROWS - 1) / SCS_ROWS;
   const int ch_base = 128 * by;
-  const uint4* planes = a.planes + (int64_t)by * nchunks * CHUNK_U4;
+  const uint4* planes = a.planes + (XP ? 16 : 0) + (int64_t)by * nchunks * CHUNK_U4;  // (XP: behind the 256-byte header)
   const int last_quad = a.cin - 4;
   // The epilogue's per-channel vectors go through LDS, and its residual row is loaded before the first store: as plain
   // global loads inside the tile loop each one sat behind the previous tile's store (the pointers may alias) — ~48
@@ -171,6 +227,14 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
     };
     float xc[SCS_RG][8];
     load_x(idx_cur, kc, xc);
+    // XP: inverse row scale of the rows in `xc` (the chunk multiplied next) and the unit the accumulators are currently kept in
+    float sc_x[SCS_RG], inv_cur[SCS_RG];
+#pragma unroll
+    for (int rg = 0; rg < SCS_RG; ++rg) {
+      inv_cur[rg] = 1.0f;
+      sc_x[rg] = 1.0f;
+      if constexpr (XP) sc_x[rg] = a.x_inv_scale[idx_cur[rg] < 0 ? 0 : idx_cur[rg]];
+    }
     const bool tail_chunks = (a.cin % SCS_KC) != 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every wave is done with both weight buffers of the previous row block
@@ -181,11 +245,31 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
       // ---- split the chunk that arrived while the previous one was multiplied
       scs_u32x4 xh[SCS_RG], xm[SCS_RG], xl[SCS_RG];
       bool any_live = false;
+      if constexpr (XP) {  // first chunk of an offset (or of this workgroup's k range): the accumulators move to the new rows' unit
+        if (ci == ci_begin || kc == 0) {
+#pragma unroll
+          for (int rg = 0; rg < SCS_RG; ++rg) {
+            if (idx_cur[rg] >= 0) {
+              const float ratio = inv_cur[rg] * __uint_as_float(0x7f000000u - __float_as_uint(sc_x[rg]));  // old unit / new unit: a power of two
+#pragma unroll
+              for (int t = 0; t < T; ++t) acc[rg][t] = acc[rg][t] * ratio;
+              inv_cur[rg] = sc_x[rg];
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int rg = 0; rg < SCS_RG; ++rg) {
         const bool live = idx_cur[rg] >= 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) xc[rg][e] = live ? xc[rg][e] : 0.0f;  // a missing neighbour contributes zeros
+        if constexpr (XP) {  // the planes ARE the operands (cin is a multiple of 32 here)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xh[rg][e] = __float_as_uint(xc[rg][e]); xl[rg][e] = __float_as_uint(xc[rg][4 + e]); }
+          xm[rg] = xh[rg];
+          any_live |= live;
+          continue;
+        }
         if (tail_chunks) {  // (uniform) a chunk can reach past cin only when cin is not a multiple of 32
 #pragma unroll
           for (int e = 0; e < 8; ++e)
@@ -209,6 +293,12 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
       if (ci + 1 < ci_end) {
         stage_w(ci + 1, buf ^ 1);
         load_x(idx_cur, nkci, xc);
+        if constexpr (XP) {
+          if (nk != k) {
+#pragma unroll
+            for (int rg = 0; rg < SCS_RG; ++rg) sc_x[rg] = a.x_inv_scale[idx_cur[rg] < 0 ? 0 : idx_cur[rg]];
+          }
+        }
         if (nk != k) {  // first chunk of a new offset: fetch the ids of the offset after it
 #pragma unroll
           for (int rg = 0; rg < SCS_RG; ++rg) idx_nxt[rg] = nk + 1 < a.kvol ? nrow[rg][nk + 1] : -1;
@@ -219,6 +309,30 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
       (void)k_this;
       if (wave_live) {
         const uint4* wc = wbuf + buf * CHUNK_U4;
+        if constexpr (XP) {
+#pragma unroll
+          for (int t = 0; t < T; t += 2) {
+            scs_f16x8 wfr[2][2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+              const uint4* wf = wc + ((t + tt) * 2) * 64 + lane;
+#pragma unroll
+              for (int pl = 0; pl < 2; ++pl) wfr[tt][pl] = __builtin_bit_cast(scs_f16x8, wf[64 * pl]);
+            }
+            constexpr int TERM_W[3] = {1, 0, 0};  // (weight plane, x plane): lo hi, hi lo, hi hi — small terms first
+            constexpr int TERM_X[3] = {0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+              for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int rg = 0; rg < SCS_RG; ++rg) {
+                  const scs_u32x4 xb = TERM_X[term] == 0 ? xh[rg] : xl[rg];
+                  acc[rg][t + tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfr[tt][TERM_W[term]], __builtin_bit_cast(scs_f16x8, xb),
+                                                                           acc[rg][t + tt], 0, 0, 0);
+                }
+          }
+        } else {
 #pragma unroll
         for (int t = 0; t < T; t += 2) {
           scs_bf16x8 wfr[2][3];
@@ -245,6 +359,16 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
 #endif
               }
         }
+        }
+      }
+    }
+    if constexpr (XP) {  // back from the last rows' unit (and the weights') to the plain product
+      const float w_inv = *reinterpret_cast<const float*>(a.planes);
+#pragma unroll
+      for (int rg = 0; rg < SCS_RG; ++rg) {
+        const float sc = inv_cur[rg] * w_inv;
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[rg][t] = acc[rg][t] * sc;
       }
     }
     // ---- epilogue: lane (row, g) holds channels ch_base + 16 t + 4 g + r of its row
@@ -383,7 +507,7 @@ extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t
   const int ksplit = scs_ksplit(m_out, cin, cout, kvol);
   if (ksplit > 1 && (!workspace || workspace_bytes < fsf_spconv_split_workspace_bytes(m_out, cin, cout, kvol))) return FSF_ERR_WORKSPACE;
   ScsArgs a{feat, (const uint4*)planes, nbr, scale, shift, residual, out, (float*)workspace, m_in, m_out,
-            (int)cin, (int)cout, (int)kvol, (int)relu, ksplit, 0, 0};
+            (int)cin, (int)cout, (int)kvol, (int)relu, ksplit, 0, 0, nullptr};
   const int64_t nblk = (m_out + SCS_ROWS - 1) / SCS_ROWS;
   const int nslice = scs_slices(cout);
   int64_t gx = (256 * SCS_WPS + nslice * ksplit - 1) / (nslice * ksplit);
@@ -407,6 +531,67 @@ extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t
 #undef FSF_SCS
   if (ksplit > 1)
     hipLaunchKernelGGL(scs_fold_kernel, dim3(fsf_stream_grid(m_out * (cout / 4), 256)), dim3(256), 0, stream, a);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+// ---- K9b-XP entry points -----------------------------------------------------------------------------------------------------
+extern "C" int64_t fsf_spconv_split_weight_f16_bytes(int32_t kvol, int32_t cin, int32_t cout) {
+  if (kvol < 1 || cin < 1 || cout < 1) return 0;
+  const int64_t nkc = (cin + SCS_KC - 1) / SCS_KC;
+  return 256 + (int64_t)scs_slices(cout) * kvol * nkc * scs_tiles(cout) * 2 * 64 * 16;
+}
+
+extern "C" int fsf_spconv_prepare_weight_split_f16(const float* weight, int32_t kvol, int32_t cin, int32_t cout, void* planes,
+                                                   void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!weight || !planes || kvol < 1 || cin < 1 || cout < 1) return FSF_ERR_INVALID_ARG;
+  if (((uintptr_t)planes % 16) != 0) return FSF_ERR_UNSUPPORTED;
+  const int T = scs_tiles(cout), nkc = (cin + SCS_KC - 1) / SCS_KC, nslice = scs_slices(cout);
+  FSF_HIP_TRY(hipMemsetAsync(planes, 0, 256, stream));
+  const int64_t nw = (int64_t)kvol * cin * cout;
+  hipLaunchKernelGGL(scs_weight_absmax_kernel, dim3(fsf_stream_grid(nw, 256)), dim3(256), 0, stream, weight, nw, (unsigned*)planes);
+  FSF_LAUNCH_CHECK();
+  const int64_t total = (int64_t)nslice * kvol * nkc * T * 64;
+  hipLaunchKernelGGL(scs_prepare_f16_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)kvol, (int)cin,
+                     (int)cout, T, nkc, nslice, (float*)planes, (uint4*)planes + 16);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_spconv_forward_split_planes(const void* feat_planes, const float* feat_inv_scales, int64_t m_in, int32_t cin,
+                                               const void* planes, int32_t kvol, int32_t cout, const int32_t* nbr, int64_t m_out,
+                                               const float* scale, const float* shift, const float* residual, int32_t relu,
+                                               float* out, void* workspace, int64_t workspace_bytes, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m_in < 0 || m_out < 0 || cin < 1 || cout < 1 || kvol < 1 || !planes || (scale && !shift) ||
+      (m_out > 0 && (!nbr || !out)) || (m_in > 0 && (!feat_planes || !feat_inv_scales)))
+    return FSF_ERR_INVALID_ARG;
+  // whole 32-cin chunks (the plane rows are cin * 4 bytes: every address of the fp32 form stands), 128-channel tiles
+  if ((cin % 32) != 0 || (cout % 4) != 0 || scs_tiles(cout) != 8 || ((uintptr_t)feat_planes % 16) != 0 || ((uintptr_t)out % 16) != 0 ||
+      ((uintptr_t)planes % 16) != 0)
+    return FSF_ERR_UNSUPPORTED;
+  if (m_out == 0) return FSF_OK;
+  if (m_in == 0) return FSF_ERR_INVALID_ARG;
+  const int ksplit = scs_ksplit(m_out, cin, cout, kvol);
+  if (ksplit > 1 && (!workspace || workspace_bytes < fsf_spconv_split_workspace_bytes(m_out, cin, cout, kvol))) return FSF_ERR_WORKSPACE;
+  ScsArgs a{(const float*)feat_planes, (const uint4*)planes, nbr, scale, shift, residual, out, (float*)workspace, m_in, m_out,
+            (int)cin, (int)cout, (int)kvol, (int)relu, ksplit, 0, 0, feat_inv_scales};
+  const int64_t nblk = (m_out + SCS_ROWS - 1) / SCS_ROWS;
+  const int nslice = scs_slices(cout);
+  int64_t gx = (256 * SCS_WPS + nslice * ksplit - 1) / (nslice * ksplit);
+  if (gx > nblk) gx = nblk;
+  dim3 grid((unsigned)gx, (unsigned)nslice, (unsigned)ksplit);
+  if (gx > 1 && nslice * ksplit >= 8) {
+    a.xcd_lanes = (int)gx;
+    a.nslice = nslice;
+    grid = dim3((unsigned)(8 * gx * ((nslice * ksplit + 7) / 8)), 1, 1);
+  }
+  constexpr size_t smem = (size_t)2 * 8 * 2 * 64 * 16 + 1024;
+  static std::atomic<uint64_t> attr_done{0};
+  FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_fwd_split_kernel<8, true>, (int)smem, attr_done));
+  hipLaunchKernelGGL((spconv_fwd_split_kernel<8, true>), grid, dim3(SCS_NW * 64), smem, stream, a);
+  if (ksplit > 1) hipLaunchKernelGGL(scs_fold_kernel, dim3(fsf_stream_grid(m_out * (cout / 4), 256)), dim3(256), 0, stream, a);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

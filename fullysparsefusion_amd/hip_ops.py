@@ -125,6 +125,9 @@ _ARGTYPES = {
     "fsf_linear_prepared_weight_f16_bytes": [c_i32, c_i32, c_i32],
     "fsf_linear_prepare_weight_f16": [_P, c_i32, c_i32, c_i32, _P, _P],
     "fsf_linear_planes_norm_act": [_P, _P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
+    "fsf_spconv_split_weight_f16_bytes": [c_i32, c_i32, c_i32],
+    "fsf_spconv_prepare_weight_split_f16": [_P, c_i32, c_i32, c_i32, _P, _P],
+    "fsf_spconv_forward_split_planes": [_P, _P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
 }
 _configured = False
 
@@ -773,6 +776,44 @@ def spconv_forward_split(feat: torch.Tensor, planes: torch.Tensor, kvol: int, co
     check(h.fsf_spconv_forward_split(ptr(feat), m_in, cin, ptr(planes), kvol, cout, ptr(nbr), m_out, ptr(scale), ptr(shift),
                                      ptr(residual), int(bool(relu)), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
           "fsf_spconv_forward_split")
+    return out
+
+
+def spconv_prepare_weight_split_f16(weight: torch.Tensor):
+    """fsf_spconv_prepare_weight_split_f16: spconv v1 weight f32 [kvol, cin, cout] -> header + f16 hi | lo fragment planes (K9b-XP)."""
+    require_cuda(weight)
+    weight = weight.detach().contiguous()
+    kvol, cin, cout = weight.shape
+    h = _L()
+    planes = torch.empty(h.fsf_spconv_split_weight_f16_bytes(kvol, cin, cout), dtype=torch.uint8, device=weight.device)
+    check(h.fsf_spconv_prepare_weight_split_f16(ptr(weight), kvol, cin, cout, ptr(planes), stream_ptr()),
+          "fsf_spconv_prepare_weight_split_f16")
+    return planes
+
+
+def spconv_split_planes_supported(cin: int, cout: int) -> bool:
+    return cin % 32 == 0 and cout % 4 == 0 and cout > 64
+
+
+def spconv_forward_split_planes(xp, planes: torch.Tensor, kvol: int, cout: int, nbr: torch.Tensor, scale=None, shift=None,
+                                residual=None, relu=False):
+    """fsf_spconv_forward_split_planes (K9b-XP): xp = RowPlanes of the input rows (rows_to_planes), planes from
+    spconv_prepare_weight_split_f16, nbr i32 [m_out, kvol] -> out f32 [m_out, cout]."""
+    require_cuda(xp.data, planes, nbr, scale, shift, residual)
+    nbr = nbr.contiguous()
+    assert nbr.size(1) == kvol and nbr.dtype == torch.int32
+    m_in, cin, m_out = xp.n, xp.c, nbr.size(0)
+    out = torch.empty((m_out, cout), dtype=torch.float32, device=nbr.device)
+    scale = scale.contiguous() if scale is not None else None
+    shift = shift.contiguous() if shift is not None else None
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == (m_out, cout)
+    h = _L()
+    ws = _lib.workspace(h.fsf_spconv_split_workspace_bytes(m_out, cin, cout, kvol), nbr.device)
+    check(h.fsf_spconv_forward_split_planes(ptr(xp.data), ptr(xp.inv_scales), m_in, cin, ptr(planes), kvol, cout, ptr(nbr), m_out,
+                                            ptr(scale), ptr(shift), ptr(residual), int(bool(relu)), ptr(out), ptr(ws), ws.numel(),
+                                            stream_ptr()), "fsf_spconv_forward_split_planes")
     return out
 
 

@@ -246,6 +246,16 @@ class SparseConvolution(SparseModule):
             self.__dict__["_wsplit_cache"] = cache
         return cache[1]
 
+    def _weight_split_f16(self):
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        cache = self.__dict__.get("_wsplit16_cache")
+        if cache is None or cache[0] != key:
+            kvol = math.prod(self.kernel_size)
+            cache = (key, hip_ops.spconv_prepare_weight_split_f16(w.detach().reshape(kvol, self.in_channels, self.out_channels)))
+            self.__dict__["_wsplit16_cache"] = cache
+        return cache[1]
+
     # K9c (pre-split f16 planes, cell skipping): every layer whose sources are <= 128 channels wide — submanifold, strided and
     # inverse alike (the kernel only sees a neighbour table).  Below ~4 k output rows the launch does not fill the chip and
     # K9b's offset splits win.
@@ -316,8 +326,14 @@ class SparseConvolution(SparseModule):
             y.plane_sources = [planes] if planes is not None else None
             return y
         elif self._use_split_kernel(nbr.size(0)) and feat.size(0) > 0:
-            out = hip_ops.spconv_forward_split(feat, self._weight_split(), nbr.size(1), self.out_channels, nbr, scale=scale,
-                                               shift=shift, residual=residual, relu=relu)
+            if (switches.SPLIT_F16 and hip_ops.spconv_split_planes_supported(self.in_channels, self.out_channels)
+                    and hip_ops.rows_to_planes_supported(feat)):
+                # K9b-XP: the deep levels (512 / 1024 input channels on a few thousand rows) with both operands as f16 planes
+                out = hip_ops.spconv_forward_split_planes(hip_ops.rows_to_planes(feat), self._weight_split_f16(), nbr.size(1),
+                                                          self.out_channels, nbr, scale=scale, shift=shift, residual=residual, relu=relu)
+            else:
+                out = hip_ops.spconv_forward_split(feat, self._weight_split(), nbr.size(1), self.out_channels, nbr, scale=scale,
+                                                   shift=shift, residual=residual, relu=relu)
         else:
             out = hip_ops.spconv_forward(feat, self._weight_t(), nbr, scale=scale, shift=shift, residual=residual,
                                          relu=relu)

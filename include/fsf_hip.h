@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 14
+#define FSF_ABI_VERSION 15
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -521,6 +521,19 @@ int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t cin, const
                              const int32_t* nbr, int64_t m_out, const float* scale, const float* shift,
                              const float* residual, int32_t relu, float* out, void* workspace, int64_t workspace_bytes,
                              void* stream);
+/* K9b-XP (round 5): the same convolution with BOTH operands as f16 hi | lo planes (three v_mfma_f32_16x16x32_f16 per fp32-equivalent
+ * product instead of six bf16 ones, nothing split inside the kernel) for the layers K9c / K9d do not take — the deep U-Net levels of
+ * SimpleSparseUNet [UNVENDORED] (512 / 1024 input channels on a few thousand rows).  feat_planes / feat_inv_scales = the input rows
+ * through fsf_rows_to_planes (one power-of-two scale per ROW; the rows a lane gathers change scale from offset to offset, so the
+ * accumulators are kept in the unit of the row being multiplied and moved by exact power-of-two ratios); planes from
+ * fsf_spconv_prepare_weight_split_f16 (256-byte header: 1 / s_w, s_w, max |w|).  cin % 32 == 0, cout > 64; workspace as
+ * fsf_spconv_split_workspace_bytes.  Same epilogue, same k-split + fold, same XCD-aware layout as fsf_spconv_forward_split. */
+int64_t fsf_spconv_split_weight_f16_bytes(int32_t kvol, int32_t cin, int32_t cout);
+int fsf_spconv_prepare_weight_split_f16(const float* weight, int32_t kvol, int32_t cin, int32_t cout, void* planes, void* stream);
+int fsf_spconv_forward_split_planes(const void* feat_planes, const float* feat_inv_scales, int64_t m_in, int32_t cin,
+                                    const void* planes, int32_t kvol, int32_t cout, const int32_t* nbr, int64_t m_out,
+                                    const float* scale, const float* shift, const float* residual, int32_t relu, float* out,
+                                    void* workspace, int64_t workspace_bytes, void* stream);
 
 /* K9c  the submanifold convolution on the f16 matrix cores from PRE-SPLIT FEATURE PLANES (inference; replaces the
  * gather -> GEMM -> scatter-add loop of spconv v1 `indice_conv`, [UNVENDORED] mmdet3d fork, for the SubMConv3d layers

@@ -2011,3 +2011,42 @@ def test_wide_mlp_chain_on_planes_equals_the_k22_path(ops, device, monkeypatch):
         a, b = got[name].double(), ref[name].double()
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), name
+
+
+@pytest.mark.parametrize("m,cin,cout", [(3000, 64, 128), (3000, 128, 256), (1517, 512, 512), (1517, 1024, 512), (7441, 512, 256),
+                                        (20000, 256, 128), (130, 32, 68)])
+def test_spconv_forward_split_planes_f16x3_vs_float64(ops, device, m, cin, cout):
+    """K9b-XP (`fsf_spconv_forward_split_planes`: K9b with both operands as f16 hi | lo planes, per-ROW input scales, the accumulators
+    moved between the rows' units by power-of-two ratios) against float64 on sampled rows — <= 1e-5 of the output scale with rows
+    spanning e^+-1 in magnitude and weights down to 1e-3 of the layer maximum —, against K9b (bf16 x 6), with the fused epilogue,
+    over the k-split + XCD-aware layout of the deep levels (1517 rows) and the unsplit one (20 000 rows); deterministic."""
+    rng = np.random.default_rng(m + cin + cout)
+    shape = (16, 48, 48) if m <= 8000 else (40, 512, 512)
+    idx = surface_sites(rng, 2 if m <= 8000 else 1, shape, m)
+    n = idx.shape[0]
+    feat = (rng.standard_normal((n, cin)) * np.exp(rng.standard_normal((n, 1)))).astype(np.float32)
+    feat[3 % n] = 0.0  # an all-zero row (scale of an empty row)
+    w = (rng.standard_normal((27, cin, cout)) / np.sqrt(cin * 6)).astype(np.float32)
+    w[:, :, ::5] *= 1e-3
+    nbr = ops.rulebook_subm(torch.from_numpy(idx).to(device), 2 if m <= 8000 else 1, shape)
+    f, wd = torch.from_numpy(feat).to(device), torch.from_numpy(w).to(device)
+    assert ops.spconv_split_planes_supported(cin, cout)
+    wp = ops.spconv_prepare_weight_split_f16(wd)
+    xp = ops.rows_to_planes(f)
+    out = ops.spconv_forward_split_planes(xp, wp, 27, cout, nbr)
+    rows = torch.from_numpy(rng.choice(n, size=min(n, 512), replace=False)).to(device)
+    nb = nbr.index_select(0, rows).long()
+    gathered = torch.where((nb >= 0)[:, :, None], f.double()[nb.clamp(min=0)], torch.zeros((), dtype=torch.float64, device=device))
+    want64 = torch.einsum("rkc,kcd->rd", gathered, wd.double())
+    scale_ = max(1.0, float(want64.abs().max()))
+    err = float((out.index_select(0, rows).double() - want64).abs().max())
+    assert err <= 1e-5 * scale_, err / scale_
+    ref = ops.spconv_forward_split(f, ops.spconv_prepare_weight_split(wd), 27, cout, nbr)
+    assert float((out - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(device)
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(device)
+    res = torch.from_numpy(rng.standard_normal((n, cout)).astype(np.float32)).to(device)
+    out2 = ops.spconv_forward_split_planes(xp, wp, 27, cout, nbr, scale=sc, shift=sh, residual=res, relu=True)
+    want2 = torch.relu(out * sc + sh + res)
+    assert float((out2 - want2).abs().max()) <= 1e-5 * max(1.0, float(want2.abs().max()))
+    assert torch.equal(out2, ops.spconv_forward_split_planes(xp, wp, 27, cout, nbr, scale=sc, shift=sh, residual=res, relu=True))

@@ -45,5 +45,11 @@ for i, (m, feat, nbr, kw) in enumerate(calls):
     else:
         c, tp, d, tf = float('nan'), float('nan'), float('nan'), float('nan')
     tot[0] += b; tot[1] += c if c == c else b; tot[2] += min(b, c) if c == c else b
-    print(f"{i:3d} {nbr.shape[0]:7d} {cin:5d} {cout:5d} {pairs / nbr.shape[0]:6.2f} {b:9.1f} {c:9.1f} {tp:9.1f} {d:13.2e}  {tf:7.1f}")
+    xp_us = xp_conv = float('nan')
+    if hasattr(hip_ops, "spconv_forward_split_planes") and hip_ops.spconv_split_planes_supported(cin, cout) and hip_ops.rows_to_planes_supported(feat):
+        w16 = hip_ops.spconv_prepare_weight_split_f16(w)
+        xpl = hip_ops.rows_to_planes(feat)
+        xp_us = t(lambda: hip_ops.spconv_forward_split_planes(xpl, w16, kvol, cout, nbr, **kw))
+        xp_conv = t(lambda: hip_ops.rows_to_planes(feat))
+    print(f"{i:3d} {nbr.shape[0]:7d} {cin:5d} {cout:5d} {pairs / nbr.shape[0]:6.2f} {b:9.1f} {c:9.1f} {tp:9.1f} {d:13.2e}  {tf:7.1f}   K9b-XP {xp_us:7.1f} + planes {xp_conv:5.1f}")
 print('total K9b', round(tot[0], 1), 'K9c-where-supported', round(tot[1], 1), 'best-of', round(tot[2], 1))
