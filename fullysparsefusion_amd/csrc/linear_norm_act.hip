@@ -974,7 +974,8 @@ extern "C" int fsf_linear_prepare_weight_f16(const float* weight, int32_t k, int
   const int T = lna_tiles(slice_c), nkc = (k + LNA_KC - 1) / LNA_KC, nslice = (c + slice_c - 1) / slice_c;
   FSF_HIP_TRY(hipMemsetAsync(planes, 0, 256, stream));
   const int64_t nw = (int64_t)c * k;
-  hipLaunchKernelGGL(lna_weight_absmax_kernel, dim3(fsf_stream_grid(nw, 256)), dim3(256), 0, stream, weight, nw, (unsigned*)planes);
+  // (at most 256 workgroups: each ends in ONE atomic on the same word — 2 048 of them took 25 us for a 1 M-element weight)
+  hipLaunchKernelGGL(lna_weight_absmax_kernel, dim3(std::min(fsf_stream_grid(nw, 256), 256)), dim3(256), 0, stream, weight, nw, (unsigned*)planes);
   FSF_LAUNCH_CHECK();
   const int64_t total = (int64_t)nslice * nkc * T * 64;
   hipLaunchKernelGGL(lna_prepare_f16_kernel, dim3(fsf_stream_grid(total, 256)), dim3(256), 0, stream, weight, (int)k, (int)c, T, nkc,
