@@ -326,7 +326,8 @@ class SparseConvolution(SparseModule):
             y.plane_sources = [planes] if planes is not None else None
             return y
         elif self._use_split_kernel(nbr.size(0)) and feat.size(0) > 0:
-            if (switches.SPLIT_F16 and hip_ops.spconv_split_planes_supported(self.in_channels, self.out_channels)
+            if (switches.SPLIT_F16 and self.in_channels >= 256  # (measured at 256 .. 1024 input channels; below, the conversion is the gain)
+                    and hip_ops.spconv_split_planes_supported(self.in_channels, self.out_channels)
                     and hip_ops.rows_to_planes_supported(feat)):
                 # K9b-XP: the deep levels (512 / 1024 input channels on a few thousand rows) with both operands as f16 planes
                 out = hip_ops.spconv_forward_split_planes(hip_ops.rows_to_planes(feat), self._weight_split_f16(), nbr.size(1),
