@@ -32,6 +32,19 @@ typedef _Float16 lna_f16x4 __attribute__((ext_vector_type(4)));
 typedef float lna_f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned lna_u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef FSF_LNA_TIMELINE  // profiling build only (tools/profiling/lna_timeline.sh): where a workgroup's wave 0 spends its clocks
+__device__ unsigned long long lna_tl[16];
+struct LnaTl {
+  unsigned long long last, acc[8];
+  __device__ __forceinline__ void start() { last = __builtin_readcyclecounter(); for (int i = 0; i < 8; ++i) acc[i] = 0; }
+  __device__ __forceinline__ void mark(int i) { const unsigned long long now = __builtin_readcyclecounter(); acc[i] += now - last; last = now; }
+};
+#define LNA_TL_MARK(tl, i) (tl).mark(i)
+#else
+struct LnaTl {};
+#define LNA_TL_MARK(tl, i) ((void)0)
+#endif
+
 constexpr int LNA_KC = 32;        // k per LDS chunk (one MFMA k step)
 constexpr int LNA_NW = 4;         // waves per workgroup (two workgroups per CU: one wave of each per SIMD)
 constexpr int LNA_RG = 2;         // 16-row groups per wave and iteration
@@ -451,7 +464,7 @@ template <int T, bool SEG = false, int NORM_CT = -1, int ACT_CT = -1>  // SEG: t
 // max-scan; NORM_CT / ACT_CT >= 0: norm and activation fixed at compile time (the K22s variants: their epilogue is already twice
 // the code, and the run-time switches of the plain kernel would double it again)
 __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[LNA_RG][T], int64_t row0, int ch_base, int rowl,
-                                             int grp, const float* vec, const LnaSegBlock* sb = nullptr) {
+                                             int grp, const float* vec, LnaTl& tl, const LnaSegBlock* sb = nullptr) {
   const float inv_c = 1.0f / (float)a.norm_w;
   // the arithmetic below runs on pairs (v_pk_*_f32): the same IEEE operations per value as the scalar form, half the instructions
   auto lo = [](const lna_f32x4& v) { return lna_f32x2{v[0], v[1]}; };
@@ -495,6 +508,7 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
         }
       }
     }
+    LNA_TL_MARK(tl, 2);  // segment context + bias + the per-row addend (its gather is waited for here)
     if ((NORM_CT >= 0 ? NORM_CT : a.norm) == 1) {  // LayerNorm over the c channels (channels >= c are exactly 0: zero weights, no bias)
       lna_f32x2 s2 = lna_pk(0.0f);
 #pragma unroll
@@ -511,6 +525,7 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
       }
       rstd = rsqrtf(lna_row_sum(q2.x + q2.y) * inv_c + a.eps);
     }
+    LNA_TL_MARK(tl, 3);  // LayerNorm statistics
     if (row < a.n || SEG) {
       float* orow = a.out + row * a.out_stride;
       const lna_f32x2 m2 = lna_pk(mean), r2 = lna_pk(rstd);
@@ -538,6 +553,7 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
         }
       }
     }
+    LNA_TL_MARK(tl, 4);  // affine + activation + stores (+ the segmented scan and its run stores)
   }
 }
 
@@ -634,9 +650,31 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
 #define LNA_BLK_END nblk
 #define LNA_BLK_STEP blk_step_
   lna_stage_vectors(a, ch_base, vec);
+  LnaTl tl;
+#ifdef FSF_LNA_TIMELINE
+  tl.start();
+#endif
+  // The per-row addend (`cat([point, group[inv]]) W^T` = point W_left^T + (group W_right^T)[inv]) enters through the ACCUMULATORS: they
+  // start a row block as the gathered addend rows instead of zeros, the MFMAs accumulate on top.  In the epilogue (round 4) the gather
+  // was four exposed round trips per block — index, then 4 + 4 tiles per row group, twice — 20 % of the grouped K22s kernel
+  // (profiles/r5_lna_timeline.txt); now the index of the NEXT block's rows is fetched under the chunk loop and the 16 row loads of a
+  // block are in flight together, into registers that are free at that point, behind the first chunk's split.
+  int64_t radd_idx[LNA_RG];
+  auto fetch_addend_index = [&](int64_t blk) {
+    if (a.row_add) {
+#pragma unroll
+      for (int rg = 0; rg < LNA_RG; ++rg) {
+        const int64_t r = blk * LNA_ROWS + (int64_t)wave * (LNA_RG * 16) + 16 * rg + rowl;
+        radd_idx[rg] = a.row_add_index[r < a.n ? r : a.n - 1];
+      }
+    }
+  };
+  LnaArgs a_epi = a;  // (the epilogue's copy: the addend is already in the accumulators)
+  a_epi.row_add = nullptr;
   float xc[LNA_RG][8];
   int buf = 0;
   if (blk_first < LNA_BLK_END) {
+    fetch_addend_index(blk_first);
     set_rows(blk_first);
     load_x(0, xc);
     stage_w(0, 0);
@@ -658,6 +696,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
     for (int rg = 0; rg < LNA_RG; ++rg)
 #pragma unroll
       for (int t = 0; t < T; ++t) acc[rg][t] = lna_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.row_add) {
+#pragma unroll
+      for (int rg = 0; rg < LNA_RG; ++rg) {
+        const float* add = a.row_add + radd_idx[rg] * a.row_add_stride;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const int lc0 = 16 * t + 4 * grp, ch0 = ch_base + lc0;
+          if (lc0 < a.slice_w && ch0 < a.c) {
+            const float4 b = *reinterpret_cast<const float4*>(add + ch0);
+            acc[rg][t] = lna_f32x4{b.x, b.y, b.z, b.w};
+          }
+        }
+      }
+    }
     float xinv[LNA_RG];
     if constexpr (XP) {  // the rows' inverse scales (requested here, used after the chunk loop)
 #pragma unroll
@@ -700,9 +752,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
       }
       // this chunk's weights (DMA issued one iteration ago, before that iteration's MFMAs) have landed; the raw barrier
       // carries no fence, so nothing else is drained with them
+      LNA_TL_MARK(tl, 0);  // chunk work: the previous chunk's MFMAs (issue), this chunk's split
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // + every wave is done reading buffer buf^1
       asm volatile("" ::: "memory");
+      LNA_TL_MARK(tl, 1);  // waiting: this chunk's x and weights, the LDS reads, the barrier
       if (kc + 1 < nkc) {
         stage_w(kc + 1, buf ^ 1);
         load_x(kc + 1, xc);
@@ -712,6 +766,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
         stage_w(0, buf ^ 1);
         set_rows(blk + LNA_BLK_STEP);
         load_x(0, xc);
+        fetch_addend_index(blk + LNA_BLK_STEP);
       }
 #endif
       const uint4* wc = wbuf + buf * CHUNK_U4;
@@ -786,14 +841,23 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
       __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS reads of the last chunk have returned ...
       __builtin_amdgcn_s_barrier();        // ... and so have every other wave's: the slots may overlay that buffer
       if (lane < 4) segsm->slot_sid[4 * wave + lane] = -1;
-      lna_epilogue<T, true, NORM_CT, ACT_CT>(a, acc, row0, ch_base, rowl, grp, vec, &sb);
+      LNA_TL_MARK(tl, 0);  // (the last chunk's MFMAs + the barrier that frees the slot buffer)
+      lna_epilogue<T, true, NORM_CT, ACT_CT>(a_epi, acc, row0, ch_base, rowl, grp, vec, tl, &sb);
       lna_seg_merge(a, slots, segsm);
+      LNA_TL_MARK(tl, 5);  // the block's slot merge (a barrier + 128 threads)
     } else {
-      lna_epilogue<T, false>(a, acc, row0, ch_base, rowl, grp, vec);
+      LNA_TL_MARK(tl, 0);
+      lna_epilogue<T, false>(a_epi, acc, row0, ch_base, rowl, grp, vec, tl);
     }
   }
 #undef LNA_BLK_END
 #undef LNA_BLK_STEP
+#ifdef FSF_LNA_TIMELINE
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&lna_tl[i], tl.acc[i]);
+    atomicAdd(&lna_tl[8], 1ull);
+  }
+#endif
 }
 
 }  // namespace fsf
@@ -1037,3 +1101,15 @@ extern "C" int fsf_linear_planes_norm_act(const void* x_planes, const float* x_i
             (int)c, nullptr, nullptr, 0, (int)slice_c, (int)slice_c, 0, nullptr, nullptr, 0, x_inv_scales};
   return lna_launch(a, nslice, stream, true);
 }
+
+#ifdef FSF_LNA_TIMELINE
+// profiling build only: clocks wave 0 of every workgroup spent per phase since the last reset ([8] = workgroups counted)
+extern "C" int fsf_debug_lna_timeline(unsigned long long* host16, int reset) {
+  if (host16 && hipMemcpyFromSymbol(host16, HIP_SYMBOL(fsf::lna_tl), 16 * sizeof(unsigned long long)) != hipSuccess) return FSF_ERR_HIP;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fsf::lna_tl), z, sizeof(z)) != hipSuccess) return FSF_ERR_HIP;
+  }
+  return FSF_OK;
+}
+#endif
