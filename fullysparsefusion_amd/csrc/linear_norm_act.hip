@@ -538,7 +538,9 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
           const lna_f32x2 yl = lna_act2((lo(acc[rg][t]) - m2) * r2 * lna_f32x2{g.x, g.y} + lna_f32x2{b.x, b.y}, ACT_CT >= 0 ? ACT_CT : a.act);
           const lna_f32x2 yh = lna_act2((hi(acc[rg][t]) - m2) * r2 * lna_f32x2{g.z, g.w} + lna_f32x2{b.z, b.w}, ACT_CT >= 0 ? ACT_CT : a.act);
           const float4 y = make_float4(yl.x, yl.y, yh.x, yh.y);
-#ifndef FSF_ABL_LNA_NO_STORE
+#if defined(FSF_ABL_LNA_COAL_ST)  // ablation (WRONG places, same bytes): every store instruction writes 1 KB of consecutive addresses
+          if (!SEG || (a.out && row < a.n)) *reinterpret_cast<float4*>(orow - (int64_t)rowl * a.out_stride + t * 256 + (rowl + 16 * grp) * 4) = y;
+#elif !defined(FSF_ABL_LNA_NO_STORE)
           if (!SEG || (a.out && row < a.n)) *reinterpret_cast<float4*>(orow + ch0) = y;
 #else
           if (y.x == 123.456f) *reinterpret_cast<float4*>(orow + ch0) = y;
@@ -638,8 +640,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
         continue;
       }
       const int kq = kc * LNA_KC + 8 * grp;  // this lane's 8 k values
+#ifdef FSF_ABL_LNA_COAL_X  // ablation (WRONG values, same bytes): every load instruction reads 1 KB of consecutive addresses, lane by lane
+      const float* cb = xrow[rg] - (int64_t)rowl * a.x_stride + (lane & 63) * 4;
+      const float4 p = *reinterpret_cast<const float4*>(cb + ((2 * kc) & 7) * 256);
+      const float4 q = *reinterpret_cast<const float4*>(cb + ((2 * kc + 1) & 7) * 256);
+#else
       const float4 p = *reinterpret_cast<const float4*>(xrow[rg] + min(kq, last_quad));
       const float4 q = *reinterpret_cast<const float4*>(xrow[rg] + min(kq + 4, last_quad));
+#endif
       v[rg][0] = p.x; v[rg][1] = p.y; v[rg][2] = p.z; v[rg][3] = p.w;
       v[rg][4] = q.x; v[rg][5] = q.y; v[rg][6] = q.z; v[rg][7] = q.w;
     }
