@@ -115,28 +115,10 @@ typedef float lna_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ lna_f32x2 lna_pk_fma(lna_f32x2 a, lna_f32x2 b, lna_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ lna_f32x2 lna_pk(float v) { return lna_f32x2{v, v}; }
 
-// GELU with erf by Abramowitz & Stegun 7.1.26, branch-free (|error| <= 1.5e-7 absolute — float epsilon; the same form as
-// K21's, see sir_input.hip), on TWO values per lane: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the rate of
-// their scalar forms, so everything but the two transcendentals (v_rcp, v_exp: quarter rate, unpacked) costs half the
-// instructions per value — the kernel is bound by VALU issue, not by the matrix pipe.
-// 0.5 y (1 + sign(y) (1 - pe)) = 0.5 ((y + |y|) - |y| pe): no compare / select.
-__device__ __forceinline__ lna_f32x2 lna_gelu2(lna_f32x2 y) {
-  lna_f32x2 ay;
-  ay.x = fabsf(y.x); ay.y = fabsf(y.y);
-  const lna_f32x2 u = ay * lna_pk(0.70710678118654752440f);
-  const lna_f32x2 d = lna_pk_fma(lna_pk(0.3275911f), u, lna_pk(1.0f));
-  lna_f32x2 t;
-  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
-  lna_f32x2 p = lna_pk_fma(lna_pk(1.061405429f), t, lna_pk(-1.453152027f));
-  p = lna_pk_fma(p, t, lna_pk(1.421413741f));
-  p = lna_pk_fma(p, t, lna_pk(-0.284496736f));
-  p = lna_pk_fma(p, t, lna_pk(0.254829592f));
-  const lna_f32x2 e = u * u * lna_pk(-1.4426950408889634f);
-  lna_f32x2 ex;
-  ex.x = __builtin_amdgcn_exp2f(e.x); ex.y = __builtin_amdgcn_exp2f(e.y);
-  const lna_f32x2 pe = p * t * ex;
-  return ((y + ay) - ay * pe) * lna_pk(0.5f);
-}
+// GELU: the library's one form (common.h: max(y, 0) - t 2^P(t), one transcendental per value), on TWO values per lane — gfx950 issues
+// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 at the rate of their scalar forms, and the kernel is bound by VALU issue, not by the
+// matrix pipe (docs/kernels/K21_K22_linear_family.md).
+__device__ __forceinline__ lna_f32x2 lna_gelu2(lna_f32x2 y) { return fsf_gelu2(y); }
 
 __device__ __forceinline__ lna_f32x2 lna_act2(lna_f32x2 y, int act) {
   if (act == 1) return lna_f32x2{fmaxf(y.x, 0.0f), fmaxf(y.y, 0.0f)};
@@ -343,7 +325,7 @@ struct LnaSegSmem {      // persistent part (behind the per-channel vectors)
 
 struct LnaSegCtx {       // per lane, for ONE 16-row group of its wave (built right before the group's tiles: half the live masks)
   bool one_seg;          // (wave-uniform) the whole group is one run
-  bool s1, s2, s4, s8;   // the row 1 / 2 / 4 / 8 above belongs to the same segment
+  uint64_t m1, m2, m4, m8;  // lane masks (SGPR pairs): the row 1 / 2 / 4 / 8 above belongs to the same segment
   bool write, to_slot;   // this lane ends a run of a group that holds rows < n; the run is open (its maxima go to an LDS slot)
   int dst;               // float offset of the run's row in seg_out (a closed run) or in the slots — 32 bits: a 64-bit pointer per
                          // lane was spilled and re-read from scratch for every tile
@@ -358,25 +340,41 @@ struct LnaSegBlock {     // what the epilogue needs to build the groups' context
   LnaSegSmem* sm;
 };
 
+// The scan of one tile's four values, hand-scheduled: a step is ONE instruction per value — `v_max_f32_dpp x, x(row_shr:k), x`, a lane
+// whose source lies outside its 16-lane row keeps x (bound_ctrl off) — plus, when the group holds more than one segment, a select on the
+// step's lane mask.  As compiled from `fmaxf(x, update_dpp(x, x))` a step was five to six (a copy for the tied old value, the hazard nop,
+// v_mov_dpp, a canonicalising v_max of the shuffled operand, the v_max, v_cndmask): the scan was ~1 400 of a wave's ~3 700 VALU
+// instructions per row block in a kernel that is bound by VALU issue (profiles/r5_pmc_k22s.txt).  The DPP read-after-VALU-write hazard
+// (two wait states; the assembler does not see into the block) is covered by the interleaving: a value's next step comes four
+// instructions after its last write, and the block opens with a nop for whatever produced the inputs.
 __device__ __forceinline__ float4 lna_seg_scan(const LnaSegCtx& sc, float4 y) {
-  float v[4] = {y.x, y.y, y.z, y.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float x = v[e];
-    if (sc.one_seg) {  // (wave-uniform) plain prefix maxima, no selects
-      x = fmaxf(x, lna_dpp<LNA_DPP_ROW_SHR + 1>(x, x));
-      x = fmaxf(x, lna_dpp<LNA_DPP_ROW_SHR + 2>(x, x));
-      x = fmaxf(x, lna_dpp<LNA_DPP_ROW_SHR + 4>(x, x));
-      x = fmaxf(x, lna_dpp<LNA_DPP_ROW_SHR + 8>(x, x));
-    } else {
-      float o = lna_dpp<LNA_DPP_ROW_SHR + 1>(x, x); x = sc.s1 ? fmaxf(x, o) : x;
-      o = lna_dpp<LNA_DPP_ROW_SHR + 2>(x, x); x = sc.s2 ? fmaxf(x, o) : x;
-      o = lna_dpp<LNA_DPP_ROW_SHR + 4>(x, x); x = sc.s4 ? fmaxf(x, o) : x;
-      o = lna_dpp<LNA_DPP_ROW_SHR + 8>(x, x); x = sc.s8 ? fmaxf(x, o) : x;
-    }
-    v[e] = x;
+  float a = y.x, b = y.y, c = y.z, d = y.w;
+#define LNA_SCAN_MAX1(K)                                               \
+  "v_max_f32_dpp %0, %0, %0 row_shr:" #K " row_mask:0xf bank_mask:0xf\n" \
+  "v_max_f32_dpp %1, %1, %1 row_shr:" #K " row_mask:0xf bank_mask:0xf\n" \
+  "v_max_f32_dpp %2, %2, %2 row_shr:" #K " row_mask:0xf bank_mask:0xf\n" \
+  "v_max_f32_dpp %3, %3, %3 row_shr:" #K " row_mask:0xf bank_mask:0xf\n"
+#define LNA_SCAN_MAXSEL(K, M)                                          \
+  "v_max_f32_dpp %4, %0, %0 row_shr:" #K " row_mask:0xf bank_mask:0xf\n" \
+  "v_max_f32_dpp %5, %1, %1 row_shr:" #K " row_mask:0xf bank_mask:0xf\n" \
+  "v_max_f32_dpp %6, %2, %2 row_shr:" #K " row_mask:0xf bank_mask:0xf\n" \
+  "v_max_f32_dpp %7, %3, %3 row_shr:" #K " row_mask:0xf bank_mask:0xf\n" \
+  "v_cndmask_b32_e64 %0, %0, %4, " M "\n"                              \
+  "v_cndmask_b32_e64 %1, %1, %5, " M "\n"                              \
+  "v_cndmask_b32_e64 %2, %2, %6, " M "\n"                              \
+  "v_cndmask_b32_e64 %3, %3, %7, " M "\n"
+  if (sc.one_seg) {  // (wave-uniform) plain prefix maxima, no selects
+    asm volatile("s_nop 1\n" LNA_SCAN_MAX1(1) LNA_SCAN_MAX1(2) LNA_SCAN_MAX1(4) LNA_SCAN_MAX1(8)
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  } else {  // (lanes without a source keep garbage in the scratch values: their mask bits are clear)
+    float oa, ob, oc, od;
+    asm volatile("s_nop 1\n" LNA_SCAN_MAXSEL(1, "%8") LNA_SCAN_MAXSEL(2, "%9") LNA_SCAN_MAXSEL(4, "%10") LNA_SCAN_MAXSEL(8, "%11")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(oa), "=&v"(ob), "=&v"(oc), "=&v"(od)
+                 : "s"(sc.m1), "s"(sc.m2), "s"(sc.m4), "s"(sc.m8));
   }
-  return make_float4(v[0], v[1], v[2], v[3]);
+#undef LNA_SCAN_MAX1
+#undef LNA_SCAN_MAXSEL
+  return make_float4(a, b, c, d);
 }
 
 // one group's segment ids -> scan flags, run ends and their destinations; called after the barrier that frees the slot buffer
@@ -388,7 +386,8 @@ __device__ __forceinline__ LnaSegCtx lna_seg_prepare(const LnaArgs& a, const Lna
   const int up1 = lna_dpp_i<LNA_DPP_ROW_SHR + 1>(-1, sid), up2 = lna_dpp_i<LNA_DPP_ROW_SHR + 2>(-1, sid);
   const int up4 = lna_dpp_i<LNA_DPP_ROW_SHR + 4>(-1, sid), up8 = lna_dpp_i<LNA_DPP_ROW_SHR + 8>(-1, sid);
   const int dn1 = lna_dpp_i<LNA_DPP_ROW_SHL + 1>(-1, sid);
-  sc.s1 = up1 == sid; sc.s2 = up2 == sid; sc.s4 = up4 == sid; sc.s8 = up8 == sid;  // (ids >= 0: -1 = no such lane)
+  sc.m1 = __builtin_amdgcn_ballot_w64(up1 == sid); sc.m2 = __builtin_amdgcn_ballot_w64(up2 == sid);  // (ids >= 0: -1 = no such lane)
+  sc.m4 = __builtin_amdgcn_ballot_w64(up4 == sid); sc.m8 = __builtin_amdgcn_ballot_w64(up8 == sid);
   sc.one_seg = __builtin_amdgcn_readfirstlane(sid) == __builtin_amdgcn_readlane(sid, 15);  // sorted: first == last
   sc.write = sc.to_slot = false;
   sc.dst = 0;

@@ -16,9 +16,9 @@ enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
 constexpr int NA_MAX_PER_LANE = 8;
 
-// erf by Abramowitz & Stegun 7.1.26, branch-free (|error| <= 1.5e-7 absolute — float epsilon; the form K21 / K22 use in their
-// epilogues): pe = 1 - erf(|y| / sqrt 2), e = exp(-y^2 / 2).  (libm's erff made these passes VALU-bound: ~80 of the 173 us
-// of the [4.9e5, 128] forward.)
+// The BACKWARD's terms: erf by Abramowitz & Stegun 7.1.26, branch-free (|error| <= 1.5e-7 absolute): pe = 1 - erf(|y| / sqrt 2),
+// e = exp(-y^2 / 2).  (The forward is common.h's fsf_gelu; libm's erff made these passes VALU-bound: ~80 of the 173 us of the
+// [4.9e5, 128] forward.)
 __device__ __forceinline__ void gelu_terms(float y, float& pe, float& e) {
   const float u = fabsf(y) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
@@ -29,32 +29,12 @@ __device__ __forceinline__ void gelu_terms(float y, float& pe, float& e) {
   e = __builtin_amdgcn_exp2f(u * u * -1.4426950408889634f);
   pe = p * t * e;
 }
-__device__ __forceinline__ float gelu_erf(float y) {
-  float pe, e;
-  gelu_terms(y, pe, e);
-  return ((y + fabsf(y)) - fabsf(y) * pe) * 0.5f;  // = 0.5 y (y < 0 ? pe : 2 - pe) without the compare / select (K21 / K22: same form)
-}
+__device__ __forceinline__ float gelu_erf(float y) { return fsf_gelu(y); }  // the forward form every kernel shares (common.h)
 
 typedef float na_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ na_f32x2 na_pk(float v) { return na_f32x2{v, v}; }
 // two values per lane on v_pk_*_f32 (full rate on gfx950: half the instructions per value outside v_rcp / v_exp)
-__device__ __forceinline__ na_f32x2 gelu_erf2(na_f32x2 y) {
-  na_f32x2 ay;
-  ay.x = fabsf(y.x); ay.y = fabsf(y.y);
-  const na_f32x2 u = ay * na_pk(0.70710678118654752440f);
-  const na_f32x2 d = __builtin_elementwise_fma(na_pk(0.3275911f), u, na_pk(1.0f));
-  na_f32x2 t;
-  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
-  na_f32x2 p = __builtin_elementwise_fma(na_pk(1.061405429f), t, na_pk(-1.453152027f));
-  p = __builtin_elementwise_fma(p, t, na_pk(1.421413741f));
-  p = __builtin_elementwise_fma(p, t, na_pk(-0.284496736f));
-  p = __builtin_elementwise_fma(p, t, na_pk(0.254829592f));
-  const na_f32x2 e = u * u * na_pk(-1.4426950408889634f);
-  na_f32x2 ex;
-  ex.x = __builtin_amdgcn_exp2f(e.x); ex.y = __builtin_amdgcn_exp2f(e.y);
-  const na_f32x2 pe = p * t * ex;
-  return ((y + ay) - ay * pe) * na_pk(0.5f);
-}
+__device__ __forceinline__ na_f32x2 gelu_erf2(na_f32x2 y) { return fsf_gelu2(y); }
 
 template <int TEAM, int ACT, int NORM, int PL = NA_MAX_PER_LANE>  // PL channels per lane (16 for the 1024-wide query MLPs)
 __global__ void __launch_bounds__(256)

@@ -36,21 +36,9 @@ struct SirInputArgs {
   int64_t n; int c;
 };
 
-// GELU(y) = y/2 * (1 + erf(y / sqrt 2)) with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. float
-// epsilon; the kernel is instruction-bound and libm's two-branch erff is 35 VALU ops + divergence per element, 60
-// elements per lane per 16 rows).  Branch-free: 1 - erf(u) = poly(t) * exp(-u^2), t = 1 / (1 + p u), u = |y| / sqrt 2;
-// for y < 0 the factor (1 + erf) IS that product (no cancellation), for y >= 0 it is 2 - product.
-__device__ __forceinline__ float si_gelu(float y) {
-  const float u = fabsf(y) * 0.70710678118654752440f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(u * u * -1.4426950408889634f);
-  const float pe = p * t * e;
-  return ((y + fabsf(y)) - fabsf(y) * pe) * 0.5f;  // = 0.5 y (y < 0 ? pe : 2 - pe) without the compare / select
-}
+// GELU: the library's one form (common.h: max(y, 0) - t 2^P(t), branch-free, one transcendental per value); the kernel is
+// instruction-bound and libm's two-branch erff is 35 VALU ops + divergence per element, 60 elements per lane per 16 rows.
+__device__ __forceinline__ float si_gelu(float y) { return fsf_gelu(y); }
 
 __device__ __forceinline__ float si_act(float y, int act) {
   if (act == 1) return fmaxf(y, 0.0f);
@@ -64,26 +52,8 @@ typedef float si_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ si_f32x2 si_pk(float v) { return si_f32x2{v, v}; }
 __device__ __forceinline__ si_f32x2 si_pk_fma(si_f32x2 a, si_f32x2 b, si_f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// The same GELU on TWO values per lane (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue at the rate of their scalar forms: everything
-// but v_rcp / v_exp costs half the instructions per value — this kernel is bound by instruction issue);
-// 0.5 y (1 + sign(y) (1 - pe)) = 0.5 ((y + |y|) - |y| pe): no compare / select.  The same form as K22's (linear_norm_act.hip).
-__device__ __forceinline__ si_f32x2 si_gelu2(si_f32x2 y) {
-  si_f32x2 ay;
-  ay.x = fabsf(y.x); ay.y = fabsf(y.y);
-  const si_f32x2 u = ay * si_pk(0.70710678118654752440f);
-  const si_f32x2 d = si_pk_fma(si_pk(0.3275911f), u, si_pk(1.0f));
-  si_f32x2 t;
-  t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
-  si_f32x2 p = si_pk_fma(si_pk(1.061405429f), t, si_pk(-1.453152027f));
-  p = si_pk_fma(p, t, si_pk(1.421413741f));
-  p = si_pk_fma(p, t, si_pk(-0.284496736f));
-  p = si_pk_fma(p, t, si_pk(0.254829592f));
-  const si_f32x2 e = u * u * si_pk(-1.4426950408889634f);
-  si_f32x2 ex;
-  ex.x = __builtin_amdgcn_exp2f(e.x); ex.y = __builtin_amdgcn_exp2f(e.y);
-  const si_f32x2 pe = p * t * ex;
-  return ((y + ay) - ay * pe) * si_pk(0.5f);
-}
+// The same GELU on TWO values per lane (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue at the rate of their scalar forms).
+__device__ __forceinline__ si_f32x2 si_gelu2(si_f32x2 y) { return fsf_gelu2(y); }
 
 __device__ __forceinline__ si_f32x2 si_act2(si_f32x2 y, int act) {
   if (act == 1) return si_f32x2{fmaxf(y.x, 0.0f), fmaxf(y.y, 0.0f)};

@@ -961,6 +961,32 @@ def test_norm_act_vs_torch(ops, device, c, act):
     np.testing.assert_allclose(got2.cpu().numpy(), want2.numpy(), rtol=1e-6, atol=5e-6)
 
 
+@pytest.mark.gpu
+def test_gelu_form_vs_float64_erf_on_1e7_points(ops, device):
+    """The library's one GELU (csrc/common.h: max(y, 0) - t 2^P(t), t = |y| / sqrt 2, P a degree-8 fit of log2 erfc(t) - 1/2;
+    tools/fit_gelu_poly.py) against float64 erf on 1e7 points: a dense sweep of [-10, 10], normal draws at three widths and every
+    magnitude down to the denormals.  Bound: 6e-8 beyond the rounding of the fp32 result (the rational form it replaced sat at
+    2.2e-7); far tails: 0 <= -GELU(y) <= 1e-8 for y <= -6, GELU(y) == y for y >= 6; no NaN for finite inputs of any size."""
+    g = torch.Generator().manual_seed(11)
+    parts = [torch.linspace(-10, 10, 6_000_000, dtype=torch.float64).float(), torch.randn(1_500_000, generator=g),
+             torch.randn(1_500_000, generator=g) * 3, torch.randn(500_000, generator=g) * 0.05,
+             (torch.rand(500_000, generator=g) * 2 - 1) * torch.pow(10.0, -torch.rand(500_000, generator=g) * 44)]
+    x = torch.cat(parts).view(-1, 128)
+    assert x.numel() >= 9_999_000
+    one, zero = torch.ones(128, device=device), torch.zeros(128, device=device)
+    got = ops.norm_act(x.to(device), one, zero, 0.0, "affine", "gelu", inplace=False).cpu().double()
+    xd = x.double()
+    want = 0.5 * xd * (1 + torch.erf(xd / 2 ** 0.5))
+    half_ulp = torch.from_numpy(np.spacing(np.abs(want.float().numpy()))).double() * 0.5
+    beyond = ((got - want).abs() - half_ulp).clamp_min(0)
+    assert beyond.max().item() <= 6e-8, (beyond.max().item(), x.view(-1)[beyond.argmax()].item())
+    far = torch.tensor([[-1e30, -1e10, -40.0, -13.0, -6.0, 6.0, 13.0, 40.0, 1e10, 1e30, 3e38, -3e38] + [0.0] * 116])
+    y = ops.norm_act(far.to(device), one, zero, 0.0, "affine", "gelu", inplace=False).cpu()[0]
+    assert torch.isfinite(y).all()
+    assert (y[:5] <= 0).all() and (y[:5] >= -1e-8).all() and y[11] <= 0 and y[11] >= -1e-8
+    assert torch.equal(y[5:11], far[0, 5:11]) and (y[12:] == 0).all()
+
+
 # ------------------------------------------------------------------------------- refine-stage ops (K17 / K20)
 def random_rois(rng, r, spread=40.0):
     ctr = rng.uniform(-spread, spread, (r, 2))
