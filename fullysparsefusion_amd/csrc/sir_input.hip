@@ -196,12 +196,27 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
     }
     float x[16][T];
     if (a.feats_index) {  // (wave-uniform) gathered feature rows: row i of the group reads row readlane(icur, i) of the feature parts
+      // Address of (row i, tile t) = cur[t] + ri * gstr[t]: the lane's columns that are NOT gathered walk down the group by their
+      // stride (cur[t], one 64-bit add per load), the gathered ones add the row index — a scalar — times their stride in ONE
+      // v_mad_u64_u32 (32 x 32 + 64 bits: indices and strides fit 32 bits, checked at launch).  As `(gathered ? ri : rr) * stride` in
+      // 64 bits every load cost two selects and a 64 x 64-bit multiply: ~190 quarter-rate integer ops per 16-row group.
+      const float* cur[T];
+      uint32_t gstr[T];
+      int64_t step[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        cur[t] = xgath[t] ? xsrc[t] : xsrc[t] + row0 * xstride[t];
+        gstr[t] = xgath[t] ? (uint32_t)xstride[t] : 0u;
+        step[t] = xgath[t] ? 0 : xstride[t];
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int64_t ri = (int64_t)__builtin_amdgcn_readlane(icur, i);   // (rows past n repeat the last one: see load_idx)
-        const int64_t rr = row0 + (i < nrow ? i : nrow - 1);
+        const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane(icur, i);   // (rows past n repeat the last one: see load_idx)
 #pragma unroll
-        for (int t = 0; t < T; ++t) x[i][t] = xsrc[t][(xgath[t] ? ri : rr) * xstride[t]];
+        for (int t = 0; t < T; ++t) {
+          x[i][t] = *(cur[t] + (uint64_t)ri * (uint64_t)gstr[t]);
+          if (i + 1 < nrow) cur[t] += step[t];  // (wave-uniform)
+        }
       }
     } else {
       const float* rp[T];  // row pointers walk down the group: one 64-bit add per load instead of a 64-bit multiply
@@ -330,8 +345,14 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
       if (i < nrow) {  // wave-uniform
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-          // true divisions, as the reference's `/` (x / 1 is exact), only in the tiles that hold a divided column
-          const float xv = xneed[t] ? __fdiv_rn(x[i][t], xdiv[t]) : x[i][t];
+          // true divisions, as the reference's `/` (x / 1 is exact), only in the tiles that hold a divided column: a REAL branch
+          // (the empty volatile statement keeps the compiler from turning the wave-uniform test into a select, which ran the
+          // thirteen-instruction IEEE division for every tile of every row: 48 per 16-row group at c = 180 where 16 are needed)
+          float xv = x[i][t];
+          if (xneed[t]) {
+            asm volatile("" ::: "memory");
+            xv = __fdiv_rn(xv, xdiv[t]);
+          }
           if (lane + 64 * t < a.c) orow[64 * t] = xv * tile[i * TS + lane + 64 * t];
         }
         orow += a.out_stride;
@@ -380,6 +401,7 @@ extern "C" int fsf_sir_input_gather(const float* points, int64_t points_stride, 
   int32_t f_cols = 0;
   for (int i = 0; i < num_parts; ++i) {
     if (feat_cols[i] < 1 || feat_strides[i] < feat_cols[i] || (n > 0 && !feat_parts[i])) return FSF_ERR_INVALID_ARG;
+    if (feat_strides[i] > 0xffffffffLL) return FSF_ERR_UNSUPPORTED;  // (the gather multiplies a 32-bit row index by a 32-bit stride)
     f_cols += feat_cols[i];
   }
   const float* feats = num_parts > 0 ? feat_parts[0] : nullptr;
