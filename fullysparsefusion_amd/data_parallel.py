@@ -16,6 +16,9 @@ launched by tools/dist_train.sh:8-9 with one process per GPU).  Differences that
     between ranks on such a step (mid-backward on one, `finish()` on the other), and `naiveSyncBN1d`'s backward issues
     its own all-reduces in between: RCCL pairs collectives by issue order PER COMMUNICATOR, so the buckets travel on
     their own process group (`dist.new_group`), never on the one the SyncBN statistics use;
+  * `backward(loss)` detaches `param.grad` from the views for the duration of the pass: autograd hands each gradient over and a
+    bucket adds its parameters' gradients in one multi-tensor kernel when the last one has arrived (264 per-parameter `add_`
+    launches per FSF step otherwise, most of them on 128 floats);
   * gradient accumulation: `no_sync()` (as in DDP) keeps micro-batch gradients local; the first backward outside it
     reduces the accumulated sum.  The buckets are cleared by `zero_grad()` — or by the optimizer's own
     `zero_grad()`: with `set_to_none=False` it zeroes the views in place, with `set_to_none=True` (torch's default) it drops
@@ -41,6 +44,7 @@ class _Bucket:
         self.pending = 0
         self.work = None
         self.launched = False
+        self.arrived = []  # (view, gradient autograd handed over) of the running backward pass, added into the bucket in one go
 
 
 class FrameDataParallel(torch.nn.Module):
@@ -134,16 +138,25 @@ class FrameDataParallel(torch.nn.Module):
         if self.world > 1 and self._sync:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _flush(self, b):
+        """The gradients autograd handed over for this bucket's parameters -> the bucket, as ONE multi-tensor add (the views hold
+        zeros or what earlier backward passes of an accumulation window left), and `param.grad` back onto the views."""
+        if b.arrived:
+            torch._foreach_add_([v for v, _ in b.arrived], [g for _, g in b.arrived])
+            b.arrived = []
+        for p, v in zip(b.params, b.views):
+            p.grad = v
+
     def _on_grad(self, p):
         if not self._armed:
             return
         b, view = self._where[p], self._view[p]
-        if p.grad.data_ptr() != view.data_ptr():  # autograd replaced the view (first accumulation into None)
-            view.copy_(p.grad)
-            p.grad = view
+        if p.grad.data_ptr() != view.data_ptr():  # autograd's own tensor (`backward()` detached the view: no per-parameter add)
+            b.arrived.append((view, p.grad))
         b.pending -= 1
         # launch in bucket order only: every rank must issue the same sequence of collectives
         if b.pending == 0:
+            self._flush(b)
             for nb in self.buckets:
                 if nb.launched:
                     continue
@@ -157,6 +170,7 @@ class FrameDataParallel(torch.nn.Module):
         every collective and turn sums into means."""
         for b in self.buckets:
             if not b.launched:
+                self._flush(b)
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:
@@ -167,7 +181,16 @@ class FrameDataParallel(torch.nn.Module):
         self._armed = False
 
     def backward(self, loss):
+        """`loss.backward()` + `finish()`.  For the duration of the pass `param.grad` is detached from the bucket views (None), so
+        autograd HANDS OVER each parameter's gradient instead of adding it into the view with a kernel of its own — FSF has 264
+        parameters per step, most of them 128 floats — and a bucket takes its parameters' gradients in ONE multi-tensor add when the
+        last of them has arrived (`_flush`), right before its all-reduce is launched.  The sums are the same additions in the same
+        order (view + gradient).  A caller that runs `loss.backward()` itself and then `finish()` gets the in-place path."""
         if not self._armed:
             self._arm(zero=False)
+        for b in self.buckets:
+            for p, v in zip(b.params, b.views):
+                if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
+                    p.grad = None
         loss.backward()
         self.finish()
