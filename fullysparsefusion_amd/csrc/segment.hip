@@ -522,6 +522,26 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// the same on the channel concatenation [a | b] WITHOUT materialising it (r = 2; widths multiples of 8, so the eight input columns of
+// an output quad lie in one source): out[i, j] = add[i, j] + cat[i, 2 j] + cat[i, 2 j + 1]
+__global__ void __launch_bounds__(256)
+    channel_pair_sum_add2_kernel(const float* __restrict__ fa, int ca, const float* __restrict__ fb, int cb, const float* __restrict__ add,
+                                 int64_t n, int cout, float* __restrict__ out) {
+  const int cv = cout / 4;
+  const int64_t total = n * cv;
+  const bool small = total <= 0x7fffffff;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = small ? (int64_t)((uint32_t)t / (uint32_t)cv) : t / cv;
+    const int j = (int)(t - i * cv) * 4;
+    const float* f = 2 * j < ca ? fa + i * ca + 2 * j : fb + i * cb + (2 * j - ca);
+    const float4 p = *reinterpret_cast<const float4*>(f), q = *reinterpret_cast<const float4*>(f + 4);
+    float4 o = add ? *reinterpret_cast<const float4*>(add + i * cout + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    o.x = __fadd_rn(o.x, __fadd_rn(p.x, p.y)); o.y = __fadd_rn(o.y, __fadd_rn(p.z, p.w));
+    o.z = __fadd_rn(o.z, __fadd_rn(q.x, q.y)); o.w = __fadd_rn(o.w, __fadd_rn(q.z, q.w));
+    *reinterpret_cast<float4*>(out + i * cout + j) = o;
+  }
+}
+
 struct V2PParams {
   float vx, vy, vz, xmin, ymin, zmin, padding;
 };
@@ -774,6 +794,19 @@ extern "C" int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t c
   if (n == 0) return FSF_OK;
   const dim3 grid(fsf_stream_grid(n * (cout / 4), 256));
   hipLaunchKernelGGL((channel_group_sum_add_kernel<2>), grid, dim3(256), 0, stream, feat, add, n, (int)cout, out);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_channel_pair_sum_add2(const float* feat_a, int32_t ca, const float* feat_b, int32_t cb, int64_t n, const float* add,
+                                         float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || ca < 1 || cb < 1 || (n > 0 && (!feat_a || !feat_b || !out))) return FSF_ERR_INVALID_ARG;
+  if (ca % 8 != 0 || cb % 8 != 0) return FSF_ERR_UNSUPPORTED;
+  if (n == 0) return FSF_OK;
+  const int cout = (ca + cb) / 2;
+  const dim3 grid(fsf_stream_grid(n * (cout / 4), 256));
+  hipLaunchKernelGGL(channel_pair_sum_add2_kernel, grid, dim3(256), 0, stream, feat_a, (int)ca, feat_b, (int)cb, add, n, cout, out);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

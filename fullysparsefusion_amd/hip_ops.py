@@ -84,6 +84,7 @@ _ARGTYPES = {
     "fsf_spconv_forward_planes": [_P, _P, c_i32, _P, _P, c_i32, c_i64, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, _P,
                                   _P],
     "fsf_channel_group_sum_add": [_P, c_i64, c_i32, c_i32, _P, _P, _P],
+    "fsf_channel_pair_sum_add2": [_P, c_i32, _P, c_i32, c_i64, _P, _P, _P],
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
     "fsf_linear_norm_act": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
@@ -412,6 +413,24 @@ def channel_group_sum_add(feat: torch.Tensor, cout: int, add: Optional[torch.Ten
         assert add.shape == (n, cout)
     out = torch.empty((n, cout), dtype=torch.float32, device=feat.device)
     check(_L().fsf_channel_group_sum_add(ptr(feat), n, cin, cout, ptr(add), ptr(out), stream_ptr()), "fsf_channel_group_sum_add")
+    return out
+
+
+def channel_pair_sum_add2_supported(a: torch.Tensor, b: torch.Tensor) -> bool:
+    return (a.is_cuda and a.dtype == b.dtype == torch.float32 and a.dim() == b.dim() == 2 and a.size(0) == b.size(0)
+            and a.size(1) % 8 == 0 and b.size(1) % 8 == 0 and a.is_contiguous() and b.is_contiguous())
+
+
+def channel_pair_sum_add2(a: torch.Tensor, b: torch.Tensor, add: Optional[torch.Tensor] = None):
+    """fsf_channel_pair_sum_add2: add + cat([a, b], 1).view(n, (ca + cb) / 2, 2).sum(2) without the concatenation."""
+    require_cuda(a, b, add)
+    n, ca, cb = a.size(0), a.size(1), b.size(1)
+    cout = (ca + cb) // 2
+    if add is not None:
+        add = add.contiguous()
+        assert add.shape == (n, cout)
+    out = torch.empty((n, cout), dtype=torch.float32, device=a.device)
+    check(_L().fsf_channel_pair_sum_add2(ptr(a), ca, ptr(b), cb, n, ptr(add), ptr(out), stream_ptr()), "fsf_channel_pair_sum_add2")
     return out
 
 

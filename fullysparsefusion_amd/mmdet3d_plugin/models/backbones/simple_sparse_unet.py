@@ -108,18 +108,23 @@ class SimpleSparseUNet(nn.Module):
     def decoder_layer_forward(self, x_lateral, x_bottom, lateral_layer, merge_layer, upsample_layer, lateral_out=None):
         x = lateral_out if lateral_out is not None else lateral_layer(x_lateral)
         lat_planes, bot_planes = x.plane_sources, x_bottom.plane_sources
-        x = x._like(torch.cat((x_bottom.features, x.features), dim=1))
-        if lat_planes is not None and len(lat_planes) == 1 and x_bottom.features.size(1) <= 128 and x_bottom.features.size(1) % 32 == 0:
+        f_bot, f_lat = x_bottom.features, x.features
+        # cat((x_bottom.features, x.features), 1), written only if somebody reads it as one tensor
+        x = x._like((f_bot, f_lat) if switches.LAZY_CAT and not torch.is_grad_enabled() else torch.cat((f_bot, f_lat), dim=1))
+        if lat_planes is not None and len(lat_planes) == 1 and f_bot.size(1) <= 128 and f_bot.size(1) % 32 == 0:
             # the merge layer reads the concatenation as two plane sources: the lateral block's own plane-form output and
-            # a conversion of the bottom-up features (the fp32 concat above is still what the channel reduction reads)
+            # a conversion of the bottom-up features
             if bot_planes is None or len(bot_planes) != 1:
-                bot_planes = [hip_ops.to_planes(x_bottom.features)]
+                bot_planes = [hip_ops.to_planes(f_bot)]
             x.plane_sources = [bot_planes[0], lat_planes[0]]
         x_merge = merge_layer(x)
-        cout, f = x_merge.features.shape[1], x.features
-        if (f.is_cuda and f.dtype == torch.float32 and not (torch.is_grad_enabled() and (f.requires_grad or x_merge.features.requires_grad))
-                and f.shape[1] == 2 * cout and cout % 4 == 0):
-            x = x._like(hip_ops.channel_group_sum_add(f, cout, add=x_merge.features))  # reduce_channel + the add, one pass
+        cout = x_merge.features.shape[1]
+        no_grad = not (torch.is_grad_enabled() and (f_bot.requires_grad or f_lat.requires_grad or x_merge.features.requires_grad))
+        if (no_grad and f_bot.size(1) + f_lat.size(1) == 2 * cout and cout % 4 == 0 and x._features is None
+                and hip_ops.channel_pair_sum_add2_supported(f_bot, f_lat)):
+            x = x._like(hip_ops.channel_pair_sum_add2(f_bot, f_lat, add=x_merge.features))  # reduce_channel + the add, no concatenation
+        elif no_grad and x.features.is_cuda and x.features.dtype == torch.float32 and x.features.shape[1] == 2 * cout and cout % 4 == 0:
+            x = x._like(hip_ops.channel_group_sum_add(x.features, cout, add=x_merge.features))  # reduce_channel + the add, one pass
         else:
             x = self.reduce_channel(x, cout)
             x = x._like(x_merge.features + x.features)

@@ -20,7 +20,11 @@ from ... import hip_ops
 
 class SparseConvTensor:
     def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
-        self.features = features
+        # `features` may be given as the PARTS of a channel concatenation (a tuple of [m, c_i] tensors: the decoder's
+        # `cat([x_bottom.features, x_lateral.features], 1)`): the concatenation is written on first read of `.features` — never, when
+        # the consumers read the parts (the plane-form merge convolution, fsf_channel_pair_sum_add2)
+        self.feature_parts = tuple(features) if isinstance(features, (tuple, list)) else None
+        self._features = None if self.feature_parts is not None else features
         self.indices = indices  # i32 [m,4] (b,z,y,x)
         self.spatial_shape = list(spatial_shape)
         self.batch_size = int(batch_size)
@@ -28,6 +32,20 @@ class SparseConvTensor:
         self.grid = grid
         # K9c plane form of `features` (hip_ops.Planes, one per source of a channel concatenation), when a producer emitted it
         self.plane_sources = None
+
+    @property
+    def features(self):
+        if self._features is None and self.feature_parts is not None:
+            self._features = torch.cat(self.feature_parts, dim=1)
+        return self._features
+
+    @features.setter
+    def features(self, value):
+        self._features, self.feature_parts = value, None
+
+    @property
+    def num_channels(self):
+        return sum(int(t.size(1)) for t in self.feature_parts) if self._features is None and self.feature_parts else int(self._features.size(1))
 
     @property
     def spatial_size(self):
@@ -276,7 +294,7 @@ class SparseConvolution(SparseModule):
         """The input in plane form: what the producer emitted, else a conversion of the fp32 features (<= 128 channels per
         source; a 256-channel input is the concatenation of two halves)."""
         srcs = x.plane_sources
-        if srcs is not None and sum(p.c for p in srcs) == self.in_channels and all(p.m == x.features.size(0) for p in srcs):
+        if srcs is not None and sum(p.c for p in srcs) == self.in_channels and all(p.m == x.indices.size(0) for p in srcs):
             return srcs
         f = x.features
         if self.in_channels <= 128:
@@ -305,6 +323,14 @@ class SparseConvolution(SparseModule):
             shift = self.bias
         elif shift is not None and self.bias is not None:
             shift = shift + (self.bias * scale if scale is not None else self.bias)
+        if (not torch.is_grad_enabled() and x.plane_sources is not None and x.indices.size(0) > 0
+                and self._use_planes_kernel(x, nbr.size(0))):  # (reads the plane sources only: a lazy concatenation stays unwritten)
+            out, planes = hip_ops.spconv_forward_planes(self._plane_sources(x), self._weight_planes(), nbr.size(1), self.out_channels,
+                                                        nbr, scale=scale, shift=shift, residual=residual, relu=relu,
+                                                        want_planes=self.emit_planes and self.out_channels <= 128)
+            y = x._like(out, out_indices, out_shape)
+            y.plane_sources = [planes] if planes is not None else None
+            return y
         feat = x.features
         needs_grad = torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad)
         if needs_grad:  # training: the epilogue stays in autograd-visible torch ops

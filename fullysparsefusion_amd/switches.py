@@ -39,6 +39,7 @@ UNIQUE_BOUNDS = _on("FSF_UNIQUE_BOUNDS")            # uniques pack their sort ke
 OVERLAP_ROWS = _on("FSF_OVERLAP_ROWS")              # inference: the camera-query row list (foreground + overlap duplicates) as two C-ABI calls (K26)
 KEY_SURVIVAL = _on("FSF_KEY_SURVIVAL")              # ... and its density filter as one C-ABI call / one read-back (K25)
 VFE_DECORATE = _on("FSF_VFE_DECORATE")              # the VFE input decoration in one kernel
+LAZY_CAT = _on("FSF_LAZY_CAT")                    # inference: the U-Net decoder's channel concatenation is written only if read as one tensor
 SPLIT_F16 = _on("FSF_SPLIT_F16")                  # inference: K9b's layers with whole 32-channel chunks on f16 x 3 planes (K9b-XP)
 K22H = _on("FSF_K22H")                              # inference: the wide (>= 256 -> >= 256 channel) Linears on f16 x 3 planes (K22h)
 K22H_MIN_ROWS = _int("FSF_K22H_MIN_ROWS", 1024)

@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 15
+#define FSF_ABI_VERSION 16
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -191,6 +191,13 @@ int fsf_gather_rows_add(const float* src, int64_t src_stride, int64_t m, int32_t
  *   r = cin / cout = 2 (every decoder level of the FSF configs; bit-identical to the two torch ops); add may be NULL;
  *   cout % 4 == 0. */
 int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t cin, int32_t cout, const float* add, float* out,
+                              void* stream);
+/* The same shortcut read straight from the two tensors the decoder concatenates — `cat([x_bottom.features, x_lateral.features], 1)`
+ * of decoder_layer_forward — so that the [n, ca + cb] concatenation is never written when the merge convolution reads its two
+ * sources as planes: out[i,j] = add[i,j] + cat[i,2j] + cat[i,2j+1], cout = (ca + cb) / 2; ca, cb multiples of 8 (an output quad's eight
+ * input columns then lie in one source; FSF_ERR_UNSUPPORTED otherwise); add may be NULL.  Bit-identical to fsf_channel_group_sum_add
+ * on the concatenation. */
+int fsf_channel_pair_sum_add2(const float* feat_a, int32_t ca, const float* feat_b, int32_t cb, int64_t n, const float* add, float* out,
                               void* stream);
 
 

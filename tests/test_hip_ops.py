@@ -1335,6 +1335,23 @@ def test_channel_group_sum_add_equals_torch(ops, device, n, cin, cout):
     assert torch.equal(ops.channel_group_sum_add(f, cout), f.view(n, cout, -1).sum(dim=2))
 
 
+@pytest.mark.parametrize("n,ca,cb", [(101119, 128, 128), (7441, 256, 256), (36508, 128, 128), (33, 8, 24), (1, 16, 8)])
+def test_channel_pair_sum_add2_equals_the_op_on_the_concatenation(ops, device, n, ca, cb):
+    """The decoder shortcut read from the two tensors `decoder_layer_forward` concatenates: bit-identical to torch's
+    `cat([a, b], 1).view(n, C, 2).sum(2) + merge` (and so to fsf_channel_group_sum_add) without writing the concatenation;
+    widths that are not multiples of 8 are refused."""
+    torch.manual_seed(n + ca)
+    a, b = torch.randn(n, ca, device=device), torch.randn(n, cb, device=device)
+    cout = (ca + cb) // 2
+    m = torch.randn(n, cout, device=device)
+    cat = torch.cat([a, b], 1)
+    assert ops.channel_pair_sum_add2_supported(a, b)
+    assert torch.equal(ops.channel_pair_sum_add2(a, b, add=m), m + cat.view(n, cout, 2).sum(dim=2))
+    assert torch.equal(ops.channel_pair_sum_add2(a, b), cat.view(n, cout, 2).sum(dim=2))
+    assert torch.equal(ops.channel_pair_sum_add2(a, b, add=m), ops.channel_group_sum_add(cat, cout, add=m))
+    assert not ops.channel_pair_sum_add2_supported(torch.zeros(n, 12, device=device), torch.zeros(n, 4, device=device))
+
+
 @pytest.mark.parametrize("n,w,k", [(20000, 60, 2), (3000, 60, 4), (17, 7, 7), (1, 128, 5)])
 def test_row_topk_desc_equals_torch_topk(ops, device, n, w, k):
     torch.manual_seed(n + w)
