@@ -532,8 +532,12 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
       for (int t = 0; t < T; ++t) {
         const int ch0 = ch_base + 16 * t + g4;
         if (16 * t + 4 * grp < a.slice_w && ch_base + 16 * t + 4 * grp < a.c) {
+#ifdef FSF_ABL_LNA_NO_VEC  // ablation: no LDS reads of gamma / beta in the tile loop (constants: WRONG results)
+          const float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
           const float4 g = *reinterpret_cast<const float4*>(vec + 128 + 16 * t + 4 * grp);  // (1 / 0 without a norm)
           const float4 b = *reinterpret_cast<const float4*>(vec + 256 + 16 * t + 4 * grp);
+#endif
           const lna_f32x2 yl = lna_act2((lo(acc[rg][t]) - m2) * r2 * lna_f32x2{g.x, g.y} + lna_f32x2{b.x, b.y}, ACT_CT >= 0 ? ACT_CT : a.act);
           const lna_f32x2 yh = lna_act2((hi(acc[rg][t]) - m2) * r2 * lna_f32x2{g.z, g.w} + lna_f32x2{b.z, b.w}, ACT_CT >= 0 ? ACT_CT : a.act);
           const float4 y = make_float4(yl.x, yl.y, yh.x, yh.y);
@@ -564,12 +568,15 @@ __device__ __forceinline__ void lna_epilogue(const LnaArgs& a, lna_f32x4 (&acc)[
 // once per 384 rows.  Measured (round 3, same box): no faster in isolation (510 k x 256 -> 128: 277 vs 279 us; k = 128 .. 180: 5-15 %
 // SLOWER — a barrier over twelve waves per chunk) and 7 % slower in the frame (a 768-thread workgroup shuts the other stream's kernels
 // out of its CU) — so the weight stream is not what this kernel waits for.  Kept behind FSF_K22_WIDE_MIN_ROWS=<rows> (default: never).
-template <int T, int NW, bool SEG = false, int NORM_CT = -1, int ACT_CT = -1, bool XP = false>  // 16-channel tiles (c <= 16 T); SEG: +
-// segmented max of the output (rows sorted by segment), norm / act fixed at compile time; XP: x and W arrive as f16 hi | lo planes (K22h)
+template <int T, int NW, bool SEG = false, int NORM_CT = -1, int ACT_CT = -1, int XM = 0>  // 16-channel tiles (c <= 16 T); SEG: +
+// segmented max of the output (rows sorted by segment), norm / act fixed at compile time; XM = 1 (XP): x and W arrive as f16 hi | lo
+// planes (K22h); XM = 2 (XF, K22f): fp32 x split IN the kernel into f16 hi | lo of x * s_row (s_row: the running power-of-two unit of the
+// row, below), W as f16 planes — three MFMA passes per product instead of the six of the exact bf16 split (XM = 0)
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WPS) : 3) linear_norm_act_kernel(LnaArgs a) {
   constexpr int LNA_NW = NW;
   constexpr int LNA_ROWS = NW * LNA_RG * 16;
-  constexpr int NPL = XP ? 2 : 3;             // weight planes per tile
+  constexpr bool XP = XM == 1, XF = XM == 2;
+  constexpr int NPL = XM != 0 ? 2 : 3;        // weight planes per tile
   constexpr int CHUNK_U4 = T * NPL * 64;      // uint4 per weight chunk
   static_assert(!SEG || (NW == 4 && CHUNK_U4 * 16 >= 16 * 128 * 4), "the segmented max parks 16 x 128 floats in a weight buffer");
   extern __shared__ __attribute__((aligned(16))) char lna_smem[];
@@ -594,7 +601,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
     blk_step_ = gridDim.x / nslice;
   }
   const int ch_base = a.slice_w * slice_id;
-  const uint4* planes = a.planes + (XP ? 16 : 0) + (int64_t)slice_id * nkc * CHUNK_U4;  // (XP: behind the 256-byte header)
+  const uint4* planes = a.planes + (XM != 0 ? 16 : 0) + (int64_t)slice_id * nkc * CHUNK_U4;  // (f16 planes: behind the 256-byte header)
 
   // weight chunk kc -> LDS buffer by LDS-DMA: fragment order in HBM == fragment order in LDS, 1 KB per wave instruction
   auto stage_w = [&](int kc, int buf) {
@@ -657,6 +664,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
 #define LNA_BLK_END nblk
 #define LNA_BLK_STEP blk_step_
   lna_stage_vectors(a, ch_base, vec);
+  // (XF) the weight scale s_w, and the cap of a row's FIRST scale: with a per-row addend in the accumulators — it enters them multiplied
+  // by s * s_w — s * s_w stays <= 2^40 (an addend below 2^87 cannot overflow; a row whose values all lie below 2^-27 / s_w loses bits
+  // it could not contribute next to an addend anyway); without one, any scale a finite row asks for
+  float w_scale = 1.0f, xs_cap = 0x1p126f, xs_cap_inv = 0x1p-126f;
+  if constexpr (XF) {
+    w_scale = reinterpret_cast<const float*>(a.planes)[1];
+    if (a.row_add) {
+      int e = (int)((__float_as_uint(reinterpret_cast<const float*>(a.planes)[0]) >> 23) & 0xffu) - 127 + 40;
+      e = e < -126 ? -126 : (e > 126 ? 126 : e);
+      xs_cap = __uint_as_float((unsigned)(e + 127) << 23);
+      xs_cap_inv = __uint_as_float((unsigned)(127 - e) << 23);
+    }
+  }
   LnaTl tl;
 #ifdef FSF_LNA_TIMELINE
   tl.start();
@@ -718,6 +738,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
       }
     }
     float xinv[LNA_RG];
+    float xs_cur[LNA_RG];  // (XF) the unit the row's accumulators are kept in: acc = (true sum) * xs_cur * s_w; xinv = 1 / xs_cur
     if constexpr (XP) {  // the rows' inverse scales (requested here, used after the chunk loop)
 #pragma unroll
       for (int rg = 0; rg < LNA_RG; ++rg) {
@@ -753,9 +774,49 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
           for (int e = 0; e < 8; ++e)
             if (kc * LNA_KC + 8 * grp + e >= a.k) xc[rg][e] = 0.0f;
       }
-      if constexpr (!XP) {
+      if constexpr (XM == 0) {
 #pragma unroll
         for (int rg = 0; rg < LNA_RG; ++rg) lna_split8(xc[rg], xh[rg], xm[rg], xl[rg]);
+      }
+      if constexpr (XF) {
+        // K22f: a row's chunk is scaled by a power of two s with s * max|x| in [2^13, 2^14) and split into f16 hi + lo (22 bits relative
+        // to the maximum — the arithmetic of K9d / K22h).  The scale may only FALL from chunk to chunk (it follows the running maximum of
+        // the row, so a row is held to 22 bits of ITS maximum, like a whole-row scale would); when it falls, the row's accumulators,
+        // which are kept in the unit s * s_w, are multiplied by new / old — a power of two, exact.  The first chunk's scale is capped
+        // (xs_cap) where a per-row addend sits in the accumulators, which it enters multiplied by s * s_w.
+        float ratio[LNA_RG];
+        bool changed = false;
+#pragma unroll
+        for (int rg = 0; rg < LNA_RG; ++rg) {
+          unsigned mb = __float_as_uint(xc[rg][0]) & 0x7fffffffu;  // (bit patterns of |x| order like the values; NaN / inf end up largest)
+#pragma unroll
+          for (int e = 1; e < 8; ++e) mb = max(mb, __float_as_uint(xc[rg][e]) & 0x7fffffffu);
+          const auto r16 = __builtin_amdgcn_permlane16_swap(mb, mb, false, false);  // the four lanes of a row: lane ^ 16, lane ^ 32
+          mb = max(r16[0], r16[1]);
+          const auto r32 = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+          mb = max(r32[0], r32[1]);
+          float s_new, inv_new;
+          lna_pick_scale(__uint_as_float(mb), s_new, inv_new);
+          if (kc == 0) {
+            if (mb == 0u || s_new > xs_cap) { s_new = xs_cap; inv_new = xs_cap_inv; }
+            ratio[rg] = s_new * w_scale;
+            changed |= a.row_add != nullptr;  // (the accumulators hold the addend, unit 1, or zeros)
+          } else {
+            if (mb == 0u || s_new > xs_cur[rg]) { s_new = xs_cur[rg]; inv_new = xinv[rg]; }
+            ratio[rg] = s_new * xinv[rg];  // (1 where nothing changed)
+            changed |= s_new != xs_cur[rg];
+          }
+          xs_cur[rg] = s_new;
+          xinv[rg] = inv_new;
+          lna_split8_f16(xc[rg], s_new, xh[rg], xl[rg]);
+          xm[rg] = xh[rg];
+        }
+        if (__builtin_amdgcn_ballot_w64(changed) != 0) {  // (wave-uniform: rare after the first chunk)
+#pragma unroll
+          for (int rg = 0; rg < LNA_RG; ++rg)
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[rg][t] = acc[rg][t] * ratio[rg];
+        }
       }
       // this chunk's weights (DMA issued one iteration ago, before that iteration's MFMAs) have landed; the raw barrier
       // carries no fence, so nothing else is drained with them
@@ -779,7 +840,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
       const uint4* wc = wbuf + buf * CHUNK_U4;
       // Two channel tiles x LNA_RG row groups = 4 independent accumulators per product term: consecutive MFMAs never hit
       // the same accumulator
-      if constexpr (XP) {
+      if constexpr (XM != 0) {
 #pragma unroll
         for (int t = 0; t < T; t += 2) {
           lna_f16x8 wfr[2][2];
@@ -833,7 +894,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
       }
       }
     }
-    if constexpr (XP) {  // back to the unscaled product: both scales are powers of two (exact)
+    if constexpr (XM != 0) {  // back to the unscaled product: both scales are powers of two (exact)
       const float w_inv = *reinterpret_cast<const float*>(a.planes);
 #pragma unroll
       for (int rg = 0; rg < LNA_RG; ++rg) {
@@ -916,7 +977,7 @@ extern "C" int fsf_linear_prepare_weight_sliced(const float* weight, int32_t k, 
   return FSF_OK;
 }
 
-static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream, bool xp = false) {
+static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream, bool xp = false, bool xf = false) {
   LnaArgs a = a_in;
   const int T = lna_tiles(a.slice_w < a.c ? a.slice_w : a.c);
   const int rows = LNA_NW * LNA_RG * 16;
@@ -934,13 +995,28 @@ static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream, bool 
     return FSF_OK;
   }
   const dim3 grid((unsigned)gx, (unsigned)nslice);
-#define FSF_LNA(T_, NW_, SEG_, NORM_, ACT_)                                                                                          \
+#define FSF_LNA_X(T_, NW_, SEG_, NORM_, ACT_, XM_)                                                                                   \
   do {                                                                                                                              \
-    constexpr size_t smem = (size_t)2 * T_ * 3 * 64 * 16 + 384 * 4 + (SEG_ ? sizeof(LnaSegSmem) : 0);                                \
+    constexpr size_t smem = (size_t)2 * T_ * (XM_ ? 2 : 3) * 64 * 16 + 384 * 4 + (SEG_ ? sizeof(LnaSegSmem) : 0);                    \
     static std::atomic<uint64_t> attr_done{0};                                                                                      \
-    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_, NW_, SEG_, NORM_, ACT_>, (int)smem, attr_done));    \
-    hipLaunchKernelGGL((linear_norm_act_kernel<T_, NW_, SEG_, NORM_, ACT_>), grid, dim3(NW_ * 64), smem, stream, a);                \
+    FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)linear_norm_act_kernel<T_, NW_, SEG_, NORM_, ACT_, XM_>, (int)smem, attr_done)); \
+    hipLaunchKernelGGL((linear_norm_act_kernel<T_, NW_, SEG_, NORM_, ACT_, XM_>), grid, dim3(NW_ * 64), smem, stream, a);           \
   } while (0)
+#define FSF_LNA(T_, NW_, SEG_, NORM_, ACT_) FSF_LNA_X(T_, NW_, SEG_, NORM_, ACT_, 0)
+  if (xf) {  // K22f: the 64- and 128-channel-tile forms (what the SIR / VFE / segmentation-head layers are)
+    if (a.seg_out) {
+      if (a.norm != 1 || (a.act != 1 && a.act != 2)) return FSF_ERR_UNSUPPORTED;
+      if (T == 4 && a.act == 2) FSF_LNA_X(4, 4, true, 1, 2, 2);
+      else if (T == 4) FSF_LNA_X(4, 4, true, 1, 1, 2);
+      else if (T == 8 && a.act == 2) FSF_LNA_X(8, 4, true, 1, 2, 2);
+      else if (T == 8) FSF_LNA_X(8, 4, true, 1, 1, 2);
+      else return FSF_ERR_UNSUPPORTED;
+    } else if (T == 4) FSF_LNA_X(4, 4, false, -1, -1, 2);
+    else if (T == 8) FSF_LNA_X(8, 4, false, -1, -1, 2);
+    else return FSF_ERR_UNSUPPORTED;
+    FSF_LAUNCH_CHECK();
+    return FSF_OK;
+  }
   if (a.seg_out) {  // K22s: LayerNorm + GELU / ReLU (the SIR layers), 36 .. 128 channels
     if (a.norm != 1 || (a.act != 1 && a.act != 2)) return FSF_ERR_UNSUPPORTED;
     if (T == 4 && a.act == 2) FSF_LNA(4, 4, true, 1, 2);
@@ -952,6 +1028,7 @@ static int lna_launch(const LnaArgs& a_in, int nslice, hipStream_t stream, bool 
   else if (T == 4) FSF_LNA(4, 4, false, -1, -1);
   else FSF_LNA(8, 4, false, -1, -1);
 #undef FSF_LNA
+#undef FSF_LNA_X
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }
@@ -986,12 +1063,12 @@ extern "C" int fsf_linear_norm_act(const float* x, int64_t n, int32_t k, int64_t
                                      out_stride, stream_);
 }
 
-extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
-                                           const float* bias, const float* row_add, const int64_t* row_add_index,
-                                           int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta,
-                                           float eps, int32_t act, float* out, int64_t out_stride, void* stream_) {
+static int lna_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c, const float* bias,
+                       const float* row_add, const int64_t* row_add_index, int64_t row_add_stride, int32_t norm, const float* gamma,
+                       const float* beta, float eps, int32_t act, float* out, int64_t out_stride, void* stream_, bool xf) {
   hipStream_t stream = (hipStream_t)stream_;
   if ((row_add == nullptr) != (row_add_index == nullptr)) return FSF_ERR_INVALID_ARG;
+  if (xf && (c <= 32 || ((uintptr_t)planes % 16) != 0)) return FSF_ERR_UNSUPPORTED;
   if (row_add && ((row_add_stride % 4) != 0 || row_add_stride < c || ((uintptr_t)row_add % 16) != 0)) return FSF_ERR_UNSUPPORTED;
   if (n < 0 || k < 1 || c < 1 || !planes || norm < 0 || norm > 2 || act < 0 || act > 2 || (norm != 0 && (!gamma || !beta)) ||
       (n > 0 && (!x || !out)))
@@ -1004,15 +1081,31 @@ extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k,
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
             row_add, row_add_index, row_add_stride, 128, (int)c, 0, nullptr, nullptr, 0, nullptr};
-  return lna_launch(a, lna_slices(c), stream);
+  return lna_launch(a, lna_slices(c), stream, false, xf);
 }
 
-extern "C" int fsf_linear_norm_act_segmax(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
-                                          const float* bias, const float* row_add, const int64_t* row_add_index,
-                                          int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta, float eps,
-                                          int32_t act, const int64_t* seg_ids, int64_t num_segments,
-                                          float* seg_out, int64_t seg_out_stride, float* out, int64_t out_stride, void* stream_) {
+extern "C" int fsf_linear_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
+                                           const float* bias, const float* row_add, const int64_t* row_add_index,
+                                           int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta,
+                                           float eps, int32_t act, float* out, int64_t out_stride, void* stream_) {
+  return lna_grouped(x, n, k, x_stride, planes, c, bias, row_add, row_add_index, row_add_stride, norm, gamma, beta, eps, act, out,
+                     out_stride, stream_, false);
+}
+
+extern "C" int fsf_linear_f16w_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* w_planes, int32_t c,
+                                                const float* bias, const float* row_add, const int64_t* row_add_index,
+                                                int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta,
+                                                float eps, int32_t act, float* out, int64_t out_stride, void* stream_) {
+  return lna_grouped(x, n, k, x_stride, w_planes, c, bias, row_add, row_add_index, row_add_stride, norm, gamma, beta, eps, act, out,
+                     out_stride, stream_, true);
+}
+
+static int lna_segmax(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c, const float* bias,
+                      const float* row_add, const int64_t* row_add_index, int64_t row_add_stride, int32_t norm, const float* gamma,
+                      const float* beta, float eps, int32_t act, const int64_t* seg_ids, int64_t num_segments, float* seg_out,
+                      int64_t seg_out_stride, float* out, int64_t out_stride, void* stream_, bool xf) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (xf && planes && ((uintptr_t)planes % 16) != 0) return FSF_ERR_UNSUPPORTED;
   if ((row_add == nullptr) != (row_add_index == nullptr)) return FSF_ERR_INVALID_ARG;
   if (row_add && ((row_add_stride % 4) != 0 || row_add_stride < c || ((uintptr_t)row_add % 16) != 0)) return FSF_ERR_UNSUPPORTED;
   if (n < 0 || k < 1 || c < 1 || !planes || norm < 0 || norm > 2 || act < 0 || act > 2 || (norm != 0 && (!gamma || !beta)) ||
@@ -1028,7 +1121,25 @@ extern "C" int fsf_linear_norm_act_segmax(const float* x, int64_t n, int32_t k, 
   if (n == 0) return FSF_OK;
   LnaArgs a{x, x_stride, (int)k, (const uint4*)planes, bias, gamma, beta, eps, (int)norm, (int)act, out, out_stride, n, (int)c,
             row_add, row_add_index, row_add_stride, 128, (int)c, 0, seg_ids, seg_out, seg_out_stride, nullptr};
-  return lna_launch(a, 1, stream);
+  return lna_launch(a, 1, stream, false, xf);
+}
+
+extern "C" int fsf_linear_norm_act_segmax(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* planes, int32_t c,
+                                          const float* bias, const float* row_add, const int64_t* row_add_index,
+                                          int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta, float eps,
+                                          int32_t act, const int64_t* seg_ids, int64_t num_segments,
+                                          float* seg_out, int64_t seg_out_stride, float* out, int64_t out_stride, void* stream_) {
+  return lna_segmax(x, n, k, x_stride, planes, c, bias, row_add, row_add_index, row_add_stride, norm, gamma, beta, eps, act, seg_ids,
+                    num_segments, seg_out, seg_out_stride, out, out_stride, stream_, false);
+}
+
+extern "C" int fsf_linear_f16w_norm_act_segmax(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* w_planes, int32_t c,
+                                               const float* bias, const float* row_add, const int64_t* row_add_index,
+                                               int64_t row_add_stride, int32_t norm, const float* gamma, const float* beta, float eps,
+                                               int32_t act, const int64_t* seg_ids, int64_t num_segments,
+                                               float* seg_out, int64_t seg_out_stride, float* out, int64_t out_stride, void* stream_) {
+  return lna_segmax(x, n, k, x_stride, w_planes, c, bias, row_add, row_add_index, row_add_stride, norm, gamma, beta, eps, act, seg_ids,
+                    num_segments, seg_out, seg_out_stride, out, out_stride, stream_, true);
 }
 
 // ---- K22h entry points ---------------------------------------------------------------------------------------------------

@@ -41,6 +41,7 @@ KEY_SURVIVAL = _on("FSF_KEY_SURVIVAL")              # ... and its density filter
 VFE_DECORATE = _on("FSF_VFE_DECORATE")              # the VFE input decoration in one kernel
 LAZY_CAT = _on("FSF_LAZY_CAT")                    # inference: the U-Net decoder's channel concatenation is written only if read as one tensor
 SPLIT_F16 = _on("FSF_SPLIT_F16")                  # inference: K9b's layers with whole 32-channel chunks on f16 x 3 planes (K9b-XP)
+K22F = _on("FSF_K22F")                              # the <= 128-channel-slice Linears (K22 / K22s) on f16 x 3: x split in the kernel per row, W as f16 planes (K22f)
 K22H = _on("FSF_K22H")                              # inference: the wide (>= 256 -> >= 256 channel) Linears on f16 x 3 planes (K22h)
 K22H_MIN_ROWS = _int("FSF_K22H_MIN_ROWS", 1024)
 UNET_MASK_ORDER = _on("FSF_UNET_MASK_ORDER")          # inference: the U-Net's fine levels in neighbour-mask row order

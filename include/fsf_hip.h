@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 16
+#define FSF_ABI_VERSION 17
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -309,6 +309,26 @@ int fsf_linear_norm_act_segmax(const float* x, int64_t n, int32_t k, int64_t x_s
                                int32_t norm, const float* gamma, const float* beta, float eps, int32_t act,
                                const int64_t* seg_ids, int64_t num_segments, float* seg_out, int64_t seg_out_stride, float* out,
                                int64_t out_stride, void* stream);
+
+/* K22f — the same two operators (fsf_linear_norm_act_grouped, of which fsf_linear_norm_act is the row_add == NULL case, and
+ * fsf_linear_norm_act_segmax: same arguments, same results up to the arithmetic below) on THREE matrix passes per product instead of six:
+ * `w_planes` comes from fsf_linear_prepare_weight_f16(weight, k, c, slice_c = min(128, c)) — f16 hi | lo of W * s_w behind a 256-byte
+ * header — and the kernel splits x the same way per row: a chunk of 32 columns is scaled by a power of two s with s * max|x| in
+ * [2^13, 2^14), s following the running maximum of the row (it only falls along the row; the accumulators, kept in the unit s * s_w, are
+ * multiplied by new / old — exact — when it does), hi = rn_f16(x s), lo = rn_f16(x s - hi); product = hi hi + hi lo + lo hi on
+ * v_mfma_f32_16x16x32_f16, fp32 accumulation.  A row is held to 22 bits relative to ITS largest element (the bf16 form: 24 bits of every
+ * element): error against float64 <= that of an fp32 GEMM on the tests' inputs (tests/test_hip_ops.py).  With a per-row addend the
+ * row's first scale is capped so that s * s_w <= 2^40 (the addend sits in the accumulators in that unit: |addend| < 2^87).
+ * 32 < c (more than two 16-channel tiles); otherwise the restrictions of the bf16 entry points.  FSF_ERR_UNSUPPORTED outside them. */
+int fsf_linear_f16w_norm_act_grouped(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* w_planes, int32_t c,
+                                     const float* bias, const float* row_add, const int64_t* row_add_index, int64_t row_add_stride,
+                                     int32_t norm, const float* gamma, const float* beta, float eps, int32_t act, float* out,
+                                     int64_t out_stride, void* stream);
+int fsf_linear_f16w_norm_act_segmax(const float* x, int64_t n, int32_t k, int64_t x_stride, const void* w_planes, int32_t c,
+                                    const float* bias, const float* row_add, const int64_t* row_add_index, int64_t row_add_stride,
+                                    int32_t norm, const float* gamma, const float* beta, float eps, int32_t act, const int64_t* seg_ids,
+                                    int64_t num_segments, float* seg_out, int64_t seg_out_stride, float* out, int64_t out_stride,
+                                    void* stream);
 /* "Sliced": nslice INDEPENDENT layers of slice_c (<= 128, % 4 == 0) output channels each in ONE launch — the per-attribute
  * MLPs of FSDSeparateHead (projects/mmdet3d_plugin/models/dense_heads/sparse_cluster_head_v2.py:18-50: center / dim / rot /
  * vel / score branches, every one `build_mlp(in, [hidden] * num_layer + [out_dim])` on the SAME query features) side by side:

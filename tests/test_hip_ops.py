@@ -1324,6 +1324,73 @@ def test_linear_norm_act_split_bf16_is_fp32_accurate(ops, device, n, k, c, norm,
                                                 beta=be if norm != "none" else None, eps=1e-3, act=act))
 
 
+@pytest.mark.parametrize("n,k,c,norm,act,addend", [(50021, 128, 128, "ln", "gelu", True), (20000, 180, 128, "ln", "relu", False),
+                                                    (7001, 133, 64, "ln", "gelu", True), (30000, 11, 64, "affine", "relu", False),
+                                                    (4099, 256, 256, "none", "none", False), (513, 96, 36, "ln", "gelu", True),
+                                                    (1, 64, 128, "ln", "gelu", True), (100003, 131, 128, "affine", "relu", True)])
+def test_linear_f16x3_in_kernel_split_vs_float64(ops, device, n, k, c, norm, act, addend):
+    """K22f (fsf_linear_f16w_norm_act_grouped): fp32 x split IN the kernel into f16 hi | lo per row with a running power-of-two unit,
+    W as f16 planes, three MFMA passes.  Against float64 on four kinds of rows — plain normal; a wide dynamic range inside every row;
+    rows whose magnitude RISES along k by 1e6 (the unit falls mid-row: the accumulators are rescaled); rows whose first 32 columns are
+    zero and the rest tiny (the first scale is the cap, later chunks lower it) — the error stays within 2 x that of torch's fp32
+    F.linear (or 2e-6 of the output scale), like the exact bf16 x 6 form, and the two forms agree to 1e-5 of the scale."""
+    torch.manual_seed(n + k)
+    F = torch.nn.functional
+    w = torch.randn(c, k) / k ** 0.5
+    b = torch.randn(c)
+    g, be = torch.rand(c) + 0.5, torch.randn(c)
+    table = torch.randn(257, c) * 2 if addend else None
+    idx = torch.randint(0, 257, (n,)) if addend else None
+    kinds = [torch.randn(n, k), torch.randn(n, k) * torch.exp(torch.randn(n, k) * 4),
+             torch.randn(n, k) * torch.logspace(-3, 3, k)[None, :],
+             torch.cat([torch.zeros(n, min(32, k)), torch.randn(n, max(k - 32, 0)) * 1e-12], 1)[:, :k]]
+    for kind, x in enumerate(kinds):
+        x = x.contiguous()
+        xs_ = torch.zeros(n, (k + 3) // 4 * 4)
+        xs_[:, :k] = x
+        xd = xs_.to(device)[:, :k]
+        def ref(dt):
+            z = F.linear(x.to(dt), w.to(dt), b.to(dt))
+            if addend:
+                z = z + table.to(dt)[idx]
+            if norm == "ln":
+                z = F.layer_norm(z, (c,), g.to(dt), be.to(dt), 1e-3)
+            elif norm == "affine":
+                z = z * g.to(dt) + be.to(dt)
+            return F.gelu(z) if act == "gelu" else F.relu(z) if act == "relu" else z
+        want, ref32 = ref(torch.float64), ref(torch.float32)
+        kw = dict(bias=b.to(device), norm=norm, gamma=g.to(device) if norm != "none" else None, beta=be.to(device) if norm != "none" else None,
+                  eps=1e-3, act=act, row_add=table.to(device) if addend else None, row_add_index=idx.to(device) if addend else None)
+        got = {}
+        for fmt in ("f16x3", "bf16x6"):
+            planes = ops.linear_prepare_weight(w.to(device), fmt=fmt)
+            assert bool(getattr(planes, "_fsf_f16w", False)) == (fmt == "f16x3")
+            got[fmt] = ops.linear_norm_act(xd, planes, c, **kw).cpu()
+        scale = float(want.abs().max())
+        err32 = float((ref32.double() - want).abs().max())
+        for fmt, y in got.items():
+            err = float((y.double() - want).abs().max())
+            assert torch.isfinite(y).all() and err <= max(2.0 * err32, 2e-6 * scale), (kind, fmt, err, err32, scale)
+        assert float((got["f16x3"] - got["bf16x6"]).abs().max()) <= 1e-5 * scale, kind
+
+
+def test_linear_f16x3_addend_magnitudes(ops, device):
+    """K22f keeps the per-row addend in the accumulators in the unit s_x * s_w; the first scale of a row is capped so that s_x * s_w <=
+    2^40: addends up to 1e20 beside inputs of any size come through to fp32 accuracy, rows of denormal-small inputs contribute nothing
+    measurable beside an O(1) addend."""
+    torch.manual_seed(5)
+    n, k, c = 4096, 128, 128
+    w = (torch.randn(c, k) / k ** 0.5).to(device)
+    for xmag, amag in [(1.0, 1e20), (1e-30, 1.0), (1e20, 1e-20), (1e-6, 1e6)]:
+        x = (torch.randn(n, k) * xmag).to(device)
+        table = (torch.randn(64, c) * amag).to(device)
+        idx = torch.randint(0, 64, (n,), device=device)
+        y = ops.linear_norm_act(x, ops.linear_prepare_weight(w, fmt="f16x3"), c, row_add=table, row_add_index=idx)
+        want = x.double() @ w.double().t() + table.double()[idx]
+        assert torch.isfinite(y).all()
+        assert float((y.double() - want).abs().max()) <= 4e-6 * float(want.abs().max()), (xmag, amag)
+
+
 @pytest.mark.parametrize("n,cin,cout", [(101119, 256, 128), (1517, 1024, 512), (33, 128, 64), (1, 8, 4)])
 def test_channel_group_sum_add_equals_torch(ops, device, n, cin, cout):
     """The U-Net decoder's `features.view(n, C, -1).sum(2) + merge` in one pass: bit-identical to the two torch ops."""
@@ -1592,7 +1659,7 @@ def test_linear_norm_act_sliced_equals_separate_calls(ops, device, n, k, ns, sc,
         sl = slice(s * sc, (s + 1) * sc)
         xs = x[:, s * off:s * off + k]
         if (s * off) % 4 == 0 and (n == 1 or True):
-            one = ops.linear_norm_act(xs, ops.linear_prepare_weight(w[sl].contiguous()), sc, bias=bias[sl].contiguous(), norm=norm,
+            one = ops.linear_norm_act(xs, ops.linear_prepare_weight(w[sl].contiguous(), fmt="bf16x6"), sc, bias=bias[sl].contiguous(), norm=norm,
                                       gamma=gam[sl].contiguous() if norm != "none" else None,
                                       beta=bet[sl].contiguous() if norm != "none" else None, eps=1e-3, act=act)
             assert torch.equal(out[:, sl], one), s

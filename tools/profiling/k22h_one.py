@@ -11,7 +11,7 @@ w = torch.randn(c, k, device=dev) / k ** 0.5
 b = torch.randn(c, device=dev)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 if os.environ.get("FSF_K22H_ONE") == "k22":
-    planes = ops.linear_prepare_weight(w)
+    planes = ops.linear_prepare_weight(w, fmt="bf16x6")
     for _ in range(reps): ops.linear_norm_act(x, planes, c, bias=b)
 else:
     wp = ops.linear_prepare_weight_f16(w, 128); xp = ops.rows_to_planes(x)

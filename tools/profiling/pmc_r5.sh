@@ -11,7 +11,7 @@ run() {  # <file> <title> <kernel substring> <cmd...>
   for set in "${SETS[@]}"; do bash tools/profiling/pmc_kernel.sh "$pat" $set -- "$@" 2>/dev/null >> $f; done
 }
 run pmc_k22s.txt "K22s: fsf_linear_norm_act_segmax, 510 652 rows sorted by group x 128 -> 128, grouped (row_add), LayerNorm + GELU + segmented max, rows written" "linear_norm_act_kernel<8, 4, true" python tools/profiling/k22s_one.py 5
-run pmc_k22h.txt "K22h: fsf_linear_planes_norm_act, 10 641 rows x 1024 -> 1024 + bias, f16 x 3 planes" "linear_norm_act_kernel<8, 4, false, -1, -1, true" python tools/profiling/k22h_one.py 5
-FSF_K22H_ONE=k22 run pmc_k22_wide_bf16x6.txt "the same product on K22 (bf16 x 6, x split in the kernel, 8 slices on blockIdx.y)" "linear_norm_act_kernel<8, 4, false, -1, -1, false" python tools/profiling/k22h_one.py 5
+run pmc_k22h.txt "K22h: fsf_linear_planes_norm_act, 10 641 rows x 1024 -> 1024 + bias, f16 x 3 planes" "linear_norm_act_kernel<8, 4, false, -1, -1, 1>" python tools/profiling/k22h_one.py 5
+FSF_K22H_ONE=k22 run pmc_k22_wide_bf16x6.txt "the same product on K22 (bf16 x 6, x split in the kernel, 8 slices on blockIdx.y)" "linear_norm_act_kernel<8, 4, false, -1, -1, 0>" python tools/profiling/k22h_one.py 5
 run pmc_stalls_k9d.txt "K9d: fsf::spconv_fwd_pipe_kernel on the 101 119-row 128 -> 128 submanifold layer (tools/profiling/planes_one.py 2)" "spconv_fwd_pipe_kernel" python tools/profiling/planes_one.py 2
 run pmc_k10p.txt "K10p: fsf::spconv_bwd_weight_split_kernel over the frame's 34 layers (tools/profiling/bwd_weight_layers.py)" "spconv_bwd_weight_split_kernel" python tools/profiling/bwd_weight_layers.py
