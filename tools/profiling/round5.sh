@@ -41,4 +41,6 @@ python bench.py --trained-like --no-cpu-baseline > $out/bench_trained_like.json 
 { hdr; python tools/profiling/stage_times.py 2>/dev/null; } > $out/stage_times.txt
 { hdr; python tools/profiling/train_ops.py 60 2>/dev/null; } > $out/train_step_ops.txt
 { hdr; bash tools/profiling/ab_bench.sh "FSF_K22H=0 FSF_SCS_XCD=0" "FSF_K22H=1" 2>/dev/null; } > $out/ab_k22h_k9b_xcd.txt
+{ hdr; bash tools/profiling/ab_env_kernel_stats.sh FSF_K22F "linear_norm_act_kernel" 2>/dev/null; } > $out/ab_k22f_kernel_stats.txt
+{ hdr; python tools/profiling/sir_bench.py 2>/dev/null | tr "|" "\n"; } > $out/sir_k21_k22_microbench.txt
 tail -c 600 $out/bench_final.json; echo; tail -c 300 $out/bench_train.json; echo; head -5 $out/kernel_stats_full_forward.txt
