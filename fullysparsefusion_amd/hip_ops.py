@@ -1013,20 +1013,24 @@ def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_di
     return out
 
 
+def linear_weight_is_f16(planes: torch.Tensor) -> bool:
+    """Which of `linear_prepare_weight`'s two formats a prepared weight is in (by its size: see there)."""
+    return (planes.numel() & 1023) == 256
+
+
 def linear_prepare_weight(weight: torch.Tensor, fmt: Optional[str] = None):
     """Linear weight f32 [c, k] -> the opaque fragment planes `linear_norm_act` / `linear_norm_act_segmax` take (u8 tensor).
     fmt "bf16x6": fsf_linear_prepare_weight (exact 3-way bf16 split, six MFMA passes per product); "f16x3": fsf_linear_prepare_weight_f16
     (f16 hi | lo of W * s_w behind a header; the kernel then splits x the same way with a per-row scale: three passes, K22f) — the
-    default for more than 32 output channels while `switches.K22F` is on.  The tensor carries its format (`_fsf_f16w`)."""
+    default for more than 32 output channels while `switches.K22F` is on.  The two formats differ in size (`linear_weight_is_f16`): the
+    bf16 planes are a multiple of 1 KB, the f16 planes a multiple of 1 KB behind a 256-byte header — a clone or a copy keeps its format."""
     require_cuda(weight)
     weight = weight.detach().contiguous()
     c, k = weight.shape
     if fmt is None:
         fmt = "f16x3" if switches.K22F and c > 32 and c % 4 == 0 else "bf16x6"
     if fmt == "f16x3":
-        planes = linear_prepare_weight_f16(weight, min(128, c))
-        planes._fsf_f16w = True
-        return planes
+        return linear_prepare_weight_f16(weight, min(128, c))
     h = _L()
     planes = torch.empty(h.fsf_linear_prepared_weight_bytes(k, c), dtype=torch.uint8, device=weight.device)
     check(h.fsf_linear_prepare_weight(ptr(weight), k, c, ptr(planes), stream_ptr()), "fsf_linear_prepare_weight")
@@ -1054,7 +1058,7 @@ def linear_norm_act(x: torch.Tensor, planes: torch.Tensor, out_features: int, bi
     xs = x.stride(0) if n > 1 else (k + 3) // 4 * 4
     os_ = out.stride(0) if n > 1 else (c + 3) // 4 * 4
     norm_code, act_code = {"none": 0, "ln": 1, "affine": 2}[norm], {"none": 0, "relu": 1, "gelu": 2}[act]
-    f16w = getattr(planes, "_fsf_f16w", False)
+    f16w = linear_weight_is_f16(planes)
     if row_add is None and not f16w:
         check(_L().fsf_linear_norm_act(c_p(x.data_ptr()) if n else c_p(None), n, k, xs, ptr(planes), c, ptr(bias), norm_code,
                                        ptr(gamma), ptr(beta), float(eps), act_code,
@@ -1096,7 +1100,7 @@ def linear_norm_act_segmax(x: torch.Tensor, planes: torch.Tensor, out_features: 
     if row_add is not None:
         assert (row_add.dtype == torch.float32 and row_add.dim() == 2 and row_add.size(1) == c and row_add.is_contiguous()
                 and row_add_index.dtype == torch.int64 and row_add_index.shape == (n,) and row_add_index.is_contiguous())
-    fn = _L().fsf_linear_f16w_norm_act_segmax if getattr(planes, "_fsf_f16w", False) else _L().fsf_linear_norm_act_segmax
+    fn = _L().fsf_linear_f16w_norm_act_segmax if linear_weight_is_f16(planes) else _L().fsf_linear_norm_act_segmax
     check(fn(c_p(x.data_ptr()) if n else c_p(None), n, k, xs, ptr(planes), c, ptr(bias), ptr(row_add),
                                           ptr(row_add_index), row_add.stride(0) if row_add is not None else 0, norm_code, ptr(gamma),
                                           ptr(beta), float(eps), act_code, ptr(seg_ids), m,

@@ -66,3 +66,18 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_the_two_prepared_linear_weight_formats_differ_in_size():
+    """hip_ops.linear_norm_act picks the entry point (bf16 x 6 or K22f's f16 x 3) from the prepared buffer's SIZE: the bf16 planes are
+    whole kilobytes, the f16 planes whole kilobytes behind a 256-byte header — for every shape (size functions only: no device)."""
+    from fullysparsefusion_amd import build
+
+    lib = ctypes.CDLL(build.build())
+    for fn in (lib.fsf_linear_prepared_weight_bytes, lib.fsf_linear_prepared_weight_f16_bytes):
+        fn.restype = ctypes.c_int64
+    for k in (1, 11, 32, 64, 128, 133, 180, 256, 1024):
+        for c in (4, 16, 36, 40, 64, 100, 128, 132, 256, 640, 1024):
+            a = lib.fsf_linear_prepared_weight_bytes(k, c)
+            b = lib.fsf_linear_prepared_weight_f16_bytes(k, c, min(128, c))
+            assert a > 0 and (a & 1023) == 0 and b > 256 and (b & 1023) == 256, (k, c, a, b)
