@@ -214,7 +214,11 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
         const uint32_t ri = (uint32_t)__builtin_amdgcn_readlane(icur, i);   // (rows past n repeat the last one: see load_idx)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
+#ifdef SI_ABL_NO_SRC  // ablation: no source loads (WRONG results)
+          x[i][t] = __uint_as_float(ri + t);
+#else
           x[i][t] = *(cur[t] + (uint64_t)ri * (uint64_t)gstr[t]);
+#endif
           if (i + 1 < nrow) cur[t] += step[t];  // (wave-uniform)
         }
       }
@@ -226,7 +230,11 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
       for (int i = 0; i < 16; ++i) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
+#ifdef SI_ABL_NO_SRC
+          x[i][t] = (float)(i + t);
+#else
           x[i][t] = *rp[t];
+#endif
           if (i + 1 < nrow) rp[t] += xstride[t];  // (wave-uniform; rows past n repeat the last one)
         }
       }
@@ -302,7 +310,11 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
       for (int t2 = 0; t2 < 2; ++t2) {
         const si_f32x4 wf = *reinterpret_cast<const si_f32x4*>(w3f + ((t3 * 2 + t2) * 64 + lane) * 4);
 #pragma unroll
+#ifdef SI_ABL_NO_MFMA3  // ablation: layer 3's 8 NT3 fp32 MFMAs replaced by one VALU op each (WRONG results)
+        for (int r = 0; r < 4; ++r) acc3[t3][r] += wf[r] * h2v[t2][r];
+#else
         for (int r = 0; r < 4; ++r) acc3[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[r], h2v[t2][r], acc3[t3], 0, 0, 0);
+#endif
       }
     }
     {
@@ -353,7 +365,11 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
             asm volatile("" ::: "memory");
             xv = __fdiv_rn(xv, xdiv[t]);
           }
+#ifdef SI_ABL_NO_STORE  // ablation: no output stores
+          if (xv * tile[i * TS + lane + 64 * t] == 123.456f) orow[64 * t] = 0.0f;
+#else
           if (lane + 64 * t < a.c) orow[64 * t] = xv * tile[i * TS + lane + 64 * t];
+#endif
         }
         orow += a.out_stride;
       }
