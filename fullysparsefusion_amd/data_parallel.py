@@ -112,6 +112,7 @@ class FrameDataParallel(torch.nn.Module):
                 b.flat.zero_()
             b.pending = len(b.params)
             b.work, b.launched = None, False
+            b.arrived = []  # (a backward pass that raised may have left hand-overs behind: they belong to no step)
             if not zero:
                 dropped = [v for p, v in zip(b.params, b.views) if p.grad is None]
                 if len(dropped) == len(b.params):
@@ -192,5 +193,24 @@ class FrameDataParallel(torch.nn.Module):
             for p, v in zip(b.params, b.views):
                 if p.grad is not None and p.grad.data_ptr() == v.data_ptr():
                     p.grad = None
-        loss.backward()
+        try:
+            loss.backward()
+        except BaseException:
+            self._abort()
+            raise
         self.finish()
+
+    def _abort(self):
+        """A backward pass that raised mid-way (a skip-on-OOM loop catches it and goes on): drop the gradients autograd had handed
+        over, wait for bucket collectives already in flight (their ranks' peers issued them too), re-point every `param.grad` at its
+        view and disarm.  The buckets then hold a partial sum of the failed step; the caller's `zero_grad()` (either style) clears
+        it as after any step, and nothing of the failed pass reaches the next one."""
+        for b in self.buckets:
+            b.arrived = []
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+            b.launched = False
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+        self._armed = False

@@ -366,6 +366,45 @@ def test_zero_grad_clears_a_gradient_tensor_that_is_not_the_bucket_view():
         assert p.grad.data_ptr() == dp._view[p].data_ptr() and bool((p.grad == 2.0).all())
 
 
+def test_a_backward_that_raises_leaves_nothing_behind_for_the_next_step():
+    """`backward()` detaches `param.grad` from the views and collects the gradients autograd hands over; a pass
+    that raises mid-way (a skip-on-OOM loop catches it) must not leak those into the next step, with either way of clearing."""
+    from fullysparsefusion_amd.data_parallel import FrameDataParallel
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("out of memory (simulated)")
+
+    for clear in ("dp", "opt_none", "opt_zero"):
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(4, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        ref = torch.nn.Sequential(torch.nn.Linear(4, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+        ref.load_state_dict(net.state_dict())
+        dp = FrameDataParallel(net, bucket_mb=0.00001)  # several buckets: the last layers' have flushed when the pass dies
+        assert len(dp.buckets) > 1
+        opt = torch.optim.SGD(net.parameters(), lr=0.0)
+        x = torch.randn(7, 4)
+        dp.zero_grad()
+        with pytest.raises(RuntimeError, match="simulated"):
+            dp.backward((net[2](Boom.apply(net[1](net[0](x)))) ** 2).sum())  # the last Linear's gradients arrive, then the pass dies
+        assert not dp._armed and all(b.arrived == [] and b.work is None for b in dp.buckets)
+        for p in net.parameters():
+            assert p.grad is not None and p.grad.data_ptr() == dp._view[p].data_ptr()
+        if clear == "dp":
+            dp.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=(clear == "opt_none"))
+        dp.backward((dp(x) ** 2).sum())
+        (ref(x) ** 2).sum().backward()
+        for (n, p), q in zip(net.named_parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-7), (clear, n)
+
+
 # ----------------------------------------------- world size 8 (north_star: the 8 GPUs of one node), gloo on CPU
 def _dp8_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
