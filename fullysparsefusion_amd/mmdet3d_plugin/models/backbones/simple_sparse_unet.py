@@ -280,9 +280,13 @@ class SimpleSparseUNet(nn.Module):
                         t.record_stream(main)  # allocated on the side stream, consumed (and later freed) on this one
                 x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f"lateral_layer{i}"),
                                                getattr(self, f"merge_layer{i}"), getattr(self, f"upsample_layer{i}"), lateral_out=lat)
-        finally:
+        except BaseException:
             if lateral_done:  # whatever happens in the decoder, the main stream ends behind the side stream's work
                 torch.cuda.current_stream().wait_stream(self._lateral_stream)
+            raise
+        # (the decoder loop has waited for every `lateral_done` event, the last things the side stream ran: a `wait_stream` here
+        # would record one more event on a stream that went idle a millisecond ago — waking its hardware queue for that marker held
+        # the main stream for ~150 us in front of the neck, on the 1-sweep frame as on the 10-sweep one)
         mark("decoder done")
         out = x.features
         if inv_perm is not None:
