@@ -133,6 +133,14 @@ _ARGTYPES = {
     "fsf_spconv_split_weight_f16_bytes": [c_i32, c_i32, c_i32],
     "fsf_spconv_prepare_weight_split_f16": [_P, c_i32, c_i32, c_i32, _P, _P],
     "fsf_spconv_forward_split_planes": [_P, _P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
+    "fsf_sorted_rows": [_P, _P, c_i64, _P, c_i64, c_i32, _P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, _P, c_i64, c_f32, _P],
+    "fsf_compact_pairs": [_P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P, _P],
+    "fsf_combine_queries": [_P, c_i64, _P, c_i64, _P, _P, _P, c_i32, c_i64, _P, _P, _P, _P],
+    "fsf_decode_rois": [_P, c_i64, c_i32, _P, c_i64, _P, c_i64, c_i64, c_f32, _P, _P],
+    "fsf_refine_rows": [_P, _P, c_i64, c_i32, _P, _P, _P, c_i64, c_i64, _P, _P, _P],
+    "fsf_encode_preds_2d": [_P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, c_f32, _P, _P, c_i64, _P],
+    "fsf_weighted_xyz": [_P, c_i64, _P, c_i64, c_f32, _P, _P],
+    "fsf_centroid_divide": [_P, c_i64, _P, _P],
 }
 _configured = False
 
@@ -1533,3 +1541,139 @@ def norm_act_backward(x: torch.Tensor, grad_out: torch.Tensor, gamma, beta, eps:
     check(h.fsf_norm_act_backward(ptr(x), ptr(grad_out), n, c, ptr(gamma), ptr(beta), float(eps), _ACTS[act], ptr(gx), ptr(dg),
                                   ptr(db), ptr(ws), ws.numel(), stream_ptr()), "fsf_norm_act_backward")
     return gx, dg, db
+
+
+# ------------------------------------------------------------------------------- K29: query-stage glue (csrc/query_glue.hip)
+def _f32_rows(t):
+    """(data pointer, row stride) of an f32 [n, c] tensor whose rows are contiguous (column slices of wider buffers qualify)."""
+    assert t.dtype == torch.float32 and t.dim() == 2
+    if t.stride(1) != 1 and t.size(1) > 1:
+        t = t.contiguous()
+    return t, c_p(t.data_ptr()) if t.numel() else c_p(None), int(t.stride(0)) if t.size(0) > 1 else int(max(t.size(1), 1))
+
+
+def sorted_rows(order, inv, points, f_cluster=None, centers=None, index=None, fill=None, fill_value=float("-inf")):
+    """fsf_sorted_rows: the operands of a SIR stack in the unique's sort order -> (seg_ids i64 [n], points [n, c], f_cluster [n, 3],
+    index i64 [n]); `fill` (a contiguous f32 tensor, e.g. the stack's group table) is set to `fill_value` in the same launch.
+    f_cluster=None: points[:, :3] - centers[inv]."""
+    require_cuda(order, inv, points, f_cluster, centers, index, fill)
+    assert order.dtype == torch.int32 and inv.dtype == torch.int64 and order.is_contiguous() and inv.is_contiguous()
+    n = order.numel()
+    pts, pp, ps = _f32_rows(points)
+    dev = points.device
+    fc = cc = None
+    fp, fs, cp_, cs = c_p(None), 3, c_p(None), 3
+    if f_cluster is not None:
+        fc, fp, fs = _f32_rows(f_cluster)
+        assert fc.shape == (n, 3)
+    else:
+        cc, cp_, cs = _f32_rows(centers)
+        assert cc.size(1) >= 3
+    if index is not None:
+        index = index.to(torch.int64).contiguous()
+    seg_ids = torch.empty((n,), dtype=torch.int64, device=dev)
+    idx_s = torch.empty((n,), dtype=torch.int64, device=dev)
+    pts_s = torch.empty((n, pts.size(1)), dtype=torch.float32, device=dev)
+    fcl_s = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    if fill is not None:
+        assert fill.dtype == torch.float32 and fill.is_contiguous()
+    check(_L().fsf_sorted_rows(ptr(order), ptr(inv), n, pp, ps, pts.size(1), fp, fs, cp_, cs, ptr(index), ptr(seg_ids), ptr(pts_s), ptr(fcl_s),
+                               ptr(idx_s), ptr(fill), fill.numel() if fill is not None else 0, float(fill_value), stream_ptr()),
+          "fsf_sorted_rows")
+    return seg_ids, pts_s, fcl_s, idx_s
+
+
+def compact_pairs(means, k_idx, g_ids, p_ids, b_pts, centers, v_idx):
+    """fsf_compact_pairs -> (means[k_idx] [nk, 3], g_ids[v_idx], p_ids[v_idx], b_pts[v_idx], centers[v_idx] [nv, 3])."""
+    require_cuda(means, k_idx, g_ids, p_ids, b_pts, centers, v_idx)
+    mm, mp, ms = _f32_rows(means)
+    centers = centers.contiguous()
+    assert centers.dtype == torch.float32 and centers.size(1) == 3 and mm.size(1) >= 3
+    k_idx, v_idx = k_idx.to(torch.int64).contiguous(), v_idx.to(torch.int64).contiguous()
+    g_ids, p_ids, b_pts = (t.to(torch.int64).contiguous() for t in (g_ids, p_ids, b_pts))
+    nk, nv, dev = k_idx.numel(), v_idx.numel(), means.device
+    vox = torch.empty((nk, 3), dtype=torch.float32, device=dev)
+    go, po, bo = (torch.empty((nv,), dtype=torch.int64, device=dev) for _ in range(3))
+    co = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+    check(_L().fsf_compact_pairs(mp, ms, ptr(k_idx), nk, ptr(vox), ptr(g_ids), ptr(p_ids), ptr(b_pts), ptr(centers), ptr(v_idx), nv, ptr(go),
+                                 ptr(po), ptr(bo), ptr(co), stream_ptr()), "fsf_compact_pairs")
+    return vox, go, po, bo, co
+
+
+def combine_queries(f_centers, l_centers, f_coors, l_coors, f_preds_2d, begin_idx):
+    """fsf_combine_queries -> (obj_centers f32 [m, 3], obj_coors i64 [m, 3], preds_2d f32 [m, d]) of FSF.combine_frustum_and_fsd."""
+    require_cuda(f_centers, l_centers, f_coors, l_coors, f_preds_2d)
+    f_centers, l_centers, f_preds_2d = f_centers.contiguous(), l_centers.contiguous(), f_preds_2d.contiguous()
+    f_coors, l_coors = f_coors.contiguous(), l_coors.contiguous()
+    mf, ml, d, dev = f_centers.size(0), l_centers.size(0), f_preds_2d.size(1), f_centers.device
+    centers = torch.empty((mf + ml, 3), dtype=torch.float32, device=dev)
+    coors = torch.empty((mf + ml, 3), dtype=torch.int64, device=dev)
+    preds = torch.empty((mf + ml, d), dtype=torch.float32, device=dev)
+    check(_L().fsf_combine_queries(ptr(f_centers), mf, ptr(l_centers), ml, ptr(f_coors), ptr(l_coors), ptr(f_preds_2d), d, int(begin_idx),
+                                   ptr(centers), ptr(coors), ptr(preds), stream_ptr()), "fsf_combine_queries")
+    return centers, coors, preds
+
+
+def decode_rois(reg_preds, centers, batch, eps):
+    """fsf_decode_rois: rois f32 [m, code] = (batch, decode(reg_preds, centers)); `batch` i64 [m] (any stride)."""
+    require_cuda(reg_preds, centers, batch)
+    rg, rp, rs = _f32_rows(reg_preds)
+    ct, cp_, cs = _f32_rows(centers)
+    assert batch.dtype == torch.int64 and batch.dim() == 1 and batch.numel() == rg.size(0) == ct.size(0)
+    m, code = rg.shape
+    rois = torch.empty((m, code), dtype=torch.float32, device=rg.device)
+    check(_L().fsf_decode_rois(rp, rs, code, cp_, cs, c_p(batch.data_ptr()) if m else c_p(None), int(batch.stride(0)) if m > 1 else 1, m,
+                               float(eps), ptr(rois), stream_ptr()), "fsf_decode_rois")
+    return rois
+
+
+def refine_rows(info, points, pts_idx, roi_idx, roi_xyz):
+    """fsf_refine_rows -> (points[pts_idx] f32 [k, c], f_cluster f32 [k, 13] = cat(info[:, 3:13], points[pts_idx, :3] - roi_xyz[roi_idx]))."""
+    require_cuda(info, points, pts_idx, roi_idx, roi_xyz)
+    info = info.contiguous()
+    pts, pp, ps = _f32_rows(points)
+    rx, rp, rs = _f32_rows(roi_xyz)
+    assert info.dtype == torch.float32 and info.size(1) == 13 and rx.size(1) >= 3
+    pts_idx, roi_idx = pts_idx.to(torch.int64).contiguous(), roi_idx.to(torch.int64).contiguous()
+    k = info.size(0)
+    out = torch.empty((k, pts.size(1)), dtype=torch.float32, device=info.device)
+    fcl = torch.empty((k, 13), dtype=torch.float32, device=info.device)
+    check(_L().fsf_refine_rows(ptr(info), pp, ps, pts.size(1), ptr(pts_idx), ptr(roi_idx), rp, rs, k, ptr(out), ptr(fcl), stream_ptr()),
+          "fsf_refine_rows")
+    return out, fcl
+
+
+def encode_preds_2d(mask_anno, obj_coors, num_classes, img_w, img_h):
+    """fsf_encode_preds_2d (ONE sample): mask_anno f32 [A, D], obj_coors i64 [m, 3] -> (preds_2d f32 [m, D], encoded f32 [m, 6 + classes])."""
+    require_cuda(mask_anno, obj_coors)
+    anno = mask_anno.to(torch.float32).contiguous()
+    coors = obj_coors.to(torch.int64).contiguous()
+    assert anno.dim() == 2 and coors.dim() == 2 and coors.size(1) == 3
+    m, d = coors.size(0), anno.size(1)
+    preds = torch.empty((m, d), dtype=torch.float32, device=anno.device)
+    w = 6 + int(num_classes)
+    enc = torch.empty((m, w), dtype=torch.float32, device=anno.device)
+    check(_L().fsf_encode_preds_2d(ptr(anno), anno.size(0), d, ptr(coors), m, int(num_classes), float(img_w), float(img_h), ptr(preds),
+                                   ptr(enc), w, stream_ptr()), "fsf_encode_preds_2d")
+    return preds, enc
+
+
+def weighted_xyz(points, weights, weight_min=1e-5):
+    """fsf_weighted_xyz: cat([points[:, :3] * w, w], 1) with w = weights.clamp(min=weight_min); f32 [n, 4]."""
+    require_cuda(points, weights)
+    pts, pp, ps = _f32_rows(points)
+    w = weights.reshape(-1).contiguous()
+    assert w.dtype == torch.float32 and w.numel() == pts.size(0)
+    out = torch.empty((pts.size(0), 4), dtype=torch.float32, device=pts.device)
+    check(_L().fsf_weighted_xyz(pp, ps, ptr(w), pts.size(0), float(weight_min), ptr(out), stream_ptr()), "fsf_weighted_xyz")
+    return out
+
+
+def centroid_divide(mean):
+    """fsf_centroid_divide: mean f32 [m, 4] -> mean[:, :3] / mean[:, 3:4]."""
+    require_cuda(mean)
+    mean = mean.contiguous()
+    assert mean.dtype == torch.float32 and mean.dim() == 2 and mean.size(1) == 4
+    out = torch.empty((mean.size(0), 3), dtype=torch.float32, device=mean.device)
+    check(_L().fsf_centroid_divide(ptr(mean), mean.size(0), ptr(out), stream_ptr()), "fsf_centroid_divide")
+    return out

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from .... import hip_ops, switches
-from ...ops.sst_ops import GatheredRows, plan_of, unique_with_plan
+from ...ops.sst_ops import GatheredRows, RowsMinusGroup, plan_of, unique_with_plan
 from ...registry import BACKBONES, build_voxel_encoder
 
 
@@ -55,13 +55,18 @@ class SIR(nn.Module):
         new_coors, unq_inv, _ = unique_with_plan(coors)
         m = new_coors.size(0)
         plan = plan_of(unq_inv, m)
-        order = plan.order.long()
-        seg_ids = unq_inv.index_select(0, order)
-        pts_s, fcl_s = hip_ops.gather_rows(points, order), hip_ops.gather_rows(f_cluster, order)
-        feats = (GatheredRows(features.sources, features.index.index_select(0, order)) if isinstance(features, GatheredRows)
-                 else GatheredRows([features], order))
         widths = [b.group_width() for b in self.block_list]
-        groups = torch.full((m, sum(widths)), float("-inf"), dtype=torch.float32, device=points.device)
+        groups = torch.empty((m, sum(widths)), dtype=torch.float32, device=points.device)
+        lazy = isinstance(f_cluster, RowsMinusGroup)
+        if lazy and not (f_cluster.inv is unq_inv and f_cluster.points is points and f_cluster.centers.size(0) == m):
+            f_cluster, lazy = f_cluster.materialize(), False  # (an offset to some other grouping: the expression itself)
+        gathered = isinstance(features, GatheredRows)
+        # ONE launch (K29a): the group id, the point rows, the centre offsets and the feature-row index of every sorted position,
+        # and the -inf the group table starts with (was: .long(), two index_selects, two row gathers, a fill)
+        seg_ids, pts_s, fcl_s, idx_s = hip_ops.sorted_rows(
+            plan.order, plan.inv, points, f_cluster=None if lazy else f_cluster, centers=f_cluster.centers if lazy else None,
+            index=features.index if gathered else None, fill=groups)
+        feats = GatheredRows(features.sources if gathered else [features], idx_s)
         col, rows = 0, None
         for i, block in enumerate(self.block_list):
             want = i < self.num_blocks - 1 or self.point_feats_needed
@@ -71,7 +76,7 @@ class SIR(nn.Module):
         out_feats = None
         if self.point_feats_needed:
             out_feats = torch.empty_like(rows)
-            out_feats.index_copy_(0, order, rows)
+            out_feats.index_copy_(0, plan.order.long(), rows)
         return out_feats, groups, new_coors
 
     def forward(self, points, features, coors, f_cluster=None):
@@ -80,6 +85,8 @@ class SIR(nn.Module):
                 and (isinstance(features, GatheredRows) or (features.dtype == torch.float32 and features.stride(1) == 1))
                 and all(getattr(b, "sorted_supported", lambda: False)() for b in self.block_list)):
             return self._forward_sorted(points, features, coors, f_cluster)
+        if isinstance(f_cluster, RowsMinusGroup):
+            f_cluster = f_cluster.materialize()
         if self.unique_once:
             new_coors, unq_inv, _ = unique_with_plan(coors)
         else:

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import hip_ops
-from ...ops.sst_ops import (GatheredRows, build_mlp, clear_unique_cache, gather_by_inverse, point_linear_add, scatter_v2,
+from ...ops.sst_ops import (GatheredRows, RowsMinusGroup, build_mlp, clear_unique_cache, gather_by_inverse, point_linear_add, scatter_v2,
                             with_key_bounds)
 from ...core.bbox import bbox3d2result
 from ...registry import BBOX_CODERS, DETECTORS, build_head, build_roi_extractor
@@ -194,6 +194,14 @@ class FSF(SingleStageFSD):
         return gather_by_inverse(voxel_mean, voxel2point_inds)
 
     def get_cluster_delta_weighted(self, points, sir_coors, point_weights):
+        if (not torch.is_grad_enabled() and points.is_cuda and points.dtype == torch.float32 and point_weights.dtype == torch.float32
+                and points.stride(1) == 1 and point_weights.numel() == points.size(0)):
+            # K29g: the reduction's operand in one launch, the weighted centres in one, the per-point offset inside the SIR stack's
+            # own permutation pass (RowsMinusGroup) — was clamp, mul, cat, div, a row gather and a subtraction
+            input_feat = hip_ops.weighted_xyz(points, point_weights, 1e-5)
+            voxel_mean_feat, voxel_mean_coors, unq_inv = scatter_v2(input_feat, sir_coors, mode="avg")
+            voxel_center = hip_ops.centroid_divide(voxel_mean_feat)
+            return RowsMinusGroup(points, voxel_center, unq_inv), voxel_center, voxel_mean_coors
         point_weights = point_weights.clamp(min=1e-5).detach()
         input_feat = torch.cat([points[:, :3] * point_weights, point_weights], dim=-1)
         voxel_mean_feat, voxel_mean_coors, unq_inv = scatter_v2(input_feat, sir_coors, mode="avg")
@@ -469,9 +477,17 @@ class FSF(SingleStageFSD):
             obj_id_tensor = self.frustum_gather(batch_idx, points_info_flat, mask_data, mask_anno, img_metas)
             lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, obj_id_tensor,
                                                                       point_fg_weights, img_metas, cluster_center)
-        preds_2d = self.get_single_cls_preds_2d(mask_anno, obj_coors)
-        img_feat = self.encode_2d_feats(preds_2d, img_w=mask_data.shape[-1], img_h=mask_data.shape[-2],
-                                        encode_mlp=self.encode_2d_mlp)
+        if (not torch.is_grad_enabled() and batch_size == 1 and not self.encode_label_only and obj_coors.is_cuda
+                and obj_coors.dtype == torch.int64 and mask_anno.dim() == 3 and mask_anno.shape[2] >= 7):
+            # K29f: the mask_anno row of every query, its validity product, the category fill, the box scaling and the one-hot in ONE
+            # launch (get_single_cls_preds_2d + encode_preds_2d: 18 ATen launches)
+            preds_2d, encoded_2d = hip_ops.encode_preds_2d(mask_anno[0], obj_coors, self.num_classes, mask_data.shape[-1],
+                                                           mask_data.shape[-2])
+            img_feat = self.encode_2d_mlp(encoded_2d)
+        else:
+            preds_2d = self.get_single_cls_preds_2d(mask_anno, obj_coors)
+            img_feat = self.encode_2d_feats(preds_2d, img_w=mask_data.shape[-1], img_h=mask_data.shape[-2],
+                                            encode_mlp=self.encode_2d_mlp)
         obj_feat = torch.cat([lidar_feat, img_feat], dim=-1)
         frustum_obj_result = self.frustum_obj_head(obj_feat) if run_head else None
         return obj_feat, obj_centers, obj_coors, frustum_obj_result, preds_2d
@@ -512,14 +528,20 @@ class FSF(SingleStageFSD):
         outs = self.bbox_head(cluster_feats) if run_head else None
         return cluster_feats, cluster_xyz, cluster_inds, outs
 
-    def _query_branches(self, camera_branch, lidar_branch):
+    def _query_branches(self, camera_branch, lidar_branch, n_points=None):
         """Run the camera-query and LiDAR-query branches (FSF.py:1127-1144 runs them back to back; they only share the
         read-only segmentor output) CONCURRENTLY at inference: the camera branch on a side HIP stream driven by a second
         host thread.  Both are chains of small launches with data-dependent sizes — ~25 host syncs between them, each a
         drained GPU — so the two streams fill each other's bubbles and idle CUs.  Every C-ABI call takes torch's
         (thread-local) current stream and a per-stream workspace; ctypes and torch release the GIL while they wait."""
         on_gpu = torch.cuda.is_available() and next(self.parameters()).is_cuda
-        if self.training or not on_gpu or not (self.test_cfg or {}).get("concurrent_query_branches", True):
+        want = (self.test_cfg or {}).get("concurrent_query_branches", "auto")
+        if want == "auto":
+            # Two host threads share one interpreter: on a small frame (a single sweep: 31 k points, every kernel of either branch a
+            # few microseconds) the hand-overs between them cost more than the overlap buys — same box, interleaved
+            # (tools/profiling/gil_ab.py): 1-sweep 8.0-9.4 ms on two threads, 7.7-8.0 on one; 10-sweep 13.5-13.8 against 14.4-14.7
+            want = n_points is None or n_points >= (self.test_cfg or {}).get("concurrent_query_min_points", 100000)
+        if self.training or not on_gpu or not want:
             return camera_branch(), lidar_branch()
         main = torch.cuda.current_stream()
         if getattr(self, "_side_stream", None) is None:
@@ -578,7 +600,7 @@ class FSF(SingleStageFSD):
         (f_feats, f_centers, f_coors, _, f_preds_2d), (l_feats, l_centers, l_coors, _) = self._query_branches(
             lambda: self.frustum_forward(seg_out_dict, mask_anno, mask_data, point_infos, img_metas, cluster_center=None,
                                          run_head=False),
-            lambda: self.fsd_forward(seg_out_dict, img_metas, run_head=False))
+            lambda: self.fsd_forward(seg_out_dict, img_metas, run_head=False), n_points=int(seg_out_dict["seg_points"].shape[0]))
         self._gather_cache = None
         self._img_pre = None
         clear_unique_cache()
@@ -591,17 +613,26 @@ class FSF(SingleStageFSD):
         """Camera queries then LiDAR queries in one list (:657-692): LiDAR coors (class, batch, id) become
         (batch, class, id + fsd_begin_idx); per-task head outputs are concatenated; both feature sets are projected to
         embed_dims; LiDAR queries carry all-zero 2-D predictions."""
-        obj_centers = torch.cat([frustum_obj_centers, fsd_obj_centers], dim=0)
-        fsd_obj_coors_re = fsd_obj_coors.clone()
-        fsd_obj_coors_re[:, 0] = fsd_obj_coors[:, 1]
-        fsd_obj_coors_re[:, 1] = fsd_obj_coors[:, 0]
-        fsd_obj_coors_re[:, 2] += self.fsd_begin_idx
-        obj_coors = torch.cat([frustum_obj_coors, fsd_obj_coors_re], dim=0)
+        fused = (not torch.is_grad_enabled() and frustum_obj_centers.is_cuda and frustum_obj_centers.dtype == fsd_obj_centers.dtype
+                 == frustum_preds_2d.dtype == torch.float32 and frustum_obj_coors.dtype == fsd_obj_coors.dtype == torch.int64
+                 and frustum_obj_centers.dim() == fsd_obj_centers.dim() == 2 and frustum_obj_centers.size(1) == fsd_obj_centers.size(1) == 3
+                 and frustum_obj_coors.size(1) == fsd_obj_coors.size(1) == 3 and frustum_preds_2d.dim() == 2)
+        if fused:  # K29c: centres, re-ordered coordinates and the 2-D prediction rows of both query lists in one launch
+            obj_centers, obj_coors, preds_2d = hip_ops.combine_queries(frustum_obj_centers, fsd_obj_centers, frustum_obj_coors,
+                                                                       fsd_obj_coors, frustum_preds_2d, self.fsd_begin_idx)
+        else:
+            obj_centers = torch.cat([frustum_obj_centers, fsd_obj_centers], dim=0)
+            fsd_obj_coors_re = fsd_obj_coors.clone()
+            fsd_obj_coors_re[:, 0] = fsd_obj_coors[:, 1]
+            fsd_obj_coors_re[:, 1] = fsd_obj_coors[:, 0]
+            fsd_obj_coors_re[:, 2] += self.fsd_begin_idx
+            obj_coors = torch.cat([frustum_obj_coors, fsd_obj_coors_re], dim=0)
         obj_result = {key: [torch.cat([frustum_obj_result[key][t], fsd_obj_result[key][t]], dim=0)
                             for t in range(len(frustum_obj_result[key]))] for key in frustum_obj_result.keys()}
         obj_feats = torch.cat([self.combine_frustum_feat_mlp(frustum_obj_feats), self.combine_fsd_feat_mlp(fsd_obj_feats)], dim=0)
-        fsd_preds_2d = frustum_preds_2d.new_zeros((fsd_obj_feats.shape[0], frustum_preds_2d.shape[1]))
-        preds_2d = torch.cat([frustum_preds_2d, fsd_preds_2d], dim=0)
+        if not fused:
+            fsd_preds_2d = frustum_preds_2d.new_zeros((fsd_obj_feats.shape[0], frustum_preds_2d.shape[1]))
+            preds_2d = torch.cat([frustum_preds_2d, fsd_preds_2d], dim=0)
         return obj_centers, obj_coors, obj_result, obj_feats, preds_2d
 
     def decode_stage_bboxes(self, obj_centers, bz_coors, reg_preds):
@@ -610,6 +641,12 @@ class FSF(SingleStageFSD):
         Single-task heads decode every query in one go here — identical at batch size 1, and correct beyond it; a
         multi-task list keeps upstream's walk."""
         decode_size = reg_preds[0].shape[-1] - 1
+        from ...core.bbox import BasePointBBoxCoder
+
+        if (len(reg_preds) == 1 and not torch.is_grad_enabled() and reg_preds[0].is_cuda and reg_preds[0].dtype == torch.float32
+                and obj_centers.dtype == torch.float32 and bz_coors.dtype == torch.int64 and type(self.bbox_coder) is BasePointBBoxCoder
+                and reg_preds[0].size(1) == self.bbox_coder.code_size and reg_preds[0].size(1) in (8, 10)):
+            return hip_ops.decode_rois(reg_preds[0], obj_centers, bz_coors, self.bbox_coder.EPS)  # K29d: decode + batch column, one launch
         if len(reg_preds) == 1:
             bboxes_tensor = self.bbox_coder.decode(reg_preds[0], obj_centers)
         else:
@@ -622,7 +659,14 @@ class FSF(SingleStageFSD):
     def query_feat_refine(self, points, pts_feat, batch_idx, input_bbox_rois, i_stage, point_infos, mask_anno, mask_data,
                           img_metas):
         ext_pts_inds, ext_pts_roi_inds, ext_pts_info = self.roi_extractor(points[:, :3], batch_idx, input_bbox_rois[:, :8])
-        extracted_points = points[ext_pts_inds]
+        info13 = ext_pts_info.get("_fsf_info13")
+        if (info13 is not None and not torch.is_grad_enabled() and points.is_cuda and points.dtype == torch.float32
+                and input_bbox_rois.dtype == torch.float32 and getattr(ext_pts_roi_inds, "_fsf_real_rows", False)):
+            # K29e: the pooled points' rows and the refine head's f_cluster (pooling info + offset to the RoI centre) in one launch
+            extracted_points, f_cluster = hip_ops.refine_rows(info13, points, ext_pts_inds, ext_pts_roi_inds, input_bbox_rois[:, 1:4])
+            ext_pts_info["_fsf_f_cluster"] = f_cluster
+        else:
+            extracted_points = points[ext_pts_inds]
         extracted_points_feats = pts_feat[ext_pts_inds]
         pts_img_feat = self.img_cross_attn(point_infos, batch_idx, mask_anno, mask_data, img_metas,
                                            self.refine_img_mlp[i_stage], ext_pts_inds)
@@ -671,7 +715,7 @@ class FSF(SingleStageFSD):
         seg_out_dict = self.segmentor_feat_inhance_test(seg_out_tuple, point_infos, mask_anno, mask_data, img_metas)
         (f_feats, f_centers, f_coors, f_result, f_preds_2d), (l_feats, l_centers, l_coors, l_result) = self._query_branches(
             lambda: self.frustum_forward(seg_out_dict, mask_anno, mask_data, point_infos, img_metas, cluster_center=None),
-            lambda: self.fsd_forward(seg_out_dict, img_metas))
+            lambda: self.fsd_forward(seg_out_dict, img_metas), n_points=int(seg_out_dict["seg_points"].shape[0]))
         obj_centers, obj_coors, obj_result, obj_feats, preds_2d = self.combine_frustum_and_fsd(
             f_centers, f_coors, f_result, f_feats, f_preds_2d, l_centers, l_coors, l_result, l_feats)
         bbox_list = self.multi_stage_refine_test(obj_centers, obj_coors, obj_result, seg_out_dict["seg_points"], point_infos,

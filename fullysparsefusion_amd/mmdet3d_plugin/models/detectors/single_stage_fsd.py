@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from .... import hip_ops
-from ...ops.sst_ops import (GatheredRows, gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, unique_with_plan,
+from ...ops.sst_ops import (GatheredRows, RowsMinusGroup, gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, unique_with_plan,
                             with_key_bounds)
 from ...ops.voxel import Voxelization
 from ...registry import (DETECTORS, SEGMENTORS, build_backbone, build_detector, build_head, build_middle_encoder,
@@ -172,7 +172,11 @@ class SingleStageFSD(nn.Module):
     def extract_feat(self, points, pts_feats, pts_cluster_inds, img_metas, center_preds):
         """:458-474 — cluster centroid of the vote centres, per-point offset to it, then the SIR backbone."""
         cluster_xyz, _, inv_inds = scatter_v2(center_preds, pts_cluster_inds, mode="avg", return_inv=True)
-        f_cluster = points[:, :3] - gather_by_inverse(cluster_xyz, inv_inds)
+        if (not torch.is_grad_enabled() and points.is_cuda and points.dtype == torch.float32 and cluster_xyz.dtype == torch.float32
+                and hasattr(self.backbone, "_forward_sorted")):
+            f_cluster = RowsMinusGroup(points, cluster_xyz, inv_inds)  # (formed by the SIR stack while it permutes its rows)
+        else:
+            f_cluster = points[:, :3] - gather_by_inverse(cluster_xyz, inv_inds)
         out_pts_feats, cluster_feats, out_coors = self.backbone(points, pts_feats, pts_cluster_inds, f_cluster)
         out_dict = dict(cluster_feats=cluster_feats, cluster_xyz=cluster_xyz, cluster_inds=out_coors)
         if self.as_rpn:
@@ -309,10 +313,15 @@ class SingleStageFSD(nn.Module):
                 vox_inv = remap.index_select(0, inv.index_select(0, v_idx))
             all_means, _, _ = scatter_v2(centers, keys, mode="avg", return_inv=True, unq_inv=inv, new_coors=new_keys,
                                          short_segments=True)
-            vox_centers = all_means.index_select(0, k_idx)
-            vox_keys = new_keys.index_select(0, k_idx) if vox_group_i32 is None else None  # (only the generic tail below reads them)
-            g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
-            centers = centers.index_select(0, v_idx)
+            if vox_group_i32 is not None and all_means.dtype == torch.float32 and centers.dtype == torch.float32:
+                # the survivors' rows of all five tensors in one launch (K29b; was five index_selects)
+                vox_centers, g_ids, p_ids, b_pts, centers = hip_ops.compact_pairs(all_means, k_idx, g_ids, p_ids, b_pts, centers, v_idx)
+                vox_keys = None
+            else:
+                vox_centers = all_means.index_select(0, k_idx)
+                vox_keys = new_keys.index_select(0, k_idx) if vox_group_i32 is None else None  # (only the generic tail below reads them)
+                g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
+                centers = centers.index_select(0, v_idx)
         else:
             valid = cnt[inv] >= ca.min_points
             # valid pairs per group: the pairs are group-major, so a running count read at the group boundaries (an index_add_ of

@@ -49,6 +49,8 @@ class DynamicPointROIExtractor(nn.Module):
             assert torch.isclose(info[:, 7] + info[:, 10], roi_per_pts[:, 3], atol=1e-4).all()
             assert torch.isclose(info[:, 8] + info[:, 11], roi_per_pts[:, 5], atol=1e-4).all()
         ext_pts_info = dict(local_xyz=info[:, 3:6], boundary_offset=info[:, 6:-1], is_in_margin=info[:, -1])
+        if info.size(1) == 13:
+            ext_pts_info["_fsf_info13"] = info  # (the three views' one tensor: FSF.query_feat_refine hands it to K29e)
         roi_inds._fsf_sorted = True  # K17's rows come in ascending (roi, point) order: FullySparseBboxHead's groups are contiguous runs
         return inds, roi_inds, ext_pts_info
 
@@ -85,7 +87,6 @@ class FullySparseBboxHead(nn.Module):
     def forward(self, pts_xyz, pts_features, pts_info, roi_inds, rois):
         assert pts_features.size(0) > 0
         rois = rois[:, 1:]
-        rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds]
         sorted_ok = (switches.SIR_SORTED and self.unique_once and getattr(roi_inds, "_fsf_sorted", False)
                      and self.use_middle_cluster_feature and not torch.is_grad_enabled() and pts_xyz.is_cuda
                      and pts_xyz.dtype == torch.float32 and pts_features.dtype == torch.float32 and pts_features.stride(1) == 1
@@ -96,8 +97,11 @@ class FullySparseBboxHead(nn.Module):
             # rows (11 ATen launches).  A RoI without points keeps the -inf the table starts with: that is the non-empty mask,
             # and its row becomes the zeros upstream returns (align_roi_feature_and_rois, :153-165).
             num_rois = len(rois)
-            f_cluster = torch.cat([pts_info["local_xyz"], pts_info["boundary_offset"], pts_info["is_in_margin"][:, None], rel_xyz],
-                                  dim=-1)
+            f_cluster = pts_info.get("_fsf_f_cluster")  # (K29e formed it with the pooled rows)
+            if f_cluster is None:
+                rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds]
+                f_cluster = torch.cat([pts_info["local_xyz"], pts_info["boundary_offset"], pts_info["is_in_margin"][:, None], rel_xyz],
+                                      dim=-1)
             widths = [b.group_width() for b in self.block_list]
             groups = torch.full((num_rois, sum(widths)), float("-inf"), dtype=torch.float32, device=pts_xyz.device)
             seg_ids = roi_inds.contiguous()
@@ -108,6 +112,7 @@ class FullySparseBboxHead(nn.Module):
                 col += widths[i]
             nonempty = groups[:, 0] > float("-inf")
             return torch.where(nonempty[:, None], groups, groups.new_zeros(())), nonempty
+        rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds]
         coors = roi_inds.unsqueeze(1)  # the segment machinery takes key ROWS; upstream groups on the 1-D index
         with_key_bounds(coors, [0], [max(rois.size(0) - 1, 0)])
         if self.unique_once:  # torch.unique(roi_inds, return_inverse=True) upstream (:114-115), with the segment plan

@@ -207,6 +207,29 @@ class GatheredRows:
         return buf
 
 
+class RowsMinusGroup:
+    """`points[:, :3] - centers[inv]` kept as its parts (inference): the offset of every point to its group's centre
+    (SingleStageFSD.extract_feat, single_stage_fsd.py:458-474; FSF.get_cluster_delta_weighted, FSF.py:313-329).  Its only consumer is
+    the SIR stack that follows, which on its sorted path forms the rows while it permutes its operands (fsf_sorted_rows): the gather
+    and the subtraction are not launches of their own.  `materialize()` is the expression itself, for anything else."""
+
+    def __init__(self, points, centers, inv):
+        self.points, self.centers, self.inv = points, centers, inv
+
+    dtype = property(lambda self: self.points.dtype)
+    is_cuda = property(lambda self: self.points.is_cuda)
+
+    @property
+    def shape(self):
+        return (self.points.size(0), 3)
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def materialize(self):
+        return self.points[:, :3] - gather_by_inverse(self.centers, self.inv)
+
+
 def _grouped_linear_norm_act(linear, norm, act, gc):
     """act(norm(linear(cat))) for a GroupedConcat through fsf_linear_norm_act_grouped; None when the layer is not covered."""
     p, g, inv = gc.point_feats, gc.group_feats, gc.inv

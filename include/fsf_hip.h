@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 17
+#define FSF_ABI_VERSION 18
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -826,6 +826,58 @@ int64_t fsf_group_pairs_workspace_bytes(int64_t n, int32_t ng);
 int fsf_group_pairs(const float* score, int64_t n, int32_t ng, int64_t score_stride, const float* thresh, int32_t keep_one,
                     const uint32_t* group_class_masks, int32_t num_classes, int64_t* g_ids, int64_t* p_ids, int64_t capacity,
                     int64_t* count_host, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K29  the row-shuffling glue between the query stages (round 6): each entry point is ONE launch for what the reference writes as a
+ * chain of 3-18 elementwise / index / cat operations; the arithmetic is that chain's, operation for operation (single IEEE adds,
+ * subtracts, multiplies, divides; expf / atan2f as in fsf_decode_cluster_boxes), so the results are bit-identical to it.
+ *
+ * fsf_sorted_rows — the inputs of a SIR stack on rows sorted by group.  Replaces: in `SIR.forward`
+ *   (projects/mmdet3d_plugin/models/backbones/sir.py:65-85) the per-block `torch.cat([points, out_feats], 1)` operands after the
+ *   stack's one `torch.unique` (:68), taken through the unique's sort order; with `f_cluster == NULL` also the
+ *   `f_cluster = points[:, :3] - cluster_xyz[inv]` of SingleStageFSD.extract_feat (detectors/single_stage_fsd.py:458-474) and of
+ *   FSF.get_cluster_delta_weighted (detectors/FSF.py:313-329).
+ *   order i32 [n] (sorted position -> source row, fsf_unique_rows' `order`), inv i64 [n] (source row -> group);
+ *   seg_ids[i] = inv[order[i]];  pts_sorted[i, :] = points[order[i], :pts_cols];  idx_sorted[i] = index ? index[order[i]] : order[i];
+ *   fcl_sorted[i, :] = f_cluster ? f_cluster[order[i], :3] : points[order[i], :3] - centers[inv[order[i]], :3];
+ *   fill[0 .. fill_count) = fill_value (the stack's group table starts at -inf) when fill != NULL.
+ * fsf_compact_pairs — ClusterAssigner's survivors.  Replaces: the boolean compactions `points[valid_mask]`, `batch_idx[valid_mask]`,
+ *   `coors[valid_mask]` of ClusterAssigner.forward_single_class (single_stage_fsd.py:951-960) and update_sample_results_by_mask
+ *   (:867-890) for all class groups at once, with the survivor lists of fsf_cluster_key_survival:
+ *   vox_centers[j] = means[k_idx[j]] (nk rows), (g_out, p_out, b_out, centers_out)[j] = (g_ids, p_ids, b_pts, centers)[v_idx[j]] (nv rows).
+ * fsf_combine_queries — FSF.combine_frustum_and_fsd (FSF.py:657-692) without the feature / head-output concatenations: camera
+ *   queries first, LiDAR coors (class, batch, id) -> (batch, class, id + begin_idx), all-zero 2-D predictions for the LiDAR queries.
+ * fsf_decode_rois — FSF.decode_stage_bboxes (FSF.py:1085-1094) for a single-task head: BasePointBBoxCoder.decode
+ *   (core/bbox/coders/base_point_bbox_coder.py:58-82) + the batch column; rois f32 [m, code_size] = (batch, x, y, z, dx, dy, dz, yaw[, vx, vy]).
+ * fsf_refine_rows — after fsf_dynamic_point_pool: `points[ext_pts_inds]` (FSF.query_feat_refine, FSF.py:961-1010) and
+ *   FullySparseBboxHead.forward's `f_cluster = cat([local_xyz, boundary_offset, is_in_margin, pts_xyz - roi_centre[roi_inds]], 1)`
+ *   (roi_heads/bbox_heads/fsd_bbox_head.py:96-112); info f32 [k, 13] as K17 writes it, roi_xyz = the RoIs' centre columns.
+ * fsf_encode_preds_2d — FSF.get_single_cls_preds_2d + encode_preds_2d (FSF.py:476-504, :449-474) for ONE sample's camera queries:
+ *   preds_2d[i] = mask_anno[id - 1] (zeros with category = num_classes for id <= 0), encoded[i] = (box / (w, h, w, h), score,
+ *   one_hot(category, num_classes + 1)) with the division as the product with the fp32 reciprocal ATen forms for a host scalar.
+ * fsf_weighted_xyz / fsf_centroid_divide — FSF.get_cluster_delta_weighted's operands (FSF.py:313-329): out f32 [n, 4] =
+ *   (xyz * w, w) with w = max(weight, weight_min) (NaN kept); out f32 [m, 3] = mean[:, :3] / mean[:, 3:4].
+ */
+int fsf_sorted_rows(const int32_t* order, const int64_t* inv, int64_t n, const float* points, int64_t pts_stride, int32_t pts_cols,
+                    const float* f_cluster, int64_t fcl_stride, const float* centers, int64_t centers_stride, const int64_t* index,
+                    int64_t* seg_ids, float* pts_sorted, float* fcl_sorted, int64_t* idx_sorted, float* fill, int64_t fill_count,
+                    float fill_value, void* stream);
+int fsf_compact_pairs(const float* means, int64_t means_stride, const int64_t* k_idx, int64_t nk, float* vox_centers, const int64_t* g_ids,
+                      const int64_t* p_ids, const int64_t* b_pts, const float* centers, const int64_t* v_idx, int64_t nv, int64_t* g_out,
+                      int64_t* p_out, int64_t* b_out, float* centers_out, void* stream);
+int fsf_combine_queries(const float* f_centers, int64_t mf, const float* l_centers, int64_t ml, const int64_t* f_coors,
+                        const int64_t* l_coors, const float* f_preds_2d, int32_t d, int64_t begin_idx, float* centers, int64_t* coors,
+                        float* preds_2d, void* stream);
+int fsf_decode_rois(const float* reg_preds, int64_t reg_stride, int32_t code_size, const float* centers, int64_t centers_stride,
+                    const int64_t* batch, int64_t batch_stride, int64_t m, float eps, float* rois, void* stream);
+int fsf_refine_rows(const float* info, const float* points, int64_t points_stride, int32_t points_cols, const int64_t* pts_idx,
+                    const int64_t* roi_idx, const float* roi_xyz, int64_t roi_stride, int64_t k, float* points_out, float* f_cluster,
+                    void* stream);
+int fsf_encode_preds_2d(const float* mask_anno, int64_t num_anno, int32_t d, const int64_t* obj_coors, int64_t m, int32_t num_classes,
+                        float img_w, float img_h, float* preds_2d, float* encoded, int64_t enc_stride, void* stream);
+int fsf_weighted_xyz(const float* points, int64_t points_stride, const float* weights, int64_t n, float weight_min, float* out,
+                     void* stream);
+int fsf_centroid_divide(const float* mean, int64_t m, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -136,7 +136,8 @@ def _hot_path_vs_oracle(model, cpu, f, device, min_clusters, min_lidar_points, m
         fsir_fwd = model.frustum_sir.forward
 
         def fcapture(points, features, coors, f_cluster=None):
-            fcap["in"] = (points, features.materialize() if hasattr(features, "materialize") else features, coors, f_cluster)
+            fcap["in"] = (points, features.materialize() if hasattr(features, "materialize") else features, coors,
+                         f_cluster.materialize() if hasattr(f_cluster, "materialize") else f_cluster)
             fcap["out"] = fsir_fwd(points, features, coors, f_cluster=f_cluster)
             return fcap["out"]
 
@@ -150,7 +151,8 @@ def _hot_path_vs_oracle(model, cpu, f, device, min_clusters, min_lidar_points, m
         sir_fwd = model.backbone.forward
 
         def capture(points, features, coors, f_cluster=None):
-            cap["in"] = (points, features.materialize() if hasattr(features, "materialize") else features, coors, f_cluster)
+            cap["in"] = (points, features.materialize() if hasattr(features, "materialize") else features, coors,
+                         f_cluster.materialize() if hasattr(f_cluster, "materialize") else f_cluster)
             return sir_fwd(points, features, coors, f_cluster)
 
         model.backbone.forward = capture
