@@ -170,6 +170,8 @@ __device__ __forceinline__ void lna_split8_f16(const float (&v)[8], float s, lna
   lo = __builtin_bit_cast(lna_u32x4, l);
 }
 
+constexpr unsigned LNA_F16_TAG = 0x4B323266u;  // "K22f": word 3 of the f16 weight planes' 256-byte header
+
 // max |w| over the layer -> hdr[2] (bit pattern; cleared by the caller), one atomic per workgroup
 __global__ void __launch_bounds__(256) lna_weight_absmax_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ hdr) {
   __shared__ float wave_max[4];
@@ -187,7 +189,11 @@ __global__ void __launch_bounds__(256)
                            uint4* __restrict__ planes) {
   float s_w, inv_w;
   lna_pick_scale(__uint_as_float(reinterpret_cast<const unsigned*>(hdr)[2]), s_w, inv_w);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = inv_w; hdr[1] = s_w; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[0] = inv_w;
+    hdr[1] = s_w;
+    reinterpret_cast<unsigned*>(hdr)[3] = LNA_F16_TAG;  // the format's tag word: the f16-weight kernels refuse a buffer without it
+  }
   const int64_t total = (int64_t)nslice * nkc * T * 64;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int lane = (int)(idx & 63);
@@ -602,6 +608,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? (SEG ? LNA_SEG_WPS : LNA_WP
   }
   const int ch_base = a.slice_w * slice_id;
   const uint4* planes = a.planes + (XM != 0 ? 16 : 0) + (int64_t)slice_id * nkc * CHUNK_U4;  // (f16 planes: behind the 256-byte header)
+  if (XM != 0 && reinterpret_cast<const unsigned*>(a.planes)[3] != LNA_F16_TAG)
+    __builtin_trap();  // a buffer that fsf_linear_prepare_weight_f16 did not write: the launch fails loudly instead of multiplying garbage
 
   // weight chunk kc -> LDS buffer by LDS-DMA: fragment order in HBM == fragment order in LDS, 1 KB per wave instruction
   auto stage_w = [&](int kc, int buf) {

@@ -516,8 +516,7 @@ static int launch_norm_act_bwd_v4(const float* x, const float* gout, int64_t n, 
 }
 
 static bool na_v4_enabled() {
-  static const bool on = !(getenv("FSF_NORM_ACT_V4") && atoi(getenv("FSF_NORM_ACT_V4")) == 0);  // (A/B switch)
-  return on;
+  return true;
 }
 
 }  // namespace fsf

@@ -434,7 +434,7 @@ extern "C" int fsf_rulebook_strided(const int32_t* indices, int64_t m, int32_t b
                      in_cap + set_cap, count_dev);
   hipLaunchKernelGGL(rb_insert_inputs_kernel, dim3(fsf_stream_grid(m, 256)), dim3(256), 0, stream, indices, m, g, in_keys,
                      in_vals, (uint64_t)(in_cap - 1));
-  static const bool propose_by_pair = getenv("FSF_RB_PROPOSE_PAIRS") != nullptr;  // (A/B switch, latched: the round-1 kernel)
+  const bool propose_by_pair = false;  // (the round-1 kernel: only where the per-workgroup list of the rows kernel does not fit)
   // (the per-workgroup list of the rows kernel is 256 * per_in * 8 bytes of dynamic LDS + 8 static: 64 KB without an attribute)
   if (propose_by_pair || 256 * per_in * 8 + 8 > 64 * 1024 || (m + 255) / 256 > 0x7FFFFFFF)
     hipLaunchKernelGGL(rb_propose_kernel, dim3(fsf_stream_grid(cand, 256)), dim3(256), 0, stream, indices, m, g, set_keys,

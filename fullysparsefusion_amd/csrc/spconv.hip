@@ -658,12 +658,7 @@ __global__ void __launch_bounds__(256)
 // has the CU to itself); every extra split adds a partial tile written and re-read by the last-arriving workgroup.
 static int pick_ksplit(int64_t tiles, int cout_blocks, int kvol, int nchunks, int64_t m_out, int cout, int64_t slots) {
   if (kvol < 3) return 1;
-  static const int kForce = [] {  // FSF_KSPLIT forces the split (tuning runs)
-    const char* e = getenv("FSF_KSPLIT");
-    return e ? atoi(e) : 0;
-  }();
   int gmax = kvol / 3 < 9 ? kvol / 3 : 9;
-  if (kForce > 0) return kForce < gmax ? kForce : gmax;
   const double t_stage = cout <= 64 ? 2.6 : 3.8, fixed = 8.0;
   const double tile_mb = (double)m_out * cout * 4 * 1e-6;
   double best = 0;
@@ -692,10 +687,7 @@ struct SpconvPlan {
 };
 
 static SpconvPlan spconv_plan(int64_t m_out, int cin, int cout, int kvol) {
-  static const int tm_env = [] {  // FSF_SPCONV_TM = 64 | 128 forces the tile height (tuning runs)
-    const char* e = getenv("FSF_SPCONV_TM");
-    return e ? atoi(e) : 0;
-  }();
+  const int tm_env = 0;
   SpconvPlan p;
   p.cout_blocks = cout <= 64 ? 1 : (cout + 127) / 128;
   const bool fast = (cin % SC_KC) == 0;
@@ -779,11 +771,7 @@ extern "C" int fsf_spconv_forward(const float* feat, int64_t m_in, int32_t cin, 
   using S128_64 = SpconvSmem<128, 64>;
   using S64_128 = SpconvSmem<64, 128>;
   using S128_128 = SpconvSmem<128, 128>;
-  static const int nw_env = [] {  // FSF_SPCONV_NW = 4 | 8 forces the waves per workgroup of the 128-column kernel
-    const char* e = getenv("FSF_SPCONV_NW");
-    return e ? atoi(e) : 0;
-  }();
-  const bool wide = nw_env != 4;
+  const bool wide = true;  // (8 waves per workgroup for the 128-column kernel)
   if (cout <= 64) {
     if (fast && plan.tm == 128) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 128, 4>), S64_128, 256);
     else if (fast) FSF_SPCONV_LAUNCH((spconv_fwd_dma_kernel<64, 64, 4>), S64_64, 256);

@@ -435,8 +435,7 @@ static void bwd_plan(int64_t cap, int cin, int cout, int kvol, int* ta, int* tb,
   // each so the accumulator write-out stays small next to the MFMA work
   // (a dense layer, kvol = 1, has one evenly divisible pair list: fewer, longer ranges keep the fold pass — which reads
   // nsplit x cin x cout floats — negligible)
-  static const int target_env = getenv("FSF_BWD_TARGET_WGS") ? atoi(getenv("FSF_BWD_TARGET_WGS")) : 0;  // (A/B switch)
-  int64_t s = fsf_cdiv(target_env > 0 ? target_env : (kvol >= 8 ? 6144 : 512), kvol * tiles);
+  int64_t s = fsf_cdiv(kvol >= 8 ? 6144 : 512, kvol * tiles);
   const int64_t max_s = fsf_cdiv(cap, 8 * BW_RT);
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
@@ -481,9 +480,7 @@ extern "C" int fsf_spconv_backward_weight(const float* feat, int64_t m_in, int32
     FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_bwd_weight_kernel<TA_, TB_>, (int)smem_bytes, attr_done));                                                                                                                    \
     hipLaunchKernelGGL((spconv_bwd_weight_kernel<TA_, TB_>), grid, dim3(256), smem_bytes, stream, a);                    \
   } while (0)
-  // (A/B switch, latched: FSF_BWD_SPLIT=0 keeps the fp32-pipe kernel for the 128 x 128 tiles as well)
-  static const bool split_on = !(getenv("FSF_BWD_SPLIT") && atoi(getenv("FSF_BWD_SPLIT")) == 0);
-  if (cap > 0 && split_on && ta == 128 && tb == 128) {
+  if (cap > 0 && ta == 128 && tb == 128) {
     static std::atomic<uint64_t> attr_done{0};
     FSF_HIP_TRY(fsf_set_max_dynamic_lds((const void*)spconv_bwd_weight_split_kernel, BWS_SMEM, attr_done));
     hipLaunchKernelGGL(spconv_bwd_weight_split_kernel, grid, dim3(256), BWS_SMEM, stream, a);

@@ -1035,8 +1035,9 @@ extern "C" int fsf_spconv_forward_planes(const void* xa, const float* sa, int32_
     hipLaunchKernelGGL((spconv_fwd_planes_kernel<RG_, TPW_, NKC_>), grid, dim3(256), S::bytes, stream, a);                 \
   } while (0)
   // sources of one width (64 or 128 channels: every layer of the U-Net) get the variants with compile-time chunk loops
-  // (A/B switches, latched at the first call: the library is driven from two host threads and getenv is not safe against setenv)
-  static const bool generic_only = getenv("FSF_PLANES_GENERIC") != nullptr;
+  // (A/B switch, latched at the first call: the library is driven from two host threads and getenv is not safe against setenv;
+  // tests/test_optin_kernels_gpu.py re-runs the plane-kernel tests with K9c as the only plane kernel)
+  const bool generic_only = false;
   static const bool pipe_on = !(getenv("FSF_PLANES_PIPE") && atoi(getenv("FSF_PLANES_PIPE")) == 0);
   const int nkc_fix = (cb == 0 || cb == ca) && (ca == 64 || ca == 128) && !generic_only ? ca / 32 : 0;
 #define FSF_SPP(TPW_, NKC_)                                                                                              \

@@ -515,8 +515,7 @@ extern "C" int fsf_spconv_forward_split(const float* feat, int64_t m_in, int32_t
   int64_t gx = (256 * SCS_WPS + nslice * ksplit - 1) / (nslice * ksplit);
   if (gx > nblk) gx = nblk;
   dim3 grid((unsigned)gx, (unsigned)nslice, (unsigned)ksplit);
-  static const int xcd_on = getenv("FSF_SCS_XCD") ? atoi(getenv("FSF_SCS_XCD")) : 1;  // (A/B switch, latched)
-  if (xcd_on && gx > 1 && nslice * ksplit >= 8) {  // several row blocks stream the same chunks and there are groups for every XCD
+  if (gx > 1 && nslice * ksplit >= 8) {  // several row blocks stream the same chunks and there are groups for every XCD
     a.xcd_lanes = (int)gx;
     a.nslice = nslice;
     grid = dim3((unsigned)(8 * gx * ((nslice * ksplit + 7) / 8)), 1, 1);

@@ -1021,17 +1021,25 @@ def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_di
     return out
 
 
+_FMT_ATTR = "_fsf_weight_format"
+
+
 def linear_weight_is_f16(planes: torch.Tensor) -> bool:
-    """Which of `linear_prepare_weight`'s two formats a prepared weight is in (by its size: see there)."""
-    return (planes.numel() & 1023) == 256
+    """Which of `linear_prepare_weight`'s two formats a prepared weight is in: the tag the preparing call attached to the tensor
+    (until round 5 this was inferred from the buffer's size — one layout change away from dispatching the wrong kernel).
+    A buffer without a tag (cloned, built by hand) is refused; the f16 kernels check the tag word of the buffer's own header as well."""
+    fmt = getattr(planes, _FMT_ATTR, None)
+    if fmt is None:
+        raise FsfHipError("prepared Linear weight without a format tag: use the tensor hip_ops.linear_prepare_weight returned")
+    return fmt == "f16x3"
 
 
 def linear_prepare_weight(weight: torch.Tensor, fmt: Optional[str] = None):
     """Linear weight f32 [c, k] -> the opaque fragment planes `linear_norm_act` / `linear_norm_act_segmax` take (u8 tensor).
     fmt "bf16x6": fsf_linear_prepare_weight (exact 3-way bf16 split, six MFMA passes per product); "f16x3": fsf_linear_prepare_weight_f16
     (f16 hi | lo of W * s_w behind a header; the kernel then splits x the same way with a per-row scale: three passes, K22f) — the
-    default for more than 32 output channels while `switches.K22F` is on.  The two formats differ in size (`linear_weight_is_f16`): the
-    bf16 planes are a multiple of 1 KB, the f16 planes a multiple of 1 KB behind a 256-byte header — a clone or a copy keeps its format."""
+    default for more than 32 output channels while `switches.K22F` is on.  The returned tensor carries its format as an attribute
+    (`linear_weight_is_f16`); the f16 buffer also holds a tag word in its header that the f16 kernels verify."""
     require_cuda(weight)
     weight = weight.detach().contiguous()
     c, k = weight.shape
@@ -1042,6 +1050,7 @@ def linear_prepare_weight(weight: torch.Tensor, fmt: Optional[str] = None):
     h = _L()
     planes = torch.empty(h.fsf_linear_prepared_weight_bytes(k, c), dtype=torch.uint8, device=weight.device)
     check(h.fsf_linear_prepare_weight(ptr(weight), k, c, ptr(planes), stream_ptr()), "fsf_linear_prepare_weight")
+    setattr(planes, _FMT_ATTR, "bf16x6")
     return planes
 
 
@@ -1191,6 +1200,7 @@ def linear_prepare_weight_f16(weight: torch.Tensor, slice_c: int = 128):
     h = _L()
     planes = torch.empty(h.fsf_linear_prepared_weight_f16_bytes(k, c, slice_c), dtype=torch.uint8, device=weight.device)
     check(h.fsf_linear_prepare_weight_f16(ptr(weight), k, c, int(slice_c), ptr(planes), stream_ptr()), "fsf_linear_prepare_weight_f16")
+    setattr(planes, _FMT_ATTR, "f16x3")
     return planes
 
 

@@ -110,7 +110,7 @@ class SimpleSparseUNet(nn.Module):
         lat_planes, bot_planes = x.plane_sources, x_bottom.plane_sources
         f_bot, f_lat = x_bottom.features, x.features
         # cat((x_bottom.features, x.features), 1), written only if somebody reads it as one tensor
-        x = x._like((f_bot, f_lat) if switches.LAZY_CAT and not torch.is_grad_enabled() else torch.cat((f_bot, f_lat), dim=1))
+        x = x._like((f_bot, f_lat) if not torch.is_grad_enabled() else torch.cat((f_bot, f_lat), dim=1))
         if lat_planes is not None and len(lat_planes) == 1 and f_bot.size(1) <= 128 and f_bot.size(1) % 32 == 0:
             # the merge layer reads the concatenation as two plane sources: the lateral block's own plane-form output and
             # a conversion of the bottom-up features

@@ -70,8 +70,6 @@ class VoteSegHead(nn.Module):
         from .... import hip_ops
         from ...ops.sst_ops import _SMALL_N_MIN
 
-        if not switches.SEG_HEAD_STACK:
-            return None
         if (self.training or (torch.is_grad_enabled() and (feat.requires_grad or self.conv_seg.weight.requires_grad))
                 or not feat.is_cuda or feat.dim() != 2 or feat.size(0) < _SMALL_N_MIN or (self.dropout is not None and self.training)):
             return None

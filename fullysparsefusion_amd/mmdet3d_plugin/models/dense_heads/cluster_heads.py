@@ -42,7 +42,7 @@ class FSDSeparateHead(nn.Module):
 
     def accepts_planes(self, n_rows):
         """Will `forward` take the query features in plane form (RowPlanes) for `n_rows` rows?  (Its first layer then runs on K22h.)"""
-        if not (switches.HEAD_SLICED and switches.K22H) or self.training or n_rows < switches.K22H_MIN_ROWS or len(self.attrs) <= 1:
+        if not switches.K22H or self.training or n_rows < switches.K22H_MIN_ROWS or len(self.attrs) <= 1:
             return False
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return False
@@ -122,8 +122,6 @@ class FSDSeparateHead(nn.Module):
         return plan
 
     def _forward_sliced(self, x):
-        if not switches.HEAD_SLICED:
-            return None
         from ...ops.sst_ops import as_row_planes
 
         is_planes = isinstance(x, hip_ops.RowPlanes)

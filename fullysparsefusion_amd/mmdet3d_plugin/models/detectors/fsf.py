@@ -236,14 +236,13 @@ class FSF(SingleStageFSD):
             else:
                 src_pt, sir_coors_fused = rows
                 obj_id_tensor = sir_coors_fused[:, 2]
-                if pts_feat.dtype == torch.float32 and pts_feat.stride(1) == 1 and switches.SIR_GATHER:
+                if pts_feat.dtype == torch.float32 and pts_feat.stride(1) == 1:
                     lazy_src, pts_feat = pts_feat, src_pt.unsqueeze(1)  # (the row index in place of the 131-wide rows, as below)
                 else:
                     pts_feat = pts_feat.index_select(0, src_pt)
                 points, point_fg_weights = points.index_select(0, src_pt), point_fg_weights.index_select(0, src_pt)
         elif fg_idx is not None:  # `obj_id_tensor` already holds the rows of the foreground points `fg_idx` (ascending)
-            if (pts_feat.is_cuda and pts_feat.dtype == torch.float32 and pts_feat.stride(1) == 1 and not torch.is_grad_enabled()
-                    and switches.SIR_GATHER):
+            if (pts_feat.is_cuda and pts_feat.dtype == torch.float32 and pts_feat.stride(1) == 1 and not torch.is_grad_enabled()):
                 # the 131-wide point features are not gathered here: their row INDEX travels through the selection / duplication
                 # steps in their place, and the first SIR layer's input kernel reads the rows through it (sst_ops.GatheredRows)
                 lazy_src, pts_feat = pts_feat, fg_idx.unsqueeze(1)
@@ -399,7 +398,7 @@ class FSF(SingleStageFSD):
         self._img_pre = None
         if (torch.is_grad_enabled() or self.is_argo or self.encode_label_only or mask_anno.shape[0] != 1 or len(point_infos) != 1
                 or mask_data.shape[2] > hip_ops.PROJECT_SCORE_MAX_CLS or mask_data.dtype not in (torch.uint8, torch.int32)
-                or not point_infos[0].is_cuda or not switches.FUSION_ADD_FUSED):
+                or not point_infos[0].is_cuda):
             return
         info = point_infos[0]
         lidar2img = torch.as_tensor(img_metas[0]["lidar2img"], dtype=torch.float32, device=info.device)
@@ -423,7 +422,7 @@ class FSF(SingleStageFSD):
         batch_idx = pts_coors[:, 0]
         pts_updated_feats = self.img_cross_attn(point_infos, batch_idx, mask_anno, mask_data, img_metas,
                                                 encode_mlp=self.segmentor_updated_mlp,
-                                                add_to=pts_lidar_feats if switches.FUSION_ADD_FUSED else None)
+                                                add_to=pts_lidar_feats)
         if getattr(pts_updated_feats, "_fsf_sum_done", False):
             pts_feats = pts_updated_feats  # (the sum already: the update MLP's last Linear added the LiDAR features in its epilogue)
         elif (pts_lidar_feats.is_cuda and pts_lidar_feats.dim() == 2 and pts_lidar_feats.size(1) % 4 != 0
@@ -451,7 +450,7 @@ class FSF(SingleStageFSD):
         if (fgc is not None and batch_size == 1 and fgc[0].data_ptr() == points_info_flat.data_ptr()
                 and fgc[0].shape == points_info_flat.shape and fgc[1] is mask_data and fgc[0]._version == points_info_flat._version):
             ncells = mask_data.shape[1] * mask_data.shape[2]
-            if switches.OVERLAP_ROWS and ncells <= 254 and not torch.is_grad_enabled():
+            if ncells <= 254 and not torch.is_grad_enabled():
                 # K26: the rows extract_fg_pts + double_overlap_pts + get_sir_coors produce, from the cell count / largest id
                 # img_cross_attn's kernel already emitted: two C-ABI calls, one read-back (was: nonzero, a second projection of the
                 # foreground points into an [F, cams * classes] int64 tensor, ~45 ATen launches, three host syncs)

@@ -240,7 +240,7 @@ class SingleStageFSD(nn.Module):
         scores = seg_logits.softmax(1)[:, :-1]
         thresh = const(("score_thresh", tuple(cfg["score_thresh"])), lambda: torch.tensor(cfg["score_thresh"], dtype=scores.dtype))
         small_groups = max(len(cols) for cols in group_cols) <= 2
-        if (bsz == 1 and switches.GROUP_PAIRS and scores.is_cuda and scores.dtype == torch.float32 and ng <= 32 and nc <= 32
+        if (bsz == 1 and scores.is_cuda and scores.dtype == torch.float32 and ng <= 32 and nc <= 32
                 and small_groups and scores.stride(1) == 1):
             # K27: the group scores (every group has one or two classes — the nuScenes grouping: their sum has one value whatever
             # adds it), the threshold, "at least one point per group" (:832-834) and the group-major pair list in one C-ABI call
@@ -266,7 +266,7 @@ class SingleStageFSD(nn.Module):
         # cluster-voxel key (torch.div(.., 'floor') with the group's voxel size, :948-950; group folded into the batch column)
         vs_rows = [ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]]
         if (seg_logits.is_cuda and nc <= 32 and ng <= 16 and seg_logits.dtype == torch.float32
-                and switches.FUSED_VOTE):
+                ):
             # one pass (fsf_vote_centers_keys) instead of ~22 launches over [n_pairs, classes(, 3)] temporaries
             masks = [sum(1 << c for c in cols) for cols in group_cols]
             centers, keys, b_pts = hip_ops.vote_centers_keys(
@@ -291,54 +291,40 @@ class SingleStageFSD(nn.Module):
         cells = [max(int(math.ceil((ca.point_cloud_range[3 + a] - ca.point_cloud_range[a]) / row[a])) for row in vs_rows) for a in range(3)]
         with_key_bounds(keys, [0] + [-(c // 2) - 8 for c in cells], [ng * bsz - 1] + [c + c // 2 + 8 for c in cells])
         new_keys, inv, cnt = unique_with_plan(keys)
-        if switches.CLUSTER_ONE_UNIQUE:
-            # Whether a pair survives is a property of its voxel key (dense enough, or its whole group has no dense voxel, :953-954),
-            # so the voxels of the surviving pairs are a SUBSET of the unique just taken: their keys, the pair -> voxel map and the
-            # voxel means (same rows in the same order per voxel) follow from it — upstream runs a second unique on the survivors.
-            if new_keys.is_cuda and ng <= 64 and switches.KEY_SURVIVAL:
-                # one C-ABI call and one read-back (K25) instead of ~22 small launches and two nonzero() round trips
-                k_idx, vox_group_i32, v_idx, vox_inv = hip_ops.cluster_key_survival(new_keys, cnt, inv, bsz, ca.min_points, ng)
-            else:
-                vox_group_i32 = None
-                key_ok = cnt >= ca.min_points
-                key_group = torch.div(new_keys[:, 0], bsz, rounding_mode="floor")           # ascending: keys sort by (group, batch) first
-                kcs = torch.cat([key_ok.new_zeros(1, dtype=torch.int64), key_ok.to(torch.int64).cumsum(0)])
-                kb = torch.searchsorted(key_group, torch.arange(ng + 1, device=dev))
-                has_valid = (kcs[kb[1:]] - kcs[kb[:-1]]) > 0
-                key_keep = key_ok | ~has_valid.index_select(0, key_group)
-                valid = key_keep.index_select(0, inv)
-                v_idx = valid.nonzero(as_tuple=False).squeeze(1)
-                k_idx = key_keep.nonzero(as_tuple=False).squeeze(1)
-                remap = key_keep.to(torch.int64).cumsum(0) - 1
-                vox_inv = remap.index_select(0, inv.index_select(0, v_idx))
-            all_means, _, _ = scatter_v2(centers, keys, mode="avg", return_inv=True, unq_inv=inv, new_coors=new_keys,
-                                         short_segments=True)
-            if vox_group_i32 is not None and all_means.dtype == torch.float32 and centers.dtype == torch.float32:
-                # the survivors' rows of all five tensors in one launch (K29b; was five index_selects)
-                vox_centers, g_ids, p_ids, b_pts, centers = hip_ops.compact_pairs(all_means, k_idx, g_ids, p_ids, b_pts, centers, v_idx)
-                vox_keys = None
-            else:
-                vox_centers = all_means.index_select(0, k_idx)
-                vox_keys = new_keys.index_select(0, k_idx) if vox_group_i32 is None else None  # (only the generic tail below reads them)
-                g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
-                centers = centers.index_select(0, v_idx)
+        # Whether a pair survives is a property of its voxel key (dense enough, or its whole group has no dense voxel, :953-954),
+        # so the voxels of the surviving pairs are a SUBSET of the unique just taken: their keys, the pair -> voxel map and the
+        # voxel means (same rows in the same order per voxel) follow from it — upstream runs a second unique on the survivors.
+        if new_keys.is_cuda and ng <= 64:
+            # one C-ABI call and one read-back (K25) instead of ~22 small launches and two nonzero() round trips
+            k_idx, vox_group_i32, v_idx, vox_inv = hip_ops.cluster_key_survival(new_keys, cnt, inv, bsz, ca.min_points, ng)
         else:
-            valid = cnt[inv] >= ca.min_points
-            # valid pairs per group: the pairs are group-major, so a running count read at the group boundaries (an index_add_ of
-            # half a million rows into six counters is 120 us of same-address atomics)
-            csum = torch.cat([valid.new_zeros(1, dtype=torch.int64), valid.to(torch.int64).cumsum(0)])
-            bounds = torch.searchsorted(g_ids, torch.arange(ng + 1, device=dev))
-            has_valid = (csum[bounds[1:]] - csum[bounds[:-1]]) > 0
-            valid |= ~has_valid.index_select(0, g_ids)             # a group without any dense voxel keeps all its points (:953-954)
+            vox_group_i32 = None
+            key_ok = cnt >= ca.min_points
+            key_group = torch.div(new_keys[:, 0], bsz, rounding_mode="floor")           # ascending: keys sort by (group, batch) first
+            kcs = torch.cat([key_ok.new_zeros(1, dtype=torch.int64), key_ok.to(torch.int64).cumsum(0)])
+            kb = torch.searchsorted(key_group, torch.arange(ng + 1, device=dev))
+            has_valid = (kcs[kb[1:]] - kcs[kb[:-1]]) > 0
+            key_keep = key_ok | ~has_valid.index_select(0, key_group)
+            valid = key_keep.index_select(0, inv)
             v_idx = valid.nonzero(as_tuple=False).squeeze(1)
+            k_idx = key_keep.nonzero(as_tuple=False).squeeze(1)
+            remap = key_keep.to(torch.int64).cumsum(0) - 1
+            vox_inv = remap.index_select(0, inv.index_select(0, v_idx))
+        all_means, _, _ = scatter_v2(centers, keys, mode="avg", return_inv=True, unq_inv=inv, new_coors=new_keys,
+                                     short_segments=True)
+        if vox_group_i32 is not None and all_means.dtype == torch.float32 and centers.dtype == torch.float32:
+            # the survivors' rows of all five tensors in one launch (K29b; was five index_selects)
+            vox_centers, g_ids, p_ids, b_pts, centers = hip_ops.compact_pairs(all_means, k_idx, g_ids, p_ids, b_pts, centers, v_idx)
+            vox_keys = None
+        else:
+            vox_centers = all_means.index_select(0, k_idx)
+            vox_keys = new_keys.index_select(0, k_idx) if vox_group_i32 is None else None  # (only the generic tail below reads them)
             g_ids, p_ids, b_pts = g_ids.index_select(0, v_idx), p_ids.index_select(0, v_idx), b_pts.index_select(0, v_idx)
             centers = centers.index_select(0, v_idx)
-            vox_centers, vox_keys, vox_inv = scatter_v2(centers, keys.index_select(0, v_idx), mode="avg", return_inv=True,
-                                                        short_segments=True)
         dist = const("connected_dist", lambda: torch.tensor([ca._per_class(ca.connected_dist, n) for n in ca.class_names[:ng]],
                                                             dtype=torch.float32))
         # test-time clustering ignores the sample index inside a group (:69-82); components never span groups
-        if switches.CLUSTER_ONE_UNIQUE and vox_group_i32 is not None:
+        if vox_group_i32 is not None:
             labels = hip_ops.connected_components_grouped(vox_centers, vox_group_i32, dist)
             # (a group's labels start at its first voxel's: renumbered from 0 per group and mapped to the pairs in two launches)
             pts_cluster_inds = hip_ops.cluster_point_ids(labels, vox_group_i32, vox_inv, g_ids, b_pts, ng)
@@ -362,7 +348,7 @@ class SingleStageFSD(nn.Module):
             # where they are, the layer's input kernel reads them through `p_ids` side by side (sst_ops.GatheredRows; materialised —
             # gathered straight into one [n, 11 + 33 + 131] buffer — by anything else that wants the matrix)
             lazy = GatheredRows(parts, p_ids)
-            self._grouped_feats_concat = lazy if switches.SIR_GATHER else lazy.materialize()
+            self._grouped_feats_concat = lazy
             return take(d["seg_points"]), None, None, None, centers, pts_cluster_inds
         self._grouped_feats_concat = None
         return (take(d["seg_points"]), take(seg_logits), take(d["seg_vote_preds"]), take(d["seg_feats"]), centers,

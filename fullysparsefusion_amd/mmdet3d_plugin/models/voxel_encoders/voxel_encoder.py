@@ -100,7 +100,7 @@ class DynamicScatterVFE(nn.Module):
             new_coors = unq_inv = None
         if (features.is_cuda and features.dtype == torch.float32 and not self._with_distance and features.size(1) >= 3
                 and (self._with_cluster_center or self._with_voxel_center)
-                and not (torch.is_grad_enabled() and features.requires_grad) and switches.VFE_DECORATE):
+                and not (torch.is_grad_enabled() and features.requires_grad)):
             # inference: the decorated input in one pass (fsf_vfe_decorate) instead of a gather, a dozen elementwise launches and
             # a cat; its rows are padded to 16 bytes, so the first layer's fused Linear reads them in place
             voxel_mean = unq_inv_c = None
@@ -229,7 +229,7 @@ class SIRLayer(nn.Module):
         if gathered and (fused is None or len(feats.sources) > 3):
             feats, gathered = feats.materialize(), False
         if fused is None:
-            if (needs_grad and switches.TRAIN_SIR_PRODUCT and self._with_rel_mlp and not gathered and torch.is_tensor(feats)
+            if (needs_grad and self._with_rel_mlp and not gathered and torch.is_tensor(feats)
                     and feats.is_cuda and feats.dtype == torch.float32 and points.dtype == torch.float32 and feats.dim() == 2
                     and not points.requires_grad and points.size(1) >= 3 and feats.size(0) > 0
                     and (extra is None or extra.dtype == torch.float32) and not torch.is_autocast_enabled()):

@@ -251,8 +251,7 @@ class SparseConvolution(SparseModule):
     def _use_split_kernel_training(self):
         """Training uses K9b for the forward AND the data gradient of the submanifold layers (their transposed table
         has the same row count); strided / inverse layers keep the compacting fp32 kernel in both directions."""
-        return (self.subm and self.in_channels % 4 == 0 and self.out_channels % 4 == 0
-                and switches.TRAIN_SPLIT)
+        return self.subm and self.in_channels % 4 == 0 and self.out_channels % 4 == 0
 
     def _weight_split(self):
         w = self.weight
@@ -305,8 +304,6 @@ class SparseConvolution(SparseModule):
     def _use_planes_kernel(self, x, m_out):
         if not (m_out >= self.PLANES_MIN_ROWS and switches.PLANES):
             return False
-        if not self.subm and not switches.PLANES_STRIDED:
-            return False
         cin = self.in_channels
         cins = [p.c for p in x.plane_sources] if x.plane_sources is not None else ([cin] if cin <= 128 else [cin // 2, cin - cin // 2])
         return sum(cins) == cin and hip_ops.spconv_planes_supported(cins, self.out_channels, math.prod(self.kernel_size))
@@ -352,7 +349,7 @@ class SparseConvolution(SparseModule):
             y.plane_sources = [planes] if planes is not None else None
             return y
         elif self._use_split_kernel(nbr.size(0)) and feat.size(0) > 0:
-            if (switches.SPLIT_F16 and self.in_channels >= 256  # (measured at 256 .. 1024 input channels; below, the conversion is the gain)
+            if (self.in_channels >= 256  # (measured at 256 .. 1024 input channels; below, the conversion is the gain)
                     and hip_ops.spconv_split_planes_supported(self.in_channels, self.out_channels)
                     and hip_ops.rows_to_planes_supported(feat)):
                 # K9b-XP: the deep levels (512 / 1024 input channels on a few thousand rows) with both operands as f16 planes

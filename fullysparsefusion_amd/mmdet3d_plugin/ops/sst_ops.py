@@ -58,7 +58,7 @@ class _GatherRows(torch.autograd.Function):
 import threading
 
 _UNIQUE_TLS = threading.local()  # .entries: (coors tensor, _version, bounds, result) of this thread's last few calls, newest last
-_UNIQUE_CACHE_SIZE = int(os.environ.get("FSF_UNIQUE_CACHE", "2"))
+_UNIQUE_CACHE_SIZE = 2
 
 
 def _unique_entries():
@@ -90,7 +90,7 @@ def unique_with_plan(coors, col_min=None, col_max=None):
     OBJECT and its version counter (the tensor is held, so its storage cannot be recycled under the key), at inference only."""
     cache_ok = _UNIQUE_CACHE_SIZE > 0 and coors.is_cuda and not torch.is_grad_enabled()
     hinted = False
-    if col_min is None and switches.UNIQUE_BOUNDS:
+    if col_min is None:
         b = getattr(coors, _BOUNDS_ATTR, None)
         if b is not None:
             (col_min, col_max), hinted = b, True
@@ -144,8 +144,7 @@ def gather_by_inverse(rows, unq_inv, out=None):
     return _GatherRows.apply(rows, plan)
 
 
-_SMALL_N_MIN = int(os.environ.get("FSF_K22_SMALL_N", "16"))  # (A/B switch: 1024 restores the library for small inputs)
-_GROUPED_CONCAT = os.environ.get("FSF_GROUPED_CONCAT", "1") != "0"  # (A/B switch for scratch scripts)
+_SMALL_N_MIN = 16  # rows from which a shallow product runs on K22 rather than on the library (host time of the GEMM selection)
 
 
 class GroupedConcat:
@@ -342,14 +341,13 @@ def sorted_stack_forward(vfe_layers, x, seg_ids, group_out, want_last_rows):
     return point
 
 
-_TRAIN_GROUPED = os.environ.get("FSF_TRAIN_GROUPED", "1") != "0"  # (A/B switch)
 
 
 def _grouped_linear_training(linear, gc):
     """`linear(cat([p, g[inv]], 1))` with gradients, without the concat: p W_left^T (per point; weight gradient on K10) +
     (g W_right^T (+ b))[inv] (per group, then one gather-add pass).  None when the input is not covered."""
     p, g = gc.point_feats, gc.group_feats
-    if not (_TRAIN_GROUPED and isinstance(linear, nn.Linear) and p.is_cuda and p.dtype == torch.float32 and p.dim() == 2
+    if not (isinstance(linear, nn.Linear) and p.is_cuda and p.dtype == torch.float32 and p.dim() == 2
             and g.dtype == torch.float32 and linear.in_features == p.size(1) + g.size(1) and p.size(0) >= 16384 and g.size(0) > 0):
         return None
     c = p.size(1)
@@ -386,8 +384,7 @@ def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, wan
                                                    short_segments=short_segments)
         cat = None
         if want_concat:
-            cat = GroupedConcat(point_feats, group_feats, inv) if _GROUPED_CONCAT else GroupedConcat(
-                point_feats, group_feats, inv).materialize()
+            cat = GroupedConcat(point_feats, group_feats, inv)
         return point_feats, group_feats, group_coors, inv, cat
     if point_feats is None:
         point_feats = vfe_layer(features)
@@ -395,7 +392,7 @@ def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, wan
                                                short_segments=short_segments)
     cat = None
     if want_concat:
-        if (_TRAIN_GROUPED and _GROUPED_CONCAT and not no_grad and point_feats.is_cuda and point_feats.dtype == torch.float32
+        if (not no_grad and point_feats.is_cuda and point_feats.dtype == torch.float32
                 and point_feats.size(0) >= 16384):
             cat = GroupedConcat(point_feats, group_feats, inv)  # consumed by the next layer's _grouped_linear_training
         else:
@@ -403,7 +400,6 @@ def point_group_concat(vfe_layer, features, coors, mode, unq_inv, new_coors, wan
     return point_feats, group_feats, group_coors, inv, cat
 
 
-_SHORT_SEGMENTS = os.environ.get("FSF_SEG_SHORT", "1") != "0"  # (A/B switch)
 
 
 def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, new_coors=None, short_segments=False):
@@ -427,7 +423,7 @@ def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, n
         coors = coors[valid_mask]
         new_coors, unq_inv, unq_cnt = unique_with_plan(coors)
     plan = plan_of(unq_inv, new_coors.size(0))
-    new_feat = _SegmentReduce.apply(feat.float(), plan, mode, bool(short_segments) and _SHORT_SEGMENTS)
+    new_feat = _SegmentReduce.apply(feat.float(), plan, mode, bool(short_segments))
     if not return_inv:
         return new_feat, new_coors
     return new_feat, new_coors, unq_inv
@@ -438,7 +434,7 @@ def scatter_mean_multi(feats, new_coors, unq_inv):
     over the same 0.1 m voxels) — at inference a single launch; otherwise one scatter_v2 per tensor."""
     plan = plan_of(unq_inv, new_coors.size(0))
     feats = [f.float() for f in feats]
-    if (_SHORT_SEGMENTS and 1 <= len(feats) <= 8 and all(f.is_cuda and f.dim() == 2 for f in feats)
+    if (1 <= len(feats) <= 8 and all(f.is_cuda and f.dim() == 2 for f in feats)
             and not (torch.is_grad_enabled() and any(f.requires_grad for f in feats))):
         # Tensors whose rows sit in 16-byte-aligned, padded storage (the 131-column point features in their 132-float rows) are
         # reduced as their padded width with float4 lanes — the pad column's mean is computed and dropped — in one launch, the
@@ -461,7 +457,7 @@ def scatter_mean_multi(feats, new_coors, unq_inv):
                 out[i] = o
             return out
         return hip_ops.segment_reduce_short(feats, plan, "mean")
-    return [_SegmentReduce.apply(f, plan, "mean", _SHORT_SEGMENTS) for f in feats]
+    return [_SegmentReduce.apply(f, plan, "mean", True) for f in feats]
 
 
 @torch.no_grad()
@@ -548,7 +544,6 @@ def fused_norm_act(x, norm, act, out=None):
     return y
 
 
-_BN_FUSED_STATS = os.environ.get("FSF_BN_FUSED_STATS", "1") != "0"  # (A/B switch)
 
 
 class _BatchNormActFn(torch.autograd.Function):
@@ -563,7 +558,7 @@ class _BatchNormActFn(torch.autograd.Function):
         if track:
             with torch.no_grad():
                 bn.num_batches_tracked += 1
-        if _BN_FUSED_STATS and (not track or bn.momentum is not None):
+        if not track or bn.momentum is not None:
             # statistics, invstd / scale / shift and the running-statistics update in four launches (fsf_batch_norm_train_stats)
             mean, invstd, scale, shift = hip_ops.batch_norm_train_stats(
                 x, weight.detach() if weight is not None else None, bias.detach() if bias is not None else None, bn.eps,
@@ -596,7 +591,7 @@ def batch_norm_act_training(bn, x, relu):
 
     if not (isinstance(bn, nn.BatchNorm1d) and bn.training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2
             and x.dtype == torch.float32 and x.size(0) > 1 and (bn.weight is None) == (bn.bias is None)
-            and switches.TRAIN_BN):
+            ):
         return None
     if type(bn).__name__ != "BatchNorm1d" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         # naiveSyncBN1d across ranks: K23 still does the row passes, the statistics travel as one packed [2C] all-reduce per
@@ -653,8 +648,7 @@ class _PointLinearFn(torch.autograd.Function):
         return g_x, g_w, g_b, g_t, None
 
 
-_TRAIN_K22 = os.environ.get("FSF_TRAIN_K22", "1") != "0"  # (A/B switch)
-_TRAIN_WIDE_MIN_ROWS = int(os.environ.get("FSF_TRAIN_WIDE_MIN_ROWS", "4096"))  # (A/B switch: 1 << 40 restores the library GEMMs)
+_TRAIN_WIDE_MIN_ROWS = 4096  # training: rows from which the heads' wide products run on K22h rather than on the library
 
 
 def _train_wide(x, k, c):
@@ -665,7 +659,7 @@ def _train_wide(x, k, c):
 
 
 def _train_k22(x, out_features):
-    return (_TRAIN_K22 and x.size(0) >= 16384 and x.size(1) % 4 == 0 and x.size(1) >= 32
+    return (x.size(0) >= 16384 and x.size(1) % 4 == 0 and x.size(1) >= 32
             and hip_ops.linear_norm_act_supported(x, out_features))
 
 

@@ -406,13 +406,16 @@ def test_grouped_concat_training_equals_the_concat_path(plugin, device, monkeypa
     x0 = torch.from_numpy(rng.standard_normal((n, cin)).astype(np.float32))
     probe = torch.from_numpy(rng.standard_normal((n, c)).astype(np.float32)).to(device)
 
+    real_grouped = sst_ops._grouped_linear_training
+
     def run(grouped):
-        monkeypatch.setattr(sst_ops, "_TRAIN_GROUPED", grouped)
+        # (reference form: the deferred concat is written out and the layer runs on the [n, 2C] tensor)
+        monkeypatch.setattr(sst_ops, "_grouped_linear_training", real_grouped if grouped else (lambda *a, **k: None))
         for m in (l1, l2):
             m.zero_grad()
         x = x0.to(device).requires_grad_()
         _, _, gcoors, inv, cat = sst_ops.point_group_concat(l1, x, coors, "max", None, None, want_concat=True)
-        assert isinstance(cat, sst_ops.GroupedConcat) == grouped
+        assert isinstance(cat, sst_ops.GroupedConcat)
         pf, gf, _, _, _ = sst_ops.point_group_concat(l2, cat, coors, "max", inv, gcoors, want_concat=False)
         ((pf * probe).sum() + gf.sum()).backward()
         return [pf.detach(), gf.detach(), x.grad] + [p.grad.clone() for m in (l1, l2) for p in m.parameters()], inv
@@ -1052,9 +1055,10 @@ def test_sir_layer_deferred_concat_equals_materialised(plugin, device, monkeypat
     gid = torch.randint(0, g, (n,), device=device)
     coors = torch.stack([torch.zeros_like(gid), gid % 7, gid], 1)
     outs = []
+    real = sst_ops._grouped_linear_norm_act
     with torch.no_grad():
         for deferred in (True, False):
-            monkeypatch.setattr(sst_ops, "_GROUPED_CONCAT", deferred)
+            monkeypatch.setattr(sst_ops, "_grouped_linear_norm_act", real if deferred else (lambda *a, **k: None))
             outs.append(layer(feats, coors, f_cluster=f_cluster, return_both=True))
     for a, b in zip(outs[0], outs[1]):
         if a.dtype.is_floating_point:
