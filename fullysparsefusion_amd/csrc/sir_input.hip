@@ -25,6 +25,7 @@ struct SirInputArgs {
   const float* feats1; int64_t feats1_stride; int f0_cols, f1_cols;
   const float* feats2; int64_t feats2_stride;
   const int64_t* feats_index;
+  int direct_mask;  // bit p: part p is NOT read through feats_index (its rows are already the layer's rows)
   const float* extra;  int64_t extra_stride;  int e_cols; float extra_div;
   const float* fcl;    int64_t fcl_stride;    int r_cols; float rel_div;
   float norm[3];
@@ -134,17 +135,20 @@ __global__ void __launch_bounds__(256, 2) sir_input_kernel(SirInputArgs a) {
       if (c < 3) xdiv[t] = a.norm[c];
     } else if (c < a.p_cols + a.f_cols) {
       const int fc = c - a.p_cols;
+      int part = 0;
       if (fc < a.f0_cols) {
         xsrc[t] = a.feats + fc;
         xstride[t] = a.feats_stride;
       } else if (fc < a.f0_cols + a.f1_cols) {
         xsrc[t] = a.feats1 + (fc - a.f0_cols);
         xstride[t] = a.feats1_stride;
+        part = 1;
       } else {
         xsrc[t] = a.feats2 + (fc - a.f0_cols - a.f1_cols);
         xstride[t] = a.feats2_stride;
+        part = 2;
       }
-      xgath[t] = a.feats_index != nullptr;
+      xgath[t] = a.feats_index != nullptr && !((a.direct_mask >> part) & 1);
     } else if (c < a.c) {
       xsrc[t] = a.extra + (c - a.p_cols - a.f_cols);
       xstride[t] = a.extra_stride;
@@ -383,7 +387,8 @@ using namespace fsf;
 
 extern "C" int fsf_sir_input_gather(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3],
                                     const float* const* feat_parts, const int64_t* feat_strides, const int32_t* feat_cols,
-                                    int32_t num_parts, const int64_t* feats_index, const float* extra, int64_t extra_stride,
+                                    int32_t num_parts, const int64_t* feats_index, int32_t direct_parts_mask, const float* extra,
+                                    int64_t extra_stride,
                                     int32_t e_cols, float extra_div, const float* f_cluster, int64_t f_cluster_stride,
                                     int32_t r_cols, float rel_div, const float* w1, const float* g1, const float* b1, int32_t h1,
                                     const float* w2, const float* g2, const float* b2, int32_t h2, const float* w3,
@@ -400,14 +405,15 @@ extern "C" int fsf_sir_input(const float* points, int64_t points_stride, int32_t
   const float* parts[1] = {feats};
   const int64_t strides[1] = {feats_stride};
   const int32_t cols[1] = {f_cols};
-  return fsf_sir_input_gather(points, points_stride, p_cols, xyz_normalizer, parts, strides, cols, f_cols > 0 ? 1 : 0, nullptr, extra,
+  return fsf_sir_input_gather(points, points_stride, p_cols, xyz_normalizer, parts, strides, cols, f_cols > 0 ? 1 : 0, nullptr, 0, extra,
                               extra_stride, e_cols, extra_div, f_cluster, f_cluster_stride, r_cols, rel_div, w1, g1, b1, h1, w2, g2,
                               b2, h2, w3, g3, b3, eps, act, n, out, out_stride, stream_);
 }
 
 extern "C" int fsf_sir_input_gather(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3],
                                     const float* const* feat_parts, const int64_t* feat_strides, const int32_t* feat_cols,
-                                    int32_t num_parts, const int64_t* feats_index, const float* extra, int64_t extra_stride,
+                                    int32_t num_parts, const int64_t* feats_index, int32_t direct_parts_mask, const float* extra,
+                                    int64_t extra_stride,
                                     int32_t e_cols, float extra_div, const float* f_cluster, int64_t f_cluster_stride,
                                     int32_t r_cols, float rel_div, const float* w1, const float* g1, const float* b1, int32_t h1,
                                     const float* w2, const float* g2, const float* b2, int32_t h2, const float* w3,
@@ -440,6 +446,7 @@ extern "C" int fsf_sir_input_gather(const float* points, int64_t points_stride, 
   a.f1_cols = num_parts > 1 ? feat_cols[1] : 0;
   a.feats2 = num_parts > 2 ? feat_parts[2] : nullptr; a.feats2_stride = num_parts > 2 ? feat_strides[2] : 0;
   a.feats_index = num_parts > 0 ? feats_index : nullptr;
+  a.direct_mask = direct_parts_mask;
   a.extra = extra; a.extra_stride = extra_stride; a.e_cols = e_cols; a.extra_div = extra_div;
   a.fcl = f_cluster; a.fcl_stride = f_cluster_stride; a.r_cols = r_cols; a.rel_div = rel_div;
   for (int i = 0; i < 3; ++i) a.norm[i] = xyz_normalizer[i];

@@ -68,7 +68,7 @@ _ARGTYPES = {
     "fsf_norm_act_backward_workspace_bytes": [c_i32],
     "fsf_norm_act_backward": [_P, _P, c_i64, c_i32, _P, _P, c_f32, c_i32, _P, _P, _P, _P, c_i64, _P],
     "fsf_row_topk_desc": [_P, c_i64, c_i32, c_i32, _P, _P],
-    "fsf_sir_input_gather": [_P, c_i64, c_i32, _P, _P, _P, _P, c_i32, _P, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
+    "fsf_sir_input_gather": [_P, c_i64, c_i32, _P, _P, _P, _P, c_i32, _P, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
                              _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
     "fsf_sir_input": [_P, c_i64, c_i32, _P, _P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, c_f32, _P, _P, _P, c_i32,
                       _P, _P, _P, c_i32, _P, _P, _P, c_f32, c_i32, c_i64, _P, c_i64, _P],
@@ -984,7 +984,7 @@ def row_topk_desc(x: torch.Tensor, k: int):
 
 # ------------------------------------------------------------------------------------- SIR-layer input
 def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_div: float, extra=None, extra_div: float = 1.0,
-              feats_index=None):
+              feats_index=None, direct_parts=()):
     """fsf_sir_input[_gather]: cat(points / normalizer, feats[, extra / extra_div]) * rel_mlp(f_cluster / rel_div) -> f32 [n, C].
     `layers` = three (linear_weight, ln_weight, ln_bias) triples of the position MLP; one eps (taken by the caller).
     `feats` may be a list of up to three tensors standing side by side, and with `feats_index` (i64 [n]) row i of the input takes row
@@ -998,7 +998,8 @@ def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_di
     assert w3.size(0) == c and w1.size(1) == f_cluster.size(1) and w2.size(1) == w1.size(0) and w3.size(1) == w2.size(0)
     for t in [points, f_cluster, extra] + parts:
         assert t is None or (t.dtype == torch.float32 and t.dim() == 2 and (t.size(0) == 0 or t.stride(1) == 1))
-    assert 1 <= len(parts) <= 3 and (feats_index is not None or all(t.size(0) == n for t in parts))
+    direct_mask = sum(1 << int(p) for p in direct_parts)  # parts whose rows are the layer's rows already (not read through the index)
+    assert 1 <= len(parts) <= 3 and all(t.size(0) == n for i, t in enumerate(parts) if feats_index is None or (direct_mask >> i) & 1)
     if feats_index is not None:
         feats_index = feats_index.to(torch.int64).contiguous()
         assert feats_index.numel() == n
@@ -1011,7 +1012,7 @@ def sir_input(points, feats, f_cluster, xyz_normalizer, layers, act: str, rel_di
     fp = (ctypes.c_void_p * k)(*[t.data_ptr() if t.numel() else None for t in parts])
     fs = (ctypes.c_int64 * k)(*[int(st(t)) for t in parts])
     fc = (ctypes.c_int32 * k)(*[int(t.size(1)) for t in parts])
-    check(_L().fsf_sir_input_gather(rp(points), st(points), points.size(1), f32_array(xyz_normalizer), fp, fs, fc, k, ptr(feats_index),
+    check(_L().fsf_sir_input_gather(rp(points), st(points), points.size(1), f32_array(xyz_normalizer), fp, fs, fc, k, ptr(feats_index), direct_mask,
                                     rp(extra), st(extra), extra.size(1) if extra is not None else 0, float(extra_div),
                                     rp(f_cluster), st(f_cluster), f_cluster.size(1), float(rel_div),
                                     ptr(w1.contiguous()), ptr(g1), ptr(b1), w1.size(0), ptr(w2.contiguous()), ptr(g2), ptr(b2),

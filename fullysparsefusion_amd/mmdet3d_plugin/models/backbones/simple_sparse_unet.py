@@ -7,6 +7,8 @@ output rows in the input voxel order.  Submodule names follow upstream (`conv_in
 `encoder_layers.encoder_layerN`, `lateral_layerN`, `merge_layerN`, `upsample_layerN`)."""
 import os
 
+import collections
+
 import torch
 import torch.nn as nn
 
@@ -174,6 +176,22 @@ class SimpleSparseUNet(nn.Module):
                 trace.append((tag, e))
 
         mark("forward enters")
+        # Tensors that cross streams (the plan stream's tables read by the main and lateral streams, encoder outputs read by the lateral
+        # stream, lateral outputs read by the main one) are HELD until an event the main stream records behind its last use of them
+        # has completed, then dropped.  `Tensor.record_stream` did the same job at a price nobody saw on the host: when such a tensor
+        # dies the caching allocator records one event per (block, stream that used it) — ~100 marker packets per frame, ~50 of them on
+        # the main queue between the U-Net's last kernel and the neck, 2.7 us each: the main stream stood for 150-160 us there
+        # (tools/profiling/neck_stall_probe.py: 158 us with both side streams, 117 / 43 with one, 0 with none).
+        held = []
+        pending = self.__dict__.setdefault("_held_cross_stream", collections.deque())
+        while pending:
+            if pending[0][0] is None:  # a forward that raised before it recorded its event: wait for everything once, then let go
+                torch.cuda.synchronize()
+            elif not pending[0][0].query():
+                break
+            pending.popleft()
+        entry = [None, held]
+        pending.append(entry)
         plan_on = (switches.UNET_PLAN_STREAM and voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training
                    and not torch.cuda.is_current_stream_capturing())
         inv_perm = None
@@ -205,12 +223,10 @@ class SimpleSparseUNet(nn.Module):
                 for rb in meta.indice_dict.values():
                     if not isinstance(rb, bool):
                         ts += [rb.nbr, rb.nbr_inv, rb.in_indices, rb.out_indices]
-                users = [main] + ([self._lateral_stream] if side_levels > 0 else [])
                 for t in ts:
                     if t is not None and id(t) not in published:
                         published.add(id(t))
-                        for st in users:
-                            t.record_stream(st)
+                        held.append(t)
                 ev = torch.cuda.Event()
                 ev.record(ps)
                 main.wait_event(ev)
@@ -262,8 +278,7 @@ class SimpleSparseUNet(nn.Module):
                         # allocated on the main stream, read by the side stream: the allocator must not hand the blocks to a later
                         # main-stream allocation before the side kernels are through with them (an exception between here and the
                         # decoder loop would otherwise free them for reuse)
-                        for t in [src.features] + [u for pl in (src.plane_sources or []) for u in (pl.data, pl.scales)]:
-                            t.record_stream(side)
+                        held.extend([src.features] + [u for pl in (src.plane_sources or []) for u in (pl.data, pl.scales)])
                         y = getattr(self, f"lateral_layer{lv}")(src)
                         ev = torch.cuda.Event()
                         ev.record(side)
@@ -276,8 +291,8 @@ class SimpleSparseUNet(nn.Module):
                 if lat is not None:
                     main = torch.cuda.current_stream()
                     main.wait_event(lateral_done[i])
-                    for t in [lat.features] + [u for pl in (lat.plane_sources or []) for u in (pl.data, pl.scales)]:
-                        t.record_stream(main)  # allocated on the side stream, consumed (and later freed) on this one
+                    # (allocated on the side stream, consumed on this one: held, see `held`)
+                    held.extend([lat.features] + [u for pl in (lat.plane_sources or []) for u in (pl.data, pl.scales)])
                 x = self.decoder_layer_forward(encode_features[i - 1], x, getattr(self, f"lateral_layer{i}"),
                                                getattr(self, f"merge_layer{i}"), getattr(self, f"upsample_layer{i}"), lateral_out=lat)
         except BaseException:
@@ -288,6 +303,12 @@ class SimpleSparseUNet(nn.Module):
         # would record one more event on a stream that went idle a millisecond ago — waking its hardware queue for that marker held
         # the main stream for ~150 us in front of the neck, on the 1-sweep frame as on the 10-sweep one)
         mark("decoder done")
+        if held and voxel_features.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())  # (the main stream has waited for every lateral event: behind this, nobody reads them)
+            entry[0] = ev
+        else:
+            pending.pop()
         out = x.features
         if inv_perm is not None:
             out = out.index_select(0, inv_perm)  # back to the caller's voxel order

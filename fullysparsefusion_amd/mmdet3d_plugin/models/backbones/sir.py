@@ -60,6 +60,8 @@ class SIR(nn.Module):
         lazy = isinstance(f_cluster, RowsMinusGroup)
         if lazy and not (f_cluster.inv is unq_inv and f_cluster.points is points and f_cluster.centers.size(0) == m):
             f_cluster, lazy = f_cluster.materialize(), False  # (an offset to some other grouping: the expression itself)
+        if isinstance(features, GatheredRows) and features.direct:
+            features = features.materialize()  # (a part that is not read through the index cannot follow the permutation)
         gathered = isinstance(features, GatheredRows)
         # ONE launch (K29a): the group id, the point rows, the centre offsets and the feature-row index of every sorted position,
         # and the -inf the group table starts with (was: .long(), two index_selects, two row gathers, a fill)

@@ -664,12 +664,19 @@ class FSF(SingleStageFSD):
             # K29e: the pooled points' rows and the refine head's f_cluster (pooling info + offset to the RoI centre) in one launch
             extracted_points, f_cluster = hip_ops.refine_rows(info13, points, ext_pts_inds, ext_pts_roi_inds, input_bbox_rois[:, 1:4])
             ext_pts_info["_fsf_f_cluster"] = f_cluster
+            lazy = (pts_feat.is_cuda and pts_feat.dtype == torch.float32 and pts_feat.dim() == 2 and pts_feat.stride(1) == 1
+                    and getattr(self.refine_sir_layers[i_stage], "takes_gathered_rows", False))
         else:
             extracted_points = points[ext_pts_inds]
-        extracted_points_feats = pts_feat[ext_pts_inds]
+            lazy = False
         pts_img_feat = self.img_cross_attn(point_infos, batch_idx, mask_anno, mask_data, img_metas,
                                            self.refine_img_mlp[i_stage], ext_pts_inds)
-        ext_pts_feats_updated = torch.cat([extracted_points_feats, pts_img_feat], dim=-1)
+        if lazy and pts_img_feat.dtype == torch.float32 and pts_img_feat.stride(1) == 1:
+            # `cat([pts_feat[ext_pts_inds], pts_img_feat], -1)` kept as its parts: the refine head's first input kernel reads the frame's
+            # point features through the pooling index and the image features as they stand (K21, direct_parts_mask)
+            ext_pts_feats_updated = GatheredRows([pts_feat, pts_img_feat], ext_pts_inds, direct=(1,))
+        else:
+            ext_pts_feats_updated = torch.cat([pts_feat[ext_pts_inds], pts_img_feat], dim=-1)
         lidar_feat, _ = self.refine_sir_layers[i_stage](extracted_points, ext_pts_feats_updated, ext_pts_info,
                                                         ext_pts_roi_inds, input_bbox_rois)
         return lidar_feat

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .... import hip_ops, switches
 from ...ops.dynamic_point_pool_op import dynamic_point_pool
-from ...ops.sst_ops import unique_with_plan, with_key_bounds
+from ...ops.sst_ops import GatheredRows, unique_with_plan, with_key_bounds
 from ...registry import HEADS, ROI_EXTRACTORS, build_voxel_encoder
 
 
@@ -84,14 +84,21 @@ class FullySparseBboxHead(nn.Module):
                 cat_voxel_feats=cat_voxel_feats, act=act, dropout=dropout)))
         self.block_list = nn.ModuleList(blocks)
 
+    takes_gathered_rows = True  # (forward accepts sst_ops.GatheredRows as `pts_features`)
+
     def forward(self, pts_xyz, pts_features, pts_info, roi_inds, rois):
         assert pts_features.size(0) > 0
         rois = rois[:, 1:]
+        lazy_feats = isinstance(pts_features, GatheredRows)
         sorted_ok = (switches.SIR_SORTED and self.unique_once and getattr(roi_inds, "_fsf_sorted", False)
                      and self.use_middle_cluster_feature and not torch.is_grad_enabled() and pts_xyz.is_cuda
-                     and pts_xyz.dtype == torch.float32 and pts_features.dtype == torch.float32 and pts_features.stride(1) == 1
+                     and pts_xyz.dtype == torch.float32 and pts_features.dtype == torch.float32
+                     and (lazy_feats or pts_features.stride(1) == 1)
                      and all(getattr(b, "sorted_supported", lambda: False)() for b in self.block_list))
-        if sorted_ok and switches.REFINE_DIRECT and getattr(roi_inds, "_fsf_real_rows", False) and roi_inds.dtype == torch.int64:
+        direct = sorted_ok and switches.REFINE_DIRECT and getattr(roi_inds, "_fsf_real_rows", False) and roi_inds.dtype == torch.int64
+        if lazy_feats and not direct:
+            pts_features = pts_features.materialize()  # (only the RoI-indexed path below reads the parts in place)
+        if direct:
             # The pooled rows are sorted by RoI and every index is a real RoI: the RoI index IS the segment id and the
             # [rois, 768] result IS the group table — no unique (12 launches, a host wait), no scatter of the groups to their RoI
             # rows (11 ATen launches).  A RoI without points keeps the -inf the table starts with: that is the non-empty mask,

@@ -250,7 +250,8 @@ class SIRLayer(nn.Module):
         layers, eps, act = fused
         if gathered:  # rows of the source tensors through the sampling index, parts side by side: no gather, no concat
             features = hip_ops.sir_input(points, feats.sources, f_cluster, self.xyz_normalizer, (*layers, eps), act,
-                                         self.rel_dist_scaler, extra=extra, extra_div=extra_div, feats_index=feats.index)
+                                         self.rel_dist_scaler, extra=extra, extra_div=extra_div, feats_index=feats.index,
+                                         direct_parts=feats.direct)
         else:
             features = hip_ops.sir_input(points, feats, f_cluster, self.xyz_normalizer, (*layers, eps), act, self.rel_dist_scaler,
                                          extra=extra, extra_div=extra_div)
@@ -277,14 +278,15 @@ class SIRLayer(nn.Module):
         group_out f32 [m, group_width()] (holding -inf) receives the block's group features; returns the point rows (sorted),
         or None unless `want_rows`."""
         layers, eps, act = self._fused_input_layers()
+        direct = ()
         if isinstance(feats, GatheredRows):
-            sources, index = feats.sources, feats.index
+            sources, index, direct = feats.sources, feats.index, feats.direct
         elif rows_index is not None:
             sources, index = [feats], rows_index
         else:
             sources, index = feats, None
         features = hip_ops.sir_input(points, sources, f_cluster, self.xyz_normalizer, (*layers, eps), act, self.rel_dist_scaler,
-                                     extra=extra, extra_div=extra_div, feats_index=index)
+                                     extra=extra, extra_div=extra_div, feats_index=index, direct_parts=direct)
         return sorted_stack_forward(self.vfe_layers, features, seg_ids, group_out, want_rows)
 
     def forward(self, features, coors, f_cluster=None, points=None, img_feats=None, img_metas=None, return_both=False,

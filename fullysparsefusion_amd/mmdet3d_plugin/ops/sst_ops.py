@@ -179,8 +179,9 @@ class GatheredRows:
     group-sampled points' features is the first SIR layer's input kernel, which reads rows through an index and several
     tensors side by side (fsf_sir_input_gather): the [n_pairs, 11 + 33 + 131] matrix is never written."""
 
-    def __init__(self, sources, index):
-        self.sources, self.index = list(sources), index
+    def __init__(self, sources, index, direct=()):
+        # `direct`: positions in `sources` of tensors that hold the gathered rows ALREADY (n rows, read as they stand)
+        self.sources, self.index, self.direct = list(sources), index, tuple(direct)
 
     @property
     def shape(self):
@@ -200,8 +201,11 @@ class GatheredRows:
         n, widths = self.index.numel(), [t.size(1) for t in self.sources]
         buf = torch.empty((n, sum(widths)), dtype=self.sources[0].dtype, device=self.sources[0].device)
         c0 = 0
-        for t, w in zip(self.sources, widths):
-            hip_ops.gather_rows(t, self.index, out=buf[:, c0:c0 + w])
+        for i, (t, w) in enumerate(zip(self.sources, widths)):
+            if i in self.direct:
+                buf[:, c0:c0 + w] = t
+            else:
+                hip_ops.gather_rows(t, self.index, out=buf[:, c0:c0 + w])
             c0 += w
         return buf
 

@@ -661,11 +661,13 @@ int fsf_sir_input(const float* points, int64_t points_stride, int32_t p_cols, co
  * HOST arrays of num_parts entries) and, with feats_index (i64 [n]), through an index: row i of the layer input reads row
  * feats_index[i] of every part.  The first SIR layer of the LiDAR-query branch then needs neither the gather of the group-sampled
  * points' features nor the torch.cat([seg_logits, seg_vote_preds, seg_feats], 1) in front of it (FSF.py fsd_forward,
- * single_stage_fsd.py:867-901). */
+ * single_stage_fsd.py:867-901).  direct_parts_mask (round 6): bit p set = part p is NOT read through the index (its rows are the layer's
+ * rows already) — the refine stage's `torch.cat([pts_feat[ext_pts_inds], pts_img_feat], -1)` (FSF.query_feat_refine, FSF.py:961-1010):
+ * part 0 = the frame's point features through `ext_pts_inds`, part 1 = the image features of the pooled points as they stand. */
 int fsf_sir_input_gather(const float* points, int64_t points_stride, int32_t p_cols, const float xyz_normalizer[3],
                          const float* const* feat_parts, const int64_t* feat_strides, const int32_t* feat_cols, int32_t num_parts,
-                         const int64_t* feats_index, const float* extra, int64_t extra_stride, int32_t e_cols, float extra_div,
-                         const float* f_cluster, int64_t f_cluster_stride, int32_t r_cols, float rel_div, const float* w1,
+                         const int64_t* feats_index, int32_t direct_parts_mask, const float* extra, int64_t extra_stride, int32_t e_cols,
+                         float extra_div, const float* f_cluster, int64_t f_cluster_stride, int32_t r_cols, float rel_div, const float* w1,
                          const float* g1, const float* b1, int32_t h1, const float* w2, const float* g2, const float* b2, int32_t h2,
                          const float* w3, const float* g3, const float* b3, float eps, int32_t act, int64_t n, float* out,
                          int64_t out_stride, void* stream);

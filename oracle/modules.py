@@ -330,18 +330,30 @@ def connected_components_xy(points, dist):
     return torch.from_numpy(connected_components(adj, directed=False)[1]).int()
 
 
-def fsf_stage3(fsf, s1):
-    """FSF.fsd_forward without the head (FSF.py:569-600): pre_voxelize, group_sample, ClusterAssigner, SIR."""
+def fsf_stage3(fsf, s1, record=None, replay=None):
+    """FSF.fsd_forward without the head (FSF.py:569-600): pre_voxelize, group_sample, ClusterAssigner, SIR.
+
+    `record` (a dict) receives every INTEGER / boolean decision of the stage — the pre-voxelization cells, per class group the
+    foreground mask, the arg-max tie weights of the vote, the density-filter mask, the cluster-voxel map and the component labels.
+    `replay` (such a dict) takes them from there instead of deriving them: the float64 arbitration chain of
+    tests/test_e2e_agreement_gpu.py runs the stage's ARITHMETIC in float64 on the integer structure the fp32 chain decided (a float64
+    threshold test or floor would move a handful of borderline points between cells / clusters and the two chains would no longer
+    describe the same groups)."""
     from . import voxelize as ovox
 
     cfg = fsf.cfg
     d = dict(seg_points=s1["seg_points"], seg_logits=s1["seg_logits"], seg_vote_preds=s1["seg_vote_preds"],
              seg_feats=s1["seg_feats"], batch_idx=s1["batch_idx"], vote_offsets=s1["offsets"])
     rng = fsf.cluster_assigner.point_cloud_range
-    coors = torch.from_numpy(ovox.divfloor_coors(d["seg_points"][:, :3].numpy(), cfg["pre_voxelization_size"], rng[:3],
-                                                 "zyx", d["batch_idx"].numpy()))
-    new_coors, inv = torch.unique(coors, return_inverse=True, dim=0)
-    vox = {k: oscatter.segment_mean(v, inv, new_coors.size(0)) for k, v in d.items() if v.dtype == torch.float32}
+    if replay is not None:
+        new_coors, inv = replay["pre_new_coors"], replay["pre_inv"]
+    else:
+        coors = torch.from_numpy(ovox.divfloor_coors(d["seg_points"][:, :3].numpy(), cfg["pre_voxelization_size"], rng[:3],
+                                                     "zyx", d["batch_idx"].numpy()))
+        new_coors, inv = torch.unique(coors, return_inverse=True, dim=0)
+    if record is not None:
+        record.update(pre_new_coors=new_coors, pre_inv=inv, groups=[])
+    vox = {k: oscatter.segment_mean(v, inv, new_coors.size(0)) for k, v in d.items() if v.is_floating_point()}
     vox["batch_idx"] = new_coors[:, 0]
     seg_logits = vox["seg_logits"]
     scores = seg_logits.softmax(1)
@@ -350,23 +362,33 @@ def fsf_stage3(fsf, s1):
     pts_all, feats_all, inds_all, centers_all = [], [], [], []
     for gi, group in enumerate(cfg["group_names"]):
         idx = [names.index(n) for n in group]
-        fg = scores[:, idx].sum(1) > cfg["score_thresh"][gi]
-        if fg.sum() == 0:
-            fg[0] = True
-        lg = seg_logits[:, idx][fg]
-        wgt = ((lg - lg.max(1)[0][:, None]).abs() < 1e-6).float()
-        wgt = wgt / wgt.sum(1)[:, None]
+        rp = replay["groups"][gi] if replay is not None else None
+        if rp is not None:
+            fg, wgt = rp["fg"], rp["wgt"].to(seg_logits.dtype)
+        else:
+            fg = scores[:, idx].sum(1) > cfg["score_thresh"][gi]
+            if fg.sum() == 0:
+                fg[0] = True
+            lg = seg_logits[:, idx][fg]
+            wgt = ((lg - lg.max(1)[0][:, None]).abs() < 1e-6).float()
+            wgt = wgt / wgt.sum(1)[:, None]
         centers = vox["seg_points"][fg, :3] + (offset[:, idx, :][fg] * wgt[:, :, None]).sum(1)
         vs = fsf.cluster_assigner.cluster_voxel_size[gi]
         bidx = vox["batch_idx"][fg].int()
-        cc = torch.from_numpy(ovox.divfloor_coors(centers.numpy(), vs, rng[:3], "xyz", bidx.numpy())).int()
-        _, cinv, ccnt = torch.unique(cc, return_inverse=True, return_counts=True, dim=0)
-        valid = ccnt[cinv] >= fsf.cluster_assigner.min_points
-        if not valid.any():
-            valid = ~valid
-        cpts, cco = centers[valid], cc[valid]
-        vc, vcoors, vinv = oscatter.scatter_v2(cpts, cco, "avg")
-        comp = connected_components_xy(vc, fsf.cluster_assigner.connected_dist[gi])
+        if rp is not None:
+            valid, vinv, comp = rp["valid"], rp["vinv"], rp["comp"]
+            cpts = centers[valid]
+        else:
+            cc = torch.from_numpy(ovox.divfloor_coors(centers.numpy(), vs, rng[:3], "xyz", bidx.numpy())).int()
+            _, cinv, ccnt = torch.unique(cc, return_inverse=True, return_counts=True, dim=0)
+            valid = ccnt[cinv] >= fsf.cluster_assigner.min_points
+            if not valid.any():
+                valid = ~valid
+            cpts, cco = centers[valid], cc[valid]
+            vc, vcoors, vinv = oscatter.scatter_v2(cpts, cco, "avg")
+            comp = connected_components_xy(vc, fsf.cluster_assigner.connected_dist[gi])
+        if record is not None:
+            record["groups"].append(dict(fg=fg, wgt=wgt, valid=valid, vinv=vinv, comp=comp))
         per_pt = comp[vinv]
         inds_all.append(torch.stack([torch.full_like(per_pt, gi), bidx[valid], per_pt], 1))
         pts_all.append(vox["seg_points"][fg][valid])
@@ -556,7 +578,8 @@ def simple_test(fsf, points8, mask_data, mask_anno, lidar2img, i_stage=0):
     img_hw = tuple(mask_data.shape[-2:])
     s1 = fsf_stage1(fsf, points8, mask_data, mask_anno, lidar2img)
     s2 = fsf_stage2(fsf, s1, mask_anno, img_hw)
-    s3 = fsf_stage3(fsf, s1)
+    s3_record = {}
+    s3 = fsf_stage3(fsf, s1, record=s3_record)
     f_res = cluster_head_forward(fsf.frustum_obj_head, s2["obj_feat"])
     l_res = cluster_head_forward(fsf.bbox_head, s3["cluster_feats"])
     centers, coors, result, feats, p2d = combine_frustum_and_fsd(
@@ -572,6 +595,6 @@ def simple_test(fsf, points8, mask_data, mask_anno, lidar2img, i_stage=0):
     res, query = refined_query(fsf, i_stage, lidar_img, feats, rois[:, 1:4])
     cfg = fsf.frustum_refined_head[i_stage].test_cfg
     rows, scs, labs, boxes, margin = get_bboxes_single(cfg, res["cls_logits"][0], res["reg_preds"][0], rois[:, 1:4])
-    return dict(boxes=boxes[rows], scores=scs, labels=labs, rows=rows, margin=margin, s1=s1, s2=s2, s3=s3,
+    return dict(boxes=boxes[rows], scores=scs, labels=labs, rows=rows, margin=margin, s1=s1, s2=s2, s3=s3, s3_decisions=s3_record,
                 query_coors=coors, query_feats=feats, rois=rois, refined_query=query, cls_logits=res["cls_logits"][0],
                 reg_preds=res["reg_preds"][0], all_boxes=boxes)

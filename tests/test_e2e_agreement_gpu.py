@@ -126,6 +126,9 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
         cpu64 = copy.deepcopy(cpu).double()
         s1_64 = omod.fsf_stage1(cpu64, pts8, mask, anno, L, dtype=torch.float64)
         s2_64 = omod.fsf_stage2(cpu64, s1_64, anno, tuple(mask.shape[-2:]))
+        # ... and the LiDAR stack (round 6): stage 3's arithmetic in float64 on the integer structure the fp32 chain decided
+        # (pre-voxel cells, foreground masks, density filter, components: oracle/modules.py::fsf_stage3 `replay`)
+        s3_64 = omod.fsf_stage3(cpu64, s1_64, replay=o["s3_decisions"])
         del cpu64
     monkeypatch.undo()
     gb, gs, gl = (res[0][k] for k in ("boxes_3d", "scores_3d", "labels_3d"))
@@ -142,6 +145,10 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
     cam_gpu64 = _feature_deviation(c(f_feats)[:, :768], c(f_coors), s2_64["obj_feat"][:, :768].numpy(), s2_64["obj_coors"].numpy())
     cam_o32_64 = _feature_deviation(o["s2"]["obj_feat"][:, :768].numpy(), o["s2"]["obj_coors"].numpy(),
                                     s2_64["obj_feat"][:, :768].numpy(), s2_64["obj_coors"].numpy())
+    assert np.array_equal(s3_64["cluster_inds"].numpy(), o["s3"]["cluster_inds"].numpy()), "the float64 chain changed the LiDAR-query keys"
+    lid_gpu64 = _feature_deviation(c(l_feats), c(l_coors), s3_64["cluster_feats"].numpy(), s3_64["cluster_inds"].numpy())
+    lid_o32_64 = _feature_deviation(o["s3"]["cluster_feats"].numpy(), o["s3"]["cluster_inds"].numpy(),
+                                    s3_64["cluster_feats"].numpy(), s3_64["cluster_inds"].numpy())
     report = dict(
         frame=which, points=int(pts8.shape[0]), gpu_boxes=int(gb.shape[0]), oracle_boxes=int(ob.shape[0]),
         matched=int(len(pairs)), matched_iou99_dscore1e3=int(good.sum()),
@@ -152,7 +159,8 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
                             keys_identical=bool(np.array_equal(c(f_coors), o["s2"]["obj_coors"].numpy())), sir_feature_dev=cam,
                             sir_feature_dev_gpu_vs_float64=cam_gpu64, sir_feature_dev_oracle32_vs_float64=cam_o32_64),
         lidar_queries=dict(gpu=int(l_coors.shape[0]), oracle=int(o["s3"]["cluster_inds"].shape[0]),
-                           keys_identical=bool(np.array_equal(c(l_coors), o["s3"]["cluster_inds"].numpy())), sir_feature_dev=lid),
+                           keys_identical=bool(np.array_equal(c(l_coors), o["s3"]["cluster_inds"].numpy())), sir_feature_dev=lid,
+                           sir_feature_dev_gpu_vs_float64=lid_gpu64, sir_feature_dev_oracle32_vs_float64=lid_o32_64),
         oracle_nms_margin=float(o["margin"]))
     print("\nE2E agreement:", json.dumps(report, indent=1))
     out_dir = os.path.join(ROOT, "gpurun_out")
@@ -170,7 +178,14 @@ def test_unrestarted_gpu_frame_vs_unrestarted_oracle(which, request, device, mon
     # per-kernel bound) — at the 99.9th percentile, at the median and at the maximum
     for q in ("median", "p999", "max"):
         assert cam_gpu64[q] <= E2E_F64_RATIO * cam_o32_64[q] + E2E_F64_FLOOR, (q, cam_gpu64, cam_o32_64)
+        assert lid_gpu64[q] <= E2E_F64_RATIO * lid_o32_64[q] + E2E_F64_FLOOR, (q, lid_gpu64, lid_o32_64)
     assert cam_gpu64["p999"] <= E2E_MAX_CAMERA_SIR_DEV_VS_F64_P999, report
+    assert lid_gpu64["p999"] <= E2E_MAX_LIDAR_SIR_DEV_VS_F64_P999, report
+    # north_star's "fp features within 1e-4", stated for what it can mean end to end: the device's distance to exact arithmetic is at
+    # most 1e-4 of the feature scale beyond the conditioning term — the distance an fp32 evaluation of the REFERENCE's own arithmetic
+    # (the oracle chain) shows to the same float64 chain on the same frame
+    assert cam_gpu64["p999"] <= E2E_CONTRACT + cam_o32_64["p999"], (cam_gpu64, cam_o32_64)
+    assert lid_gpu64["p999"] <= E2E_CONTRACT + lid_o32_64["p999"], (lid_gpu64, lid_o32_64)
 
 
 # Thresholds: measured first (round 4, MI355X, gpurun_out/e2e_agreement_*.json -> DESIGN.md section 3), then frozen with margin.
@@ -187,5 +202,11 @@ E2E_MAX_CAMERA_SIR_DEV_P999 = 2e-2   # vs the fp32 ORACLE chain — whose own di
 # 60 x closer on the large ones (its centroids and LayerNorm statistics are accumulated in blocked / pairwise order).
 E2E_F64_RATIO = 3.0                  # |gpu - float64 chain| <= ratio x |fp32 oracle - float64 chain| + floor
 E2E_F64_FLOOR = 1e-5
-E2E_MAX_CAMERA_SIR_DEV_VS_F64_P999 = 5e-4   # (40 x tighter than the bound against the fp32 oracle)
-E2E_MAX_LIDAR_SIR_DEV_P999 = 2e-3
+E2E_MAX_CAMERA_SIR_DEV_VS_F64_P999 = 4e-4   # <= 2 x the largest measured (1.8e-4: the 1-sweep frame, where the fp32 ORACLE sits the same 1.8e-4
+#                                             from float64 — groups of one to three points put f_cluster at ~0 in front of three LayerNorm(eps=1e-3))
+# Round 6: the LiDAR stack arbitrated the same way (stage 3 in float64 on the fp32 chain's integer structure).  Measured on MI355X
+# (profiles/r6_e2e_agreement_*.json), 99.9th percentile: device vs the fp32 oracle 3.2e-4 / 3.4e-4 / (AV2) — of which the ORACLE's own
+# distance to float64 is 3.4e-4 (1 sweep, CPU-side number); the device-vs-float64 figures are in the profiles and bounded here at 2 x.
+E2E_MAX_LIDAR_SIR_DEV_P999 = 7e-4            # vs the fp32 oracle chain (was 2e-3): <= 2 x the measured 3.4e-4
+E2E_MAX_LIDAR_SIR_DEV_VS_F64_P999 = 4e-4     # vs the float64 chain: provisional until measured (set to <= 2 x the measurement)
+E2E_CONTRACT = 1e-4                          # north_star's feature tolerance, beyond the frame's fp32 conditioning term

@@ -171,3 +171,29 @@ def test_detector_glue_branches_equal_their_generic_forms(device):
         la, ca, ka = model.get_cluster_delta_weighted(points, coors, w)
     lb, cb, kb = model.get_cluster_delta_weighted(points, coors, w)
     assert torch.equal(ca, cb) and torch.equal(ka, kb) and torch.equal(la.materialize(), lb)
+
+
+@pytest.mark.parametrize("n,act", [(37, "gelu"), (25000, "gelu"), (4001, "relu")])
+def test_sir_input_direct_part_equals_the_materialised_concat(device, n, act):
+    """fsf_sir_input_gather's direct_parts_mask (round 6): part 0 through the pooling index, part 1 as it stands — the refine stage's
+    `cat([pts_feat[ext_pts_inds], pts_img_feat], -1)` (FSF.py:961-1010) never written — against the same kernel on the concatenation."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops.sst_ops import GatheredRows
+
+    torch.manual_seed(n)
+    P = 30000
+    wide = torch.randn(P, 132, device=device)
+    feats = wide[:, :131]
+    img = torch.randn(n, 32, device=device)
+    idx = torch.randint(0, P, (n,), device=device)
+    points, fcl, extra = torch.randn(n, 5, device=device), torch.randn(n, 13, device=device), torch.randn(n, 13, device=device)
+    c = 5 + 131 + 32 + 13
+    dims = [13, 16, 32, c]
+    layers = [(torch.randn(dims[i + 1], dims[i], device=device) / dims[i] ** 0.5, torch.rand(dims[i + 1], device=device) + 0.5,
+               torch.randn(dims[i + 1], device=device) * 0.1) for i in range(3)]
+    norm = [20.0, 20.0, 4.0]
+    mat = torch.cat([feats[idx], img], 1).contiguous()
+    want = hip_ops.sir_input(points, mat, fcl, norm, (*layers, 1e-3), act, 10.0, extra=extra, extra_div=10.0)
+    got = hip_ops.sir_input(points, [feats, img], fcl, norm, (*layers, 1e-3), act, 10.0, extra=extra, extra_div=10.0, feats_index=idx,
+                            direct_parts=(1,))
+    assert torch.equal(got, want)
+    assert torch.equal(GatheredRows([feats, img], idx, direct=(1,)).materialize(), mat)
