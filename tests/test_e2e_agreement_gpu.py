@@ -202,11 +202,15 @@ E2E_MAX_CAMERA_SIR_DEV_P999 = 2e-2   # vs the fp32 ORACLE chain — whose own di
 # 60 x closer on the large ones (its centroids and LayerNorm statistics are accumulated in blocked / pairwise order).
 E2E_F64_RATIO = 3.0                  # |gpu - float64 chain| <= ratio x |fp32 oracle - float64 chain| + floor
 E2E_F64_FLOOR = 1e-5
-E2E_MAX_CAMERA_SIR_DEV_VS_F64_P999 = 4e-4   # <= 2 x the largest measured (1.8e-4: the 1-sweep frame, where the fp32 ORACLE sits the same 1.8e-4
+E2E_MAX_CAMERA_SIR_DEV_VS_F64_P999 = 3.6e-4  # = 2 x the largest measured (1.8e-4: the 1-sweep frame, where the fp32 ORACLE sits the same 1.8e-4
 #                                             from float64 — groups of one to three points put f_cluster at ~0 in front of three LayerNorm(eps=1e-3))
 # Round 6: the LiDAR stack arbitrated the same way (stage 3 in float64 on the fp32 chain's integer structure).  Measured on MI355X
-# (profiles/r6_e2e_agreement_*.json), 99.9th percentile: device vs the fp32 oracle 3.2e-4 / 3.4e-4 / (AV2) — of which the ORACLE's own
-# distance to float64 is 3.4e-4 (1 sweep, CPU-side number); the device-vs-float64 figures are in the profiles and bounded here at 2 x.
+# (profiles/r6_e2e_agreement_*.json; 1 sweep / 10 sweeps / AV2), 99.9th percentile of the row maximum relative to the feature scale:
+#   device vs the fp32 oracle chain   3.2e-4 / 3.4e-4 / 2.5e-5
+#   device vs the float64 chain       3.3e-4 / 3.8e-4 / 2.3e-4
+#   fp32 ORACLE vs the float64 chain  3.4e-4 / 5.1e-4 / 2.3e-4   <- the frame's conditioning term: what ANY fp32 evaluation of the reference's
+# arithmetic shows on these clusters (centroid rounding amplified by the position MLP's LayerNorms).  The device is never farther from
+# float64 than the fp32 oracle is; the 1e-4 contract is asserted beyond that term.
 E2E_MAX_LIDAR_SIR_DEV_P999 = 7e-4            # vs the fp32 oracle chain (was 2e-3): <= 2 x the measured 3.4e-4
-E2E_MAX_LIDAR_SIR_DEV_VS_F64_P999 = 4e-4     # vs the float64 chain: provisional until measured (set to <= 2 x the measurement)
+E2E_MAX_LIDAR_SIR_DEV_VS_F64_P999 = 7.5e-4   # vs the float64 chain: <= 2 x the measured 3.8e-4
 E2E_CONTRACT = 1e-4                          # north_star's feature tolerance, beyond the frame's fp32 conditioning term
