@@ -558,7 +558,9 @@ extern "C" int fsf_norm_act_backward(const float* x, const float* grad_out, int6
   hipStream_t stream = (hipStream_t)stream_;
   if (n < 0 || c < 1 || act < 0 || act > 2 || (n > 0 && (!x || !grad_out || !grad_x)) || ((gamma == nullptr) != (beta == nullptr)))
     return FSF_ERR_INVALID_ARG;
-  if (c > 64 * NA_MAX_PER_LANE) return FSF_ERR_UNSUPPORTED;
+  const bool v4_ok = na_v4_enabled() && (c % 4) == 0 && (((uintptr_t)x | (uintptr_t)grad_out | (uintptr_t)grad_x) % 16) == 0 &&
+                     (!gamma || (((uintptr_t)gamma | (uintptr_t)beta) % 16) == 0);
+  if (c > 64 * 16 || (c > 64 * NA_MAX_PER_LANE && !v4_ok)) return FSF_ERR_UNSUPPORTED;  // (513 .. 1024 channels: the float4 form only)
   if (workspace_bytes < fsf_norm_act_backward_workspace_bytes(c) || !workspace) return FSF_ERR_WORKSPACE;
   float* part = (float*)workspace;
   if (n == 0) {
@@ -566,13 +568,14 @@ extern "C" int fsf_norm_act_backward(const float* x, const float* grad_out, int6
     if (grad_beta) FSF_HIP_TRY(hipMemsetAsync(grad_beta, 0, sizeof(float) * c, stream));
     return FSF_OK;
   }
-  if (na_v4_enabled() && (c % 4) == 0 && (((uintptr_t)x | (uintptr_t)grad_out | (uintptr_t)grad_x) % 16) == 0 &&
-      (!gamma || (((uintptr_t)gamma | (uintptr_t)beta) % 16) == 0)) {
+  if (v4_ok) {
     const int c4 = c / 4;
     if (c4 <= 16) return launch_norm_act_bwd_v4<16, 1, 2>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
     if (c4 <= 32) return launch_norm_act_bwd_v4<32, 1, 2>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
     if (c4 <= 64) return launch_norm_act_bwd_v4<64, 1, 1>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
-    return launch_norm_act_bwd_v4<64, 2, 1>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
+    if (c4 <= 128) return launch_norm_act_bwd_v4<64, 2, 1>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
+    // the 1024-wide LayerNorm + GELU of the query / refine heads (round 6: torch's layer_norm backward + a GELU backward pass before)
+    return launch_norm_act_bwd_v4<64, 4, 1>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);
   }
   if (c <= 16 * NA_MAX_PER_LANE / 2)
     return launch_norm_act_bwd<16>(x, grad_out, n, c, gamma, beta, eps, act, grad_x, grad_gamma, grad_beta, part, stream);

@@ -1170,6 +1170,14 @@ class RowPlanes:
     def __init__(self, data, inv_scales, n, c):
         self.data, self.inv_scales, self.n, self.c = data, inv_scales, int(n), int(c)
 
+    def rows(self):
+        """The matrix back as f32 [n, c]: (hi + lo) * inv_scale, exact (the two halves do not overlap, the scale is a power of two) —
+        i.e. the 22-bit rounding of the values the planes were made from.  For a consumer that is not a wide Linear (a
+        head whose first layer does not take planes used to raise here); never on the built paths."""
+        n, c = self.n, self.c
+        d = self.data[: n * c * 4].view(torch.float16).view(n, c // 8, 2, 8).to(torch.float32)
+        return (d[:, :, 0, :] + d[:, :, 1, :]).reshape(n, c) * self.inv_scales[:n, None]
+
 
 def rows_to_planes_supported(x: torch.Tensor) -> bool:
     return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.size(1) % 8 == 0 and 8 <= x.size(1) <= 2048

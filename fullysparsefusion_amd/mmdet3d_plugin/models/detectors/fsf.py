@@ -794,6 +794,7 @@ class FSF(SingleStageFSD):
     def forward_train(self, points, img_metas, *args, mask_data=None, mask_anno=None, **kwargs):
         """`forward_train` (:806-903): the graph is `forward_train_graph`; the `.loss(...)` calls that close it upstream (label
         assignment on the host, focal / L1 losses) are outside the built path and the heads' `loss` says so."""
-        out = self.forward_train_graph(points, img_metas, mask_data, mask_anno)
-        self.frustum_obj_head.loss(out["frustum_obj_result"]["cls_logits"], out["frustum_obj_result"]["reg_preds"])  # raises
-        return out
+        # (ADVICE r5: this used to run the whole graph and only then raise through `head.loss`)
+        raise NotImplementedError(
+            "FSF.forward_train: target assignment and the losses (`*.loss(...)`, FSF.py:806-903) are host-side code outside the built "
+            "path; `forward_train_graph(points, img_metas, mask_data, mask_anno)` returns every tensor they would consume")

@@ -528,7 +528,8 @@ def fused_norm_act(x, norm, act, out=None):
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in norm.parameters()))
     fusable = act_code is not None and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(1) <= 1024
     if (fusable and needs_grad and out is None and isinstance(norm, nn.LayerNorm) and len(norm.normalized_shape) == 1
-            and norm.elementwise_affine and x.size(0) > 0 and x.size(1) <= 512):
+            and norm.elementwise_affine and x.size(0) > 0
+            and (x.size(1) <= 512 or (x.size(1) <= 1024 and x.size(1) % 4 == 0))):
         return _NormActFn.apply(x, norm.weight, norm.bias, norm.eps, act_code)  # training: fused forward AND backward (K12)
     if fusable and not needs_grad:
         x = x.contiguous()
@@ -728,9 +729,11 @@ def _wide_linear_norm_act(linear, norm, act, x, out=None, planes_out=False):
 
 
 def materialize_rows(x):
-    """RowPlanes reached a consumer that wants fp32 rows (never on the built paths: producers only emit planes for a wide consumer)."""
+    """RowPlanes reached a consumer that wants fp32 rows (not on the built paths: producers only emit planes for a wide consumer —
+    but a head whose first layer has another shape, or a switch flipped between producer and consumer, lands here): the rows back
+    from the planes, `RowPlanes.rows()`."""
     if isinstance(x, hip_ops.RowPlanes):
-        raise hip_ops.FsfHipError("RowPlanes handed to a layer that is not a wide Linear")
+        return x.rows()
     return x
 
 

@@ -197,3 +197,20 @@ def test_sir_input_direct_part_equals_the_materialised_concat(device, n, act):
                             direct_parts=(1,))
     assert torch.equal(got, want)
     assert torch.equal(GatheredRows([feats, img], idx, direct=(1,)).materialize(), mat)
+
+
+def test_row_planes_fall_back_to_rows_for_a_consumer_that_is_not_a_wide_linear(device):
+    """planes handed to a layer K22h does not cover (a head whose first layer has another shape) used to raise; now the rows
+    come back from the planes — (hi + lo) * inv_scale, the 22-bit rounding of the source relative to its row maximum."""
+    from fullysparsefusion_amd.mmdet3d_plugin.ops import sst_ops
+
+    torch.manual_seed(3)
+    x = torch.randn(3000, 256, device=device) * torch.logspace(-6, 6, 3000, device=device)[:, None]
+    rp = hip_ops.rows_to_planes(x)
+    back = rp.rows()
+    assert back.shape == x.shape and float(((back - x).abs() / x.abs().amax(1, keepdim=True)).max()) <= 2.0 ** -21
+    lin = torch.nn.Linear(256, 12).to(device)  # 12 outputs: not a wide layer
+    with torch.no_grad():
+        got = sst_ops.point_linear(lin, rp)
+        want = torch.nn.functional.linear(back, lin.weight, lin.bias)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
