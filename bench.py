@@ -290,7 +290,7 @@ def count_launch_sources(model, inp, hot_path_only=False):
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir) if os.path.isdir(pdir) else [], reverse=True):
         if name.endswith("_kernel_stats_full_forward.txt"):
-            m = re.search(r"(\d+) launches/frame", open(os.path.join(pdir, name)).read(400))
+            m = re.search(r"(\d+) launches/frame", open(os.path.join(pdir, name)).read(1500))
             if m:
                 traced = dict(value=int(m.group(1)), source=f"profiles/{name}")
                 break

@@ -675,6 +675,13 @@ struct SpPipeSmem {
 #ifndef SP_PIPE_WPS
 #define SP_PIPE_WPS 3
 #endif
+// (experiment, off: -DSP_PIPE_DENSE treats every cell of a live offset as live — dead cells multiply the zero row — so that the
+// four cells of an iteration are one basic block; tools/profiling/k9d_shape_probe.hip says what the branch-free shape could reach)
+#ifdef SP_PIPE_DENSE
+#define SP_PIPE_LIVE(mask, g) (true)
+#else
+#define SP_PIPE_LIVE(mask, g) (((mask) >> (g)) & 1u)
+#endif
 template <int TPW, int NKC>
 __global__ void __launch_bounds__(256, SP_PIPE_WPS) spconv_fwd_pipe_kernel(SpArgs a) {
   using S = SpPipeSmem<TPW>;
@@ -796,7 +803,7 @@ __global__ void __launch_bounds__(256, SP_PIPE_WPS) spconv_fwd_pipe_kernel(SpArg
 #ifdef PD_ABL_NO_LDS_WRITE
     return;
 #endif
-    if ((st.mask >> wave) & 1u) {
+    if SP_PIPE_LIVE(st.mask, wave) {
       uint4* dst = xring + (slot * RG + wave) * 128;
       dst[wr_a] = va;
       dst[wr_b] = vb;
@@ -881,7 +888,7 @@ __global__ void __launch_bounds__(256, SP_PIPE_WPS) spconv_fwd_pipe_kernel(SpArg
   __syncthreads();
 #pragma unroll
   for (int g = 0; g < RG; ++g)
-    if ((r0.mask >> g) & 1u) read_cell(0, g, xh[g], xl[g]);
+    if SP_PIPE_LIVE(r0.mask, g) read_cell(0, g, xh[g], xl[g]);
 
   // one iteration: chunk KC of the step r0; ODD = parity of that step (which half of sring, and for NKC == 2 which pair of slots)
   auto iteration = [&](auto kc_tag, auto odd_tag) {
@@ -908,18 +915,18 @@ __global__ void __launch_bounds__(256, SP_PIPE_WPS) spconv_fwd_pipe_kernel(SpArg
     if (KC == 0) {
 #pragma unroll
       for (int g = 0; g < RG; ++g)
-        if ((st.mask >> g) & 1u) inv[g] = sring[(ODD * RG + g) * 16 + j];
+        if SP_PIPE_LIVE(st.mask, g) inv[g] = sring[(ODD * RG + g) * 16 + j];
     }
     // multiply chunk KC; each cell's fragment registers take chunk KC + 1 as soon as its MFMAs are issued
 #pragma unroll
     for (int g = 0; g < RG; ++g) {
-      if ((st.mask >> g) & 1u) mma_cell(KC == 0, g, xh[g], xl[g], (KC % 2 == 0) ? wA : wB);
-      if ((st1.mask >> g) & 1u) read_cell((I + 1) % 4, g, xh[g], xl[g]);
+      if SP_PIPE_LIVE(st.mask, g) mma_cell(KC == 0, g, xh[g], xl[g], (KC % 2 == 0) ? wA : wB);
+      if SP_PIPE_LIVE(st1.mask, g) read_cell((I + 1) % 4, g, xh[g], xl[g]);
     }
     if (KC == NKC - 1) {  // fold the step: this lane's row scale in every live cell
 #pragma unroll
       for (int g = 0; g < RG; ++g) {
-        if ((st.mask >> g) & 1u) {
+        if SP_PIPE_LIVE(st.mask, g) {
           const float sc = __fmul_rn(inv[g], w_inv);
 #pragma unroll
           for (int t = 0; t < TPW; ++t)

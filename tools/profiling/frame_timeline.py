@@ -5,6 +5,10 @@ db = sqlite3.connect(sys.argv[1]); frames = int(sys.argv[2])
 rows = db.cursor().execute("select name, start, end, queue_id, grid_x, workgroup_x from kernels order by start").fetchall()
 per = len(rows) // frames
 last = rows[len(rows) - per:]
+marks = [i for i, r in enumerate(rows) if 'bt_select_kernel' in r[0]]
+if len(marks) >= 2:  # the full forward: a frame = what lies between two box-tail selection kernels (round 6; was: an equal share of ALL
+    last = rows[marks[-2] + 1:marks[-1] + 1]  # dispatches of the process, start-up included)
+    per = len(last)
 t0 = last[0][1]
 prev_end = {}
 busy = collections.Counter(); gaps = collections.Counter(); n = collections.Counter()
