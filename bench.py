@@ -29,6 +29,7 @@ import argparse
 import copy
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -794,6 +795,24 @@ SPCONV_KERNELS = {
 }
 
 
+def shape_ceiling(achieved_tflops, dom_key):
+    """What the dominant kernel's SHAPE reaches with the sparse-convolution specifics removed (tools/profiling/k9d_shape_probe.hip: the
+    same per-iteration loads, LDS round trip and MFMAs at the same occupancy, every cell live) — from the newest committed probe run.
+    `frac` stays priced against the pipe's peak; this says how much of the gap is the shape's and how much the kernel's."""
+    if dom_key != "spconv_planes":
+        return None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir) if os.path.isdir(pdir) else [], reverse=True):
+        if name.endswith("_k9d_shape_ceiling_probe.txt"):
+            m = re.search(r"^full shape.*?=\s*([0-9.]+) fp32-eq = ([0-9.]+) of 833", open(os.path.join(pdir, name)).read(), flags=re.M)
+            if m:
+                tf = float(m.group(1))
+                return dict(tflops_fp32_equivalent=tf, frac_of_pipe_peak=float(m.group(2)), kernel_frac_of_shape=round(achieved_tflops / tf, 4),
+                            source=f"profiles/{name}",
+                            note="gather -> LDS -> MFMA pipeline of K9d, three workgroups per CU, all cells live, no table / scales / epilogue")
+    return None
+
+
 def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic_of):
     """`roofline` (dominant kernel = the sparse-conv forward kernel with the most time), `hbm` and `frame_roofline_ms`."""
     kernels = {}
@@ -846,6 +865,7 @@ def roofline_blocks(conv, hbm_table, steps, ms_per_step, traffic_of):
                                      algorithmic_gflop_per_step=round(all_flops / steps / 1e9, 1)),
         kernels=kernels, traffic=traffic.get("value"), traffic_unit=traffic.get("unit"), traffic_source=traffic.get("source"),
         traffic_kernel=traffic.get("kernel"),
+        shape_ceiling=shape_ceiling(achieved, dom_key),
         hbm_in_situ=in_situ,
         debug=dict(hbm_isolated_replay=hbm,
                    note="cache-warm isolated replay of one frame's calls (4 launches back to back per call): an upper bound of what each "
