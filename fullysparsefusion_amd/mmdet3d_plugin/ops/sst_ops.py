@@ -435,32 +435,51 @@ def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, n
 
 def scatter_mean_multi(feats, new_coors, unq_inv):
     """The mean of several per-point tensors over ONE short-segment plan (pre_voxelize: every float field of the point dict
-    over the same 0.1 m voxels) — at inference a single launch; otherwise one scatter_v2 per tensor."""
+    over the same 0.1 m voxels) — at inference two launches at most; otherwise one scatter_v2 per tensor."""
     plan = plan_of(unq_inv, new_coors.size(0))
     feats = [f.float() for f in feats]
     if (1 <= len(feats) <= 8 and all(f.is_cuda and f.dim() == 2 for f in feats)
             and not (torch.is_grad_enabled() and any(f.requires_grad for f in feats))):
-        # Tensors whose rows sit in 16-byte-aligned, padded storage (the 131-column point features in their 132-float rows) are
-        # reduced as their padded width with float4 lanes — the pad column's mean is computed and dropped — in one launch, the
-        # odd-width rest in another; four-byte lanes over all 213 columns took 324 us on the 0.1 m voxels of the 10-sweep frame.
-        def padded_view(f):
-            c4 = (f.size(1) + 3) // 4 * 4
-            if (f.size(1) >= 64 and f.stride(1) == 1 and f.size(0) > 1 and f.stride(0) % 4 == 0 and f.stride(0) >= c4
-                    and f.data_ptr() % 16 == 0):
-                return f.as_strided((f.size(0), c4), (f.stride(0), 1))
-            return None
+        # Everything that can be read with float4 lanes goes into one launch: tensors whose rows sit in 16-byte-aligned storage padded
+        # to a multiple of four floats (the 131-column point features in their 132-float rows, the 33 vote offsets in 36: the pad
+        # column's mean is computed and dropped), and column blocks that stand side by side in one buffer (the segmentation head's
+        # logits | vote predictions = the [n, 11 + 33] result of its one stacked launch) as that buffer.  The odd-width rest (the 5-column
+        # points) takes the four-byte lanes.  Four-byte lanes over all 213 columns took 324 us on the 0.1 m voxels of the 10-sweep frame;
+        # round 5's split (only >= 64-wide tensors on float4 lanes) left 82 columns = 139 us on them, this one 5.
+        def aligned(f, c):
+            return (f.stride(1) == 1 and f.size(0) > 1 and f.stride(0) % 4 == 0 and f.stride(0) >= c and f.data_ptr() % 16 == 0)
 
-        wide = [(i, padded_view(f)) for i, f in enumerate(feats)]
-        wide = [(i, v) for i, v in wide if v is not None]
-        if wide and len(wide) < len(feats):
-            out = [None] * len(feats)
-            for (i, _), o in zip(wide, hip_ops.segment_reduce_short([v for _, v in wide], plan, "mean")):
-                out[i] = o[:, :feats[i].size(1)]
-            rest = [i for i in range(len(feats)) if out[i] is None]
+        groups = []  # (view to reduce, [(index into feats, first column, width)])
+        used = [False] * len(feats)
+        for i, f in enumerate(feats):
+            if used[i]:
+                continue
+            members, end = [(i, 0, f.size(1))], f.size(1)
+            if f.stride(1) == 1 and f.size(0) > 1:
+                grown = True
+                while grown:  # column blocks of the same rows that follow this one directly
+                    grown = False
+                    for j, g in enumerate(feats):
+                        if (not used[j] and j != i and all(j != m[0] for m in members) and g.stride(1) == 1 and g.stride(0) == f.stride(0)
+                                and g.size(0) == f.size(0) and g.data_ptr() == f.data_ptr() + 4 * end and end + g.size(1) <= f.stride(0)):
+                            members.append((j, end, g.size(1)))
+                            end += g.size(1)
+                            grown = True
+            c4 = (end + 3) // 4 * 4
+            if aligned(f, c4):
+                for m in members:
+                    used[m[0]] = True
+                groups.append((f.as_strided((f.size(0), c4), (f.stride(0), 1)), members))
+        out = [None] * len(feats)
+        if groups:
+            for (view, members), o in zip(groups, hip_ops.segment_reduce_short([v for v, _ in groups], plan, "mean")):
+                for idx, c0, w in members:
+                    out[idx] = o[:, c0:c0 + w]
+        rest = [i for i in range(len(feats)) if out[i] is None]
+        if rest:
             for i, o in zip(rest, hip_ops.segment_reduce_short([feats[i] for i in rest], plan, "mean")):
                 out[i] = o
-            return out
-        return hip_ops.segment_reduce_short(feats, plan, "mean")
+        return out
     return [_SegmentReduce.apply(f, plan, "mean", True) for f in feats]
 
 
