@@ -141,6 +141,9 @@ _ARGTYPES = {
     "fsf_encode_preds_2d": [_P, c_i64, c_i32, _P, c_i64, c_i32, c_f32, c_f32, _P, _P, c_i64, _P],
     "fsf_weighted_xyz": [_P, c_i64, _P, c_i64, c_f32, _P, _P],
     "fsf_centroid_divide": [_P, c_i64, _P, _P],
+    "fsf_lidar_cluster_frontend_arena_bytes": [c_i64, c_i32, c_i32],
+    "fsf_lidar_cluster_frontend": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, _P, c_i32, _P, c_i32, _P, c_i32, c_i32, _P, _P, _P, _P, _P, c_i64, _P,
+                                   _P, c_i64, _P, _P],
 }
 _configured = False
 
@@ -1696,3 +1699,46 @@ def centroid_divide(mean):
     out = torch.empty((mean.size(0), 3), dtype=torch.float32, device=mean.device)
     check(_L().fsf_centroid_divide(ptr(mean), mean.size(0), ptr(out), stream_ptr()), "fsf_centroid_divide")
     return out
+
+
+# ------------------------------------------------------------------- K30: the LiDAR-query clustering front end (csrc/lidar_frontend.hip)
+def lidar_cluster_frontend(scores, thresh, group_cols, logits, offsets, points, batch_idx, num_classes, group_voxel_sizes, range_min,
+                           key_min, key_max, min_points, dist_table):
+    """fsf_lidar_cluster_frontend (one sample): group_sample + ClusterAssigner + the SIR stack's unique + the cluster centroids as ONE
+    native call.  Returns dict(p_ids i64 [V], centers f32 [V, 3], cluster_inds i64 [V, 3], points f32 [V, c], new_coors i64 [C, 3],
+    plan SegmentPlan over cluster_inds, cluster_xyz f32 [C, 3], counts) — views of one arena tensor."""
+    require_cuda(scores, thresh, logits, offsets, points, batch_idx, dist_table)
+    sc, sp, ss = _f32_rows(scores)
+    lg, lp, ls = _f32_rows(logits)
+    of, op, os_ = _f32_rows(offsets)
+    pt, pp, ps = _f32_rows(points)
+    m, ng = sc.size(0), len(group_cols)
+    assert thresh.dtype == torch.float32 and thresh.numel() == ng and dist_table.dtype == torch.float32 and dist_table.numel() == ng
+    assert lg.size(0) == of.size(0) == pt.size(0) == m and all(1 <= len(c) <= 2 for c in group_cols)
+    masks = (ctypes.c_uint32 * ng)(*[sum(1 << int(c) for c in cs) for cs in group_cols])
+    vs = (ctypes.c_float * (3 * ng))(*[float(v) for row in group_voxel_sizes for v in row])
+    if batch_idx is not None:
+        batch_idx = batch_idx.to(torch.int64).contiguous()
+    h = _L()
+    pc = pt.size(1)
+    nbytes = int(h.fsf_lidar_cluster_frontend_arena_bytes(m, ng, pc))
+    arena = torch.empty((nbytes,), dtype=torch.uint8, device=pt.device)
+    assert arena.data_ptr() % 256 == 0
+    out = (ctypes.c_int64 * 16)()
+    check(h.fsf_lidar_cluster_frontend(sp, m, int(num_classes), ss, ptr(thresh.contiguous()), ng, masks, lp, ls, op, os_, pp, ps, pc,
+                                       ptr(batch_idx), vs, f32_array(range_min), i64_array(key_min), i64_array(key_max), int(min_points),
+                                       ptr(dist_table.contiguous()), ptr(arena), nbytes, ctypes.cast(out, c_p), stream_ptr()),
+          "fsf_lidar_cluster_frontend")
+    P, K, Kk, V, C = (int(out[i]) for i in range(5))
+
+    def view(slot, dtype, shape):
+        off, n = int(out[slot]), 1
+        for d in shape:
+            n *= d
+        return arena[off:off + n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(shape)
+
+    inv = view(10, torch.int64, (V,))
+    plan = SegmentPlan(inv=inv, order=view(12, torch.int32, (V,)), seg_offsets=view(13, torch.int32, (C + 1,)), m=C, cnt=view(11, torch.int64, (C,)))
+    return dict(p_ids=view(5, torch.int64, (V,)), centers=view(6, torch.float32, (V, 3)), cluster_inds=view(7, torch.int64, (V, 3)),
+                points=view(8, torch.float32, (V, pc)), new_coors=view(9, torch.int64, (C, 3)), plan=plan,
+                cluster_xyz=view(14, torch.float32, (C, 3)), counts=dict(pairs=P, keys=K, kept_keys=Kk, rows=V, clusters=C))

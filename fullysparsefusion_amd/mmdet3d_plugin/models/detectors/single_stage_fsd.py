@@ -15,8 +15,8 @@ import torch
 from torch import nn
 
 from .... import hip_ops
-from ...ops.sst_ops import (GatheredRows, RowsMinusGroup, gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, unique_with_plan,
-                            with_key_bounds)
+from ...ops.sst_ops import (GatheredRows, RowsMinusGroup, gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, seed_unique_cache,
+                            unique_with_plan, with_key_bounds)
 from ...ops.voxel import Voxelization
 from ...registry import (DETECTORS, SEGMENTORS, build_backbone, build_detector, build_head, build_middle_encoder,
                          build_neck, build_voxel_encoder)
@@ -171,7 +171,12 @@ class SingleStageFSD(nn.Module):
 
     def extract_feat(self, points, pts_feats, pts_cluster_inds, img_metas, center_preds):
         """:458-474 — cluster centroid of the vote centres, per-point offset to it, then the SIR backbone."""
-        cluster_xyz, _, inv_inds = scatter_v2(center_preds, pts_cluster_inds, mode="avg", return_inv=True)
+        pre = self.__dict__.pop("_cluster_xyz_pre", None)
+        if pre is not None and pre[0] is pts_cluster_inds and pre[1] is center_preds and not torch.is_grad_enabled():
+            cluster_xyz = pre[2]  # (K30 formed the centroids behind its own unique)
+            inv_inds = unique_with_plan(pts_cluster_inds)[1]
+        else:
+            cluster_xyz, _, inv_inds = scatter_v2(center_preds, pts_cluster_inds, mode="avg", return_inv=True)
         if (not torch.is_grad_enabled() and points.is_cuda and points.dtype == torch.float32 and cluster_xyz.dtype == torch.float32
                 and hasattr(self.backbone, "_forward_sorted")):
             f_cluster = RowsMinusGroup(points, cluster_xyz, inv_inds)  # (formed by the SIR stack while it permutes its rows)
@@ -240,6 +245,26 @@ class SingleStageFSD(nn.Module):
         scores = seg_logits.softmax(1)[:, :-1]
         thresh = const(("score_thresh", tuple(cfg["score_thresh"])), lambda: torch.tensor(cfg["score_thresh"], dtype=scores.dtype))
         small_groups = max(len(cols) for cols in group_cols) <= 2
+        parts = [seg_logits, d["seg_vote_preds"], d["seg_feats"]]
+        if (bsz == 1 and getattr(self, "native_cluster_frontend", True) and scores.is_cuda and scores.dtype == torch.float32 and ng <= 32
+                and nc <= 32 and small_groups and scores.stride(1) == 1 and seg_logits.dtype == torch.float32
+                and all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 for t in parts)
+                and d["vote_offsets"].dtype == torch.float32 and d["seg_points"].dtype == torch.float32 and d["seg_points"].stride(1) == 1):
+            # K30: everything from the (group, point) pairs to the SIR stack's unique and the cluster centroids — eleven C-ABI entry points,
+            # four host waits — as ONE native call that sequences them from C++ (the waits stay, the interpreter between them does not)
+            vs_rows = [ca._per_class(ca.cluster_voxel_size, n) for n in ca.class_names[:ng]]
+            cells = [max(int(math.ceil((ca.point_cloud_range[3 + a] - ca.point_cloud_range[a]) / row[a])) for row in vs_rows) for a in range(3)]
+            dist = const("connected_dist", lambda: torch.tensor([ca._per_class(ca.connected_dist, n) for n in ca.class_names[:ng]],
+                                                                dtype=torch.float32))
+            res = hip_ops.lidar_cluster_frontend(
+                scores, thresh, group_cols, seg_logits, d["vote_offsets"], d["seg_points"], batch_idx, nc, vs_rows,
+                ca.point_cloud_range[:3], [0] + [-(c // 2) - 8 for c in cells], [ng - 1] + [c + c // 2 + 8 for c in cells], ca.min_points, dist)
+            pts_cluster_inds = res["cluster_inds"]
+            with_key_bounds(pts_cluster_inds, [0, 0, 0], [ng - 1, 0, max(res["counts"]["kept_keys"] - 1, 0)])
+            seed_unique_cache(pts_cluster_inds, res["new_coors"], res["plan"])  # (extract_feat's scatter_v2 and the SIR stack ask for it)
+            self._cluster_xyz_pre = (pts_cluster_inds, res["centers"], res["cluster_xyz"])
+            self._grouped_feats_concat = GatheredRows(parts, res["p_ids"])
+            return res["points"], None, None, None, res["centers"], pts_cluster_inds
         if (bsz == 1 and scores.is_cuda and scores.dtype == torch.float32 and ng <= 32 and nc <= 32
                 and small_groups and scores.stride(1) == 1):
             # K27: the group scores (every group has one or two classes — the nuScenes grouping: their sum has one value whatever

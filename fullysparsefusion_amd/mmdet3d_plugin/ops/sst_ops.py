@@ -122,6 +122,20 @@ def unique_with_plan(coors, col_min=None, col_max=None):
     return res
 
 
+def seed_unique_cache(coors, new_coors, plan):
+    """Enter a unique that was computed elsewhere (the native LiDAR front end, K30: fsf_unique_rows inside the stage driver) as if
+    `unique_with_plan(coors)` had just returned it — keyed like that call would key it (the bounds attached to `coors`)."""
+    if not (_UNIQUE_CACHE_SIZE > 0 and coors.is_cuda and not torch.is_grad_enabled()):
+        return
+    b = getattr(coors, _BOUNDS_ATTR, None)
+    key = (None, None) if b is None else (tuple(b[0]), tuple(b[1]))
+    inv = plan.inv.detach()
+    setattr(inv, _PLAN_ATTR, plan)
+    entries = _unique_entries()
+    entries.append((coors, coors._version, key, (new_coors, inv, plan.cnt)))
+    del entries[:-_UNIQUE_CACHE_SIZE]
+
+
 def clear_unique_cache():
     """Drop the cached uniques (and the key / result tensors they hold): the detector calls this at the end of a frame."""
     del _unique_entries()[:]

@@ -881,6 +881,49 @@ int fsf_weighted_xyz(const float* points, int64_t points_stride, const float* we
                      void* stream);
 int fsf_centroid_divide(const float* mean, int64_t m, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * K30  the LiDAR-query branch's clustering front end as ONE call (round 6): a stage-level driver that sequences eleven of the entry points
+ * above from C++ on the caller's stream.
+ * Replaces: SingleStageFSD.group_sample (projects/mmdet3d_plugin/models/detectors/single_stage_fsd.py:802-865), ClusterAssigner.forward
+ *   (:903-982), update_sample_results_by_mask (:867-890), combine_classes (:892-901), the `scatter_v2(center_preds, pts_cluster_inds, 'avg')`
+ *   of SingleStageFSD.extract_feat (:458-474) and the `torch.unique` of SIR.forward (models/backbones/sir.py:68) — for all class groups of
+ *   ONE sample: fsf_group_pairs -> fsf_vote_centers_keys -> fsf_unique_rows -> fsf_cluster_key_survival -> fsf_segment_reduce_short ->
+ *   fsf_compact_pairs -> fsf_connected_components_grouped -> fsf_cluster_point_ids -> fsf_gather_rows_strided -> fsf_unique_rows ->
+ *   fsf_segment_reduce, same arguments as the Python sequence issues (bit-identical results); the four host waits between them stay (each
+ *   count sizes what follows) but the next launch follows a wait by microseconds instead of the interpreter's 30-110 us.
+ *   scores f32 [m, num_classes] (row stride score_stride; softmax of the logits without its last column), thresh f32 [ng] (device),
+ *   group_class_masks u32 [ng] (HOST: one or two member classes per group), logits / offsets / points: the pre-voxelized fields
+ *   (row strides in floats), batch_idx i64 [m] or NULL, group_voxel_size f32 [ng * 3] (HOST), key_min / key_max i64 [4] (HOST: bounds of
+ *   the (group, vx, vy, vz) keys; a key outside them sends that unique through its range pass), dist_table f32 [ng] (device).
+ *   arena: >= fsf_lidar_cluster_frontend_arena_bytes(m, ng, point_cols) bytes, 256-byte aligned; every result lives inside it at the byte
+ *   offset out[FSF_LCF_OFF_*]:  p_ids i64 [rows], centers f32 [rows, 3], cluster_inds i64 [rows, 3] = (group, sample, cluster id), points
+ *   f32 [rows, point_cols], new_coors i64 [clusters, 3], inv i64 [rows], cnt i64 [clusters], order i32 [rows], seg_offsets i32
+ *   [clusters + 1], cluster_xyz f32 [clusters, 3]; out[FSF_LCF_PAIRS .. FSF_LCF_CLUSTERS] = the five counts.
+ */
+#define FSF_LCF_PAIRS 0
+#define FSF_LCF_KEYS 1
+#define FSF_LCF_KEPT_KEYS 2
+#define FSF_LCF_ROWS 3
+#define FSF_LCF_CLUSTERS 4
+#define FSF_LCF_OFF_P_IDS 5
+#define FSF_LCF_OFF_CENTERS 6
+#define FSF_LCF_OFF_CLUSTER_INDS 7
+#define FSF_LCF_OFF_POINTS 8
+#define FSF_LCF_OFF_NEW_COORS 9
+#define FSF_LCF_OFF_INV 10
+#define FSF_LCF_OFF_CNT 11
+#define FSF_LCF_OFF_ORDER 12
+#define FSF_LCF_OFF_SEG_OFFSETS 13
+#define FSF_LCF_OFF_CLUSTER_XYZ 14
+#define FSF_LCF_OUT_WORDS 16
+int64_t fsf_lidar_cluster_frontend_arena_bytes(int64_t m, int32_t ng, int32_t point_cols);
+int fsf_lidar_cluster_frontend(const float* scores, int64_t m, int32_t num_classes, int64_t score_stride, const float* thresh, int32_t ng,
+                               const uint32_t* group_class_masks, const float* logits, int32_t logit_stride, const float* offsets,
+                               int32_t offset_stride, const float* points, int32_t point_stride, int32_t point_cols,
+                               const int64_t* batch_idx, const float* group_voxel_size, const float range_min[3], const int64_t key_min[4],
+                               const int64_t key_max[4], int64_t min_points, const float* dist_table, void* arena, int64_t arena_bytes,
+                               int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
