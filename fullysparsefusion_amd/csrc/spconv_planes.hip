@@ -110,6 +110,60 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The decoder shortcut straight into planes (round 6): out[i, j] = add[i, j] + cat([a, b], 1)[i, 2j] + cat[i, 2j + 1]
+// (fsf_channel_pair_sum_add2: `reduce_channel(x) + x_merge` of SimpleSparseUNet.decoder_layer_forward [UNVENDORED; SURVEY App. C]) whose
+// only reader is the level's upsampling convolution on K9d: the sums are formed exactly as fsf_channel_pair_sum_add2 forms them and
+// leave as the planes fsf_to_planes would make of them — the [n, cout] fp32 rows are neither written nor read back, one launch instead
+// of two.  A team of 16 threads owns one (row, 128-channel chunk), 8 output channels = 16 input columns per thread.
+__global__ void __launch_bounds__(256)
+    pair_sum_planes_kernel(const float* __restrict__ fa, int ca, const float* __restrict__ fb, int cb, const float* __restrict__ add, int64_t m,
+                           int c, uint4* __restrict__ planes, float* __restrict__ scales) {
+  const int nchunk = (c + 127) / 128;
+  const int tl = threadIdx.x & 15;
+  const int64_t teams = (m + 1) * nchunk;
+  for (int64_t team = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; team < teams; team += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+    const int64_t row = team / nchunk;
+    const int ch = (int)(team - row * nchunk);
+    const int c0 = ch * 128 + tl * 8;
+    const bool active = c0 < c;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.0f;
+    if (active && row < m) {
+      const float* f = 2 * c0 < ca ? fa + row * ca + 2 * c0 : fb + row * cb + (2 * c0 - ca);  // (ca % 16 == 0: the 16 columns lie in one source)
+      const float4 p0 = *reinterpret_cast<const float4*>(f), p1 = *reinterpret_cast<const float4*>(f + 4);
+      const float4 p2 = *reinterpret_cast<const float4*>(f + 8), p3 = *reinterpret_cast<const float4*>(f + 12);
+      float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0;
+      if (add) {
+        o0 = *reinterpret_cast<const float4*>(add + row * c + c0);
+        o1 = *reinterpret_cast<const float4*>(add + row * c + c0 + 4);
+      }
+      v[0] = __fadd_rn(o0.x, __fadd_rn(p0.x, p0.y)); v[1] = __fadd_rn(o0.y, __fadd_rn(p0.z, p0.w));
+      v[2] = __fadd_rn(o0.z, __fadd_rn(p1.x, p1.y)); v[3] = __fadd_rn(o0.w, __fadd_rn(p1.z, p1.w));
+      v[4] = __fadd_rn(o1.x, __fadd_rn(p2.x, p2.y)); v[5] = __fadd_rn(o1.y, __fadd_rn(p2.z, p2.w));
+      v[6] = __fadd_rn(o1.z, __fadd_rn(p3.x, p3.y)); v[7] = __fadd_rn(o1.w, __fadd_rn(p3.z, p3.w));
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 16));
+    float s, inv;
+    sp_pick_scale(amax, s, inv);
+    if (active) {
+      sp_u32x2 h0, l0, h1, l1;
+      const float a4[4] = {v[0], v[1], v[2], v[3]}, b4[4] = {v[4], v[5], v[6], v[7]};
+      sp_split4(a4, s, h0, l0);
+      sp_split4(b4, s, h1, l1);
+      uint4* dst = planes + (row * (c / 8) + (c0 >> 3)) * 2;
+      dst[0] = make_uint4(h0[0], h0[1], h1[0], h1[1]);
+      dst[1] = make_uint4(l0[0], l0[1], l1[0], l1[1]);
+    }
+    if (tl == 0) scales[team] = row < m ? inv : 1.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // weights [kvol][cin][cout] fp32 (spconv v1 layout) -> per-wave A-fragment planes of W_k^T, one power-of-two scale per layer
 __global__ void __launch_bounds__(256) sp_weight_absmax_kernel(const float* __restrict__ w, int64_t n, unsigned* __restrict__ hdr) {
   __shared__ float wave_max[4];
@@ -983,6 +1037,20 @@ extern "C" int fsf_to_planes(const float* feat, int64_t m, int32_t c, int64_t ro
   const int64_t teams = (m + 1) * ((c + 127) / 128);
   hipLaunchKernelGGL(to_planes_kernel, dim3(fsf_stream_grid(teams * 16, 256)), dim3(256), 0, stream, feat, m, (int)c, row_stride,
                      (uint4*)planes, scales);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_channel_pair_sum_add2_planes(const float* feat_a, int32_t ca, const float* feat_b, int32_t cb, int64_t n, const float* add,
+                                                void* planes, float* scales, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n < 0 || ca < 16 || cb < 16 || !planes || !scales || (n > 0 && (!feat_a || !feat_b))) return FSF_ERR_INVALID_ARG;
+  if ((ca % 16) != 0 || (cb % 16) != 0 || ((uintptr_t)feat_a % 16) != 0 || ((uintptr_t)feat_b % 16) != 0 || ((uintptr_t)add % 16) != 0)
+    return FSF_ERR_UNSUPPORTED;
+  const int c = (ca + cb) / 2;
+  const int64_t teams = (n + 1) * ((c + 127) / 128);
+  hipLaunchKernelGGL(pair_sum_planes_kernel, dim3(fsf_stream_grid(teams * 16, 256)), dim3(256), 0, stream, feat_a, (int)ca, feat_b, (int)cb, add, n,
+                     c, (uint4*)planes, scales);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

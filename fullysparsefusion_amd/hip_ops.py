@@ -85,6 +85,7 @@ _ARGTYPES = {
                                   _P],
     "fsf_channel_group_sum_add": [_P, c_i64, c_i32, c_i32, _P, _P, _P],
     "fsf_channel_pair_sum_add2": [_P, c_i32, _P, c_i32, c_i64, _P, _P, _P],
+    "fsf_channel_pair_sum_add2_planes": [_P, c_i32, _P, c_i32, c_i64, _P, _P, _P, _P],
     "fsf_linear_prepared_weight_bytes": [c_i32, c_i32],
     "fsf_linear_prepare_weight": [_P, c_i32, c_i32, _P, _P],
     "fsf_linear_norm_act": [_P, c_i64, c_i32, c_i64, _P, c_i32, _P, c_i32, _P, _P, c_f32, c_i32, _P, c_i64, _P],
@@ -446,6 +447,21 @@ def channel_pair_sum_add2(a: torch.Tensor, b: torch.Tensor, add: Optional[torch.
         assert add.shape == (n, cout)
     out = torch.empty((n, cout), dtype=torch.float32, device=a.device)
     check(_L().fsf_channel_pair_sum_add2(ptr(a), ca, ptr(b), cb, n, ptr(add), ptr(out), stream_ptr()), "fsf_channel_pair_sum_add2")
+    return out
+
+
+def channel_pair_sum_add2_planes(a: torch.Tensor, b: torch.Tensor, add: Optional[torch.Tensor] = None) -> "Planes":
+    """fsf_channel_pair_sum_add2_planes: to_planes(channel_pair_sum_add2(a, b, add)) in one launch, the fp32 rows never written."""
+    require_cuda(a, b, add)
+    n, ca, cb = a.size(0), a.size(1), b.size(1)
+    cout = (ca + cb) // 2
+    assert ca % 16 == 0 and cb % 16 == 0 and a.is_contiguous() and b.is_contiguous()
+    if add is not None:
+        add = add.contiguous()
+        assert add.shape == (n, cout)
+    out = planes_empty(n, cout, a.device)
+    check(_L().fsf_channel_pair_sum_add2_planes(ptr(a), ca, ptr(b), cb, n, ptr(add), ptr(out.data), ptr(out.scales), stream_ptr()),
+          "fsf_channel_pair_sum_add2_planes")
     return out
 
 

@@ -124,7 +124,19 @@ class SimpleSparseUNet(nn.Module):
         no_grad = not (torch.is_grad_enabled() and (f_bot.requires_grad or f_lat.requires_grad or x_merge.features.requires_grad))
         if (no_grad and f_bot.size(1) + f_lat.size(1) == 2 * cout and cout % 4 == 0 and x._features is None
                 and hip_ops.channel_pair_sum_add2_supported(f_bot, f_lat)):
-            x = x._like(hip_ops.channel_pair_sum_add2(f_bot, f_lat, add=x_merge.features))  # reduce_channel + the add, no concatenation
+            up = upsample_layer[0]
+            add = x_merge.features
+            if (switches.PLANES and f_bot.size(1) % 16 == 0 and f_lat.size(1) % 16 == 0 and f_bot.size(0) >= up.PLANES_MIN_ROWS
+                    and getattr(up, "in_channels", 0) == cout and hip_ops.spconv_planes_supported([cout], up.out_channels, 27)
+                    and up.kernel_size == [3, 3, 3]):
+                # the sums' only reader is this level's upsampling convolution on K9d: they leave as planes (one launch instead of
+                # sum + fsf_to_planes, the fp32 rows never written); anything that asks for `.features` gets them formed then
+                y = x._like(None)
+                y.plane_sources = [hip_ops.channel_pair_sum_add2_planes(f_bot, f_lat, add)]
+                y.features_thunk = lambda: hip_ops.channel_pair_sum_add2(f_bot, f_lat, add=add)
+                x = y
+            else:
+                x = x._like(hip_ops.channel_pair_sum_add2(f_bot, f_lat, add=add))  # reduce_channel + the add, no concatenation
         elif no_grad and x.features.is_cuda and x.features.dtype == torch.float32 and x.features.shape[1] == 2 * cout and cout % 4 == 0:
             x = x._like(hip_ops.channel_group_sum_add(x.features, cout, add=x_merge.features))  # reduce_channel + the add, one pass
         else:

@@ -32,11 +32,15 @@ class SparseConvTensor:
         self.grid = grid
         # K9c plane form of `features` (hip_ops.Planes, one per source of a channel concatenation), when a producer emitted it
         self.plane_sources = None
+        # fp32 rows that exist only as a recipe (a producer that emitted `plane_sources` for a plane-form consumer): formed on first read
+        self.features_thunk = None
 
     @property
     def features(self):
         if self._features is None and self.feature_parts is not None:
             self._features = torch.cat(self.feature_parts, dim=1)
+        elif self._features is None and self.features_thunk is not None:
+            self._features, self.features_thunk = self.features_thunk(), None
         return self._features
 
     @features.setter
@@ -45,7 +49,11 @@ class SparseConvTensor:
 
     @property
     def num_channels(self):
-        return sum(int(t.size(1)) for t in self.feature_parts) if self._features is None and self.feature_parts else int(self._features.size(1))
+        if self._features is None and self.feature_parts:
+            return sum(int(t.size(1)) for t in self.feature_parts)
+        if self._features is None and self.plane_sources:
+            return sum(int(p.c) for p in self.plane_sources)
+        return int(self._features.size(1))
 
     @property
     def spatial_size(self):

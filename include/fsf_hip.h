@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 18
+#define FSF_ABI_VERSION 19
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -199,6 +199,11 @@ int fsf_channel_group_sum_add(const float* feat, int64_t n, int32_t cin, int32_t
  * on the concatenation. */
 int fsf_channel_pair_sum_add2(const float* feat_a, int32_t ca, const float* feat_b, int32_t cb, int64_t n, const float* add, float* out,
                               void* stream);
+/* The same sums leaving as PLANES (round 6): what fsf_to_planes makes of fsf_channel_pair_sum_add2's result (planes / scales as there,
+ * bit for bit), in one launch and without the [n, cout] fp32 rows — for a decoder level whose upsampling convolution
+ * (SimpleSparseUNet.decoder_layer_forward's `upsample_layer(x)`) reads planes only.  ca, cb multiples of 16, rows 16-byte aligned. */
+int fsf_channel_pair_sum_add2_planes(const float* feat_a, int32_t ca, const float* feat_b, int32_t cb, int64_t n, const float* add,
+                                     void* planes, float* scales, void* stream);
 
 
 /* Fused a7: Voxel2PointScatterNeck.forward (voxel2point_neck.py:27-70) without the boolean compaction:

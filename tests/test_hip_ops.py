@@ -1421,6 +1421,26 @@ def test_channel_pair_sum_add2_equals_the_op_on_the_concatenation(ops, device, n
     assert not ops.channel_pair_sum_add2_supported(torch.zeros(n, 12, device=device), torch.zeros(n, 4, device=device))
 
 
+@pytest.mark.parametrize("n,ca,cb", [(101119, 128, 128), (5003, 64, 64), (1, 128, 128), (0, 128, 128), (777, 256, 256), (4099, 32, 96)])
+def test_channel_pair_sum_add2_planes_equals_sum_then_to_planes(ops, device, n, ca, cb):
+    """fsf_channel_pair_sum_add2_planes (round 6): the decoder shortcut leaving as planes for the level's upsampling convolution — the
+    planes and the scales fsf_to_planes makes of fsf_channel_pair_sum_add2's rows, bit for bit (zero row behind the last one included),
+    with and without the addend."""
+    torch.manual_seed(n + ca)
+    a, b = torch.randn(n, ca, device=device) * 3, torch.randn(n, cb, device=device)
+    if n > 3:
+        a[1] = 0.0
+        b[1] = 0.0          # an all-zero row: scale of the empty maximum
+        a[2] *= 1e-30       # tiny values next to ordinary ones
+    cout = (ca + cb) // 2
+    m = torch.randn(n, cout, device=device)
+    for add in (m, None):
+        want = ops.to_planes(ops.channel_pair_sum_add2(a, b, add=add))
+        got = ops.channel_pair_sum_add2_planes(a, b, add=add)
+        assert got.m == want.m == n and got.c == want.c == cout
+        assert torch.equal(got.data, want.data) and torch.equal(got.scales, want.scales)
+
+
 @pytest.mark.parametrize("n,w,k", [(20000, 60, 2), (3000, 60, 4), (17, 7, 7), (1, 128, 5)])
 def test_row_topk_desc_equals_torch_topk(ops, device, n, w, k):
     torch.manual_seed(n + w)
