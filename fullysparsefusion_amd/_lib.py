@@ -59,7 +59,7 @@ def lib():
                 h.fsf_status_string.restype = ctypes.c_char_p
                 h.fsf_status_string.argtypes = [ctypes.c_int]
                 for name in (
-                    "fsf_unique_rows_workspace_bytes",
+                    "fsf_unique_rows_workspace_bytes", "fsf_sir_stack_arena_bytes",
                     "fsf_segment_plan_workspace_bytes",
                     "fsf_segment_reduce_workspace_bytes",
                     "fsf_rulebook_workspace_bytes", "fsf_rulebook_to_pairs_workspace_bytes",

@@ -134,6 +134,9 @@ _ARGTYPES = {
     "fsf_spconv_split_weight_f16_bytes": [c_i32, c_i32, c_i32],
     "fsf_spconv_prepare_weight_split_f16": [_P, c_i32, c_i32, c_i32, _P, _P],
     "fsf_spconv_forward_split_planes": [_P, _P, c_i64, c_i32, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, c_i64, _P],
+    "fsf_sir_stack_arena_bytes": [_P, c_i32, c_i64, c_i64],
+    "fsf_sir_stack_forward": [_P, c_i32, _P, c_i64, c_i32, _P, _P, _P, c_i32, _P, c_i32, _P, c_i64, c_i32, c_f32, _P, c_i64, c_i32, _P, c_i64,
+                              c_i64, _P, c_i64, _P, _P, c_i64, _P],
     "fsf_sorted_rows": [_P, _P, c_i64, _P, c_i64, c_i32, _P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, _P, c_i64, c_f32, _P],
     "fsf_compact_pairs": [_P, c_i64, _P, c_i64, _P, _P, _P, _P, _P, _P, c_i64, _P, _P, _P, _P, _P],
     "fsf_combine_queries": [_P, c_i64, _P, c_i64, _P, _P, _P, c_i32, c_i64, _P, _P, _P, _P],
@@ -1619,6 +1622,93 @@ def sorted_rows(order, inv, points, f_cluster=None, centers=None, index=None, fi
                                ptr(idx_s), ptr(fill), fill.numel() if fill is not None else 0, float(fill_value), stream_ptr()),
           "fsf_sorted_rows")
     return seg_ids, pts_s, fcl_s, idx_s
+
+
+class _SirLayerC(ctypes.Structure):  # FsfSirLayer (include/fsf_hip.h)
+    _fields_ = [("planes_left", ctypes.c_void_p), ("planes_right", ctypes.c_void_p), ("left_f16", ctypes.c_int32), ("right_f16", ctypes.c_int32),
+                ("bias", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("eps", ctypes.c_float),
+                ("norm", ctypes.c_int32), ("act", ctypes.c_int32), ("c", ctypes.c_int32)]
+
+
+class _SirBlockC(ctypes.Structure):  # FsfSirBlock
+    _fields_ = [("w1", ctypes.c_void_p), ("g1", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("w2", ctypes.c_void_p), ("g2", ctypes.c_void_p),
+                ("b2", ctypes.c_void_p), ("w3", ctypes.c_void_p), ("g3", ctypes.c_void_p), ("b3", ctypes.c_void_p),
+                ("h1", ctypes.c_int32), ("h2", ctypes.c_int32), ("mlp_eps", ctypes.c_float), ("mlp_act", ctypes.c_int32),
+                ("xyz_normalizer", ctypes.c_float * 3), ("rel_div", ctypes.c_float), ("in_cols", ctypes.c_int32),
+                ("num_layers", ctypes.c_int32), ("layer", _SirLayerC * 4)]
+
+
+class SirStackDescriptor:
+    """The HOST side of fsf_sir_stack_forward's `blocks` argument: one FsfSirBlock per SIRLayer / DynamicClusterVFE of a stack.
+    `blocks` = [dict(mlp=((w1, g1, b1), (w2, g2, b2), (w3, g3, b3)), mlp_eps, mlp_act, xyz_normalizer, rel_div, in_cols,
+    layers=[dict(planes_left, planes_right | None, bias, gamma, beta, eps, norm, act, c)])].  Every tensor is kept alive here."""
+
+    def __init__(self, blocks):
+        codes_n, codes_a = {"none": 0, "ln": 1, "affine": 2}, {"none": 0, "relu": 1, "gelu": 2}
+        self.keep = []
+        self.num_blocks = len(blocks)
+        self.widths = [[int(l["c"]) for l in b["layers"]] for b in blocks]
+        arr = (_SirBlockC * len(blocks))()
+
+        def dp(t):
+            if t is None:
+                return None
+            assert t.is_cuda and t.is_contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        for k, b in zip(arr, blocks):
+            (w1, g1, b1), (w2, g2, b2), (w3, g3, b3) = b["mlp"]
+            for name, t in (("w1", w1), ("g1", g1), ("b1", b1), ("w2", w2), ("g2", g2), ("b2", b2), ("w3", w3), ("g3", g3), ("b3", b3)):
+                assert t.dtype == torch.float32
+                setattr(k, name, dp(t.contiguous()))
+            assert w2.size(1) == w1.size(0) and w3.size(1) == w2.size(0) and w3.size(0) == b["in_cols"]
+            k.h1, k.h2, k.mlp_eps, k.mlp_act = w1.size(0), w2.size(0), float(b["mlp_eps"]), codes_a[b["mlp_act"]]
+            k.xyz_normalizer = (ctypes.c_float * 3)(*[float(v) for v in b["xyz_normalizer"]])
+            k.rel_div, k.in_cols, k.num_layers = float(b["rel_div"]), int(b["in_cols"]), len(b["layers"])
+            assert 1 <= len(b["layers"]) <= 4
+            for i, l in enumerate(b["layers"]):
+                L = k.layer[i]
+                L.planes_left, L.left_f16 = dp(l["planes_left"]), int(linear_weight_is_f16(l["planes_left"]))
+                if l.get("planes_right") is not None:
+                    L.planes_right, L.right_f16 = dp(l["planes_right"]), int(linear_weight_is_f16(l["planes_right"]))
+                L.bias, L.gamma, L.beta = dp(l.get("bias")), dp(l.get("gamma")), dp(l.get("beta"))
+                L.eps, L.norm, L.act, L.c = float(l["eps"]), codes_n[l["norm"]], codes_a[l["act"]], int(l["c"])
+        self.blocks = arr
+
+
+def sir_stack_forward(desc: SirStackDescriptor, points, feats, f_cluster, seg_ids, groups, want_rows, extra=None, extra_div: float = 1.0,
+                      feats_index=None, direct_parts=()):
+    """fsf_sir_stack_forward (K31): every block of a SIR stack on rows sorted by group in ONE native call.  Arguments as
+    `sir_input` takes them for the stack's first block (`feats`: tensor or up to three side by side, through `feats_index`), `seg_ids`
+    i64 [n] nondecreasing, `groups` f32 [m, sum of all layers' widths] holding -inf.  Returns the last layer's rows f32 [n, c] or None."""
+    parts = list(feats) if isinstance(feats, (list, tuple)) else [feats]
+    require_cuda(points, f_cluster, extra, feats_index, seg_ids, groups, *parts)
+    n, m = points.size(0), groups.size(0)
+    for t in [points, f_cluster, extra] + parts:
+        assert t is None or (t.dtype == torch.float32 and t.dim() == 2 and (t.size(0) == 0 or t.stride(1) == 1))
+    assert n >= 1 and m >= 1 and seg_ids.dtype == torch.int64 and seg_ids.shape == (n,) and seg_ids.is_contiguous()
+    assert groups.dtype == torch.float32 and groups.stride(1) == 1 and groups.size(1) >= sum(sum(w) for w in desc.widths)
+    direct_mask = sum(1 << int(p) for p in direct_parts)
+    assert 1 <= len(parts) <= 3 and all(t.size(0) == n for i, t in enumerate(parts) if feats_index is None or (direct_mask >> i) & 1)
+    if feats_index is not None:
+        feats_index = feats_index.to(torch.int64).contiguous()
+        assert feats_index.numel() == n
+    rp = lambda t: c_p(t.data_ptr()) if t is not None and t.numel() else c_p(None)  # noqa: E731
+    st = lambda t: t.stride(0) if t is not None and t.size(0) > 1 else (t.size(1) if t is not None else 0)  # noqa: E731
+    k = len(parts)
+    fp = (ctypes.c_void_p * k)(*[t.data_ptr() if t.numel() else None for t in parts])
+    fs = (ctypes.c_int64 * k)(*[int(st(t)) for t in parts])
+    fc = (ctypes.c_int32 * k)(*[int(t.size(1)) for t in parts])
+    h = _L()
+    nbytes = int(h.fsf_sir_stack_arena_bytes(desc.blocks, desc.num_blocks, n, m))
+    arena = torch.empty((nbytes,), dtype=torch.uint8, device=points.device)
+    rows = torch.empty((n, desc.widths[-1][-1]), dtype=torch.float32, device=points.device) if want_rows else None
+    check(h.fsf_sir_stack_forward(desc.blocks, desc.num_blocks, rp(points), st(points), points.size(1), fp, fs, fc, k, ptr(feats_index), direct_mask,
+                                  rp(extra), st(extra), extra.size(1) if extra is not None else 0, float(extra_div), rp(f_cluster), st(f_cluster),
+                                  f_cluster.size(1), ptr(seg_ids), n, m, c_p(groups.data_ptr()), groups.stride(0) if m > 1 else groups.size(1),
+                                  ptr(rows), ptr(arena), nbytes, stream_ptr()), "fsf_sir_stack_forward")
+    return rows
 
 
 def compact_pairs(means, k_idx, g_ids, p_ids, b_pts, centers, v_idx):

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from .... import hip_ops, switches
-from ...ops.sst_ops import GatheredRows, RowsMinusGroup, plan_of, unique_with_plan
+from ...ops.sst_ops import GatheredRows, RowsMinusGroup, plan_of, sir_stack_descriptor, unique_with_plan
 from ...registry import BACKBONES, build_voxel_encoder
 
 
@@ -46,6 +46,7 @@ class SIR(nn.Module):
         # features (FSF.py:436-447, single_stage_fsd.py:468-474) and say so; then the sorted path neither writes the last layer's
         # rows nor un-sorts them, and the first return value is None.
         self.point_feats_needed = True
+        self.native_stack = True  # the sorted stack as one native call (K31); False: one C-ABI call per kernel (the tests' reference)
 
     def _forward_sorted(self, points, features, coors, f_cluster):
         """Inference: the whole stack on rows SORTED by group (one permutation in, through the indices K21 reads its sources by):
@@ -69,12 +70,19 @@ class SIR(nn.Module):
             plan.order, plan.inv, points, f_cluster=None if lazy else f_cluster, centers=f_cluster.centers if lazy else None,
             index=features.index if gathered else None, fill=groups)
         feats = GatheredRows(features.sources if gathered else [features], idx_s)
-        col, rows = 0, None
-        for i, block in enumerate(self.block_list):
-            want = i < self.num_blocks - 1 or self.point_feats_needed
-            rows = block.forward_sorted(pts_s, feats, fcl_s, seg_ids, groups[:, col:col + widths[i]], want)
-            feats = rows
-            col += widths[i]
+        desc = sir_stack_descriptor(self, self.block_list) if self.native_stack and m >= 16 and len(feats.sources) <= 3 else None
+        if desc is not None:
+            # K31: the blocks below as ONE native call (fsf_sir_stack_forward: the same entry points with the same arguments, sequenced
+            # from C++ — 13 C-ABI calls and their interpreter time per stack; bit-identical, tests/test_sir_stack_gpu.py)
+            rows = hip_ops.sir_stack_forward(desc, pts_s, feats.sources, fcl_s, seg_ids, groups, self.point_feats_needed,
+                                             feats_index=feats.index, direct_parts=feats.direct)
+        else:
+            col, rows = 0, None
+            for i, block in enumerate(self.block_list):
+                want = i < self.num_blocks - 1 or self.point_feats_needed
+                rows = block.forward_sorted(pts_s, feats, fcl_s, seg_ids, groups[:, col:col + widths[i]], want)
+                feats = rows
+                col += widths[i]
         out_feats = None
         if self.point_feats_needed:
             out_feats = torch.empty_like(rows)

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .... import hip_ops, switches
 from ...ops.dynamic_point_pool_op import dynamic_point_pool
-from ...ops.sst_ops import GatheredRows, unique_with_plan, with_key_bounds
+from ...ops.sst_ops import GatheredRows, sir_stack_descriptor, unique_with_plan, with_key_bounds
 from ...registry import HEADS, ROI_EXTRACTORS, build_voxel_encoder
 
 
@@ -112,11 +112,19 @@ class FullySparseBboxHead(nn.Module):
             widths = [b.group_width() for b in self.block_list]
             groups = torch.full((num_rois, sum(widths)), float("-inf"), dtype=torch.float32, device=pts_xyz.device)
             seg_ids = roi_inds.contiguous()
-            out_feats, col = pts_features, 0
-            for i, block in enumerate(self.block_list):
-                out_feats = block.forward_sorted(pts_xyz, out_feats, f_cluster, seg_ids, groups[:, col:col + widths[i]],
-                                                 i < self.num_blocks - 1, extra=f_cluster if self.geo_input else None, extra_div=10.0)
-                col += widths[i]
+            srcs = pts_features.sources if lazy_feats else [pts_features]
+            desc = (sir_stack_descriptor(self, self.block_list)
+                    if getattr(self, "native_stack", True) and num_rois >= 16 and len(srcs) <= 3 and pts_xyz.size(0) > 0 else None)
+            if desc is not None:  # K31: the three blocks as one native call (see SIR._forward_sorted)
+                hip_ops.sir_stack_forward(desc, pts_xyz, srcs, f_cluster, seg_ids, groups, False, extra=f_cluster if self.geo_input else None,
+                                          extra_div=10.0, feats_index=pts_features.index if lazy_feats else None,
+                                          direct_parts=pts_features.direct if lazy_feats else ())
+            else:
+                out_feats, col = pts_features, 0
+                for i, block in enumerate(self.block_list):
+                    out_feats = block.forward_sorted(pts_xyz, out_feats, f_cluster, seg_ids, groups[:, col:col + widths[i]],
+                                                     i < self.num_blocks - 1, extra=f_cluster if self.geo_input else None, extra_div=10.0)
+                    col += widths[i]
             nonempty = groups[:, 0] > float("-inf")
             return torch.where(nonempty[:, None], groups, groups.new_zeros(())), nonempty
         rel_xyz = pts_xyz[:, :3] - rois[:, :3][roi_inds]

@@ -320,6 +320,59 @@ def sorted_stack_supported(vfe_layers, mode):
     return True
 
 
+def _grouped_planes(lin, c_left):
+    """(key, prepared W[:, :c_left], W[:, c_left:], prepared W[:, c_left:]) of a layer that takes `cat([point, group[inv]], 1)`:
+    prepared once per weight version."""
+    key = (lin.weight.data_ptr(), lin.weight._version, lin.weight.device, c_left)
+    cache = lin.__dict__.get("_fsf_planes_grouped")
+    if cache is None or cache[0] != key:
+        w = lin.weight.detach()
+        w_right = w[:, c_left:].contiguous()
+        cache = (key, hip_ops.linear_prepare_weight(w[:, :c_left].contiguous()), w_right, hip_ops.linear_prepare_weight(w_right))
+        lin.__dict__["_fsf_planes_grouped"] = cache
+    return cache
+
+
+def sir_stack_descriptor(owner, blocks):
+    """hip_ops.SirStackDescriptor of a stack of SIRLayer / DynamicClusterVFE blocks (fsf_sir_stack_forward, K31), cached on `owner`
+    until a parameter of the stack changes; None when a block is outside what the native stack takes (the per-block path then runs)."""
+    params = [p for b in blocks for p in b.parameters()]
+    key = tuple((p.data_ptr(), p._version) for p in params) + (switches.K22F,)
+    cached = owner.__dict__.get("_fsf_sir_stack_desc")
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    specs = []
+    for b in blocks:
+        fused = b._fused_input_layers()
+        if fused is None or not (1 <= len(b.vfe_layers) <= 4):
+            specs = None
+            break
+        layers, eps, act = fused
+        ls, prev = [], None
+        for i, vfe in enumerate(b.vfe_layers):
+            lin = vfe.linear
+            c = lin.out_features
+            na = _k22_norm_act(vfe.norm, vfe.act, c)
+            if na is None:
+                specs = None
+                break
+            kind, gamma, beta, e, act_code = na
+            if i == 0:
+                left, right = _prepared_planes(lin), None
+            else:
+                cache = _grouped_planes(lin, prev)
+                left, right = cache[1], cache[3]
+            ls.append(dict(planes_left=left, planes_right=right, bias=lin.bias, gamma=gamma, beta=beta, eps=e, norm=kind, act=act_code, c=c))
+            prev = c
+        if specs is None:
+            break
+        specs.append(dict(mlp=layers, mlp_eps=eps, mlp_act=act, xyz_normalizer=b.xyz_normalizer, rel_div=b.rel_dist_scaler,
+                          in_cols=layers[2][0].size(0), layers=ls))
+    desc = hip_ops.SirStackDescriptor(specs) if specs is not None else None
+    owner.__dict__["_fsf_sir_stack_desc"] = (key, desc)
+    return desc
+
+
 def sorted_stack_forward(vfe_layers, x, seg_ids, group_out, want_last_rows):
     """The layer stack of one SIRLayer on rows SORTED by group: per layer ONE K22s launch (`fsf_linear_norm_act_segmax`) computes
     point_feats = act(norm(linear(.))) and the group maxima; from the second layer on the input `cat([point, group[inv]], 1)` is
@@ -340,13 +393,7 @@ def sorted_stack_forward(vfe_layers, x, seg_ids, group_out, want_last_rows):
                                                    want_rows=(not last) or want_last_rows)
         else:
             c_left = point.size(1)
-            key = (lin.weight.data_ptr(), lin.weight._version, lin.weight.device, c_left)
-            cache = lin.__dict__.get("_fsf_planes_grouped")
-            if cache is None or cache[0] != key:
-                w = lin.weight.detach()
-                w_right = w[:, c_left:].contiguous()
-                cache = (key, hip_ops.linear_prepare_weight(w[:, :c_left].contiguous()), w_right, hip_ops.linear_prepare_weight(w_right))
-                lin.__dict__["_fsf_planes_grouped"] = cache
+            cache = _grouped_planes(lin, c_left)
             g = group_out[:, col - c_left:col]  # the previous layer's group maxima (a column slice: rows 16-byte aligned)
             if g.size(0) >= _SMALL_N_MIN and hip_ops.linear_norm_act_supported(g, c):
                 table = hip_ops.linear_norm_act(g, cache[3], c)

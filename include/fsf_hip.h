@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 19
+#define FSF_ABI_VERSION 20
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -676,6 +676,51 @@ int fsf_sir_input_gather(const float* points, int64_t points_stride, int32_t p_c
                          const float* g1, const float* b1, int32_t h1, const float* w2, const float* g2, const float* b2, int32_t h2,
                          const float* w3, const float* g3, const float* b3, float eps, int32_t act, int64_t n, float* out,
                          int64_t out_stride, void* stream);
+
+/* K31 (round 6)  a whole SIR stack on rows SORTED by group as one call: SIR.forward (projects/mmdet3d_plugin/models/backbones/sir.py:65-85)
+ * and FullySparseBboxHead.forward (models/roi_heads/bbox_heads/fsd_bbox_head.py:96-197) at test time.  Per block: fsf_sir_input_gather (the
+ * block's input rows), then per DynamicVFELayer fsf_linear[_f16w]_norm_act_segmax, preceded from the second layer on by the group half of
+ * the layer's weight on the previous layer's group maxima (fsf_linear_norm_act / fsf_linear_f16w_norm_act_grouped on [num_groups, c]) —
+ * the calls hip_ops.sir_input / sst_ops.sorted_stack_forward issue from Python, with the same arguments, sequenced from C++.
+ *   blocks        HOST array [num_blocks]; device pointers inside: the position MLP (w* f32 row-major, g* / b* LayerNorm affine), per layer
+ *                 the prepared weights of the point half (`planes_left`, fsf_linear_prepare_weight[_f16]; *_f16 != 0: the f16 format)
+ *                 and — layers >= 1 — of the group half (`planes_right`), bias / gamma / beta (or NULL), norm / act codes of
+ *                 fsf_linear_norm_act, c = output channels; in_cols = the block's input width (p_cols + feature columns + e_cols);
+ *   points / f_cluster / extra / seg_ids: the stack's rows in sorted order (fsf_sorted_rows); block 0 reads its feature columns from
+ *                 feat_parts through feats_index exactly as fsf_sir_input_gather does, later blocks the previous block's rows;
+ *   groups        f32 [num_groups, groups_stride >= sum of all layers' c], holding -inf: layer by layer, block by block, the group maxima
+ *                 side by side (the `cat` SIR.forward returns);
+ *   rows_out      f32 [n, c of the last layer] or NULL (the last layer's point rows are then never written);
+ *   arena         device, 256-byte aligned, >= fsf_sir_stack_arena_bytes(blocks, num_blocks, n, num_groups).
+ * n >= 1, num_groups >= 1 (the host path keeps the degenerate cases). */
+#define FSF_SIR_MAX_LAYERS 4
+typedef struct {
+  const void* planes_left;
+  const void* planes_right;
+  int32_t left_f16, right_f16;
+  const float *bias, *gamma, *beta;
+  float eps;
+  int32_t norm, act, c;
+} FsfSirLayer;
+typedef struct {
+  const float *w1, *g1, *b1;
+  const float *w2, *g2, *b2;
+  const float *w3, *g3, *b3;
+  int32_t h1, h2;
+  float mlp_eps;
+  int32_t mlp_act;
+  float xyz_normalizer[3];
+  float rel_div;
+  int32_t in_cols, num_layers;
+  FsfSirLayer layer[FSF_SIR_MAX_LAYERS];
+} FsfSirBlock;
+int64_t fsf_sir_stack_arena_bytes(const FsfSirBlock* blocks, int32_t num_blocks, int64_t n, int64_t num_groups);
+int fsf_sir_stack_forward(const FsfSirBlock* blocks, int32_t num_blocks, const float* points, int64_t points_stride, int32_t p_cols,
+                          const float* const* feat_parts, const int64_t* feat_strides, const int32_t* feat_cols, int32_t num_parts,
+                          const int64_t* feats_index, int32_t direct_parts_mask, const float* extra, int64_t extra_stride, int32_t e_cols,
+                          float extra_div, const float* f_cluster, int64_t f_cluster_stride, int32_t r_cols, const int64_t* seg_ids,
+                          int64_t n, int64_t num_groups, float* groups, int64_t groups_stride, float* rows_out, void* arena,
+                          int64_t arena_bytes, void* stream);
 
 /* K28 (training)  y = cat([points[:, :3] / xyz_normalizer, points[:, 3:], feats, extra / extra_div], 1) * h  — the input side of
  * SIRLayer.forward [UNVENDORED; SURVEY App. C] around the position MLP's output h f32 [n, c] (contiguous), c = p_cols + f_cols + e_cols —
