@@ -230,12 +230,22 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
     float xc[SCS_RG][8];
     load_x(idx_cur, kc, xc);
     // XP: inverse row scale of the rows in `xc` (the chunk multiplied next) and the unit the accumulators are currently kept in
-    float sc_x[SCS_RG], inv_cur[SCS_RG];
+    // A row's unit is CAPPED at 2^60: the accumulators move between the units of the rows they meet, and a neighbour row
+    // whose maximum is tiny but not zero (1e-30 behind a ReLU) would otherwise multiply accumulators of ~2^42 by ~2^100 — inf, and inf
+    // again after the way back.  Such a row's f16 fragments are scaled down to the capped unit instead (`dn` = 2^60 / s_row, a power of
+    // two: exact until it flushes what lies 2^-22 below 7e-15); rows of ordinary magnitude never see the branch.
+    float sc_x[SCS_RG], inv_cur[SCS_RG], dn[SCS_RG];
+    auto row_unit = [&](int rg) {
+      const float raw = a.x_inv_scale[idx_cur[rg] < 0 ? 0 : idx_cur[rg]];
+      sc_x[rg] = fmaxf(raw, 0x1p-60f);
+      dn[rg] = raw * __uint_as_float(0x7f000000u - __float_as_uint(sc_x[rg]));  // 1 unless capped
+    };
 #pragma unroll
     for (int rg = 0; rg < SCS_RG; ++rg) {
       inv_cur[rg] = 1.0f;
       sc_x[rg] = 1.0f;
-      if constexpr (XP) sc_x[rg] = a.x_inv_scale[idx_cur[rg] < 0 ? 0 : idx_cur[rg]];
+      dn[rg] = 1.0f;
+      if constexpr (XP) row_unit(rg);
     }
     const bool tail_chunks = (a.cin % SCS_KC) != 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -268,6 +278,16 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
         if constexpr (XP) {  // the planes ARE the operands (cin is a multiple of 32 here)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { xh[rg][e] = __float_as_uint(xc[rg][e]); xl[rg][e] = __float_as_uint(xc[rg][4 + e]); }
+          if (dn[rg] != 1.0f) {  // (a row beyond the unit cap: its fragments move to the capped unit)
+            typedef _Float16 scs_h2 __attribute__((ext_vector_type(2)));
+            const _Float16 d = (_Float16)dn[rg];
+            const scs_h2 d2 = {d, d};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              xh[rg][e] = __builtin_bit_cast(unsigned, (scs_h2)(__builtin_bit_cast(scs_h2, xh[rg][e]) * d2));
+              xl[rg][e] = __builtin_bit_cast(unsigned, (scs_h2)(__builtin_bit_cast(scs_h2, xl[rg][e]) * d2));
+            }
+          }
           xm[rg] = xh[rg];
           any_live |= live;
           continue;
@@ -298,7 +318,7 @@ __global__ void __launch_bounds__(SCS_NW * 64, SCS_WPS) spconv_fwd_split_kernel(
         if constexpr (XP) {
           if (nk != k) {
 #pragma unroll
-            for (int rg = 0; rg < SCS_RG; ++rg) sc_x[rg] = a.x_inv_scale[idx_cur[rg] < 0 ? 0 : idx_cur[rg]];
+            for (int rg = 0; rg < SCS_RG; ++rg) row_unit(rg);
           }
         }
         if (nk != k) {  // first chunk of a new offset: fetch the ids of the offset after it
