@@ -116,31 +116,66 @@ struct VoteArgs {
   float* centers; int64_t* keys; int64_t* batch_out;
 };
 
+// (round 6) The rows of a pair — nc logits, 3 nc vote offsets — are read with 16-byte loads (4-byte aligned: rows of 11 / 33 floats)
+// into registers and walked with compile-time indices; as runtime-bounded scalar loops every one of the ~75 loads of a pair was a wave
+// instruction of its own touching ~50 cache lines (144 us for 510 k pairs, 0.4 TB/s).  The arithmetic and its order are unchanged.
+struct __attribute__((packed, aligned(4))) vc_quad { float v[4]; };
+
 __global__ void __launch_bounds__(256) vote_centers_keys_kernel(VoteArgs a) {
+  const int nc = a.nc;  // <= 32 (the class masks are 32 bits wide)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (int64_t)gridDim.x * blockDim.x) {
     const int g = (int)a.g_ids[i];
     const int64_t p = a.p_ids[i];
     const uint32_t mem = a.mask[g];
-    const float* lg = a.logits + p * a.logit_stride;
+    const float* lgp = a.logits + p * a.logit_stride;
+    float lg[32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (4 * q + 4 <= nc) {  // (uniform) a whole quad of the row
+        const vc_quad v = *reinterpret_cast<const vc_quad*>(lgp + 4 * q);
+        lg[4 * q] = v.v[0]; lg[4 * q + 1] = v.v[1]; lg[4 * q + 2] = v.v[2]; lg[4 * q + 3] = v.v[3];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lg[4 * q + r] = 4 * q + r < nc ? lgp[4 * q + r] : 0.0f;
+      }
+    }
     float mx = -INFINITY;
-    for (int c = 0; c < a.nc; ++c)
-      if ((mem >> c) & 1u) mx = fmaxf(mx, lg[c]);
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < nc && ((mem >> c) & 1u)) mx = fmaxf(mx, lg[c]);
     uint32_t tie = 0;
     float cnt = 0.0f;
-    for (int c = 0; c < a.nc; ++c)
-      if (((mem >> c) & 1u) && fabsf(__fsub_rn(lg[c], mx)) < 1e-6f) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < nc && ((mem >> c) & 1u) && fabsf(__fsub_rn(lg[c], mx)) < 1e-6f) {
         tie |= 1u << c;
         cnt = __fadd_rn(cnt, 1.0f);
       }
     const float wv = __fdiv_rn(1.0f, cnt);
     const float* off = a.offsets + p * a.offset_stride;
-    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    for (int c = 0; c < a.nc; ++c) {
-      const float w = ((tie >> c) & 1u) ? wv : 0.0f;
-      sx = __fadd_rn(sx, __fmul_rn(off[3 * c + 0], w));
-      sy = __fadd_rn(sy, __fmul_rn(off[3 * c + 1], w));
-      sz = __fadd_rn(sz, __fmul_rn(off[3 * c + 2], w));
+    float sacc[3] = {0.0f, 0.0f, 0.0f};
+    const int ne = 3 * nc;
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+      if (4 * q >= ne) break;  // (uniform)
+      float o4[4];
+      if (4 * q + 4 <= ne) {
+        const vc_quad v = *reinterpret_cast<const vc_quad*>(off + 4 * q);
+        o4[0] = v.v[0]; o4[1] = v.v[1]; o4[2] = v.v[2]; o4[3] = v.v[3];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = 4 * q + r < ne ? off[4 * q + r] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = 4 * q + r, c = e / 3, jx = e - 3 * c;  // (compile-time)
+        if (e < ne) {
+          const float w = ((tie >> c) & 1u) ? wv : 0.0f;
+          sacc[jx] = __fadd_rn(sacc[jx], __fmul_rn(o4[r], w));
+        }
+      }
     }
+    const float sx = sacc[0], sy = sacc[1], sz = sacc[2];
     const float* pt = a.points + p * a.point_stride;
     const float cx = __fadd_rn(pt[0], sx), cy = __fadd_rn(pt[1], sy), cz = __fadd_rn(pt[2], sz);
     a.centers[3 * i + 0] = cx;
