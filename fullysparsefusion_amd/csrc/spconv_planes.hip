@@ -70,9 +70,10 @@ __device__ __forceinline__ void sp_split4(const float (&v)[4], float s, sp_u32x2
 // ---------------------------------------------------------------------------------------------------------------------
 // fp32 rows -> planes.  planes: [m + 1][c / 8][2][8] f16 (row m = zeros, the neighbour of a missing pair);
 // scales: [m + 1][ceil(c / 128)] f32 = the INVERSE scale of each 128-channel chunk of the row.
+// (`row_index`, optional: plane row r is made of feature row row_index[r] — the U-Net's neighbour-mask row order applied while converting)
 __global__ void __launch_bounds__(256)
     to_planes_kernel(const float* __restrict__ feat, int64_t m, int c, int64_t stride, uint4* __restrict__ planes,
-                     float* __restrict__ scales) {
+                     float* __restrict__ scales, const int64_t* __restrict__ row_index = nullptr) {
   const int nchunk = (c + 127) / 128;
   const int tl = threadIdx.x & 15;
   const int64_t teams = (m + 1) * nchunk;
@@ -85,8 +86,9 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = 0.0f;
     if (active && row < m) {
-      const float4 p = *reinterpret_cast<const float4*>(feat + row * stride + c0);
-      const float4 r = *reinterpret_cast<const float4*>(feat + row * stride + c0 + 4);
+      const int64_t src = row_index ? row_index[row] : row;
+      const float4 p = *reinterpret_cast<const float4*>(feat + src * stride + c0);
+      const float4 r = *reinterpret_cast<const float4*>(feat + src * stride + c0 + 4);
       v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = r.x; v[5] = r.y; v[6] = r.z; v[7] = r.w;
     }
     float amax = 0.0f;
@@ -1037,6 +1039,18 @@ extern "C" int fsf_to_planes(const float* feat, int64_t m, int32_t c, int64_t ro
   const int64_t teams = (m + 1) * ((c + 127) / 128);
   hipLaunchKernelGGL(to_planes_kernel, dim3(fsf_stream_grid(teams * 16, 256)), dim3(256), 0, stream, feat, m, (int)c, row_stride,
                      (uint4*)planes, scales);
+  FSF_LAUNCH_CHECK();
+  return FSF_OK;
+}
+
+extern "C" int fsf_to_planes_rows(const float* feat, int64_t m, int32_t c, int64_t row_stride, const int64_t* row_index, void* planes,
+                                  float* scales, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (m < 0 || c < 8 || (c % 8) != 0 || row_stride < c || !planes || !scales || (m > 0 && (!feat || !row_index))) return FSF_ERR_INVALID_ARG;
+  if (((uintptr_t)feat % 16) != 0 || (row_stride % 4) != 0) return FSF_ERR_UNSUPPORTED;
+  const int64_t teams = (m + 1) * ((c + 127) / 128);
+  hipLaunchKernelGGL(to_planes_kernel, dim3(fsf_stream_grid(teams * 16, 256)), dim3(256), 0, stream, feat, m, (int)c, row_stride,
+                     (uint4*)planes, scales, row_index);
   FSF_LAUNCH_CHECK();
   return FSF_OK;
 }

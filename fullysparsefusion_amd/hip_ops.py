@@ -79,6 +79,7 @@ _ARGTYPES = {
     "fsf_planes_bytes": [c_i64, c_i32],
     "fsf_planes_scale_count": [c_i64, c_i32],
     "fsf_to_planes": [_P, c_i64, c_i32, c_i64, _P, _P, _P],
+    "fsf_to_planes_rows": [_P, c_i64, c_i32, c_i64, _P, _P, _P, _P],
     "fsf_spconv_planes_weight_bytes": [c_i32, c_i32, c_i32],
     "fsf_spconv_prepare_weight_planes": [_P, c_i32, c_i32, c_i32, _P, _P],
     "fsf_spconv_forward_planes": [_P, _P, c_i32, _P, _P, c_i32, c_i64, _P, c_i32, c_i32, _P, c_i64, _P, _P, _P, c_i32, _P, _P, _P,
@@ -887,13 +888,21 @@ def planes_empty(m: int, c: int, device):
     return Planes(data, scales, m, c)
 
 
-def to_planes(feat: torch.Tensor) -> Planes:
-    """fsf_to_planes: f32 [m, c] (rows may be strided, c % 8 == 0) -> Planes."""
-    require_cuda(feat)
+def to_planes(feat: torch.Tensor, row_index: Optional[torch.Tensor] = None) -> Planes:
+    """fsf_to_planes: f32 [m, c] (rows may be strided, c % 8 == 0) -> Planes; with `row_index` (i64 [m']) fsf_to_planes_rows: the planes
+    of feat[row_index] without the gathered rows."""
+    require_cuda(feat, row_index)
     assert feat.dtype == torch.float32 and feat.dim() == 2 and feat.size(1) % 8 == 0
     feat, stride = _rows_view(feat)
     if stride % 4 or feat.data_ptr() % 16:
         feat, stride = feat.contiguous(), feat.size(1)
+    if row_index is not None:
+        assert row_index.dtype == torch.int64 and row_index.dim() == 1 and row_index.is_contiguous()
+        m, c = row_index.numel(), feat.size(1)
+        out = planes_empty(m, c, feat.device)
+        check(_L().fsf_to_planes_rows(c_p(feat.data_ptr()) if m else c_p(None), m, c, stride, ptr(row_index), ptr(out.data), ptr(out.scales),
+                                      stream_ptr()), "fsf_to_planes_rows")
+        return out
     m, c = feat.shape
     out = planes_empty(m, c, feat.device)
     check(_L().fsf_to_planes(c_p(feat.data_ptr()) if m else c_p(None), m, c, stride, ptr(out.data), ptr(out.scales), stream_ptr()),

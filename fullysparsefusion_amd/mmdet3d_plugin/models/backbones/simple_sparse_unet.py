@@ -255,9 +255,7 @@ class SimpleSparseUNet(nn.Module):
                 meta.indice_dict["__mask_order__"] = reorder
                 meta = self._plan_modules(self._plan_modules(meta, self.conv_input), levels[0])
             publish(meta, [coors, perm64, inv_perm])
-            if perm64 is not None:
-                voxel_features = voxel_features.index_select(0, perm64)
-            x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+            x = self._permuted_input(voxel_features, perm64, coors, batch_size)
             x.indice_dict = meta.indice_dict
         else:
             coors = own_coors()
@@ -265,8 +263,7 @@ class SimpleSparseUNet(nn.Module):
                 perm, inv_perm = hip_ops.order_by_neighbor_mask(coors, batch_size, self.sparse_shape)
                 perm64, inv_perm = perm.long(), inv_perm.long()
                 coors = coors.index_select(0, perm64)
-                voxel_features = voxel_features.index_select(0, perm64)
-            x = SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+            x = self._permuted_input(voxel_features, perm64 if reorder else None, coors, batch_size)
             x.indice_dict["__mask_order__"] = reorder  # (the dict is shared by every tensor derived from x)
         mark("conv_input starts")
         x = self.conv_input(x)
@@ -322,9 +319,50 @@ class SimpleSparseUNet(nn.Module):
         else:
             pending.pop()
         out = x.features
-        if inv_perm is not None:
-            out = out.index_select(0, inv_perm)  # back to the caller's voxel order
         # every decoder stage ends in a ReLU (asserted in __init__): no row can equal the neck's negative padding value, which spares
         # Voxel2PointScatterNeck its `pts_mask.all()` reduction and the host wait on its result
         out._fsf_nonnegative = True
+        if inv_perm is not None:
+            # back to the caller's voxel order — on first read of "voxel_feats"; a consumer that gathers rows anyway (the neck: one
+            # row per POINT) composes its index with `inv_perm` instead and the [voxels, C] copy is never made
+            return [PermutedRowsOutput(out, inv_perm)]
         return [{"voxel_feats": out}]
+
+    def _permuted_input(self, voxel_features, perm64, coors, batch_size):
+        """The network's input in the (permuted) row order: as planes made straight through the permutation when `conv_input` runs on
+        the plane kernel (the permuted fp32 rows are then never written), else the gathered rows."""
+        if perm64 is None:
+            return SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        conv = self.conv_input[0]
+        if (switches.PLANES and voxel_features.is_cuda and voxel_features.dtype == torch.float32 and not torch.is_grad_enabled()
+                and voxel_features.size(0) >= conv.PLANES_MIN_ROWS and conv.subm and conv.in_channels <= 128 and conv.in_channels % 32 == 0
+                and voxel_features.size(1) == conv.in_channels and hip_ops.spconv_planes_supported([conv.in_channels], conv.out_channels, 27)):
+            x = SparseConvTensor(None, coors, self.sparse_shape, batch_size)
+            x.plane_sources = [hip_ops.to_planes(voxel_features, row_index=perm64)]
+            x.features_thunk = lambda: voxel_features.index_select(0, perm64)
+            return x
+        return SparseConvTensor(voxel_features.index_select(0, perm64), coors, self.sparse_shape, batch_size)
+
+
+class PermutedRowsOutput(dict):
+    """`{"voxel_feats": rows.index_select(0, row_map)}` whose gather happens on first read of the key: `permuted` = (rows, row_map) for a
+    consumer that indexes the rows itself (VoteSegmentor.extract_feat hands them to the neck)."""
+
+    def __init__(self, rows, row_map):
+        super().__init__()
+        self.permuted = (rows, row_map)
+
+    def __missing__(self, key):
+        if key != "voxel_feats":
+            raise KeyError(key)
+        rows, row_map = self.permuted
+        out = rows.index_select(0, row_map)
+        out._fsf_nonnegative = getattr(rows, "_fsf_nonnegative", False)
+        self[key] = out
+        return out
+
+    def __contains__(self, key):
+        return key == "voxel_feats" or super().__contains__(key)
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default

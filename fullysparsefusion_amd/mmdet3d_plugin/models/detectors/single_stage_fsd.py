@@ -93,8 +93,13 @@ class VoteSegmentor(nn.Module):
         x = self.backbone(voxel_info)[0]
         padding = -1
         assert "shuffle_inds" not in voxel_info  # SST-only branch (:238-241)
-        voxel_feats_reorder = x["voxel_feats"]
-        out = self.decode_neck(batch_points, coors, voxel_feats_reorder, voxel2point_inds, padding)
+        permuted = getattr(x, "permuted", None)
+        if permuted is not None and getattr(self.decode_neck, "takes_row_map", False) and not torch.is_grad_enabled():
+            # (the U-Net's rows in ITS order + the map back: the neck gathers one row per point through the composed index)
+            out = self.decode_neck(batch_points, coors, permuted[0], voxel2point_inds, padding, row_map=permuted[1])
+        else:
+            voxel_feats_reorder = x["voxel_feats"]
+            out = self.decode_neck(batch_points, coors, voxel_feats_reorder, voxel2point_inds, padding)
         return out, coors, batch_points
 
     def voxel_downsample(self, points_list):

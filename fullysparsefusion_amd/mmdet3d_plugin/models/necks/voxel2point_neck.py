@@ -18,8 +18,14 @@ class Voxel2PointScatterNeck(nn.Module):
         self.with_xyz = with_xyz
         self.normalize_local_xyz = normalize_local_xyz
 
-    def forward(self, points, pts_coors, voxel_feats, voxel2point_inds, voxel_padding=-1):
+    takes_row_map = True  # (forward accepts `row_map`: voxel row r of the caller's order is row row_map[r] of `voxel_feats`)
+
+    def forward(self, points, pts_coors, voxel_feats, voxel2point_inds, voxel_padding=-1, row_map=None):
         assert points.size(0) == pts_coors.size(0) == voxel2point_inds.size(-1)
+        if row_map is not None:  # one small index gather (a point's voxel row in the given order) instead of a [voxels, C] copy
+            nonneg = getattr(voxel_feats, "_fsf_nonnegative", False)
+            voxel2point_inds = row_map.index_select(0, voxel2point_inds.long())
+            voxel_feats._fsf_nonnegative = nonneg
         fused_ok = self.with_xyz and not self.normalize_local_xyz and not (torch.is_grad_enabled() and voxel_feats.requires_grad)
         if fused_ok:
             out, pts_mask = hip_ops.voxel2point(points, pts_coors, voxel_feats, voxel2point_inds, self.voxel_size,

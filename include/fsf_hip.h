@@ -31,7 +31,7 @@ extern "C" {
 const char* fsf_status_string(int status);
 /* ABI version, bumped whenever a signature changes or an entry point is added; a loader compares fsf_abi_version() of the
  * library it found with the FSF_ABI_VERSION of the header it was written against. */
-#define FSF_ABI_VERSION 20
+#define FSF_ABI_VERSION 21
 int fsf_abi_version(void);
 
 /* Process-wide algorithm switches (A/B runs and tests that compare two device paths in one process); the defaults are the
@@ -588,6 +588,10 @@ int fsf_spconv_forward_split_planes(const void* feat_planes, const float* feat_i
 int64_t fsf_planes_bytes(int64_t m, int32_t c);
 int64_t fsf_planes_scale_count(int64_t m, int32_t c);
 int fsf_to_planes(const float* feat, int64_t m, int32_t c, int64_t row_stride, void* planes, float* scales, void* stream);
+/* The same through a row index (round 6): plane row r = feat row row_index[r] (i64 [m]) — SimpleSparseUNet's neighbour-mask row order
+ * (`voxel_features.index_select(0, perm)` in front of conv_input) applied while converting, the permuted fp32 rows never written. */
+int fsf_to_planes_rows(const float* feat, int64_t m, int32_t c, int64_t row_stride, const int64_t* row_index, void* planes, float* scales,
+                       void* stream);
 int64_t fsf_spconv_planes_weight_bytes(int32_t kvol, int32_t cin, int32_t cout);
 int fsf_spconv_prepare_weight_planes(const float* weight, int32_t kvol, int32_t cin, int32_t cout, void* planes, void* stream);
 int fsf_spconv_forward_planes(const void* planes_a, const float* scales_a, int32_t ca, const void* planes_b,

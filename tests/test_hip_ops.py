@@ -1421,6 +1421,19 @@ def test_channel_pair_sum_add2_equals_the_op_on_the_concatenation(ops, device, n
     assert not ops.channel_pair_sum_add2_supported(torch.zeros(n, 12, device=device), torch.zeros(n, 4, device=device))
 
 
+@pytest.mark.parametrize("n,m,c", [(92639, 92639, 64), (5000, 777, 128), (300, 1, 256), (10, 0, 32)])
+def test_to_planes_rows_equals_to_planes_of_the_gathered_rows(ops, device, n, m, c):
+    """fsf_to_planes_rows (round 6): the planes of feat[row_index] — bit for bit what fsf_to_planes makes of the gathered rows (row-strided
+    source included), without writing them."""
+    torch.manual_seed(n + c)
+    wide = torch.randn(n, c + 8, device=device) * torch.exp(torch.randn(n, 1, device=device))
+    feat = wide[:, :c]
+    idx = torch.randperm(n, device=device)[:m] if m <= n else torch.randint(0, n, (m,), device=device)
+    want = ops.to_planes(feat.index_select(0, idx).contiguous())
+    got = ops.to_planes(feat, row_index=idx)
+    assert got.m == want.m == m and got.c == c and torch.equal(got.data, want.data) and torch.equal(got.scales, want.scales)
+
+
 @pytest.mark.parametrize("n,ca,cb", [(101119, 128, 128), (5003, 64, 64), (1, 128, 128), (0, 128, 128), (777, 256, 256), (4099, 32, 96)])
 def test_channel_pair_sum_add2_planes_equals_sum_then_to_planes(ops, device, n, ca, cb):
     """fsf_channel_pair_sum_add2_planes (round 6): the decoder shortcut leaving as planes for the level's upsampling convolution — the
