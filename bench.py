@@ -226,7 +226,7 @@ def step(model, inp, hot_path_only=False):
 
 def count_launch_sources(model, inp, hot_path_only=False):
     """How many things one frame asks the device / the host for, counted in ONE extra untimed frame: C-ABI calls
-    of libfsf_hip (each 1-12 kernel launches), ATen ops that do device work (non-view ops seen by a TorchDispatchMode, ~1 launch each)
+    of libfsf_hip (each 1-13 kernel launches; the stage drivers K30 / K31 more), ATen ops that do device work (non-view ops seen by a TorchDispatchMode, ~1 launch each)
     and host synchronisations the Python side can see (`.item()` / `bool()` / `int()` of a device tensor, `nonzero`, boolean-mask
     indexing, `torch.cuda.synchronize`, and the C-ABI calls that read a count back: fsf_unique_rows, fsf_rulebook_strided, fsf_cluster_key_survival).  The exact
     kernel-launch count needs a trace: `kernel_launches_per_frame_rocprof` is read from the newest committed
@@ -297,7 +297,7 @@ def count_launch_sources(model, inp, hot_path_only=False):
                 break
     return dict(c_abi_calls_per_frame=counts["cabi"], aten_device_ops_per_frame=counts["aten"], host_syncs_per_frame=counts["sync"],
                 kernel_launches_per_frame_rocprof=traced,
-                note="counted in one extra untimed frame with both query branches on one host thread; a C-ABI call is 1-12 launches")
+                note="counted in one extra untimed frame with both query branches on one host thread; a C-ABI call is 1-13 launches (a stage driver — K30, K31 — more)")
 
 
 def describe_output(model, inp, out, args):
@@ -775,11 +775,18 @@ def instrumented_pass(model, pool, steps, hot_path_only):
     q.wrap(hip_ops, "rows_to_planes", _acc_rows_to_planes)
     if hasattr(hip_ops, "project_score"):
         q.wrap(hip_ops, "project_score", _acc_project_score)
+    # (the capture counts the calls of hip_ops' wrappers: for this one untimed frame the SIR stacks run kernel by kernel from Python
+    # instead of through fsf_sir_stack_forward, K31 — the same kernels with the same arguments, tests/test_sir_stack_gpu.py)
+    stacks = [m for m in model.modules() if getattr(m, "native_stack", None) is True or type(m).__name__ == "FullySparseBboxHead"]
+    for m in stacks:
+        m.native_stack = False
     try:
         step(model, pool[0], hot_path_only)
         torch.cuda.synchronize()
     finally:
         q.restore()
+        for m in stacks:
+            m.native_stack = True
     hbm = q.table()
     return conv, hbm
 
