@@ -156,6 +156,26 @@ class SimpleSparseUNet(nn.Module):
         return meta
 
     def forward(self, voxel_info, batch_size=None):
+        return self.finish(self.begin(voxel_info, batch_size))
+
+    def begin(self, voxel_info, batch_size=None):
+        """The part of `forward` in front of `conv_input`: the row order, the first level's index plan (on the plan stream) and the
+        network's input in that order — everything that can be issued before the main stream has room for the first convolution.
+        `finish(begin(...))` is `forward`; a caller that knows the next frame early (FSF.set_next_frame) runs `begin` on a side
+        stream under the previous frame's tail.  The streams `finish` runs on are the ones current THEN."""
+        steps = self._forward_steps(voxel_info, batch_size)
+        next(steps)
+        return steps
+
+    @staticmethod
+    def finish(steps):
+        try:
+            next(steps)
+        except StopIteration as done:
+            return done.value
+        raise RuntimeError("SimpleSparseUNet.finish: the forward did not end")
+
+    def _forward_steps(self, voxel_info, batch_size=None):
         raw_coors = voxel_info["voxel_coors"]
         voxel_features = voxel_info["voxel_feats"]
 
@@ -241,7 +261,7 @@ class SimpleSparseUNet(nn.Module):
                         held.append(t)
                 ev = torch.cuda.Event()
                 ev.record(ps)
-                main.wait_event(ev)
+                torch.cuda.current_stream().wait_event(ev)  # (the stream current NOW: `begin` may have run on another one)
                 mark("plan published", ps)
 
             with torch.cuda.stream(ps):
@@ -265,6 +285,7 @@ class SimpleSparseUNet(nn.Module):
                 coors = coors.index_select(0, perm64)
             x = self._permuted_input(voxel_features, perm64 if reorder else None, coors, batch_size)
             x.indice_dict["__mask_order__"] = reorder  # (the dict is shared by every tensor derived from x)
+        yield  # ---- `begin` ends here
         mark("conv_input starts")
         x = self.conv_input(x)
         encode_features = []

@@ -368,6 +368,9 @@ class SparseClusterHeadV2(SparseClusterHead):
         buf = hip_ops.nms_select(boxes, scores_t, order, keep, num, max_num, max_num, self._label_lut(task_id, cls_logits.device),
                                  incomplete)
         d = boxes.size(1)
+        hook = self.__dict__.pop("_before_readback", None)
+        if hook is not None:
+            hook()  # (FSF: the next frame's front, issued while the device works through this frame's tail)
         host = buf.cpu()  # the frame's one read-back for the box tail: rows + (rows written, boxes kept, incomplete)
         meta = host[max_num * (d + 2):].view(torch.int32)
         if int(meta[2]) != 0:  # a class ran out of its mask window before max_num keeps (never seen): the generic path repeats it in full

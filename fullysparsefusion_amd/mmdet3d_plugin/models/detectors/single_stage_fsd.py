@@ -86,11 +86,23 @@ class VoteSegmentor(nn.Module):
         return self.voxel_layer.forward_batch(points)
 
     def extract_feat(self, points, img_metas):
+        return self.extract_feat_finish(self.extract_feat_begin(points))
+
+    def extract_feat_begin(self, points):
+        """`extract_feat` up to the backbone's first convolution (:226-234): voxelization, DynamicScatterVFE, the voxel dict and — where
+        the backbone splits its forward (SimpleSparseUNet.begin) — its row order, first index plan and input planes.  A chain of ~60
+        small launches with one host wait (the voxel count): the part of a frame the HOST bounds.  `extract_feat_finish` runs the rest."""
         batch_points, coors = self.voxelize(points)
         self.voxel_encoder.max_batch = len(points)
         voxel_features, voxel_coors, voxel2point_inds = self.voxel_encoder(batch_points, coors, return_inv=True)
         voxel_info = self.middle_encoder(voxel_features, voxel_coors, batch_size=len(points))
-        x = self.backbone(voxel_info)[0]
+        steps = self.backbone.begin(voxel_info) if hasattr(self.backbone, "begin") else None
+        return dict(batch_points=batch_points, coors=coors, voxel2point_inds=voxel2point_inds, voxel_info=voxel_info, backbone_steps=steps)
+
+    def extract_feat_finish(self, front):
+        batch_points, coors, voxel2point_inds = front["batch_points"], front["coors"], front["voxel2point_inds"]
+        voxel_info, steps = front["voxel_info"], front["backbone_steps"]
+        x = (self.backbone.finish(steps) if steps is not None else self.backbone(voxel_info))[0]
         padding = -1
         assert "shuffle_inds" not in voxel_info  # SST-only branch (:238-241)
         permuted = getattr(x, "permuted", None)
@@ -122,9 +134,12 @@ class VoteSegmentor(nn.Module):
         return points
 
     def simple_test(self, points, img_metas, gt_bboxes_3d=None, gt_labels_3d=None, extract_feat_only=False,
-                    rescale=False):
-        points = self._prep(points)
-        x, pts_coors, points = self.extract_feat(points, img_metas)
+                    rescale=False, front=None):
+        if front is not None:  # (FSF's frame front: `_prep` + `extract_feat_begin` already ran on these points)
+            x, pts_coors, points = self.extract_feat_finish(front)
+        else:
+            points = self._prep(points)
+            x, pts_coors, points = self.extract_feat(points, img_metas)
         if extract_feat_only:
             return x, pts_coors, points
         feats, valid_pts_mask = x[0], x[1]

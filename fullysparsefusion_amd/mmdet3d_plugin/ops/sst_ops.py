@@ -141,6 +141,14 @@ def clear_unique_cache():
     del _unique_entries()[:]
 
 
+def swap_unique_cache(entries):
+    """Replace this thread's cached uniques by `entries` and return the ones that were there (FSF's frame front runs inside the frame
+    before its own and must neither see nor evict that frame's entries; what it caches travels with its state)."""
+    old = list(_unique_entries())
+    _unique_entries()[:] = entries
+    return old
+
+
 def plan_of(unq_inv, num_segments):
     plan = getattr(unq_inv, _PLAN_ATTR, None)
     if plan is None or plan.m != num_segments:
