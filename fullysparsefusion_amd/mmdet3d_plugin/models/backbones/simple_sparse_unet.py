@@ -155,12 +155,18 @@ class SimpleSparseUNet(nn.Module):
                     meta = meta._like(None, rb.out_indices, rb.out_shape)
         return meta
 
+    # Encoder levels `begin` runs.  Issued under the previous frame's tail (FSF.set_next_frame) the first levels' convolutions fill the
+    # CUs its NMS / box-tail launches leave idle; same-box interleaved A/B on the 10-sweep frame (tools/profiling/frame_front_ab.py,
+    # unannounced - announced): 0 levels (up to the input planes) 0.36-0.46 ms, 1 level 0.24-0.53, 2 levels 0.53-0.72, 3 levels 0.55-0.85,
+    # 4 levels 0.59 — from the third level on the host waits of the index plan keep the frame's results waiting for nothing more
+    BEGIN_LEVELS = 2
+
     def forward(self, voxel_info, batch_size=None):
         return self.finish(self.begin(voxel_info, batch_size))
 
     def begin(self, voxel_info, batch_size=None):
-        """The part of `forward` in front of `conv_input`: the row order, the first level's index plan (on the plan stream) and the
-        network's input in that order — everything that can be issued before the main stream has room for the first convolution.
+        """The first part of `forward`: the row order, the first levels' index plans (on the plan stream), the network's input in that
+        order, `conv_input` and the first BEGIN_LEVELS encoder levels.
         `finish(begin(...))` is `forward`; a caller that knows the next frame early (FSF.set_next_frame) runs `begin` on a side
         stream under the previous frame's tail.  The streams `finish` runs on are the ones current THEN."""
         steps = self._forward_steps(voxel_info, batch_size)
@@ -285,7 +291,6 @@ class SimpleSparseUNet(nn.Module):
                 coors = coors.index_select(0, perm64)
             x = self._permuted_input(voxel_features, perm64 if reorder else None, coors, batch_size)
             x.indice_dict["__mask_order__"] = reorder  # (the dict is shared by every tensor derived from x)
-        yield  # ---- `begin` ends here
         mark("conv_input starts")
         x = self.conv_input(x)
         encode_features = []
@@ -294,6 +299,8 @@ class SimpleSparseUNet(nn.Module):
             mark(f"encoder level {level} starts")
             x = encoder_layer(x)
             encode_features.append(x)
+            if level == min(self.BEGIN_LEVELS, len(levels)):
+                yield  # ---- `begin` ends here
             if plan_on and level < len(levels):  # the next level's tables, while the main stream runs this level's convolutions
                 with torch.cuda.stream(ps):
                     meta = self._plan_modules(meta, levels[level])
