@@ -120,7 +120,7 @@ def make_inputs(sweeps, seed, device, frames=1, dataset="nuscenes", trained_like
     return fs[0], dev
 
 
-def h2d_inclusive(model, sweeps, seeds, device, steps, warmup, ms_resident):
+def h2d_inclusive(model, sweeps, seeds, device, steps, warmup, ms_resident, announce=True):
     """The boundary hands over HOST buffers (`datasets/pipelines.py::frame_to_device`: points f32 [n, 8], the u8 id planes
     [1, 6, 10, 900, 1600] exactly as LoadMaskFromFiles leaves them, mask_anno, lidar2img — datasets/pipelines/loading.py:213-234,
     :301-339, :781-877): the same forward with every frame starting in PINNED host memory.  Two device slots; frame i + 1's copies are
@@ -157,7 +157,7 @@ def h2d_inclusive(model, sweeps, seeds, device, steps, warmup, ms_resident):
             sl["lidar2img"].copy_(h["lidar2img"], non_blocking=True)
             ready[i % 2].record(copy_stream)
         return dict(points=[sl["points"][:n]], mask_data=sl["mask_data"], mask_anno=sl["mask_anno"][:, :a],
-                    img_metas=[dict(lidar2img=sl["lidar2img"])])
+                    img_metas=[dict(lidar2img=sl["lidar2img"])], ready=ready[i % 2])
 
     def loop(k):
         nxt = upload(0)
@@ -166,7 +166,8 @@ def h2d_inclusive(model, sweeps, seeds, device, steps, warmup, ms_resident):
             if i + 1 < k:
                 nxt = upload(i + 1)  # (behind frame i: issued before its forward, on the copy stream)
             main.wait_event(ready[i % 2])
-            step(model, cur)
+            # (frame i + 1 is announced with its upload's event: the detector's front stream waits for the copy, not the host)
+            step(model, cur, nxt=nxt if announce and i + 1 < k else None)
             free[i % 2].record(main)
 
     loop(max(warmup, 2))
@@ -225,7 +226,7 @@ def step(model, inp, hot_path_only=False, nxt=None):
     (voxelization, VFE, first index plan) is issued on a side stream while this step's host thread waits for its results."""
     with torch.no_grad():
         if nxt is not None:
-            model.set_next_frame(nxt["points"], nxt["img_metas"], nxt["mask_data"], nxt["mask_anno"])
+            model.set_next_frame(nxt["points"], nxt["img_metas"], nxt["mask_data"], nxt["mask_anno"], ready=nxt.get("ready"))
         if hot_path_only:
             return model.forward_hot_path(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
         return model.simple_test(inp["points"], inp["img_metas"], inp["mask_data"], inp["mask_anno"])
@@ -1169,7 +1170,7 @@ def main():
             and args.dataset == "nuscenes" and args.frames_per_gpu == 1):
         # BESIDE the headline: the same forward with every frame handed over as host buffers (PCIe-inclusive rate)
         result["h2d"] = h2d_inclusive(model, args.sweeps, [rank * 131 + j for j in range(nframes)], device, args.steps, args.warmup,
-                                      ms_plain)  # (its loop announces nothing: compared with the unannounced resident loop)
+                                      result["ms_per_step"], announce=not args.no_frame_front)
     if (rank == 0 and world == 1 and not (args.train or args.hot_path_only or args.trained_like or args.no_trained_like)
             and args.dataset == "nuscenes" and args.frames_per_gpu == 1):
         # BESIDE the headline: the same forward on the trained-like variant (see calibrate_trained_like)
@@ -1182,7 +1183,7 @@ def main():
         t0 = time.perf_counter()
         k2 = 10
         for i in range(k2):
-            out2 = step(m2, pool2[i % 2])
+            out2 = step(m2, pool2[i % 2], nxt=None if args.no_frame_front else pool2[(i + 1) % 2])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / k2
         hot2 = step(m2, pool2[(k2 - 1) % 2], hot_path_only=True)

@@ -591,10 +591,11 @@ class FSF(SingleStageFSD):
     # before is the host idling in the box tail's read-back while the device runs a queue of heads / NMS launches.  A caller that
     # knows the next frame (`set_next_frame`: a test loop's data loader does) gets that frame's front issued on a side stream inside
     # that wait: same kernels on the same inputs in the same order, only earlier (bit-identical, tests/test_frame_front_gpu.py).
-    def set_next_frame(self, points, img_metas, mask_data, mask_anno):
+    def set_next_frame(self, points, img_metas, mask_data, mask_anno, ready=None):
         """Announce the arguments of the NEXT `simple_test` / `forward_hot_path` call (one sample, inference).  Optional: a call that
-        was not announced — or announced with other tensors — computes its front in place as before."""
-        self._next_frame = (points, img_metas, mask_data, mask_anno)
+        was not announced — or announced with other tensors — computes its front in place as before.  `ready`: an event behind which
+        the tensors hold the frame (an upload still in flight on a copy stream); the front stream waits for it."""
+        self._next_frame = (points, img_metas, mask_data, mask_anno, ready)
 
     @staticmethod
     def _frame_key(points, img_metas, mask_data, mask_anno):
@@ -624,7 +625,7 @@ class FSF(SingleStageFSD):
         self._front_ready = None
         if nf is None:
             return
-        points, img_metas, mask_data, mask_anno = nf
+        points, img_metas, mask_data, mask_anno, ready = nf
         if (self.training or torch.is_grad_enabled() or self.voxel_downsampling_size is not None or len(points) != 1
                 or not points[0].is_cuda or getattr(self.segmentor, "tanh_dims", None) != [] or torch.cuda.is_current_stream_capturing()):
             return  # (in-place point transforms / the downsampling unique stay inside their own frame)
@@ -635,6 +636,8 @@ class FSF(SingleStageFSD):
         mine = swap_unique_cache([])
         try:
             key = self._frame_key(points, img_metas, mask_data, mask_anno)
+            if ready is not None:
+                side.wait_event(ready)
             with torch.cuda.stream(side):
                 state = self._frame_front(points, img_metas, mask_data, mask_anno)
                 ev = torch.cuda.Event()
