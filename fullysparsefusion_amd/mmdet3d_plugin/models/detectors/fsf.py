@@ -395,11 +395,15 @@ class FSF(SingleStageFSD):
         and every layer of `segmentor_updated_mlp` but the last — issued BEFORE the segmentor.  The frame's first half millisecond
         is the host's (results to the host, the voxel unique's read-back): these ~250 us of kernels run inside it instead of behind
         the U-Net.  Same kernels on the same inputs, only earlier."""
-        self._img_pre = None
+        self._img_pre = self._image_branch_table(point_infos, mask_anno, mask_data, img_metas)
+
+    def _image_branch_table(self, point_infos, mask_anno, mask_data, img_metas):
+        """(`_prefetch_image_branch`'s work as a function of its arguments: no attribute of `self` is written — the frame front may run
+        on another host thread while the frame before still reads ITS table)"""
         if (torch.is_grad_enabled() or self.is_argo or self.encode_label_only or mask_anno.shape[0] != 1 or len(point_infos) != 1
                 or mask_data.shape[2] > hip_ops.PROJECT_SCORE_MAX_CLS or mask_data.dtype not in (torch.uint8, torch.int32)
                 or not point_infos[0].is_cuda):
-            return
+            return None
         info = point_infos[0]
         lidar2img = torch.as_tensor(img_metas[0]["lidar2img"], dtype=torch.float32, device=info.device)
         score, fg, overlap = hip_ops.project_score(info[:, :3], lidar2img, mask_data[0], mask_anno[0], score_col=4, return_overlap=True)
@@ -409,8 +413,8 @@ class FSF(SingleStageFSD):
             hidden = score
             for layer in list(mlp)[:-1]:
                 hidden = layer(hidden)
-        self._img_pre = dict(info=info, version=info._version, mask_data=mask_data, mask_anno=mask_anno, lidar2img=lidar2img, score=score,
-                             fg=fg, overlap=overlap, mlp=mlp, hidden=hidden)
+        return dict(info=info, version=info._version, mask_data=mask_data, mask_anno=mask_anno, lidar2img=lidar2img, score=score,
+                    fg=fg, overlap=overlap, mlp=mlp, hidden=hidden)
 
     def segmentor_feat_inhance_test(self, seg_out_tuple, point_infos, mask_anno, mask_data, img_metas):
         (neck_out, pts_coors, points) = seg_out_tuple
@@ -609,18 +613,21 @@ class FSF(SingleStageFSD):
     def _frame_front(self, points, img_metas, mask_data, mask_anno):
         """simple_test (:1114-1126) up to the backbone's first convolution, on the current stream."""
         points, point_infos = self.split_points_last_3dim(points)
-        self._prefetch_image_branch(point_infos, mask_anno, mask_data, img_metas)
+        img_pre = self._image_branch_table(point_infos, mask_anno, mask_data, img_metas)
         seg = self.segmentor
         if hasattr(seg, "extract_feat_begin"):
             seg_front, points = seg.extract_feat_begin(seg._prep(points)), None
         else:
             seg_front = None
-        return dict(points=points, point_infos=point_infos, img_pre=self._img_pre, seg_front=seg_front)
+        return dict(points=points, point_infos=point_infos, img_pre=img_pre, seg_front=seg_front)
 
     def _prefetch_front(self):
         """Issue the announced frame's front on the front stream (called where this frame's host thread is about to wait for the
-        device: right before the box tail's read-back, or at the end of the frame).  The frame-scoped caches of THIS frame are put
-        aside and restored; what the front left in them travels with its state."""
+        device: right before the box tail's read-back, or at the end of the frame).  `_frame_front` writes no attribute of `self`; the
+        per-thread unique cache of the frame still running is put aside and restored, what the front left in it travels with its state.
+        (Handed to the process's worker thread behind the RoI pooling's read-back instead — 2 ms earlier, the calling thread going on
+        with the refine stage: 12.95 against 12.97 ms unannounced on the 10-sweep frame, 8.7 against 7.5 on the 1-sweep one — two
+        threads issuing launches through one interpreter lock; docs/kernels/K32_frame_front.md.)"""
         nf = self.__dict__.pop("_next_frame", None)
         self._front_ready = None
         if nf is None:
@@ -632,22 +639,23 @@ class FSF(SingleStageFSD):
         if getattr(self, "_front_stream", None) is None:
             self._front_stream = torch.cuda.Stream()  # (normal priority: at high priority its launches hold up the tail and the loop is 3 % SLOWER than unannounced)
         side = self._front_stream
-        saved = (self._img_pre, self._fg_cache, self._gather_cache)
-        mine = swap_unique_cache([])
-        try:
-            key = self._frame_key(points, img_metas, mask_data, mask_anno)
-            if ready is not None:
-                side.wait_event(ready)
-            with torch.cuda.stream(side):
-                state = self._frame_front(points, img_metas, mask_data, mask_anno)
-                ev = torch.cuda.Event()
-                ev.record(side)
-            self._front_ready = dict(key=key, state=state, event=ev, unique=swap_unique_cache(mine))
-            mine = None
-        finally:
-            if mine is not None:
+        key = self._frame_key(points, img_metas, mask_data, mask_anno)
+
+        def work():
+            mine = swap_unique_cache([])  # (this THREAD's entries)
+            try:
+                if ready is not None:
+                    side.wait_event(ready)
+                with torch.no_grad(), torch.cuda.stream(side):
+                    state = self._frame_front(points, img_metas, mask_data, mask_anno)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                return dict(key=key, state=state, event=ev, unique=swap_unique_cache(mine))
+            except BaseException:
                 swap_unique_cache(mine)
-            self._img_pre, self._fg_cache, self._gather_cache = saved
+                raise
+
+        self._front_ready = work()
 
     def _take_front(self, points, img_metas, mask_data, mask_anno):
         """This frame's front: the prefetched one if it was made from exactly these tensors, else computed here."""
@@ -668,7 +676,9 @@ class FSF(SingleStageFSD):
             if steps is not None:
                 steps.close()
         self._front_hold = None
-        return self._frame_front(points, img_metas, mask_data, mask_anno)
+        state = self._frame_front(points, img_metas, mask_data, mask_anno)
+        self._img_pre = state["img_pre"]
+        return state
 
     def _segment(self, points, img_metas, mask_data, mask_anno):
         """Stage 1 (:1114-1126): the segmentor's features with the image branch mixed in; returns (seg_out_dict, point_infos)."""
