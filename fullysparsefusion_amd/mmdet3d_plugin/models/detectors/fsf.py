@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from .... import hip_ops
 from ...ops.sst_ops import (GatheredRows, RowsMinusGroup, build_mlp, clear_unique_cache, gather_by_inverse, point_linear_add, scatter_v2,
-                            swap_unique_cache, with_key_bounds)
+                            swap_unique_cache, unique_with_plan, with_key_bounds)
 from ...core.bbox import bbox3d2result
 from ...registry import BBOX_CODERS, DETECTORS, build_head, build_roi_extractor
 from .single_stage_fsd import SingleStageFSD
@@ -688,7 +688,38 @@ class FSF(SingleStageFSD):
         point_infos = front["point_infos"]
         seg_out_tuple = self.segmentor.simple_test(front["points"], img_metas, extract_feat_only=True, rescale=False,
                                                    front=front["seg_front"])
+        self._pre_voxel_keys_early(seg_out_tuple, front["seg_front"], img_metas)
         return self.segmentor_feat_inhance_test(seg_out_tuple, point_infos, mask_anno, mask_data, img_metas), point_infos
+
+    def _pre_voxel_keys_early(self, seg_out_tuple, seg_front, img_metas):
+        """`pre_voxelize`'s 0.1 m keys and their unique (single_stage_fsd.py:585-599) depend on the points alone, not on anything the
+        segmentor computes — and stood at the head of the LiDAR-query branch with a host wait behind the WHOLE segmentor: the branch's
+        first launches (the field means, the clustering front end) could only be issued once the device had drained, ~0.4 ms of
+        interpreter time with nothing queued.  Here they are formed on the front stream right after the U-Net and the neck have been
+        issued (the host is ~2 ms ahead of the device at this point and would spend them in that very wait); `pre_voxelize` finds them
+        (same key tensor, same unique — tests/test_frame_front_gpu.py) and issues what follows while the segmentor is still running."""
+        self._pre_vox = None
+        size = self.cfg.get("pre_voxelization_size", None) if self.cfg is not None else None
+        points, coors = seg_out_tuple[2], seg_out_tuple[1]
+        ready = getattr(seg_front["voxel_info"]["voxel_coors"], "_fsf_ready_event", None) if seg_front is not None else None
+        if (size is None or ready is None or self.training or torch.is_grad_enabled() or not points.is_cuda or points.dtype != torch.float32
+                or img_metas is None or torch.cuda.is_current_stream_capturing()):
+            return
+        if getattr(self, "_front_stream", None) is None:
+            self._front_stream = torch.cuda.Stream()
+        side = self._front_stream
+        side.wait_event(ready)  # (recorded behind the voxel unique: the points and their coordinates exist)
+        mine = swap_unique_cache([])
+        try:
+            with torch.cuda.stream(side):
+                keys = self.pre_voxel_keys(points, coors[:, 0], len(img_metas))
+                res = unique_with_plan(keys)
+                ev = torch.cuda.Event()
+                ev.record(side)
+        finally:
+            swap_unique_cache(mine)
+        # (held until the next frame's: the front stream's allocator must not re-use these blocks while this frame reads them)
+        self._pre_vox = self._pre_vox_hold = dict(points=points, batch_ptr=coors.data_ptr(), keys=keys, res=res, event=ev)
 
     def forward_hot_path(self, points, img_metas, mask_data, mask_anno):
         """Stages 1-3 of simple_test (:1114-1144): segmentation + image fusion, camera queries, LiDAR queries —

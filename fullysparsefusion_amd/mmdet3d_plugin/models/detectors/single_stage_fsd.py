@@ -16,7 +16,7 @@ from torch import nn
 
 from .... import hip_ops
 from ...ops.sst_ops import (GatheredRows, RowsMinusGroup, gather_by_inverse, get_inner_win_inds, scatter_mean_multi, scatter_v2, seed_unique_cache,
-                            unique_with_plan, with_key_bounds)
+                            seed_unique_result, unique_with_plan, with_key_bounds)
 from ...ops.voxel import Voxelization
 from ...registry import (DETECTORS, SEGMENTORS, build_backbone, build_detector, build_head, build_middle_encoder,
                          build_neck, build_voxel_encoder)
@@ -402,18 +402,30 @@ class SingleStageFSD(nn.Module):
     def combine_classes(self, data_dict, name_list):
         return {name: torch.cat(data_dict[name], 0) for name in data_dict if name in name_list}
 
-    def pre_voxelize(self, data_dict):
-        """:585-605 — torch.div-floor 0.1 m keys (zyx + batch), ONE unique, mean of every float field."""
-        batch_idx = data_dict["batch_idx"]
-        points = data_dict["seg_points"]
+    def pre_voxel_keys(self, points, batch_idx, bsz):
+        """:585-591 — the (batch, z, y, x) div-floor keys of `pre_voxelize`, with the bounds the unique packs its sort key from."""
         coors = hip_ops.voxelize_divfloor(points, self.cfg["pre_voxelization_size"],
                                           self.cluster_assigner.point_cloud_range[:3], order="zyx", batch_idx=batch_idx)
-        bsz = getattr(self, "_batch_size_hint", None)
         if bsz is not None:  # (batch, z, y, x) cells of the cluster assigner's range, a few cells of slack either side
             rng, vs = self.cluster_assigner.point_cloud_range, self.cfg["pre_voxelization_size"]
             cells = [int(math.ceil((rng[3 + a] - rng[a]) / vs[a])) for a in (2, 1, 0)]
             with_key_bounds(coors, [0, -8, -8, -8], [bsz - 1] + [c + 8 for c in cells])
-        new_coors, unq_inv, _ = unique_with_plan(coors)
+        return coors
+
+    def pre_voxelize(self, data_dict):
+        """:585-605 — torch.div-floor 0.1 m keys (zyx + batch), ONE unique, mean of every float field."""
+        batch_idx = data_dict["batch_idx"]
+        points = data_dict["seg_points"]
+        pre = self.__dict__.pop("_pre_vox", None)
+        if (pre is not None and pre["points"] is points and batch_idx.data_ptr() == pre["batch_ptr"] and batch_idx.dim() == 1
+                and batch_idx.size(0) == points.size(0) and not torch.is_grad_enabled()):
+            # (FSF._pre_voxel_keys_early: the same keys and their unique, formed on the front stream while the segmentor ran)
+            torch.cuda.current_stream().wait_event(pre["event"])
+            coors, (new_coors, unq_inv, _) = pre["keys"], pre["res"]
+            seed_unique_result(coors, pre["res"])
+        else:
+            coors = self.pre_voxel_keys(points, batch_idx, getattr(self, "_batch_size_hint", None))
+            new_coors, unq_inv, _ = unique_with_plan(coors)
         # (upstream: one scatter_v2(.., mode='avg') per float field over the shared unique; here the fields go through one launch)
         names = [name for name, data in data_dict.items() if data.dtype in (torch.float, torch.float16)]
         voxelized = dict(zip(names, scatter_mean_multi([data_dict[n] for n in names], new_coors, unq_inv)))

@@ -141,6 +141,17 @@ def clear_unique_cache():
     del _unique_entries()[:]
 
 
+def seed_unique_result(coors, res):
+    """Enter `res` = what `unique_with_plan(coors)` returned on another stream / at another time as this thread's newest entry."""
+    if not (_UNIQUE_CACHE_SIZE > 0 and coors.is_cuda and not torch.is_grad_enabled()):
+        return
+    b = getattr(coors, _BOUNDS_ATTR, None)
+    key = (None, None) if b is None else (tuple(b[0]), tuple(b[1]))
+    entries = _unique_entries()
+    entries.append((coors, coors._version, key, res))
+    del entries[:-_UNIQUE_CACHE_SIZE]
+
+
 def swap_unique_cache(entries):
     """Replace this thread's cached uniques by `entries` and return the ones that were there (FSF's frame front runs inside the frame
     before its own and must neither see nor evict that frame's entries; what it caches travels with its state)."""

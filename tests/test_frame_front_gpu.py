@@ -120,3 +120,27 @@ def test_training_mode_and_grad_mode_never_prefetch(model, frames):
     with torch.enable_grad():
         model._prefetch_front()
     assert model._front_ready is None and "_next_frame" not in model.__dict__
+
+
+def test_pre_voxelize_keys_formed_early_equal_the_ones_formed_in_place(model, frames, plain):
+    """`FSF._pre_voxel_keys_early` (the 0.1 m keys + their unique on the front stream while the segmentor runs) against
+    `pre_voxelize` forming them itself: the same boxes bit for bit, and the early form is the one the default path takes."""
+    used = []
+    orig = model.pre_voxelize
+
+    def spying(d):
+        used.append(model.__dict__.get("_pre_vox") is not None)
+        return orig(d)
+
+    model.pre_voxelize = spying
+    try:
+        _loop(model, frames, ORDER[:3], announce=False)
+    finally:
+        del model.__dict__["pre_voxelize"]
+    assert used == [True] * 3
+    model._pre_voxel_keys_early = lambda *a, **k: None
+    try:
+        _same(plain, _loop(model, frames, ORDER, announce=False))
+        _same(plain, _loop(model, frames, ORDER, announce=True))
+    finally:
+        del model.__dict__["_pre_voxel_keys_early"]
