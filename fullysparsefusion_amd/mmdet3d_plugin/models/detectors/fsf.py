@@ -26,7 +26,7 @@ import torch.nn.functional as F
 
 from .... import hip_ops
 from ...ops.sst_ops import (GatheredRows, RowsMinusGroup, build_mlp, clear_unique_cache, gather_by_inverse, point_linear_add, scatter_v2,
-                            swap_unique_cache, unique_with_plan, with_key_bounds)
+                            seed_unique_result, swap_unique_cache, unique_with_plan, with_key_bounds)
 from ...core.bbox import bbox3d2result
 from ...registry import BBOX_CODERS, DETECTORS, build_head, build_roi_extractor
 from .single_stage_fsd import SingleStageFSD
@@ -413,8 +413,10 @@ class FSF(SingleStageFSD):
             hidden = score
             for layer in list(mlp)[:-1]:
                 hidden = layer(hidden)
+        ready = torch.cuda.Event()
+        ready.record()
         return dict(info=info, version=info._version, mask_data=mask_data, mask_anno=mask_anno, lidar2img=lidar2img, score=score,
-                    fg=fg, overlap=overlap, mlp=mlp, hidden=hidden)
+                    fg=fg, overlap=overlap, mlp=mlp, hidden=hidden, ready=ready)
 
     def segmentor_feat_inhance_test(self, seg_out_tuple, point_infos, mask_anno, mask_data, img_metas):
         (neck_out, pts_coors, points) = seg_out_tuple
@@ -459,14 +461,22 @@ class FSF(SingleStageFSD):
                 # img_cross_attn's kernel already emitted: two C-ABI calls, one read-back (was: nonzero, a second projection of the
                 # foreground points into an [F, cams * classes] int64 tensor, ~45 ATen launches, three host syncs)
                 fg_u8, count_u8, max_id = fgc[3]
-                num_fg, num_multi, num_extra, ws = hip_ops.overlap_plan(fg_u8, count_u8, ncells)
-                rows = None
-                if num_fg > 0:
-                    rows = hip_ops.overlap_rows(points_info_flat[:, :3], fgc[4], mask_data[0], max_id, None, ws, num_fg, num_multi,
-                                                num_extra)
-                    # (sample, 0, instance id): ids index mask_anno's rows; a u8 plane cannot hold more than 255 either way
-                    top = mask_anno.shape[1] if mask_data.dtype != torch.uint8 else 255
-                    with_key_bounds(rows[1], [0, 0, 0], [0, 0, max(int(top), 1)])
+                early = self.__dict__.pop("_cam_rows", None)
+                if early is not None and early["overlap"] is fgc[3] and early["info"] is points_info_flat:
+                    # (_camera_rows_early: the same rows and the unique of their keys, formed while the segmentor ran)
+                    torch.cuda.current_stream().wait_event(early["event"])
+                    rows = early["rows"]
+                    if rows is not None:
+                        seed_unique_result(rows[1], early["res"])
+                else:
+                    num_fg, num_multi, num_extra, ws = hip_ops.overlap_plan(fg_u8, count_u8, ncells)
+                    rows = None
+                    if num_fg > 0:
+                        rows = hip_ops.overlap_rows(points_info_flat[:, :3], fgc[4], mask_data[0], max_id, None, ws, num_fg, num_multi,
+                                                    num_extra)
+                        # (sample, 0, instance id): ids index mask_anno's rows; a u8 plane cannot hold more than 255 either way
+                        top = mask_anno.shape[1] if mask_data.dtype != torch.uint8 else 255
+                        with_key_bounds(rows[1], [0, 0, 0], [0, 0, max(int(top), 1)])
                 lidar_feat, obj_coors, obj_centers = self.frustum_pooling(pts_feat, batch_idx.unsqueeze(-1), points, None,
                                                                           point_fg_weights, img_metas, cluster_center, rows=rows)
             else:
@@ -531,12 +541,7 @@ class FSF(SingleStageFSD):
         outs = self.bbox_head(cluster_feats) if run_head else None
         return cluster_feats, cluster_xyz, cluster_inds, outs
 
-    def _query_branches(self, camera_branch, lidar_branch, n_points=None):
-        """Run the camera-query and LiDAR-query branches (FSF.py:1127-1144 runs them back to back; they only share the
-        read-only segmentor output) CONCURRENTLY at inference: the camera branch on a side HIP stream driven by a second
-        host thread.  Both are chains of small launches with data-dependent sizes — ~25 host syncs between them, each a
-        drained GPU — so the two streams fill each other's bubbles and idle CUs.  Every C-ABI call takes torch's
-        (thread-local) current stream and a per-stream workspace; ctypes and torch release the GIL while they wait."""
+    def _branches_concurrent(self, n_points):
         on_gpu = torch.cuda.is_available() and next(self.parameters()).is_cuda
         want = (self.test_cfg or {}).get("concurrent_query_branches", "auto")
         if want == "auto":
@@ -544,7 +549,15 @@ class FSF(SingleStageFSD):
             # few microseconds) the hand-overs between them cost more than the overlap buys — same box, interleaved
             # (tools/profiling/gil_ab.py): 1-sweep 8.0-9.4 ms on two threads, 7.7-8.0 on one; 10-sweep 13.5-13.8 against 14.4-14.7
             want = n_points is None or n_points >= (self.test_cfg or {}).get("concurrent_query_min_points", 100000)
-        if self.training or not on_gpu or not want:
+        return bool(want) and on_gpu and not self.training
+
+    def _query_branches(self, camera_branch, lidar_branch, n_points=None):
+        """Run the camera-query and LiDAR-query branches (FSF.py:1127-1144 runs them back to back; they only share the
+        read-only segmentor output) CONCURRENTLY at inference: the camera branch on a side HIP stream driven by a second
+        host thread.  Both are chains of small launches with data-dependent sizes — ~25 host syncs between them, each a
+        drained GPU — so the two streams fill each other's bubbles and idle CUs.  Every C-ABI call takes torch's
+        (thread-local) current stream and a per-stream workspace; ctypes and torch release the GIL while they wait."""
+        if not self._branches_concurrent(n_points):
             return camera_branch(), lidar_branch()
         main = torch.cuda.current_stream()
         if getattr(self, "_side_stream", None) is None:
@@ -689,6 +702,7 @@ class FSF(SingleStageFSD):
         seg_out_tuple = self.segmentor.simple_test(front["points"], img_metas, extract_feat_only=True, rescale=False,
                                                    front=front["seg_front"])
         self._pre_voxel_keys_early(seg_out_tuple, front["seg_front"], img_metas)
+        self._camera_rows_early(front, mask_anno, mask_data)
         return self.segmentor_feat_inhance_test(seg_out_tuple, point_infos, mask_anno, mask_data, img_metas), point_infos
 
     def _pre_voxel_keys_early(self, seg_out_tuple, seg_front, img_metas):
@@ -720,6 +734,45 @@ class FSF(SingleStageFSD):
             swap_unique_cache(mine)
         # (held until the next frame's: the front stream's allocator must not re-use these blocks while this frame reads them)
         self._pre_vox = self._pre_vox_hold = dict(points=points, batch_ptr=coors.data_ptr(), keys=keys, res=res, event=ev)
+
+    def _camera_rows_early(self, front, mask_anno, mask_data):
+        """The camera-query branch's row list — which points lie inside a mask, the duplicates of points inside several, their
+        (sample, 0, instance id) keys (FSF.py:299-308, :260-297, :357-365) — and the unique of those keys depend on the projection
+        alone, i.e. on the image branch's table the frame front formed: two host waits and ~12 launches that stood at the head of the
+        branch (1.1 ms of it on the worker thread, whose interpreter time then fell into the LiDAR branch's).  Formed here, on the
+        front stream while the segmentor runs; `frustum_forward` finds them (same rows, same unique — test)."""
+        self._cam_rows = None
+        pre = front["img_pre"]
+        if (pre is None or self.training or torch.is_grad_enabled() or mask_anno.shape[0] != 1 or pre["mask_data"] is not mask_data
+                or mask_data.shape[1] * mask_data.shape[2] > 254 or torch.cuda.is_current_stream_capturing()):
+            return
+        if self._branches_concurrent(int(pre["info"].shape[0])):
+            # On its own host thread the branch's index work costs the frame nothing, and a camera branch that ENDS earlier takes its
+            # SIR stack out from under the LiDAR branch's clustering front end (small launches it otherwise runs beside): same-box
+            # interleaved A/B on the 10-sweep frame 11.83-11.96 ms without, 12.00-12.04 with.  Where both branches share the calling
+            # thread (the 1-sweep frame) its two host waits are the frame's: 6.53 -> 6.18 ms.
+            return
+        if getattr(self, "_front_stream", None) is None:
+            self._front_stream = torch.cuda.Stream()
+        side = self._front_stream
+        side.wait_event(pre["ready"])  # (recorded behind the table's kernels on the stream that ran them)
+        fg_u8, count_u8, max_id = pre["overlap"]
+        mine = swap_unique_cache([])
+        try:
+            with torch.cuda.stream(side):
+                num_fg, num_multi, num_extra, ws = hip_ops.overlap_plan(fg_u8, count_u8, mask_data.shape[1] * mask_data.shape[2])
+                rows = res = None
+                if num_fg > 0:
+                    rows = hip_ops.overlap_rows(pre["info"][:, :3], pre["lidar2img"], mask_data[0], max_id, None, ws, num_fg, num_multi,
+                                                num_extra)
+                    top = mask_anno.shape[1] if mask_data.dtype != torch.uint8 else 255
+                    with_key_bounds(rows[1], [0, 0, 0], [0, 0, max(int(top), 1)])
+                    res = unique_with_plan(rows[1])
+                ev = torch.cuda.Event()
+                ev.record(side)
+        finally:
+            swap_unique_cache(mine)
+        self._cam_rows = self._cam_rows_hold = dict(overlap=pre["overlap"], info=pre["info"], rows=rows, res=res, event=ev, ws=ws)
 
     def forward_hot_path(self, points, img_metas, mask_data, mask_anno):
         """Stages 1-3 of simple_test (:1114-1144): segmentation + image fusion, camera queries, LiDAR queries —

@@ -144,3 +144,16 @@ def test_pre_voxelize_keys_formed_early_equal_the_ones_formed_in_place(model, fr
         _same(plain, _loop(model, frames, ORDER, announce=True))
     finally:
         del model.__dict__["_pre_voxel_keys_early"]
+
+
+def test_camera_rows_formed_early_equal_the_ones_formed_in_place(model, frames, plain):
+    """`FSF._camera_rows_early` (the camera branch's row list + the unique of its keys, on the front stream while the segmentor runs)
+    against `frustum_forward` forming them itself: the same boxes bit for bit; the early form is what the default path takes."""
+    assert model.__dict__.get("_cam_rows_hold") is not None and model._cam_rows_hold["rows"] is not None
+    # (frames below `concurrent_query_min_points` run both branches on the calling thread: the case the early form is on for)
+    model._camera_rows_early = lambda *a, **k: None
+    try:
+        _same(plain, _loop(model, frames, ORDER, announce=False))
+        _same(plain, _loop(model, frames, ORDER, announce=True))
+    finally:
+        del model.__dict__["_camera_rows_early"]
