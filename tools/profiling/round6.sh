@@ -42,4 +42,7 @@ if [ "$light" != "light" ]; then
   { hdr; python tools/profiling/k22_calls.py 2>/dev/null; } > $out/k22_family_calls.txt
   { hdr; python tools/profiling/train_ops.py 60 2>/dev/null; } > $out/train_step_ops.txt
 fi
+{ hdr; python tools/profiling/frame_front_ab.py 10 7 2>/dev/null | grep -v amdgpu; python tools/profiling/frame_front_ab.py 1 7 2>/dev/null | grep -v amdgpu; } > $out/frame_front_ab.txt
+{ hdr; python tools/profiling/frame_front_host.py 10 2>/dev/null | grep -v amdgpu; } > $out/frame_front_host.txt
+{ hdr; python tools/profiling/host_gaps.py 2>/dev/null | grep -v amdgpu; } > $out/host_gaps_full_forward.txt
 tail -c 400 $out/bench_final.json 2>/dev/null; echo; head -12 $out/kernel_stats_full_forward_serial.txt
