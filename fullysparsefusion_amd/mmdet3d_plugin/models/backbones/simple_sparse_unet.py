@@ -340,6 +340,10 @@ class SimpleSparseUNet(nn.Module):
         # would record one more event on a stream that went idle a millisecond ago — waking its hardware queue for that marker held
         # the main stream for ~150 us in front of the neck, on the 1-sweep frame as on the 10-sweep one)
         mark("decoder done")
+        # `begin` may have run on another stream than this one (FSF's frame front): what it allocated there and this stream's kernels
+        # read — the encoder outputs the decoder takes, the tables of a forward without a plan stream, the row maps — must not go back
+        # to THAT stream's allocator while they are queued here; held like every other cross-stream tensor of the forward
+        held.append((encode_features, lateral_out, x, coors, inv_perm, voxel_features, voxel_info))
         if held and voxel_features.is_cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())  # (the main stream has waited for every lateral event: behind this, nobody reads them)

@@ -719,9 +719,12 @@ class FSF(SingleStageFSD):
         if (size is None or ready is None or self.training or torch.is_grad_enabled() or not points.is_cuda or points.dtype != torch.float32
                 or img_metas is None or torch.cuda.is_current_stream_capturing()):
             return
-        if getattr(self, "_front_stream", None) is None:
-            self._front_stream = torch.cuda.Stream()
-        side = self._front_stream
+        if getattr(self, "_early_stream", None) is None:
+            # (NOT the front stream: what `begin` allocated there and died with the U-Net's forward — encoder outputs the decoder has
+            # not read yet — sits in that stream's free pool at this point of the frame; this stream's pool holds only what it
+            # allocated a frame ago)
+            self._early_stream = torch.cuda.Stream()
+        side = self._early_stream
         side.wait_event(ready)  # (recorded behind the voxel unique: the points and their coordinates exist)
         mine = swap_unique_cache([])
         try:
@@ -752,9 +755,12 @@ class FSF(SingleStageFSD):
             # interleaved A/B on the 10-sweep frame 11.83-11.96 ms without, 12.00-12.04 with.  Where both branches share the calling
             # thread (the 1-sweep frame) its two host waits are the frame's: 6.53 -> 6.18 ms.
             return
-        if getattr(self, "_front_stream", None) is None:
-            self._front_stream = torch.cuda.Stream()
-        side = self._front_stream
+        if getattr(self, "_early_stream", None) is None:
+            # (NOT the front stream: what `begin` allocated there and died with the U-Net's forward — encoder outputs the decoder has
+            # not read yet — sits in that stream's free pool at this point of the frame; this stream's pool holds only what it
+            # allocated a frame ago)
+            self._early_stream = torch.cuda.Stream()
+        side = self._early_stream
         side.wait_event(pre["ready"])  # (recorded behind the table's kernels on the stream that ran them)
         fg_u8, count_u8, max_id = pre["overlap"]
         mine = swap_unique_cache([])
