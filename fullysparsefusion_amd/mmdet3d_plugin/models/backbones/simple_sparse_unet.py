@@ -239,7 +239,7 @@ class SimpleSparseUNet(nn.Module):
         # dozen workgroups per launch — leave idle, instead of running alone after them.
         side_levels = 0
         if (voxel_features.is_cuda and not torch.is_grad_enabled() and not self.training and switches.UNET_LATERAL_STREAM
-                and not torch.cuda.is_current_stream_capturing()):
+                and voxel_features.size(0) >= switches.UNET_LATERAL_MIN_ROWS and not torch.cuda.is_current_stream_capturing()):
             side_levels = min(switches.UNET_LATERAL_LEVELS, self.stage_num - 1)
             if getattr(self, "_lateral_stream", None) is None:
                 self._lateral_stream = torch.cuda.Stream()

@@ -30,6 +30,7 @@ K22H = _on("FSF_K22H")                                # the >= 256-wide Linears 
 PLANES_MIN_ROWS = 4096            # K9d from this many output rows (round 2)
 K22H_MIN_ROWS = 1024              # K22h from this many rows (round 5)
 UNET_LATERAL_LEVELS = 3           # how many fine levels' lateral blocks go to the side stream (round 3)
+UNET_LATERAL_MIN_ROWS = 32768     # ... from this many voxels (round 6: the 1-sweep frame, ~20 k voxels, is 0.2-0.3 ms faster without it)
 UNET_MASK_ORDER_LEVELS = 2        # how many levels from the finest run in neighbour-mask order (round 3)
 UNET_MASK_ORDER_MIN_ROWS = 16384  # ... from this many voxels
 
