@@ -1137,9 +1137,15 @@ def main():
                 step(model, pool[(args.warmup + i) % nframes], args.hot_path_only)
             torch.cuda.synchronize()
             ms_plain = (time.perf_counter() - t1) / args.steps * 1e3
+            t1 = time.perf_counter()  # (and the announced loop once more, behind it: a process's first loop runs 0.2-0.5 ms slower
+            for i in range(args.steps):  # than its later ones whatever it is, so the pair to compare is this one and the unannounced)
+                run(args.warmup + i)
+            torch.cuda.synchronize()
+            ms_again = (time.perf_counter() - t1) / args.steps * 1e3
         if rank == 0:
             result["frame_front"] = {
                 "announced": not args.no_frame_front, "ms_per_step_unannounced": round(ms_plain, 3),
+                **({"ms_per_step_announced_repeat": round(ms_again, 3)} if not args.no_frame_front else {}),
                 "note": "the timed loop announces step i + 1's batch before step i (FSF.set_next_frame — what a test loop's data loader "
                         "knows): that frame's host-bound front (point split, image-branch projection + score MLP, voxelization, voxel "
                         "unique + read-back, DynamicScatterVFE, the U-Net's row order / first index plan / input planes) is issued on a "
@@ -1147,7 +1153,9 @@ def main():
                         "bit-identical boxes (tests/test_frame_front_gpu.py); every step still runs every kernel of its frame inside "
                         "the timed region (the first timed step's front falls in the last warm-up step, the last timed step issues "
                         "the front of a frame beyond the region); `ms_per_step_unannounced` = the same loop, same process, nothing "
-                        "announced (`--no-frame-front` times that loop as the headline)"}
+                        "announced (`--no-frame-front` times that loop as the headline), `ms_per_step_announced_repeat` = the announced "
+                        "loop again behind it (the loops of a process get faster as it warms: compare these two, not the headline, with "
+                        "the unannounced figure; interleaved rounds: tools/profiling/frame_front_ab.py, profiles/r6_frame_front_ab.txt)"}
     if args.train and not args.no_roofline:  # (all ranks: the measurement runs real collectives)
         roof, allreduce = train_extras(train_step, pool, args.steps, world, dist, device)
         if rank == 0:

@@ -1,5 +1,6 @@
 """Same-process interleaved A/B of the announced loop (FSF.set_next_frame, K32) against the plain loop: usage
 python tools/profiling/frame_front_ab.py [sweeps] [rounds] [steps]"""
+import os
 import sys
 import time
 
@@ -12,8 +13,12 @@ sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = torch.device("cuda", 0)
-model = bench.build_model(dev)
-pool = [bench.make_inputs(sweeps, seed=j, device=dev)[1] for j in range(4)]
+dataset = os.environ.get("AB_DATASET", "nuscenes")
+tl = os.environ.get("AB_TRAINED_LIKE") == "1"
+model = bench.build_model(dev, dataset)
+pool = [bench.make_inputs(sweeps, seed=j, device=dev, dataset=dataset, trained_like=tl)[1] for j in range(4)]
+if tl:
+    bench.calibrate_trained_like(model, pool[0])
 
 
 def loop(announce, k):
@@ -25,7 +30,6 @@ def loop(announce, k):
     return (time.perf_counter() - t0) / k * 1e3
 
 
-import os
 for name in os.environ.get("AB_DISABLE", "").split(","):  # e.g. AB_DISABLE=_camera_rows_early,_pre_voxel_keys_early
     if name:
         setattr(model, name, lambda *a, **k: None)
