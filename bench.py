@@ -1031,6 +1031,9 @@ def main():
         from fullysparsefusion_amd import switches
 
         switches.UNET_LATERAL_STREAM = switches.UNET_PLAN_STREAM = False
+        # (one stream means one stream: nothing announced, the early key / row work in its place — the same kernels, in line)
+        args.no_frame_front = True
+        model._pre_voxel_keys_early = model._camera_rows_early = lambda *a, **k: None
         for m in model.modules():
             if isinstance(getattr(m, "test_cfg", None), dict) or hasattr(getattr(m, "test_cfg", None), "get"):
                 try:
