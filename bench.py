@@ -188,8 +188,9 @@ def h2d_inclusive(model, sweeps, seeds, device, steps, warmup, ms_resident, anno
                 exposed_h2d_ms=round(ms - ms_resident, 3), h2d_alone_ms=round(alone, 3), h2d_mb_per_frame=round(mb, 1),
                 h2d_gb_per_s_alone=round(mb / alone, 1),
                 note="frames start in pinned host memory; two device slots, frame i + 1 copied on a copy stream while frame i runs; "
-                     "`exposed_h2d_ms` = this loop's ms/frame - `ms_per_step` of the HBM-resident loop of the same run (the box-to-box "
-                     "noise of either is ~0.1 ms); the headline `value` stays the HBM-resident rate")
+                     "nothing announced to the detector in this loop; `exposed_h2d_ms` = this loop's ms/frame - the UNANNOUNCED "
+                     "HBM-resident loop of the same run (`frame_front.ms_per_step_unannounced`; the noise of either is ~0.1 ms); the "
+                     "headline `value` stays the HBM-resident rate")
 
 
 def dtype_text(train):
@@ -1181,7 +1182,10 @@ def main():
             and args.dataset == "nuscenes" and args.frames_per_gpu == 1):
         # BESIDE the headline: the same forward with every frame handed over as host buffers (PCIe-inclusive rate)
         result["h2d"] = h2d_inclusive(model, args.sweeps, [rank * 131 + j for j in range(nframes)], device, args.steps, args.warmup,
-                                      result["ms_per_step"], announce=not args.no_frame_front)
+                                      ms_plain, announce=False)
+        # (the host-buffer loop announces nothing: with the next frame announced it ran 13.45 ms against 13.11 unannounced on the same
+        # box — the upload of frame i + 2, issued when frame i ends, then runs beside frame i + 1's front instead of beside its tail;
+        # cause not established further.  Compared with the unannounced resident loop of the same run.)
     if (rank == 0 and world == 1 and not (args.train or args.hot_path_only or args.trained_like or args.no_trained_like)
             and args.dataset == "nuscenes" and args.frames_per_gpu == 1):
         # BESIDE the headline: the same forward on the trained-like variant (see calibrate_trained_like)
