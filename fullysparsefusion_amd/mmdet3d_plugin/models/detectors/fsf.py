@@ -603,8 +603,8 @@ class FSF(SingleStageFSD):
 
     # ------------------------------------------------------------------------------ frame front (K32)
     # The first millisecond of a frame — point split, the image branch's projection + score MLP, voxelization, the voxel unique with
-    # its read-back, DynamicScatterVFE, the U-Net's row order / first index plan / input planes: ~60 launches of 2-60 us — is bound by
-    # the HOST (profiles/r6_frame_timeline_full_forward.txt: 0.67 ms of kernels in 1.18 ms), and the LAST millisecond of the frame
+    # its read-back, DynamicScatterVFE, the U-Net's row order / first index plans / input planes / first two encoder levels: ~85 launches
+    # of 2-140 us — is bound by the HOST (round 6's timeline at 87bc341: 0.67 ms of kernels in the first 1.18 ms), and the LAST millisecond of the frame
     # before is the host idling in the box tail's read-back while the device runs a queue of heads / NMS launches.  A caller that
     # knows the next frame (`set_next_frame`: a test loop's data loader does) gets that frame's front issued on a side stream inside
     # that wait: same kernels on the same inputs in the same order, only earlier (bit-identical, tests/test_frame_front_gpu.py).
@@ -624,7 +624,8 @@ class FSF(SingleStageFSD):
                 and a[2][0] is b[2][0] and a[2][1] == b[2][1] and a[3][0] is b[3][0] and a[3][1] == b[3][1])
 
     def _frame_front(self, points, img_metas, mask_data, mask_anno):
-        """simple_test (:1114-1126) up to the backbone's first convolution, on the current stream."""
+        """simple_test (:1114-1126) up to the backbone's third encoder level (SimpleSparseUNet.begin), on the current stream; writes no
+        attribute of `self`."""
         points, point_infos = self.split_points_last_3dim(points)
         img_pre = self._image_branch_table(point_infos, mask_anno, mask_data, img_metas)
         seg = self.segmentor
@@ -650,7 +651,8 @@ class FSF(SingleStageFSD):
                 or not points[0].is_cuda or getattr(self.segmentor, "tanh_dims", None) != [] or torch.cuda.is_current_stream_capturing()):
             return  # (in-place point transforms / the downsampling unique stay inside their own frame)
         if getattr(self, "_front_stream", None) is None:
-            self._front_stream = torch.cuda.Stream()  # (normal priority: at high priority its launches hold up the tail and the loop is 3 % SLOWER than unannounced)
+            # (normal priority: at high priority its launches hold up the tail the finished frame waits for — 3 % SLOWER than unannounced)
+            self._front_stream = torch.cuda.Stream()
         side = self._front_stream
         key = self._frame_key(points, img_metas, mask_data, mask_anno)
 
