@@ -157,3 +157,18 @@ def test_camera_rows_formed_early_equal_the_ones_formed_in_place(model, frames, 
         _same(plain, _loop(model, frames, ORDER, announce=True))
     finally:
         del model.__dict__["_camera_rows_early"]
+
+
+def test_announced_loop_without_the_plan_and_lateral_streams(device, frames, plain, monkeypatch):
+    """`bench.py --serial`'s U-Net (no plan stream: the rulebooks are allocated on whatever stream `begin` runs on — the FRONT stream for
+    an announced frame) under an announced loop.  The first version of K32 let those tables go back to the front stream's allocator when
+    the forward's generator ended, the early key work re-used them while the convolutions that read them were still queued, and the
+    process died with a memory access fault; they are now held like every other cross-stream tensor of the forward."""
+    from fullysparsefusion_amd import switches
+
+    monkeypatch.setattr(switches, "UNET_PLAN_STREAM", False)
+    monkeypatch.setattr(switches, "UNET_LATERAL_STREAM", False)
+    model = bench.build_model(device)
+    for _ in range(3):  # (the hazard needs the allocator's pools warm: several passes over the loop)
+        got = _loop(model, frames, ORDER, announce=True)
+    _same(plain, got)
