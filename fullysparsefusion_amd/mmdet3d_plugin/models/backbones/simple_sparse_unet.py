@@ -343,7 +343,8 @@ class SimpleSparseUNet(nn.Module):
         # `begin` may have run on another stream than this one (FSF's frame front): what it allocated there and this stream's kernels
         # read — the encoder outputs the decoder takes, the tables of a forward without a plan stream, the row maps — must not go back
         # to THAT stream's allocator while they are queued here; held like every other cross-stream tensor of the forward
-        held.append((encode_features, lateral_out, x, coors, inv_perm, voxel_features, voxel_info))
+        if not torch.is_grad_enabled():  # (training never splits its forward over two streams, and must not keep its graph alive here)
+            held.append((encode_features, lateral_out, x, coors, inv_perm, voxel_features, voxel_info))
         if held and voxel_features.is_cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())  # (the main stream has waited for every lateral event: behind this, nobody reads them)
