@@ -1152,7 +1152,7 @@ def main():
                 **({"ms_per_step_announced_repeat": round(ms_again, 3)} if not args.no_frame_front else {}),
                 "note": "the timed loop announces step i + 1's batch before step i (FSF.set_next_frame — what a test loop's data loader "
                         "knows): that frame's host-bound front (point split, image-branch projection + score MLP, voxelization, voxel "
-                        "unique + read-back, DynamicScatterVFE, the U-Net's row order / first index plan / input planes) is issued on a "
+                        "unique + read-back, DynamicScatterVFE, the U-Net's row order / first index plans / input planes / first two encoder levels) is issued on a "
                         "side stream while step i's host thread would idle in the box tail's read-back; same kernels, same inputs, "
                         "bit-identical boxes (tests/test_frame_front_gpu.py); every step still runs every kernel of its frame inside "
                         "the timed region (the first timed step's front falls in the last warm-up step, the last timed step issues "
